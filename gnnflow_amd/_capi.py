@@ -1,0 +1,130 @@
+"""ctypes binding of include/gnnflow_hip.h (the C-ABI drop-in boundary).
+
+The library is gnnflow_amd/csrc/libgnnflow_hip.so, built in-tree by
+gnnflow_amd/_build.py.  There is NO fallback: if the HIP library is missing or
+fails to load, importing this module raises — the product path never runs on a
+CPU restatement.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgnnflow_hip.so")
+
+GF_OK = 0
+GF_ERR_INVALID_ARGUMENT = 1
+GF_ERR_TIMESTAMP_ORDER = 2
+GF_ERR_OUT_OF_MEMORY = 3
+GF_ERR_HIP = 4
+GF_ERR_IO = 5
+
+INSERTION_POLICY = {"insert": 0, "replace": 1}
+SAMPLING_POLICY = {"recent": 0, "uniform": 1}
+MEM_RESOURCE = {"cuda": 0, "unified": 1, "pinned": 2, "shared": 3}
+
+PROFILE_SLOTS = {"search": 0, "emit": 1, "gather": 2, "scan": 3, "lru": 4}
+
+
+class GfBlock(C.Structure):
+    """struct gf_block (include/gnnflow_hip.h)."""
+    _fields_ = [
+        ("all_nodes", C.c_void_p),
+        ("all_timestamps", C.c_void_p),
+        ("delta_timestamps", C.c_void_p),
+        ("eids", C.c_void_p),
+        ("row", C.c_void_p),
+        ("col", C.c_void_p),
+        ("num_dst_nodes", C.c_uint64),
+        ("num_src_nodes", C.c_uint64),
+        ("num_edges", C.c_uint64),
+    ]
+
+
+# every symbol include/gnnflow_hip.h declares: name -> (restype, argtypes)
+_p = C.c_void_p
+_sz = C.c_size_t
+PROTOTYPES = {
+    "gf_last_error": (C.c_char_p, []),
+    "gf_version": (C.c_char_p, []),
+    "gf_graph_create": (C.c_int, [C.POINTER(_p), _sz, _sz, C.c_int, _sz, _sz, C.c_int,
+                                  C.c_int, C.c_int]),
+    "gf_graph_destroy": (C.c_int, [_p]),
+    "gf_graph_add_edges": (C.c_int, [_p, _p, _p, _p, _p, _sz]),
+    "gf_graph_offload_old_blocks": (C.c_int, [_p, C.c_float, C.c_int, C.POINTER(_sz)]),
+    "gf_graph_num_vertices": (C.c_int, [_p, C.POINTER(_sz)]),
+    "gf_graph_num_source_vertices": (C.c_int, [_p, C.POINTER(_sz)]),
+    "gf_graph_num_edges": (C.c_int, [_p, C.POINTER(_sz)]),
+    "gf_graph_max_vertex_id": (C.c_int, [_p, C.POINTER(C.c_int64)]),
+    "gf_graph_out_degree": (C.c_int, [_p, _p, _sz, _p]),
+    "gf_graph_nodes": (C.c_int, [_p, _p, _sz, C.POINTER(_sz)]),
+    "gf_graph_src_nodes": (C.c_int, [_p, _p, _sz, C.POINTER(_sz)]),
+    "gf_graph_edges": (C.c_int, [_p, _p, _sz, C.POINTER(_sz)]),
+    "gf_graph_get_temporal_neighbors": (C.c_int, [_p, C.c_int64, _p, _p, _p, _sz,
+                                                  C.POINTER(_sz)]),
+    "gf_graph_avg_linked_list_length": (C.c_int, [_p, C.POINTER(C.c_float)]),
+    "gf_graph_memory_usage": (C.c_int, [_p, C.POINTER(C.c_float)]),
+    "gf_graph_metadata_memory_usage": (C.c_int, [_p, C.POINTER(C.c_float)]),
+    "gf_graph_device": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "gf_sampler_create": (C.c_int, [C.POINTER(_p), _p, C.POINTER(C.c_uint32), _sz, C.c_int,
+                                    C.c_uint32, C.c_float, C.c_int, C.c_uint64]),
+    "gf_sampler_destroy": (C.c_int, [_p]),
+    "gf_sampler_output_bytes": (C.c_int, [_p, _sz, C.POINTER(_sz)]),
+    "gf_sampler_sample": (C.c_int, [_p, _p, _p, _sz, _p, _sz, C.POINTER(GfBlock), _p]),
+    "gf_sampler_layer_output_bytes": (C.c_int, [_p, _sz, C.c_uint32, C.POINTER(_sz)]),
+    "gf_sampler_sample_layer": (C.c_int, [_p, _p, _p, _sz, C.c_uint32, C.c_uint32, _p, _sz,
+                                          C.POINTER(GfBlock), _p]),
+    "gf_sampler_sample_host": (C.c_int, [_p, _p, _p, _sz, C.POINTER(GfBlock)]),
+    "gf_sampler_sample_layer_host": (C.c_int, [_p, _p, _p, _sz, C.c_uint32, C.c_uint32,
+                                               C.POINTER(GfBlock)]),
+    "gf_host_blocks_free": (None, [C.POINTER(GfBlock), _sz]),
+    "gf_cache_create": (C.c_int, [C.POINTER(_p), _sz, _sz, _sz, _p, C.c_int]),
+    "gf_cache_destroy": (C.c_int, [_p]),
+    "gf_cache_init": (C.c_int, [_p, _p]),
+    "gf_cache_resize": (C.c_int, [_p, _sz, _sz, _p, _p]),
+    "gf_cache_fetch": (C.c_int, [_p, _p, _sz, _p, C.c_int, _p, _p]),
+    "gf_gather_rows": (C.c_int, [_p, _sz, _sz, _p, _sz, _p, C.c_int, _p]),
+    "gf_cache_slot_ids": (C.c_int, [_p, _p, _sz]),
+    "gf_cache_mem_bytes": (C.c_int, [_p, C.POINTER(_sz)]),
+    "gf_profile_enable": (C.c_int, [C.c_int]),
+    "gf_profile_reset": (C.c_int, []),
+    "gf_profile_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libgnnflow_hip.so and binds every prototype.  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "gnnflow_amd: HIP library not built ({}). Run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` or `python gnnflow_amd/_build.py`. "
+            "There is no CPU fallback.".format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class GnnflowError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def check(rc):
+    """Maps a GF_ERR_* status to the exception the reference's Python layer documents."""
+    if rc == GF_OK:
+        return
+    msg = load().gf_last_error().decode("utf-8", "replace")
+    if rc in (GF_ERR_INVALID_ARGUMENT, GF_ERR_TIMESTAMP_ORDER):
+        raise ValueError(msg)
+    if rc == GF_ERR_OUT_OF_MEMORY:
+        raise MemoryError(msg)
+    raise GnnflowError(rc, msg)

@@ -1,0 +1,278 @@
+// extern "C" entry points of include/gnnflow_hip.h: thin, exception-free shims
+// over EdgeStore / Sampler / FeatureCache.
+#include <mutex>
+#include <string>
+
+#include "common.hpp"
+#include "edge_store.hpp"
+#include "feature_cache.hpp"
+#include "sampler.hpp"
+
+struct gf_graph { gf::EdgeStore impl; template <typename... A> explicit gf_graph(A&&... a) : impl(std::forward<A>(a)...) {} };
+struct gf_sampler { gf::Sampler impl; template <typename... A> explicit gf_sampler(A&&... a) : impl(std::forward<A>(a)...) {} };
+struct gf_cache { gf::FeatureCache impl; template <typename... A> explicit gf_cache(A&&... a) : impl(std::forward<A>(a)...) {} };
+
+namespace gf {
+
+namespace {
+thread_local std::string g_last_error;
+
+struct ProfileRecord { int slot; hipEvent_t start, stop; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfileRecord> g_prof_pending;
+double g_prof_ms[kProfSlots] = {0};
+uint64_t g_prof_launches[kProfSlots] = {0};
+
+void drain_profile_locked() {
+  for (ProfileRecord& r : g_prof_pending) {
+    float ms = 0;
+    if (hipEventSynchronize(r.stop) == hipSuccess &&
+        hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      g_prof_ms[r.slot] += ms;
+      g_prof_launches[r.slot]++;
+    }
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  g_prof_pending.clear();
+}
+}  // namespace
+
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+bool profile_enabled() { return g_prof_on; }
+
+ProfileScope::ProfileScope(int slot_, hipStream_t stream_) : slot(slot_), stream(stream_) {
+  if (!g_prof_on) return;
+  if (hipEventCreate(&start) != hipSuccess) { start = nullptr; return; }
+  (void)hipEventRecord(start, stream);
+}
+
+ProfileScope::~ProfileScope() {
+  if (!start) return;
+  hipEvent_t stop = nullptr;
+  if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start); return; }
+  (void)hipEventRecord(stop, stream);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_pending.push_back({slot, start, stop});
+}
+
+}  // namespace gf
+
+using gf::guarded;
+
+extern "C" {
+
+const char* gf_last_error(void) { return gf::g_last_error.c_str(); }
+const char* gf_version(void) { return "gnnflow_amd 0.1 (gfx950)"; }
+
+// ---- graph -------------------------------------------------------------------------
+int gf_graph_create(gf_graph** out, size_t initial_pool_size, size_t maximum_pool_size,
+                    int mem_resource_type, size_t minium_block_size,
+                    size_t blocks_to_preallocate, int insertion_policy, int device,
+                    int adaptive_block_size) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_graph_create: null out");
+    *out = new gf_graph(initial_pool_size, maximum_pool_size, mem_resource_type,
+                        minium_block_size, blocks_to_preallocate, insertion_policy, device,
+                        adaptive_block_size != 0);
+  });
+}
+int gf_graph_destroy(gf_graph* g) {
+  return guarded([&] { delete g; });
+}
+#define GF_G(g) GF_REQUIRE((g) != nullptr, "null graph handle")
+
+int gf_graph_add_edges(gf_graph* g, const int64_t* src, const int64_t* dst, const float* ts,
+                       const int64_t* eids, size_t n) {
+  return guarded([&] { GF_G(g); g->impl.add_edges(src, dst, ts, eids, n); });
+}
+int gf_graph_offload_old_blocks(gf_graph* g, float timestamp, int to_file, size_t* num_blocks) {
+  return guarded([&] {
+    GF_G(g);
+    size_t n = g->impl.offload_old_blocks(timestamp, to_file != 0);
+    if (num_blocks) *num_blocks = n;
+  });
+}
+int gf_graph_num_vertices(const gf_graph* g, size_t* out) {
+  return guarded([&] { GF_G(g); *out = g->impl.num_nodes(); });
+}
+int gf_graph_num_source_vertices(const gf_graph* g, size_t* out) {
+  return guarded([&] { GF_G(g); *out = g->impl.num_src_nodes(); });
+}
+int gf_graph_num_edges(const gf_graph* g, size_t* out) {
+  return guarded([&] { GF_G(g); *out = g->impl.num_edges(); });
+}
+int gf_graph_max_vertex_id(const gf_graph* g, int64_t* out) {
+  return guarded([&] { GF_G(g); *out = g->impl.max_node_id(); });
+}
+int gf_graph_out_degree(const gf_graph* g, const int64_t* nodes, size_t n, size_t* out) {
+  return guarded([&] { GF_G(g); g->impl.out_degree(nodes, n, out); });
+}
+int gf_graph_nodes(const gf_graph* g, int64_t* out, size_t capacity, size_t* count) {
+  return guarded([&] { GF_G(g); *count = g->impl.nodes(out, capacity, false); });
+}
+int gf_graph_src_nodes(const gf_graph* g, int64_t* out, size_t capacity, size_t* count) {
+  return guarded([&] { GF_G(g); *count = g->impl.nodes(out, capacity, true); });
+}
+int gf_graph_edges(const gf_graph* g, int64_t* out, size_t capacity, size_t* count) {
+  return guarded([&] { GF_G(g); *count = g->impl.edges(out, capacity); });
+}
+int gf_graph_get_temporal_neighbors(const gf_graph* g, int64_t node, int64_t* dst, float* ts,
+                                    int64_t* eids, size_t capacity, size_t* count) {
+  return guarded([&] {
+    GF_G(g);
+    *count = g->impl.get_temporal_neighbors(node, dst, ts, eids, capacity);
+  });
+}
+int gf_graph_avg_linked_list_length(const gf_graph* g, float* out) {
+  return guarded([&] { GF_G(g); *out = g->impl.avg_linked_list_length(); });
+}
+int gf_graph_memory_usage(const gf_graph* g, float* out) {
+  return guarded([&] { GF_G(g); *out = g->impl.graph_mem_usage(); });
+}
+int gf_graph_metadata_memory_usage(const gf_graph* g, float* out) {
+  return guarded([&] { GF_G(g); *out = g->impl.metadata_mem_usage(); });
+}
+int gf_graph_device(const gf_graph* g, int* out) {
+  return guarded([&] { GF_G(g); *out = g->impl.device(); });
+}
+
+// ---- sampler -----------------------------------------------------------------------
+#define GF_S(s) GF_REQUIRE((s) != nullptr, "null sampler handle")
+
+int gf_sampler_create(gf_sampler** out, gf_graph* g, const uint32_t* fanouts, size_t num_layers,
+                      int sampling_policy, uint32_t num_snapshots, float snapshot_time_window,
+                      int prop_time, uint64_t seed) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_sampler_create: null out");
+    GF_G(g);
+    GF_REQUIRE(fanouts != nullptr, "gf_sampler_create: null fanouts");
+    *out = new gf_sampler(&g->impl, fanouts, num_layers, sampling_policy, num_snapshots,
+                          snapshot_time_window, prop_time != 0, seed);
+  });
+}
+int gf_sampler_destroy(gf_sampler* s) {
+  return guarded([&] { delete s; });
+}
+int gf_sampler_output_bytes(const gf_sampler* s, size_t num_roots, size_t* bytes) {
+  return guarded([&] { GF_S(s); *bytes = s->impl.output_bytes(num_roots); });
+}
+int gf_sampler_layer_output_bytes(const gf_sampler* s, size_t num_roots, uint32_t layer,
+                                  size_t* bytes) {
+  return guarded([&] {
+    GF_S(s);
+    GF_REQUIRE(layer < s->impl.num_layers(), "layer out of range");
+    *bytes = s->impl.layer_output_bytes(num_roots, layer);
+  });
+}
+int gf_sampler_sample(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
+                      size_t num_roots, void* d_out, size_t out_bytes, gf_block* blocks,
+                      void* stream) {
+  return guarded([&] {
+    GF_S(s);
+    s->impl.sample(d_roots, d_root_ts, num_roots, d_out, out_bytes, blocks,
+                   static_cast<hipStream_t>(stream));
+  });
+}
+int gf_sampler_sample_layer(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
+                            size_t num_roots, uint32_t layer, uint32_t snapshot, void* d_out,
+                            size_t out_bytes, gf_block* block, void* stream) {
+  return guarded([&] {
+    GF_S(s);
+    s->impl.sample_layer(d_roots, d_root_ts, num_roots, layer, snapshot, d_out, out_bytes, block,
+                         static_cast<hipStream_t>(stream));
+  });
+}
+int gf_sampler_sample_host(gf_sampler* s, const int64_t* nodes, const float* ts,
+                           size_t num_roots, gf_block* blocks) {
+  return guarded([&] { GF_S(s); s->impl.sample_host(nodes, ts, num_roots, blocks); });
+}
+int gf_sampler_sample_layer_host(gf_sampler* s, const int64_t* nodes, const float* ts,
+                                 size_t num_roots, uint32_t layer, uint32_t snapshot,
+                                 gf_block* block) {
+  return guarded([&] {
+    GF_S(s);
+    s->impl.sample_layer_host(nodes, ts, num_roots, layer, snapshot, block);
+  });
+}
+void gf_host_blocks_free(gf_block* blocks, size_t n) {
+  if (!blocks) return;
+  for (size_t i = 0; i < n; ++i) {
+    free(blocks[i].all_nodes);
+    free(blocks[i].all_timestamps);
+    free(blocks[i].delta_timestamps);
+    free(blocks[i].eids);
+    free(blocks[i].row);
+    free(blocks[i].col);
+    blocks[i] = gf_block{};
+  }
+}
+
+// ---- feature cache -----------------------------------------------------------------
+#define GF_C(c) GF_REQUIRE((c) != nullptr, "null cache handle")
+
+int gf_cache_create(gf_cache** out, size_t num_ids, size_t capacity, size_t dim,
+                    const float* d_feats, int device) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_cache_create: null out");
+    *out = new gf_cache(num_ids, capacity, dim, d_feats, device);
+  });
+}
+int gf_cache_destroy(gf_cache* c) {
+  return guarded([&] { delete c; });
+}
+int gf_cache_init(gf_cache* c, void* stream) {
+  return guarded([&] { GF_C(c); c->impl.init(static_cast<hipStream_t>(stream)); });
+}
+int gf_cache_resize(gf_cache* c, size_t new_num_ids, size_t new_capacity, const float* d_feats,
+                    void* stream) {
+  return guarded([&] {
+    GF_C(c);
+    c->impl.resize(new_num_ids, new_capacity, d_feats, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_cache_fetch(gf_cache* c, const int64_t* d_ids, size_t n, float* d_out, int update,
+                   uint32_t* d_stats, void* stream) {
+  return guarded([&] {
+    GF_C(c);
+    c->impl.fetch(d_ids, n, d_out, update != 0, d_stats, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_t* d_ids,
+                   size_t n, float* d_out, int device, void* stream) {
+  return guarded([&] {
+    gf::gather_rows(d_feats, num_rows, dim, d_ids, n, d_out, device,
+                    static_cast<hipStream_t>(stream));
+  });
+}
+int gf_cache_slot_ids(const gf_cache* c, int64_t* out, size_t capacity) {
+  return guarded([&] { GF_C(c); c->impl.slot_ids(out, capacity); });
+}
+int gf_cache_mem_bytes(const gf_cache* c, size_t* out) {
+  return guarded([&] { GF_C(c); *out = c->impl.mem_bytes(); });
+}
+
+// ---- profiling ---------------------------------------------------------------------
+int gf_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(gf::g_prof_mu);
+  gf::g_prof_on = on != 0;
+  return GF_OK;
+}
+int gf_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(gf::g_prof_mu);
+  gf::drain_profile_locked();
+  for (int i = 0; i < gf::kProfSlots; ++i) { gf::g_prof_ms[i] = 0; gf::g_prof_launches[i] = 0; }
+  return GF_OK;
+}
+int gf_profile_get(int which, double* total_ms, uint64_t* launches) {
+  return guarded([&] {
+    GF_REQUIRE(which >= 0 && which < gf::kProfSlots, "gf_profile_get: bad slot");
+    std::lock_guard<std::mutex> lk(gf::g_prof_mu);
+    gf::drain_profile_locked();
+    if (total_ms) *total_ms = gf::g_prof_ms[which];
+    if (launches) *launches = gf::g_prof_launches[which];
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,628 @@
+// EdgeStore implementation: host-side ingest planning + the HIP kernels that
+// move bytes.  See edge_store.hpp for the layout; reference lines are cited on
+// each function that restates reference behaviour.
+#include "edge_store.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+
+namespace gf {
+
+namespace {
+
+constexpr size_t kBlockSpace = 20;       // common.h:23-24 bytes per edge
+constexpr size_t kIngestChunk = 1 << 23; // edges per staging upload
+
+inline uint64_t pow2_ceil(uint64_t n) {
+  uint64_t p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+inline int log2_exact(uint64_t p) { return 63 - __builtin_clzll(p); }
+
+// ---- kernels -------------------------------------------------------------------
+// Append a sorted batch: edge i goes to pool element dest[i].  Writes are 4 B + 16 B
+// per edge; within one source node dest[] is consecutive, so stores coalesce.
+__global__ void scatter_edges_kernel(const uint64_t* __restrict__ dest,
+                                     const int64_t* __restrict__ dst,
+                                     const int64_t* __restrict__ eid,
+                                     const float* __restrict__ ts, size_t n,
+                                     float* __restrict__ ts_pool,
+                                     EdgePair* __restrict__ nbr_pool) {
+  size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += stride) {
+    uint64_t d = dest[i];
+    ts_pool[d] = ts[i];
+    EdgePair p;
+    p.dst = dst[i];
+    p.eid = eid[i];
+    nbr_pool[d] = p;
+  }
+}
+
+struct MoveDesc { uint64_t src, dst, count; };
+
+// Relocate full segments (source and destination never overlap: the destination
+// is a fresh segment and frees are deferred to the end of the ingest call).
+__global__ void move_segments_kernel(const MoveDesc* __restrict__ moves, size_t nmoves,
+                                     float* __restrict__ ts_pool,
+                                     EdgePair* __restrict__ nbr_pool) {
+  for (size_t m = blockIdx.x; m < nmoves; m += gridDim.x) {
+    MoveDesc mv = moves[m];
+    for (uint64_t i = threadIdx.x; i < mv.count; i += blockDim.x) {
+      ts_pool[mv.dst + i] = ts_pool[mv.src + i];
+      nbr_pool[mv.dst + i] = nbr_pool[mv.src + i];
+    }
+  }
+}
+
+__global__ void update_nodes_kernel(const int64_t* __restrict__ ids,
+                                    const NodeEntry* __restrict__ entries, size_t n,
+                                    NodeEntry* __restrict__ table) {
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) table[ids[i]] = entries[i];
+}
+
+struct RangeDesc { uint64_t start, count, out; };
+
+__global__ void gather_ranges_kernel(const RangeDesc* __restrict__ ranges, size_t nranges,
+                                     const float* __restrict__ ts_pool,
+                                     const EdgePair* __restrict__ nbr_pool,
+                                     int64_t* __restrict__ o_dst, int64_t* __restrict__ o_eid,
+                                     float* __restrict__ o_ts) {
+  for (size_t r = blockIdx.x; r < nranges; r += gridDim.x) {
+    RangeDesc rd = ranges[r];
+    for (uint64_t i = threadIdx.x; i < rd.count; i += blockDim.x) {
+      EdgePair p = nbr_pool[rd.start + i];
+      o_dst[rd.out + i] = p.dst;
+      o_eid[rd.out + i] = p.eid;
+      o_ts[rd.out + i] = ts_pool[rd.start + i];
+    }
+  }
+}
+
+}  // namespace
+
+// ---- lifetime -------------------------------------------------------------------
+EdgeStore::EdgeStore(size_t initial_pool_size, size_t maximum_pool_size,
+                     int mem_resource_type, size_t minimum_block_size,
+                     size_t /*blocks_to_preallocate*/, int insertion_policy, int device,
+                     bool adaptive_block_size)
+    : initial_pool_size_(initial_pool_size),
+      maximum_pool_size_(maximum_pool_size),
+      minimum_block_size_(minimum_block_size),
+      mem_resource_type_(mem_resource_type),
+      insertion_policy_(insertion_policy),
+      device_(device),
+      adaptive_(adaptive_block_size),
+      free_lists_(64) {
+  GF_REQUIRE(mem_resource_type >= GF_MEM_CUDA && mem_resource_type <= GF_MEM_SHARED,
+             "invalid memory resource type");
+  GF_REQUIRE(insertion_policy == GF_INSERTION_POLICY_INSERT ||
+                 insertion_policy == GF_INSERTION_POLICY_REPLACE,
+             "invalid insertion policy");
+  GF_REQUIRE(maximum_pool_size >= initial_pool_size,
+             "maximum_pool_size must be >= initial_pool_size");
+  int count = 0;
+  GF_HIP(hipGetDeviceCount(&count));
+  GF_REQUIRE(device >= 0 && device < count, "invalid device id");
+  DeviceGuard dg(device_);
+  GF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+}
+
+EdgeStore::~EdgeStore() {
+  if (stream_) {
+    (void)hipStreamSynchronize(stream_);
+    (void)hipStreamDestroy(stream_);
+  }
+}
+
+GraphView EdgeStore::view() const {
+  GraphView v;
+  v.table = table_.as<NodeEntry>();
+  v.table_len = any_node_ ? max_node_id_ + 1 : 0;
+  v.ts_pool = ts_pool_.as<float>();
+  v.nbr_pool = nbr_pool_.as<EdgePair>();
+  return v;
+}
+
+// ---- bookkeeping ----------------------------------------------------------------
+// dynamic_graph.cu:140-147 AddNodes
+void EdgeStore::add_nodes(int64_t max_node) {
+  size_t need = static_cast<size_t>(max_node) + 1;
+  if (any_node_ && need <= nodes_.size()) return;
+  nodes_.resize(need);
+  seen_.resize(need, 0);
+  if (need > table_cap_) {
+    size_t cap = table_cap_ ? table_cap_ : 1024;
+    while (cap < need) cap *= 2;
+    table_.reserve(cap * sizeof(NodeEntry), table_cap_ * sizeof(NodeEntry), stream_,
+                   /*zero_new=*/true);
+    table_cap_ = table_.bytes() / sizeof(NodeEntry);
+  }
+  max_node_id_ = static_cast<size_t>(max_node);
+  any_node_ = true;
+}
+
+// `edges_[eid]++` (dynamic_graph.cu:93-95).  Dense counters for the usual
+// non-negative, roughly contiguous eids; a hash map for everything else.
+void EdgeStore::bump_eid(int64_t eid) {
+  eids_inserted_++;
+  if (eid >= 0) {
+    uint64_t u = static_cast<uint64_t>(eid);
+    if (u >= eid_dense_.size() && u < 64 + 8 * eids_inserted_) {
+      size_t nsz = std::max<size_t>(u + 1, eid_dense_.size() * 2);
+      nsz = std::min<size_t>(nsz, 64 + 8 * eids_inserted_);
+      nsz = std::max<size_t>(nsz, u + 1);
+      eid_dense_.resize(nsz, 0);
+      if (!eid_sparse_.empty()) {  // keep "eid < dense.size() => counted densely"
+        for (auto it = eid_sparse_.begin(); it != eid_sparse_.end();) {
+          if (it->first >= 0 && static_cast<uint64_t>(it->first) < nsz) {
+            eid_dense_[it->first] += static_cast<uint32_t>(it->second);
+            it = eid_sparse_.erase(it);
+          } else {
+            ++it;
+          }
+        }
+      }
+    }
+    if (u < eid_dense_.size()) {
+      if (eid_dense_[u]++ == 0) num_live_eids_++;
+      return;
+    }
+  }
+  if (eid_sparse_[eid]++ == 0) num_live_eids_++;
+}
+
+// `if (--edges_[eid] == 0) edges_.erase(eid)` (dynamic_graph.cu:393-397)
+void EdgeStore::drop_eid(int64_t eid) {
+  if (eid >= 0 && static_cast<uint64_t>(eid) < eid_dense_.size()) {
+    uint32_t& c = eid_dense_[eid];
+    if (c > 0 && --c == 0) num_live_eids_--;
+    return;
+  }
+  auto it = eid_sparse_.find(eid);
+  if (it != eid_sparse_.end() && --it->second == 0) {
+    eid_sparse_.erase(it);
+    num_live_eids_--;
+  }
+}
+
+uint64_t EdgeStore::seg_alloc(uint64_t cap) {
+  int cls = log2_exact(cap);
+  auto& fl = free_lists_[cls];
+  if (!fl.empty()) {
+    uint64_t s = fl.back();
+    fl.pop_back();
+    return s;
+  }
+  uint64_t s = bump_;
+  bump_ += cap;
+  return s;
+}
+
+void EdgeStore::seg_free(uint64_t start, uint64_t cap) {
+  free_lists_[log2_exact(cap)].push_back(start);
+}
+
+void EdgeStore::ensure_pool(uint64_t elems) {
+  if (elems <= pool_elems_) return;
+  uint64_t cap = pool_elems_ ? pool_elems_ : std::max<uint64_t>(initial_pool_size_ / kBlockSpace, 1024);
+  while (cap < elems) cap *= 2;
+  // the whole used prefix [0, old bump) is preserved across the reallocation
+  uint64_t keep = std::min<uint64_t>(pool_elems_, bump_);
+  ts_pool_.reserve(cap * sizeof(float), keep * sizeof(float), stream_);
+  nbr_pool_.reserve(cap * sizeof(EdgePair), keep * sizeof(EdgePair), stream_);
+  pool_elems_ = cap;
+}
+
+// temporal_block_allocator.cu:83-88,134-149 (AlignUp + AllocateInternal header init)
+LogicalBlock EdgeStore::new_block(size_t size) {
+  LogicalBlock b;
+  b.size = 0;
+  b.capacity = size < minimum_block_size_ ? minimum_block_size_ : size;
+  b.start_ts = std::numeric_limits<float>::max();
+  b.end_ts = 0;
+  logical_bytes_ += b.capacity * kBlockSpace;
+  logical_blocks_++;
+  if (logical_bytes_ > maximum_pool_size_) {
+    throw Error(GF_ERR_OUT_OF_MEMORY,
+                "maximum_pool_size exceeded: temporal blocks need " +
+                    std::to_string(logical_bytes_) + " bytes > " +
+                    std::to_string(maximum_pool_size_));
+  }
+  return b;
+}
+
+// dynamic_graph.cu:206-287 AddEdgesForOneNode + utils.cu:33-63 CopyEdgesToBlock,
+// replayed on block headers only (the bytes live in the node's flat segment).
+void EdgeStore::simulate_blocks(NodeState& st, const float* ts, size_t n) {
+  auto copy_to = [&](LogicalBlock& b, size_t start_idx, size_t cnt) {
+    b.size += cnt;
+    b.start_ts = std::min(b.start_ts, ts[start_idx]);
+    b.end_ts = ts[start_idx + cnt - 1];
+  };
+  size_t num = n, start_idx = 0;
+  if (st.num_blocks() == 0) {
+    st.blocks.push_back(new_block(num));           // case 1: empty list
+  } else {
+    LogicalBlock& tail = st.blocks.back();
+    if (tail.size + num > tail.capacity) {         // case 2: tail overflows
+      if (insertion_policy_ == GF_INSERTION_POLICY_INSERT) {
+        size_t fill = tail.capacity - tail.size;
+        if (fill > 0) {
+          copy_to(tail, 0, fill);
+          start_idx = fill;
+          num -= fill;
+        }
+        size_t avg = st.num_insertions == 0 ? num : st.num_edges / st.num_insertions;
+        size_t new_size = adaptive_ ? pow2_ceil(std::max(num, avg)) : num;
+        st.blocks.push_back(new_block(new_size));
+      } else {                                     // replace: Reallocate(size + n)
+        logical_bytes_ -= tail.capacity * kBlockSpace;
+        size_t want = tail.size + num;
+        tail.capacity = want < minimum_block_size_ ? minimum_block_size_ : want;
+        logical_bytes_ += tail.capacity * kBlockSpace;
+        if (logical_bytes_ > maximum_pool_size_)
+          throw Error(GF_ERR_OUT_OF_MEMORY, "maximum_pool_size exceeded");
+      }
+    }                                              // case 3: fits in the tail
+  }
+  copy_to(st.blocks.back(), start_idx, num);
+  st.num_edges += n;
+  st.num_insertions++;
+}
+
+void EdgeStore::upload_entries(const std::vector<int64_t>& ids) {
+  if (ids.empty()) return;
+  size_t k = ids.size();
+  size_t bytes = k * (sizeof(int64_t) + sizeof(NodeEntry));
+  pinned_.reserve(bytes);
+  staging_.reserve(bytes, 0, stream_);
+  int64_t* h_ids = pinned_.as<int64_t>();
+  NodeEntry* h_ent = reinterpret_cast<NodeEntry*>(h_ids + k);
+  for (size_t i = 0; i < k; ++i) {
+    const NodeState& st = nodes_[ids[i]];
+    h_ids[i] = ids[i];
+    h_ent[i].start = st.seg_start + st.live_off;
+    h_ent[i].size = static_cast<uint32_t>(st.live_size);
+    h_ent[i].reserved = 0;
+  }
+  GF_HIP(hipMemcpyAsync(staging_.data(), pinned_.data(), bytes, hipMemcpyHostToDevice, stream_));
+  int64_t* d_ids = staging_.as<int64_t>();
+  NodeEntry* d_ent = reinterpret_cast<NodeEntry*>(d_ids + k);
+  update_nodes_kernel<<<dim3((k + 255) / 256), dim3(256), 0, stream_>>>(
+      d_ids, d_ent, k, table_.as<NodeEntry>());
+  GF_HIP(hipGetLastError());
+  GF_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---- ingest: DynamicGraph::AddEdges, dynamic_graph.cu:77-138 -------------------
+void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* ts,
+                          const int64_t* eids, size_t n) {
+  GF_REQUIRE(n > 0, "add_edges: empty batch (reference: CHECK_GT(src_nodes.size(), 0))");
+  GF_REQUIRE(src && dst && ts && eids, "add_edges: null array");
+  DeviceGuard dg(device_);
+
+  int64_t max_node = 0;
+  for (size_t i = 0; i < n; ++i) {
+    GF_REQUIRE(src[i] >= 0 && dst[i] >= 0, "add_edges: negative vertex id");
+    max_node = std::max(max_node, std::max(src[i], dst[i]));
+  }
+
+  // 1. order by (source, timestamp, input position): the reference groups by
+  //    source in input order and stable-sorts each group by timestamp
+  //    (dynamic_graph.cu:105-128, utils.h:16-27).
+  std::vector<size_t> perm(n);
+  {
+    size_t table_len = static_cast<size_t>(max_node) + 1;
+    if (table_len <= 4 * n + (1u << 16)) {
+      // counting sort by source (stable), then fix up unsorted groups by time
+      std::vector<size_t> head(table_len + 1, 0);
+      for (size_t i = 0; i < n; ++i) head[src[i] + 1]++;
+      for (size_t v = 0; v < table_len; ++v) head[v + 1] += head[v];
+      std::vector<size_t> cur(head.begin(), head.end() - 1);
+      for (size_t i = 0; i < n; ++i) perm[cur[src[i]]++] = i;
+      for (size_t v = 0; v < table_len; ++v) {
+        size_t a = head[v], b = head[v + 1];
+        if (b - a < 2) continue;
+        bool sorted = true;
+        for (size_t k = a + 1; k < b && sorted; ++k) sorted = !(ts[perm[k]] < ts[perm[k - 1]]);
+        if (!sorted)
+          std::stable_sort(perm.begin() + a, perm.begin() + b,
+                           [&](size_t x, size_t y) { return ts[x] < ts[y]; });
+      }
+    } else {
+      std::iota(perm.begin(), perm.end(), 0);
+      std::sort(perm.begin(), perm.end(), [&](size_t x, size_t y) {
+        if (src[x] != src[y]) return src[x] < src[y];
+        if (ts[x] < ts[y]) return true;
+        if (ts[y] < ts[x]) return false;
+        return x < y;
+      });
+    }
+  }
+
+  // 2. validate before mutating anything: a group's oldest new edge must not be
+  //    older than the node's newest stored edge (reference: CHECK_LE ->
+  //    abort, utils.cu:42-43; the docstring promises ValueError,
+  //    gnnflow/dynamic_graph.py:99-101).
+  for (size_t i = 0; i < n;) {
+    int64_t v = src[perm[i]];
+    size_t j = i;
+    while (j < n && src[perm[j]] == v) ++j;
+    if (static_cast<size_t>(v) < nodes_.size()) {
+      const NodeState& st = nodes_[v];
+      if (ts[perm[i]] < st.last_ts) {
+        throw Error(GF_ERR_TIMESTAMP_ORDER,
+                    "add_edges: vertex " + std::to_string(v) + " got an edge at t=" +
+                        std::to_string(ts[perm[i]]) + " older than its newest stored edge t=" +
+                        std::to_string(st.last_ts));
+      }
+      GF_REQUIRE(st.live_size + (j - i) < 0xFFFFFFFFull,
+                 "add_edges: more than 2^32-1 live edges on one vertex");
+    }
+    i = j;
+  }
+
+  // 3. bookkeeping sets (dynamic_graph.cu:89-103)
+  add_nodes(max_node);
+  for (size_t i = 0; i < n; ++i) {
+    uint8_t& s = seen_[src[i]];
+    if (!(s & 1)) { s |= 1; num_nodes_++; }
+    if (!(s & 2)) { s |= 2; num_src_nodes_++; }
+    uint8_t& d = seen_[dst[i]];
+    if (!(d & 1)) { d |= 1; num_nodes_++; }
+    bump_eid(eids[i]);
+  }
+
+  // 4. plan: logical blocks, physical segments, per-edge destinations
+  std::vector<uint64_t> dest(n);
+  std::vector<Move> moves;
+  std::vector<std::pair<uint64_t, uint64_t>> deferred_free;
+  std::vector<int64_t> touched;
+  std::vector<float> group_ts;
+  const uint64_t min_phys = pow2_ceil(std::max<size_t>(minimum_block_size_, 1));
+  for (size_t i = 0; i < n;) {
+    int64_t v = src[perm[i]];
+    size_t j = i;
+    while (j < n && src[perm[j]] == v) ++j;
+    size_t cnt = j - i;
+    NodeState& st = nodes_[v];
+    group_ts.resize(cnt);
+    for (size_t k = 0; k < cnt; ++k) group_ts[k] = ts[perm[i + k]];
+    simulate_blocks(st, group_ts.data(), cnt);
+
+    uint64_t need = st.live_size + cnt;
+    if (st.seg_cap == 0) {
+      st.seg_cap = pow2_ceil(std::max<uint64_t>(need, min_phys));
+      st.seg_start = seg_alloc(st.seg_cap);
+      st.live_off = 0;
+    } else if (st.live_off + need > st.seg_cap) {
+      uint64_t cap = pow2_ceil(std::max<uint64_t>(need, min_phys));
+      uint64_t ns = seg_alloc(cap);
+      if (st.live_size) moves.push_back({st.seg_start + st.live_off, ns, st.live_size});
+      deferred_free.emplace_back(st.seg_start, st.seg_cap);
+      st.seg_start = ns;
+      st.seg_cap = cap;
+      st.live_off = 0;
+    }
+    uint64_t base = st.seg_start + st.live_off + st.live_size;
+    for (size_t k = 0; k < cnt; ++k) dest[i + k] = base + k;
+    st.live_size = need;
+    st.last_ts = group_ts[cnt - 1];
+    touched.push_back(v);
+    i = j;
+  }
+  ensure_pool(bump_);
+
+  // 5. device: relocate grown segments, then scatter the batch, then publish entries
+  if (!moves.empty()) {
+    size_t bytes = moves.size() * sizeof(MoveDesc);
+    pinned_.reserve(bytes);
+    staging_.reserve(bytes, 0, stream_);
+    std::memcpy(pinned_.data(), moves.data(), bytes);
+    GF_HIP(hipMemcpyAsync(staging_.data(), pinned_.data(), bytes, hipMemcpyHostToDevice, stream_));
+    unsigned grid = static_cast<unsigned>(std::min<size_t>(moves.size(), 4096));
+    move_segments_kernel<<<dim3(grid), dim3(256), 0, stream_>>>(
+        staging_.as<MoveDesc>(), moves.size(), ts_pool_.as<float>(), nbr_pool_.as<EdgePair>());
+    GF_HIP(hipGetLastError());
+    GF_HIP(hipStreamSynchronize(stream_));  // staging is reused below
+  }
+  for (size_t off = 0; off < n; off += kIngestChunk) {
+    size_t m = std::min(kIngestChunk, n - off);
+    size_t o_dst = m * sizeof(uint64_t), o_eid = o_dst + m * sizeof(int64_t),
+           o_ts = o_eid + m * sizeof(int64_t), bytes = o_ts + m * sizeof(float);
+    pinned_.reserve(bytes);
+    staging_.reserve(bytes, 0, stream_);
+    char* h = pinned_.as<char>();
+    uint64_t* h_dest = reinterpret_cast<uint64_t*>(h);
+    int64_t* h_dst = reinterpret_cast<int64_t*>(h + o_dst);
+    int64_t* h_eid = reinterpret_cast<int64_t*>(h + o_eid);
+    float* h_ts = reinterpret_cast<float*>(h + o_ts);
+    for (size_t k = 0; k < m; ++k) {
+      size_t p = perm[off + k];
+      h_dest[k] = dest[off + k];
+      h_dst[k] = dst[p];
+      h_eid[k] = eids[p];
+      h_ts[k] = ts[p];
+    }
+    GF_HIP(hipMemcpyAsync(staging_.data(), h, bytes, hipMemcpyHostToDevice, stream_));
+    char* d = staging_.as<char>();
+    unsigned grid = static_cast<unsigned>(std::min<size_t>((m + 255) / 256, 8192));
+    scatter_edges_kernel<<<dim3(grid), dim3(256), 0, stream_>>>(
+        reinterpret_cast<uint64_t*>(d), reinterpret_cast<int64_t*>(d + o_dst),
+        reinterpret_cast<int64_t*>(d + o_eid), reinterpret_cast<float*>(d + o_ts), m,
+        ts_pool_.as<float>(), nbr_pool_.as<EdgePair>());
+    GF_HIP(hipGetLastError());
+    GF_HIP(hipStreamSynchronize(stream_));  // the pinned chunk is refilled next
+  }
+  for (auto& f : deferred_free) seg_free(f.first, f.second);
+  upload_entries(touched);  // ends with the stream sync of dynamic_graph.cu:135-137
+}
+
+// ---- DynamicGraph::OffloadOldBlocks, dynamic_graph.cu:382-411 --------------------
+size_t EdgeStore::offload_old_blocks(float timestamp, bool to_file) {
+  DeviceGuard dg(device_);
+  struct Dropped { int64_t node; uint64_t out; std::vector<LogicalBlock> blocks; };
+  std::vector<RangeDesc> ranges;
+  std::vector<Dropped> dropped;
+  std::vector<int64_t> touched;
+  uint64_t total = 0;
+  size_t num_blocks = 0;
+  for (size_t v = 0; v < nodes_.size(); ++v) {
+    if (!(seen_[v] & 1)) continue;
+    NodeState& st = nodes_[v];
+    // blocks are chronological, so the blocks with end_ts < t form a prefix
+    uint64_t k = 0;
+    Dropped d{static_cast<int64_t>(v), total, {}};
+    while (st.num_blocks() > 0 && st.blocks[st.first_block].end_ts < timestamp) {
+      const LogicalBlock& b = st.blocks[st.first_block];
+      k += b.size;
+      logical_bytes_ -= b.capacity * kBlockSpace;
+      logical_blocks_--;
+      d.blocks.push_back(b);
+      st.first_block++;
+      num_blocks++;
+    }
+    if (d.blocks.empty()) continue;
+    if (k > 0) ranges.push_back({st.seg_start + st.live_off, k, total});
+    total += k;
+    st.live_off += k;
+    st.live_size -= k;
+    if (st.num_blocks() == 0) {
+      st.blocks.clear();
+      st.first_block = 0;
+      if (st.live_size == 0 && st.seg_cap) {
+        seg_free(st.seg_start, st.seg_cap);
+        st.seg_start = st.seg_cap = st.live_off = 0;
+      }
+    }
+    dropped.push_back(std::move(d));
+    touched.push_back(static_cast<int64_t>(v));
+  }
+  if (total > 0) {
+    size_t rbytes = align_up(ranges.size() * sizeof(RangeDesc), 16);
+    size_t o_dst = rbytes, o_eid = o_dst + total * 8, o_ts = o_eid + total * 8,
+           bytes = o_ts + total * 4;
+    pinned_.reserve(bytes);
+    staging_.reserve(bytes, 0, stream_);
+    std::memcpy(pinned_.data(), ranges.data(), ranges.size() * sizeof(RangeDesc));
+    GF_HIP(hipMemcpyAsync(staging_.data(), pinned_.data(), rbytes, hipMemcpyHostToDevice, stream_));
+    char* d = staging_.as<char>();
+    unsigned grid = static_cast<unsigned>(std::min<size_t>(ranges.size(), 4096));
+    gather_ranges_kernel<<<dim3(grid), dim3(256), 0, stream_>>>(
+        reinterpret_cast<RangeDesc*>(d), ranges.size(), ts_pool_.as<float>(),
+        nbr_pool_.as<EdgePair>(), reinterpret_cast<int64_t*>(d + o_dst),
+        reinterpret_cast<int64_t*>(d + o_eid), reinterpret_cast<float*>(d + o_ts));
+    GF_HIP(hipGetLastError());
+    GF_HIP(hipMemcpyAsync(pinned_.as<char>() + o_dst, d + o_dst, bytes - o_dst,
+                          hipMemcpyDeviceToHost, stream_));
+    GF_HIP(hipStreamSynchronize(stream_));
+    const int64_t* h_dst = reinterpret_cast<const int64_t*>(pinned_.as<char>() + o_dst);
+    const int64_t* h_eid = reinterpret_cast<const int64_t*>(pinned_.as<char>() + o_eid);
+    const float* h_ts = reinterpret_cast<const float*>(pinned_.as<char>() + o_ts);
+    for (uint64_t i = 0; i < total; ++i) drop_eid(h_eid[i]);
+    if (to_file) {
+      // temporal_block_allocator.cu:182-221 SaveToFile record layout
+      for (const Dropped& dr : dropped) {
+        uint64_t off = dr.out;
+        NodeState& st = nodes_[dr.node];
+        for (const LogicalBlock& b : dr.blocks) {
+          std::string name = "temporal_block_" + std::to_string(dr.node) + "-" +
+                             std::to_string(st.saved_blocks++) + ".bin";
+          std::ofstream f(name, std::ios::out | std::ios::binary);
+          if (!f) throw Error(GF_ERR_IO, "cannot open " + name);
+          uint64_t size = b.size, cap = b.capacity, null_ptr = 0;
+          f.write(reinterpret_cast<const char*>(&size), 8);
+          f.write(reinterpret_cast<const char*>(&cap), 8);
+          f.write(reinterpret_cast<const char*>(&b.start_ts), 4);
+          f.write(reinterpret_cast<const char*>(&b.end_ts), 4);
+          f.write(reinterpret_cast<const char*>(h_dst + off), 8 * b.size);
+          f.write(reinterpret_cast<const char*>(h_ts + off), 4 * b.size);
+          f.write(reinterpret_cast<const char*>(h_eid + off), 8 * b.size);
+          f.write(reinterpret_cast<const char*>(&null_ptr), 8);  // prev
+          f.write(reinterpret_cast<const char*>(&null_ptr), 8);  // next
+          off += b.size;
+        }
+      }
+    }
+  }
+  upload_entries(touched);
+  return num_blocks;
+}
+
+// ---- accessors: dynamic_graph.cu:289-380 -----------------------------------------
+void EdgeStore::out_degree(const int64_t* nodes, size_t n, size_t* out) const {
+  for (size_t i = 0; i < n; ++i) {
+    GF_REQUIRE(nodes[i] >= 0 && static_cast<size_t>(nodes[i]) < nodes_.size(),
+               "out_degree: vertex id out of range");
+    out[i] = nodes_[nodes[i]].num_edges;
+  }
+}
+
+size_t EdgeStore::nodes(int64_t* out, size_t cap, bool src_only) const {
+  size_t k = 0;
+  const uint8_t bit = src_only ? 2 : 1;
+  for (size_t v = 0; v < seen_.size(); ++v) {
+    if (!(seen_[v] & bit)) continue;
+    if (out && k < cap) out[k] = static_cast<int64_t>(v);
+    k++;
+  }
+  return k;
+}
+
+size_t EdgeStore::edges(int64_t* out, size_t cap) const {
+  size_t k = 0;
+  for (size_t e = 0; e < eid_dense_.size(); ++e) {
+    if (!eid_dense_[e]) continue;
+    if (out && k < cap) out[k] = static_cast<int64_t>(e);
+    k++;
+  }
+  for (const auto& kv : eid_sparse_) {
+    if (out && k < cap) out[k] = kv.first;
+    k++;
+  }
+  return k;
+}
+
+size_t EdgeStore::get_temporal_neighbors(int64_t node, int64_t* dst, float* ts,
+                                         int64_t* eids, size_t cap) const {
+  if (node < 0 || static_cast<size_t>(node) >= nodes_.size()) return 0;
+  const NodeState& st = nodes_[node];
+  size_t n = st.live_size;
+  if (!dst || n == 0) return n;
+  GF_REQUIRE(cap >= n, "get_temporal_neighbors: output arrays too small");
+  DeviceGuard dg(device_);
+  std::vector<float> h_ts(n);
+  std::vector<EdgePair> h_nb(n);
+  uint64_t s = st.seg_start + st.live_off;
+  GF_HIP(hipMemcpy(h_ts.data(), ts_pool_.as<float>() + s, n * sizeof(float), hipMemcpyDeviceToHost));
+  GF_HIP(hipMemcpy(h_nb.data(), nbr_pool_.as<EdgePair>() + s, n * sizeof(EdgePair), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {  // newest first
+    dst[i] = h_nb[n - 1 - i].dst;
+    eids[i] = h_nb[n - 1 - i].eid;
+    ts[i] = h_ts[n - 1 - i];
+  }
+  return n;
+}
+
+float EdgeStore::avg_linked_list_length() const {
+  float sum = 0;
+  for (size_t v = 0; v < nodes_.size(); ++v)
+    if (seen_[v] & 1) sum += static_cast<float>(nodes_[v].num_blocks());
+  return sum / static_cast<float>(num_nodes_);
+}
+
+float EdgeStore::metadata_mem_usage() const {
+  // sizeof(TemporalBlock) * #blocks + sizeof(DoublyLinkedList) * table size
+  // (dynamic_graph.cu:370-380), with this layout's 16-byte table entries
+  return static_cast<float>(64 * logical_blocks_ +
+                            sizeof(NodeEntry) * (any_node_ ? max_node_id_ + 1 : 0));
+}
+
+}  // namespace gf

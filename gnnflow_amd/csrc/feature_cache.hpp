@@ -1,0 +1,43 @@
+// Fused feature gather + LRU feature cache in HBM — MI355X counterpart of
+// gnnflow/cache/cache.py (Cache.fetch_feature) and gnnflow/cache/lru_cache.py.
+#pragma once
+
+#include <cstdint>
+
+#include "common.hpp"
+
+namespace gf {
+
+// out[i,:] = feats[ids[i],:]  (gnnflow/utils.py:465-474; cache.py:411)
+void gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_t* d_ids,
+                 size_t n, float* d_out, int device, hipStream_t stream);
+
+class FeatureCache {
+ public:
+  FeatureCache(size_t num_ids, size_t capacity, size_t dim, const float* d_feats, int device);
+  ~FeatureCache() = default;
+
+  void init(hipStream_t stream);
+  void resize(size_t new_num_ids, size_t new_capacity, const float* d_feats, hipStream_t stream);
+  void fetch(const int64_t* d_ids, size_t n, float* d_out, bool update, uint32_t* d_stats,
+             hipStream_t stream);
+  void slot_ids(int64_t* out, size_t capacity) const;
+  size_t mem_bytes() const;
+
+ private:
+  void reserve_workspace(size_t n);
+
+  size_t num_ids_, capacity_, dim_;
+  const float* feats_;
+  int device_;
+
+  DeviceBuffer buffer_;    // float[capacity * dim]        cache rows
+  DeviceBuffer map_;       // int32[num_ids]               id -> slot (kAbsent if none)
+  DeviceBuffer slot_id_;   // int64[capacity]              slot -> id (-1 empty)
+  DeviceBuffer stamp_;     // uint32[capacity]             epoch of last touch
+  DeviceBuffer state_;     // uint32 epoch
+  DeviceBuffer ws_;        // per-fetch scratch
+  size_t ws_rows_ = 0;
+};
+
+}  // namespace gf

@@ -1,0 +1,540 @@
+// Temporal neighbour sampling on MI355X (gfx950).
+//
+// Replaces gnnflow/csrc/sampling_kernels.cu (SampleLayerRecentKernel :11-107,
+// SampleLayerUniformKernel :109-273), the thrust::remove_if compaction
+// (temporal_sampler.cu:191-204) and the host-side result assembly
+// (temporal_sampler.cu:236-274) with three launches per (layer, snapshot), all
+// device resident:
+//
+//   1. search : one 16- or 64-lane group per root.  Resolves the root's time
+//               window ONCE (the reference repeats the block walk and both binary
+//               searches in each of the F slot threads) with a group-wide k-ary
+//               search over the node's flat timestamp segment: every round the
+//               group's lanes probe GROUP pivots in parallel and a ballot/popcount
+//               picks the sub-range, so a window over 4096 edges is found in 2
+//               dependent memory round trips at GROUP=64 instead of 12.
+//   2. scan   : exclusive prefix sum of the per-root valid-slot counts (wave
+//               shuffles + LDS), which gives every root its base in the compacted
+//               output and the layer's edge count S (and R' = R + S, the next
+//               layer's root count, which never leaves HBM).
+//   3. emit   : one thread per (root, slot): reads the selected edge (4 B
+//               timestamp + one 16 B {dst, eid} pair) and writes the final MFG
+//               arrays (all_nodes, all_timestamps, delta_timestamps, eids, row, col)
+//               directly at base[root] + slot, i.e. already compacted, root-major,
+//               newest first — the order thrust's stable remove_if leaves.
+//
+// Equivalence with the reference's per-block case analysis
+// (sampling_kernels.cu:55-86): for chronologically ingested edges the union over
+// blocks of [LowerBound(start), LowerBound(end)) equals
+// [lower_bound(start), lower_bound(end)) on the node's concatenated sequence, and
+// "j-th most recent, spilling to the previous block" (:88-92) is index
+// end-1-j on that sequence.  tests/ proves it against the block-walking oracle.
+#include "sampler.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/gnnflow_rng.h"
+
+namespace gf {
+
+namespace {
+
+constexpr int kSearchThreads = 256;
+constexpr int kEmitThreads = 256;
+constexpr int kScanThreads = 1024;
+constexpr int kScanItems = 4;  // per thread per tile
+
+// sampling_kernels.cu:28-40
+__device__ inline void time_window(float root_ts, uint32_t snapshot_idx,
+                                   uint32_t num_snapshots, float window, float* start,
+                                   float* end) {
+  if (num_snapshots == 1) {
+    *start = (fabs(static_cast<double>(window)) < 1e-6) ? 0.0f : root_ts - window;
+    *end = root_ts;
+  } else {
+    float k = static_cast<float>(num_snapshots - snapshot_idx - 1);
+    *end = fmaf(-k, window, root_ts);  // nvcc contracts `t - k*w` (see oracle)
+    *start = *end - window;
+  }
+}
+
+template <int GROUP>
+__device__ inline uint32_t group_count(bool pred, int group_in_wave) {
+  unsigned long long m = __ballot(pred);
+  if (GROUP == 64) return __popcll(m);
+  return __popcll((m >> (group_in_wave * GROUP)) & ((1ull << GROUP) - 1ull));
+}
+
+// First index in [0, n) with ts[idx] >= x (utils.cu:96-109 LowerBound), evaluated
+// cooperatively by a GROUP-lane group; every lane returns the result.
+template <int GROUP>
+__device__ inline uint32_t lower_bound_group(const float* __restrict__ ts, uint32_t n,
+                                             float x, int lane, int group_in_wave) {
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > GROUP) {
+    uint32_t span = hi - lo;
+    uint32_t stride = (span + GROUP - 1) / GROUP;
+    uint32_t p = lo + lane * stride;
+    bool less = (p < hi) && (ts[p] < x);
+    uint32_t c = group_count<GROUP>(less, group_in_wave);
+    if (c == 0) {
+      hi = lo;
+    } else {
+      uint32_t nlo = lo + (c - 1) * stride + 1;
+      uint32_t nhi = lo + c * stride;
+      hi = nhi < hi ? nhi : hi;
+      lo = nlo;
+    }
+  }
+  uint32_t p = lo + lane;
+  bool less = (p < hi) && (ts[p] < x);
+  return lo + group_count<GROUP>(less, group_in_wave);
+}
+
+// ---- 1. search --------------------------------------------------------------------
+template <int GROUP>
+__global__ __launch_bounds__(kSearchThreads) void sample_search_kernel(
+    GraphView g, const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t snapshot_idx,
+    uint32_t num_snapshots, float window, uint64_t* __restrict__ rec_end,
+    uint32_t* __restrict__ rec_cnt) {
+  const uint64_t R = d_R ? *d_R : R_host;
+  constexpr int kGroupsPerBlock = kSearchThreads / GROUP;
+  const int lane = threadIdx.x % GROUP;
+  const int group_in_wave = (threadIdx.x % 64) / GROUP;
+  const uint64_t group = static_cast<uint64_t>(blockIdx.x) * kGroupsPerBlock + threadIdx.x / GROUP;
+  const uint64_t num_groups = static_cast<uint64_t>(gridDim.x) * kGroupsPerBlock;
+  for (uint64_t r = group; r < R; r += num_groups) {
+    const int64_t nid = roots[r];
+    const float t = root_ts[r];
+    float start, end;
+    time_window(t, snapshot_idx, num_snapshots, window, &start, &end);
+    uint64_t end_off = 0;
+    uint32_t n_cand = 0;
+    if (nid >= 0 && static_cast<uint64_t>(nid) < g.table_len) {
+      const NodeEntry e = g.table[nid];
+      if (e.size > 0) {
+        const float* ts = g.ts_pool + e.start;
+        const float first = ts[0];
+        const uint32_t hi = lower_bound_group<GROUP>(ts, e.size, end, lane, group_in_wave);
+        uint32_t lo = 0;
+        if (start > first) lo = lower_bound_group<GROUP>(ts, hi, start, lane, group_in_wave);
+        n_cand = hi > lo ? hi - lo : 0;
+        end_off = e.start + hi;
+      }
+    }
+    if (lane == 0) {
+      rec_end[r] = end_off;
+      rec_cnt[r] = n_cand;
+    }
+  }
+}
+
+// ---- 2. scan -----------------------------------------------------------------------
+__device__ inline uint32_t valid_slots(uint32_t n_cand, uint32_t fanout, int uniform) {
+  // recent: slot j valid iff j < #candidates (sampling_kernels.cu:88-104);
+  // uniform: every slot valid iff there is a candidate (:202, with replacement)
+  if (uniform) return n_cand ? fanout : 0u;
+  return n_cand < fanout ? n_cand : fanout;
+}
+
+__global__ __launch_bounds__(kScanThreads) void sample_scan_kernel(
+    const uint32_t* __restrict__ rec_cnt, uint32_t* __restrict__ base,
+    const uint64_t* d_R, uint64_t R_host, uint32_t fanout, int uniform, uint64_t* out_R,
+    uint64_t* out_S, uint64_t* next_R) {
+  __shared__ uint32_t wave_sums[kScanThreads / 64];
+  __shared__ uint32_t carry_s;
+  const uint64_t R = d_R ? *d_R : R_host;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  constexpr uint64_t kTile = static_cast<uint64_t>(kScanThreads) * kScanItems;
+  for (uint64_t tile = 0; tile < R; tile += kTile) {
+    uint32_t v[kScanItems];
+    uint32_t local = 0;
+    const uint64_t i0 = tile + static_cast<uint64_t>(tid) * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      v[k] = (i0 + k < R) ? valid_slots(rec_cnt[i0 + k], fanout, uniform) : 0u;
+      local += v[k];
+    }
+    // inclusive scan of `local` across the wave
+    uint32_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wave_sums[w];
+    uint32_t run = carry_s + wave_base + incl - local;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      if (i0 + k < R) base[i0 + k] = run;
+      run += v[k];
+    }
+    __syncthreads();
+    if (tid == kScanThreads - 1) carry_s = run;  // last thread's run = tile total + carry
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const uint64_t S = carry_s;
+    *out_R = R;
+    *out_S = S;
+    if (next_R) *next_R = R + S;
+  }
+}
+
+// ---- 3. emit -----------------------------------------------------------------------
+__global__ __launch_bounds__(kEmitThreads) void sample_emit_kernel(
+    GraphView g, const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t fanout, int uniform,
+    int prop_time, uint64_t seed, uint64_t call, const uint64_t* __restrict__ rec_end,
+    const uint32_t* __restrict__ rec_cnt, const uint32_t* __restrict__ base,
+    int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
+    int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col) {
+  const uint64_t R = d_R ? *d_R : R_host;
+  const uint64_t total = R * fanout;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    if (t < R) {  // dst nodes come first in all_nodes / all_timestamps
+      all_nodes[t] = roots[t];
+      all_ts[t] = root_ts[t];
+    }
+    const uint64_t r = t / fanout;
+    const uint32_t j = static_cast<uint32_t>(t - r * fanout);
+    const uint32_t n = rec_cnt[r];
+    if (j >= valid_slots(n, fanout, uniform)) continue;
+    const uint32_t pick = uniform ? gf_philox4x32_10_first(seed, t, call) % n : j;
+    const uint64_t e = rec_end[r] - 1 - pick;
+    const float ets = g.ts_pool[e];
+    const EdgePair nb = g.nbr_pool[e];
+    const float rts = root_ts[r];
+    const uint64_t o = static_cast<uint64_t>(base[r]) + j;
+    all_nodes[R + o] = nb.dst;
+    all_ts[R + o] = prop_time ? rts : ets;
+    dt[o] = rts - ets;
+    eids[o] = nb.eid;
+    row[o] = static_cast<int64_t>(r);
+    col[o] = static_cast<int64_t>(R + o);
+  }
+}
+
+inline unsigned capped_grid(uint64_t work_items, unsigned per_block, unsigned cap) {
+  uint64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  return static_cast<unsigned>(std::min<uint64_t>(g, cap));
+}
+
+// lanes cooperating on one root in the search kernel (16 or 64); read when a
+// sampler is created so tests and benches can compare both
+int search_group_width_from_env() {
+  const char* v = std::getenv("GNNFLOW_SEARCH_GROUP");
+  int g = v ? std::atoi(v) : 16;
+  return (g == 64) ? 64 : 16;
+}
+
+}  // namespace
+
+// ---- host driver -------------------------------------------------------------------
+Sampler::Sampler(EdgeStore* graph, const uint32_t* fanouts, size_t num_layers, int policy,
+                 uint32_t num_snapshots, float window, bool prop_time, uint64_t seed)
+    : graph_(graph),
+      fanouts_(fanouts, fanouts + num_layers),
+      policy_(policy),
+      num_snapshots_(num_snapshots),
+      window_(window),
+      prop_time_(prop_time),
+      seed_(seed) {
+  GF_REQUIRE(graph != nullptr, "sampler: null graph");
+  GF_REQUIRE(num_layers > 0, "sampler: fanouts must not be empty");
+  for (uint32_t f : fanouts_) GF_REQUIRE(f > 0, "sampler: fanout must be positive");
+  GF_REQUIRE(policy == GF_SAMPLING_POLICY_RECENT || policy == GF_SAMPLING_POLICY_UNIFORM,
+             "sampler: invalid sampling policy");
+  GF_REQUIRE(num_snapshots >= 1, "sampler: num_snapshots must be >= 1");
+  search_group_ = search_group_width_from_env();
+  DeviceGuard dg(graph_->device());
+  GF_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+}
+
+Sampler::~Sampler() {
+  if (own_stream_) {
+    (void)hipStreamSynchronize(own_stream_);
+    (void)hipStreamDestroy(own_stream_);
+  }
+}
+
+size_t Sampler::root_bound(size_t R, size_t layer) const {
+  size_t b = R;
+  for (size_t l = 0; l < layer; ++l) b += b * fanouts_[l];
+  return b;
+}
+
+// Per-block carve of the output buffer; every array 16-byte aligned.
+size_t Sampler::layer_output_bytes(size_t Rb, size_t layer) const {
+  const size_t F = fanouts_[layer], Sb = Rb * F;
+  return align_up((Rb + Sb) * 8, 16) + align_up((Rb + Sb) * 4, 16) + align_up(Sb * 4, 16) +
+         3 * align_up(Sb * 8, 16);
+}
+
+Sampler::BlockPtrs Sampler::carve(char* p, size_t Rb, uint32_t F) const {
+  const size_t Sb = Rb * F;
+  BlockPtrs b;
+  b.all_nodes = reinterpret_cast<int64_t*>(p); p += align_up((Rb + Sb) * 8, 16);
+  b.eids = reinterpret_cast<int64_t*>(p);      p += align_up(Sb * 8, 16);
+  b.row = reinterpret_cast<int64_t*>(p);       p += align_up(Sb * 8, 16);
+  b.col = reinterpret_cast<int64_t*>(p);       p += align_up(Sb * 8, 16);
+  b.all_ts = reinterpret_cast<float*>(p);      p += align_up((Rb + Sb) * 4, 16);
+  b.dt = reinterpret_cast<float*>(p);
+  return b;
+}
+
+size_t Sampler::output_bytes(size_t R) const {
+  size_t total = 0;
+  for (size_t l = 0; l < fanouts_.size(); ++l)
+    total += num_snapshots_ * layer_output_bytes(root_bound(R, l), l);
+  return total;
+}
+
+void Sampler::reserve_workspace(size_t Rb, size_t num_blocks, hipStream_t stream) {
+  if (Rb <= ws_roots_ && num_blocks <= ws_blocks_) return;
+  ws_roots_ = std::max(ws_roots_, Rb);
+  ws_blocks_ = std::max(ws_blocks_, num_blocks);
+  size_t bytes = align_up(ws_roots_ * 8, 16) + 2 * align_up(ws_roots_ * 4, 16) +
+                 ws_blocks_ * 2 * sizeof(uint64_t) + 64;
+  (void)stream;
+  ws_.reserve(bytes, 0, nullptr);
+  h_counts_.reserve(ws_blocks_ * 2 * sizeof(uint64_t));
+}
+
+void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb,
+                            const uint64_t* d_R, uint64_t R_host, uint32_t layer,
+                            uint32_t snapshot, const BlockPtrs& out, uint64_t* d_counts_slot,
+                            uint64_t* next_R, hipStream_t stream) {
+  const uint32_t F = fanouts_[layer];
+  const int uniform = policy_ == GF_SAMPLING_POLICY_UNIFORM;
+  GF_REQUIRE(static_cast<uint64_t>(Rb) * F < 0xFFFFFFFFull,
+             "sampler: more than 2^32-1 slots in one layer");
+  char* w = ws_.as<char>();
+  uint64_t* rec_end = reinterpret_cast<uint64_t*>(w); w += align_up(ws_roots_ * 8, 16);
+  uint32_t* rec_cnt = reinterpret_cast<uint32_t*>(w); w += align_up(ws_roots_ * 4, 16);
+  uint32_t* base = reinterpret_cast<uint32_t*>(w);
+  const GraphView gv = graph_->view();
+  const uint64_t call = calls_++;
+  {
+    ProfileScope ps(kProfSearch, stream);
+    if (search_group_ == 64) {
+      unsigned grid = capped_grid(Rb, kSearchThreads / 64, 256 * 8);
+      sample_search_kernel<64><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(
+          gv, d_roots, d_ts, d_R, R_host, snapshot, num_snapshots_, window_, rec_end, rec_cnt);
+    } else {
+      unsigned grid = capped_grid(Rb, kSearchThreads / 16, 256 * 8);
+      sample_search_kernel<16><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(
+          gv, d_roots, d_ts, d_R, R_host, snapshot, num_snapshots_, window_, rec_end, rec_cnt);
+    }
+    GF_HIP(hipGetLastError());
+  }
+  {
+    ProfileScope ps(kProfScan, stream);
+    sample_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
+        rec_cnt, base, d_R, R_host, F, uniform, d_counts_slot, d_counts_slot + 1, next_R);
+    GF_HIP(hipGetLastError());
+  }
+  {
+    ProfileScope ps(kProfEmit, stream);
+    unsigned grid = capped_grid(static_cast<uint64_t>(Rb) * F, kEmitThreads, 256 * 16);
+    sample_emit_kernel<<<dim3(grid), dim3(kEmitThreads), 0, stream>>>(
+        gv, d_roots, d_ts, d_R, R_host, F, uniform, prop_time_ ? 1 : 0, seed_, call, rec_end,
+        rec_cnt, base, out.all_nodes, out.all_ts, out.dt, out.eids, out.row, out.col);
+    GF_HIP(hipGetLastError());
+  }
+}
+
+// TemporalSampler::Sample, temporal_sampler.cu:279-305
+void Sampler::sample(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
+                     size_t out_bytes, gf_block* blocks, hipStream_t stream) {
+  const size_t L = fanouts_.size(), NS = num_snapshots_;
+  GF_REQUIRE(blocks != nullptr, "sample: null blocks array");
+  if (R == 0) {  // temporal_sampler.cu:107-114
+    for (size_t b = 0; b < L * NS; ++b) std::memset(&blocks[b], 0, sizeof(gf_block));
+    calls_ += L * NS;
+    return;
+  }
+  GF_REQUIRE(d_roots && d_ts && d_out, "sample: null device pointer");
+  GF_REQUIRE(out_bytes >= output_bytes(R), "sample: output buffer too small");
+  DeviceGuard dg(graph_->device());
+  reserve_workspace(root_bound(R, L - 1), L * NS, stream);
+  uint64_t* d_counts = reinterpret_cast<uint64_t*>(
+      ws_.as<char>() + align_up(ws_roots_ * 8, 16) + 2 * align_up(ws_roots_ * 4, 16));
+
+  std::vector<BlockPtrs> ptrs(L * NS);
+  char* p = static_cast<char*>(d_out);
+  for (size_t l = 0; l < L; ++l) {
+    const size_t Rb = root_bound(R, l);
+    for (size_t s = 0; s < NS; ++s) {
+      ptrs[l * NS + s] = carve(p, Rb, fanouts_[l]);
+      p += layer_output_bytes(Rb, l);
+    }
+  }
+  for (size_t l = 0; l < L; ++l) {
+    const size_t Rb = root_bound(R, l);
+    for (size_t s = 0; s < NS; ++s) {
+      const size_t b = l * NS + s;
+      uint64_t* slot = d_counts + 2 * b;
+      // the next layer of the same snapshot reads its root count R + S from next_R
+      uint64_t* next_R = (l + 1 < L) ? slot + 2 * NS : nullptr;
+      if (l == 0) {
+        enqueue_layer(d_roots, d_ts, Rb, nullptr, R, l, s, ptrs[b], slot, next_R, stream);
+      } else {
+        const BlockPtrs& prev = ptrs[(l - 1) * NS + s];
+        enqueue_layer(prev.all_nodes, prev.all_ts, Rb, slot, 0, l, s, ptrs[b], slot, next_R,
+                      stream);
+      }
+    }
+  }
+  GF_HIP(hipMemcpyAsync(h_counts_.data(), d_counts, L * NS * 2 * sizeof(uint64_t),
+                        hipMemcpyDeviceToHost, stream));
+  GF_HIP(hipStreamSynchronize(stream));
+  const uint64_t* hc = h_counts_.as<uint64_t>();
+  for (size_t b = 0; b < L * NS; ++b) {
+    gf_block& o = blocks[b];
+    o.all_nodes = ptrs[b].all_nodes;
+    o.all_timestamps = ptrs[b].all_ts;
+    o.delta_timestamps = ptrs[b].dt;
+    o.eids = ptrs[b].eids;
+    o.row = ptrs[b].row;
+    o.col = ptrs[b].col;
+    o.num_dst_nodes = hc[2 * b];
+    o.num_edges = hc[2 * b + 1];
+    o.num_src_nodes = o.num_dst_nodes + o.num_edges;
+  }
+}
+
+// TemporalSampler::SampleLayer, temporal_sampler.cu:97-277
+void Sampler::sample_layer(const int64_t* d_roots, const float* d_ts, size_t R, uint32_t layer,
+                           uint32_t snapshot, void* d_out, size_t out_bytes, gf_block* block,
+                           hipStream_t stream) {
+  GF_REQUIRE(layer < fanouts_.size(), "sample_layer: layer out of range");
+  GF_REQUIRE(snapshot < num_snapshots_, "sample_layer: snapshot out of range");
+  GF_REQUIRE(block != nullptr, "sample_layer: null block");
+  if (R == 0) {
+    std::memset(block, 0, sizeof(gf_block));
+    calls_++;
+    return;
+  }
+  GF_REQUIRE(d_roots && d_ts && d_out, "sample_layer: null device pointer");
+  GF_REQUIRE(out_bytes >= layer_output_bytes(R, layer), "sample_layer: output buffer too small");
+  DeviceGuard dg(graph_->device());
+  reserve_workspace(R, 2, stream);
+  uint64_t* d_counts = reinterpret_cast<uint64_t*>(
+      ws_.as<char>() + align_up(ws_roots_ * 8, 16) + 2 * align_up(ws_roots_ * 4, 16));
+  BlockPtrs ptrs = carve(static_cast<char*>(d_out), R, fanouts_[layer]);
+  enqueue_layer(d_roots, d_ts, R, nullptr, R, layer, snapshot, ptrs, d_counts, nullptr, stream);
+  GF_HIP(hipMemcpyAsync(h_counts_.data(), d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                        stream));
+  GF_HIP(hipStreamSynchronize(stream));
+  const uint64_t* hc = h_counts_.as<uint64_t>();
+  block->all_nodes = ptrs.all_nodes;
+  block->all_timestamps = ptrs.all_ts;
+  block->delta_timestamps = ptrs.dt;
+  block->eids = ptrs.eids;
+  block->row = ptrs.row;
+  block->col = ptrs.col;
+  block->num_dst_nodes = hc[0];
+  block->num_edges = hc[1];
+  block->num_src_nodes = hc[0] + hc[1];
+}
+
+// Copies device-resident blocks into freshly malloc'ed host arrays
+// (api.cc:17-24 vec2npy copies likewise).
+void Sampler::to_host_blocks(const gf_block* dev, gf_block* host, size_t n, hipStream_t stream) {
+  auto dup = [&](const void* d, size_t bytes) -> void* {
+    void* h = std::malloc(bytes ? bytes : 1);
+    if (!h) throw std::bad_alloc();
+    if (bytes) GF_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream));
+    return h;
+  };
+  for (size_t b = 0; b < n; ++b) {
+    const gf_block& d = dev[b];
+    gf_block& h = host[b];
+    h.num_dst_nodes = d.num_dst_nodes;
+    h.num_src_nodes = d.num_src_nodes;
+    h.num_edges = d.num_edges;
+    h.all_nodes = static_cast<int64_t*>(dup(d.all_nodes, d.num_src_nodes * 8));
+    h.all_timestamps = static_cast<float*>(dup(d.all_timestamps, d.num_src_nodes * 4));
+    h.delta_timestamps = static_cast<float*>(dup(d.delta_timestamps, d.num_edges * 4));
+    h.eids = static_cast<int64_t*>(dup(d.eids, d.num_edges * 8));
+    h.row = static_cast<int64_t*>(dup(d.row, d.num_edges * 8));
+    h.col = static_cast<int64_t*>(dup(d.col, d.num_edges * 8));
+  }
+  GF_HIP(hipStreamSynchronize(stream));
+}
+
+void Sampler::sample_host(const int64_t* nodes, const float* ts, size_t R, gf_block* blocks) {
+  const size_t nb = fanouts_.size() * num_snapshots_;
+  if (R == 0) {
+    // R = 0 short-circuit (temporal_sampler.cu:107-114): empty arrays, 0 nodes
+    calls_ += nb;
+    for (size_t b = 0; b < nb; ++b) {
+      std::memset(&blocks[b], 0, sizeof(gf_block));
+      blocks[b].all_nodes = static_cast<int64_t*>(std::malloc(1));
+      blocks[b].all_timestamps = static_cast<float*>(std::malloc(1));
+      blocks[b].delta_timestamps = static_cast<float*>(std::malloc(1));
+      blocks[b].eids = static_cast<int64_t*>(std::malloc(1));
+      blocks[b].row = static_cast<int64_t*>(std::malloc(1));
+      blocks[b].col = static_cast<int64_t*>(std::malloc(1));
+    }
+    return;
+  }
+  GF_REQUIRE(nodes && ts, "sample: null input array");
+  DeviceGuard dg(graph_->device());
+  const size_t in_bytes = align_up(R * 8, 16) + align_up(R * 4, 16);
+  const size_t out_bytes = output_bytes(R);
+  host_io_.reserve(in_bytes + out_bytes, 0, own_stream_);
+  char* d = host_io_.as<char>();
+  int64_t* d_nodes = reinterpret_cast<int64_t*>(d);
+  float* d_ts = reinterpret_cast<float*>(d + align_up(R * 8, 16));
+  GF_HIP(hipMemcpyAsync(d_nodes, nodes, R * 8, hipMemcpyHostToDevice, own_stream_));
+  GF_HIP(hipMemcpyAsync(d_ts, ts, R * 4, hipMemcpyHostToDevice, own_stream_));
+  std::vector<gf_block> dev(nb);
+  sample(d_nodes, d_ts, R, d + in_bytes, out_bytes, dev.data(), own_stream_);
+  to_host_blocks(dev.data(), blocks, nb, own_stream_);
+}
+
+void Sampler::sample_layer_host(const int64_t* nodes, const float* ts, size_t R, uint32_t layer,
+                                uint32_t snapshot, gf_block* block) {
+  GF_REQUIRE(layer < fanouts_.size(), "sample_layer: layer out of range");
+  GF_REQUIRE(snapshot < num_snapshots_, "sample_layer: snapshot out of range");
+  if (R == 0) {
+    calls_++;
+    std::memset(block, 0, sizeof(gf_block));
+    block->all_nodes = static_cast<int64_t*>(std::malloc(1));
+    block->all_timestamps = static_cast<float*>(std::malloc(1));
+    block->delta_timestamps = static_cast<float*>(std::malloc(1));
+    block->eids = static_cast<int64_t*>(std::malloc(1));
+    block->row = static_cast<int64_t*>(std::malloc(1));
+    block->col = static_cast<int64_t*>(std::malloc(1));
+    return;
+  }
+  GF_REQUIRE(nodes && ts, "sample_layer: null input array");
+  DeviceGuard dg(graph_->device());
+  const size_t in_bytes = align_up(R * 8, 16) + align_up(R * 4, 16);
+  const size_t out_bytes = layer_output_bytes(R, layer);
+  host_io_.reserve(in_bytes + out_bytes, 0, own_stream_);
+  char* d = host_io_.as<char>();
+  int64_t* d_nodes = reinterpret_cast<int64_t*>(d);
+  float* d_ts = reinterpret_cast<float*>(d + align_up(R * 8, 16));
+  GF_HIP(hipMemcpyAsync(d_nodes, nodes, R * 8, hipMemcpyHostToDevice, own_stream_));
+  GF_HIP(hipMemcpyAsync(d_ts, ts, R * 4, hipMemcpyHostToDevice, own_stream_));
+  gf_block dev;
+  sample_layer(d_nodes, d_ts, R, layer, snapshot, d + in_bytes, out_bytes, &dev, own_stream_);
+  to_host_blocks(&dev, block, 1, own_stream_);
+}
+
+}  // namespace gf

@@ -1,0 +1,68 @@
+// TemporalSampler host driver — MI355X counterpart of
+// gnnflow/csrc/temporal_sampler.{h,cu} + sampling_kernels.cu.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "common.hpp"
+#include "edge_store.hpp"
+
+namespace gf {
+
+class Sampler {
+ public:
+  Sampler(EdgeStore* graph, const uint32_t* fanouts, size_t num_layers, int policy,
+          uint32_t num_snapshots, float window, bool prop_time, uint64_t seed);
+  ~Sampler();
+
+  size_t num_layers() const { return fanouts_.size(); }
+  uint32_t num_snapshots() const { return num_snapshots_; }
+  int device() const { return graph_->device(); }
+
+  // worst-case number of roots entering `layer` when sample() starts from R roots
+  size_t root_bound(size_t R, size_t layer) const;
+  size_t layer_output_bytes(size_t num_roots, size_t layer) const;  // one snapshot
+  size_t output_bytes(size_t num_roots) const;                      // all layers x snapshots
+
+  void sample(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
+              size_t out_bytes, gf_block* blocks, hipStream_t stream);
+  void sample_layer(const int64_t* d_roots, const float* d_ts, size_t R, uint32_t layer,
+                    uint32_t snapshot, void* d_out, size_t out_bytes, gf_block* block,
+                    hipStream_t stream);
+  // host-vector forms (reference calling convention)
+  void sample_host(const int64_t* nodes, const float* ts, size_t R, gf_block* blocks);
+  void sample_layer_host(const int64_t* nodes, const float* ts, size_t R, uint32_t layer,
+                         uint32_t snapshot, gf_block* block);
+
+ private:
+  struct BlockPtrs {
+    int64_t* all_nodes; float* all_ts; float* dt; int64_t* eids; int64_t* row; int64_t* col;
+  };
+  BlockPtrs carve(char* base, size_t Rb, uint32_t fanout) const;
+  // Enqueues one (layer, snapshot); R comes from d_R (device) when non-null.
+  void enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t R_bound,
+                     const uint64_t* d_R, uint64_t R_host, uint32_t layer, uint32_t snapshot,
+                     const BlockPtrs& out, uint64_t* d_counts_slot, uint64_t* next_R,
+                     hipStream_t stream);
+  void reserve_workspace(size_t R_bound_max, size_t num_blocks, hipStream_t stream);
+  void to_host_blocks(const gf_block* dev, gf_block* host, size_t n, hipStream_t stream);
+
+  EdgeStore* graph_;
+  std::vector<uint32_t> fanouts_;
+  int policy_;
+  uint32_t num_snapshots_;
+  float window_;
+  bool prop_time_;
+  uint64_t seed_;
+  uint64_t calls_ = 0;  // sample_layer invocations so far (uniform RNG counter)
+  int search_group_ = 16;
+
+  DeviceBuffer ws_;        // per-root search records + scan scratch + counters
+  size_t ws_roots_ = 0, ws_blocks_ = 0;
+  PinnedBuffer h_counts_;
+  DeviceBuffer host_io_;   // device buffers behind the *_host entry points
+  hipStream_t own_stream_ = nullptr;
+};
+
+}  // namespace gf

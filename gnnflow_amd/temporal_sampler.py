@@ -1,0 +1,208 @@
+"""gnnflow.TemporalSampler on MI355X — same constructor, methods and MFG layout as the
+reference's Python wrapper (gnnflow/temporal_sampler.py:14-177); all layers and
+snapshots are sampled in one device-resident call (gf_sampler_sample) and the returned
+blocks hold torch tensors in HBM, so mfgs_to_cuda (gnnflow/utils.py:477-481) is a no-op."""
+import ctypes as C
+from typing import List, Union
+
+import numpy as np
+import torch
+
+from . import _capi
+from .dynamic_graph import DynamicGraph
+from .mfg import MFGBlock
+
+
+class SamplingResult:
+    """libgnnflow.SamplingResult look-alike (gnnflow/csrc/api.cc:87-109): accessor
+    *methods* returning host numpy arrays; `*_tensor()` give the device tensors."""
+
+    def __init__(self, block: MFGBlock):
+        self._b = block
+
+    def row(self): return self._b.edges()[1].cpu().numpy()
+    def col(self): return self._b.edges()[0].cpu().numpy()
+    def all_nodes(self): return self._b.srcdata['ID'].cpu().numpy()
+    def all_timestamps(self): return self._b.srcdata['ts'].cpu().numpy()
+    def delta_timestamps(self): return self._b.edata['dt'].cpu().numpy()
+    def eids(self): return self._b.edata['ID'].cpu().numpy()
+    def num_src_nodes(self): return self._b.num_src_nodes()
+    def num_dst_nodes(self): return self._b.num_dst_nodes()
+    def block(self) -> MFGBlock: return self._b
+
+
+class TemporalSampler:
+    """
+    TemporalSampler samples k-hop multi-snapshots neighbors of given vertices.
+    """
+
+    def __init__(
+            self, graph: DynamicGraph, fanouts: List[int],
+            sample_strategy: str = "recent", num_snapshots: int = 1,
+            snapshot_time_window: float = 0.0, prop_time: bool = False,
+            seed: int = 1234, *args, **kwargs):
+        sample_strategy = sample_strategy.lower()
+        if sample_strategy not in ["recent", "uniform"]:
+            raise ValueError("strategy must be 'recent' or 'uniform'")
+
+        self._lib = _capi.load()
+        self._graph = graph  # keep the graph alive (temporal_sampler.h:62 holds a ref)
+        self._device = torch.device("cuda", graph.device)
+        self._fanouts = [int(f) for f in fanouts]
+        self._num_layers = len(self._fanouts)
+        self._num_snapshots = int(num_snapshots)
+        self._h = C.c_void_p()
+        arr = (C.c_uint32 * self._num_layers)(*self._fanouts)
+        _capi.check(self._lib.gf_sampler_create(
+            C.byref(self._h), graph._h, arr, self._num_layers,
+            _capi.SAMPLING_POLICY[sample_strategy], self._num_snapshots,
+            float(snapshot_time_window), 1 if prop_time else 0, int(seed)))
+        self._is_static = bool(kwargs.get('is_static', False))
+        self._bytes_cache = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.gf_sampler_destroy(h)
+            self._h = None
+
+    # ---- helpers ------------------------------------------------------------------
+    def _to_device(self, target_vertices, timestamps):
+        if isinstance(target_vertices, torch.Tensor):
+            nodes = target_vertices.to(self._device, torch.int64).contiguous()
+        else:
+            nodes = torch.from_numpy(
+                np.ascontiguousarray(target_vertices, dtype=np.int64)).to(self._device)
+        if self._is_static:
+            # gnnflow/temporal_sampler.py:72-76
+            ts = torch.full((nodes.shape[0],), float(np.finfo(np.float32).max),
+                            dtype=torch.float32, device=self._device)
+        elif isinstance(timestamps, torch.Tensor):
+            ts = timestamps.to(self._device, torch.float32).contiguous()
+        else:
+            ts = torch.from_numpy(
+                np.ascontiguousarray(timestamps, dtype=np.float32)).to(self._device)
+        assert nodes.dim() == 1 and ts.shape == nodes.shape, \
+            "target_vertices and timestamps must be 1D and of equal length"
+        return nodes, ts
+
+    def _view(self, buf, base, ptr, count, dtype, itemsize):
+        if count == 0:
+            return torch.empty(0, dtype=dtype, device=self._device)
+        off = ptr - base
+        return buf[off:off + count * itemsize].view(dtype)
+
+    def _block(self, buf, gb) -> MFGBlock:
+        base = buf.data_ptr()
+        ns, ne = gb.num_src_nodes, gb.num_edges
+        if gb.all_nodes is None:
+            raise RuntimeError("sampler returned a null block")
+        b = MFGBlock(ns, gb.num_dst_nodes,
+                     self._view(buf, base, gb.col, ne, torch.int64, 8),
+                     self._view(buf, base, gb.row, ne, torch.int64, 8), keepalive=buf)
+        b.srcdata['ID'] = self._view(buf, base, gb.all_nodes, ns, torch.int64, 8)
+        b.srcdata['ts'] = self._view(buf, base, gb.all_timestamps, ns, torch.float32, 4)
+        b.edata['dt'] = self._view(buf, base, gb.delta_timestamps, ne, torch.float32, 4)
+        b.edata['ID'] = self._view(buf, base, gb.eids, ne, torch.int64, 8)
+        return b
+
+    def _empty_block(self) -> MFGBlock:
+        e64 = torch.empty(0, dtype=torch.int64, device=self._device)
+        e32 = torch.empty(0, dtype=torch.float32, device=self._device)
+        b = MFGBlock(0, 0, e64, e64)
+        b.srcdata['ID'], b.srcdata['ts'] = e64, e32
+        b.edata['dt'], b.edata['ID'] = e32, e64
+        return b
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    # ---- reference API ------------------------------------------------------------
+    def sample(self, target_vertices: np.ndarray, timestamps: np.ndarray) -> List[List[MFGBlock]]:
+        """
+        Sample k-hop neighbors of given vertices.
+
+        Returns:
+            list of message flow graphs (# of graphs = # of snapshots) for each layer;
+            mfgs[0] is the last-sampled (largest) layer, mfgs[-1] the roots' layer
+            (gnnflow/temporal_sampler.py:149-165).
+        """
+        nodes, ts = self._to_device(target_vertices, timestamps)
+        R = int(nodes.shape[0])
+        nblocks = self._num_layers * self._num_snapshots
+        blocks = (_capi.GfBlock * nblocks)()
+        if R == 0:
+            _capi.check(self._lib.gf_sampler_sample(self._h, None, None, 0, None, 0, blocks,
+                                                    self._stream()))
+            mfgs = [[self._empty_block() for _ in range(self._num_snapshots)]
+                    for _ in range(self._num_layers)]
+            return mfgs
+        nbytes = self._bytes_cache.get(R)
+        if nbytes is None:
+            n = C.c_size_t(0)
+            _capi.check(self._lib.gf_sampler_output_bytes(self._h, R, C.byref(n)))
+            nbytes = self._bytes_cache[R] = n.value
+        with torch.cuda.device(self._device):
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self._device)
+            _capi.check(self._lib.gf_sampler_sample(
+                self._h, nodes.data_ptr(), ts.data_ptr(), R, buf.data_ptr(), nbytes, blocks,
+                self._stream()))
+        mfgs = []
+        for layer in range(self._num_layers):
+            mfgs.append([self._block(buf, blocks[layer * self._num_snapshots + s])
+                         for s in range(self._num_snapshots)])
+        mfgs.reverse()
+        return mfgs
+
+    def sample_layer(self, target_vertices: np.ndarray, timestamps: np.ndarray,
+                     layer: int, snapshot: int, to_dgl_block: bool = True) \
+            -> Union[MFGBlock, SamplingResult]:
+        """
+        Sample neighbors of given vertices in a specific layer and snapshot
+        (gnnflow/temporal_sampler.py:124-147).
+        """
+        nodes, ts = self._to_device(target_vertices, timestamps)
+        R = int(nodes.shape[0])
+        gb = _capi.GfBlock()
+        if R == 0:
+            _capi.check(self._lib.gf_sampler_sample_layer(
+                self._h, None, None, 0, int(layer), int(snapshot), None, 0, C.byref(gb),
+                self._stream()))
+            b = self._empty_block()
+        else:
+            n = C.c_size_t(0)
+            _capi.check(self._lib.gf_sampler_layer_output_bytes(self._h, R, int(layer),
+                                                                C.byref(n)))
+            with torch.cuda.device(self._device):
+                buf = torch.empty(n.value, dtype=torch.uint8, device=self._device)
+                _capi.check(self._lib.gf_sampler_sample_layer(
+                    self._h, nodes.data_ptr(), ts.data_ptr(), R, int(layer), int(snapshot),
+                    buf.data_ptr(), n.value, C.byref(gb), self._stream()))
+            b = self._block(buf, gb)
+        return b if to_dgl_block else SamplingResult(b)
+
+    def _sample(self, target_vertices: np.ndarray, timestamps: np.ndarray, sort: bool = False):
+        """benchmarks/benchmark_sampler.py:83 entry point: [layer][snapshot]
+        SamplingResults (not reversed) and the time spent sorting roots."""
+        import time
+        results, sort_time = [], 0.0
+        for layer in range(self._num_layers):
+            layer_results = []
+            for snapshot in range(self._num_snapshots):
+                if layer == 0:
+                    n, t = target_vertices, timestamps
+                else:
+                    prev = results[layer - 1][snapshot].block()
+                    n, t = prev.srcdata['ID'], prev.srcdata['ts']
+                if sort:
+                    s0 = time.time()
+                    if isinstance(n, torch.Tensor):
+                        idx = torch.argsort(n)
+                    else:
+                        idx = np.argsort(n)
+                    n, t = n[idx], t[idx]
+                    sort_time += time.time() - s0
+                layer_results.append(self.sample_layer(n, t, layer, snapshot,
+                                                       to_dgl_block=False))
+            results.append(layer_results)
+        return results, sort_time

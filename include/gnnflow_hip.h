@@ -1,0 +1,213 @@
+/*
+ * gnnflow_hip.h — C ABI of the MI355X-native GNNFlow hot path
+ * (temporal edge store -> TemporalSampler.sample() -> feature gather / LRU cache).
+ *
+ * This is the drop-in boundary: every entry point below replaces one method of
+ * the reference's pybind11 module `libgnnflow` (gnnflow/csrc/api.cc) or one step
+ * of the Python feature cache (gnnflow/cache/cache.py, lru_cache.py).  Signatures
+ * use only plain pointers and sizes — no torch / pybind / STL types — so the same
+ * library binds from ctypes (gnnflow_amd/_capi.py), from pybind11
+ * (gnnflow_amd/csrc/pybind_libgnnflow.cpp builds a module named `libgnnflow` with
+ * the reference's class/method names) or from any other FFI.
+ *
+ * Conventions
+ *   - every function returns GF_OK (0) or a GF_ERR_* code; gf_last_error() gives
+ *     the message for the calling thread (the reference CHECK()/abort()s instead,
+ *     gnnflow/csrc/logging.h:9-46 — an error code is strictly friendlier).
+ *   - "host" pointers are ordinary CPU memory; "device" pointers are HBM
+ *     addresses on the graph's device.  `stream` is a hipStream_t passed as
+ *     void* (NULL = the null stream).
+ *   - node / edge ids are int64, timestamps float32 (gnnflow/csrc/common.h:13-15).
+ *   - not thread-safe per handle (one in-flight call per graph / sampler / cache,
+ *     as in the reference: gnnflow/csrc/temporal_sampler.h:73-80); different
+ *     handles may be used from different threads.  Calls do not hold the GIL.
+ */
+#ifndef GNNFLOW_HIP_H_
+#define GNNFLOW_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF_API __attribute__((visibility("default")))
+
+/* ---- status ----------------------------------------------------------------- */
+enum {
+  GF_OK = 0,
+  GF_ERR_INVALID_ARGUMENT = 1,
+  GF_ERR_TIMESTAMP_ORDER = 2, /* add_edges: edges older than the node's newest edge
+                                 (reference: CHECK_LE at gnnflow/csrc/utils.cu:42-43) */
+  GF_ERR_OUT_OF_MEMORY = 3,   /* maximum_pool_size exceeded / hipMalloc failed */
+  GF_ERR_HIP = 4,             /* a HIP runtime call failed */
+  GF_ERR_IO = 5
+};
+
+/* gnnflow/csrc/api.cc:27-39 enum values, same order */
+enum { GF_INSERTION_POLICY_INSERT = 0, GF_INSERTION_POLICY_REPLACE = 1 };
+enum { GF_SAMPLING_POLICY_RECENT = 0, GF_SAMPLING_POLICY_UNIFORM = 1 };
+enum { GF_MEM_CUDA = 0, GF_MEM_UNIFIED = 1, GF_MEM_PINNED = 2, GF_MEM_SHARED = 3 };
+
+GF_API const char* gf_last_error(void);
+GF_API const char* gf_version(void);
+
+/* ---- DynamicGraph: gnnflow/csrc/api.cc:41-85, dynamic_graph.h:26-170 --------- */
+typedef struct gf_graph gf_graph;
+
+/* _DynamicGraph.__init__ (api.cc:42-47; `minium_block_size` spelling is the
+ * reference's).  All four memory resource types place the edge store in HBM on
+ * `device` (288 GB per MI355X makes the managed / pinned spill modes moot). */
+GF_API int gf_graph_create(gf_graph** out, size_t initial_pool_size,
+                           size_t maximum_pool_size, int mem_resource_type,
+                           size_t minium_block_size, size_t blocks_to_preallocate,
+                           int insertion_policy, int device, int adaptive_block_size);
+GF_API int gf_graph_destroy(gf_graph* g);
+
+/* _DynamicGraph.add_edges (api.cc:48-50 -> DynamicGraph::AddEdges,
+ * dynamic_graph.cu:77-138).  Four host arrays of length n, any order inside the
+ * batch; grouped by source and stable-sorted by timestamp on ingest. */
+GF_API int gf_graph_add_edges(gf_graph* g, const int64_t* src, const int64_t* dst,
+                              const float* ts, const int64_t* eids, size_t n);
+
+/* _DynamicGraph.offload_old_blocks (api.cc:51-52 -> dynamic_graph.cu:382-411):
+ * drops every whole logical block whose end timestamp < `timestamp`;
+ * to_file != 0 also writes temporal_block_<node>-<k>.bin
+ * (temporal_block_allocator.cu:182-221 format). */
+GF_API int gf_graph_offload_old_blocks(gf_graph* g, float timestamp, int to_file,
+                                       size_t* num_blocks);
+
+/* api.cc:53-55,70-71 */
+GF_API int gf_graph_num_vertices(const gf_graph* g, size_t* out);
+GF_API int gf_graph_num_source_vertices(const gf_graph* g, size_t* out);
+GF_API int gf_graph_num_edges(const gf_graph* g, size_t* out);
+GF_API int gf_graph_max_vertex_id(const gf_graph* g, int64_t* out);
+/* api.cc:56-59 out_degree(list) */
+GF_API int gf_graph_out_degree(const gf_graph* g, const int64_t* nodes, size_t n,
+                               size_t* out);
+/* api.cc:60-69 nodes() / src_nodes() / edges(): pass out = NULL to query *count */
+GF_API int gf_graph_nodes(const gf_graph* g, int64_t* out, size_t capacity, size_t* count);
+GF_API int gf_graph_src_nodes(const gf_graph* g, int64_t* out, size_t capacity, size_t* count);
+GF_API int gf_graph_edges(const gf_graph* g, int64_t* out, size_t capacity, size_t* count);
+/* api.cc:72-78 get_temporal_neighbors(node) -> newest first; out arrays may be
+ * NULL to query *count */
+GF_API int gf_graph_get_temporal_neighbors(const gf_graph* g, int64_t node, int64_t* dst,
+                                           float* ts, int64_t* eids, size_t capacity,
+                                           size_t* count);
+/* api.cc:79-85 */
+GF_API int gf_graph_avg_linked_list_length(const gf_graph* g, float* out);
+GF_API int gf_graph_memory_usage(const gf_graph* g, float* out);
+GF_API int gf_graph_metadata_memory_usage(const gf_graph* g, float* out);
+GF_API int gf_graph_device(const gf_graph* g, int* out);
+
+/* ---- TemporalSampler: api.cc:111-120, temporal_sampler.h:19-38 -------------- */
+typedef struct gf_sampler gf_sampler;
+
+/* _TemporalSampler.__init__ (api.cc:112-116).  The sampler keeps a pointer to
+ * the graph: destroy the sampler first (the reference holds `const DynamicGraph&`,
+ * temporal_sampler.h:62). */
+GF_API int gf_sampler_create(gf_sampler** out, gf_graph* g, const uint32_t* fanouts,
+                             size_t num_layers, int sampling_policy,
+                             uint32_t num_snapshots, float snapshot_time_window,
+                             int prop_time, uint64_t seed);
+GF_API int gf_sampler_destroy(gf_sampler* s);
+
+/* One (layer, snapshot) SamplingResult (gnnflow/csrc/common.h:51-60).  Pointers
+ * address the caller's output buffer; counts are valid after the call returns. */
+typedef struct gf_block {
+  int64_t* all_nodes;       /* [num_src_nodes] roots ++ sampled neighbours */
+  float* all_timestamps;    /* [num_src_nodes] */
+  float* delta_timestamps;  /* [num_edges] root ts - edge ts */
+  int64_t* eids;            /* [num_edges] */
+  int64_t* row;             /* [num_edges] root index of each edge (non-decreasing) */
+  int64_t* col;             /* [num_edges] num_dst_nodes .. num_src_nodes-1 */
+  uint64_t num_dst_nodes;   /* R */
+  uint64_t num_src_nodes;   /* R + S */
+  uint64_t num_edges;       /* S */
+} gf_block;
+
+/* Worst-case byte size of the output buffer of gf_sampler_sample for
+ * `num_roots` roots (all layers x snapshots, every slot valid). */
+GF_API int gf_sampler_output_bytes(const gf_sampler* s, size_t num_roots, size_t* bytes);
+
+/* _TemporalSampler.sample (api.cc:117-118 -> TemporalSampler::Sample,
+ * temporal_sampler.cu:279-305), device resident: roots / timestamps and the
+ * output buffer are device pointers; all layers and snapshots are sampled without
+ * leaving HBM (layer l+1 roots = layer l all_nodes / all_timestamps).
+ * blocks: host array [num_layers * num_snapshots], index layer*num_snapshots+snap
+ * (the reference's [layer][snapshot] order, before Python reverses the layers).
+ * Synchronises `stream` once at the end to read the per-block sizes. */
+GF_API int gf_sampler_sample(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
+                             size_t num_roots, void* d_out, size_t out_bytes,
+                             gf_block* blocks, void* stream);
+
+/* _TemporalSampler.sample_layer (api.cc:119-120 -> TemporalSampler::SampleLayer,
+ * temporal_sampler.cu:97-277), device resident; *bytes variant sizes the buffer. */
+GF_API int gf_sampler_layer_output_bytes(const gf_sampler* s, size_t num_roots,
+                                         uint32_t layer, size_t* bytes);
+GF_API int gf_sampler_sample_layer(gf_sampler* s, const int64_t* d_roots,
+                                   const float* d_root_ts, size_t num_roots,
+                                   uint32_t layer, uint32_t snapshot, void* d_out,
+                                   size_t out_bytes, gf_block* block, void* stream);
+
+/* Host-vector forms with the reference's exact calling convention (host arrays
+ * in, freshly allocated host arrays out; api.cc:17-24 copies into numpy the same
+ * way).  Results are released with gf_host_blocks_free. */
+GF_API int gf_sampler_sample_host(gf_sampler* s, const int64_t* nodes, const float* ts,
+                                  size_t num_roots, gf_block* blocks);
+GF_API int gf_sampler_sample_layer_host(gf_sampler* s, const int64_t* nodes,
+                                        const float* ts, size_t num_roots, uint32_t layer,
+                                        uint32_t snapshot, gf_block* block);
+GF_API void gf_host_blocks_free(gf_block* blocks, size_t n);
+
+/* ---- feature gather + LRU cache: gnnflow/cache/cache.py, lru_cache.py -------- */
+typedef struct gf_cache gf_cache;
+
+/* One cache "kind" (node or edge) of Cache.__init__ (cache.py:82-134) +
+ * LRUCache.__init__ (lru_cache.py:56-61): `capacity` rows of `dim` float32 in
+ * HBM, id -> slot map over `num_ids`, slot -> id table, LRU stamps.
+ * d_feats: the full feature table [num_ids, dim] float32 — a device pointer, or
+ * device-accessible pinned host memory (misses are then read over PCIe). */
+GF_API int gf_cache_create(gf_cache** out, size_t num_ids, size_t capacity, size_t dim,
+                           const float* d_feats, int device);
+GF_API int gf_cache_destroy(gf_cache* c);
+/* Cache.init_cache / LRUCache.reset (cache.py:157-195, lru_cache.py:74-105):
+ * slots 0..capacity-1 hold ids 0..capacity-1, LRU state zeroed. */
+GF_API int gf_cache_init(gf_cache* c, void* stream);
+/* Cache.resize (cache.py:197-221) */
+GF_API int gf_cache_resize(gf_cache* c, size_t new_num_ids, size_t new_capacity,
+                           const float* d_feats, void* stream);
+
+/* One block of Cache.fetch_feature (cache.py:255-400): out[i,:] = feats[ids[i],:]
+ * served from the cache on a hit and from d_feats on a miss, then (update != 0
+ * and at least one miss) the LRU replacement of lru_cache.py:121-201.
+ * d_ids [n] int64 device, d_out [n, dim] float32 device.  d_stats (device,
+ * 2 x uint32, may be NULL) receives {hits, n}; no host synchronisation. */
+GF_API int gf_cache_fetch(gf_cache* c, const int64_t* d_ids, size_t n, float* d_out,
+                          int update, uint32_t* d_stats, void* stream);
+
+/* Cache-free gather, gnnflow/utils.py:465-474 prepare_input and
+ * cache.py:411 `edge_feats[eid]`: out[i,:] = feats[ids[i],:]. */
+GF_API int gf_gather_rows(const float* d_feats, size_t num_rows, size_t dim,
+                          const int64_t* d_ids, size_t n, float* d_out, int device,
+                          void* stream);
+
+/* Introspection for tests / get_mem_size (cache.py:136-155): copies the slot ->
+ * id table (int64[capacity], -1 = empty) to a host array. */
+GF_API int gf_cache_slot_ids(const gf_cache* c, int64_t* out, size_t capacity);
+GF_API int gf_cache_mem_bytes(const gf_cache* c, size_t* out);
+
+/* ---- measurement support (bench.py) ---------------------------------------- */
+/* Accumulated device time of the named kernel family since the last reset,
+ * measured with HIP events on the launching stream when profiling is enabled.
+ * which: 0 = sampler search, 1 = sampler emit, 2 = feature gather, 3 = scan,
+ * 4 = LRU update. */
+GF_API int gf_profile_enable(int on);
+GF_API int gf_profile_reset(void);
+GF_API int gf_profile_get(int which, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNFLOW_HIP_H_ */

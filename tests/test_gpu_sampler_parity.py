@@ -1,0 +1,176 @@
+"""GPU parity, part 2: the HIP sampler against the block-walking CPU oracle on seeded
+power-law temporal graphs — every SamplingResult array bit-for-bit (int64 ids,
+float32 timestamps / deltas), for recent and uniform policies, multi-layer,
+multi-snapshot, windows, prop_time, ties, chunked ingestion, offload, duplicate and
+out-of-range roots, and both search-group widths."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+MB = 1 << 20
+
+
+def _graphs(min_block, policy="insert", adaptive=True):
+    import gnnflow_amd
+    from oracle import oracle as O
+    g = gnnflow_amd.DynamicGraph(1 * MB, 1024 * MB, "cuda", min_block, 128, policy,
+                                 adaptive_block_size=adaptive)
+    o = O.OracleGraph(minimum_block_size=min_block, insertion_policy=policy,
+                      adaptive_block_size=adaptive)
+    return g, o
+
+
+def _cmp_blocks(hip_mfgs, ora_mfgs, where):
+    assert len(hip_mfgs) == len(ora_mfgs)
+    for li, (hl, ol) in enumerate(zip(hip_mfgs, ora_mfgs)):
+        assert len(hl) == len(ol)
+        for si, (hb, ob) in enumerate(zip(hl, ol)):
+            w = "{} block[{}][{}]".format(where, li, si)
+            assert hb.num_src_nodes() == ob.num_src_nodes(), w
+            assert hb.num_dst_nodes() == ob.num_dst_nodes(), w
+            for key in ("ID", "ts"):
+                a = hb.srcdata[key].cpu().numpy()
+                assert a.dtype == ob.srcdata[key].dtype, w
+                assert np.array_equal(a, ob.srcdata[key]), w + " srcdata " + key
+            for key in ("dt", "ID"):
+                a = hb.edata[key].cpu().numpy()
+                assert a.dtype == ob.edata[key].dtype, w
+                assert np.array_equal(a.view(np.uint8), ob.edata[key].view(np.uint8)), \
+                    w + " edata " + key
+            assert np.array_equal(hb.edges()[0].cpu().numpy(), ob.edges()[0]), w + " col"
+            assert np.array_equal(hb.edges()[1].cpu().numpy(), ob.edges()[1]), w + " row"
+
+
+CONFIGS = [
+    dict(fanouts=[10], sample_strategy="recent"),
+    dict(fanouts=[10, 10], sample_strategy="recent"),
+    dict(fanouts=[5, 3, 2], sample_strategy="recent"),
+    dict(fanouts=[10, 10], sample_strategy="uniform", seed=99),
+    dict(fanouts=[4, 4], sample_strategy="recent", num_snapshots=3, snapshot_time_window=50.0),
+    dict(fanouts=[4], sample_strategy="uniform", num_snapshots=2, snapshot_time_window=100.0,
+         prop_time=True),
+    dict(fanouts=[7], sample_strategy="recent", snapshot_time_window=30.0),
+    dict(fanouts=[40], sample_strategy="recent", prop_time=True),
+    dict(fanouts=[3, 3], sample_strategy="recent", is_static=True),
+]
+
+
+@pytest.mark.parametrize("group", ["16", "64"])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[str(i) for i in range(len(CONFIGS))])
+def test_random_graph_bit_exact(cfg, group, monkeypatch):
+    import gnnflow_amd
+    from oracle import oracle as O
+    monkeypatch.setenv("GNNFLOW_SEARCH_GROUP", group)
+    N, E = 2000, 60000
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=7, tie_levels=5000)
+    g, o = _graphs(min_block=8)
+    synth.ingest_chunks(g, src, dst, ts, eid, 7000)
+    synth.ingest_chunks(o, src, dst, ts, eid, 7000)
+    hs = gnnflow_amd.TemporalSampler(g, **cfg)
+    os_ = O.OracleSampler(o, **cfg)
+    for it, R in enumerate([1, 63, 600, 1800]):
+        nodes, t = synth.random_roots(N, R, 1000.0, seed=100 + it, extra_ids=[N + 5, N - 1])
+        _cmp_blocks(hs.sample(nodes, t), os_.sample(nodes, t), "R={}".format(R))
+
+
+def test_graph_accessors_match_oracle_add_reverse_and_offload():
+    N, E = 500, 20000
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=3, tie_levels=300)
+    g, o = _graphs(min_block=4)
+    synth.ingest_chunks(g, src, dst, ts, eid, 3000, add_reverse=True)
+    synth.ingest_chunks(o, src, dst, ts, eid, 3000, add_reverse=True)
+
+    def compare():
+        assert g.num_edges() == o.num_edges()
+        assert g.num_vertices() == o.num_vertices()
+        assert g.num_source_vertices() == o.num_source_vertices()
+        assert g.max_vertex_id() == o.max_vertex_id()
+        assert np.array_equal(g.nodes(), o.nodes())
+        assert np.array_equal(g.src_nodes(), o.src_nodes())
+        assert np.array_equal(np.sort(g.edges()), np.sort(o.edges()))
+        ids = np.arange(0, o.max_vertex_id() + 1)
+        assert np.array_equal(g.out_degree(ids), o.out_degree(ids))
+        assert g.avg_linked_list_length() == pytest.approx(o.avg_linked_list_length())
+        assert g.get_graph_memory_usage() == o.get_graph_memory_usage()
+        for v in list(range(0, 40)) + [int(ids[-1])]:
+            for a, b in zip(g.get_temporal_neighbors(v), o.get_temporal_neighbors(v)):
+                assert np.array_equal(a, b), v
+
+    compare()
+    assert g.offload_old_blocks(400.0) == o.offload_old_blocks(400.0)
+    compare()
+    # sampling after offload sees only the surviving blocks
+    import gnnflow_amd
+    from oracle import oracle as O
+    hs = gnnflow_amd.TemporalSampler(g, [6, 6])
+    os_ = O.OracleSampler(o, [6, 6])
+    nodes, t = synth.random_roots(N, 700, 1000.0, seed=11)
+    _cmp_blocks(hs.sample(nodes, t), os_.sample(nodes, t), "after offload")
+    # and ingest continues correctly afterwards
+    src2, dst2, ts2, eid2 = synth.powerlaw_graph(N, 5000, seed=5)
+    ts2 = (ts2 + 1000.0).astype(np.float32)
+    eid2 = eid2 + E
+    g.add_edges(src2, dst2, ts2, eid2)
+    o.add_edges(src2, dst2, ts2, eid2)
+    compare()
+    nodes, t = synth.random_roots(N, 700, 2100.0, seed=12)
+    _cmp_blocks(hs.sample(nodes, t), os_.sample(nodes, t), "after re-ingest")
+
+
+@pytest.mark.parametrize("policy,adaptive", [("replace", True), ("insert", False)])
+def test_block_policies_match_oracle(policy, adaptive):
+    N, E = 300, 8000
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=9)
+    g, o = _graphs(min_block=4, policy=policy, adaptive=adaptive)
+    synth.ingest_chunks(g, src, dst, ts, eid, 500)
+    synth.ingest_chunks(o, src, dst, ts, eid, 500)
+    assert g.avg_linked_list_length() == pytest.approx(o.avg_linked_list_length())
+    assert g.get_graph_memory_usage() == o.get_graph_memory_usage()
+    assert g.offload_old_blocks(500.0) == o.offload_old_blocks(500.0)
+    assert g.num_edges() == o.num_edges()
+
+
+def test_uniform_distribution_chi_square():
+    """Uniform policy is distribution-matched, not bit-matched, to cuRAND: every
+    in-window edge must be equally likely (chi-square over many independent roots)."""
+    import gnnflow_amd
+    n = 16
+    g, _ = _graphs(min_block=4)
+    g.add_edges(np.zeros(n, np.int64), np.arange(1, n + 1), np.arange(n, dtype=np.float32))
+    s = gnnflow_amd.TemporalSampler(g, [8], "uniform", seed=2024)
+    R = 20000
+    b = s.sample(np.zeros(R, np.int64), np.full(R, 12.0, np.float32))[0][0]
+    picked = b.srcdata["ID"][R:].cpu().numpy()
+    assert len(picked) == R * 8
+    counts = np.bincount(picked, minlength=n + 1)[1:13]   # 12 candidates: dst 1..12
+    assert counts.sum() == R * 8
+    expected = R * 8 / 12.0
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    assert chi2 < 40.0, chi2   # 11 dof: P(chi2 > 40) ~ 4e-5
+
+
+def test_sample_layer_result_object_and_debug_sample():
+    """SamplingResult accessor methods (api.cc:87-109) and the benchmark harness's
+    `_sample` entry point (benchmarks/benchmark_sampler.py:83)."""
+    import gnnflow_amd
+    from oracle import oracle as O
+    N, E = 400, 9000
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=21)
+    g, o = _graphs(min_block=16)
+    g.add_edges(src, dst, ts, eid)
+    o.add_edges(src, dst, ts, eid)
+    hs = gnnflow_amd.TemporalSampler(g, [5, 5])
+    os_ = O.OracleSampler(o, [5, 5])
+    nodes, t = synth.random_roots(N, 333, 1000.0, seed=1)
+    res, _ = hs._sample(nodes, t)
+    ref = os_.sample_raw(nodes, t)
+    for l in range(2):
+        r, q = res[l][0], ref[l][0]
+        for name in ("row", "col", "all_nodes", "all_timestamps", "delta_timestamps", "eids"):
+            assert np.array_equal(getattr(r, name)(), getattr(q, name)()), (l, name)
+        assert r.num_src_nodes() == q.num_src_nodes()
+        assert r.num_dst_nodes() == q.num_dst_nodes()
