@@ -1,0 +1,257 @@
+"""gnnflow.cache.Cache on MI355X — the reference's feature-cache protocol
+(gnnflow/cache/cache.py:10-413) over the fused HIP gather (gf_cache_fetch).
+
+Same constructor arguments, attributes read by callers (`cache_node_ratio`,
+`cache_edge_ratio`, `target_edge_features`, `name`) and methods (`init_cache`, `reset`,
+`fetch_feature`, `get_mem_size`, `resize`).  Differences, all internal:
+  * the per-block torch op chains + host round trip for misses are one kernel per block;
+  * the feature tables must be device-readable: they are placed in HBM when they fit
+    (`feature_placement="device"`, the default on a 288 GB MI355X) or kept in pinned
+    host memory that the gather kernel reads directly over PCIe (`"pinned"`);
+  * hit ratios are accumulated on the device and only synchronised when read.
+"""
+import ctypes as C
+import os
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from .. import _capi
+
+
+class _Kind:
+    """One cache kind (node or edge): C handle + the device-readable feature table."""
+
+    def __init__(self, lib, num_ids, capacity, feats: torch.Tensor, dim, device, placement):
+        self.lib = lib
+        self.num_ids, self.capacity, self.dim = int(num_ids), int(capacity), int(dim)
+        self.device = device
+        feats = feats.detach()
+        if feats.dtype != torch.float32:
+            feats = feats.to(torch.float32)       # cache.py:71-74 (bool -> float32)
+        assert feats.dim() == 2 and feats.shape[1] == self.dim, \
+            "feature table must be [num_ids, dim]"
+        if placement == "pinned":
+            feats = feats.contiguous()
+            self.table = feats if feats.is_pinned() else feats.pin_memory()
+        else:
+            self.table = feats.to(device).contiguous()
+        self.h = C.c_void_p()
+        _capi.check(lib.gf_cache_create(C.byref(self.h), self.num_ids, self.capacity,
+                                        self.dim, self.table.data_ptr(), device.index))
+
+    def close(self):
+        if self.h is not None and self.h.value:
+            self.lib.gf_cache_destroy(self.h)
+            self.h = None
+
+    def init(self, stream):
+        _capi.check(self.lib.gf_cache_init(self.h, stream))
+
+    def fetch(self, ids: torch.Tensor, update: bool, stats_ptr, stream) -> torch.Tensor:
+        n = int(ids.shape[0])
+        out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        if n:
+            _capi.check(self.lib.gf_cache_fetch(self.h, ids.data_ptr(), n, out.data_ptr(),
+                                                1 if update else 0, stats_ptr, stream))
+        return out
+
+    def gather(self, ids: torch.Tensor, stream) -> torch.Tensor:
+        n = int(ids.shape[0])
+        out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        if n:
+            _capi.check(self.lib.gf_gather_rows(self.table.data_ptr(), self.num_ids, self.dim,
+                                                ids.data_ptr(), n, out.data_ptr(),
+                                                self.device.index, stream))
+        return out
+
+    def mem_bytes(self) -> int:
+        n = C.c_size_t(0)
+        _capi.check(self.lib.gf_cache_mem_bytes(self.h, C.byref(n)))
+        return n.value
+
+    def slot_ids(self) -> np.ndarray:
+        out = np.zeros(self.capacity, np.int64)
+        if self.capacity:
+            _capi.check(self.lib.gf_cache_slot_ids(self.h, out.ctypes.data, self.capacity))
+        return out
+
+
+class Cache:
+    """
+    Feature cache on GPU
+    """
+
+    def __init__(self, edge_cache_ratio: int, node_cache_ratio: int,
+                 num_nodes: int, num_edges: int,
+                 device: Union[str, torch.device],
+                 node_feats: Optional[torch.Tensor] = None,
+                 edge_feats: Optional[torch.Tensor] = None,
+                 dim_node_feat: Optional[int] = 0,
+                 dim_edge_feat: Optional[int] = 0,
+                 pinned_nfeat_buffs: Optional[torch.Tensor] = None,
+                 pinned_efeat_buffs: Optional[torch.Tensor] = None,
+                 kvstore_client=None,
+                 distributed: Optional[bool] = False,
+                 neg_sample_ratio: Optional[int] = 1,
+                 feature_placement: Optional[str] = None):
+        if device == 'cpu' or device == torch.device('cpu'):
+            raise ValueError('Cache must be on GPU')
+        if distributed:
+            raise NotImplementedError(
+                'the multi-machine KVStore feature path is out of scope of gnnflow_amd '
+                '(single node: features are sharded / replicated in HBM)')
+        if node_feats is None and edge_feats is None:
+            raise ValueError('At least one of node_feats and edge_feats must be provided')
+        if node_feats is not None and node_feats.shape[0] != num_nodes:
+            raise ValueError(
+                'The number of nodes in node_feats {} does not match num_nodes {}'.format(
+                    node_feats.shape[0], num_nodes))
+        if edge_feats is not None and edge_feats.shape[0] != num_edges:
+            raise ValueError(
+                'The number of edges in edge_feats {} does not match num_edges {}'.format(
+                    edge_feats.shape[0], num_edges))
+        assert 0 <= edge_cache_ratio <= 1, 'edge_cache_ratio must be in [0, 1]'
+        assert 0 <= node_cache_ratio <= 1, 'node_cache_ratio must be in [0, 1]'
+
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise ValueError('Cache must be on GPU')
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        placement = (feature_placement or
+                     os.environ.get('GNNFLOW_FEATURE_PLACEMENT', 'device')).lower()
+        if placement not in ('device', 'pinned'):
+            raise ValueError("feature_placement must be 'device' or 'pinned'")
+
+        self.edge_cache_ratio = edge_cache_ratio
+        self.node_cache_ratio = node_cache_ratio
+        self.node_capacity = int(node_cache_ratio * num_nodes)   # cache.py:82
+        self.edge_capacity = int(edge_cache_ratio * num_edges)   # cache.py:83
+        self.num_nodes, self.num_edges = num_nodes, num_edges
+        self.node_feats, self.edge_feats = node_feats, edge_feats
+        self.dim_node_feat = dim_node_feat if node_feats is not None else 0
+        self.dim_edge_feat = dim_edge_feat if edge_feats is not None else 0
+        self.device = device
+        self.pinned_nfeat_buffs = pinned_nfeat_buffs   # accepted, unused: misses never
+        self.pinned_efeat_buffs = pinned_efeat_buffs   # stage through the host here
+        self.kvstore_client = kvstore_client
+        self.distributed = False
+        self.neg_sample_ratio = neg_sample_ratio
+        self.target_edge_features = None
+        self.feature_placement = placement
+
+        self._lib = _capi.load()
+        self._node = self._edge = None
+        with torch.cuda.device(device):
+            if self.dim_node_feat != 0:
+                self._node = _Kind(self._lib, num_nodes, self.node_capacity, node_feats,
+                                   self.dim_node_feat, device, placement)
+            if self.dim_edge_feat != 0:
+                self._edge = _Kind(self._lib, num_edges, self.edge_capacity, edge_feats,
+                                   self.dim_edge_feat, device, placement)
+        self._node_stats = self._edge_stats = None
+
+    def __del__(self):
+        for k in (getattr(self, "_node", None), getattr(self, "_edge", None)):
+            if k is not None:
+                k.close()
+
+    # ---- hit ratios: mean over blocks of hits/len (cache.py:277,323,337,400) ---------
+    @staticmethod
+    def _ratio(stats):
+        if stats is None or stats.shape[0] == 0:
+            return 0
+        s = stats.to(torch.float32)
+        return (s[:, 0] / s[:, 1]).mean()
+
+    @property
+    def cache_node_ratio(self):
+        return self._ratio(self._node_stats)
+
+    @property
+    def cache_edge_ratio(self):
+        return self._ratio(self._edge_stats)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def get_mem_size(self) -> int:
+        """Memory size of the cache in bytes (cache.py:136-155)."""
+        return sum(k.mem_bytes() for k in (self._node, self._edge) if k is not None)
+
+    def init_cache(self, *args, **kwargs):
+        """Fill the cache with the first `capacity` rows (cache.py:157-195)."""
+        with torch.cuda.device(self.device):
+            for k in (self._node, self._edge):
+                if k is not None:
+                    k.init(self._stream())
+
+    def resize(self, new_num_nodes: int, new_num_edges: int):
+        """Grow the id spaces (cache.py:197-221).  The caller must have replaced
+        `node_feats` / `edge_feats` with tables covering the new ids."""
+        with torch.cuda.device(self.device):
+            if self._node is not None and new_num_nodes > self.num_nodes:
+                self._regrow("_node", self.node_feats, new_num_nodes,
+                             int(self.node_cache_ratio * new_num_nodes), self.dim_node_feat)
+                self.num_nodes = new_num_nodes
+                self.node_capacity = self._node.capacity
+            if self._edge is not None and new_num_edges > self.num_edges:
+                self._regrow("_edge", self.edge_feats, new_num_edges,
+                             int(self.edge_cache_ratio * new_num_edges), self.dim_edge_feat)
+                self.num_edges = new_num_edges
+                self.edge_capacity = self._edge.capacity
+
+    def _regrow(self, attr, feats, num_ids, capacity, dim):
+        kind = getattr(self, attr)
+        if feats is None or feats.shape[0] < num_ids:
+            raise ValueError("resize: feature table does not cover the new ids")
+        f = feats.detach()
+        if f.dtype != torch.float32:
+            f = f.to(torch.float32)
+        if self.feature_placement == "pinned":
+            f = f.contiguous()
+            table = f if f.is_pinned() else f.pin_memory()
+        else:
+            table = f.to(self.device).contiguous()
+        _capi.check(self._lib.gf_cache_resize(kind.h, num_ids, max(capacity, kind.capacity),
+                                              table.data_ptr(), self._stream()))
+        kind.table = table
+        kind.num_ids, kind.capacity = num_ids, max(capacity, kind.capacity)
+
+    def reset(self):
+        raise NotImplementedError
+
+    def _ids(self, t) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor):
+            t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.int64))
+        return t.to(self.device, torch.int64).contiguous()
+
+    def fetch_feature(self, mfgs: List[List], eid: Optional[np.ndarray] = None,
+                      update_cache: bool = True, target_edge_features: bool = True):
+        """Fetching the node/edge features of input_node_ids (cache.py:255-413):
+        node features for the blocks of mfgs[0] -> srcdata['h'], edge features for every
+        block -> edata['f'], target edge features for TGN memory."""
+        with torch.cuda.device(self.device):
+            stream = self._stream()
+            if self._node is not None:
+                blocks = list(mfgs[0])
+                stats = torch.zeros((len(blocks), 2), dtype=torch.int32, device=self.device)
+                for i, b in enumerate(blocks):
+                    ids = self._ids(b.srcdata['ID'])
+                    b.srcdata['h'] = self._node.fetch(
+                        ids, update_cache, stats[i].data_ptr() if len(ids) else None, stream)
+                self._node_stats = stats
+            if self._edge is not None:
+                blocks = [b for mfg in mfgs for b in mfg if len(b.edata['ID']) > 0]
+                stats = torch.zeros((len(blocks), 2), dtype=torch.int32, device=self.device)
+                for i, b in enumerate(blocks):
+                    ids = self._ids(b.edata['ID'])
+                    b.edata['f'] = self._edge.fetch(ids, update_cache, stats[i].data_ptr(),
+                                                    stream)
+                self._edge_stats = stats
+                if target_edge_features and eid is not None:
+                    # cache.py:411 `self.edge_feats[eid]`
+                    self.target_edge_features = self._edge.gather(self._ids(eid), stream)
+        return mfgs

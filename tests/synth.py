@@ -28,7 +28,8 @@ def ingest_chunks(graph, src, dst, ts, eid, chunk, add_reverse=False):
 def random_roots(num_nodes, n, t_max, seed, extra_ids=()):
     rng = np.random.RandomState(seed)
     nodes = rng.randint(0, num_nodes, size=n).astype(np.int64)
-    if len(extra_ids):
-        nodes[:len(extra_ids)] = np.asarray(extra_ids, dtype=np.int64)
+    k = min(len(extra_ids), n)
+    if k:
+        nodes[:k] = np.asarray(extra_ids, dtype=np.int64)[:k]
     ts = rng.uniform(0, t_max * 1.1, size=n).astype(np.float32)
     return nodes, ts
