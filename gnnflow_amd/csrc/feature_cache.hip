@@ -59,8 +59,10 @@ struct Workspace {
   uint32_t* rep_flag;   // [n]  1 = first row of a distinct missed id
   uint32_t* rep_rank;   // [n]  exclusive scan of rep_flag
   uint32_t* rep_row;    // [n]  rank -> row
-  uint32_t* tile_cnt;   // [tiles]
-  uint32_t* tile_base;  // [tiles]
+  uint32_t* tile_tie;   // [tiles] slots at the threshold age
+  uint32_t* tile_old;   // [tiles] slots older than the threshold
+  uint32_t* tie_base;   // [tiles] exclusive scans of the two
+  uint32_t* old_base;   // [tiles]
   uint2* pairs;         // [n]  ticket -> {slot, row}
 };
 
@@ -110,21 +112,27 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(
     const uint64_t src_bits = reinterpret_cast<uint64_t>(src);
     const uint32_t total = rows * dimv;
     VecT* o = out + static_cast<uint64_t>(row0) * dimv;
-    auto load = [&](uint32_t fu) -> VecT {
-      const uint32_t r = fu / dimv, c = fu - r * dimv;
+    // The loop trip count is wave-uniform and every lane executes the cross-lane read:
+    // ds_bpermute returns 0 for a source lane that EXEC has switched off, so the
+    // row-base broadcast must never sit under a per-lane condition.
+    auto load = [&](uint32_t fu, bool* valid) -> VecT {
+      *valid = fu < total;
+      const uint32_t r = *valid ? fu / dimv : 0u;
+      const uint32_t c = fu - r * dimv;
       const VecT* s = reinterpret_cast<const VecT*>(__shfl(src_bits, r, 64));
-      return s ? s[c] : vec_zero<VecT>();
+      return (*valid && s) ? s[c] : vec_zero<VecT>();
     };
-    uint32_t f = lane;
     // 4 independent 16-byte loads in flight per lane
-    for (; f + 192 < total; f += 256) {
-      const VecT v0 = load(f), v1 = load(f + 64), v2 = load(f + 128), v3 = load(f + 192);
-      o[f] = v0;
-      o[f + 64] = v1;
-      o[f + 128] = v2;
-      o[f + 192] = v3;
+    for (uint32_t base = 0; base < total; base += 256) {
+      const uint32_t f = base + lane;
+      bool p0, p1, p2, p3;
+      const VecT v0 = load(f, &p0), v1 = load(f + 64, &p1), v2 = load(f + 128, &p2),
+                 v3 = load(f + 192, &p3);
+      if (p0) o[f] = v0;
+      if (p1) o[f + 64] = v1;
+      if (p2) o[f + 128] = v2;
+      if (p3) o[f + 192] = v3;
     }
-    for (; f < total; f += 64) o[f] = load(f);
   }
   if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], n);
 }
@@ -164,14 +172,18 @@ __global__ void lru_mark_kernel(const int64_t* __restrict__ ids, uint32_t n,
 // single-workgroup chained exclusive scan (n up to a few million)
 __global__ __launch_bounds__(kScanThreads) void scan_u32_kernel(
     const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
-    uint32_t* __restrict__ total_out, const Counters* __restrict__ ctr) {
+    uint32_t* __restrict__ total_out, const uint32_t* __restrict__ in2,
+    uint32_t* __restrict__ out2, const Counters* __restrict__ ctr) {
   if (ctr->n_miss == 0) return;
   __shared__ uint32_t wave_sums[kScanThreads / 64];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr uint32_t kItems = 4;
+  for (int pass = 0; pass < (in2 ? 2 : 1); ++pass) {
+  if (pass == 1) { in = in2; out = out2; total_out = nullptr; }
+  __syncthreads();
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  constexpr uint32_t kItems = 4;
   for (uint32_t tile = 0; tile < n; tile += kScanThreads * kItems) {
     uint32_t v[kItems], local = 0;
     const uint32_t i0 = tile + tid * kItems;
@@ -201,6 +213,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_u32_kernel(
     __syncthreads();
   }
   if (tid == 0 && total_out) *total_out = carry_s;
+  }
 }
 
 __device__ inline uint32_t slot_age(uint32_t epoch_new, uint32_t stamp) {
@@ -318,42 +331,56 @@ __device__ inline Threshold find_threshold(const uint32_t* hist_hi, const uint32
   return t;
 }
 
-// per tile of kTile slots: how many sit exactly at the threshold age
+// per tile of kTile slots: how many sit exactly at the threshold age, and how many are
+// older than it (all of those are evicted)
 __global__ __launch_bounds__(kThreads) void lru_tie_count_kernel(
     const uint32_t* __restrict__ stamp, uint32_t capacity, const uint32_t* __restrict__ epoch,
     const uint32_t* __restrict__ hist_hi, const uint32_t* __restrict__ hist_lo,
-    uint32_t* __restrict__ tile_cnt, const Counters* __restrict__ ctr) {
+    uint32_t* __restrict__ tile_tie, uint32_t* __restrict__ tile_old,
+    const Counters* __restrict__ ctr) {
   if (ctr->n_miss == 0) return;
-  __shared__ uint32_t cnt;
+  __shared__ uint32_t cnt[2];
   const uint32_t k = min(ctr->n_unique, capacity);
   const Threshold th = find_threshold(hist_hi, hist_lo, k);
   const uint32_t epoch_new = *epoch + 1;
   const uint32_t tiles = (capacity + kTile - 1) / kTile;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    if (threadIdx.x == 0) cnt = 0;
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t c = 0;
+    uint32_t c = 0, o = 0;
     for (uint32_t s = tile * kTile + threadIdx.x; s < min(capacity, (tile + 1) * kTile);
-         s += kThreads)
-      c += slot_age(epoch_new, stamp[s]) == th.age;
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt, c);
+         s += kThreads) {
+      const uint32_t a = slot_age(epoch_new, stamp[s]);
+      c += a == th.age;
+      o += a > th.age;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+      c += __shfl_down(c, d, 64);
+      o += __shfl_down(o, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (c) atomicAdd(&cnt[0], c);
+      if (o) atomicAdd(&cnt[1], o);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) tile_cnt[tile] = cnt;
+    if (threadIdx.x == 0) { tile_tie[tile] = cnt[0]; tile_old[tile] = cnt[1]; }
     __syncthreads();
   }
 }
 
-// evict + install: slots older than the threshold, plus the first k_tie slots (in slot
-// order) exactly at it (lru_cache.py:141-160 with a deterministic tie rule)
+// evict + install: every slot older than the threshold plus the first k_tie slots (in
+// slot order) exactly at it (lru_cache.py:141-160 with a deterministic tie rule).  The
+// i-th evicted slot in slot order receives the i-th distinct missed id in block order,
+// so the whole update is deterministic (no atomics).
 __global__ __launch_bounds__(kTile) void lru_install_kernel(
     const int64_t* __restrict__ ids, const uint32_t* __restrict__ rep_row, int32_t* map,
     int64_t* __restrict__ slot_id, uint32_t* __restrict__ stamp, uint32_t capacity,
     const uint32_t* __restrict__ epoch, const uint32_t* __restrict__ hist_hi,
-    const uint32_t* __restrict__ hist_lo, const uint32_t* __restrict__ tile_base,
-    uint2* __restrict__ pairs, Counters* ctr) {
+    const uint32_t* __restrict__ hist_lo, const uint32_t* __restrict__ tie_base,
+    const uint32_t* __restrict__ old_base, uint2* __restrict__ pairs, Counters* ctr) {
   if (ctr->n_miss == 0) return;
-  __shared__ uint32_t wave_cnt[kTile / 64];
+  __shared__ uint32_t wave_tie[kTile / 64];
+  __shared__ uint32_t wave_old[kTile / 64];
   const uint32_t k = min(ctr->n_unique, capacity);
   const Threshold th = find_threshold(hist_hi, hist_lo, k);
   const uint32_t epoch_new = *epoch + 1;
@@ -364,16 +391,17 @@ __global__ __launch_bounds__(kTile) void lru_install_kernel(
     const bool in = s < capacity;
     const uint32_t a = in ? slot_age(epoch_new, stamp[s]) : 0u;
     const bool tie = in && a == th.age;
-    // rank of this tie inside the tile, in slot order
-    const unsigned long long m = __ballot(tie);
-    const uint32_t before_in_wave = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    const bool older = in && a > th.age;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long mt = __ballot(tie), mo = __ballot(older);
+    if (lane == 0) { wave_tie[wave] = __popcll(mt); wave_old[wave] = __popcll(mo); }
     __syncthreads();
-    uint32_t before = tile_base[tile] + before_in_wave;
-    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-    const bool evict = in && k > 0 && (a > th.age || (tie && before < th.k_tie));
+    uint32_t ties_before = tie_base[tile] + __popcll(mt & below);
+    uint32_t old_before = old_base[tile] + __popcll(mo & below);
+    for (int w = 0; w < wave; ++w) { ties_before += wave_tie[w]; old_before += wave_old[w]; }
+    const bool evict = k > 0 && (older || (tie && ties_before < th.k_tie));
     if (evict) {
-      const uint32_t v = atomicAdd(&ctr->victim_ctr, 1u);
+      const uint32_t v = old_before + min(ties_before, th.k_tie);  // rank in slot order
       if (v < k) {
         const uint32_t row = rep_row[v];
         const int64_t nid = ids[row];
@@ -550,7 +578,7 @@ void FeatureCache::reserve_workspace(size_t n) {
   const size_t tiles = (capacity_ + kTile - 1) / kTile + 1;
   size_t bytes = align_up(sizeof(Counters), 16) + 2 * kBins * sizeof(uint32_t) +
                  4 * align_up(ws_rows_ * 4, 16) + align_up(ws_rows_ * 8, 16) +
-                 2 * align_up(tiles * 4, 16) + 64;
+                 4 * align_up(tiles * 4, 16) + 64;
   ws_.reserve(bytes, 0, nullptr);
 }
 
@@ -573,8 +601,10 @@ void FeatureCache::fetch(const int64_t* d_ids, size_t n, float* d_out, bool upda
   w.rep_rank = reinterpret_cast<uint32_t*>(p);      p += align_up(ws_rows_ * 4, 16);
   w.rep_row = reinterpret_cast<uint32_t*>(p);       p += align_up(ws_rows_ * 4, 16);
   w.pairs = reinterpret_cast<uint2*>(p);            p += align_up(ws_rows_ * 8, 16);
-  w.tile_cnt = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
-  w.tile_base = reinterpret_cast<uint32_t*>(p);
+  w.tile_tie = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
+  w.tile_old = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
+  w.tie_base = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
+  w.old_base = reinterpret_cast<uint32_t*>(p);
 
   GF_HIP(hipMemsetAsync(ws_.data(), 0, zero_bytes, stream));
   launch_gather(d_ids, n, capacity_ ? map_.as<int32_t>() : nullptr, buffer_.as<float>(), feats_,
@@ -593,20 +623,21 @@ void FeatureCache::fetch(const int64_t* d_ids, size_t n, float* d_out, bool upda
   lru_mark_kernel<<<dim3(row_grid), dim3(kThreads), 0, stream>>>(
       d_ids, n32, w.slot_of_row, map_.as<int32_t>(), stamp_.as<uint32_t>(), epoch, w.rep_flag,
       w.ctr);
-  scan_u32_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(w.rep_flag, w.rep_rank, n32,
-                                                              &w.ctr->n_unique, w.ctr);
+  scan_u32_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
+      w.rep_flag, w.rep_rank, n32, &w.ctr->n_unique, nullptr, nullptr, w.ctr);
   lru_rank_hist_kernel<<<dim3(slot_grid), dim3(kThreads), 0, stream>>>(
       d_ids, n32, w.rep_flag, w.rep_rank, w.rep_row, map_.as<int32_t>(), stamp_.as<uint32_t>(),
       cap32, epoch, w.hist_hi, w.ctr);
   lru_hist_lo_kernel<<<dim3(slot_grid), dim3(kThreads), 0, stream>>>(
       stamp_.as<uint32_t>(), cap32, epoch, w.hist_hi, w.hist_lo, w.ctr);
   lru_tie_count_kernel<<<dim3(tile_grid), dim3(kThreads), 0, stream>>>(
-      stamp_.as<uint32_t>(), cap32, epoch, w.hist_hi, w.hist_lo, w.tile_cnt, w.ctr);
+      stamp_.as<uint32_t>(), cap32, epoch, w.hist_hi, w.hist_lo, w.tile_tie, w.tile_old, w.ctr);
   scan_u32_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
-      w.tile_cnt, w.tile_base, static_cast<uint32_t>(tiles), nullptr, w.ctr);
+      w.tile_tie, w.tie_base, static_cast<uint32_t>(tiles), nullptr, w.tile_old, w.old_base,
+      w.ctr);
   lru_install_kernel<<<dim3(tile_grid), dim3(kTile), 0, stream>>>(
       d_ids, w.rep_row, map_.as<int32_t>(), slot_id_.as<int64_t>(), stamp_.as<uint32_t>(), cap32,
-      epoch, w.hist_hi, w.hist_lo, w.tile_base, w.pairs, w.ctr);
+      epoch, w.hist_hi, w.hist_lo, w.tie_base, w.old_base, w.pairs, w.ctr);
   const unsigned copy_grid = static_cast<unsigned>(
       std::max<size_t>(1, std::min<size_t>((std::min(n, capacity_) + 3) / 4, 4096)));
   if (vec4_ok(dim_, buffer_.data(), d_out, d_out)) {

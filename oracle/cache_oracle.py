@@ -11,7 +11,8 @@ fetched features bit-exact, hit ratios exact wherever the reference's `torch.top
 tie to break.  Two places where the reference is under-specified are made deterministic
 here and in the HIP path the same way:
   * eviction ties (equal `count`): lowest slot index first (torch.topk's tie order is
-    unspecified and differs between its CPU and CUDA kernels);
+    unspecified and differs between its CPU and CUDA kernels), and the evicted slots
+    receive the new ids in slot order;
   * overflow_rule: when a block has more distinct missed ids than the cache has slots,
     the reference keeps the `capacity` smallest ids (an artefact of torch.unique
     sorting); "first_seen" keeps the first `capacity` distinct missed ids in block order,
@@ -72,8 +73,10 @@ class LRUKind:
         ids_to_cache = uncached_ids[:k]
         self.count -= 1
         self.count[cached_index] = 0
-        # topk(k, largest=False) with ties -> lowest slot index
-        removing = np.argsort(self.count, kind="stable")[:k]
+        # topk(k, largest=False) with ties -> lowest slot index; the evicted slots are
+        # refilled in slot order (the reference pairs ids with topk's output order,
+        # which only matters through later ties)
+        removing = np.sort(np.argsort(self.count, kind="stable")[:k])
         removing_ids = self.index_to_id[removing]
         self.buffer[removing] = self.feats[ids_to_cache]
         self.count[removing] = 0
