@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""
+bench.py — sampled edges/s of the GNNFlow hot path on MI355X.
+
+One step = one pass of the hot path over one batch of the REDDIT-shaped synthetic
+stream: TemporalSampler.sample() (2 layers, fanout [10,10], most-recent, 1800 roots =
+[src || dst || random] of a 600-edge batch) followed by LRUCache.fetch_feature()
+(edge + node cache ratio 0.2, 172-d features) — BASELINE.json configs[1].  Inputs
+(roots, timestamps, feature tables, graph) are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline":     feature-gather kernel, algorithmic bytes / HIP-event time vs 8 TB/s
+  "cpu_baseline": the CPU oracle (C port of the reference algorithm) timed on this
+                  host on a bounded sample of the same batches (rank 0, N=1 only).
+Multi-GPU: every rank holds a replica of the (13 MB) graph and feature tables and
+replays its own interleaved share of the batches — data parallel, no data-path
+collective, "scaling": "weak" (DESIGN.md "Multi-GPU"; the hash-partitioned
+all-to-all path for graphs that do not fit one GPU is gnnflow_amd.dist).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1121)   # one full chronological replay
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch-size", type=int, default=600)
+    ap.add_argument("--fanouts", type=str, default="10,10")
+    ap.add_argument("--strategy", type=str, default="recent")
+    ap.add_argument("--cache-ratio", type=float, default=0.2)
+    ap.add_argument("--undirected", action="store_true",
+                    help="add reverse edges (the reference's REDDIT config is directed)")
+    ap.add_argument("--feature-placement", default="device", choices=["device", "pinned"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sample-only", action="store_true",
+                    help="time sample() alone (no feature gather)")
+    ap.add_argument("--breakdown", action="store_true",
+                    help="extra untimed pass with per-kernel-family HIP-event times")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_gather(mfgs, d_e, d_n):
+    """sum_blocks E_b*(8 + 2*4*d_e) + N_src(mfgs[0])*(8 + 2*4*d_n)."""
+    b = 0
+    for mfg in mfgs:
+        for blk in mfg:
+            b += blk.num_edges() * (8 + 8 * d_e)
+    for blk in mfgs[0]:
+        b += blk.num_src_nodes() * (8 + 8 * d_n)
+    return b
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, "--gpus must match the launched world size"
+
+    import gnnflow_amd
+    from gnnflow_amd import _capi, synthetic
+    from gnnflow_amd.cache import LRUCache
+
+    lib = _capi.load()
+    fanouts = [int(x) for x in args.fanouts.split(",")]
+    g = synthetic.reddit_like(seed=42)
+    d_e, d_n = synthetic.REDDIT["dim_edge"], synthetic.REDDIT["dim_node"]
+    MiB = 1 << 20
+    # gnnflow/config.py:121-131 _reddit_default_config
+    graph = gnnflow_amd.DynamicGraph(20 * MiB, 1000 * MiB, "cuda", 62, 1024, "insert",
+                                     device=local_rank)
+    t0 = time.time()
+    for lo in range(0, g["num_edges"], 100000):   # benchmark_sampler.py:56-63
+        hi = lo + 100000
+        graph.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
+                        add_reverse=args.undirected)
+    build_s = time.time() - t0
+    sampler = gnnflow_amd.TemporalSampler(graph, fanouts, args.strategy, seed=1234)
+
+    gen = torch.Generator(device=dev).manual_seed(42)
+    edge_feats = torch.rand((g["num_edges"], d_e), generator=gen, device=dev)
+    node_feats = torch.rand((g["num_nodes"], d_n), generator=gen, device=dev)
+    cache = None
+    if not args.sample_only:
+        cache = LRUCache(args.cache_ratio, args.cache_ratio, g["num_nodes"], g["num_edges"],
+                         dev, node_feats, edge_feats, d_n, d_e,
+                         feature_placement=args.feature_placement)
+        cache.init_cache()
+
+    # this rank's share of the chronological replay, resident in HBM
+    batches = list(synthetic.replay_batches(g, args.batch_size, seed=42))
+    mine = batches[rank::world] if world > 1 else batches
+    need = args.steps + args.warmup
+    dev_batches = []
+    for i in range(min(need, len(mine))):
+        r, t, e = mine[i]
+        dev_batches.append((torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev),
+                            torch.from_numpy(e).to(dev)))
+
+    def step(i):
+        r, t, e = dev_batches[i % len(dev_batches)]
+        mfgs = sampler.sample(r, t)
+        if cache is not None:
+            cache.fetch_feature(mfgs, e)
+        return mfgs
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    # the timed region replays from the first batch again: LRU state starts from reset
+    if cache is not None:
+        cache.init_cache()
+    lib.gf_profile_reset()
+    lib.gf_profile_enable(1 << _capi.PROFILE_SLOTS["gather"])   # HIP events on the gather
+    barrier()
+    t0 = time.perf_counter()
+    edges = 0
+    gather_bytes = 0
+    for i in range(args.steps):
+        mfgs = step(i)
+        for mfg in mfgs:
+            for b in mfg:
+                edges += b.num_edges()
+        if cache is not None:
+            gather_bytes += algorithmic_bytes_gather(mfgs, d_e, d_n)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.gf_profile_enable(0)
+
+    import ctypes as C
+    g_ms, g_n = C.c_double(0), C.c_uint64(0)
+    lib.gf_profile_get(_capi.PROFILE_SLOTS["gather"], C.byref(g_ms), C.byref(g_n))
+
+    stats = torch.tensor([elapsed, float(edges)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        esum = stats[1:2].clone()
+        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+        elapsed_max, edges_all = float(tmax), float(esum)
+    else:
+        elapsed_max, edges_all = elapsed, float(edges)
+
+    out = {
+        "metric": "sampled_edges_per_s",
+        "value": edges_all / elapsed_max,
+        "unit": "edges/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed_max / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int64/f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "REDDIT-shaped synthetic (10984 nodes, 672447 edges, directed), "
+                        "2-layer fanout [{}] {} sampling, batch {} (1800 roots), "
+                        "LRUCache ratio {} + 172-d edge/node feature gather; "
+                        "step = sample() + fetch_feature()".format(
+                            args.fanouts, args.strategy, args.batch_size, args.cache_ratio)
+            if cache is not None else
+            "REDDIT-shaped synthetic, 2-layer fanout [{}] {} sampling, batch {}; "
+            "step = sample() only".format(args.fanouts, args.strategy, args.batch_size),
+            "batch_size": args.batch_size,
+            "roots_per_step": 3 * args.batch_size,
+            "edges_per_step": edges / max(args.steps, 1),
+            "feature_placement": args.feature_placement,
+            "graph_build_s": round(build_s, 3),
+            "parallelism": "replica-dp{}".format(world),
+        },
+    }
+    if cache is not None and g_n.value:
+        # dominant kernel by bytes: the fused feature gather (one launch per block)
+        achieved = gather_bytes / (g_ms.value * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "gather_rows_kernel<float4>",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "launches": int(g_n.value),
+            "avg_launch_us": 1e3 * g_ms.value / g_n.value,
+            "algorithmic_bytes_per_launch": gather_bytes / g_n.value,
+        }
+        out["cache_edge_ratio"] = float(cache.cache_edge_ratio)
+        out["cache_node_ratio"] = float(cache.cache_node_ratio)
+
+    if args.breakdown and rank == 0:
+        lib.gf_profile_reset()
+        lib.gf_profile_enable(0x1F)
+        for i in range(min(args.steps, 200)):
+            step(i)
+        torch.cuda.synchronize()
+        lib.gf_profile_enable(0)
+        bd = {}
+        for name, slot in _capi.PROFILE_SLOTS.items():
+            ms, n = C.c_double(0), C.c_uint64(0)
+            lib.gf_profile_get(slot, C.byref(ms), C.byref(n))
+            bd[name] = {"total_ms": ms.value, "intervals": int(n.value)}
+        out["kernel_breakdown_200_steps"] = bd
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(g, batches, fanouts, args, edge_feats.cpu().numpy(),
+                                           node_feats.cpu().numpy(), cache is not None)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather):
+    """The CPU oracle (oracle/gnnflow_oracle.c: single-threaded C port of the reference's
+    block-walking sampler + cache-free gather) on a bounded sample of the same batches,
+    evenly spread over the replay.  Reported baseline, not the target."""
+    from oracle import oracle as O
+    og = O.OracleGraph(minimum_block_size=62, insertion_policy="insert")
+    for lo in range(0, g["num_edges"], 100000):
+        hi = lo + 100000
+        og.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
+                     add_reverse=args.undirected)
+    osamp = O.OracleSampler(og, fanouts, args.strategy, seed=1234)
+    picks = list(range(0, len(batches), max(1, len(batches) // 64)))
+    edges, t_total, n_done = 0, 0.0, 0
+    for bi in picks:
+        r, t, e = batches[bi]
+        t0 = time.perf_counter()
+        mfgs = osamp.sample(r, t)
+        if with_gather:
+            for blk in mfgs[0]:
+                blk.srcdata["h"] = O.gather_rows(node_feats, blk.srcdata["ID"])
+            for mfg in mfgs:
+                for blk in mfg:
+                    if blk.num_edges():
+                        blk.edata["f"] = O.gather_rows(edge_feats, blk.edata["ID"])
+        t_total += time.perf_counter() - t0
+        edges += sum(b.num_edges() for mfg in mfgs for b in mfg)
+        n_done += 1
+        if t_total > args.cpu_seconds:
+            break
+    return {
+        "value": edges / t_total, "unit": "edges/s", "cores": 1, "kind": "port",
+        "sample": "{} of {} batches evenly spaced over the same replay "
+                  "({:.1f} s of CPU work; sample()+cache-free gather)".format(
+                      n_done, len(batches), t_total),
+        "ms_per_step": 1e3 * t_total / max(n_done, 1),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,7 @@ thread_local std::string g_last_error;
 
 struct ProfileRecord { int slot; hipEvent_t start, stop; };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+unsigned g_prof_mask = 0;
 std::vector<ProfileRecord> g_prof_pending;
 double g_prof_ms[kProfSlots] = {0};
 uint64_t g_prof_launches[kProfSlots] = {0};
@@ -40,10 +40,10 @@ void drain_profile_locked() {
 }  // namespace
 
 void set_last_error(const std::string& msg) { g_last_error = msg; }
-bool profile_enabled() { return g_prof_on; }
+bool profile_enabled() { return g_prof_mask != 0; }
 
 ProfileScope::ProfileScope(int slot_, hipStream_t stream_) : slot(slot_), stream(stream_) {
-  if (!g_prof_on) return;
+  if (!(g_prof_mask & (1u << slot))) return;
   if (hipEventCreate(&start) != hipSuccess) { start = nullptr; return; }
   (void)hipEventRecord(start, stream);
 }
@@ -254,9 +254,9 @@ int gf_cache_mem_bytes(const gf_cache* c, size_t* out) {
 }
 
 // ---- profiling ---------------------------------------------------------------------
-int gf_profile_enable(int on) {
+int gf_profile_enable(int mask) {
   std::lock_guard<std::mutex> lk(gf::g_prof_mu);
-  gf::g_prof_on = on != 0;
+  gf::g_prof_mask = static_cast<unsigned>(mask);
   return GF_OK;
 }
 int gf_profile_reset(void) {

@@ -199,11 +199,12 @@ GF_API int gf_cache_slot_ids(const gf_cache* c, int64_t* out, size_t capacity);
 GF_API int gf_cache_mem_bytes(const gf_cache* c, size_t* out);
 
 /* ---- measurement support (bench.py) ---------------------------------------- */
-/* Accumulated device time of the named kernel family since the last reset,
- * measured with HIP events on the launching stream when profiling is enabled.
- * which: 0 = sampler search, 1 = sampler emit, 2 = feature gather, 3 = scan,
- * 4 = LRU update. */
-GF_API int gf_profile_enable(int on);
+/* Accumulated device time of a kernel family since the last reset, measured with
+ * HIP events recorded around each launch on the launching stream.
+ * which: 0 = sampler search, 1 = sampler emit, 2 = feature gather, 3 = sampler scan,
+ * 4 = LRU update (all bookkeeping kernels of one fetch as one interval).
+ * gf_profile_enable takes a bit mask of the families to time (0 = off). */
+GF_API int gf_profile_enable(int mask);
 GF_API int gf_profile_reset(void);
 GF_API int gf_profile_get(int which, double* total_ms, uint64_t* launches);
 
