@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--sample-only", action="store_true",
                     help="time sample() alone (no feature gather)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap batch i+1's sample() with batch i's fetch_feature()")
     ap.add_argument("--breakdown", action="store_true",
                     help="extra untimed pass with per-kernel-family HIP-event times")
     return ap.parse_args()
@@ -128,13 +130,49 @@ def main():
             cache.fetch_feature(mfgs, e)
         return mfgs
 
+    # Software pipeline (the reference's training loop prefetches the next batch's
+    # sample() on a Python thread, scripts/offline_edge_prediction.py:343-346,397-399):
+    # a worker thread samples batch i+1 on its own HIP stream while the main thread
+    # runs fetch_feature() of batch i.  Every batch still goes through the same calls.
+    from concurrent.futures import ThreadPoolExecutor
+    pipelined = cache is not None and not args.no_pipeline
+    pool = ThreadPoolExecutor(max_workers=1) if pipelined else None
+    side = torch.cuda.Stream(device=dev) if pipelined else None
+
+    def sample_job(i):
+        torch.cuda.set_device(dev)
+        r, t, _ = dev_batches[i % len(dev_batches)]
+        with torch.cuda.stream(side):
+            return sampler.sample(r, t)
+
+    def run_steps(first, count, on_step=None):
+        """Runs `count` steps starting at batch `first`; returns nothing, calls
+        on_step(mfgs) after each step."""
+        if not pipelined:
+            for i in range(first, first + count):
+                mfgs = step(i)
+                if on_step:
+                    on_step(mfgs)
+            return
+        main = torch.cuda.current_stream(dev)
+        fut = pool.submit(sample_job, first)
+        for i in range(first, first + count):
+            mfgs = fut.result()
+            if i + 1 < first + count:
+                fut = pool.submit(sample_job, i + 1)
+            for mfg in mfgs:
+                for b in mfg:
+                    b.record_stream(main)
+            cache.fetch_feature(mfgs, dev_batches[i % len(dev_batches)][2])
+            if on_step:
+                on_step(mfgs)
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    run_steps(0, args.warmup)
     # the timed region replays from the first batch again: LRU state starts from reset
     if cache is not None:
         cache.init_cache()
@@ -142,16 +180,19 @@ def main():
     lib.gf_profile_enable(1 << _capi.PROFILE_SLOTS["gather"])   # HIP events on the gather
     barrier()
     t0 = time.perf_counter()
-    edges = 0
-    gather_bytes = 0
-    for i in range(args.steps):
-        mfgs = step(i)
+    acc = {"edges": 0, "bytes": 0}
+
+    def account(mfgs):
         for mfg in mfgs:
             for b in mfg:
-                edges += b.num_edges()
+                acc["edges"] += b.num_edges()
         if cache is not None:
-            gather_bytes += algorithmic_bytes_gather(mfgs, d_e, d_n)
+            acc["bytes"] += algorithmic_bytes_gather(mfgs, d_e, d_n) + \
+                args.batch_size * 8 * d_e   # target_edge_features rows (read + write)
+
+    run_steps(0, args.steps, account)
     barrier()
+    edges, gather_bytes = acc["edges"], acc["bytes"]
     elapsed = time.perf_counter() - t0
     lib.gf_profile_enable(0)
 
@@ -197,6 +238,7 @@ def main():
             "feature_placement": args.feature_placement,
             "graph_build_s": round(build_s, 3),
             "parallelism": "replica-dp{}".format(world),
+            "pipelined": bool(pipelined),
         },
     }
     if cache is not None and g_n.value:
@@ -216,8 +258,7 @@ def main():
     if args.breakdown and rank == 0:
         lib.gf_profile_reset()
         lib.gf_profile_enable(0x1F)
-        for i in range(min(args.steps, 200)):
-            step(i)
+        run_steps(0, min(args.steps, 200))
         torch.cuda.synchronize()
         lib.gf_profile_enable(0)
         bd = {}

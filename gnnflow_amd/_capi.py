@@ -40,6 +40,18 @@ class GfBlock(C.Structure):
     ]
 
 
+class GfFetchDesc(C.Structure):
+    """struct gf_fetch_desc (include/gnnflow_hip.h)."""
+    _fields_ = [
+        ("kind", C.c_int),
+        ("update", C.c_int),
+        ("d_ids", C.c_void_p),
+        ("n", C.c_size_t),
+        ("d_out", C.c_void_p),
+        ("d_stats", C.c_void_p),
+    ]
+
+
 # every symbol include/gnnflow_hip.h declares: name -> (restype, argtypes)
 _p = C.c_void_p
 _sz = C.c_size_t
@@ -82,6 +94,7 @@ PROTOTYPES = {
     "gf_cache_init": (C.c_int, [_p, _p]),
     "gf_cache_resize": (C.c_int, [_p, _sz, _sz, _p, _p]),
     "gf_cache_fetch": (C.c_int, [_p, _p, _sz, _p, C.c_int, _p, _p]),
+    "gf_cache_fetch_blocks": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p]),
     "gf_gather_rows": (C.c_int, [_p, _sz, _sz, _p, _sz, _p, C.c_int, _p]),
     "gf_cache_slot_ids": (C.c_int, [_p, _p, _sz]),
     "gf_cache_mem_bytes": (C.c_int, [_p, C.POINTER(_sz)]),

@@ -161,10 +161,11 @@ class Cache:
     # ---- hit ratios: mean over blocks of hits/len (cache.py:277,323,337,400) ---------
     @staticmethod
     def _ratio(stats):
+        # stats[b] = 16 x int32: hits in the even words (8 shards), n in word 1
         if stats is None or stats.shape[0] == 0:
             return 0
         s = stats.to(torch.float32)
-        return (s[:, 0] / s[:, 1]).mean()
+        return (s[:, 0::2].sum(dim=1) / s[:, 1]).mean()
 
     @property
     def cache_node_ratio(self):
@@ -232,26 +233,48 @@ class Cache:
                       update_cache: bool = True, target_edge_features: bool = True):
         """Fetching the node/edge features of input_node_ids (cache.py:255-413):
         node features for the blocks of mfgs[0] -> srcdata['h'], edge features for every
-        block -> edata['f'], target edge features for TGN memory."""
+        block -> edata['f'], target edge features for TGN memory.  One native call
+        (gf_cache_fetch_blocks) issues every gather + LRU update; node and edge caches
+        proceed concurrently on the device."""
+        upd = 1 if update_cache else 0
+        jobs = []    # (kind, ids tensor, dim, setter)
+        if self._node is not None:
+            for b in mfgs[0]:
+                jobs.append((0, self._ids(b.srcdata['ID']), self.dim_node_feat, b.srcdata, 'h'))
+        n_node = len(jobs)
+        if self._edge is not None:
+            for mfg in mfgs:
+                for b in mfg:
+                    if len(b.edata['ID']) > 0:
+                        jobs.append((1, self._ids(b.edata['ID']), self.dim_edge_feat,
+                                     b.edata, 'f'))
+        n_cached = len(jobs)
+        if self._edge is not None and target_edge_features and eid is not None:
+            jobs.append((2, self._ids(eid), self.dim_edge_feat, None, None))
+        if not jobs:
+            return mfgs
         with torch.cuda.device(self.device):
-            stream = self._stream()
-            if self._node is not None:
-                blocks = list(mfgs[0])
-                stats = torch.zeros((len(blocks), 2), dtype=torch.int32, device=self.device)
-                for i, b in enumerate(blocks):
-                    ids = self._ids(b.srcdata['ID'])
-                    b.srcdata['h'] = self._node.fetch(
-                        ids, update_cache, stats[i].data_ptr() if len(ids) else None, stream)
-                self._node_stats = stats
-            if self._edge is not None:
-                blocks = [b for mfg in mfgs for b in mfg if len(b.edata['ID']) > 0]
-                stats = torch.zeros((len(blocks), 2), dtype=torch.int32, device=self.device)
-                for i, b in enumerate(blocks):
-                    ids = self._ids(b.edata['ID'])
-                    b.edata['f'] = self._edge.fetch(ids, update_cache, stats[i].data_ptr(),
-                                                    stream)
-                self._edge_stats = stats
-                if target_edge_features and eid is not None:
-                    # cache.py:411 `self.edge_feats[eid]`
-                    self.target_edge_features = self._edge.gather(self._ids(eid), stream)
+            stats = torch.zeros((max(n_cached, 1), 16), dtype=torch.int32, device=self.device)
+            descs = (_capi.GfFetchDesc * len(jobs))()
+            stats_ptr = stats.data_ptr()
+            for i, (kind, ids, dim, store, key) in enumerate(jobs):
+                n = int(ids.shape[0])
+                out = torch.empty((n, dim), dtype=torch.float32, device=self.device)
+                d = descs[i]
+                d.kind, d.update, d.n = kind, upd, n
+                d.d_ids, d.d_out = ids.data_ptr(), out.data_ptr()
+                d.d_stats = stats_ptr + 64 * i if (kind != 2 and n) else None
+                if store is not None:
+                    store[key] = out
+                else:
+                    self.target_edge_features = out    # cache.py:411 `edge_feats[eid]`
+            _capi.check(self._lib.gf_cache_fetch_blocks(
+                self._node.h if self._node is not None else None,
+                self._edge.h if self._edge is not None else None,
+                descs, len(jobs), self._stream()))
+            # keep ids alive until the kernels are enqueued (they are, above)
+        if self._node is not None:
+            self._node_stats = stats[:n_node]
+        if self._edge is not None:
+            self._edge_stats = stats[n_node:n_cached]
         return mfgs

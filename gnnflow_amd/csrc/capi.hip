@@ -239,6 +239,14 @@ int gf_cache_fetch(gf_cache* c, const int64_t* d_ids, size_t n, float* d_out, in
     c->impl.fetch(d_ids, n, d_out, update != 0, d_stats, static_cast<hipStream_t>(stream));
   });
 }
+int gf_cache_fetch_blocks(gf_cache* node_cache, gf_cache* edge_cache, const gf_fetch_desc* descs,
+                          size_t n, void* stream) {
+  return guarded([&] {
+    gf::fetch_blocks(node_cache ? &node_cache->impl : nullptr,
+                     edge_cache ? &edge_cache->impl : nullptr, descs, n,
+                     static_cast<hipStream_t>(stream));
+  });
+}
 int gf_gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_t* d_ids,
                    size_t n, float* d_out, int device, void* stream) {
   return guarded([&] {

@@ -9,22 +9,35 @@
 //   evicted and refilled with the missed ids' rows.
 // The reference spends ~10 ATen launches, a host round trip for the missed rows
 // (unique -> CPU index_select -> pinned -> H2D) and a topk over the whole capacity
-// on this.  Here:
-//   * ONE gather kernel reads ids, probes the id->slot map, picks the source row
-//     (cache slot in HBM, or the feature table — HBM or device-mapped pinned host
-//     memory) and streams it to the output with 16-byte loads/stores; a wave owns
-//     64 consecutive output rows so the stores are one contiguous 64*dim*4-byte run
-//     and every lane keeps 4 independent 16 B loads in flight.  It also records each
-//     row's slot (for the LRU pass) and the hit count.  This kernel moves ~all the
-//     bytes (2 * dim * 4 per row) and is the one priced against the HBM roofline.
-//   * LRU bookkeeping runs entirely on the device with no host synchronisation:
-//     `count` is kept as an epoch stamp per slot (count == stamp - epoch), victims
-//     are selected with a two-level 2048-bin histogram select over slot ages
-//     (no sort, no topk), ties resolved towards the lowest slot index so the result
-//     is deterministic, and the missed rows are installed from the just-written
-//     output rows (already in HBM) instead of being fetched a second time.
-//     Every bookkeeping kernel exits immediately when the block had no miss
-//     (the reference skips update_*_cache in that case too).
+// on this.  Here one fetch is 1 + 5 launches, none of which waits for the host:
+//
+//   gather  : reads ids, probes the id->slot map, picks the source row (cache slot in
+//             HBM, or the feature table — HBM or device-mapped pinned host memory) and
+//             streams it to the output with 16-byte loads/stores.  A wave owns
+//             `tile_rows` consecutive output rows, flattened, so its stores form one
+//             contiguous run and every lane keeps 4 independent 16 B loads in flight;
+//             tile_rows shrinks for small blocks so that a 10k-row block still spreads
+//             over >2000 waves.  It also records each row's slot, counts hits/misses
+//             and (when the cache will be updated) lets every missed row claim its id
+//             with atomicMax(map[id], -(row+1)) — the lowest row of each distinct
+//             missed id wins.  This kernel moves ~all the bytes (2*dim*4 per row) and
+//             is the one priced against the HBM roofline.
+//   mark    : representatives of the distinct missed ids; hit slots take the new epoch.
+//   scan+h1 : workgroup 0 prefix-sums the representative flags (first-seen order and
+//             #unique); the other workgroups histogram the slot ages.
+//   rank+h2 : rank -> row table of the ids to install (the rest give their claim back);
+//             second-level histogram only when the eviction threshold is older than
+//             2047 epochs.
+//   count   : per 1024-slot tile, slots older than / exactly at the threshold age.
+//   install : evicts every older slot plus the first k_tie threshold-age slots in slot
+//             order, gives the i-th evicted slot (slot order) the i-th distinct missed
+//             id (block order), and copies the freshly gathered rows from the output
+//             (already in HBM) into the cache.  No atomics: fully deterministic.
+//
+// `count` of the reference is kept as an epoch stamp per slot (count == stamp - epoch);
+// the k smallest counts are found with a histogram select (no sort, no topk); ties go to
+// the lowest slot index.  Bookkeeping kernels return immediately when the block had no
+// miss (the reference skips update_*_cache in that case too, cache.py:318).
 #include "feature_cache.hpp"
 
 #include <algorithm>
@@ -37,33 +50,45 @@ namespace gf {
 namespace {
 
 constexpr int32_t kAbsent = INT32_MIN;  // map[] value of an uncached id
-constexpr int kThreads = 256;
-constexpr int kBins = 2048;             // 11 bits per histogram level
-constexpr uint32_t kAgeMax = (1u << 22) - 1;
-constexpr int kTile = 1024;             // slots per tie-count tile
-constexpr int kScanThreads = 1024;
+constexpr int kThreads = 256;           // gather / row kernels
+constexpr int kWide = 1024;             // slot kernels, scans
+constexpr int kFine = 2048;             // ages 0..2047: one bin each
+constexpr int kBins1 = 4096;            // + 2048 coarse bins of 2048 ages each
+constexpr int kBins2 = 2048;            // second level inside one coarse bin
+constexpr uint32_t kAgeMax = kFine + 2048u * 2048u - 1u;
+constexpr int kTile = 1024;             // slots per tile (= install workgroup)
+constexpr int kRing = 32;               // per-fetch counter records before a re-zero
 
-struct Counters {
-  uint32_t hits;        // rows served from the cache
-  uint32_t n_miss;      // rows served from the feature table
-  uint32_t n_unique;    // distinct missed ids
-  uint32_t victim_ctr;  // install tickets handed out
-  uint32_t reserved[4];
+// One record per fetch.  hits / misses are accumulated once per workgroup into one of 8
+// shards that sit on separate 128-byte lines: same-address atomics retire at only
+// ~88/us on MI355X, so one counter word per wave would dominate the gather itself.
+constexpr int kShards = 8;
+struct Shard {
+  uint32_t hits;      // rows served from the cache
+  uint32_t n_miss;    // rows served from the feature table
+  uint32_t pad[30];
 };
+struct Counters {
+  Shard shard[kShards];
+  uint32_t n_unique;  // distinct missed ids
+  uint32_t pad[31];
+};
+__device__ inline uint32_t total_miss(const Counters* c) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < kShards; ++i) m += c->shard[i].n_miss;
+  return m;
+}
 
 struct Workspace {
-  Counters* ctr;
-  uint32_t* hist_hi;    // [kBins]
-  uint32_t* hist_lo;    // [kBins]
+  uint32_t* hist1;      // [kBins1]
+  uint32_t* hist2;      // [kBins2]
   int32_t* slot_of_row; // [n]  >=0 slot (hit), -1 miss, -2 invalid id
   uint32_t* rep_flag;   // [n]  1 = first row of a distinct missed id
   uint32_t* rep_rank;   // [n]  exclusive scan of rep_flag
   uint32_t* rep_row;    // [n]  rank -> row
   uint32_t* tile_tie;   // [tiles] slots at the threshold age
   uint32_t* tile_old;   // [tiles] slots older than the threshold
-  uint32_t* tie_base;   // [tiles] exclusive scans of the two
-  uint32_t* old_base;   // [tiles]
-  uint2* pairs;         // [n]  ticket -> {slot, row}
 };
 
 template <typename VecT> __device__ inline VecT vec_zero();
@@ -71,20 +96,26 @@ template <> __device__ inline float vec_zero<float>() { return 0.0f; }
 template <> __device__ inline float4 vec_zero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ---- the gather kernel -------------------------------------------------------------
-// VecT = float4 (dim % 4 == 0, 16 B aligned rows) or float.
+// VecT = float4 (dim % 4 == 0, 16 B aligned rows) or float.  tile_rows in [1, 64].
 template <typename VecT>
 __global__ __launch_bounds__(kThreads) void gather_rows_kernel(
-    const int64_t* __restrict__ ids, uint32_t n, const int32_t* __restrict__ map,
+    const int64_t* __restrict__ ids, uint32_t n, int32_t* map,
     const VecT* __restrict__ cache_buf, const VecT* __restrict__ feats, uint64_t num_ids,
-    uint32_t dimv, VecT* __restrict__ out, int32_t* __restrict__ slot_of_row,
-    Counters* __restrict__ ctr, uint32_t* __restrict__ stats) {
+    uint32_t dimv, uint32_t tile_rows, VecT* __restrict__ out,
+    int32_t* __restrict__ slot_of_row, Counters* __restrict__ ctr,
+    uint32_t* __restrict__ stats, int claim, uint32_t* __restrict__ zero_words,
+    uint32_t num_zero_words) {
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
+  const uint32_t gtid = blockIdx.x * kThreads + threadIdx.x;
+  // this fetch's histograms are cleared here (they are first used two launches later)
+  for (uint32_t i = gtid; i < num_zero_words; i += gridDim.x * kThreads) zero_words[i] = 0;
+  const uint32_t wave = gtid >> 6;
   const uint32_t num_waves = (gridDim.x * kThreads) >> 6;
-  const uint32_t tiles = (n + 63) / 64;
+  const uint32_t tiles = (n + tile_rows - 1) / tile_rows;
+  uint32_t acc_hits = 0, acc_miss = 0;   // wave-uniform
   for (uint32_t tile = wave; tile < tiles; tile += num_waves) {
-    const uint32_t row0 = tile * 64;
-    const uint32_t rows = min(64u, n - row0);
+    const uint32_t row0 = tile * tile_rows;
+    const uint32_t rows = min(tile_rows, n - row0);
     const VecT* src = nullptr;
     int32_t slot = -2;
     if (lane < static_cast<int>(rows)) {
@@ -96,19 +127,13 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(
         } else {
           slot = -1;
           src = feats + static_cast<uint64_t>(id) * dimv;
+          if (claim) atomicMax(&map[id], -static_cast<int32_t>(row0 + lane + 1));
         }
       }
       if (slot_of_row) slot_of_row[row0 + lane] = slot;
     }
-    if (ctr) {
-      const uint32_t hits = __popcll(__ballot(slot >= 0));
-      const uint32_t miss = __popcll(__ballot(slot == -1));
-      if (lane == 0) {
-        if (hits) atomicAdd(&ctr->hits, hits);
-        if (miss) atomicAdd(&ctr->n_miss, miss);
-        if (stats && hits) atomicAdd(&stats[0], hits);
-      }
-    }
+    acc_hits += __popcll(__ballot(slot >= 0));
+    acc_miss += __popcll(__ballot(slot == -1));
     const uint64_t src_bits = reinterpret_cast<uint64_t>(src);
     const uint32_t total = rows * dimv;
     VecT* o = out + static_cast<uint64_t>(row0) * dimv;
@@ -134,57 +159,63 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(
       if (p3) o[f + 192] = v3;
     }
   }
-  if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], n);
+  if (ctr) {
+    __shared__ uint32_t wg_hits, wg_miss;
+    if (threadIdx.x == 0) { wg_hits = 0; wg_miss = 0; }
+    __syncthreads();
+    if (lane == 0) {
+      if (acc_hits) atomicAdd(&wg_hits, acc_hits);
+      if (acc_miss) atomicAdd(&wg_miss, acc_miss);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      Shard* sh = &ctr->shard[blockIdx.x & (kShards - 1)];
+      if (wg_hits) atomicAdd(&sh->hits, wg_hits);
+      if (wg_miss) atomicAdd(&sh->n_miss, wg_miss);
+      if (stats && wg_hits) atomicAdd(&stats[2 * (blockIdx.x & (kShards - 1))], wg_hits);
+    }
+  }
+  if (stats && gtid == 0) atomicAdd(&stats[1], n);
 }
 
-// ---- LRU bookkeeping kernels -------------------------------------------------------
-// claim: the lowest row of every distinct missed id wins map[id] = -(row+1)
-__global__ void lru_claim_kernel(const int64_t* __restrict__ ids, uint32_t n,
-                                 const int32_t* __restrict__ slot_of_row, int32_t* map,
-                                 const Counters* __restrict__ ctr) {
-  if (ctr->n_miss == 0) return;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || slot_of_row[i] != -1) return;
-  atomicMax(&map[ids[i]], -static_cast<int32_t>(i + 1));
+// ---- LRU bookkeeping ---------------------------------------------------------------
+__device__ inline uint32_t slot_age(uint32_t epoch_new, uint32_t stamp) {
+  const uint32_t a = epoch_new - stamp;
+  return a < kAgeMax ? a : kAgeMax;
+}
+__device__ inline uint32_t age_bin1(uint32_t a) {
+  return a < kFine ? a : kFine + ((a - kFine) >> 11);
 }
 
-// mark: representatives of the distinct missed ids; hit slots get the new epoch
-// (`self.cache_*_count[cached_index] = 0`, lru_cache.py:138-139)
-__global__ void lru_mark_kernel(const int64_t* __restrict__ ids, uint32_t n,
-                                const int32_t* __restrict__ slot_of_row,
-                                const int32_t* __restrict__ map, uint32_t* __restrict__ stamp,
-                                const uint32_t* __restrict__ epoch,
-                                uint32_t* __restrict__ rep_flag,
-                                const Counters* __restrict__ ctr) {
-  if (ctr->n_miss == 0) return;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// mark: representatives of the distinct missed ids (the row whose claim survived); hit
+// slots take the new epoch (`self.cache_*_count[cached_index] = 0`, lru_cache.py:138-139)
+__global__ __launch_bounds__(kThreads) void lru_mark_kernel(
+    const int64_t* __restrict__ ids, uint32_t n, const int32_t* __restrict__ slot_of_row,
+    const int32_t* __restrict__ map, uint32_t* __restrict__ stamp, uint32_t epoch_new,
+    uint32_t* __restrict__ rep_flag, const Counters* __restrict__ ctr) {
+  if (total_miss(ctr) == 0) return;
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n) return;
   const int32_t s = slot_of_row[i];
   uint32_t rep = 0;
   if (s >= 0) {
-    stamp[s] = *epoch + 1;
+    stamp[s] = epoch_new;
   } else if (s == -1) {
     rep = map[ids[i]] == -static_cast<int32_t>(i + 1);
   }
   rep_flag[i] = rep;
 }
 
-// single-workgroup chained exclusive scan (n up to a few million)
-__global__ __launch_bounds__(kScanThreads) void scan_u32_kernel(
-    const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
-    uint32_t* __restrict__ total_out, const uint32_t* __restrict__ in2,
-    uint32_t* __restrict__ out2, const Counters* __restrict__ ctr) {
-  if (ctr->n_miss == 0) return;
-  __shared__ uint32_t wave_sums[kScanThreads / 64];
+// workgroup-wide chained exclusive scan of in[0..n) (kWide threads)
+__device__ inline uint32_t block_scan_u32(const uint32_t* __restrict__ in,
+                                          uint32_t* __restrict__ out, uint32_t n) {
+  __shared__ uint32_t wave_sums[kWide / 64];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr uint32_t kItems = 4;
-  for (int pass = 0; pass < (in2 ? 2 : 1); ++pass) {
-  if (pass == 1) { in = in2; out = out2; total_out = nullptr; }
-  __syncthreads();
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (uint32_t tile = 0; tile < n; tile += kScanThreads * kItems) {
+  for (uint32_t tile = 0; tile < n; tile += kWide * kItems) {
     uint32_t v[kItems], local = 0;
     const uint32_t i0 = tile + tid * kItems;
 #pragma unroll
@@ -209,60 +240,49 @@ __global__ __launch_bounds__(kScanThreads) void scan_u32_kernel(
       run += v[k];
     }
     __syncthreads();
-    if (tid == kScanThreads - 1) carry_s = run;
+    if (tid == kWide - 1) carry_s = run;
     __syncthreads();
   }
-  if (tid == 0 && total_out) *total_out = carry_s;
-  }
+  return carry_s;
 }
 
-__device__ inline uint32_t slot_age(uint32_t epoch_new, uint32_t stamp) {
-  const uint32_t a = epoch_new - stamp;
-  return a < kAgeMax ? a : kAgeMax;
-}
-
-// Part A (rows): rank -> row table of the representatives that will be installed;
-// representatives beyond the capacity give their claim back
-// ("we only cache the first self.capacity", lru_cache.py:127-133).
-// Part B (slots): level-1 histogram of slot ages (bits 21..11).
-__global__ __launch_bounds__(kThreads) void lru_rank_hist_kernel(
-    const int64_t* __restrict__ ids, uint32_t n, const uint32_t* __restrict__ rep_flag,
-    const uint32_t* __restrict__ rep_rank, uint32_t* __restrict__ rep_row, int32_t* map,
-    const uint32_t* __restrict__ stamp, uint32_t capacity, const uint32_t* __restrict__ epoch,
-    uint32_t* __restrict__ hist_hi, const Counters* __restrict__ ctr) {
-  if (ctr->n_miss == 0) return;
-  __shared__ uint32_t h[kBins];
-  for (int b = threadIdx.x; b < kBins; b += kThreads) h[b] = 0;
-  __syncthreads();
-  const uint32_t k = min(ctr->n_unique, capacity);
-  const uint32_t epoch_new = *epoch + 1;
-  const uint32_t stride = gridDim.x * kThreads;
-  for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
-    if (!rep_flag[i]) continue;
-    const uint32_t rank = rep_rank[i];
-    if (rank < k) rep_row[rank] = i;
-    else map[ids[i]] = kAbsent;
+// workgroup 0: scan of the representative flags (rank in block order, #unique);
+// workgroups 1..: level-1 histogram of the slot ages
+__global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(
+    const uint32_t* __restrict__ rep_flag, uint32_t* __restrict__ rep_rank, uint32_t n,
+    const uint32_t* __restrict__ stamp, uint32_t capacity, uint32_t epoch_new,
+    uint32_t* __restrict__ hist1, Counters* ctr) {
+  if (total_miss(ctr) == 0) return;
+  if (blockIdx.x == 0) {
+    const uint32_t total = block_scan_u32(rep_flag, rep_rank, n);
+    if (threadIdx.x == 0) ctr->n_unique = total;
+    return;
   }
-  for (uint32_t s = blockIdx.x * kThreads + threadIdx.x; s < capacity; s += stride)
-    atomicAdd(&h[slot_age(epoch_new, stamp[s]) >> 11], 1u);
+  __shared__ uint32_t h[kBins1];
+  for (int b = threadIdx.x; b < kBins1; b += kWide) h[b] = 0;
   __syncthreads();
-  for (int b = threadIdx.x; b < kBins; b += kThreads)
-    if (h[b]) atomicAdd(&hist_hi[b], h[b]);
+  const uint32_t stride = (gridDim.x - 1) * kWide;
+  for (uint32_t s = (blockIdx.x - 1) * kWide + threadIdx.x; s < capacity; s += stride)
+    atomicAdd(&h[age_bin1(slot_age(epoch_new, stamp[s]))], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBins1; b += kWide)
+    if (h[b]) atomicAdd(&hist1[b], h[b]);
 }
 
 // Finds the bin B (scanning from the oldest = highest bin) where the cumulative count
 // reaches k; returns B and k_rem = k - (count in bins > B).  Called by EVERY thread of
-// the workgroup (barriers inside); the first kThreads threads do the work and the
-// result is broadcast through LDS.
+// the workgroup (barriers inside); the first 256 threads do the work.
+template <int NBINS>
 __device__ inline void find_bin_from_top(const uint32_t* __restrict__ hist, uint32_t k,
                                          uint32_t* bin, uint32_t* k_rem) {
-  __shared__ uint32_t part[kThreads];
+  constexpr int kWorkers = 256;
+  constexpr int kPer = NBINS / kWorkers;
+  __shared__ uint32_t part[kWorkers];
   __shared__ uint32_t res[2];
-  constexpr int kPer = kBins / kThreads;  // 8 bins per thread
   const int t = threadIdx.x;
-  const bool worker = t < kThreads;
+  const bool worker = t < kWorkers;
   // thread t owns bins [hi_first - kPer + 1, hi_first], hi_first descending with t
-  const int hi_first = kBins - 1 - t * kPer;
+  const int hi_first = NBINS - 1 - t * kPer;
   uint32_t mine[kPer], sum = 0;
   if (worker) {
 #pragma unroll
@@ -296,68 +316,80 @@ __device__ inline void find_bin_from_top(const uint32_t* __restrict__ hist, uint
   __syncthreads();
 }
 
-// level-2 histogram (bits 10..0) of the slots whose level-1 bin is the boundary bin
-__global__ __launch_bounds__(kThreads) void lru_hist_lo_kernel(
-    const uint32_t* __restrict__ stamp, uint32_t capacity, const uint32_t* __restrict__ epoch,
-    const uint32_t* __restrict__ hist_hi, uint32_t* __restrict__ hist_lo,
-    const Counters* __restrict__ ctr) {
-  if (ctr->n_miss == 0) return;
-  __shared__ uint32_t h[kBins];
-  for (int b = threadIdx.x; b < kBins; b += kThreads) h[b] = 0;
-  const uint32_t k = min(ctr->n_unique, capacity);
-  uint32_t b_hi, k_rem;
-  find_bin_from_top(hist_hi, k, &b_hi, &k_rem);
-  const uint32_t epoch_new = *epoch + 1;
-  const uint32_t stride = gridDim.x * kThreads;
-  for (uint32_t s = blockIdx.x * kThreads + threadIdx.x; s < capacity; s += stride) {
-    const uint32_t a = slot_age(epoch_new, stamp[s]);
-    if ((a >> 11) == b_hi) atomicAdd(&h[a & (kBins - 1)], 1u);
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < kBins; b += kThreads)
-    if (h[b]) atomicAdd(&hist_lo[b], h[b]);
-}
-
 struct Threshold { uint32_t age; uint32_t k_tie; };
 
-__device__ inline Threshold find_threshold(const uint32_t* hist_hi, const uint32_t* hist_lo,
+// eviction threshold: every slot older than `age` goes, plus the first k_tie slots
+// (slot order) of exactly that age
+__device__ inline Threshold find_threshold(const uint32_t* hist1, const uint32_t* hist2,
                                            uint32_t k) {
-  uint32_t b_hi, k_rem, b_lo, k_tie;
-  find_bin_from_top(hist_hi, k, &b_hi, &k_rem);
-  find_bin_from_top(hist_lo, k_rem, &b_lo, &k_tie);
+  uint32_t b1, k_rem;
+  find_bin_from_top<kBins1>(hist1, k, &b1, &k_rem);
   Threshold t;
-  t.age = (b_hi << 11) | b_lo;
-  t.k_tie = k_tie;
+  if (b1 < kFine) {
+    t.age = b1;
+    t.k_tie = k_rem;
+  } else {
+    uint32_t b2, k_tie;
+    find_bin_from_top<kBins2>(hist2, k_rem, &b2, &k_tie);
+    t.age = kFine + ((b1 - kFine) << 11) + b2;
+    t.k_tie = k_tie;
+  }
   return t;
+}
+
+// rows: rank -> row table of the representatives that will be installed; the ones beyond
+// the capacity give their claim back ("we only cache the first self.capacity",
+// lru_cache.py:127-133).  slots: level-2 histogram, only when the threshold lies in a
+// coarse bin (a slot untouched for more than 2047 updates).
+__global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(
+    const int64_t* __restrict__ ids, uint32_t n, const uint32_t* __restrict__ rep_flag,
+    const uint32_t* __restrict__ rep_rank, uint32_t* __restrict__ rep_row, int32_t* map,
+    const uint32_t* __restrict__ stamp, uint32_t capacity, uint32_t epoch_new,
+    const uint32_t* __restrict__ hist1, uint32_t* __restrict__ hist2,
+    const Counters* __restrict__ ctr) {
+  if (total_miss(ctr) == 0) return;
+  const uint32_t k = min(ctr->n_unique, capacity);
+  const uint32_t stride = gridDim.x * kWide;
+  for (uint32_t i = blockIdx.x * kWide + threadIdx.x; i < n; i += stride) {
+    if (!rep_flag[i]) continue;
+    const uint32_t rank = rep_rank[i];
+    if (rank < k) rep_row[rank] = i;
+    else map[ids[i]] = kAbsent;
+  }
+  uint32_t b1, k_rem;
+  find_bin_from_top<kBins1>(hist1, k, &b1, &k_rem);
+  if (b1 < kFine) return;   // uniform across the grid
+  __shared__ uint32_t h[kBins2];
+  for (int b = threadIdx.x; b < kBins2; b += kWide) h[b] = 0;
+  __syncthreads();
+  for (uint32_t s = blockIdx.x * kWide + threadIdx.x; s < capacity; s += stride) {
+    const uint32_t a = slot_age(epoch_new, stamp[s]);
+    if (age_bin1(a) == b1) atomicAdd(&h[(a - kFine) & (kBins2 - 1)], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBins2; b += kWide)
+    if (h[b]) atomicAdd(&hist2[b], h[b]);
 }
 
 // per tile of kTile slots: how many sit exactly at the threshold age, and how many are
 // older than it (all of those are evicted)
-__global__ __launch_bounds__(kThreads) void lru_tie_count_kernel(
-    const uint32_t* __restrict__ stamp, uint32_t capacity, const uint32_t* __restrict__ epoch,
-    const uint32_t* __restrict__ hist_hi, const uint32_t* __restrict__ hist_lo,
+__global__ __launch_bounds__(kWide) void lru_tile_count_kernel(
+    const uint32_t* __restrict__ stamp, uint32_t capacity, uint32_t epoch_new,
+    const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ hist2,
     uint32_t* __restrict__ tile_tie, uint32_t* __restrict__ tile_old,
     const Counters* __restrict__ ctr) {
-  if (ctr->n_miss == 0) return;
+  if (total_miss(ctr) == 0) return;
   __shared__ uint32_t cnt[2];
   const uint32_t k = min(ctr->n_unique, capacity);
-  const Threshold th = find_threshold(hist_hi, hist_lo, k);
-  const uint32_t epoch_new = *epoch + 1;
+  const Threshold th = find_threshold(hist1, hist2, k);
   const uint32_t tiles = (capacity + kTile - 1) / kTile;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t c = 0, o = 0;
-    for (uint32_t s = tile * kTile + threadIdx.x; s < min(capacity, (tile + 1) * kTile);
-         s += kThreads) {
-      const uint32_t a = slot_age(epoch_new, stamp[s]);
-      c += a == th.age;
-      o += a > th.age;
-    }
-    for (int d = 32; d > 0; d >>= 1) {
-      c += __shfl_down(c, d, 64);
-      o += __shfl_down(o, d, 64);
-    }
+    const uint32_t s = tile * kTile + threadIdx.x;
+    const uint32_t a = s < capacity ? slot_age(epoch_new, stamp[s]) : 0u;
+    const uint32_t c = __popcll(__ballot(s < capacity && a == th.age));
+    const uint32_t o = __popcll(__ballot(s < capacity && a > th.age));
     if ((threadIdx.x & 63) == 0) {
       if (c) atomicAdd(&cnt[0], c);
       if (o) atomicAdd(&cnt[1], o);
@@ -368,25 +400,39 @@ __global__ __launch_bounds__(kThreads) void lru_tie_count_kernel(
   }
 }
 
-// evict + install: every slot older than the threshold plus the first k_tie slots (in
-// slot order) exactly at it (lru_cache.py:141-160 with a deterministic tie rule).  The
+// evict + install + copy (lru_cache.py:141-160 with a deterministic tie rule): every slot
+// older than the threshold plus the first k_tie slots (in slot order) exactly at it; the
 // i-th evicted slot in slot order receives the i-th distinct missed id in block order,
-// so the whole update is deterministic (no atomics).
+// and its row is copied from the output rows gathered a moment ago.
+template <typename VecT>
 __global__ __launch_bounds__(kTile) void lru_install_kernel(
     const int64_t* __restrict__ ids, const uint32_t* __restrict__ rep_row, int32_t* map,
     int64_t* __restrict__ slot_id, uint32_t* __restrict__ stamp, uint32_t capacity,
-    const uint32_t* __restrict__ epoch, const uint32_t* __restrict__ hist_hi,
-    const uint32_t* __restrict__ hist_lo, const uint32_t* __restrict__ tie_base,
-    const uint32_t* __restrict__ old_base, uint2* __restrict__ pairs, Counters* ctr) {
-  if (ctr->n_miss == 0) return;
+    uint32_t epoch_new, const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ hist2,
+    const uint32_t* __restrict__ tile_tie, const uint32_t* __restrict__ tile_old,
+    const VecT* __restrict__ out, VecT* __restrict__ cache_buf, uint32_t dimv,
+    const Counters* __restrict__ ctr) {
+  if (total_miss(ctr) == 0) return;
   __shared__ uint32_t wave_tie[kTile / 64];
   __shared__ uint32_t wave_old[kTile / 64];
+  __shared__ uint32_t red[2][kTile / 64];
+  __shared__ uint2 inst[kTile];   // {slot, row} of this tile's installs
+  __shared__ uint32_t n_inst;
   const uint32_t k = min(ctr->n_unique, capacity);
-  const Threshold th = find_threshold(hist_hi, hist_lo, k);
-  const uint32_t epoch_new = *epoch + 1;
+  const Threshold th = find_threshold(hist1, hist2, k);
   const uint32_t tiles = (capacity + kTile - 1) / kTile;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    // bases = counts of all preceding tiles (summed by the whole workgroup)
+    uint32_t pt = 0, po = 0;
+    for (uint32_t t = threadIdx.x; t < tile; t += kTile) { pt += tile_tie[t]; po += tile_old[t]; }
+    for (int d = 32; d > 0; d >>= 1) { pt += __shfl_down(pt, d, 64); po += __shfl_down(po, d, 64); }
+    if (lane == 0) { red[0][wave] = pt; red[1][wave] = po; }
+    if (threadIdx.x == 0) n_inst = 0;
+    __syncthreads();
+    uint32_t tie_base = 0, old_base = 0;
+    for (int w = 0; w < kTile / 64; ++w) { tie_base += red[0][w]; old_base += red[1][w]; }
+
     const uint32_t s = tile * kTile + threadIdx.x;
     const bool in = s < capacity;
     const uint32_t a = in ? slot_age(epoch_new, stamp[s]) : 0u;
@@ -396,8 +442,8 @@ __global__ __launch_bounds__(kTile) void lru_install_kernel(
     const unsigned long long mt = __ballot(tie), mo = __ballot(older);
     if (lane == 0) { wave_tie[wave] = __popcll(mt); wave_old[wave] = __popcll(mo); }
     __syncthreads();
-    uint32_t ties_before = tie_base[tile] + __popcll(mt & below);
-    uint32_t old_before = old_base[tile] + __popcll(mo & below);
+    uint32_t ties_before = tie_base + __popcll(mt & below);
+    uint32_t old_before = old_base + __popcll(mo & below);
     for (int w = 0; w < wave; ++w) { ties_before += wave_tie[w]; old_before += wave_old[w]; }
     const bool evict = k > 0 && (older || (tie && ties_before < th.k_tie));
     if (evict) {
@@ -410,34 +456,20 @@ __global__ __launch_bounds__(kTile) void lru_install_kernel(
         slot_id[s] = nid;
         map[nid] = static_cast<int32_t>(s);
         stamp[s] = epoch_new;
-        pairs[v] = make_uint2(s, row);
+        inst[atomicAdd(&n_inst, 1u)] = make_uint2(s, row);
       }
     }
     __syncthreads();
+    // one wave per installed row
+    const uint32_t m = n_inst;
+    for (uint32_t i = wave; i < m; i += kTile / 64) {
+      const uint2 p = inst[i];
+      const VecT* src = out + static_cast<uint64_t>(p.y) * dimv;
+      VecT* dst = cache_buf + static_cast<uint64_t>(p.x) * dimv;
+      for (uint32_t c = lane; c < dimv; c += 64) dst[c] = src[c];
+    }
+    __syncthreads();
   }
-}
-
-// copy the installed rows out[row,:] -> cache_buffer[slot,:]; publish the new epoch
-template <typename VecT>
-__global__ __launch_bounds__(kThreads) void lru_copy_rows_kernel(
-    const uint2* __restrict__ pairs, const VecT* __restrict__ out, VecT* __restrict__ cache_buf,
-    uint32_t dimv, uint32_t capacity, uint32_t* epoch, const Counters* __restrict__ ctr) {
-  if (ctr->n_miss == 0) return;
-  const uint32_t k = min(ctr->n_unique, capacity);
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * kThreads + threadIdx.x) >> 6;
-  const uint32_t num_waves = (gridDim.x * kThreads) >> 6;
-  for (uint32_t v = wave; v < k; v += num_waves) {
-    const uint2 p = pairs[v];
-    const VecT* src = out + static_cast<uint64_t>(p.y) * dimv;
-    VecT* dst = cache_buf + static_cast<uint64_t>(p.x) * dimv;
-    for (uint32_t c = lane; c < dimv; c += 64) dst[c] = src[c];
-  }
-}
-
-__global__ void lru_bump_epoch_kernel(uint32_t* epoch, const Counters* __restrict__ ctr) {
-  if (ctr->n_miss == 0) return;
-  *epoch += 1;
 }
 
 __global__ void cache_fill_kernel(int32_t* map, uint64_t num_ids, int64_t* slot_id,
@@ -458,28 +490,35 @@ inline bool vec4_ok(size_t dim, const void* a, const void* b, const void* c) {
   return dim % 4 == 0 && al(a) && al(b) && al(c);
 }
 
-inline unsigned gather_grid(size_t n) {
-  // one wave per 64 rows, 4 waves per workgroup; enough workgroups to fill 256 CUs
-  size_t waves = (n + 63) / 64;
-  size_t blocks = (waves + 3) / 4;
-  return static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(blocks, 256 * 16)));
+// rows per wave: 64 for big blocks; fewer for small ones so the block still spreads
+// over ~4096 waves (1024 workgroups = 256 CUs x 4)
+inline uint32_t pick_tile_rows(size_t n) {
+  uint32_t t = 64;
+  while (t > 4 && (n + t - 1) / t < 4096) t >>= 1;
+  return t;
 }
 
-void launch_gather(const int64_t* ids, size_t n, const int32_t* map, const float* cache_buf,
+void launch_gather(const int64_t* ids, size_t n, int32_t* map, const float* cache_buf,
                    const float* feats, size_t num_ids, size_t dim, float* out,
-                   int32_t* slot_of_row, Counters* ctr, uint32_t* stats, hipStream_t stream) {
+                   int32_t* slot_of_row, Counters* ctr, uint32_t* stats, bool claim,
+                   uint32_t* zero_words, uint32_t num_zero_words, hipStream_t stream) {
   GF_REQUIRE(n < 0x7FFFFFFFull, "gather: more than 2^31-1 rows in one block");
   ProfileScope ps(kProfGather, stream);
-  const unsigned grid = gather_grid(n);
+  const uint32_t tile_rows = pick_tile_rows(n);
+  const size_t waves = (n + tile_rows - 1) / tile_rows;
+  const unsigned grid = static_cast<unsigned>(
+      std::max<size_t>(1, std::min<size_t>((waves + 3) / 4, 1024)));
   if (vec4_ok(dim, cache_buf, feats, out)) {
     gather_rows_kernel<float4><<<dim3(grid), dim3(kThreads), 0, stream>>>(
         ids, static_cast<uint32_t>(n), map, reinterpret_cast<const float4*>(cache_buf),
         reinterpret_cast<const float4*>(feats), num_ids, static_cast<uint32_t>(dim / 4),
-        reinterpret_cast<float4*>(out), slot_of_row, ctr, stats);
+        tile_rows, reinterpret_cast<float4*>(out), slot_of_row, ctr, stats, claim ? 1 : 0,
+        zero_words, num_zero_words);
   } else {
     gather_rows_kernel<float><<<dim3(grid), dim3(kThreads), 0, stream>>>(
         ids, static_cast<uint32_t>(n), map, cache_buf, feats, num_ids,
-        static_cast<uint32_t>(dim), out, slot_of_row, ctr, stats);
+        static_cast<uint32_t>(dim), tile_rows, out, slot_of_row, ctr, stats, claim ? 1 : 0,
+        zero_words, num_zero_words);
   }
   GF_HIP(hipGetLastError());
 }
@@ -493,7 +532,7 @@ void gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_
   GF_REQUIRE(dim > 0, "gather_rows: dim must be positive");
   DeviceGuard dg(device);
   launch_gather(d_ids, n, nullptr, nullptr, d_feats, num_rows, dim, d_out, nullptr, nullptr,
-                nullptr, stream);
+                nullptr, false, nullptr, 0, stream);
 }
 
 FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const float* d_feats,
@@ -508,11 +547,10 @@ FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const fl
   map_.reserve(std::max<size_t>(num_ids * sizeof(int32_t), 16));
   slot_id_.reserve(std::max<size_t>(capacity * sizeof(int64_t), 16));
   stamp_.reserve(std::max<size_t>(capacity * sizeof(uint32_t), 16));
-  state_.reserve(16, 0, nullptr, true);
+  state_.reserve(kRing * sizeof(Counters), 0, nullptr, true);
   cache_fill_kernel<<<dim3(1024), dim3(256), 0, nullptr>>>(
       map_.as<int32_t>(), num_ids_, slot_id_.as<int64_t>(), stamp_.as<uint32_t>(), capacity_, 0);
   GF_HIP(hipGetLastError());
-  GF_HIP(hipMemsetAsync(state_.data(), 0, 16, nullptr));
   GF_HIP(hipMemsetAsync(buffer_.data(), 0, buffer_.bytes(), nullptr));
   GF_HIP(hipStreamSynchronize(nullptr));
 }
@@ -523,7 +561,7 @@ void FeatureCache::init(hipStream_t stream) {
   cache_fill_kernel<<<dim3(1024), dim3(256), 0, stream>>>(
       map_.as<int32_t>(), num_ids_, slot_id_.as<int64_t>(), stamp_.as<uint32_t>(), capacity_, 1);
   GF_HIP(hipGetLastError());
-  GF_HIP(hipMemsetAsync(state_.data(), 0, 16, stream));
+  epoch_ = 0;
   if (capacity_)
     GF_HIP(hipMemcpyAsync(buffer_.data(), feats_, capacity_ * dim_ * sizeof(float),
                           hipMemcpyDefault, stream));
@@ -541,8 +579,7 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
   if (new_num_ids > num_ids_) {
     DeviceBuffer nmap;
     nmap.reserve(new_num_ids * sizeof(int32_t));
-    // new ids start uncached
-    std::vector<int32_t> tail(new_num_ids - num_ids_, kAbsent);
+    std::vector<int32_t> tail(new_num_ids - num_ids_, kAbsent);  // new ids start uncached
     GF_HIP(hipMemcpyAsync(nmap.data(), map_.data(), num_ids_ * sizeof(int32_t),
                           hipMemcpyDeviceToDevice, stream));
     GF_HIP(hipMemcpyAsync(nmap.as<int32_t>() + num_ids_, tail.data(),
@@ -570,15 +607,15 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
   }
   num_ids_ = new_num_ids;
   capacity_ = new_capacity;
+  ws_rows_ = 0;   // tile arrays depend on the capacity
 }
 
 void FeatureCache::reserve_workspace(size_t n) {
   if (n <= ws_rows_ && ws_.data()) return;
   ws_rows_ = std::max(ws_rows_, n);
   const size_t tiles = (capacity_ + kTile - 1) / kTile + 1;
-  size_t bytes = align_up(sizeof(Counters), 16) + 2 * kBins * sizeof(uint32_t) +
-                 4 * align_up(ws_rows_ * 4, 16) + align_up(ws_rows_ * 8, 16) +
-                 4 * align_up(tiles * 4, 16) + 64;
+  size_t bytes = (kBins1 + kBins2) * sizeof(uint32_t) + 4 * align_up(ws_rows_ * 4, 16) +
+                 2 * align_up(tiles * 4, 16) + 64;
   ws_.reserve(bytes, 0, nullptr);
 }
 
@@ -592,64 +629,130 @@ void FeatureCache::fetch(const int64_t* d_ids, size_t n, float* d_out, bool upda
   const size_t tiles = (capacity_ + kTile - 1) / kTile;
   Workspace w;
   char* p = ws_.as<char>();
-  w.ctr = reinterpret_cast<Counters*>(p);           p += align_up(sizeof(Counters), 16);
-  w.hist_hi = reinterpret_cast<uint32_t*>(p);       p += kBins * sizeof(uint32_t);
-  w.hist_lo = reinterpret_cast<uint32_t*>(p);       p += kBins * sizeof(uint32_t);
-  const size_t zero_bytes = p - ws_.as<char>();
+  w.hist1 = reinterpret_cast<uint32_t*>(p);         p += kBins1 * sizeof(uint32_t);
+  w.hist2 = reinterpret_cast<uint32_t*>(p);         p += kBins2 * sizeof(uint32_t);
   w.slot_of_row = reinterpret_cast<int32_t*>(p);    p += align_up(ws_rows_ * 4, 16);
   w.rep_flag = reinterpret_cast<uint32_t*>(p);      p += align_up(ws_rows_ * 4, 16);
   w.rep_rank = reinterpret_cast<uint32_t*>(p);      p += align_up(ws_rows_ * 4, 16);
   w.rep_row = reinterpret_cast<uint32_t*>(p);       p += align_up(ws_rows_ * 4, 16);
-  w.pairs = reinterpret_cast<uint2*>(p);            p += align_up(ws_rows_ * 8, 16);
   w.tile_tie = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
-  w.tile_old = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
-  w.tie_base = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
-  w.old_base = reinterpret_cast<uint32_t*>(p);
+  w.tile_old = reinterpret_cast<uint32_t*>(p);
 
-  GF_HIP(hipMemsetAsync(ws_.data(), 0, zero_bytes, stream));
+  // per-fetch counter record from a ring that is re-zeroed every kRing fetches
+  if (ring_pos_ % kRing == 0)
+    GF_HIP(hipMemsetAsync(state_.data(), 0, kRing * sizeof(Counters), stream));
+  Counters* ctr = state_.as<Counters>() + (ring_pos_ % kRing);
+  ring_pos_++;
+
+  const bool do_update = update && capacity_ > 0;
   launch_gather(d_ids, n, capacity_ ? map_.as<int32_t>() : nullptr, buffer_.as<float>(), feats_,
-                num_ids_, dim_, d_out, w.slot_of_row, w.ctr, d_stats, stream);
-  if (!update || capacity_ == 0) return;
+                num_ids_, dim_, d_out, w.slot_of_row, ctr, d_stats, do_update,
+                do_update ? w.hist1 : nullptr, do_update ? kBins1 + kBins2 : 0, stream);
+  if (!do_update) return;
 
   ProfileScope ps(kProfLru, stream);
   const uint32_t n32 = static_cast<uint32_t>(n), cap32 = static_cast<uint32_t>(capacity_);
-  uint32_t* epoch = state_.as<uint32_t>();
+  const uint32_t epoch_new = ++epoch_;
   const unsigned row_grid = static_cast<unsigned>((n + kThreads - 1) / kThreads);
   const unsigned slot_grid = static_cast<unsigned>(
-      std::max<size_t>(1, std::min<size_t>((std::max(n, capacity_) + kThreads - 1) / kThreads, 2048)));
+      std::max<size_t>(1, std::min<size_t>((capacity_ + 4 * kWide - 1) / (4 * kWide), 1024)));
+  const unsigned both_grid = static_cast<unsigned>(std::max<size_t>(
+      1, std::min<size_t>((std::max(n, capacity_) + 4 * kWide - 1) / (4 * kWide), 1024)));
   const unsigned tile_grid = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(tiles, 2048)));
-  lru_claim_kernel<<<dim3(row_grid), dim3(kThreads), 0, stream>>>(d_ids, n32, w.slot_of_row,
-                                                                  map_.as<int32_t>(), w.ctr);
   lru_mark_kernel<<<dim3(row_grid), dim3(kThreads), 0, stream>>>(
-      d_ids, n32, w.slot_of_row, map_.as<int32_t>(), stamp_.as<uint32_t>(), epoch, w.rep_flag,
-      w.ctr);
-  scan_u32_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
-      w.rep_flag, w.rep_rank, n32, &w.ctr->n_unique, nullptr, nullptr, w.ctr);
-  lru_rank_hist_kernel<<<dim3(slot_grid), dim3(kThreads), 0, stream>>>(
+      d_ids, n32, w.slot_of_row, map_.as<int32_t>(), stamp_.as<uint32_t>(), epoch_new,
+      w.rep_flag, ctr);
+  lru_scan_hist_kernel<<<dim3(1 + slot_grid), dim3(kWide), 0, stream>>>(
+      w.rep_flag, w.rep_rank, n32, stamp_.as<uint32_t>(), cap32, epoch_new, w.hist1, ctr);
+  lru_rank_hist2_kernel<<<dim3(both_grid), dim3(kWide), 0, stream>>>(
       d_ids, n32, w.rep_flag, w.rep_rank, w.rep_row, map_.as<int32_t>(), stamp_.as<uint32_t>(),
-      cap32, epoch, w.hist_hi, w.ctr);
-  lru_hist_lo_kernel<<<dim3(slot_grid), dim3(kThreads), 0, stream>>>(
-      stamp_.as<uint32_t>(), cap32, epoch, w.hist_hi, w.hist_lo, w.ctr);
-  lru_tie_count_kernel<<<dim3(tile_grid), dim3(kThreads), 0, stream>>>(
-      stamp_.as<uint32_t>(), cap32, epoch, w.hist_hi, w.hist_lo, w.tile_tie, w.tile_old, w.ctr);
-  scan_u32_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
-      w.tile_tie, w.tie_base, static_cast<uint32_t>(tiles), nullptr, w.tile_old, w.old_base,
-      w.ctr);
-  lru_install_kernel<<<dim3(tile_grid), dim3(kTile), 0, stream>>>(
-      d_ids, w.rep_row, map_.as<int32_t>(), slot_id_.as<int64_t>(), stamp_.as<uint32_t>(), cap32,
-      epoch, w.hist_hi, w.hist_lo, w.tie_base, w.old_base, w.pairs, w.ctr);
-  const unsigned copy_grid = static_cast<unsigned>(
-      std::max<size_t>(1, std::min<size_t>((std::min(n, capacity_) + 3) / 4, 4096)));
+      cap32, epoch_new, w.hist1, w.hist2, ctr);
+  lru_tile_count_kernel<<<dim3(tile_grid), dim3(kWide), 0, stream>>>(
+      stamp_.as<uint32_t>(), cap32, epoch_new, w.hist1, w.hist2, w.tile_tie, w.tile_old, ctr);
   if (vec4_ok(dim_, buffer_.data(), d_out, d_out)) {
-    lru_copy_rows_kernel<float4><<<dim3(copy_grid), dim3(kThreads), 0, stream>>>(
-        w.pairs, reinterpret_cast<const float4*>(d_out), buffer_.as<float4>(),
-        static_cast<uint32_t>(dim_ / 4), cap32, epoch, w.ctr);
+    lru_install_kernel<float4><<<dim3(tile_grid), dim3(kTile), 0, stream>>>(
+        d_ids, w.rep_row, map_.as<int32_t>(), slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
+        cap32, epoch_new, w.hist1, w.hist2, w.tile_tie, w.tile_old,
+        reinterpret_cast<const float4*>(d_out), buffer_.as<float4>(),
+        static_cast<uint32_t>(dim_ / 4), ctr);
   } else {
-    lru_copy_rows_kernel<float><<<dim3(copy_grid), dim3(kThreads), 0, stream>>>(
-        w.pairs, d_out, buffer_.as<float>(), static_cast<uint32_t>(dim_), cap32, epoch, w.ctr);
+    lru_install_kernel<float><<<dim3(tile_grid), dim3(kTile), 0, stream>>>(
+        d_ids, w.rep_row, map_.as<int32_t>(), slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
+        cap32, epoch_new, w.hist1, w.hist2, w.tile_tie, w.tile_old, d_out, buffer_.as<float>(),
+        static_cast<uint32_t>(dim_), ctr);
   }
-  lru_bump_epoch_kernel<<<dim3(1), dim3(1), 0, stream>>>(epoch, w.ctr);
   GF_HIP(hipGetLastError());
+}
+
+void FeatureCache::gather_plain(const int64_t* d_ids, size_t n, float* d_out,
+                                hipStream_t stream) {
+  gather_rows(feats_, num_ids_, dim_, d_ids, n, d_out, device_, stream);
+}
+
+hipStream_t FeatureCache::side_stream() {
+  if (!side_stream_) {
+    DeviceGuard dg(device_);
+    GF_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+    GF_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    GF_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  }
+  return side_stream_;
+}
+
+FeatureCache::~FeatureCache() {
+  if (side_stream_) {
+    (void)hipStreamSynchronize(side_stream_);
+    (void)hipEventDestroy(ev_fork_);
+    (void)hipEventDestroy(ev_join_);
+    (void)hipStreamDestroy(side_stream_);
+  }
+}
+
+// All feature fetches of one fetch_feature() call (cache.py:255-413) in one go.  The node
+// cache and the edge cache are independent, so the node blocks run on the node cache's
+// side stream while the edge blocks (which must stay ordered: each sees the LRU state the
+// previous one left) run on `stream`; fork/join with events, no host synchronisation.
+void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
+                  hipStream_t stream) {
+  GF_REQUIRE(descs != nullptr || n == 0, "fetch_blocks: null descriptors");
+  bool has_node = false, has_edge = false;
+  for (size_t i = 0; i < n; ++i) {
+    GF_REQUIRE(descs[i].kind >= 0 && descs[i].kind <= 2, "fetch_blocks: bad kind");
+    if (descs[i].kind == 0) {
+      GF_REQUIRE(node != nullptr, "fetch_blocks: node block without a node cache");
+      has_node = true;
+    } else {
+      GF_REQUIRE(edge != nullptr, "fetch_blocks: edge block without an edge cache");
+      has_edge = true;
+    }
+  }
+  const bool fork = has_node && has_edge;
+  hipStream_t node_stream = stream;
+  if (fork) {
+    DeviceGuard dg(node->device());
+    node_stream = node->side_stream();
+    GF_HIP(hipEventRecord(node->ev_fork_, stream));
+    GF_HIP(hipStreamWaitEvent(node_stream, node->ev_fork_, 0));
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (descs[i].kind == 0)
+      node->fetch(descs[i].d_ids, descs[i].n, descs[i].d_out, descs[i].update != 0,
+                  descs[i].d_stats, node_stream);
+  if (fork) {
+    DeviceGuard dg(node->device());
+    GF_HIP(hipEventRecord(node->ev_join_, node_stream));
+  }
+  for (size_t i = 0; i < n; ++i) {
+    if (descs[i].kind == 1)
+      edge->fetch(descs[i].d_ids, descs[i].n, descs[i].d_out, descs[i].update != 0,
+                  descs[i].d_stats, stream);
+    else if (descs[i].kind == 2)
+      edge->gather_plain(descs[i].d_ids, descs[i].n, descs[i].d_out, stream);
+  }
+  if (fork) {
+    DeviceGuard dg(node->device());
+    GF_HIP(hipStreamWaitEvent(stream, node->ev_join_, 0));
+  }
 }
 
 void FeatureCache::slot_ids(int64_t* out, size_t capacity) const {

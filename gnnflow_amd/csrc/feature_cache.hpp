@@ -15,14 +15,18 @@ void gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_
 class FeatureCache {
  public:
   FeatureCache(size_t num_ids, size_t capacity, size_t dim, const float* d_feats, int device);
-  ~FeatureCache() = default;
+  ~FeatureCache();
 
   void init(hipStream_t stream);
   void resize(size_t new_num_ids, size_t new_capacity, const float* d_feats, hipStream_t stream);
   void fetch(const int64_t* d_ids, size_t n, float* d_out, bool update, uint32_t* d_stats,
              hipStream_t stream);
+  void gather_plain(const int64_t* d_ids, size_t n, float* d_out, hipStream_t stream);
   void slot_ids(int64_t* out, size_t capacity) const;
   size_t mem_bytes() const;
+  int device() const { return device_; }
+  hipStream_t side_stream();
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
 
  private:
   void reserve_workspace(size_t n);
@@ -35,9 +39,15 @@ class FeatureCache {
   DeviceBuffer map_;       // int32[num_ids]               id -> slot (kAbsent if none)
   DeviceBuffer slot_id_;   // int64[capacity]              slot -> id (-1 empty)
   DeviceBuffer stamp_;     // uint32[capacity]             epoch of last touch
-  DeviceBuffer state_;     // uint32 epoch
+  DeviceBuffer state_;     // ring of per-fetch counter records
   DeviceBuffer ws_;        // per-fetch scratch
   size_t ws_rows_ = 0;
+  uint32_t epoch_ = 0;     // fetches with update so far (host side; kernel argument)
+  uint64_t ring_pos_ = 0;
+  hipStream_t side_stream_ = nullptr;
 };
+
+void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
+                  hipStream_t stream);
 
 }  // namespace gf

@@ -38,6 +38,13 @@ class MFGBlock:
     def device(self) -> torch.device:
         return self._row.device
 
+    def record_stream(self, stream):
+        """Marks the sampler output buffer behind this block as in use on `stream`
+        (needed when the block was sampled on a side stream, e.g. by a prefetch thread,
+        and is consumed on another one)."""
+        if self._keepalive is not None:
+            self._keepalive.record_stream(stream)
+
     def to(self, device, **kwargs):
         device = torch.device(device)
         if device == self.device:

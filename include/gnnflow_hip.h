@@ -183,9 +183,29 @@ GF_API int gf_cache_resize(gf_cache* c, size_t new_num_ids, size_t new_capacity,
  * served from the cache on a hit and from d_feats on a miss, then (update != 0
  * and at least one miss) the LRU replacement of lru_cache.py:121-201.
  * d_ids [n] int64 device, d_out [n, dim] float32 device.  d_stats (device,
- * 2 x uint32, may be NULL) receives {hits, n}; no host synchronisation. */
+ * 16 x uint32, zeroed by the caller, may be NULL) accumulates the block's hit count in
+ * the even words (8 shards; hits = sum of d_stats[0,2,..,14]) and n in d_stats[1]; no
+ * host synchronisation. */
 GF_API int gf_cache_fetch(gf_cache* c, const int64_t* d_ids, size_t n, float* d_out,
                           int update, uint32_t* d_stats, void* stream);
+
+/* All fetches of one Cache.fetch_feature() call (cache.py:255-413) in one call.
+ * kind 0: block of node ids through node_cache (srcdata['h'], cache.py:269-323);
+ * kind 1: block of edge ids through edge_cache (edata['f'], cache.py:326-400), executed
+ *         in array order; kind 2: cache-free gather from the edge feature table
+ *         (target_edge_features, cache.py:411).
+ * Node blocks run concurrently with the edge blocks on an internal side stream that is
+ * forked from / joined to `stream` with events. */
+typedef struct gf_fetch_desc {
+  int kind;
+  int update;
+  const int64_t* d_ids;
+  size_t n;
+  float* d_out;
+  uint32_t* d_stats;
+} gf_fetch_desc;
+GF_API int gf_cache_fetch_blocks(gf_cache* node_cache, gf_cache* edge_cache,
+                                 const gf_fetch_desc* descs, size_t n, void* stream);
 
 /* Cache-free gather, gnnflow/utils.py:465-474 prepare_input and
  * cache.py:411 `edge_feats[eid]`: out[i,:] = feats[ids[i],:]. */
