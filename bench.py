@@ -132,22 +132,14 @@ def main():
 
     # Software pipeline (the reference's training loop prefetches the next batch's
     # sample() on a Python thread, scripts/offline_edge_prediction.py:343-346,397-399):
-    # a worker thread samples batch i+1 on its own HIP stream while the main thread
-    # runs fetch_feature() of batch i.  Every batch still goes through the same calls.
-    from concurrent.futures import ThreadPoolExecutor
+    # batch i+1's sample() is enqueued on a side HIP stream (sample_async) before batch
+    # i's fetch_feature() is issued on the main stream, so the two overlap on the GPU.
+    # Every batch still goes through the same calls; nothing is skipped or cached.
     pipelined = cache is not None and not args.no_pipeline
-    pool = ThreadPoolExecutor(max_workers=1) if pipelined else None
     side = torch.cuda.Stream(device=dev) if pipelined else None
 
-    def sample_job(i):
-        torch.cuda.set_device(dev)
-        r, t, _ = dev_batches[i % len(dev_batches)]
-        with torch.cuda.stream(side):
-            return sampler.sample(r, t)
-
     def run_steps(first, count, on_step=None):
-        """Runs `count` steps starting at batch `first`; returns nothing, calls
-        on_step(mfgs) after each step."""
+        """Runs `count` steps starting at batch `first`; calls on_step(mfgs) after each."""
         if not pipelined:
             for i in range(first, first + count):
                 mfgs = step(i)
@@ -155,15 +147,18 @@ def main():
                     on_step(mfgs)
             return
         main = torch.cuda.current_stream(dev)
-        fut = pool.submit(sample_job, first)
+        nb = len(dev_batches)
+        pending = sampler.sample_async(dev_batches[first % nb][0], dev_batches[first % nb][1],
+                                       stream=side)
         for i in range(first, first + count):
-            mfgs = fut.result()
+            mfgs = pending.wait()
             if i + 1 < first + count:
-                fut = pool.submit(sample_job, i + 1)
+                r, t, _ = dev_batches[(i + 1) % nb]
+                pending = sampler.sample_async(r, t, stream=side)
             for mfg in mfgs:
                 for b in mfg:
                     b.record_stream(main)
-            cache.fetch_feature(mfgs, dev_batches[i % len(dev_batches)][2])
+            cache.fetch_feature(mfgs, dev_batches[i % nb][2])
             if on_step:
                 on_step(mfgs)
 

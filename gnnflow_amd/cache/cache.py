@@ -227,7 +227,22 @@ class Cache:
     def _ids(self, t) -> torch.Tensor:
         if not isinstance(t, torch.Tensor):
             t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.int64))
-        return t.to(self.device, torch.int64).contiguous()
+        if t.device != self.device or t.dtype != torch.int64 or not t.is_contiguous():
+            t = t.to(self.device, torch.int64).contiguous()
+        return t
+
+    def _stats_rows(self, n):
+        """n zeroed 16-word stats records from a ring that is re-zeroed when it wraps
+        (a torch.zeros per call is one more kernel launch on the critical path)."""
+        n = max(n, 1)
+        ring = getattr(self, "_stats_ring", None)
+        if ring is None or self._stats_pos + n > ring.shape[0]:
+            self._stats_ring = ring = torch.zeros((max(256, 4 * n), 16), dtype=torch.int32,
+                                                  device=self.device)
+            self._stats_pos = 0
+        rows = ring[self._stats_pos:self._stats_pos + n]
+        self._stats_pos += n
+        return rows
 
     def fetch_feature(self, mfgs: List[List], eid: Optional[np.ndarray] = None,
                       update_cache: bool = True, target_edge_features: bool = True):
@@ -254,7 +269,7 @@ class Cache:
         if not jobs:
             return mfgs
         with torch.cuda.device(self.device):
-            stats = torch.zeros((max(n_cached, 1), 16), dtype=torch.int32, device=self.device)
+            stats = self._stats_rows(n_cached)
             descs = (_capi.GfFetchDesc * len(jobs))()
             stats_ptr = stats.data_ptr()
             for i, (kind, ids, dim, store, key) in enumerate(jobs):

@@ -175,6 +175,17 @@ int gf_sampler_sample(gf_sampler* s, const int64_t* d_roots, const float* d_root
                    static_cast<hipStream_t>(stream));
   });
 }
+int gf_sampler_sample_begin(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
+                            size_t num_roots, void* d_out, size_t out_bytes, void* stream) {
+  return guarded([&] {
+    GF_S(s);
+    s->impl.sample_begin(d_roots, d_root_ts, num_roots, d_out, out_bytes,
+                         static_cast<hipStream_t>(stream));
+  });
+}
+int gf_sampler_sample_end(gf_sampler* s, gf_block* blocks) {
+  return guarded([&] { GF_S(s); s->impl.sample_end(blocks); });
+}
 int gf_sampler_sample_layer(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
                             size_t num_roots, uint32_t layer, uint32_t snapshot, void* d_out,
                             size_t out_bytes, gf_block* block, void* stream) {

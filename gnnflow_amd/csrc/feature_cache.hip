@@ -71,7 +71,9 @@ struct Shard {
 struct Counters {
   Shard shard[kShards];
   uint32_t n_unique;  // distinct missed ids
-  uint32_t pad[31];
+  uint32_t th_age;    // eviction threshold (written by the tile-count kernel)
+  uint32_t th_k_tie;
+  uint32_t pad[29];
 };
 __device__ inline uint32_t total_miss(const Counters* c) {
   uint32_t m = 0;
@@ -376,12 +378,15 @@ __global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(
 __global__ __launch_bounds__(kWide) void lru_tile_count_kernel(
     const uint32_t* __restrict__ stamp, uint32_t capacity, uint32_t epoch_new,
     const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ hist2,
-    uint32_t* __restrict__ tile_tie, uint32_t* __restrict__ tile_old,
-    const Counters* __restrict__ ctr) {
+    uint32_t* __restrict__ tile_tie, uint32_t* __restrict__ tile_old, Counters* ctr) {
   if (total_miss(ctr) == 0) return;
   __shared__ uint32_t cnt[2];
   const uint32_t k = min(ctr->n_unique, capacity);
   const Threshold th = find_threshold(hist1, hist2, k);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the install kernel reads it from here
+    ctr->th_age = th.age;
+    ctr->th_k_tie = th.k_tie;
+  }
   const uint32_t tiles = (capacity + kTile - 1) / kTile;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
@@ -408,9 +413,8 @@ template <typename VecT>
 __global__ __launch_bounds__(kTile) void lru_install_kernel(
     const int64_t* __restrict__ ids, const uint32_t* __restrict__ rep_row, int32_t* map,
     int64_t* __restrict__ slot_id, uint32_t* __restrict__ stamp, uint32_t capacity,
-    uint32_t epoch_new, const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ hist2,
-    const uint32_t* __restrict__ tile_tie, const uint32_t* __restrict__ tile_old,
-    const VecT* __restrict__ out, VecT* __restrict__ cache_buf, uint32_t dimv,
+    uint32_t epoch_new, const uint32_t* __restrict__ tile_tie,
+    const uint32_t* __restrict__ tile_old, const VecT* __restrict__ out, VecT* __restrict__ cache_buf, uint32_t dimv,
     const Counters* __restrict__ ctr) {
   if (total_miss(ctr) == 0) return;
   __shared__ uint32_t wave_tie[kTile / 64];
@@ -419,7 +423,9 @@ __global__ __launch_bounds__(kTile) void lru_install_kernel(
   __shared__ uint2 inst[kTile];   // {slot, row} of this tile's installs
   __shared__ uint32_t n_inst;
   const uint32_t k = min(ctr->n_unique, capacity);
-  const Threshold th = find_threshold(hist1, hist2, k);
+  Threshold th;
+  th.age = ctr->th_age;
+  th.k_tie = ctr->th_k_tie;
   const uint32_t tiles = (capacity + kTile - 1) / kTile;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -672,13 +678,13 @@ void FeatureCache::fetch(const int64_t* d_ids, size_t n, float* d_out, bool upda
   if (vec4_ok(dim_, buffer_.data(), d_out, d_out)) {
     lru_install_kernel<float4><<<dim3(tile_grid), dim3(kTile), 0, stream>>>(
         d_ids, w.rep_row, map_.as<int32_t>(), slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
-        cap32, epoch_new, w.hist1, w.hist2, w.tile_tie, w.tile_old,
+        cap32, epoch_new, w.tile_tie, w.tile_old,
         reinterpret_cast<const float4*>(d_out), buffer_.as<float4>(),
         static_cast<uint32_t>(dim_ / 4), ctr);
   } else {
     lru_install_kernel<float><<<dim3(tile_grid), dim3(kTile), 0, stream>>>(
         d_ids, w.rep_row, map_.as<int32_t>(), slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
-        cap32, epoch_new, w.hist1, w.hist2, w.tile_tie, w.tile_old, d_out, buffer_.as<float>(),
+        cap32, epoch_new, w.tile_tie, w.tile_old, d_out, buffer_.as<float>(),
         static_cast<uint32_t>(dim_), ctr);
   }
   GF_HIP(hipGetLastError());

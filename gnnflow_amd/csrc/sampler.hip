@@ -46,6 +46,7 @@ constexpr int kSearchThreads = 256;
 constexpr int kEmitThreads = 256;
 constexpr int kScanThreads = 1024;
 constexpr int kScanItems = 4;  // per thread per tile
+constexpr size_t kSmallRoots = 32768;  // layers up to this many roots skip the scan launch
 
 // sampling_kernels.cu:28-40
 __device__ inline void time_window(float root_ts, uint32_t snapshot_idx,
@@ -94,13 +95,24 @@ __device__ inline uint32_t lower_bound_group(const float* __restrict__ ts, uint3
   return lo + group_count<GROUP>(less, group_in_wave);
 }
 
+__device__ inline uint32_t valid_slots(uint32_t n_cand, uint32_t fanout, int uniform) {
+  // recent: slot j valid iff j < #candidates (sampling_kernels.cu:88-104);
+  // uniform: every slot valid iff there is a candidate (:202, with replacement)
+  if (uniform) return n_cand ? fanout : 0u;
+  return n_cand < fanout ? n_cand : fanout;
+}
+
 // ---- 1. search --------------------------------------------------------------------
 template <int GROUP>
 __global__ __launch_bounds__(kSearchThreads) void sample_search_kernel(
     GraphView g, const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
     const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t snapshot_idx,
     uint32_t num_snapshots, float window, uint64_t* __restrict__ rec_end,
-    uint32_t* __restrict__ rec_cnt) {
+    uint32_t* __restrict__ rec_cnt, uint32_t fanout, int uniform,
+    uint32_t* __restrict__ wg_sum) {
+  __shared__ uint32_t s_sum;
+  if (wg_sum && threadIdx.x == 0) s_sum = 0;
+  if (wg_sum) __syncthreads();
   const uint64_t R = d_R ? *d_R : R_host;
   constexpr int kGroupsPerBlock = kSearchThreads / GROUP;
   const int lane = threadIdx.x % GROUP;
@@ -129,18 +141,19 @@ __global__ __launch_bounds__(kSearchThreads) void sample_search_kernel(
     if (lane == 0) {
       rec_end[r] = end_off;
       rec_cnt[r] = n_cand;
+      if (wg_sum) atomicAdd(&s_sum, valid_slots(n_cand, fanout, uniform));
     }
+  }
+  // small-batch path: the grid covers every root exactly once (no striding), so
+  // workgroup b owns roots [b*kGroupsPerBlock, (b+1)*kGroupsPerBlock) and publishes
+  // their valid-slot total for the emit kernel's prefix
+  if (wg_sum) {
+    __syncthreads();
+    if (threadIdx.x == 0) wg_sum[blockIdx.x] = s_sum;
   }
 }
 
 // ---- 2. scan -----------------------------------------------------------------------
-__device__ inline uint32_t valid_slots(uint32_t n_cand, uint32_t fanout, int uniform) {
-  // recent: slot j valid iff j < #candidates (sampling_kernels.cu:88-104);
-  // uniform: every slot valid iff there is a candidate (:202, with replacement)
-  if (uniform) return n_cand ? fanout : 0u;
-  return n_cand < fanout ? n_cand : fanout;
-}
-
 __global__ __launch_bounds__(kScanThreads) void sample_scan_kernel(
     const uint32_t* __restrict__ rec_cnt, uint32_t* __restrict__ base,
     const uint64_t* d_R, uint64_t R_host, uint32_t fanout, int uniform, uint64_t* out_R,
@@ -226,6 +239,91 @@ __global__ __launch_bounds__(kEmitThreads) void sample_emit_kernel(
   }
 }
 
+// ---- 2+3 fused (small batches): emit with an in-kernel prefix -----------------------
+// For layers with at most kSmallRoots roots the separate scan launch is dropped: every
+// emit workgroup derives the compacted base of its first root from the search kernel's
+// per-workgroup sums (a few hundred to a few thousand L2-resident words), scans its own
+// <= 256 roots in LDS, and the workgroup owning the last slot publishes S and R' = R + S.
+__global__ __launch_bounds__(kEmitThreads) void sample_emit_prefix_kernel(
+    GraphView g, const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
+    const uint64_t* d_R, uint64_t R_host, uint32_t fanout, int uniform, int prop_time,
+    uint64_t seed, uint64_t call, const uint64_t* __restrict__ rec_end,
+    const uint32_t* __restrict__ rec_cnt, const uint32_t* __restrict__ wg_sum,
+    uint32_t roots_per_search_wg, int64_t* __restrict__ all_nodes, float* __restrict__ all_ts,
+    float* __restrict__ dt, int64_t* __restrict__ eids, int64_t* __restrict__ row,
+    int64_t* __restrict__ col, uint64_t* out_R, uint64_t* out_S, uint64_t* next_R) {
+  __shared__ uint32_t red[kEmitThreads / 64];
+  __shared__ uint32_t lbase[kEmitThreads];
+  __shared__ uint32_t wave_tot[kEmitThreads / 64];
+  const uint64_t R = d_R ? *d_R : R_host;
+  const uint64_t total = R * fanout;
+  const uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kEmitThreads;
+  if (t0 >= total) return;   // uniform for the workgroup
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t t_last = min(t0 + kEmitThreads - 1, total - 1);
+  const uint32_t r_first = static_cast<uint32_t>(t0 / fanout);
+  const uint32_t r_last = static_cast<uint32_t>(t_last / fanout);
+  const uint32_t nroots = r_last - r_first + 1;   // <= kEmitThreads
+  // 1. base of r_first = search-workgroup sums before it + the remainder inside its group
+  const uint32_t b_first = r_first / roots_per_search_wg;
+  uint32_t part = 0;
+  for (uint32_t b = tid; b < b_first; b += kEmitThreads) part += wg_sum[b];
+  for (uint32_t r = b_first * roots_per_search_wg + tid; r < r_first; r += kEmitThreads)
+    part += valid_slots(rec_cnt[r], fanout, uniform);
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+  if (lane == 0) red[wave] = part;
+  // 2. exclusive scan of this workgroup's own roots
+  const uint32_t mine = tid < static_cast<int>(nroots)
+                            ? valid_slots(rec_cnt[r_first + tid], fanout, uniform) : 0u;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+#pragma unroll
+  for (int w = 0; w < kEmitThreads / 64; ++w) base += red[w];
+  uint32_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+  lbase[tid] = base + wbase + incl - mine;
+  __syncthreads();
+  // 3. emit
+  const uint64_t t = t0 + tid;
+  if (t < total) {
+    if (t < R) {
+      all_nodes[t] = roots[t];
+      all_ts[t] = root_ts[t];
+    }
+    const uint32_t r = static_cast<uint32_t>(t / fanout);
+    const uint32_t j = static_cast<uint32_t>(t - static_cast<uint64_t>(r) * fanout);
+    const uint32_t n = rec_cnt[r];
+    if (j < valid_slots(n, fanout, uniform)) {
+      const uint32_t pick = uniform ? gf_philox4x32_10_first(seed, t, call) % n : j;
+      const uint64_t e = rec_end[r] - 1 - pick;
+      const float ets = g.ts_pool[e];
+      const EdgePair nb = g.nbr_pool[e];
+      const float rts = root_ts[r];
+      const uint64_t o = static_cast<uint64_t>(lbase[r - r_first]) + j;
+      all_nodes[R + o] = nb.dst;
+      all_ts[R + o] = prop_time ? rts : ets;
+      dt[o] = rts - ets;
+      eids[o] = nb.eid;
+      row[o] = static_cast<int64_t>(r);
+      col[o] = static_cast<int64_t>(R + o);
+    }
+  }
+  // 4. the workgroup that owns the last slot knows the layer's edge count
+  if (t_last == total - 1 && tid == static_cast<int>(nroots) - 1) {
+    const uint64_t S = static_cast<uint64_t>(lbase[tid]) + mine;
+    *out_R = R;
+    *out_S = S;
+    if (next_R) *next_R = R + S;
+  }
+}
+
 inline unsigned capped_grid(uint64_t work_items, unsigned per_block, unsigned cap) {
   uint64_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -259,11 +357,17 @@ Sampler::Sampler(EdgeStore* graph, const uint32_t* fanouts, size_t num_layers, i
              "sampler: invalid sampling policy");
   GF_REQUIRE(num_snapshots >= 1, "sampler: num_snapshots must be >= 1");
   search_group_ = search_group_width_from_env();
+  {
+    const char* v = std::getenv("GNNFLOW_SAMPLER_FUSED_SCAN");
+    fused_scan_ = !(v && std::atoi(v) == 0);
+  }
+  GF_HIP(hipEventCreateWithFlags(&done_ev_, hipEventDisableTiming));
   DeviceGuard dg(graph_->device());
   GF_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
 }
 
 Sampler::~Sampler() {
+  if (done_ev_) (void)hipEventDestroy(done_ev_);
   if (own_stream_) {
     (void)hipStreamSynchronize(own_stream_);
     (void)hipStreamDestroy(own_stream_);
@@ -306,7 +410,7 @@ void Sampler::reserve_workspace(size_t Rb, size_t num_blocks, hipStream_t stream
   if (Rb <= ws_roots_ && num_blocks <= ws_blocks_) return;
   ws_roots_ = std::max(ws_roots_, Rb);
   ws_blocks_ = std::max(ws_blocks_, num_blocks);
-  size_t bytes = align_up(ws_roots_ * 8, 16) + 2 * align_up(ws_roots_ * 4, 16) +
+  size_t bytes = align_up(ws_roots_ * 8, 16) + 3 * align_up(ws_roots_ * 4, 16) +
                  ws_blocks_ * 2 * sizeof(uint64_t) + 64;
   (void)stream;
   ws_.reserve(bytes, 0, nullptr);
@@ -324,21 +428,38 @@ void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb
   char* w = ws_.as<char>();
   uint64_t* rec_end = reinterpret_cast<uint64_t*>(w); w += align_up(ws_roots_ * 8, 16);
   uint32_t* rec_cnt = reinterpret_cast<uint32_t*>(w); w += align_up(ws_roots_ * 4, 16);
-  uint32_t* base = reinterpret_cast<uint32_t*>(w);
+  uint32_t* base = reinterpret_cast<uint32_t*>(w);    w += align_up(ws_roots_ * 4, 16);
+  uint32_t* wg_sum = reinterpret_cast<uint32_t*>(w);
   const GraphView gv = graph_->view();
   const uint64_t call = calls_++;
+  // small layers: search publishes per-workgroup sums and emit does its own prefix
+  const bool small = fused_scan_ && Rb <= kSmallRoots;
+  const unsigned roots_per_wg = kSearchThreads / search_group_;
   {
     ProfileScope ps(kProfSearch, stream);
+    const unsigned grid = small ? static_cast<unsigned>((Rb + roots_per_wg - 1) / roots_per_wg)
+                                : capped_grid(Rb, roots_per_wg, 256 * 8);
     if (search_group_ == 64) {
-      unsigned grid = capped_grid(Rb, kSearchThreads / 64, 256 * 8);
       sample_search_kernel<64><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(
-          gv, d_roots, d_ts, d_R, R_host, snapshot, num_snapshots_, window_, rec_end, rec_cnt);
+          gv, d_roots, d_ts, d_R, R_host, snapshot, num_snapshots_, window_, rec_end, rec_cnt, F,
+          uniform, small ? wg_sum : nullptr);
     } else {
-      unsigned grid = capped_grid(Rb, kSearchThreads / 16, 256 * 8);
       sample_search_kernel<16><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(
-          gv, d_roots, d_ts, d_R, R_host, snapshot, num_snapshots_, window_, rec_end, rec_cnt);
+          gv, d_roots, d_ts, d_R, R_host, snapshot, num_snapshots_, window_, rec_end, rec_cnt, F,
+          uniform, small ? wg_sum : nullptr);
     }
     GF_HIP(hipGetLastError());
+  }
+  if (small) {
+    ProfileScope ps(kProfEmit, stream);
+    const unsigned grid = static_cast<unsigned>(
+        (static_cast<uint64_t>(Rb) * F + kEmitThreads - 1) / kEmitThreads);
+    sample_emit_prefix_kernel<<<dim3(grid), dim3(kEmitThreads), 0, stream>>>(
+        gv, d_roots, d_ts, d_R, R_host, F, uniform, prop_time_ ? 1 : 0, seed_, call, rec_end,
+        rec_cnt, wg_sum, roots_per_wg, out.all_nodes, out.all_ts, out.dt, out.eids, out.row,
+        out.col, d_counts_slot, d_counts_slot + 1, next_R);
+    GF_HIP(hipGetLastError());
+    return;
   }
   {
     ProfileScope ps(kProfScan, stream);
@@ -356,14 +477,19 @@ void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb
   }
 }
 
-// TemporalSampler::Sample, temporal_sampler.cu:279-305
-void Sampler::sample(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
-                     size_t out_bytes, gf_block* blocks, hipStream_t stream) {
+// TemporalSampler::Sample, temporal_sampler.cu:279-305 — split in two so a caller can
+// overlap the sampling of batch i+1 (on its own stream) with other work on batch i:
+// begin() enqueues every kernel plus the size read-back and returns; end() waits on the
+// completion event and reports the block sizes.
+void Sampler::sample_begin(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
+                           size_t out_bytes, hipStream_t stream) {
   const size_t L = fanouts_.size(), NS = num_snapshots_;
-  GF_REQUIRE(blocks != nullptr, "sample: null blocks array");
+  GF_REQUIRE(!pending_, "sample_begin: a sample is already in flight on this sampler");
+  pending_ptrs_.assign(L * NS, BlockPtrs{});
+  pending_roots_ = R;
   if (R == 0) {  // temporal_sampler.cu:107-114
-    for (size_t b = 0; b < L * NS; ++b) std::memset(&blocks[b], 0, sizeof(gf_block));
     calls_ += L * NS;
+    pending_ = true;
     return;
   }
   GF_REQUIRE(d_roots && d_ts && d_out, "sample: null device pointer");
@@ -371,9 +497,9 @@ void Sampler::sample(const int64_t* d_roots, const float* d_ts, size_t R, void* 
   DeviceGuard dg(graph_->device());
   reserve_workspace(root_bound(R, L - 1), L * NS, stream);
   uint64_t* d_counts = reinterpret_cast<uint64_t*>(
-      ws_.as<char>() + align_up(ws_roots_ * 8, 16) + 2 * align_up(ws_roots_ * 4, 16));
+      ws_.as<char>() + align_up(ws_roots_ * 8, 16) + 3 * align_up(ws_roots_ * 4, 16));
 
-  std::vector<BlockPtrs> ptrs(L * NS);
+  std::vector<BlockPtrs>& ptrs = pending_ptrs_;
   char* p = static_cast<char*>(d_out);
   for (size_t l = 0; l < L; ++l) {
     const size_t Rb = root_bound(R, l);
@@ -400,20 +526,41 @@ void Sampler::sample(const int64_t* d_roots, const float* d_ts, size_t R, void* 
   }
   GF_HIP(hipMemcpyAsync(h_counts_.data(), d_counts, L * NS * 2 * sizeof(uint64_t),
                         hipMemcpyDeviceToHost, stream));
-  GF_HIP(hipStreamSynchronize(stream));
+  GF_HIP(hipEventRecord(done_ev_, stream));
+  pending_ = true;
+}
+
+void Sampler::sample_end(gf_block* blocks) {
+  const size_t L = fanouts_.size(), NS = num_snapshots_;
+  GF_REQUIRE(blocks != nullptr, "sample: null blocks array");
+  GF_REQUIRE(pending_, "sample_end: no sample in flight");
+  pending_ = false;
+  if (pending_roots_ == 0) {
+    for (size_t b = 0; b < L * NS; ++b) std::memset(&blocks[b], 0, sizeof(gf_block));
+    return;
+  }
+  DeviceGuard dg(graph_->device());
+  GF_HIP(hipEventSynchronize(done_ev_));
   const uint64_t* hc = h_counts_.as<uint64_t>();
   for (size_t b = 0; b < L * NS; ++b) {
     gf_block& o = blocks[b];
-    o.all_nodes = ptrs[b].all_nodes;
-    o.all_timestamps = ptrs[b].all_ts;
-    o.delta_timestamps = ptrs[b].dt;
-    o.eids = ptrs[b].eids;
-    o.row = ptrs[b].row;
-    o.col = ptrs[b].col;
+    o.all_nodes = pending_ptrs_[b].all_nodes;
+    o.all_timestamps = pending_ptrs_[b].all_ts;
+    o.delta_timestamps = pending_ptrs_[b].dt;
+    o.eids = pending_ptrs_[b].eids;
+    o.row = pending_ptrs_[b].row;
+    o.col = pending_ptrs_[b].col;
     o.num_dst_nodes = hc[2 * b];
     o.num_edges = hc[2 * b + 1];
     o.num_src_nodes = o.num_dst_nodes + o.num_edges;
   }
+}
+
+void Sampler::sample(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
+                     size_t out_bytes, gf_block* blocks, hipStream_t stream) {
+  GF_REQUIRE(blocks != nullptr, "sample: null blocks array");
+  sample_begin(d_roots, d_ts, R, d_out, out_bytes, stream);
+  sample_end(blocks);
 }
 
 // TemporalSampler::SampleLayer, temporal_sampler.cu:97-277
@@ -433,7 +580,7 @@ void Sampler::sample_layer(const int64_t* d_roots, const float* d_ts, size_t R, 
   DeviceGuard dg(graph_->device());
   reserve_workspace(R, 2, stream);
   uint64_t* d_counts = reinterpret_cast<uint64_t*>(
-      ws_.as<char>() + align_up(ws_roots_ * 8, 16) + 2 * align_up(ws_roots_ * 4, 16));
+      ws_.as<char>() + align_up(ws_roots_ * 8, 16) + 3 * align_up(ws_roots_ * 4, 16));
   BlockPtrs ptrs = carve(static_cast<char*>(d_out), R, fanouts_[layer]);
   enqueue_layer(d_roots, d_ts, R, nullptr, R, layer, snapshot, ptrs, d_counts, nullptr, stream);
   GF_HIP(hipMemcpyAsync(h_counts_.data(), d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost,

@@ -27,6 +27,9 @@ class Sampler {
 
   void sample(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
               size_t out_bytes, gf_block* blocks, hipStream_t stream);
+  void sample_begin(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
+                    size_t out_bytes, hipStream_t stream);
+  void sample_end(gf_block* blocks);
   void sample_layer(const int64_t* d_roots, const float* d_ts, size_t R, uint32_t layer,
                     uint32_t snapshot, void* d_out, size_t out_bytes, gf_block* block,
                     hipStream_t stream);
@@ -57,6 +60,11 @@ class Sampler {
   uint64_t seed_;
   uint64_t calls_ = 0;  // sample_layer invocations so far (uniform RNG counter)
   int search_group_ = 16;
+  bool fused_scan_ = true;
+  hipEvent_t done_ev_ = nullptr;
+  bool pending_ = false;
+  size_t pending_roots_ = 0;
+  std::vector<BlockPtrs> pending_ptrs_;
 
   DeviceBuffer ws_;        // per-root search records + scan scratch + counters
   size_t ws_roots_ = 0, ws_blocks_ = 0;

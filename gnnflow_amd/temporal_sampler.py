@@ -31,6 +31,20 @@ class SamplingResult:
     def block(self) -> MFGBlock: return self._b
 
 
+class PendingSample:
+    """Handle of an in-flight TemporalSampler.sample_async()."""
+
+    def __init__(self, sampler, buf, inputs, num_roots):
+        self._sampler, self._buf, self._inputs, self._R = sampler, buf, inputs, num_roots
+        self._result = None
+
+    def wait(self) -> List[List[MFGBlock]]:
+        if self._result is None:
+            self._result = self._sampler._finish(self._buf, self._R)
+            self._inputs = None
+        return self._result
+
+
 class TemporalSampler:
     """
     TemporalSampler samples k-hop multi-snapshots neighbors of given vertices.
@@ -69,7 +83,10 @@ class TemporalSampler:
     # ---- helpers ------------------------------------------------------------------
     def _to_device(self, target_vertices, timestamps):
         if isinstance(target_vertices, torch.Tensor):
-            nodes = target_vertices.to(self._device, torch.int64).contiguous()
+            nodes = target_vertices
+            if nodes.device != self._device or nodes.dtype != torch.int64 \
+                    or not nodes.is_contiguous():
+                nodes = nodes.to(self._device, torch.int64).contiguous()
         else:
             nodes = torch.from_numpy(
                 np.ascontiguousarray(target_vertices, dtype=np.int64)).to(self._device)
@@ -78,7 +95,10 @@ class TemporalSampler:
             ts = torch.full((nodes.shape[0],), float(np.finfo(np.float32).max),
                             dtype=torch.float32, device=self._device)
         elif isinstance(timestamps, torch.Tensor):
-            ts = timestamps.to(self._device, torch.float32).contiguous()
+            ts = timestamps
+            if ts.device != self._device or ts.dtype != torch.float32 \
+                    or not ts.is_contiguous():
+                ts = ts.to(self._device, torch.float32).contiguous()
         else:
             ts = torch.from_numpy(
                 np.ascontiguousarray(timestamps, dtype=np.float32)).to(self._device)
@@ -93,17 +113,23 @@ class TemporalSampler:
         return buf[off:off + count * itemsize].view(dtype)
 
     def _block(self, buf, gb) -> MFGBlock:
+        """MFG over one gf_block; the tensor views into `buf` are built on first access."""
         base = buf.data_ptr()
         ns, ne = gb.num_src_nodes, gb.num_edges
         if gb.all_nodes is None:
             raise RuntimeError("sampler returned a null block")
+        view = self._view
+        i64, f32 = torch.int64, torch.float32
+        col_p, row_p = gb.col, gb.row
+        nodes_p, ts_p, dt_p, eid_p = gb.all_nodes, gb.all_timestamps, gb.delta_timestamps, gb.eids
         b = MFGBlock(ns, gb.num_dst_nodes,
-                     self._view(buf, base, gb.col, ne, torch.int64, 8),
-                     self._view(buf, base, gb.row, ne, torch.int64, 8), keepalive=buf)
-        b.srcdata['ID'] = self._view(buf, base, gb.all_nodes, ns, torch.int64, 8)
-        b.srcdata['ts'] = self._view(buf, base, gb.all_timestamps, ns, torch.float32, 4)
-        b.edata['dt'] = self._view(buf, base, gb.delta_timestamps, ne, torch.float32, 4)
-        b.edata['ID'] = self._view(buf, base, gb.eids, ne, torch.int64, 8)
+                     lambda: view(buf, base, col_p, ne, i64, 8),
+                     lambda: view(buf, base, row_p, ne, i64, 8),
+                     keepalive=buf, num_edges=ne, device=self._device)
+        b.srcdata.set_lazy('ID', lambda: view(buf, base, nodes_p, ns, i64, 8))
+        b.srcdata.set_lazy('ts', lambda: view(buf, base, ts_p, ns, f32, 4))
+        b.edata.set_lazy('dt', lambda: view(buf, base, dt_p, ne, f32, 4))
+        b.edata.set_lazy('ID', lambda: view(buf, base, eid_p, ne, i64, 8))
         return b
 
     def _empty_block(self) -> MFGBlock:
@@ -127,30 +153,42 @@ class TemporalSampler:
             mfgs[0] is the last-sampled (largest) layer, mfgs[-1] the roots' layer
             (gnnflow/temporal_sampler.py:149-165).
         """
+        return self.sample_async(target_vertices, timestamps).wait()
+
+    def sample_async(self, target_vertices, timestamps, stream=None) -> "PendingSample":
+        """Enqueues sample() on `stream` (default: the current stream) and returns at
+        once; `.wait()` blocks until the kernels finished and returns the MFGs.  Lets a
+        single Python thread overlap the sampling of batch i+1 with the feature fetch /
+        training of batch i (the reference uses a prefetch thread for this,
+        scripts/offline_edge_prediction.py:343-346).  One sample in flight per sampler."""
         nodes, ts = self._to_device(target_vertices, timestamps)
         R = int(nodes.shape[0])
+        if stream is None:
+            stream = torch.cuda.current_stream(self._device)
+        buf, nbytes = None, 0
+        if R:
+            nbytes = self._bytes_cache.get(R)
+            if nbytes is None:
+                n = C.c_size_t(0)
+                _capi.check(self._lib.gf_sampler_output_bytes(self._h, R, C.byref(n)))
+                nbytes = self._bytes_cache[R] = n.value
+            with torch.cuda.stream(stream):
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=self._device)
+        _capi.check(self._lib.gf_sampler_sample_begin(
+            self._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
+            buf.data_ptr() if R else None, nbytes, C.c_void_p(stream.cuda_stream)))
+        return PendingSample(self, buf, (nodes, ts), R)
+
+    def _finish(self, buf, R) -> List[List[MFGBlock]]:
         nblocks = self._num_layers * self._num_snapshots
         blocks = (_capi.GfBlock * nblocks)()
+        _capi.check(self._lib.gf_sampler_sample_end(self._h, blocks))
         if R == 0:
-            _capi.check(self._lib.gf_sampler_sample(self._h, None, None, 0, None, 0, blocks,
-                                                    self._stream()))
-            mfgs = [[self._empty_block() for _ in range(self._num_snapshots)]
+            return [[self._empty_block() for _ in range(self._num_snapshots)]
                     for _ in range(self._num_layers)]
-            return mfgs
-        nbytes = self._bytes_cache.get(R)
-        if nbytes is None:
-            n = C.c_size_t(0)
-            _capi.check(self._lib.gf_sampler_output_bytes(self._h, R, C.byref(n)))
-            nbytes = self._bytes_cache[R] = n.value
-        with torch.cuda.device(self._device):
-            buf = torch.empty(nbytes, dtype=torch.uint8, device=self._device)
-            _capi.check(self._lib.gf_sampler_sample(
-                self._h, nodes.data_ptr(), ts.data_ptr(), R, buf.data_ptr(), nbytes, blocks,
-                self._stream()))
-        mfgs = []
-        for layer in range(self._num_layers):
-            mfgs.append([self._block(buf, blocks[layer * self._num_snapshots + s])
-                         for s in range(self._num_snapshots)])
+        ns = self._num_snapshots
+        mfgs = [[self._block(buf, blocks[layer * ns + s]) for s in range(ns)]
+                for layer in range(self._num_layers)]
         mfgs.reverse()
         return mfgs
 

@@ -142,6 +142,15 @@ GF_API int gf_sampler_sample(gf_sampler* s, const int64_t* d_roots, const float*
                              size_t num_roots, void* d_out, size_t out_bytes,
                              gf_block* blocks, void* stream);
 
+/* The same call split in two, for software pipelining (the reference overlaps the next
+ * batch's sample() with training on a Python thread, scripts/offline_edge_prediction.py:
+ * 343-346): begin enqueues everything on `stream` and returns without waiting; end waits
+ * for that work and fills `blocks`.  One sample may be in flight per sampler. */
+GF_API int gf_sampler_sample_begin(gf_sampler* s, const int64_t* d_roots,
+                                   const float* d_root_ts, size_t num_roots, void* d_out,
+                                   size_t out_bytes, void* stream);
+GF_API int gf_sampler_sample_end(gf_sampler* s, gf_block* blocks);
+
 /* _TemporalSampler.sample_layer (api.cc:119-120 -> TemporalSampler::SampleLayer,
  * temporal_sampler.cu:97-277), device resident; *bytes variant sizes the buffer. */
 GF_API int gf_sampler_layer_output_bytes(const gf_sampler* s, size_t num_roots,
