@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--sample-only", action="store_true",
                     help="time sample() alone (no feature gather)")
+    ap.add_argument("--partition", default="replica", choices=["replica", "hash"],
+                    help="multi-GPU mode: per-GPU replicas of the graph (default; what the "
+                         "reference does inside one machine) or hash-partitioned shards with "
+                         "an all-to-all exchange per layer (gnnflow_amd/dist.py)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap batch i+1's sample() with batch i's fetch_feature()")
     ap.add_argument("--breakdown", action="store_true",
@@ -78,9 +82,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.partition == "hash":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     assert world == args.gpus, "--gpus must match the launched world size"
 
     import gnnflow_amd
@@ -96,12 +101,23 @@ def main():
     graph = gnnflow_amd.DynamicGraph(20 * MiB, 1000 * MiB, "cuda", 62, 1024, "insert",
                                      device=local_rank)
     t0 = time.time()
+    ingest = graph
+    if args.partition == "hash":
+        from gnnflow_amd.dist import PartitionedGraph, PartitionedSampler
+        ingest = PartitionedGraph(graph, rank, world)
     for lo in range(0, g["num_edges"], 100000):   # benchmark_sampler.py:56-63
         hi = lo + 100000
-        graph.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
-                        add_reverse=args.undirected)
+        ingest.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
+                         add_reverse=args.undirected)
     build_s = time.time() - t0
     sampler = gnnflow_amd.TemporalSampler(graph, fanouts, args.strategy, seed=1234)
+    if args.partition == "hash":
+        # every rank owns a shard; roots are exchanged with two all-to-all-v per layer
+        local = sampler
+        sampler = PartitionedSampler(
+            lambda n, t, layer, snap: local.sample_layer(n, t, layer, snap),
+            len(fanouts), 1, device=dev)
+        args.no_pipeline = True
 
     gen = torch.Generator(device=dev).manual_seed(42)
     edge_feats = torch.rand((g["num_edges"], d_e), generator=gen, device=dev)
@@ -232,7 +248,7 @@ def main():
             "edges_per_step": edges / max(args.steps, 1),
             "feature_placement": args.feature_placement,
             "graph_build_s": round(build_s, 3),
-            "parallelism": "replica-dp{}".format(world),
+            "parallelism": "{}-dp{}".format(args.partition, world),
             "pipelined": bool(pipelined),
         },
     }
@@ -268,7 +284,7 @@ def main():
                                            node_feats.cpu().numpy(), cache is not None)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -63,5 +63,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def pybind_module_path() -> str:
+    import sysconfig
+    return os.path.join(CSRC, "libgnnflow" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind(force: bool = False) -> str:
+    """Builds the pybind11 module `libgnnflow` (the reference's native module name and
+    surface, gnnflow/csrc/api.cc) over the C ABI; plain g++, links libgnnflow_hip.so."""
+    import sysconfig
+    import pybind11
+    build()
+    out = pybind_module_path()
+    src = os.path.join(CSRC, "pybind_libgnnflow.cpp")
+    hdr = os.path.join(CSRC, "..", "..", "include", "gnnflow_hip.h")
+    if not force and not _newer(out, [src, hdr, LIB]):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+           "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include(),
+           src, "-o", out, "-L" + CSRC, "-lgnnflow_hip", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_pybind(force="--force" in sys.argv))

@@ -1,0 +1,209 @@
+"""Hash-partitioned sampling across the GPUs of one node.
+
+The reference partitions the graph by source vertex across *machines* and samples remote
+roots through torch RPC (gnnflow/distributed/dist_sampler.py:159-242, merge at :244-314).
+Here the partitions are the GPUs of one node and the exchange is two all-to-all-v per layer
+over RCCL/xGMI (`torch.distributed`, backend "nccl" on ROCm; "gloo" in the CPU tests):
+
+    1. bucket this rank's roots by owner(root) = splitmix64(root) mod P
+    2. all-to-all-v (root id, root ts)                       12 B / root
+    3. every rank samples the roots it received on its own shard (local HIP sampler)
+    4. all-to-all-v back: per-root edge count, then (dst, eid, ts, dt) per sampled edge
+    5. the requester scatters the replies into root-major order
+
+Step 5 restores the original root order, so for most-recent sampling the MFG is
+bit-identical to what a single GPU holding the whole graph returns (the reference's merge
+is partition-major instead, dist_sampler.py:294-299).  Uniform sampling stays
+distribution-matched (each owner draws from its own Philox stream).
+
+Everything is expressed on torch tensors of whatever device the process group works on, so
+the same code runs on HBM tensors over RCCL and on CPU tensors over gloo; the local sampler
+is injected (`local_sample_layer`), in production `gnnflow_amd.TemporalSampler.sample_layer`.
+"""
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+_MASK = (1 << 64) - 1
+
+
+def splitmix64_np(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser (Steele, Lea, Flood 2014) on uint64 numpy arrays."""
+    z = x.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _lsr(x: torch.Tensor, k: int) -> torch.Tensor:
+    """logical shift right on int64 tensors (torch's >> is arithmetic)."""
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def _wrap(c: int) -> int:
+    """64-bit constant as a signed python int (torch int64 arithmetic wraps)."""
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def owner_of(nodes: torch.Tensor, world_size: int) -> torch.Tensor:
+    """owner(v) = splitmix64(v) mod P, deterministic on every rank and device (the
+    reference's HashPartitioner uses Python's salted hash(str(v)) % P,
+    gnnflow/distributed/partition.py:324, which is not reproducible across processes)."""
+    z = nodes.to(torch.int64) + _wrap(0x9E3779B97F4A7C15)
+    z = (z ^ _lsr(z, 30)) * _wrap(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * _wrap(0x94D049BB133111EB)
+    z = z ^ _lsr(z, 31)
+    # unsigned modulo of the 64-bit pattern: fold the top bit in
+    lo = z & ((1 << 63) - 1)
+    top = _lsr(z, 63)
+    return ((lo % world_size) + top * ((1 << 63) % world_size)) % world_size
+
+
+def owner_of_np(nodes: np.ndarray, world_size: int) -> np.ndarray:
+    return (splitmix64_np(np.asarray(nodes, dtype=np.int64).astype(np.uint64))
+            % np.uint64(world_size)).astype(np.int64)
+
+
+class PartitionedGraph:
+    """Wraps a per-rank DynamicGraph: `add_edges` keeps only the edges whose source this
+    rank owns (edges are partitioned by source vertex, gnnflow/distributed/partition.py:25-26).
+    Every rank is given the full batch, as the reference's dispatcher would route it."""
+
+    def __init__(self, local_graph, rank: int, world_size: int):
+        self.local = local_graph
+        self.rank, self.world_size = rank, world_size
+        self._global_edges = 0
+
+    def add_edges(self, source_vertices, target_vertices, timestamps, eids=None,
+                  add_reverse=False):
+        src = np.asarray(source_vertices, dtype=np.int64)
+        dst = np.asarray(target_vertices, dtype=np.int64)
+        ts = np.asarray(timestamps, dtype=np.float32)
+        if eids is None:   # gnnflow/dynamic_graph.py:111-113, on the global edge count
+            eids = np.arange(self._global_edges, self._global_edges + len(src))
+        eids = np.asarray(eids, dtype=np.int64)
+        self._global_edges += len(src)
+        if add_reverse:
+            src, dst = np.concatenate([src, dst]), np.concatenate([dst, src])
+            ts, eids = np.concatenate([ts, ts]), np.concatenate([eids, eids])
+        keep = owner_of_np(src, self.world_size) == self.rank
+        if keep.any():
+            self.local.add_edges(src[keep], dst[keep], ts[keep], eids[keep])
+
+
+LayerFn = Callable[[torch.Tensor, torch.Tensor, int, int], "object"]
+
+
+def _block_arrays(block, device):
+    """(counts per root, dst, eid, ts_out, dt) of a locally sampled block (MFG-like:
+    srcdata['ID','ts'], edata['dt','ID'], edges() -> (col,row), num_dst_nodes())."""
+    def t(x, dtype):
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        return x.to(device=device, dtype=dtype)
+    R = block.num_dst_nodes()
+    row = t(block.edges()[1], torch.int64)
+    counts = torch.bincount(row, minlength=R) if R else torch.zeros(0, dtype=torch.int64, device=device)
+    return (counts, t(block.srcdata["ID"], torch.int64)[R:], t(block.edata["ID"], torch.int64),
+            t(block.srcdata["ts"], torch.float32)[R:], t(block.edata["dt"], torch.float32))
+
+
+class LayerResult:
+    """One (layer, snapshot) MFG in the reference's SamplingResult layout."""
+
+    def __init__(self, all_nodes, all_ts, dt, eids, row, col, num_dst):
+        self.srcdata = {"ID": all_nodes, "ts": all_ts}
+        self.edata = {"dt": dt, "ID": eids}
+        self._row, self._col, self._R = row, col, int(num_dst)
+
+    def num_dst_nodes(self): return self._R
+    def num_src_nodes(self): return int(self.srcdata["ID"].shape[0])
+    def num_edges(self): return int(self._row.shape[0])
+    def edges(self): return self._col, self._row
+
+
+def _all_to_all_v(send: torch.Tensor, send_counts: List[int], recv_counts: List[int], group):
+    recv = send.new_empty((sum(recv_counts),) + tuple(send.shape[1:]))
+    dist.all_to_all_single(recv, send, output_split_sizes=recv_counts,
+                           input_split_sizes=send_counts, group=group)
+    return recv
+
+
+class PartitionedSampler:
+    """TemporalSampler over a hash-partitioned graph: same `sample()` result layout as
+    the single-GPU sampler ([layer][snapshot] reversed, gnnflow/temporal_sampler.py:149-165)."""
+
+    def __init__(self, local_sample_layer: LayerFn, num_layers: int, num_snapshots: int = 1,
+                 group=None, device: Optional[torch.device] = None):
+        self._local = local_sample_layer
+        self._L, self._S = int(num_layers), int(num_snapshots)
+        self._group = group
+        self._P = dist.get_world_size(group)
+        self._rank = dist.get_rank(group)
+        self._device = device or torch.device("cpu")
+
+    def sample_layer(self, nodes: torch.Tensor, ts: torch.Tensor, layer: int,
+                     snapshot: int) -> LayerResult:
+        dev, P = self._device, self._P
+        nodes = nodes.to(dev, torch.int64)
+        ts = ts.to(dev, torch.float32)
+        R = int(nodes.shape[0])
+        # 1. bucket by owner (stable: keeps the original order inside a bucket)
+        dest = owner_of(nodes, P)
+        order = torch.argsort(dest, stable=True)
+        send_counts = torch.bincount(dest, minlength=P)
+        # 2. counts, then roots + timestamps
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self._group)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()
+        got_nodes = _all_to_all_v(nodes[order], sc, rc, self._group)
+        got_ts = _all_to_all_v(ts[order], sc, rc, self._group)
+        # 3. local sample of everything this rank owns
+        blk = self._local(got_nodes, got_ts, layer, snapshot)
+        counts, dst, eid, ts_out, dt = _block_arrays(blk, dev)
+        # 4. replies: per-root counts, then the edges (edge splits follow the root splits)
+        back_counts = _all_to_all_v(counts, rc, sc, self._group)          # sorted-root order
+        edge_send = [int(c.sum()) for c in torch.split(counts, rc)] if len(rc) else []
+        edge_recv = [int(c.sum()) for c in torch.split(back_counts, sc)] if len(sc) else []
+        b_dst = _all_to_all_v(dst, edge_send, edge_recv, self._group)
+        b_eid = _all_to_all_v(eid, edge_send, edge_recv, self._group)
+        b_ts = _all_to_all_v(ts_out, edge_send, edge_recv, self._group)
+        b_dt = _all_to_all_v(dt, edge_send, edge_recv, self._group)
+        # 5. scatter into root-major order of the ORIGINAL roots
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(R, device=dev)
+        start_sorted = torch.cumsum(back_counts, 0) - back_counts           # exclusive
+        cnt = back_counts[inv]
+        src_start = start_sorted[inv]
+        S = int(cnt.sum())
+        row = torch.repeat_interleave(torch.arange(R, device=dev), cnt)
+        base = torch.cumsum(cnt, 0) - cnt
+        idx = src_start[row] + (torch.arange(S, device=dev) - base[row])
+        all_nodes = torch.cat([nodes, b_dst[idx]])
+        all_ts = torch.cat([ts, b_ts[idx]])
+        col = torch.arange(R, R + S, device=dev)
+        return LayerResult(all_nodes, all_ts, b_dt[idx], b_eid[idx], row, col, R)
+
+    def sample(self, nodes, ts) -> List[List[LayerResult]]:
+        if not isinstance(nodes, torch.Tensor):
+            nodes = torch.from_numpy(np.ascontiguousarray(nodes, dtype=np.int64))
+        if not isinstance(ts, torch.Tensor):
+            ts = torch.from_numpy(np.ascontiguousarray(ts, dtype=np.float32))
+        results: List[List[LayerResult]] = []
+        for layer in range(self._L):
+            cur = []
+            for s in range(self._S):
+                if layer == 0:
+                    n, t = nodes, ts
+                else:
+                    prev = results[-1][s]
+                    n, t = prev.srcdata["ID"], prev.srcdata["ts"]
+                cur.append(self.sample_layer(n, t, layer, s))
+            results.append(cur)
+        results.reverse()
+        return results

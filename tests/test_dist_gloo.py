@@ -1,0 +1,106 @@
+"""CPU multi-process test (gloo, world_size 2) of the hash-partitioned sampling exchange
+(gnnflow_amd/dist.py): every rank's merged MFGs must be bit-identical to a single sampler
+holding the whole graph.  The local sampler injected here is the CPU oracle (tests may use
+it); on GPUs it is gnnflow_amd.TemporalSampler.sample_layer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, cfg, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnnflow_amd.dist import PartitionedGraph, PartitionedSampler
+        from oracle import oracle as O
+        from tests import synth
+        N, E = 400, 12000
+        src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=5, tie_levels=500)
+        full = O.OracleGraph(minimum_block_size=8)
+        shard = O.OracleGraph(minimum_block_size=8)
+        pg = PartitionedGraph(shard, rank, world)
+        for lo in range(0, E, 2500):
+            sl = slice(lo, lo + 2500)
+            full.add_edges(src[sl], dst[sl], ts[sl], eid[sl], add_reverse=cfg["reverse"])
+            pg.add_edges(src[sl], dst[sl], ts[sl], eid[sl], add_reverse=cfg["reverse"])
+        kw = dict(fanouts=cfg["fanouts"], sample_strategy="recent",
+                  num_snapshots=cfg["snapshots"], snapshot_time_window=cfg["window"],
+                  prop_time=cfg["prop_time"])
+        ref = O.OracleSampler(full, **kw)
+        local = O.OracleSampler(shard, **kw)
+
+        def local_layer(nodes, t, layer, snap):
+            return local.sample_layer(nodes.numpy(), t.numpy(), layer, snap)
+
+        ps = PartitionedSampler(local_layer, len(cfg["fanouts"]), cfg["snapshots"])
+        ok = True
+        for it, R in enumerate(cfg["batches"]):
+            nodes, t = synth.random_roots(N, R, 1000.0, seed=1000 * rank + it,
+                                          extra_ids=[N + 3])
+            got = ps.sample(nodes, t)
+            want = ref.sample(nodes, t)
+            for gl, wl in zip(got, want):
+                for gb, wb in zip(gl, wl):
+                    ok &= gb.num_src_nodes() == wb.num_src_nodes()
+                    ok &= np.array_equal(gb.srcdata["ID"].numpy(), wb.srcdata["ID"])
+                    ok &= np.array_equal(gb.srcdata["ts"].numpy(), wb.srcdata["ts"])
+                    ok &= np.array_equal(gb.edata["ID"].numpy(), wb.edata["ID"])
+                    ok &= np.array_equal(gb.edata["dt"].numpy().view(np.uint8),
+                                         wb.edata["dt"].view(np.uint8))
+                    ok &= np.array_equal(gb.edges()[0].numpy(), wb.edges()[0])
+                    ok &= np.array_equal(gb.edges()[1].numpy(), wb.edges()[1])
+        # each shard holds only the vertices it owns
+        from gnnflow_amd.dist import owner_of_np
+        srcs = shard.src_nodes()
+        ok &= bool((owner_of_np(srcs, world) == rank).all())
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+CFGS = [
+    dict(fanouts=[5, 5], snapshots=1, window=0.0, prop_time=False, reverse=False,
+         batches=[0, 1, 97, 600]),
+    dict(fanouts=[4], snapshots=2, window=60.0, prop_time=True, reverse=True,
+         batches=[64, 333]),
+]
+
+
+@pytest.mark.parametrize("cfg", CFGS, ids=["2layer", "snapshots_reverse_proptime"])
+def test_partitioned_sampler_matches_single_graph(cfg):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), cfg, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_owner_hash_matches_between_torch_and_numpy():
+    from gnnflow_amd.dist import owner_of, owner_of_np
+    ids = np.concatenate([np.arange(0, 5000), np.random.RandomState(0).randint(0, 2**62, 5000)])
+    for P in (1, 2, 3, 4, 8):
+        a = owner_of(torch.from_numpy(ids), P).numpy()
+        b = owner_of_np(ids, P)
+        assert np.array_equal(a, b)
+        assert a.min() >= 0 and a.max() < P
+    # reasonably balanced
+    c = np.bincount(owner_of_np(np.arange(100000), 8), minlength=8)
+    assert c.min() > 11000 and c.max() < 14000
