@@ -203,6 +203,109 @@ __global__ __launch_bounds__(kScanThreads) void sample_scan_kernel(
   }
 }
 
+// ---- 2b. parallel scan for large layers --------------------------------------------
+// tile = kScanTile roots.  (a) per-tile sums, (b) one workgroup scans the tile sums and
+// publishes S / R', (c) every tile scans itself and adds its base.
+constexpr int kScanTile = 4096;
+
+__global__ __launch_bounds__(kScanThreads) void sample_tile_sum_kernel(
+    const uint32_t* __restrict__ rec_cnt, const uint64_t* d_R, uint64_t R_host,
+    uint32_t fanout, int uniform, uint32_t* __restrict__ tile_sum) {
+  __shared__ uint32_t red[kScanThreads / 64];
+  const uint64_t R = d_R ? *d_R : R_host;
+  const uint64_t tiles = (R + kScanTile - 1) / kScanTile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    uint32_t local = 0;
+    const uint64_t i0 = tile * kScanTile + static_cast<uint64_t>(tid) * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+      if (i0 + k < R) local += valid_slots(rec_cnt[i0 + k], fanout, uniform);
+    for (int d = 32; d > 0; d >>= 1) local += __shfl_down(local, d, 64);
+    if (lane == 0) red[wave] = local;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < kScanThreads / 64; ++w) t += red[w];
+      tile_sum[tile] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kScanThreads) void sample_tile_scan_kernel(
+    const uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ tile_base,
+    const uint64_t* d_R, uint64_t R_host, uint64_t* out_R, uint64_t* out_S, uint64_t* next_R) {
+  __shared__ uint32_t wave_sums[kScanThreads / 64];
+  __shared__ uint32_t carry_s;
+  const uint64_t R = d_R ? *d_R : R_host;
+  const uint64_t tiles = (R + kScanTile - 1) / kScanTile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t t0 = 0; t0 < tiles; t0 += kScanThreads) {
+    const uint64_t i = t0 + tid;
+    const uint32_t v = i < tiles ? tile_sum[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wave_sums[w];
+    const uint32_t excl = carry_s + wave_base + incl - v;
+    if (i < tiles) tile_base[i] = excl;
+    __syncthreads();
+    if (tid == kScanThreads - 1) carry_s = excl + v;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const uint64_t S = carry_s;
+    *out_R = R;
+    *out_S = S;
+    if (next_R) *next_R = R + S;
+  }
+}
+
+__global__ __launch_bounds__(kScanThreads) void sample_tile_apply_kernel(
+    const uint32_t* __restrict__ rec_cnt, const uint32_t* __restrict__ tile_base,
+    const uint64_t* d_R, uint64_t R_host, uint32_t fanout, int uniform,
+    uint32_t* __restrict__ base) {
+  __shared__ uint32_t wave_sums[kScanThreads / 64];
+  const uint64_t R = d_R ? *d_R : R_host;
+  const uint64_t tiles = (R + kScanTile - 1) / kScanTile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    uint32_t v[kScanItems], local = 0;
+    const uint64_t i0 = tile * kScanTile + static_cast<uint64_t>(tid) * kScanItems;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      v[k] = (i0 + k < R) ? valid_slots(rec_cnt[i0 + k], fanout, uniform) : 0u;
+      local += v[k];
+    }
+    uint32_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += wave_sums[w];
+    uint32_t run = tile_base[tile] + wave_base + incl - local;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      if (i0 + k < R) base[i0 + k] = run;
+      run += v[k];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- 3. emit -----------------------------------------------------------------------
 __global__ __launch_bounds__(kEmitThreads) void sample_emit_kernel(
     GraphView g, const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
@@ -463,8 +566,22 @@ void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb
   }
   {
     ProfileScope ps(kProfScan, stream);
-    sample_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
-        rec_cnt, base, d_R, R_host, F, uniform, d_counts_slot, d_counts_slot + 1, next_R);
+    if (Rb <= 65536) {
+      sample_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
+          rec_cnt, base, d_R, R_host, F, uniform, d_counts_slot, d_counts_slot + 1, next_R);
+    } else {
+      // wg_sum doubles as the tile-sum / tile-base scratch (2 * tiles <= ws_roots_ words)
+      const size_t tiles = (Rb + kScanTile - 1) / kScanTile;
+      uint32_t* tile_sum = wg_sum;
+      uint32_t* tile_base = wg_sum + tiles;
+      const unsigned grid = static_cast<unsigned>(std::min<size_t>(tiles, 2048));
+      sample_tile_sum_kernel<<<dim3(grid), dim3(kScanThreads), 0, stream>>>(
+          rec_cnt, d_R, R_host, F, uniform, tile_sum);
+      sample_tile_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
+          tile_sum, tile_base, d_R, R_host, d_counts_slot, d_counts_slot + 1, next_R);
+      sample_tile_apply_kernel<<<dim3(grid), dim3(kScanThreads), 0, stream>>>(
+          rec_cnt, tile_base, d_R, R_host, F, uniform, base);
+    }
     GF_HIP(hipGetLastError());
   }
   {

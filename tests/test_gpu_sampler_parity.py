@@ -174,3 +174,22 @@ def test_sample_layer_result_object_and_debug_sample():
             assert np.array_equal(getattr(r, name)(), getattr(q, name)()), (l, name)
         assert r.num_src_nodes() == q.num_src_nodes()
         assert r.num_dst_nodes() == q.num_dst_nodes()
+
+
+@pytest.mark.parametrize("strategy", ["recent", "uniform"])
+def test_large_batch_parallel_scan_path(strategy):
+    """Layers with more than 65 536 roots take the tiled 3-phase scan instead of the
+    single-workgroup one; 70 000 roots x fanouts [3, 2] exercises it (layer 1 bound 280 000)
+    bit-exactly against the oracle."""
+    import gnnflow_amd
+    from oracle import oracle as O
+    N, E = 5000, 200000
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=13, tie_levels=20000)
+    g, o = _graphs(min_block=16)
+    synth.ingest_chunks(g, src, dst, ts, eid, 50000)
+    synth.ingest_chunks(o, src, dst, ts, eid, 50000)
+    cfg = dict(fanouts=[3, 2], sample_strategy=strategy, seed=5)
+    hs = gnnflow_amd.TemporalSampler(g, **cfg)
+    os_ = O.OracleSampler(o, **cfg)
+    nodes, t = synth.random_roots(N, 70000, 1000.0, seed=77)
+    _cmp_blocks(hs.sample(nodes, t), os_.sample(nodes, t), "R=70000")
