@@ -174,9 +174,10 @@ def main():
             for mfg in mfgs:
                 for b in mfg:
                     b.record_stream(main)
-            cache.fetch_feature(mfgs, dev_batches[i % nb][2])
+            cache.fetch_feature(mfgs, dev_batches[i % nb][2], async_enqueue=True)
             if on_step:
                 on_step(mfgs)
+        cache.wait_enqueued()
 
     def barrier():
         if world > 1:

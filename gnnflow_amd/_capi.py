@@ -97,6 +97,9 @@ PROTOTYPES = {
     "gf_cache_resize": (C.c_int, [_p, _sz, _sz, _p, _p]),
     "gf_cache_fetch": (C.c_int, [_p, _p, _sz, _p, C.c_int, _p, _p]),
     "gf_cache_fetch_blocks": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p]),
+    "gf_cache_fetch_blocks_async": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p,
+                                              C.POINTER(C.c_uint64)]),
+    "gf_cache_fetch_wait": (C.c_int, [C.c_uint64]),
     "gf_gather_rows": (C.c_int, [_p, _sz, _sz, _p, _sz, _p, C.c_int, _p]),
     "gf_cache_slot_ids": (C.c_int, [_p, _p, _sz]),
     "gf_cache_mem_bytes": (C.c_int, [_p, C.POINTER(_sz)]),

@@ -139,7 +139,9 @@ class Cache:
         self.kvstore_client = kvstore_client
         self.distributed = False
         self.neg_sample_ratio = neg_sample_ratio
-        self.target_edge_features = None
+        self._target_edge_features = None
+        self._ticket = 0
+        self._pending_refs = None
         self.feature_placement = placement
 
         self._lib = _capi.load()
@@ -244,13 +246,39 @@ class Cache:
         self._stats_pos += n
         return rows
 
+    def wait_enqueued(self):
+        """Blocks until the last asynchronous fetch_feature() has been enqueued on its
+        stream (no-op otherwise).  Stream order then guarantees the results."""
+        ticket = getattr(self, "_ticket", 0)
+        if ticket:
+            self._ticket = 0
+            rc = self._lib.gf_cache_fetch_wait(ticket)
+            self._pending_refs = None
+            _capi.check(rc)
+
+    @property
+    def target_edge_features(self):
+        self.wait_enqueued()
+        return self._target_edge_features
+
+    @target_edge_features.setter
+    def target_edge_features(self, value):
+        self._target_edge_features = value
+
     def fetch_feature(self, mfgs: List[List], eid: Optional[np.ndarray] = None,
-                      update_cache: bool = True, target_edge_features: bool = True):
+                      update_cache: bool = True, target_edge_features: bool = True,
+                      async_enqueue: bool = False):
         """Fetching the node/edge features of input_node_ids (cache.py:255-413):
         node features for the blocks of mfgs[0] -> srcdata['h'], edge features for every
         block -> edata['f'], target edge features for TGN memory.  One native call
         (gf_cache_fetch_blocks) issues every gather + LRU update; node and edge caches
-        proceed concurrently on the device."""
+        proceed concurrently on the device.
+
+        async_enqueue=True returns as soon as the work has been handed to the library's
+        enqueue thread; `b.srcdata['h']` / `b.edata['f']` / `target_edge_features` then wait
+        for the enqueue on first access (blocks built by gnnflow_amd.TemporalSampler), or
+        call wait_enqueued()."""
+        self.wait_enqueued()      # at most one submission in flight
         upd = 1 if update_cache else 0
         jobs = []    # (kind, ids tensor, dim, setter)
         if self._node is not None:
@@ -279,15 +307,26 @@ class Cache:
                 d.kind, d.update, d.n = kind, upd, n
                 d.d_ids, d.d_out = ids.data_ptr(), out.data_ptr()
                 d.d_stats = stats_ptr + 64 * i if (kind != 2 and n) else None
-                if store is not None:
-                    store[key] = out
+                lazy = async_enqueue and hasattr(store, "set_lazy")
+                if store is None:
+                    self._target_edge_features = out    # cache.py:411 `edge_feats[eid]`
+                elif lazy:
+                    store.pop(key, None)
+                    store.set_lazy(key, lambda out=out: (self.wait_enqueued(), out)[1])
                 else:
-                    self.target_edge_features = out    # cache.py:411 `edge_feats[eid]`
-            _capi.check(self._lib.gf_cache_fetch_blocks(
-                self._node.h if self._node is not None else None,
-                self._edge.h if self._edge is not None else None,
-                descs, len(jobs), self._stream()))
-            # keep ids alive until the kernels are enqueued (they are, above)
+                    store[key] = out
+            node_h = self._node.h if self._node is not None else None
+            edge_h = self._edge.h if self._edge is not None else None
+            if async_enqueue:
+                ticket = C.c_uint64(0)
+                _capi.check(self._lib.gf_cache_fetch_blocks_async(
+                    node_h, edge_h, descs, len(jobs), self._stream(), C.byref(ticket)))
+                self._ticket = ticket.value
+                # ids / outputs must outlive the enqueue
+                self._pending_refs = (jobs, descs, mfgs)
+            else:
+                _capi.check(self._lib.gf_cache_fetch_blocks(
+                    node_h, edge_h, descs, len(jobs), self._stream()))
         if self._node is not None:
             self._node_stats = stats[:n_node]
         if self._edge is not None:

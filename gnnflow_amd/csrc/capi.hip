@@ -1,7 +1,10 @@
 // extern "C" entry points of include/gnnflow_hip.h: thin, exception-free shims
 // over EdgeStore / Sampler / FeatureCache.
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "common.hpp"
 #include "edge_store.hpp"
@@ -57,6 +60,87 @@ ProfileScope::~ProfileScope() {
   g_prof_pending.push_back({slot, start, stop});
 }
 
+}  // namespace gf
+
+namespace gf {
+namespace {
+
+// Enqueue worker: issuing the ~20 launches of one fetch_feature() costs more host time
+// (~3 us per launch) than the kernels take on the GPU at batch 600, so an asynchronous
+// submission hands the descriptor list to this thread and returns; the caller overlaps its
+// own host work (building the next batch, Python) and later waits for the *enqueue* to
+// have happened (stream order then covers the execution).
+class FetchWorker {
+ public:
+  struct Job {
+    FeatureCache* node;
+    FeatureCache* edge;
+    std::vector<gf_fetch_desc> descs;
+    hipStream_t stream;
+  };
+  static FetchWorker& get() {
+    static FetchWorker* w = new FetchWorker();   // intentionally leaked: no exit-order issues
+    return *w;
+  }
+  uint64_t submit(Job&& job) {
+    std::unique_lock<std::mutex> lk(mu_);
+    q_.push_back(std::move(job));
+    const uint64_t ticket = ++submitted_;
+    cv_job_.notify_one();
+    return ticket;
+  }
+  // status of the submission `ticket` once it has been enqueued
+  int wait(uint64_t ticket, std::string* err) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return completed_ >= ticket; });
+    if (first_error_ticket_ && first_error_ticket_ <= ticket) {
+      *err = error_;
+      const int rc = error_code_;
+      first_error_ticket_ = 0;
+      return rc;
+    }
+    return GF_OK;
+  }
+
+ private:
+  FetchWorker() { std::thread(&FetchWorker::run, this).detach(); }
+  void run() {
+    for (;;) {
+      Job job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_job_.wait(lk, [&] { return !q_.empty(); });
+        job = std::move(q_.front());
+        q_.pop_front();
+      }
+      int rc = GF_OK;
+      std::string msg;
+      try {
+        fetch_blocks(job.node, job.edge, job.descs.data(), job.descs.size(), job.stream);
+      } catch (const Error& e) {
+        rc = e.code; msg = e.what();
+      } catch (const std::exception& e) {
+        rc = GF_ERR_INVALID_ARGUMENT; msg = e.what();
+      }
+      std::unique_lock<std::mutex> lk(mu_);
+      ++completed_;
+      if (rc != GF_OK && !first_error_ticket_) {
+        first_error_ticket_ = completed_;
+        error_code_ = rc;
+        error_ = msg;
+      }
+      cv_done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_job_, cv_done_;
+  std::deque<Job> q_;
+  uint64_t submitted_ = 0, completed_ = 0, first_error_ticket_ = 0;
+  int error_code_ = GF_OK;
+  std::string error_;
+};
+
+}  // namespace
 }  // namespace gf
 
 using gf::guarded;
@@ -257,6 +341,26 @@ int gf_cache_fetch_blocks(gf_cache* node_cache, gf_cache* edge_cache, const gf_f
                      edge_cache ? &edge_cache->impl : nullptr, descs, n,
                      static_cast<hipStream_t>(stream));
   });
+}
+int gf_cache_fetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
+                                const gf_fetch_desc* descs, size_t n, void* stream,
+                                uint64_t* ticket) {
+  return guarded([&] {
+    GF_REQUIRE(ticket != nullptr, "fetch_blocks_async: null ticket");
+    GF_REQUIRE(descs != nullptr || n == 0, "fetch_blocks_async: null descriptors");
+    gf::FetchWorker::Job job;
+    job.node = node_cache ? &node_cache->impl : nullptr;
+    job.edge = edge_cache ? &edge_cache->impl : nullptr;
+    job.descs.assign(descs, descs + n);
+    job.stream = static_cast<hipStream_t>(stream);
+    *ticket = gf::FetchWorker::get().submit(std::move(job));
+  });
+}
+int gf_cache_fetch_wait(uint64_t ticket) {
+  std::string err;
+  const int rc = gf::FetchWorker::get().wait(ticket, &err);
+  if (rc != GF_OK) gf::set_last_error(err);
+  return rc;
 }
 int gf_gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_t* d_ids,
                    size_t n, float* d_out, int device, void* stream) {

@@ -216,6 +216,16 @@ typedef struct gf_fetch_desc {
 GF_API int gf_cache_fetch_blocks(gf_cache* node_cache, gf_cache* edge_cache,
                                  const gf_fetch_desc* descs, size_t n, void* stream);
 
+/* Asynchronous submission of the same work: the descriptors are copied and handed to an
+ * enqueue thread inside the library, the call returns at once with a ticket, and
+ * gf_cache_fetch_wait(ticket) blocks until that submission has been ENQUEUED on `stream`
+ * (and returns its status); ordering of the results is then the stream's.  Submissions
+ * are enqueued in ticket order.  The caller keeps ids / outputs alive until the wait. */
+GF_API int gf_cache_fetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
+                                       const gf_fetch_desc* descs, size_t n, void* stream,
+                                       uint64_t* ticket);
+GF_API int gf_cache_fetch_wait(uint64_t ticket);
+
 /* Cache-free gather, gnnflow/utils.py:465-474 prepare_input and
  * cache.py:411 `edge_feats[eid]`: out[i,:] = feats[ids[i],:]. */
 GF_API int gf_gather_rows(const float* d_feats, size_t num_rows, size_t dim,

@@ -160,3 +160,40 @@ def test_large_block_round_trip_properties():
     cache.fetch_feature(b2)
     assert torch.equal(b2[0][0].edata["f"], f1)
     assert float(cache.cache_edge_ratio) >= r1
+
+
+def test_async_enqueue_matches_sync():
+    """fetch_feature(async_enqueue=True) hands the launches to the library's enqueue thread;
+    results, hit ratios and LRU state must be those of the synchronous call."""
+    import torch
+    import gnnflow_amd
+    from gnnflow_amd.cache import LRUCache
+    from tests import synth
+    N, E, d = 600, 20000, 16
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=3)
+    g = gnnflow_amd.DynamicGraph(1 << 20, 1 << 28, "cuda", 16, 128, "insert")
+    g.add_edges(src, dst, ts, eid)
+    s = gnnflow_amd.TemporalSampler(g, [6, 6])
+    rng = np.random.RandomState(1)
+    nf = torch.from_numpy(rng.rand(N, d).astype(np.float32))
+    ef = torch.from_numpy(rng.rand(E, d).astype(np.float32))
+    caches = [LRUCache(0.1, 0.1, N, E, "cuda:0", nf, ef, d, d) for _ in range(2)]
+    for c in caches:
+        c.init_cache()
+    for it in range(6):
+        nodes, t = synth.random_roots(N, 500, 1000.0, seed=it)
+        e_ids = rng.randint(0, E, 50)
+        ma, mb = s.sample(nodes, t), s.sample(nodes, t)
+        caches[0].fetch_feature(ma, e_ids)
+        caches[1].fetch_feature(mb, e_ids, async_enqueue=True)
+        for la, lb in zip(ma, mb):
+            for ba, bb in zip(la, lb):
+                if ba.num_edges():
+                    assert torch.equal(ba.edata["f"], bb.edata["f"])
+        assert torch.equal(ma[0][0].srcdata["h"], mb[0][0].srcdata["h"])
+        assert torch.equal(caches[0].target_edge_features, caches[1].target_edge_features)
+        assert float(caches[0].cache_edge_ratio) == float(caches[1].cache_edge_ratio)
+        assert float(caches[0].cache_node_ratio) == float(caches[1].cache_node_ratio)
+    caches[1].wait_enqueued()
+    assert np.array_equal(caches[0]._edge.slot_ids(), caches[1]._edge.slot_ids())
+    assert np.array_equal(caches[0]._node.slot_ids(), caches[1]._node.slot_ids())
