@@ -165,12 +165,12 @@ def main():
         main = torch.cuda.current_stream(dev)
         nb = len(dev_batches)
         pending = sampler.sample_async(dev_batches[first % nb][0], dev_batches[first % nb][1],
-                                       stream=side)
+                                       stream=side, worker_enqueue=True)
         for i in range(first, first + count):
             mfgs = pending.wait()
             if i + 1 < first + count:
                 r, t, _ = dev_batches[(i + 1) % nb]
-                pending = sampler.sample_async(r, t, stream=side)
+                pending = sampler.sample_async(r, t, stream=side, worker_enqueue=True)
             for mfg in mfgs:
                 for b in mfg:
                     b.record_stream(main)

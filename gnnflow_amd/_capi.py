@@ -83,6 +83,7 @@ PROTOTYPES = {
     "gf_sampler_output_bytes": (C.c_int, [_p, _sz, C.POINTER(_sz)]),
     "gf_sampler_sample": (C.c_int, [_p, _p, _p, _sz, _p, _sz, C.POINTER(GfBlock), _p]),
     "gf_sampler_sample_begin": (C.c_int, [_p, _p, _p, _sz, _p, _sz, _p]),
+    "gf_sampler_sample_begin_async": (C.c_int, [_p, _p, _p, _sz, _p, _sz, _p]),
     "gf_sampler_sample_end": (C.c_int, [_p, C.POINTER(GfBlock)]),
     "gf_sampler_layer_output_bytes": (C.c_int, [_p, _sz, C.c_uint32, C.POINTER(_sz)]),
     "gf_sampler_sample_layer": (C.c_int, [_p, _p, _p, _sz, C.c_uint32, C.c_uint32, _p, _sz,
@@ -100,6 +101,7 @@ PROTOTYPES = {
     "gf_cache_fetch_blocks_async": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p,
                                               C.POINTER(C.c_uint64)]),
     "gf_cache_fetch_wait": (C.c_int, [C.c_uint64]),
+    "gf_worker_stats": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "gf_gather_rows": (C.c_int, [_p, _sz, _sz, _p, _sz, _p, C.c_int, _p]),
     "gf_cache_slot_ids": (C.c_int, [_p, _p, _sz]),
     "gf_cache_mem_bytes": (C.c_int, [_p, C.POINTER(_sz)]),

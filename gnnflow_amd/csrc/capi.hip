@@ -1,7 +1,9 @@
 // extern "C" entry points of include/gnnflow_hip.h: thin, exception-free shims
 // over EdgeStore / Sampler / FeatureCache.
+#include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -12,7 +14,7 @@
 #include "sampler.hpp"
 
 struct gf_graph { gf::EdgeStore impl; template <typename... A> explicit gf_graph(A&&... a) : impl(std::forward<A>(a)...) {} };
-struct gf_sampler { gf::Sampler impl; template <typename... A> explicit gf_sampler(A&&... a) : impl(std::forward<A>(a)...) {} };
+struct gf_sampler { gf::Sampler impl; uint64_t begin_ticket = 0; template <typename... A> explicit gf_sampler(A&&... a) : impl(std::forward<A>(a)...) {} };
 struct gf_cache { gf::FeatureCache impl; template <typename... A> explicit gf_cache(A&&... a) : impl(std::forward<A>(a)...) {} };
 
 namespace gf {
@@ -65,21 +67,16 @@ ProfileScope::~ProfileScope() {
 namespace gf {
 namespace {
 
-// Enqueue worker: issuing the ~20 launches of one fetch_feature() costs more host time
-// (~3 us per launch) than the kernels take on the GPU at batch 600, so an asynchronous
-// submission hands the descriptor list to this thread and returns; the caller overlaps its
-// own host work (building the next batch, Python) and later waits for the *enqueue* to
-// have happened (stream order then covers the execution).
-class FetchWorker {
+// Enqueue worker: issuing the ~25 launches of one step costs more host time (~3 us per
+// launch) than the kernels take on the GPU at batch 600, so asynchronous submissions hand
+// the work to this single thread (one issuer: no runtime-lock convoy between threads) and
+// return; the caller overlaps its own host work (Python, building the next batch) and
+// later waits for the *enqueue* to have happened (stream order covers the execution).
+class EnqueueWorker {
  public:
-  struct Job {
-    FeatureCache* node;
-    FeatureCache* edge;
-    std::vector<gf_fetch_desc> descs;
-    hipStream_t stream;
-  };
-  static FetchWorker& get() {
-    static FetchWorker* w = new FetchWorker();   // intentionally leaked: no exit-order issues
+  using Job = std::function<void()>;
+  static EnqueueWorker& get() {
+    static EnqueueWorker* w = new EnqueueWorker();   // intentionally leaked: no exit-order issues
     return *w;
   }
   uint64_t submit(Job&& job) {
@@ -103,7 +100,7 @@ class FetchWorker {
   }
 
  private:
-  FetchWorker() { std::thread(&FetchWorker::run, this).detach(); }
+  EnqueueWorker() { std::thread(&EnqueueWorker::run, this).detach(); }
   void run() {
     for (;;) {
       Job job;
@@ -115,14 +112,17 @@ class FetchWorker {
       }
       int rc = GF_OK;
       std::string msg;
+      const auto t0 = std::chrono::steady_clock::now();
       try {
-        fetch_blocks(job.node, job.edge, job.descs.data(), job.descs.size(), job.stream);
+        job();
       } catch (const Error& e) {
         rc = e.code; msg = e.what();
       } catch (const std::exception& e) {
         rc = GF_ERR_INVALID_ARGUMENT; msg = e.what();
       }
+      const auto t1 = std::chrono::steady_clock::now();
       std::unique_lock<std::mutex> lk(mu_);
+      busy_us_ += std::chrono::duration<double, std::micro>(t1 - t0).count();
       ++completed_;
       if (rc != GF_OK && !first_error_ticket_) {
         first_error_ticket_ = completed_;
@@ -138,6 +138,14 @@ class FetchWorker {
   uint64_t submitted_ = 0, completed_ = 0, first_error_ticket_ = 0;
   int error_code_ = GF_OK;
   std::string error_;
+
+ public:
+  double busy_us_ = 0;   // time spent issuing work (diagnostics)
+  void stats(double* busy_us, uint64_t* jobs) {
+    std::unique_lock<std::mutex> lk(mu_);
+    *busy_us = busy_us_;
+    *jobs = completed_;
+  }
 };
 
 }  // namespace
@@ -267,7 +275,28 @@ int gf_sampler_sample_begin(gf_sampler* s, const int64_t* d_roots, const float* 
                          static_cast<hipStream_t>(stream));
   });
 }
+int gf_sampler_sample_begin_async(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
+                                  size_t num_roots, void* d_out, size_t out_bytes,
+                                  void* stream) {
+  return guarded([&] {
+    GF_S(s);
+    GF_REQUIRE(s->begin_ticket == 0, "sample_begin_async: a sample is already in flight");
+    gf::Sampler* impl = &s->impl;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    s->begin_ticket = gf::EnqueueWorker::get().submit(
+        [impl, d_roots, d_root_ts, num_roots, d_out, out_bytes, st]() {
+          impl->sample_begin(d_roots, d_root_ts, num_roots, d_out, out_bytes, st);
+        });
+  });
+}
 int gf_sampler_sample_end(gf_sampler* s, gf_block* blocks) {
+  if (s && s->begin_ticket) {   // begun through the enqueue thread: wait for the enqueue
+    std::string err;
+    const uint64_t t = s->begin_ticket;
+    s->begin_ticket = 0;
+    const int rc = gf::EnqueueWorker::get().wait(t, &err);
+    if (rc != GF_OK) { gf::set_last_error(err); return rc; }
+  }
   return guarded([&] { GF_S(s); s->impl.sample_end(blocks); });
 }
 int gf_sampler_sample_layer(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
@@ -348,19 +377,26 @@ int gf_cache_fetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
   return guarded([&] {
     GF_REQUIRE(ticket != nullptr, "fetch_blocks_async: null ticket");
     GF_REQUIRE(descs != nullptr || n == 0, "fetch_blocks_async: null descriptors");
-    gf::FetchWorker::Job job;
-    job.node = node_cache ? &node_cache->impl : nullptr;
-    job.edge = edge_cache ? &edge_cache->impl : nullptr;
-    job.descs.assign(descs, descs + n);
-    job.stream = static_cast<hipStream_t>(stream);
-    *ticket = gf::FetchWorker::get().submit(std::move(job));
+    gf::FeatureCache* node = node_cache ? &node_cache->impl : nullptr;
+    gf::FeatureCache* edge = edge_cache ? &edge_cache->impl : nullptr;
+    std::vector<gf_fetch_desc> copy(descs, descs + n);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    *ticket = gf::EnqueueWorker::get().submit([node, edge, copy = std::move(copy), st]() {
+      gf::fetch_blocks(node, edge, copy.data(), copy.size(), st);
+    });
   });
 }
 int gf_cache_fetch_wait(uint64_t ticket) {
   std::string err;
-  const int rc = gf::FetchWorker::get().wait(ticket, &err);
+  const int rc = gf::EnqueueWorker::get().wait(ticket, &err);
   if (rc != GF_OK) gf::set_last_error(err);
   return rc;
+}
+int gf_worker_stats(double* busy_us, uint64_t* jobs) {
+  return guarded([&] {
+    GF_REQUIRE(busy_us && jobs, "gf_worker_stats: null output");
+    gf::EnqueueWorker::get().stats(busy_us, jobs);
+  });
 }
 int gf_gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_t* d_ids,
                    size_t n, float* d_out, int device, void* stream) {

@@ -102,6 +102,26 @@ __device__ inline uint32_t valid_slots(uint32_t n_cand, uint32_t fanout, int uni
   return n_cand < fanout ? n_cand : fanout;
 }
 
+// Size read-back without a memcpy + event wait: the last kernel of a sample() copies the
+// per-block {R, S} words into pinned host memory and then stores the call's sequence
+// number; the host spins on that word (hipEventSynchronize wakes up 10-20 us late).
+struct Publish {
+  const uint64_t* d_counts;   // device counts array (all blocks of this sample)
+  uint64_t* h_counts;         // pinned host mirror (device-mapped)
+  uint64_t* h_flag;           // pinned host sequence word
+  uint64_t seq;
+  uint32_t num_words;         // 0 = nothing to publish
+};
+
+// Stream-ordered after the last emit kernel, so every output of the sample is complete
+// (and released by the kernel boundary) before the host can observe the sequence word.
+__global__ void sample_publish_kernel(Publish p) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (uint32_t i = 0; i < p.num_words; ++i) p.h_counts[i] = p.d_counts[i];
+  __threadfence_system();
+  *reinterpret_cast<volatile uint64_t*>(p.h_flag) = p.seq;
+}
+
 // ---- 1. search --------------------------------------------------------------------
 template <int GROUP>
 __global__ __launch_bounds__(kSearchThreads) void sample_search_kernel(
@@ -517,7 +537,7 @@ void Sampler::reserve_workspace(size_t Rb, size_t num_blocks, hipStream_t stream
                  ws_blocks_ * 2 * sizeof(uint64_t) + 64;
   (void)stream;
   ws_.reserve(bytes, 0, nullptr);
-  h_counts_.reserve(ws_blocks_ * 2 * sizeof(uint64_t));
+  h_counts_.reserve((ws_blocks_ * 2 + 1) * sizeof(uint64_t));
 }
 
 void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb,
@@ -641,8 +661,15 @@ void Sampler::sample_begin(const int64_t* d_roots, const float* d_ts, size_t R, 
       }
     }
   }
-  GF_HIP(hipMemcpyAsync(h_counts_.data(), d_counts, L * NS * 2 * sizeof(uint64_t),
-                        hipMemcpyDeviceToHost, stream));
+  *h_counts_.as<volatile uint64_t>() = 0;   // no publish is pending: one sample in flight
+  Publish pub;
+  pub.d_counts = d_counts;
+  pub.h_counts = h_counts_.as<uint64_t>() + 1;   // word 0 is the sequence flag
+  pub.h_flag = h_counts_.as<uint64_t>();
+  pub.seq = ++publish_seq_;
+  pub.num_words = static_cast<uint32_t>(L * NS * 2);
+  sample_publish_kernel<<<dim3(1), dim3(64), 0, stream>>>(pub);
+  GF_HIP(hipGetLastError());
   GF_HIP(hipEventRecord(done_ev_, stream));
   pending_ = true;
 }
@@ -657,8 +684,17 @@ void Sampler::sample_end(gf_block* blocks) {
     return;
   }
   DeviceGuard dg(graph_->device());
-  GF_HIP(hipEventSynchronize(done_ev_));
-  const uint64_t* hc = h_counts_.as<uint64_t>();
+  // spin on the pinned sequence word (sub-microsecond reaction); fall back to the event
+  // if the kernel has not published after a generous number of polls
+  volatile uint64_t* flag = h_counts_.as<volatile uint64_t>();
+  bool seen = false;
+  for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
+    if (*flag == publish_seq_) { seen = true; break; }
+    __builtin_ia32_pause();
+  }
+  if (!seen) GF_HIP(hipEventSynchronize(done_ev_));
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const uint64_t* hc = h_counts_.as<uint64_t>() + 1;
   for (size_t b = 0; b < L * NS; ++b) {
     gf_block& o = blocks[b];
     o.all_nodes = pending_ptrs_[b].all_nodes;

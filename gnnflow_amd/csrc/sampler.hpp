@@ -63,6 +63,7 @@ class Sampler {
   bool fused_scan_ = true;
   hipEvent_t done_ev_ = nullptr;
   bool pending_ = false;
+  uint64_t publish_seq_ = 0;
   size_t pending_roots_ = 0;
   std::vector<BlockPtrs> pending_ptrs_;
 

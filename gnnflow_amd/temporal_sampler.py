@@ -155,12 +155,14 @@ class TemporalSampler:
         """
         return self.sample_async(target_vertices, timestamps).wait()
 
-    def sample_async(self, target_vertices, timestamps, stream=None) -> "PendingSample":
+    def sample_async(self, target_vertices, timestamps, stream=None,
+                     worker_enqueue=False) -> "PendingSample":
         """Enqueues sample() on `stream` (default: the current stream) and returns at
         once; `.wait()` blocks until the kernels finished and returns the MFGs.  Lets a
         single Python thread overlap the sampling of batch i+1 with the feature fetch /
         training of batch i (the reference uses a prefetch thread for this,
-        scripts/offline_edge_prediction.py:343-346).  One sample in flight per sampler."""
+        scripts/offline_edge_prediction.py:343-346).  One sample in flight per sampler.
+        worker_enqueue=True lets the library's enqueue thread issue the launches."""
         nodes, ts = self._to_device(target_vertices, timestamps)
         R = int(nodes.shape[0])
         if stream is None:
@@ -174,7 +176,9 @@ class TemporalSampler:
                 nbytes = self._bytes_cache[R] = n.value
             with torch.cuda.stream(stream):
                 buf = torch.empty(nbytes, dtype=torch.uint8, device=self._device)
-        _capi.check(self._lib.gf_sampler_sample_begin(
+        begin = self._lib.gf_sampler_sample_begin_async if worker_enqueue \
+            else self._lib.gf_sampler_sample_begin
+        _capi.check(begin(
             self._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
             buf.data_ptr() if R else None, nbytes, C.c_void_p(stream.cuda_stream)))
         return PendingSample(self, buf, (nodes, ts), R)

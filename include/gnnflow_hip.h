@@ -150,6 +150,12 @@ GF_API int gf_sampler_sample_begin(gf_sampler* s, const int64_t* d_roots,
                                    const float* d_root_ts, size_t num_roots, void* d_out,
                                    size_t out_bytes, void* stream);
 GF_API int gf_sampler_sample_end(gf_sampler* s, gf_block* blocks);
+/* As gf_sampler_sample_begin, but the launches are issued by the library's enqueue thread
+ * (the one gf_cache_fetch_blocks_async uses, in submission order); gf_sampler_sample_end
+ * waits for it.  The inputs must stay alive until gf_sampler_sample_end returns. */
+GF_API int gf_sampler_sample_begin_async(gf_sampler* s, const int64_t* d_roots,
+                                         const float* d_root_ts, size_t num_roots,
+                                         void* d_out, size_t out_bytes, void* stream);
 
 /* _TemporalSampler.sample_layer (api.cc:119-120 -> TemporalSampler::SampleLayer,
  * temporal_sampler.cu:97-277), device resident; *bytes variant sizes the buffer. */
@@ -225,6 +231,8 @@ GF_API int gf_cache_fetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cach
                                        const gf_fetch_desc* descs, size_t n, void* stream,
                                        uint64_t* ticket);
 GF_API int gf_cache_fetch_wait(uint64_t ticket);
+/* Diagnostics: cumulative time the enqueue thread spent issuing work, and jobs done. */
+GF_API int gf_worker_stats(double* busy_us, uint64_t* jobs);
 
 /* Cache-free gather, gnnflow/utils.py:465-474 prepare_input and
  * cache.py:411 `edge_feats[eid]`: out[i,:] = feats[ids[i],:]. */
