@@ -9,35 +9,40 @@
 //   evicted and refilled with the missed ids' rows.
 // The reference spends ~10 ATen launches, a host round trip for the missed rows
 // (unique -> CPU index_select -> pinned -> H2D) and a topk over the whole capacity
-// on this.  Here one fetch is 1 + 5 launches, none of which waits for the host:
+// on every block.  Here a *round* of up to three independent blocks (one node-cache
+// block, one edge-cache block, one cache-free gather) is 1 + 4 launches, none of which
+// waits for the host; each kernel takes the round's contexts by value and blockIdx.y
+// selects the context, so the node and edge caches advance in the same launches:
 //
-//   gather  : reads ids, probes the id->slot map, picks the source row (cache slot in
-//             HBM, or the feature table — HBM or device-mapped pinned host memory) and
-//             streams it to the output with 16-byte loads/stores.  A wave owns
-//             `tile_rows` consecutive output rows, flattened, so its stores form one
-//             contiguous run and every lane keeps 4 independent 16 B loads in flight;
-//             tile_rows shrinks for small blocks so that a 10k-row block still spreads
-//             over >2000 waves.  It also records each row's slot, counts hits/misses
-//             and (when the cache will be updated) lets every missed row claim its id
-//             with atomicMax(map[id], -(row+1)) — the lowest row of each distinct
-//             missed id wins.  This kernel moves ~all the bytes (2*dim*4 per row) and
-//             is the one priced against the HBM roofline.
-//   mark    : representatives of the distinct missed ids; hit slots take the new epoch.
-//   scan+h1 : workgroup 0 prefix-sums the representative flags (first-seen order and
-//             #unique); the other workgroups histogram the slot ages.
-//   rank+h2 : rank -> row table of the ids to install (the rest give their claim back);
-//             second-level histogram only when the eviction threshold is older than
-//             2047 epochs.
-//   count   : per 1024-slot tile, slots older than / exactly at the threshold age.
-//   install : evicts every older slot plus the first k_tie threshold-age slots in slot
-//             order, gives the i-th evicted slot (slot order) the i-th distinct missed
-//             id (block order), and copies the freshly gathered rows from the output
-//             (already in HBM) into the cache.  No atomics: fully deterministic.
+//   gather   : reads ids, probes the id->slot map, picks the source row (cache slot in
+//              HBM, or the feature table — HBM or device-mapped pinned host memory) and
+//              streams it to the output with 16-byte loads/stores.  A wave owns
+//              `tile_rows` consecutive output rows, flattened, so its stores form one
+//              contiguous run and every lane keeps 4 independent 16 B loads in flight;
+//              tile_rows shrinks for small blocks so that a 10k-row block still spreads
+//              over >2000 waves.  It also records each row's slot, marks hit slots as
+//              touched in this epoch, counts hits/misses (once per workgroup, sharded) and
+//              lets every missed row claim its id with atomicMax(map[id], -(row+1)) — the
+//              lowest row of each distinct missed id wins (this replaces torch.unique).
+//              This kernel moves ~all the bytes (2*dim*4 per row) and is the one priced
+//              against the HBM roofline.
+//   scan+h1  : workgroup 0 prefix-sums the representative flags (rank in first-seen order,
+//              #unique); the other workgroups histogram the slot ages.
+//   rank+h2  : rank -> row table of the ids to install (the rest give their claim back);
+//              second-level histogram only when the eviction threshold is older than 2047
+//              epochs.
+//   count    : per 1024-slot tile, slots older than / exactly at the threshold age.
+//   install  : evicts every older slot plus the first k_tie threshold-age slots in slot
+//              order, gives the i-th evicted slot (slot order) the i-th distinct missed id
+//              (block order), copies the freshly gathered rows from the output (already in
+//              HBM) into the cache and turns this epoch's touch marks into stamps.
+//              No atomics: fully deterministic.
 //
 // `count` of the reference is kept as an epoch stamp per slot (count == stamp - epoch);
 // the k smallest counts are found with a histogram select (no sort, no topk); ties go to
-// the lowest slot index.  Bookkeeping kernels return immediately when the block had no
-// miss (the reference skips update_*_cache in that case too, cache.py:318).
+// the lowest slot index.  The four bookkeeping kernels return at once for a context whose
+// block had no miss (the reference skips update_*_cache then too, cache.py:318); a hit only
+// changes LRU state if the block also had a miss, exactly as in the reference.
 #include "feature_cache.hpp"
 
 #include <algorithm>
@@ -50,14 +55,15 @@ namespace gf {
 namespace {
 
 constexpr int32_t kAbsent = INT32_MIN;  // map[] value of an uncached id
-constexpr int kThreads = 256;           // gather / row kernels
+constexpr int kThreads = 256;           // gather workgroup
 constexpr int kWide = 1024;             // slot kernels, scans
 constexpr int kFine = 2048;             // ages 0..2047: one bin each
 constexpr int kBins1 = 4096;            // + 2048 coarse bins of 2048 ages each
 constexpr int kBins2 = 2048;            // second level inside one coarse bin
 constexpr uint32_t kAgeMax = kFine + 2048u * 2048u - 1u;
 constexpr int kTile = 1024;             // slots per tile (= install workgroup)
-constexpr int kRing = 32;               // per-fetch counter records before a re-zero
+constexpr int kRing = 32;               // per-fetch counter records
+constexpr int kMaxCtx = 3;              // contexts per round
 
 // One record per fetch.  hits / misses are accumulated once per workgroup into one of 8
 // shards that sit on separate 128-byte lines: same-address atomics retire at only
@@ -75,44 +81,77 @@ struct Counters {
   uint32_t th_k_tie;
   uint32_t pad[29];
 };
+constexpr uint32_t kCounterWords = sizeof(Counters) / 4;
+
+// Everything one block fetch needs on the device.  `update` == 0: gather only.
+struct Ctx {
+  const int64_t* ids;
+  uint32_t n;
+  int vec4;                 // rows are float4-addressable
+  uint32_t dimv;            // row length in float4s (vec4) or floats
+  uint32_t tile_rows;       // rows per wave in the gather
+  float* out;
+  const float* feats;
+  uint64_t num_ids;
+  int32_t* map;             // null: no cache (plain gather)
+  float* cache_buf;
+  int64_t* slot_id;
+  uint32_t* stamp;
+  uint32_t* touched;
+  uint32_t capacity;
+  uint32_t epoch_new;
+  int update;
+  int32_t* slot_of_row;
+  uint32_t* rep_flag;
+  uint32_t* rep_rank;
+  uint32_t* rep_row;
+  uint32_t* hist1;
+  uint32_t* hist2;
+  uint32_t* tile_tie;
+  uint32_t* tile_old;
+  Counters* ctr;            // this fetch's record (zeroed by the previous fetch)
+  Counters* ctr_next;       // record of the next fetch on this cache: zeroed here
+  uint32_t* stats;          // caller's 16-word hit statistics, may be null
+};
+struct Round {
+  Ctx c[kMaxCtx];
+  int count;
+};
+
 __device__ inline uint32_t total_miss(const Counters* c) {
   uint32_t m = 0;
 #pragma unroll
   for (int i = 0; i < kShards; ++i) m += c->shard[i].n_miss;
   return m;
 }
-
-struct Workspace {
-  uint32_t* hist1;      // [kBins1]
-  uint32_t* hist2;      // [kBins2]
-  int32_t* slot_of_row; // [n]  >=0 slot (hit), -1 miss, -2 invalid id
-  uint32_t* rep_flag;   // [n]  1 = first row of a distinct missed id
-  uint32_t* rep_rank;   // [n]  exclusive scan of rep_flag
-  uint32_t* rep_row;    // [n]  rank -> row
-  uint32_t* tile_tie;   // [tiles] slots at the threshold age
-  uint32_t* tile_old;   // [tiles] slots older than the threshold
-};
+__device__ inline bool needs_update(const Ctx& c) {
+  return c.update && total_miss(c.ctr) != 0;
+}
 
 template <typename VecT> __device__ inline VecT vec_zero();
 template <> __device__ inline float vec_zero<float>() { return 0.0f; }
 template <> __device__ inline float4 vec_zero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ---- the gather kernel -------------------------------------------------------------
-// VecT = float4 (dim % 4 == 0, 16 B aligned rows) or float.  tile_rows in [1, 64].
 template <typename VecT>
-__global__ __launch_bounds__(kThreads) void gather_rows_kernel(
-    const int64_t* __restrict__ ids, uint32_t n, int32_t* map,
-    const VecT* __restrict__ cache_buf, const VecT* __restrict__ feats, uint64_t num_ids,
-    uint32_t dimv, uint32_t tile_rows, VecT* __restrict__ out,
-    int32_t* __restrict__ slot_of_row, Counters* __restrict__ ctr,
-    uint32_t* __restrict__ stats, int claim, uint32_t* __restrict__ zero_words,
-    uint32_t num_zero_words) {
+__device__ inline void gather_body(const Ctx& c) {
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * kThreads + threadIdx.x;
-  // this fetch's histograms are cleared here (they are first used two launches later)
-  for (uint32_t i = gtid; i < num_zero_words; i += gridDim.x * kThreads) zero_words[i] = 0;
+  const uint32_t nthreads = gridDim.x * kThreads;
+  // housekeeping for later launches: this fetch's histograms and the NEXT fetch's counter
+  // record are cleared here (neither is in use by anyone else at this point)
+  if (c.update)
+    for (uint32_t i = gtid; i < kBins1 + kBins2; i += nthreads) c.hist1[i] = 0;  // hist2 follows
+  if (c.ctr_next) {
+    uint32_t* nxt = reinterpret_cast<uint32_t*>(c.ctr_next);
+    for (uint32_t i = gtid; i < kCounterWords; i += nthreads) nxt[i] = 0;
+  }
+  const VecT* feats = reinterpret_cast<const VecT*>(c.feats);
+  const VecT* cache_buf = reinterpret_cast<const VecT*>(c.cache_buf);
+  VecT* out = reinterpret_cast<VecT*>(c.out);
+  const uint32_t dimv = c.dimv, tile_rows = c.tile_rows, n = c.n;
   const uint32_t wave = gtid >> 6;
-  const uint32_t num_waves = (gridDim.x * kThreads) >> 6;
+  const uint32_t num_waves = nthreads >> 6;
   const uint32_t tiles = (n + tile_rows - 1) / tile_rows;
   uint32_t acc_hits = 0, acc_miss = 0;   // wave-uniform
   for (uint32_t tile = wave; tile < tiles; tile += num_waves) {
@@ -121,18 +160,19 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(
     const VecT* src = nullptr;
     int32_t slot = -2;
     if (lane < static_cast<int>(rows)) {
-      const int64_t id = ids[row0 + lane];
-      if (id >= 0 && static_cast<uint64_t>(id) < num_ids) {
-        slot = map ? map[id] : -1;
+      const int64_t id = c.ids[row0 + lane];
+      if (id >= 0 && static_cast<uint64_t>(id) < c.num_ids) {
+        slot = c.map ? c.map[id] : -1;
         if (slot >= 0) {
           src = cache_buf + static_cast<uint64_t>(slot) * dimv;
+          if (c.update) c.touched[slot] = c.epoch_new;   // takes effect only if a miss follows
         } else {
           slot = -1;
           src = feats + static_cast<uint64_t>(id) * dimv;
-          if (claim) atomicMax(&map[id], -static_cast<int32_t>(row0 + lane + 1));
+          if (c.update) atomicMax(&c.map[id], -static_cast<int32_t>(row0 + lane + 1));
         }
       }
-      if (slot_of_row) slot_of_row[row0 + lane] = slot;
+      if (c.slot_of_row) c.slot_of_row[row0 + lane] = slot;
     }
     acc_hits += __popcll(__ballot(slot >= 0));
     acc_miss += __popcll(__ballot(slot == -1));
@@ -145,9 +185,9 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(
     auto load = [&](uint32_t fu, bool* valid) -> VecT {
       *valid = fu < total;
       const uint32_t r = *valid ? fu / dimv : 0u;
-      const uint32_t c = fu - r * dimv;
+      const uint32_t cc = fu - r * dimv;
       const VecT* s = reinterpret_cast<const VecT*>(__shfl(src_bits, r, 64));
-      return (*valid && s) ? s[c] : vec_zero<VecT>();
+      return (*valid && s) ? s[cc] : vec_zero<VecT>();
     };
     // 4 independent 16-byte loads in flight per lane
     for (uint32_t base = 0; base < total; base += 256) {
@@ -161,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(
       if (p3) o[f + 192] = v3;
     }
   }
-  if (ctr) {
+  if (c.ctr) {
     __shared__ uint32_t wg_hits, wg_miss;
     if (threadIdx.x == 0) { wg_hits = 0; wg_miss = 0; }
     __syncthreads();
@@ -171,104 +211,91 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      Shard* sh = &ctr->shard[blockIdx.x & (kShards - 1)];
-      if (wg_hits) atomicAdd(&sh->hits, wg_hits);
-      if (wg_miss) atomicAdd(&sh->n_miss, wg_miss);
-      if (stats && wg_hits) atomicAdd(&stats[2 * (blockIdx.x & (kShards - 1))], wg_hits);
+      const int sh = blockIdx.x & (kShards - 1);
+      if (wg_hits) atomicAdd(&c.ctr->shard[sh].hits, wg_hits);
+      if (wg_miss) atomicAdd(&c.ctr->shard[sh].n_miss, wg_miss);
+      if (c.stats && wg_hits) atomicAdd(&c.stats[2 * sh], wg_hits);
     }
   }
-  if (stats && gtid == 0) atomicAdd(&stats[1], n);
+  if (c.stats && gtid == 0) atomicAdd(&c.stats[1], n);
+}
+
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (c.n == 0) return;
+  if (c.vec4) gather_body<float4>(c);
+  else gather_body<float>(c);
 }
 
 // ---- LRU bookkeeping ---------------------------------------------------------------
-__device__ inline uint32_t slot_age(uint32_t epoch_new, uint32_t stamp) {
-  const uint32_t a = epoch_new - stamp;
+__device__ inline uint32_t slot_age(const Ctx& c, uint32_t s) {
+  if (c.touched[s] == c.epoch_new) return 0;     // hit in this block
+  const uint32_t a = c.epoch_new - c.stamp[s];
   return a < kAgeMax ? a : kAgeMax;
 }
 __device__ inline uint32_t age_bin1(uint32_t a) {
   return a < kFine ? a : kFine + ((a - kFine) >> 11);
 }
-
-// mark: representatives of the distinct missed ids (the row whose claim survived); hit
-// slots take the new epoch (`self.cache_*_count[cached_index] = 0`, lru_cache.py:138-139)
-__global__ __launch_bounds__(kThreads) void lru_mark_kernel(
-    const int64_t* __restrict__ ids, uint32_t n, const int32_t* __restrict__ slot_of_row,
-    const int32_t* __restrict__ map, uint32_t* __restrict__ stamp, uint32_t epoch_new,
-    uint32_t* __restrict__ rep_flag, const Counters* __restrict__ ctr) {
-  if (total_miss(ctr) == 0) return;
-  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n) return;
-  const int32_t s = slot_of_row[i];
-  uint32_t rep = 0;
-  if (s >= 0) {
-    stamp[s] = epoch_new;
-  } else if (s == -1) {
-    rep = map[ids[i]] == -static_cast<int32_t>(i + 1);
-  }
-  rep_flag[i] = rep;
-}
-
-// workgroup-wide chained exclusive scan of in[0..n) (kWide threads)
-__device__ inline uint32_t block_scan_u32(const uint32_t* __restrict__ in,
-                                          uint32_t* __restrict__ out, uint32_t n) {
-  __shared__ uint32_t wave_sums[kWide / 64];
-  __shared__ uint32_t carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr uint32_t kItems = 4;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (uint32_t tile = 0; tile < n; tile += kWide * kItems) {
-    uint32_t v[kItems], local = 0;
-    const uint32_t i0 = tile + tid * kItems;
-#pragma unroll
-    for (uint32_t k = 0; k < kItems; ++k) {
-      v[k] = (i0 + k < n) ? in[i0 + k] : 0u;
-      local += v[k];
-    }
-    uint32_t incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t up = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += up;
-    }
-    if (lane == 63) wave_sums[wave] = incl;
-    __syncthreads();
-    uint32_t wave_base = 0;
-    for (int w = 0; w < wave; ++w) wave_base += wave_sums[w];
-    uint32_t run = carry_s + wave_base + incl - local;
-#pragma unroll
-    for (uint32_t k = 0; k < kItems; ++k) {
-      if (i0 + k < n) out[i0 + k] = run;
-      run += v[k];
-    }
-    __syncthreads();
-    if (tid == kWide - 1) carry_s = run;
-    __syncthreads();
-  }
-  return carry_s;
+// first row of a distinct missed id: its claim survived the gather's atomicMax
+__device__ inline uint32_t is_rep(const Ctx& c, uint32_t i) {
+  return c.slot_of_row[i] == -1 && c.map[c.ids[i]] == -static_cast<int32_t>(i + 1);
 }
 
 // workgroup 0: scan of the representative flags (rank in block order, #unique);
 // workgroups 1..: level-1 histogram of the slot ages
-__global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(
-    const uint32_t* __restrict__ rep_flag, uint32_t* __restrict__ rep_rank, uint32_t n,
-    const uint32_t* __restrict__ stamp, uint32_t capacity, uint32_t epoch_new,
-    uint32_t* __restrict__ hist1, Counters* ctr) {
-  if (total_miss(ctr) == 0) return;
+__global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(Round r) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (!needs_update(c)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (blockIdx.x == 0) {
-    const uint32_t total = block_scan_u32(rep_flag, rep_rank, n);
-    if (threadIdx.x == 0) ctr->n_unique = total;
+    __shared__ uint32_t wave_sums[kWide / 64];
+    __shared__ uint32_t carry_s;
+    constexpr uint32_t kItems = 4;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t tile = 0; tile < c.n; tile += kWide * kItems) {
+      uint32_t v[kItems], local = 0;
+      const uint32_t i0 = tile + tid * kItems;
+#pragma unroll
+      for (uint32_t k = 0; k < kItems; ++k) {
+        v[k] = (i0 + k < c.n) ? is_rep(c, i0 + k) : 0u;
+        local += v[k];
+      }
+      uint32_t incl = local;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      if (lane == 63) wave_sums[wave] = incl;
+      __syncthreads();
+      uint32_t wave_base = 0;
+      for (int w = 0; w < wave; ++w) wave_base += wave_sums[w];
+      uint32_t run = carry_s + wave_base + incl - local;
+#pragma unroll
+      for (uint32_t k = 0; k < kItems; ++k) {
+        if (i0 + k < c.n) {
+          c.rep_flag[i0 + k] = v[k];
+          c.rep_rank[i0 + k] = run;
+        }
+        run += v[k];
+      }
+      __syncthreads();
+      if (tid == kWide - 1) carry_s = run;
+      __syncthreads();
+    }
+    if (tid == 0) c.ctr->n_unique = carry_s;
     return;
   }
   __shared__ uint32_t h[kBins1];
-  for (int b = threadIdx.x; b < kBins1; b += kWide) h[b] = 0;
+  for (int b = tid; b < kBins1; b += kWide) h[b] = 0;
   __syncthreads();
   const uint32_t stride = (gridDim.x - 1) * kWide;
-  for (uint32_t s = (blockIdx.x - 1) * kWide + threadIdx.x; s < capacity; s += stride)
-    atomicAdd(&h[age_bin1(slot_age(epoch_new, stamp[s]))], 1u);
+  for (uint32_t s = (blockIdx.x - 1) * kWide + tid; s < c.capacity; s += stride)
+    atomicAdd(&h[age_bin1(slot_age(c, s))], 1u);
   __syncthreads();
-  for (int b = threadIdx.x; b < kBins1; b += kWide)
-    if (h[b]) atomicAdd(&hist1[b], h[b]);
+  for (int b = tid; b < kBins1; b += kWide)
+    if (h[b]) atomicAdd(&c.hist1[b], h[b]);
 }
 
 // Finds the bin B (scanning from the oldest = highest bin) where the cumulative count
@@ -343,64 +370,58 @@ __device__ inline Threshold find_threshold(const uint32_t* hist1, const uint32_t
 // the capacity give their claim back ("we only cache the first self.capacity",
 // lru_cache.py:127-133).  slots: level-2 histogram, only when the threshold lies in a
 // coarse bin (a slot untouched for more than 2047 updates).
-__global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(
-    const int64_t* __restrict__ ids, uint32_t n, const uint32_t* __restrict__ rep_flag,
-    const uint32_t* __restrict__ rep_rank, uint32_t* __restrict__ rep_row, int32_t* map,
-    const uint32_t* __restrict__ stamp, uint32_t capacity, uint32_t epoch_new,
-    const uint32_t* __restrict__ hist1, uint32_t* __restrict__ hist2,
-    const Counters* __restrict__ ctr) {
-  if (total_miss(ctr) == 0) return;
-  const uint32_t k = min(ctr->n_unique, capacity);
+__global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(Round r) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (!needs_update(c)) return;
+  const uint32_t k = min(c.ctr->n_unique, c.capacity);
   const uint32_t stride = gridDim.x * kWide;
-  for (uint32_t i = blockIdx.x * kWide + threadIdx.x; i < n; i += stride) {
-    if (!rep_flag[i]) continue;
-    const uint32_t rank = rep_rank[i];
-    if (rank < k) rep_row[rank] = i;
-    else map[ids[i]] = kAbsent;
+  for (uint32_t i = blockIdx.x * kWide + threadIdx.x; i < c.n; i += stride) {
+    if (!c.rep_flag[i]) continue;
+    const uint32_t rank = c.rep_rank[i];
+    if (rank < k) c.rep_row[rank] = i;
+    else c.map[c.ids[i]] = kAbsent;
   }
   uint32_t b1, k_rem;
-  find_bin_from_top<kBins1>(hist1, k, &b1, &k_rem);
-  if (b1 < kFine) return;   // uniform across the grid
+  find_bin_from_top<kBins1>(c.hist1, k, &b1, &k_rem);
+  if (b1 < kFine) return;   // uniform across the context's workgroups
   __shared__ uint32_t h[kBins2];
   for (int b = threadIdx.x; b < kBins2; b += kWide) h[b] = 0;
   __syncthreads();
-  for (uint32_t s = blockIdx.x * kWide + threadIdx.x; s < capacity; s += stride) {
-    const uint32_t a = slot_age(epoch_new, stamp[s]);
+  for (uint32_t s = blockIdx.x * kWide + threadIdx.x; s < c.capacity; s += stride) {
+    const uint32_t a = slot_age(c, s);
     if (age_bin1(a) == b1) atomicAdd(&h[(a - kFine) & (kBins2 - 1)], 1u);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < kBins2; b += kWide)
-    if (h[b]) atomicAdd(&hist2[b], h[b]);
+    if (h[b]) atomicAdd(&c.hist2[b], h[b]);
 }
 
 // per tile of kTile slots: how many sit exactly at the threshold age, and how many are
 // older than it (all of those are evicted)
-__global__ __launch_bounds__(kWide) void lru_tile_count_kernel(
-    const uint32_t* __restrict__ stamp, uint32_t capacity, uint32_t epoch_new,
-    const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ hist2,
-    uint32_t* __restrict__ tile_tie, uint32_t* __restrict__ tile_old, Counters* ctr) {
-  if (total_miss(ctr) == 0) return;
+__global__ __launch_bounds__(kWide) void lru_tile_count_kernel(Round r) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (!needs_update(c)) return;
   __shared__ uint32_t cnt[2];
-  const uint32_t k = min(ctr->n_unique, capacity);
-  const Threshold th = find_threshold(hist1, hist2, k);
+  const uint32_t k = min(c.ctr->n_unique, c.capacity);
+  const Threshold th = find_threshold(c.hist1, c.hist2, k);
   if (blockIdx.x == 0 && threadIdx.x == 0) {   // the install kernel reads it from here
-    ctr->th_age = th.age;
-    ctr->th_k_tie = th.k_tie;
+    c.ctr->th_age = th.age;
+    c.ctr->th_k_tie = th.k_tie;
   }
-  const uint32_t tiles = (capacity + kTile - 1) / kTile;
+  const uint32_t tiles = (c.capacity + kTile - 1) / kTile;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t s = tile * kTile + threadIdx.x;
-    const uint32_t a = s < capacity ? slot_age(epoch_new, stamp[s]) : 0u;
-    const uint32_t c = __popcll(__ballot(s < capacity && a == th.age));
-    const uint32_t o = __popcll(__ballot(s < capacity && a > th.age));
+    const uint32_t a = s < c.capacity ? slot_age(c, s) : 0u;
+    const uint32_t t = __popcll(__ballot(s < c.capacity && a == th.age));
+    const uint32_t o = __popcll(__ballot(s < c.capacity && a > th.age));
     if ((threadIdx.x & 63) == 0) {
-      if (c) atomicAdd(&cnt[0], c);
+      if (t) atomicAdd(&cnt[0], t);
       if (o) atomicAdd(&cnt[1], o);
     }
     __syncthreads();
-    if (threadIdx.x == 0) { tile_tie[tile] = cnt[0]; tile_old[tile] = cnt[1]; }
+    if (threadIdx.x == 0) { c.tile_tie[tile] = cnt[0]; c.tile_old[tile] = cnt[1]; }
     __syncthreads();
   }
 }
@@ -408,30 +429,27 @@ __global__ __launch_bounds__(kWide) void lru_tile_count_kernel(
 // evict + install + copy (lru_cache.py:141-160 with a deterministic tie rule): every slot
 // older than the threshold plus the first k_tie slots (in slot order) exactly at it; the
 // i-th evicted slot in slot order receives the i-th distinct missed id in block order,
-// and its row is copied from the output rows gathered a moment ago.
+// and its row is copied from the output rows gathered a moment ago.  Slots hit in this
+// block get their stamp here.
 template <typename VecT>
-__global__ __launch_bounds__(kTile) void lru_install_kernel(
-    const int64_t* __restrict__ ids, const uint32_t* __restrict__ rep_row, int32_t* map,
-    int64_t* __restrict__ slot_id, uint32_t* __restrict__ stamp, uint32_t capacity,
-    uint32_t epoch_new, const uint32_t* __restrict__ tile_tie,
-    const uint32_t* __restrict__ tile_old, const VecT* __restrict__ out, VecT* __restrict__ cache_buf, uint32_t dimv,
-    const Counters* __restrict__ ctr) {
-  if (total_miss(ctr) == 0) return;
+__device__ inline void install_body(const Ctx& c) {
   __shared__ uint32_t wave_tie[kTile / 64];
   __shared__ uint32_t wave_old[kTile / 64];
   __shared__ uint32_t red[2][kTile / 64];
   __shared__ uint2 inst[kTile];   // {slot, row} of this tile's installs
   __shared__ uint32_t n_inst;
-  const uint32_t k = min(ctr->n_unique, capacity);
+  const VecT* out = reinterpret_cast<const VecT*>(c.out);
+  VecT* cache_buf = reinterpret_cast<VecT*>(c.cache_buf);
+  const uint32_t k = min(c.ctr->n_unique, c.capacity);
   Threshold th;
-  th.age = ctr->th_age;
-  th.k_tie = ctr->th_k_tie;
-  const uint32_t tiles = (capacity + kTile - 1) / kTile;
+  th.age = c.ctr->th_age;
+  th.k_tie = c.ctr->th_k_tie;
+  const uint32_t tiles = (c.capacity + kTile - 1) / kTile;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     // bases = counts of all preceding tiles (summed by the whole workgroup)
     uint32_t pt = 0, po = 0;
-    for (uint32_t t = threadIdx.x; t < tile; t += kTile) { pt += tile_tie[t]; po += tile_old[t]; }
+    for (uint32_t t = threadIdx.x; t < tile; t += kTile) { pt += c.tile_tie[t]; po += c.tile_old[t]; }
     for (int d = 32; d > 0; d >>= 1) { pt += __shfl_down(pt, d, 64); po += __shfl_down(po, d, 64); }
     if (lane == 0) { red[0][wave] = pt; red[1][wave] = po; }
     if (threadIdx.x == 0) n_inst = 0;
@@ -440,8 +458,9 @@ __global__ __launch_bounds__(kTile) void lru_install_kernel(
     for (int w = 0; w < kTile / 64; ++w) { tie_base += red[0][w]; old_base += red[1][w]; }
 
     const uint32_t s = tile * kTile + threadIdx.x;
-    const bool in = s < capacity;
-    const uint32_t a = in ? slot_age(epoch_new, stamp[s]) : 0u;
+    const bool in = s < c.capacity;
+    const bool hit = in && c.touched[s] == c.epoch_new;
+    const uint32_t a = in ? slot_age(c, s) : 0u;
     const bool tie = in && a == th.age;
     const bool older = in && a > th.age;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -452,34 +471,45 @@ __global__ __launch_bounds__(kTile) void lru_install_kernel(
     uint32_t old_before = old_base + __popcll(mo & below);
     for (int w = 0; w < wave; ++w) { ties_before += wave_tie[w]; old_before += wave_old[w]; }
     const bool evict = k > 0 && (older || (tie && ties_before < th.k_tie));
+    bool stamped = false;
     if (evict) {
       const uint32_t v = old_before + min(ties_before, th.k_tie);  // rank in slot order
       if (v < k) {
-        const uint32_t row = rep_row[v];
-        const int64_t nid = ids[row];
-        const int64_t old = slot_id[s];
-        if (old >= 0) map[old] = kAbsent;
-        slot_id[s] = nid;
-        map[nid] = static_cast<int32_t>(s);
-        stamp[s] = epoch_new;
+        const uint32_t row = c.rep_row[v];
+        const int64_t nid = c.ids[row];
+        const int64_t old = c.slot_id[s];
+        if (old >= 0) c.map[old] = kAbsent;
+        c.slot_id[s] = nid;
+        c.map[nid] = static_cast<int32_t>(s);
+        c.stamp[s] = c.epoch_new;
+        stamped = true;
         inst[atomicAdd(&n_inst, 1u)] = make_uint2(s, row);
       }
     }
+    if (hit && !stamped) c.stamp[s] = c.epoch_new;   // count[cached_index] = 0
     __syncthreads();
     // one wave per installed row
     const uint32_t m = n_inst;
     for (uint32_t i = wave; i < m; i += kTile / 64) {
       const uint2 p = inst[i];
-      const VecT* src = out + static_cast<uint64_t>(p.y) * dimv;
-      VecT* dst = cache_buf + static_cast<uint64_t>(p.x) * dimv;
-      for (uint32_t c = lane; c < dimv; c += 64) dst[c] = src[c];
+      const VecT* src = out + static_cast<uint64_t>(p.y) * c.dimv;
+      VecT* dst = cache_buf + static_cast<uint64_t>(p.x) * c.dimv;
+      for (uint32_t cc = lane; cc < c.dimv; cc += 64) dst[cc] = src[cc];
     }
     __syncthreads();
   }
 }
 
+__global__ __launch_bounds__(kTile) void lru_install_kernel(Round r) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (!needs_update(c)) return;
+  if (c.vec4) install_body<float4>(c);
+  else install_body<float>(c);
+}
+
 __global__ void cache_fill_kernel(int32_t* map, uint64_t num_ids, int64_t* slot_id,
-                                  uint32_t* stamp, uint64_t capacity, int identity) {
+                                  uint32_t* stamp, uint32_t* touched, uint64_t capacity,
+                                  int identity) {
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < num_ids;
        i += stride)
@@ -488,6 +518,7 @@ __global__ void cache_fill_kernel(int32_t* map, uint64_t num_ids, int64_t* slot_
        s += stride) {
     slot_id[s] = identity ? static_cast<int64_t>(s) : -1;
     stamp[s] = 0;
+    touched[s] = 0;
   }
 }
 
@@ -504,29 +535,62 @@ inline uint32_t pick_tile_rows(size_t n) {
   return t;
 }
 
-void launch_gather(const int64_t* ids, size_t n, int32_t* map, const float* cache_buf,
-                   const float* feats, size_t num_ids, size_t dim, float* out,
-                   int32_t* slot_of_row, Counters* ctr, uint32_t* stats, bool claim,
-                   uint32_t* zero_words, uint32_t num_zero_words, hipStream_t stream) {
-  GF_REQUIRE(n < 0x7FFFFFFFull, "gather: more than 2^31-1 rows in one block");
-  ProfileScope ps(kProfGather, stream);
-  const uint32_t tile_rows = pick_tile_rows(n);
+inline unsigned gather_grid_for(size_t n, uint32_t tile_rows) {
   const size_t waves = (n + tile_rows - 1) / tile_rows;
-  const unsigned grid = static_cast<unsigned>(
-      std::max<size_t>(1, std::min<size_t>((waves + 3) / 4, 1024)));
-  if (vec4_ok(dim, cache_buf, feats, out)) {
-    gather_rows_kernel<float4><<<dim3(grid), dim3(kThreads), 0, stream>>>(
-        ids, static_cast<uint32_t>(n), map, reinterpret_cast<const float4*>(cache_buf),
-        reinterpret_cast<const float4*>(feats), num_ids, static_cast<uint32_t>(dim / 4),
-        tile_rows, reinterpret_cast<float4*>(out), slot_of_row, ctr, stats, claim ? 1 : 0,
-        zero_words, num_zero_words);
-  } else {
-    gather_rows_kernel<float><<<dim3(grid), dim3(kThreads), 0, stream>>>(
-        ids, static_cast<uint32_t>(n), map, cache_buf, feats, num_ids,
-        static_cast<uint32_t>(dim), tile_rows, out, slot_of_row, ctr, stats, claim ? 1 : 0,
-        zero_words, num_zero_words);
+  return static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>((waves + 3) / 4, 1024)));
+}
+
+// Issues one round: the gather for every context, then (if any context updates its cache)
+// the four bookkeeping launches.
+void launch_round(Round& r, hipStream_t stream) {
+  if (r.count == 0) return;
+  unsigned ggrid = 1;
+  size_t max_n = 0, max_cap = 0, max_tiles = 0;
+  bool any_update = false;
+  for (int i = 0; i < r.count; ++i) {
+    const Ctx& c = r.c[i];
+    GF_REQUIRE(c.n < 0x7FFFFFFFull, "gather: more than 2^31-1 rows in one block");
+    ggrid = std::max(ggrid, gather_grid_for(c.n, c.tile_rows));
+    if (c.update) {
+      any_update = true;
+      max_n = std::max<size_t>(max_n, c.n);
+      max_cap = std::max<size_t>(max_cap, c.capacity);
+      max_tiles = std::max<size_t>(max_tiles, (c.capacity + kTile - 1) / kTile);
+    }
   }
+  {
+    ProfileScope ps(kProfGather, stream);
+    gather_rows_kernel<<<dim3(ggrid, r.count), dim3(kThreads), 0, stream>>>(r);
+    GF_HIP(hipGetLastError());
+  }
+  if (!any_update) return;
+  ProfileScope ps(kProfLru, stream);
+  const unsigned slot_grid = static_cast<unsigned>(
+      std::max<size_t>(1, std::min<size_t>((max_cap + 4 * kWide - 1) / (4 * kWide), 1024)));
+  const unsigned both_grid = static_cast<unsigned>(std::max<size_t>(
+      1, std::min<size_t>((std::max(max_n, max_cap) + 4 * kWide - 1) / (4 * kWide), 1024)));
+  const unsigned tile_grid =
+      static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(max_tiles, 2048)));
+  lru_scan_hist_kernel<<<dim3(1 + slot_grid, r.count), dim3(kWide), 0, stream>>>(r);
+  lru_rank_hist2_kernel<<<dim3(both_grid, r.count), dim3(kWide), 0, stream>>>(r);
+  lru_tile_count_kernel<<<dim3(tile_grid, r.count), dim3(kWide), 0, stream>>>(r);
+  lru_install_kernel<<<dim3(tile_grid, r.count), dim3(kTile), 0, stream>>>(r);
   GF_HIP(hipGetLastError());
+}
+
+Ctx plain_ctx(const float* feats, size_t num_rows, size_t dim, const int64_t* ids, size_t n,
+              float* out) {
+  Ctx c;
+  std::memset(&c, 0, sizeof(c));
+  c.ids = ids;
+  c.n = static_cast<uint32_t>(n);
+  c.vec4 = vec4_ok(dim, feats, out, out) ? 1 : 0;
+  c.dimv = static_cast<uint32_t>(c.vec4 ? dim / 4 : dim);
+  c.tile_rows = pick_tile_rows(n);
+  c.out = out;
+  c.feats = feats;
+  c.num_ids = num_rows;
+  return c;
 }
 
 }  // namespace
@@ -537,8 +601,10 @@ void gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_
   GF_REQUIRE(d_feats && d_ids && d_out, "gather_rows: null pointer");
   GF_REQUIRE(dim > 0, "gather_rows: dim must be positive");
   DeviceGuard dg(device);
-  launch_gather(d_ids, n, nullptr, nullptr, d_feats, num_rows, dim, d_out, nullptr, nullptr,
-                nullptr, false, nullptr, 0, stream);
+  Round r;
+  r.count = 1;
+  r.c[0] = plain_ctx(d_feats, num_rows, dim, d_ids, n, d_out);
+  launch_round(r, stream);
 }
 
 FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const float* d_feats,
@@ -553,19 +619,25 @@ FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const fl
   map_.reserve(std::max<size_t>(num_ids * sizeof(int32_t), 16));
   slot_id_.reserve(std::max<size_t>(capacity * sizeof(int64_t), 16));
   stamp_.reserve(std::max<size_t>(capacity * sizeof(uint32_t), 16));
+  touched_.reserve(std::max<size_t>(capacity * sizeof(uint32_t), 16));
   state_.reserve(kRing * sizeof(Counters), 0, nullptr, true);
   cache_fill_kernel<<<dim3(1024), dim3(256), 0, nullptr>>>(
-      map_.as<int32_t>(), num_ids_, slot_id_.as<int64_t>(), stamp_.as<uint32_t>(), capacity_, 0);
+      map_.as<int32_t>(), num_ids_, slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
+      touched_.as<uint32_t>(), capacity_, 0);
   GF_HIP(hipGetLastError());
   GF_HIP(hipMemsetAsync(buffer_.data(), 0, buffer_.bytes(), nullptr));
+  GF_HIP(hipMemsetAsync(state_.data(), 0, state_.bytes(), nullptr));
   GF_HIP(hipStreamSynchronize(nullptr));
 }
+
+FeatureCache::~FeatureCache() = default;
 
 // Cache.init_cache (cache.py:175-195) / LRUCache.reset (lru_cache.py:91-105)
 void FeatureCache::init(hipStream_t stream) {
   DeviceGuard dg(device_);
   cache_fill_kernel<<<dim3(1024), dim3(256), 0, stream>>>(
-      map_.as<int32_t>(), num_ids_, slot_id_.as<int64_t>(), stamp_.as<uint32_t>(), capacity_, 1);
+      map_.as<int32_t>(), num_ids_, slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
+      touched_.as<uint32_t>(), capacity_, 1);
   GF_HIP(hipGetLastError());
   epoch_ = 0;
   if (capacity_)
@@ -596,9 +668,10 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
   if (new_capacity > capacity_) {
     buffer_.reserve(new_capacity * dim_ * sizeof(float), capacity_ * dim_ * sizeof(float),
                     stream, true);
-    DeviceBuffer nid, nst;
+    DeviceBuffer nid, nst, ntc;
     nid.reserve(new_capacity * sizeof(int64_t));
     nst.reserve(new_capacity * sizeof(uint32_t));
+    ntc.reserve(new_capacity * sizeof(uint32_t));
     std::vector<int64_t> empty_ids(new_capacity - capacity_, -1);
     GF_HIP(hipMemcpyAsync(nid.data(), slot_id_.data(), capacity_ * sizeof(int64_t),
                           hipMemcpyDeviceToDevice, stream));
@@ -607,9 +680,13 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
     GF_HIP(hipMemsetAsync(nst.data(), 0, new_capacity * sizeof(uint32_t), stream));
     GF_HIP(hipMemcpyAsync(nst.data(), stamp_.data(), capacity_ * sizeof(uint32_t),
                           hipMemcpyDeviceToDevice, stream));
+    GF_HIP(hipMemsetAsync(ntc.data(), 0, new_capacity * sizeof(uint32_t), stream));
+    GF_HIP(hipMemcpyAsync(ntc.data(), touched_.data(), capacity_ * sizeof(uint32_t),
+                          hipMemcpyDeviceToDevice, stream));
     GF_HIP(hipStreamSynchronize(stream));
     std::swap(slot_id_, nid);
     std::swap(stamp_, nst);
+    std::swap(touched_, ntc);
   }
   num_ids_ = new_num_ids;
   capacity_ = new_capacity;
@@ -622,72 +699,60 @@ void FeatureCache::reserve_workspace(size_t n) {
   const size_t tiles = (capacity_ + kTile - 1) / kTile + 1;
   size_t bytes = (kBins1 + kBins2) * sizeof(uint32_t) + 4 * align_up(ws_rows_ * 4, 16) +
                  2 * align_up(tiles * 4, 16) + 64;
+  // a reallocation must not pull the buffer from under kernels that are still queued
+  GF_HIP(hipDeviceSynchronize());
   ws_.reserve(bytes, 0, nullptr);
+}
+
+// Fills the device context of one block fetch and advances this cache's host-side state
+// (epoch, counter ring).  The caller launches the round.
+void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool update,
+                           uint32_t* d_stats, void* ctx_out) {
+  GF_REQUIRE(d_ids && d_out, "cache fetch: null pointer");
+  reserve_workspace(n);
+  const size_t tiles = (capacity_ + kTile - 1) / kTile;
+  Ctx& c = *static_cast<Ctx*>(ctx_out);
+  std::memset(&c, 0, sizeof(c));
+  char* p = ws_.as<char>();
+  c.hist1 = reinterpret_cast<uint32_t*>(p);         p += kBins1 * sizeof(uint32_t);
+  c.hist2 = reinterpret_cast<uint32_t*>(p);         p += kBins2 * sizeof(uint32_t);
+  c.slot_of_row = reinterpret_cast<int32_t*>(p);    p += align_up(ws_rows_ * 4, 16);
+  c.rep_flag = reinterpret_cast<uint32_t*>(p);      p += align_up(ws_rows_ * 4, 16);
+  c.rep_rank = reinterpret_cast<uint32_t*>(p);      p += align_up(ws_rows_ * 4, 16);
+  c.rep_row = reinterpret_cast<uint32_t*>(p);       p += align_up(ws_rows_ * 4, 16);
+  c.tile_tie = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
+  c.tile_old = reinterpret_cast<uint32_t*>(p);
+  c.ids = d_ids;
+  c.n = static_cast<uint32_t>(n);
+  c.vec4 = vec4_ok(dim_, buffer_.data(), feats_, d_out) ? 1 : 0;
+  c.dimv = static_cast<uint32_t>(c.vec4 ? dim_ / 4 : dim_);
+  c.tile_rows = pick_tile_rows(n);
+  c.out = d_out;
+  c.feats = feats_;
+  c.num_ids = num_ids_;
+  c.map = capacity_ ? map_.as<int32_t>() : nullptr;
+  c.cache_buf = buffer_.as<float>();
+  c.slot_id = slot_id_.as<int64_t>();
+  c.stamp = stamp_.as<uint32_t>();
+  c.touched = touched_.as<uint32_t>();
+  c.capacity = static_cast<uint32_t>(capacity_);
+  c.update = (update && capacity_ > 0) ? 1 : 0;
+  c.epoch_new = c.update ? ++epoch_ : epoch_;
+  c.ctr = state_.as<Counters>() + (ring_pos_ % kRing);
+  c.ctr_next = state_.as<Counters>() + ((ring_pos_ + 1) % kRing);
+  ring_pos_++;
+  c.stats = d_stats;
 }
 
 // One block of Cache.fetch_feature (cache.py:269-323 / :326-400)
 void FeatureCache::fetch(const int64_t* d_ids, size_t n, float* d_out, bool update,
                          uint32_t* d_stats, hipStream_t stream) {
   if (n == 0) return;
-  GF_REQUIRE(d_ids && d_out, "cache fetch: null pointer");
   DeviceGuard dg(device_);
-  reserve_workspace(n);
-  const size_t tiles = (capacity_ + kTile - 1) / kTile;
-  Workspace w;
-  char* p = ws_.as<char>();
-  w.hist1 = reinterpret_cast<uint32_t*>(p);         p += kBins1 * sizeof(uint32_t);
-  w.hist2 = reinterpret_cast<uint32_t*>(p);         p += kBins2 * sizeof(uint32_t);
-  w.slot_of_row = reinterpret_cast<int32_t*>(p);    p += align_up(ws_rows_ * 4, 16);
-  w.rep_flag = reinterpret_cast<uint32_t*>(p);      p += align_up(ws_rows_ * 4, 16);
-  w.rep_rank = reinterpret_cast<uint32_t*>(p);      p += align_up(ws_rows_ * 4, 16);
-  w.rep_row = reinterpret_cast<uint32_t*>(p);       p += align_up(ws_rows_ * 4, 16);
-  w.tile_tie = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
-  w.tile_old = reinterpret_cast<uint32_t*>(p);
-
-  // per-fetch counter record from a ring that is re-zeroed every kRing fetches
-  if (ring_pos_ % kRing == 0)
-    GF_HIP(hipMemsetAsync(state_.data(), 0, kRing * sizeof(Counters), stream));
-  Counters* ctr = state_.as<Counters>() + (ring_pos_ % kRing);
-  ring_pos_++;
-
-  const bool do_update = update && capacity_ > 0;
-  launch_gather(d_ids, n, capacity_ ? map_.as<int32_t>() : nullptr, buffer_.as<float>(), feats_,
-                num_ids_, dim_, d_out, w.slot_of_row, ctr, d_stats, do_update,
-                do_update ? w.hist1 : nullptr, do_update ? kBins1 + kBins2 : 0, stream);
-  if (!do_update) return;
-
-  ProfileScope ps(kProfLru, stream);
-  const uint32_t n32 = static_cast<uint32_t>(n), cap32 = static_cast<uint32_t>(capacity_);
-  const uint32_t epoch_new = ++epoch_;
-  const unsigned row_grid = static_cast<unsigned>((n + kThreads - 1) / kThreads);
-  const unsigned slot_grid = static_cast<unsigned>(
-      std::max<size_t>(1, std::min<size_t>((capacity_ + 4 * kWide - 1) / (4 * kWide), 1024)));
-  const unsigned both_grid = static_cast<unsigned>(std::max<size_t>(
-      1, std::min<size_t>((std::max(n, capacity_) + 4 * kWide - 1) / (4 * kWide), 1024)));
-  const unsigned tile_grid = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(tiles, 2048)));
-  lru_mark_kernel<<<dim3(row_grid), dim3(kThreads), 0, stream>>>(
-      d_ids, n32, w.slot_of_row, map_.as<int32_t>(), stamp_.as<uint32_t>(), epoch_new,
-      w.rep_flag, ctr);
-  lru_scan_hist_kernel<<<dim3(1 + slot_grid), dim3(kWide), 0, stream>>>(
-      w.rep_flag, w.rep_rank, n32, stamp_.as<uint32_t>(), cap32, epoch_new, w.hist1, ctr);
-  lru_rank_hist2_kernel<<<dim3(both_grid), dim3(kWide), 0, stream>>>(
-      d_ids, n32, w.rep_flag, w.rep_rank, w.rep_row, map_.as<int32_t>(), stamp_.as<uint32_t>(),
-      cap32, epoch_new, w.hist1, w.hist2, ctr);
-  lru_tile_count_kernel<<<dim3(tile_grid), dim3(kWide), 0, stream>>>(
-      stamp_.as<uint32_t>(), cap32, epoch_new, w.hist1, w.hist2, w.tile_tie, w.tile_old, ctr);
-  if (vec4_ok(dim_, buffer_.data(), d_out, d_out)) {
-    lru_install_kernel<float4><<<dim3(tile_grid), dim3(kTile), 0, stream>>>(
-        d_ids, w.rep_row, map_.as<int32_t>(), slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
-        cap32, epoch_new, w.tile_tie, w.tile_old,
-        reinterpret_cast<const float4*>(d_out), buffer_.as<float4>(),
-        static_cast<uint32_t>(dim_ / 4), ctr);
-  } else {
-    lru_install_kernel<float><<<dim3(tile_grid), dim3(kTile), 0, stream>>>(
-        d_ids, w.rep_row, map_.as<int32_t>(), slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
-        cap32, epoch_new, w.tile_tie, w.tile_old, d_out, buffer_.as<float>(),
-        static_cast<uint32_t>(dim_), ctr);
-  }
-  GF_HIP(hipGetLastError());
+  Round r;
+  r.count = 1;
+  prepare(d_ids, n, d_out, update, d_stats, &r.c[0]);
+  launch_round(r, stream);
 }
 
 void FeatureCache::gather_plain(const int64_t* d_ids, size_t n, float* d_out,
@@ -695,69 +760,56 @@ void FeatureCache::gather_plain(const int64_t* d_ids, size_t n, float* d_out,
   gather_rows(feats_, num_ids_, dim_, d_ids, n, d_out, device_, stream);
 }
 
-hipStream_t FeatureCache::side_stream() {
-  if (!side_stream_) {
-    DeviceGuard dg(device_);
-    GF_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
-    GF_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-    GF_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-  }
-  return side_stream_;
-}
-
-FeatureCache::~FeatureCache() {
-  if (side_stream_) {
-    (void)hipStreamSynchronize(side_stream_);
-    (void)hipEventDestroy(ev_fork_);
-    (void)hipEventDestroy(ev_join_);
-    (void)hipStreamDestroy(side_stream_);
-  }
-}
-
-// All feature fetches of one fetch_feature() call (cache.py:255-413) in one go.  The node
-// cache and the edge cache are independent, so the node blocks run on the node cache's
-// side stream while the edge blocks (which must stay ordered: each sees the LRU state the
-// previous one left) run on `stream`; fork/join with events, no host synchronisation.
+// All feature fetches of one fetch_feature() call (cache.py:255-413).  The node cache and
+// the edge cache are independent, so round i carries the i-th node block AND the i-th edge
+// block (the edge blocks must stay ordered: each sees the LRU state the previous one left);
+// cache-free gathers ride in the first round.  Every round is 1 + 4 launches whatever the
+// number of contexts in it.
 void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
                   hipStream_t stream) {
   GF_REQUIRE(descs != nullptr || n == 0, "fetch_blocks: null descriptors");
-  bool has_node = false, has_edge = false;
+  std::vector<const gf_fetch_desc*> nodes, edges, plain;
   for (size_t i = 0; i < n; ++i) {
-    GF_REQUIRE(descs[i].kind >= 0 && descs[i].kind <= 2, "fetch_blocks: bad kind");
-    if (descs[i].kind == 0) {
+    const gf_fetch_desc& d = descs[i];
+    GF_REQUIRE(d.kind >= 0 && d.kind <= 2, "fetch_blocks: bad kind");
+    if (d.n == 0) continue;
+    if (d.kind == 0) {
       GF_REQUIRE(node != nullptr, "fetch_blocks: node block without a node cache");
-      has_node = true;
+      nodes.push_back(&d);
     } else {
       GF_REQUIRE(edge != nullptr, "fetch_blocks: edge block without an edge cache");
-      has_edge = true;
+      (d.kind == 1 ? edges : plain).push_back(&d);
     }
   }
-  const bool fork = has_node && has_edge;
-  hipStream_t node_stream = stream;
-  if (fork) {
-    DeviceGuard dg(node->device());
-    node_stream = node->side_stream();
-    GF_HIP(hipEventRecord(node->ev_fork_, stream));
-    GF_HIP(hipStreamWaitEvent(node_stream, node->ev_fork_, 0));
+  const int device = node ? node->device() : (edge ? edge->device() : 0);
+  DeviceGuard dg(device);
+  size_t pi = 0;
+  const size_t rounds = std::max(nodes.size(), edges.size());
+  for (size_t i = 0; i < rounds; ++i) {
+    Round r;
+    r.count = 0;
+    if (i < nodes.size()) {
+      const gf_fetch_desc& d = *nodes[i];
+      node->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &r.c[r.count++]);
+    }
+    if (i < edges.size()) {
+      const gf_fetch_desc& d = *edges[i];
+      edge->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &r.c[r.count++]);
+    }
+    while (pi < plain.size() && r.count < kMaxCtx) {
+      const gf_fetch_desc& d = *plain[pi++];
+      r.c[r.count++] = plain_ctx(edge->feats_, edge->num_ids_, edge->dim_, d.d_ids, d.n, d.d_out);
+    }
+    launch_round(r, stream);
   }
-  for (size_t i = 0; i < n; ++i)
-    if (descs[i].kind == 0)
-      node->fetch(descs[i].d_ids, descs[i].n, descs[i].d_out, descs[i].update != 0,
-                  descs[i].d_stats, node_stream);
-  if (fork) {
-    DeviceGuard dg(node->device());
-    GF_HIP(hipEventRecord(node->ev_join_, node_stream));
-  }
-  for (size_t i = 0; i < n; ++i) {
-    if (descs[i].kind == 1)
-      edge->fetch(descs[i].d_ids, descs[i].n, descs[i].d_out, descs[i].update != 0,
-                  descs[i].d_stats, stream);
-    else if (descs[i].kind == 2)
-      edge->gather_plain(descs[i].d_ids, descs[i].n, descs[i].d_out, stream);
-  }
-  if (fork) {
-    DeviceGuard dg(node->device());
-    GF_HIP(hipStreamWaitEvent(stream, node->ev_join_, 0));
+  while (pi < plain.size()) {   // cache-free gathers that did not fit into a round
+    Round r;
+    r.count = 0;
+    while (pi < plain.size() && r.count < kMaxCtx) {
+      const gf_fetch_desc& d = *plain[pi++];
+      r.c[r.count++] = plain_ctx(edge->feats_, edge->num_ids_, edge->dim_, d.d_ids, d.n, d.d_out);
+    }
+    launch_round(r, stream);
   }
 }
 
@@ -771,7 +823,7 @@ void FeatureCache::slot_ids(int64_t* out, size_t capacity) const {
 
 size_t FeatureCache::mem_bytes() const {
   return capacity_ * dim_ * sizeof(float) + num_ids_ * sizeof(int32_t) +
-         capacity_ * (sizeof(int64_t) + sizeof(uint32_t));
+         capacity_ * (sizeof(int64_t) + 2 * sizeof(uint32_t));
 }
 
 }  // namespace gf

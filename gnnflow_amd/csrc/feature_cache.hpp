@@ -12,6 +12,10 @@ namespace gf {
 void gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_t* d_ids,
                  size_t n, float* d_out, int device, hipStream_t stream);
 
+class FeatureCache;
+void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
+                  hipStream_t stream);
+
 class FeatureCache {
  public:
   FeatureCache(size_t num_ids, size_t capacity, size_t dim, const float* d_feats, int device);
@@ -25,11 +29,15 @@ class FeatureCache {
   void slot_ids(int64_t* out, size_t capacity) const;
   size_t mem_bytes() const;
   int device() const { return device_; }
-  hipStream_t side_stream();
-  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
 
  private:
+  friend void fetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
+                           hipStream_t);
   void reserve_workspace(size_t n);
+  // fills a device context (feature_cache.hip: struct Ctx) for one block fetch and advances
+  // the host-side epoch / counter ring
+  void prepare(const int64_t* d_ids, size_t n, float* d_out, bool update, uint32_t* d_stats,
+               void* ctx_out);
 
   size_t num_ids_, capacity_, dim_;
   const float* feats_;
@@ -39,15 +47,12 @@ class FeatureCache {
   DeviceBuffer map_;       // int32[num_ids]               id -> slot (kAbsent if none)
   DeviceBuffer slot_id_;   // int64[capacity]              slot -> id (-1 empty)
   DeviceBuffer stamp_;     // uint32[capacity]             epoch of last touch
+  DeviceBuffer touched_;   // uint32[capacity]             epoch of the last hit (pending)
   DeviceBuffer state_;     // ring of per-fetch counter records
   DeviceBuffer ws_;        // per-fetch scratch
   size_t ws_rows_ = 0;
   uint32_t epoch_ = 0;     // fetches with update so far (host side; kernel argument)
   uint64_t ring_pos_ = 0;
-  hipStream_t side_stream_ = nullptr;
 };
-
-void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
-                  hipStream_t stream);
 
 }  // namespace gf
