@@ -64,6 +64,8 @@ constexpr uint32_t kAgeMax = kFine + 2048u * 2048u - 1u;
 constexpr int kTile = 1024;             // slots per tile (= install workgroup)
 constexpr int kRing = 32;               // per-fetch counter records
 constexpr int kMaxCtx = 3;              // contexts per round
+constexpr uint32_t kRowTile = 4096;     // rows per scan workgroup (kWide threads x 4)
+constexpr uint32_t kMaxRowTiles = 1024; // more row tiles than this: chained single-workgroup scan
 
 // One record per fetch.  hits / misses are accumulated once per workgroup into one of 8
 // shards that sit on separate 128-byte lines: same-address atomics retire at only
@@ -104,7 +106,9 @@ struct Ctx {
   int32_t* slot_of_row;
   uint32_t* rep_flag;
   uint32_t* rep_rank;
-  uint32_t* rep_row;
+  uint32_t* rep_row;        // rank -> row of the representative
+  int64_t* rep_id;          // rank -> id (saves the install kernel a dependent load)
+  uint32_t* row_tile_sum;   // [ceil(n / kRowTile)] representatives per row tile
   uint32_t* hist1;
   uint32_t* hist2;
   uint32_t* tile_tie;
@@ -241,21 +245,29 @@ __device__ inline uint32_t is_rep(const Ctx& c, uint32_t i) {
   return c.slot_of_row[i] == -1 && c.map[c.ids[i]] == -static_cast<int32_t>(i + 1);
 }
 
-// workgroup 0: scan of the representative flags (rank in block order, #unique);
-// workgroups 1..: level-1 histogram of the slot ages
-__global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(Round r) {
+// One launch, two kinds of workgroups (per context):
+//  * scan workgroups: each owns one tile of kRowTile rows, finds the representatives (first
+//    row of every distinct missed id) in it, ranks them inside the tile and publishes the
+//    tile's count; the next kernel adds the counts of the preceding tiles.  (Blocks of more
+//    than kMaxRowTiles tiles fall back to one workgroup chaining over all tiles.)
+//  * histogram workgroups: level-1 histogram of the slot ages.
+__global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(Round r, uint32_t scan_blocks) {
   const Ctx& c = r.c[blockIdx.y];
   if (!needs_update(c)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (blockIdx.x == 0) {
+  if (blockIdx.x < scan_blocks) {
     __shared__ uint32_t wave_sums[kWide / 64];
     __shared__ uint32_t carry_s;
-    constexpr uint32_t kItems = 4;
+    constexpr uint32_t kItems = kRowTile / kWide;
+    const uint32_t row_tiles = (c.n + kRowTile - 1) / kRowTile;
+    const bool chained = row_tiles > kMaxRowTiles;   // one workgroup walks every tile
+    if (chained ? blockIdx.x != 0 : blockIdx.x >= row_tiles) return;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t tile = 0; tile < c.n; tile += kWide * kItems) {
+    const uint32_t t_begin = chained ? 0 : blockIdx.x, t_end = chained ? row_tiles : blockIdx.x + 1;
+    for (uint32_t t = t_begin; t < t_end; ++t) {
       uint32_t v[kItems], local = 0;
-      const uint32_t i0 = tile + tid * kItems;
+      const uint32_t i0 = t * kRowTile + tid * kItems;
 #pragma unroll
       for (uint32_t k = 0; k < kItems; ++k) {
         v[k] = (i0 + k < c.n) ? is_rep(c, i0 + k) : 0u;
@@ -281,21 +293,53 @@ __global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(Round r) {
         run += v[k];
       }
       __syncthreads();
-      if (tid == kWide - 1) carry_s = run;
+      if (tid == kWide - 1) {
+        if (chained) carry_s = run;               // ranks are global already
+        else c.row_tile_sum[t] = run;             // tile-local ranks + the tile's count
+      }
       __syncthreads();
     }
-    if (tid == 0) c.ctr->n_unique = carry_s;
+    if (chained && tid == 0) {
+      c.row_tile_sum[0] = carry_s;                // the whole block as "one tile"
+    }
     return;
   }
   __shared__ uint32_t h[kBins1];
   for (int b = tid; b < kBins1; b += kWide) h[b] = 0;
   __syncthreads();
-  const uint32_t stride = (gridDim.x - 1) * kWide;
-  for (uint32_t s = (blockIdx.x - 1) * kWide + tid; s < c.capacity; s += stride)
+  const uint32_t hist_blocks = gridDim.x - scan_blocks;
+  const uint32_t stride = hist_blocks * kWide;
+  for (uint32_t s = (blockIdx.x - scan_blocks) * kWide + tid; s < c.capacity; s += stride)
     atomicAdd(&h[age_bin1(slot_age(c, s))], 1u);
   __syncthreads();
   for (int b = tid; b < kBins1; b += kWide)
     if (h[b]) atomicAdd(&c.hist1[b], h[b]);
+}
+
+// Exclusive prefix of the row-tile counts into LDS (every thread of the kWide-wide workgroup
+// calls it: one tile per thread, workgroup scan); returns the number of distinct missed ids.
+__device__ inline uint32_t load_row_tile_prefix(const Ctx& c, uint32_t* prefix /*[kMaxRowTiles]*/) {
+  __shared__ uint32_t wsum[kWide / 64];
+  __shared__ uint32_t total_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t row_tiles = (c.n + kRowTile - 1) / kRowTile;
+  const bool chained = row_tiles > kMaxRowTiles;   // one entry holding the total, base 0
+  const uint32_t m = chained ? 1u : row_tiles;
+  const uint32_t v = static_cast<uint32_t>(tid) < m ? c.row_tile_sum[tid] : 0u;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wsum[w];
+  if (static_cast<uint32_t>(tid) < m) prefix[tid] = chained ? 0u : wbase + incl - v;
+  if (tid == kWide - 1) total_s = wbase + incl;
+  __syncthreads();
+  return total_s;
 }
 
 // Finds the bin B (scanning from the oldest = highest bin) where the cumulative count
@@ -373,13 +417,22 @@ __device__ inline Threshold find_threshold(const uint32_t* hist1, const uint32_t
 __global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
   if (!needs_update(c)) return;
-  const uint32_t k = min(c.ctr->n_unique, c.capacity);
+  __shared__ uint32_t tile_prefix[kMaxRowTiles];
+  const uint32_t n_unique = load_row_tile_prefix(c, tile_prefix);
+  if (blockIdx.x == 0 && threadIdx.x == 0) c.ctr->n_unique = n_unique;   // for later kernels
+  const uint32_t k = min(n_unique, c.capacity);
+  const bool chained = (c.n + kRowTile - 1) / kRowTile > kMaxRowTiles;
   const uint32_t stride = gridDim.x * kWide;
   for (uint32_t i = blockIdx.x * kWide + threadIdx.x; i < c.n; i += stride) {
     if (!c.rep_flag[i]) continue;
-    const uint32_t rank = c.rep_rank[i];
-    if (rank < k) c.rep_row[rank] = i;
-    else c.map[c.ids[i]] = kAbsent;
+    const uint32_t rank = c.rep_rank[i] + (chained ? 0u : tile_prefix[i / kRowTile]);
+    const int64_t id = c.ids[i];
+    if (rank < k) {
+      c.rep_row[rank] = i;
+      c.rep_id[rank] = id;
+    } else {
+      c.map[id] = kAbsent;
+    }
   }
   uint32_t b1, k_rem;
   find_bin_from_top<kBins1>(c.hist1, k, &b1, &k_rem);
@@ -461,6 +514,7 @@ __device__ inline void install_body(const Ctx& c) {
     const bool in = s < c.capacity;
     const bool hit = in && c.touched[s] == c.epoch_new;
     const uint32_t a = in ? slot_age(c, s) : 0u;
+    const int64_t old = in ? c.slot_id[s] : -1;   // loaded for every slot: off the critical path
     const bool tie = in && a == th.age;
     const bool older = in && a > th.age;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -476,8 +530,7 @@ __device__ inline void install_body(const Ctx& c) {
       const uint32_t v = old_before + min(ties_before, th.k_tie);  // rank in slot order
       if (v < k) {
         const uint32_t row = c.rep_row[v];
-        const int64_t nid = c.ids[row];
-        const int64_t old = c.slot_id[s];
+        const int64_t nid = c.rep_id[v];
         if (old >= 0) c.map[old] = kAbsent;
         c.slot_id[s] = nid;
         c.map[nid] = static_cast<int32_t>(s);
@@ -571,7 +624,10 @@ void launch_round(Round& r, hipStream_t stream) {
       1, std::min<size_t>((std::max(max_n, max_cap) + 4 * kWide - 1) / (4 * kWide), 1024)));
   const unsigned tile_grid =
       static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(max_tiles, 2048)));
-  lru_scan_hist_kernel<<<dim3(1 + slot_grid, r.count), dim3(kWide), 0, stream>>>(r);
+  const unsigned scan_blocks = static_cast<unsigned>(
+      std::max<size_t>(1, std::min<size_t>((max_n + kRowTile - 1) / kRowTile, kMaxRowTiles)));
+  lru_scan_hist_kernel<<<dim3(scan_blocks + slot_grid, r.count), dim3(kWide), 0, stream>>>(
+      r, scan_blocks);
   lru_rank_hist2_kernel<<<dim3(both_grid, r.count), dim3(kWide), 0, stream>>>(r);
   lru_tile_count_kernel<<<dim3(tile_grid, r.count), dim3(kWide), 0, stream>>>(r);
   lru_install_kernel<<<dim3(tile_grid, r.count), dim3(kTile), 0, stream>>>(r);
@@ -698,7 +754,8 @@ void FeatureCache::reserve_workspace(size_t n) {
   ws_rows_ = std::max(ws_rows_, n);
   const size_t tiles = (capacity_ + kTile - 1) / kTile + 1;
   size_t bytes = (kBins1 + kBins2) * sizeof(uint32_t) + 4 * align_up(ws_rows_ * 4, 16) +
-                 2 * align_up(tiles * 4, 16) + 64;
+                 align_up(ws_rows_ * 8, 16) + 2 * align_up(tiles * 4, 16) +
+                 align_up((kMaxRowTiles + 1) * 4, 16) + 64;
   // a reallocation must not pull the buffer from under kernels that are still queued
   GF_HIP(hipDeviceSynchronize());
   ws_.reserve(bytes, 0, nullptr);
@@ -720,8 +777,10 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
   c.rep_flag = reinterpret_cast<uint32_t*>(p);      p += align_up(ws_rows_ * 4, 16);
   c.rep_rank = reinterpret_cast<uint32_t*>(p);      p += align_up(ws_rows_ * 4, 16);
   c.rep_row = reinterpret_cast<uint32_t*>(p);       p += align_up(ws_rows_ * 4, 16);
+  c.rep_id = reinterpret_cast<int64_t*>(p);         p += align_up(ws_rows_ * 8, 16);
   c.tile_tie = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
-  c.tile_old = reinterpret_cast<uint32_t*>(p);
+  c.tile_old = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
+  c.row_tile_sum = reinterpret_cast<uint32_t*>(p);
   c.ids = d_ids;
   c.n = static_cast<uint32_t>(n);
   c.vec4 = vec4_ok(dim_, buffer_.data(), feats_, d_out) ? 1 : 0;

@@ -197,3 +197,29 @@ def test_async_enqueue_matches_sync():
     caches[1].wait_enqueued()
     assert np.array_equal(caches[0]._edge.slot_ids(), caches[1]._edge.slot_ids())
     assert np.array_equal(caches[0]._node.slot_ids(), caches[1]._node.slot_ids())
+
+
+def test_huge_block_takes_chained_scan_path():
+    """More than 1024 row tiles (> 4 194 304 rows in one block) fall back to the chained
+    single-workgroup scan; results must still equal the oracle's."""
+    import torch
+    from gnnflow_amd.cache import LRUCache
+    from oracle.cache_oracle import OracleLRUCache
+    N, E, d = 8, 3000, 4
+    rng = np.random.RandomState(9)
+    ef = rng.rand(E, d).astype(np.float32)
+    nf = rng.rand(N, d).astype(np.float32)
+    hip = LRUCache(0.1, 0.0, N, E, "cuda:0", torch.from_numpy(nf), torch.from_numpy(ef), 0, d)
+    ora = OracleLRUCache(0.1, 0.0, N, E, None, ef, 0, d, overflow_rule="first_seen")
+    hip.init_cache()
+    ora.init_cache()
+    for it in range(2):
+        ids = rng.randint(0, E, 4300000).astype(np.int64)
+        hb = [[Blk(_to_ids(np.zeros(1, np.int64)), _to_ids(ids))]]
+        ob = [[Blk(np.zeros(1, np.int64), ids)]]
+        hip.fetch_feature(hb)
+        ora.fetch_feature(ob)
+        assert np.array_equal(_to_np(hb[0][0].edata["f"]), ob[0][0].edata["f"])
+        assert float(hip.cache_edge_ratio) == pytest.approx(ora.cache_edge_ratio, abs=1e-6)
+        sid = hip._edge.slot_ids()
+        assert np.array_equal(np.sort(sid[sid >= 0]), ora.edge.cached_ids())
