@@ -257,13 +257,24 @@ def main():
         # dominant kernel by bytes: the fused feature gather (one launch per block)
         achieved = gather_bytes / (g_ms.value * 1e-3) / 1e9
         out["roofline"] = {
-            "bound": "hbm", "kernel": "gather_rows_kernel<float4>",
+            "bound": "hbm", "kernel": "gather_rows_kernel",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "launches": int(g_n.value),
             "avg_launch_us": 1e3 * g_ms.value / g_n.value,
             "algorithmic_bytes_per_launch": gather_bytes / g_n.value,
         }
+        # HBM traffic of the same kernel from PMC counters (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate passes of this command, gfx950 FETCH x2 correction);
+        # collected offline by scripts/rocprof_pmc.sh and committed under profiles/
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gather_traffic.json")
+        default_cfg = (args.steps == 1121 and args.batch_size == 600 and args.fanouts == "10,10"
+                       and args.strategy == "recent" and args.cache_ratio == 0.2
+                       and not args.undirected and args.feature_placement == "device")
+        if default_cfg and os.path.exists(pmc):
+            with open(pmc) as f:
+                out["roofline"]["traffic"] = json.load(f)["hbm_traffic_bytes_per_dispatch"]
+            out["roofline"]["traffic_source"] = "profiles/r01_pmc_gather_traffic.json"
         out["cache_edge_ratio"] = float(cache.cache_edge_ratio)
         out["cache_node_ratio"] = float(cache.cache_node_ratio)
 

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 TAG=${1:-r1}
 mkdir -p gpurun_out/pmc
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc -o ${TAG}_$C -- python3 bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-pipeline > gpurun_out/pmc/${TAG}_$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc -o ${TAG}_$C -- python3 bench.py --no-cpu-baseline --no-pipeline > gpurun_out/pmc/${TAG}_$C.log 2>&1
 done
 ls gpurun_out/pmc | head
 python3 - <<PY
