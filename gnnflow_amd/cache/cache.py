@@ -33,7 +33,7 @@ class _Kind:
         assert feats.dim() == 2 and feats.shape[1] == self.dim, \
             "feature table must be [num_ids, dim]"
         if placement == "pinned":
-            feats = feats.contiguous()
+            feats = feats.cpu().contiguous()
             self.table = feats if feats.is_pinned() else feats.pin_memory()
         else:
             self.table = feats.to(device).contiguous()
@@ -214,7 +214,7 @@ class Cache:
         if f.dtype != torch.float32:
             f = f.to(torch.float32)
         if self.feature_placement == "pinned":
-            f = f.contiguous()
+            f = f.cpu().contiguous()
             table = f if f.is_pinned() else f.pin_memory()
         else:
             table = f.to(self.device).contiguous()

@@ -209,8 +209,9 @@ GF_API int gf_cache_fetch(gf_cache* c, const int64_t* d_ids, size_t n, float* d_
  * kind 1: block of edge ids through edge_cache (edata['f'], cache.py:326-400), executed
  *         in array order; kind 2: cache-free gather from the edge feature table
  *         (target_edge_features, cache.py:411).
- * Node blocks run concurrently with the edge blocks on an internal side stream that is
- * forked from / joined to `stream` with events. */
+ * The i-th node block and the i-th edge block share one round of launches (the kernels
+ * take several contexts and blockIdx.y selects one), so the two caches advance together
+ * on `stream`; no host synchronisation. */
 typedef struct gf_fetch_desc {
   int kind;
   int update;
