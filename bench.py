@@ -80,12 +80,20 @@ def main():
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # test hooks (single-GPU box): several ranks on one device, gloo for the bookkeeping
+    # collectives.  The driver's multi-GPU runs use neither.
+    if "GNNFLOW_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["GNNFLOW_BENCH_DEVICE"])
+    backend = os.environ.get("GNNFLOW_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.partition == "hash":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "--gpus must match the launched world size"
 
     import gnnflow_amd
@@ -212,7 +220,8 @@ def main():
     g_ms, g_n = C.c_double(0), C.c_uint64(0)
     lib.gf_profile_get(_capi.PROFILE_SLOTS["gather"], C.byref(g_ms), C.byref(g_n))
 
-    stats = torch.tensor([elapsed, float(edges)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, float(edges)], dtype=torch.float64,
+                         device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = stats[0:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -42,6 +42,8 @@ class PendingSample:
         if self._result is None:
             self._result = self._sampler._finish(self._buf, self._R)
             self._inputs = None
+            if self._sampler._inflight is self:
+                self._sampler._inflight = None
         return self._result
 
 
@@ -73,6 +75,7 @@ class TemporalSampler:
             float(snapshot_time_window), 1 if prop_time else 0, int(seed)))
         self._is_static = bool(kwargs.get('is_static', False))
         self._bytes_cache = {}
+        self._inflight = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -163,6 +166,9 @@ class TemporalSampler:
         training of batch i (the reference uses a prefetch thread for this,
         scripts/offline_edge_prediction.py:343-346).  One sample in flight per sampler.
         worker_enqueue=True lets the library's enqueue thread issue the launches."""
+        prev = getattr(self, "_inflight", None)
+        if prev is not None:       # an earlier sample_async() was never waited for
+            prev.wait()
         nodes, ts = self._to_device(target_vertices, timestamps)
         R = int(nodes.shape[0])
         if stream is None:
@@ -181,7 +187,8 @@ class TemporalSampler:
         _capi.check(begin(
             self._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
             buf.data_ptr() if R else None, nbytes, C.c_void_p(stream.cuda_stream)))
-        return PendingSample(self, buf, (nodes, ts), R)
+        self._inflight = PendingSample(self, buf, (nodes, ts), R)
+        return self._inflight
 
     def _finish(self, buf, R) -> List[List[MFGBlock]]:
         nblocks = self._num_layers * self._num_snapshots
