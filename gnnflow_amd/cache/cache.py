@@ -49,23 +49,6 @@ class _Kind:
     def init(self, stream):
         _capi.check(self.lib.gf_cache_init(self.h, stream))
 
-    def fetch(self, ids: torch.Tensor, update: bool, stats_ptr, stream) -> torch.Tensor:
-        n = int(ids.shape[0])
-        out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
-        if n:
-            _capi.check(self.lib.gf_cache_fetch(self.h, ids.data_ptr(), n, out.data_ptr(),
-                                                1 if update else 0, stats_ptr, stream))
-        return out
-
-    def gather(self, ids: torch.Tensor, stream) -> torch.Tensor:
-        n = int(ids.shape[0])
-        out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
-        if n:
-            _capi.check(self.lib.gf_gather_rows(self.table.data_ptr(), self.num_ids, self.dim,
-                                                ids.data_ptr(), n, out.data_ptr(),
-                                                self.device.index, stream))
-        return out
-
     def mem_bytes(self) -> int:
         n = C.c_size_t(0)
         _capi.check(self.lib.gf_cache_mem_bytes(self.h, C.byref(n)))
