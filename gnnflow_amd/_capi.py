@@ -101,6 +101,10 @@ PROTOTYPES = {
     "gf_cache_fetch_blocks_async": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p,
                                               C.POINTER(C.c_uint64)]),
     "gf_cache_fetch_wait": (C.c_int, [C.c_uint64]),
+    "gf_memory_prepare_input": (C.c_int, [_p, _p, _p, _p, _sz, _sz, _sz, _p, _sz, _p, _p, _p, _p,
+                                          C.c_int, _p]),
+    "gf_memory_update": (C.c_int, [_p, _p, _p, _p, _sz, _sz, _sz, _p, _p, _p, _p, _sz, C.c_int,
+                                   _p, _p, C.c_uint64, C.c_int, _p]),
     "gf_worker_stats": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "gf_gather_rows": (C.c_int, [_p, _sz, _sz, _p, _sz, _p, C.c_int, _p]),
     "gf_cache_slot_ids": (C.c_int, [_p, _p, _sz]),

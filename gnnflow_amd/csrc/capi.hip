@@ -392,6 +392,33 @@ int gf_cache_fetch_wait(uint64_t ticket) {
   if (rc != GF_OK) gf::set_last_error(err);
   return rc;
 }
+int gf_memory_prepare_input(const float* d_node_memory, const float* d_node_memory_ts,
+                            const float* d_mailbox, const float* d_mailbox_ts, size_t num_nodes,
+                            size_t dim_memory, size_t dim_mail, const int64_t* d_ids, size_t n,
+                            float* d_mem, float* d_mem_ts, float* d_mail_ts, float* d_mem_input,
+                            int device, void* stream) {
+  return guarded([&] {
+    const float* tables[4] = {d_node_memory, d_mailbox, d_node_memory_ts, d_mailbox_ts};
+    const size_t dims[4] = {dim_memory, dim_mail, 1, 1};
+    float* outs[4] = {d_mem, d_mem_input, d_mem_ts, d_mail_ts};
+    gf::gather_rows_multi(tables, dims, outs, 4, num_nodes, d_ids, n, device,
+                          static_cast<hipStream_t>(stream));
+  });
+}
+int gf_memory_update(float* d_node_memory, float* d_node_memory_ts, float* d_mailbox,
+                     float* d_mailbox_ts, size_t num_nodes, size_t dim_memory, size_t dim_edge,
+                     const int64_t* d_nid, const float* d_memory, const float* d_ts,
+                     const float* d_edge_feats, size_t n, int neg_sample_ratio,
+                     uint64_t* d_win_mail, uint64_t* d_win_mem, uint64_t epoch, int device,
+                     void* stream) {
+  return guarded([&] {
+    gf::memory_update(d_node_memory, d_node_memory_ts, d_mailbox, d_mailbox_ts, num_nodes,
+                      dim_memory, dim_edge, d_nid, d_memory, d_ts, d_edge_feats, n,
+                      neg_sample_ratio, reinterpret_cast<unsigned long long*>(d_win_mail),
+                      reinterpret_cast<unsigned long long*>(d_win_mem), epoch, device,
+                      static_cast<hipStream_t>(stream));
+  });
+}
 int gf_worker_stats(double* busy_us, uint64_t* jobs) {
   return guarded([&] {
     GF_REQUIRE(busy_us && jobs, "gf_worker_stats: null output");

@@ -64,7 +64,7 @@ constexpr int kBins2 = 2048;            // second level inside one coarse bin
 constexpr uint32_t kAgeMax = kFine + 2048u * 2048u - 1u;
 constexpr int kTile = 1024;             // slots per tile (= install workgroup)
 constexpr int kRing = 32;               // per-fetch counter records
-constexpr int kMaxCtx = 3;              // contexts per round
+constexpr int kMaxCtx = 4;              // contexts per round
 constexpr uint32_t kRowTile = 4096;     // rows per scan workgroup (kWide threads x 4)
 constexpr uint32_t kMaxRowTiles = 1024; // more row tiles than this: chained single-workgroup scan
 
@@ -668,6 +668,23 @@ void gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_
   Round r;
   r.count = 1;
   r.c[0] = plain_ctx(d_feats, num_rows, dim, d_ids, n, d_out);
+  launch_round(r, stream);
+}
+
+// Several cache-free gathers that share one id list (TGN memory: four tables), one launch.
+void gather_rows_multi(const float* const* tables, const size_t* dims, float* const* outs,
+                       size_t num_tables, size_t num_rows, const int64_t* d_ids, size_t n,
+                       int device, hipStream_t stream) {
+  if (n == 0 || num_tables == 0) return;
+  GF_REQUIRE(num_tables <= static_cast<size_t>(kMaxCtx), "gather_rows_multi: too many tables");
+  GF_REQUIRE(tables && dims && outs && d_ids, "gather_rows_multi: null pointer");
+  DeviceGuard dg(device);
+  Round r;
+  r.count = static_cast<int>(num_tables);
+  for (size_t t = 0; t < num_tables; ++t) {
+    GF_REQUIRE(tables[t] && outs[t] && dims[t] > 0, "gather_rows_multi: bad table");
+    r.c[t] = plain_ctx(tables[t], num_rows, dims[t], d_ids, n, outs[t]);
+  }
   launch_round(r, stream);
 }
 

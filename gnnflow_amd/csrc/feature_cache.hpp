@@ -12,6 +12,18 @@ namespace gf {
 void gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_t* d_ids,
                  size_t n, float* d_out, int device, hipStream_t stream);
 
+void gather_rows_multi(const float* const* tables, const size_t* dims, float* const* outs,
+                       size_t num_tables, size_t num_rows, const int64_t* d_ids, size_t n,
+                       int device, hipStream_t stream);
+
+// TGN memory / mailbox update, memory_ops.hip
+void memory_update(float* node_memory, float* node_memory_ts, float* mailbox, float* mailbox_ts,
+                   size_t num_nodes, size_t dim_memory, size_t dim_edge, const int64_t* nid,
+                   const float* memory, const float* ts, const float* edge_feats, size_t n,
+                   int neg_sample_ratio, unsigned long long* win_mail,
+                   unsigned long long* win_mem, unsigned long long epoch, int device,
+                   hipStream_t stream);
+
 class FeatureCache;
 void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
                   hipStream_t stream);

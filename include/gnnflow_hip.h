@@ -241,6 +241,30 @@ GF_API int gf_gather_rows(const float* d_feats, size_t num_rows, size_t dim,
                           const int64_t* d_ids, size_t n, float* d_out, int device,
                           void* stream);
 
+/* ---- TGN memory / mailbox: gnnflow/models/modules/memory.py -------- */
+/* Memory.prepare_input (memory.py:156-190): mem = node_memory[ids], mem_ts =
+ * node_memory_ts[ids], mail_ts = mailbox_ts[ids], mem_input = mailbox[ids] — the reference's
+ * CPU unique + inverse scatter is only an optimisation of exactly that.  One launch.
+ * dim_mail = 2 * dim_memory + dim_edge. */
+GF_API int gf_memory_prepare_input(const float* d_node_memory, const float* d_node_memory_ts,
+                                   const float* d_mailbox, const float* d_mailbox_ts,
+                                   size_t num_nodes, size_t dim_memory, size_t dim_mail,
+                                   const int64_t* d_ids, size_t n, float* d_mem, float* d_mem_ts,
+                                   float* d_mail_ts, float* d_mem_input, int device,
+                                   void* stream);
+/* Memory.update_mem_mail (memory.py:192-269): d_nid / d_memory / d_ts are the
+ * last_updated_{nid,memory,ts} of the n = (2 + neg_sample_ratio) * B roots; d_edge_feats
+ * [B, dim_edge] or NULL (zeros).  Per distinct node the LAST occurrence wins (mailbox: in the
+ * interleaved src0,dst0,src1,... order; memory: in src.. ++ dst.. order).  d_win_mail /
+ * d_win_mem: caller-owned uint64[num_nodes] scratch, zero-initialised once; epoch: strictly
+ * increasing, starting at 1. */
+GF_API int gf_memory_update(float* d_node_memory, float* d_node_memory_ts, float* d_mailbox,
+                            float* d_mailbox_ts, size_t num_nodes, size_t dim_memory,
+                            size_t dim_edge, const int64_t* d_nid, const float* d_memory,
+                            const float* d_ts, const float* d_edge_feats, size_t n,
+                            int neg_sample_ratio, uint64_t* d_win_mail, uint64_t* d_win_mem,
+                            uint64_t epoch, int device, void* stream);
+
 /* Introspection for tests / get_mem_size (cache.py:136-155): copies the slot ->
  * id table (int64[capacity], -1 = empty) to a host array. */
 GF_API int gf_cache_slot_ids(const gf_cache* c, int64_t* out, size_t capacity);
