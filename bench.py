@@ -124,7 +124,7 @@ def main():
         local = sampler
         sampler = PartitionedSampler(
             lambda n, t, layer, snap: local.sample_layer(n, t, layer, snap),
-            len(fanouts), 1, device=dev)
+            fanouts, 1, device=dev)
         args.no_pipeline = True
 
     gen = torch.Generator(device=dev).manual_seed(42)

@@ -6,10 +6,11 @@ Here the partitions are the GPUs of one node and the exchange is two all-to-all-
 over RCCL/xGMI (`torch.distributed`, backend "nccl" on ROCm; "gloo" in the CPU tests):
 
     1. bucket this rank's roots by owner(root) = splitmix64(root) mod P
-    2. all-to-all-v (root id, root ts)                       12 B / root
+    2. all-to-all-v of packed (root id, root ts)             16 B / root
     3. every rank samples the roots it received on its own shard (local HIP sampler)
-    4. all-to-all-v back: per-root edge count, then (dst, eid, ts, dt) per sampled edge
-    5. the requester scatters the replies into root-major order
+    4. all-to-all-v back: a fixed `fanout` slots per root of (dst, eid, ts|dt), invalid slots
+       marked -1, so the reply sizes follow from the request sizes (no count exchange)
+    5. the requester restores the original root order and keeps the valid slots
 
 Step 5 restores the original root order, so for most-recent sampling the MFG is
 bit-identical to what a single GPU holding the whole graph returns (the reference's merge
@@ -134,14 +135,34 @@ def _all_to_all_v(send: torch.Tensor, send_counts: List[int], recv_counts: List[
     return recv
 
 
+def _pack_f32_pair(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """two float32 vectors -> one int64 vector (bit pattern), so ids and timestamps travel
+    in a single all-to-all"""
+    p = torch.stack([a, b], dim=1)
+    return p.new_empty(p.shape).copy_(p).view(torch.int64).reshape(-1)
+
+
+def _unpack_f32_pair(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    # a fresh dense copy: .contiguous() keeps a stride-2 view when it has <= 1 element,
+    # and a dtype-changing view needs stride 1
+    f = x.new_empty(x.shape).copy_(x).view(torch.float32).reshape(-1, 2)
+    return f[:, 0].contiguous(), f[:, 1].contiguous()
+
+
 class PartitionedSampler:
     """TemporalSampler over a hash-partitioned graph: same `sample()` result layout as
-    the single-GPU sampler ([layer][snapshot] reversed, gnnflow/temporal_sampler.py:149-165)."""
+    the single-GPU sampler ([layer][snapshot] reversed, gnnflow/temporal_sampler.py:149-165).
 
-    def __init__(self, local_sample_layer: LayerFn, num_layers: int, num_snapshots: int = 1,
-                 group=None, device: Optional[torch.device] = None):
+    Three collectives per layer: per-destination root counts; one
+    all-to-all-v of packed (root id, root ts) requests; one all-to-all-v of replies with a
+    FIXED `fanout` slots per root (invalid slots marked), so the reply sizes follow from the
+    request sizes and no second count exchange is needed."""
+
+    def __init__(self, local_sample_layer: LayerFn, fanouts: Sequence[int],
+                 num_snapshots: int = 1, group=None, device: Optional[torch.device] = None):
         self._local = local_sample_layer
-        self._L, self._S = int(num_layers), int(num_snapshots)
+        self._fanouts = [int(f) for f in fanouts]
+        self._L, self._S = len(self._fanouts), int(num_snapshots)
         self._group = group
         self._P = dist.get_world_size(group)
         self._rank = dist.get_rank(group)
@@ -149,7 +170,7 @@ class PartitionedSampler:
 
     def sample_layer(self, nodes: torch.Tensor, ts: torch.Tensor, layer: int,
                      snapshot: int) -> LayerResult:
-        dev, P = self._device, self._P
+        dev, P, F = self._device, self._P, self._fanouts[layer]
         nodes = nodes.to(dev, torch.int64)
         ts = ts.to(dev, torch.float32)
         R = int(nodes.shape[0])
@@ -157,37 +178,42 @@ class PartitionedSampler:
         dest = owner_of(nodes, P)
         order = torch.argsort(dest, stable=True)
         send_counts = torch.bincount(dest, minlength=P)
-        # 2. counts, then roots + timestamps
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=self._group)
         sc, rc = send_counts.tolist(), recv_counts.tolist()
-        got_nodes = _all_to_all_v(nodes[order], sc, rc, self._group)
-        got_ts = _all_to_all_v(ts[order], sc, rc, self._group)
-        # 3. local sample of everything this rank owns
+        # 2. requests: [n, 2] int64 = (root id, root ts bits)
+        req = torch.stack([nodes[order], _pack_f32_pair(ts[order], torch.zeros_like(ts))], dim=1)
+        got = _all_to_all_v(req, sc, rc, self._group)
+        got_nodes = got[:, 0].contiguous()
+        got_ts, _ = _unpack_f32_pair(got[:, 1])
+        Rr = int(got_nodes.shape[0])
+        # 3. local sample of everything this rank owns, re-laid out as F fixed slots per root
         blk = self._local(got_nodes, got_ts, layer, snapshot)
         counts, dst, eid, ts_out, dt = _block_arrays(blk, dev)
-        # 4. replies: per-root counts, then the edges (edge splits follow the root splits)
-        back_counts = _all_to_all_v(counts, rc, sc, self._group)          # sorted-root order
-        edge_send = [int(c.sum()) for c in torch.split(counts, rc)] if len(rc) else []
-        edge_recv = [int(c.sum()) for c in torch.split(back_counts, sc)] if len(sc) else []
-        b_dst = _all_to_all_v(dst, edge_send, edge_recv, self._group)
-        b_eid = _all_to_all_v(eid, edge_send, edge_recv, self._group)
-        b_ts = _all_to_all_v(ts_out, edge_send, edge_recv, self._group)
-        b_dt = _all_to_all_v(dt, edge_send, edge_recv, self._group)
-        # 5. scatter into root-major order of the ORIGINAL roots
+        pad = torch.full((Rr, F, 3), -1, dtype=torch.int64, device=dev)
+        if dst.shape[0]:
+            row_l = torch.repeat_interleave(torch.arange(Rr, device=dev), counts)
+            base_l = torch.cumsum(counts, 0) - counts
+            pos = torch.arange(dst.shape[0], device=dev) - base_l[row_l]
+            pad[row_l, pos, 0] = dst
+            pad[row_l, pos, 1] = eid
+            pad[row_l, pos, 2] = _pack_f32_pair(ts_out, dt)
+        # 4. replies: F*3 words per requested root, same splits as the requests (reversed)
+        rep = _all_to_all_v(pad.reshape(Rr, F * 3), rc, sc, self._group).reshape(R, F, 3)
+        # 5. back to the ORIGINAL root order, then keep the valid slots (root-major order)
         inv = torch.empty_like(order)
         inv[order] = torch.arange(R, device=dev)
-        start_sorted = torch.cumsum(back_counts, 0) - back_counts           # exclusive
-        cnt = back_counts[inv]
-        src_start = start_sorted[inv]
-        S = int(cnt.sum())
-        row = torch.repeat_interleave(torch.arange(R, device=dev), cnt)
-        base = torch.cumsum(cnt, 0) - cnt
-        idx = src_start[row] + (torch.arange(S, device=dev) - base[row])
-        all_nodes = torch.cat([nodes, b_dst[idx]])
-        all_ts = torch.cat([ts, b_ts[idx]])
+        rep = rep[inv]
+        valid = rep[:, :, 0] >= 0
+        rj = torch.nonzero(valid)                 # sorted by (root, slot)
+        row = rj[:, 0].contiguous()
+        sel = rep[valid]                          # [S, 3] in the same order
+        S = int(sel.shape[0])
+        b_ts, b_dt = _unpack_f32_pair(sel[:, 2]) if S else (ts.new_empty(0), ts.new_empty(0))
+        all_nodes = torch.cat([nodes, sel[:, 0]])
+        all_ts = torch.cat([ts, b_ts])
         col = torch.arange(R, R + S, device=dev)
-        return LayerResult(all_nodes, all_ts, b_dt[idx], b_eid[idx], row, col, R)
+        return LayerResult(all_nodes, all_ts, b_dt, sel[:, 1].contiguous(), row, col, R)
 
     def sample(self, nodes, ts) -> List[List[LayerResult]]:
         if not isinstance(nodes, torch.Tensor):

@@ -108,8 +108,8 @@ class OracleGraph:
                                          1 if adaptive_block_size else 0)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().gfo_graph_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:   # not during interpreter exit
+            _lib.gfo_graph_destroy(self._h)
             self._h = None
 
     # gnnflow/dynamic_graph.py:85-126

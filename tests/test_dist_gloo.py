@@ -50,7 +50,7 @@ def _worker(rank, world, port, cfg, ret):
         def local_layer(nodes, t, layer, snap):
             return local.sample_layer(nodes.numpy(), t.numpy(), layer, snap)
 
-        ps = PartitionedSampler(local_layer, len(cfg["fanouts"]), cfg["snapshots"])
+        ps = PartitionedSampler(local_layer, cfg["fanouts"], cfg["snapshots"])
         ok = True
         for it, R in enumerate(cfg["batches"]):
             nodes, t = synth.random_roots(N, R, 1000.0, seed=1000 * rank + it,
