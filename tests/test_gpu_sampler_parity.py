@@ -193,3 +193,31 @@ def test_large_batch_parallel_scan_path(strategy):
     os_ = O.OracleSampler(o, **cfg)
     nodes, t = synth.random_roots(N, 70000, 1000.0, seed=77)
     _cmp_blocks(hs.sample(nodes, t), os_.sample(nodes, t), "R=70000")
+
+
+def test_offload_to_file_writes_reference_record_layout(tmp_path, monkeypatch):
+    """offload_old_blocks(to_file=True) writes temporal_block_<node>-<k>.bin with the
+    reference's record layout (temporal_block_allocator.cu:182-221): size, capacity (u64),
+    start_ts, end_ts (f32), dst[size] i64, ts[size] f32, eid[size] i64, prev, next (ptr)."""
+    import struct
+    monkeypatch.chdir(tmp_path)
+    g, o = _graphs(min_block=4)
+    s = np.array([0, 0, 0, 1, 1, 1])
+    d = np.array([1, 2, 3, 1, 2, 3])
+    for t0, e0 in ((0, 0), (3, 6)):
+        g.add_edges(s, d, np.array([t0, t0 + 1, t0 + 2] * 2), np.arange(e0, e0 + 6))
+        o.add_edges(s, d, np.array([t0, t0 + 1, t0 + 2] * 2), np.arange(e0, e0 + 6))
+    assert g.offload_old_blocks(3.5, to_file=True) == o.offload_old_blocks(3.5) == 2
+    for node, eids in ((0, [0, 1, 2, 6]), (1, [3, 4, 5, 9])):
+        raw = open("temporal_block_{}-0.bin".format(node), "rb").read()
+        size, cap = struct.unpack_from("<QQ", raw, 0)
+        start_ts, end_ts = struct.unpack_from("<ff", raw, 16)
+        assert (size, cap, start_ts, end_ts) == (4, 4, 0.0, 3.0)
+        off = 24
+        dst = np.frombuffer(raw, np.int64, size, off); off += 8 * size
+        ts = np.frombuffer(raw, np.float32, size, off); off += 4 * size
+        eid = np.frombuffer(raw, np.int64, size, off); off += 8 * size
+        assert dst.tolist() == [1, 2, 3, 1] and ts.tolist() == [0, 1, 2, 3]
+        assert eid.tolist() == eids
+        assert len(raw) == off + 16      # prev, next
+    assert g.num_edges() == o.num_edges() == 4
