@@ -22,6 +22,7 @@ INSERTION_POLICY = {"insert": 0, "replace": 1}
 SAMPLING_POLICY = {"recent": 0, "uniform": 1}
 MEM_RESOURCE = {"cuda": 0, "unified": 1, "pinned": 2, "shared": 3}
 
+CACHE_POLICY = {"lru": 0, "lfu": 1, "fifo": 2}
 PROFILE_SLOTS = {"search": 0, "emit": 1, "gather": 2, "scan": 3, "lru": 4}
 
 
@@ -94,6 +95,9 @@ PROTOTYPES = {
     "gf_host_blocks_free": (None, [C.POINTER(GfBlock), _sz]),
     "gf_cache_create": (C.c_int, [C.POINTER(_p), _sz, _sz, _sz, _p, C.c_int]),
     "gf_cache_destroy": (C.c_int, [_p]),
+    "gf_cache_set_policy": (C.c_int, [_p, C.c_int]),
+    "gf_cache_reset_order": (C.c_int, [_p, _p]),
+    "gf_cache_init_ids": (C.c_int, [_p, _p, _sz, _p]),
     "gf_cache_init": (C.c_int, [_p, _p]),
     "gf_cache_resize": (C.c_int, [_p, _sz, _sz, _p, _p]),
     "gf_cache_fetch": (C.c_int, [_p, _p, _sz, _p, C.c_int, _p, _p]),

@@ -1,4 +1,5 @@
 from .cache import Cache
 from .lru_cache import LRUCache
+from .policies import FIFOCache, GNNLabStaticCache, LFUCache
 
-__all__ = ["Cache", "LRUCache"]
+__all__ = ["Cache", "LRUCache", "LFUCache", "FIFOCache", "GNNLabStaticCache"]

@@ -23,7 +23,8 @@ from .. import _capi
 class _Kind:
     """One cache kind (node or edge): C handle + the device-readable feature table."""
 
-    def __init__(self, lib, num_ids, capacity, feats: torch.Tensor, dim, device, placement):
+    def __init__(self, lib, num_ids, capacity, feats: torch.Tensor, dim, device, placement,
+                 policy="lru"):
         self.lib = lib
         self.num_ids, self.capacity, self.dim = int(num_ids), int(capacity), int(dim)
         self.device = device
@@ -40,6 +41,7 @@ class _Kind:
         self.h = C.c_void_p()
         _capi.check(lib.gf_cache_create(C.byref(self.h), self.num_ids, self.capacity,
                                         self.dim, self.table.data_ptr(), device.index))
+        _capi.check(lib.gf_cache_set_policy(self.h, _capi.CACHE_POLICY[policy]))
 
     def close(self):
         if self.h is not None and self.h.value:
@@ -48,6 +50,9 @@ class _Kind:
 
     def init(self, stream):
         _capi.check(self.lib.gf_cache_init(self.h, stream))
+
+    def init_ids(self, ids: torch.Tensor, stream):
+        _capi.check(self.lib.gf_cache_init_ids(self.h, ids.data_ptr(), int(ids.shape[0]), stream))
 
     def mem_bytes(self) -> int:
         n = C.c_size_t(0)
@@ -65,6 +70,7 @@ class Cache:
     """
     Feature cache on GPU
     """
+    _policy = "lru"   # replacement policy of the native cache (subclasses override)
 
     def __init__(self, edge_cache_ratio: int, node_cache_ratio: int,
                  num_nodes: int, num_edges: int,
@@ -132,10 +138,10 @@ class Cache:
         with torch.cuda.device(device):
             if self.dim_node_feat != 0:
                 self._node = _Kind(self._lib, num_nodes, self.node_capacity, node_feats,
-                                   self.dim_node_feat, device, placement)
+                                   self.dim_node_feat, device, placement, self._policy)
             if self.dim_edge_feat != 0:
                 self._edge = _Kind(self._lib, num_edges, self.edge_capacity, edge_feats,
-                                   self.dim_edge_feat, device, placement)
+                                   self.dim_edge_feat, device, placement, self._policy)
         self._node_stats = self._edge_stats = None
 
     def __del__(self):

@@ -346,6 +346,15 @@ int gf_cache_create(gf_cache** out, size_t num_ids, size_t capacity, size_t dim,
 int gf_cache_destroy(gf_cache* c) {
   return guarded([&] { delete c; });
 }
+int gf_cache_set_policy(gf_cache* c, int policy) {
+  return guarded([&] { GF_C(c); c->impl.set_policy(policy); });
+}
+int gf_cache_reset_order(gf_cache* c, void* stream) {
+  return guarded([&] { GF_C(c); c->impl.reset_order(static_cast<hipStream_t>(stream)); });
+}
+int gf_cache_init_ids(gf_cache* c, const int64_t* d_ids, size_t n, void* stream) {
+  return guarded([&] { GF_C(c); c->impl.init_ids(d_ids, n, static_cast<hipStream_t>(stream)); });
+}
 int gf_cache_init(gf_cache* c, void* stream) {
   return guarded([&] { GF_C(c); c->impl.init(static_cast<hipStream_t>(stream)); });
 }

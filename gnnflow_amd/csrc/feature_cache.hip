@@ -82,7 +82,8 @@ struct Counters {
   uint32_t n_unique;  // distinct missed ids
   uint32_t th_age;    // eviction threshold (written by the tile-count kernel)
   uint32_t th_k_tie;
-  uint32_t pad[29];
+  uint32_t fifo_start;  // FIFO: first slot of this block's refill arc
+  uint32_t pad[28];
 };
 constexpr uint32_t kCounterWords = sizeof(Counters) / 4;
 
@@ -104,6 +105,8 @@ struct Ctx {
   uint32_t capacity;
   uint32_t epoch_new;
   int update;
+  int policy;               // GF_CACHE_LRU / _LFU / _FIFO
+  uint32_t* fifo_ptr;       // FIFO: last refilled slot (fifo_cache.py:66-69), device resident
   int32_t* slot_of_row;
   uint32_t* rep_flag;
   uint32_t* rep_rank;
@@ -170,7 +173,9 @@ __device__ inline void gather_body(const Ctx& c) {
         slot = c.map ? c.map[id] : -1;
         if (slot >= 0) {
           src = cache_buf + static_cast<uint64_t>(slot) * dimv;
-          if (c.update) c.touched[slot] = c.epoch_new;   // takes effect only if a miss follows
+          // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
+          // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161)
+          if (c.update && c.policy != GF_CACHE_FIFO) c.touched[slot] = c.epoch_new;
         } else {
           slot = -1;
           src = feats + static_cast<uint64_t>(id) * dimv;
@@ -233,8 +238,18 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
 }
 
 // ---- LRU bookkeeping ---------------------------------------------------------------
+// Eviction priority of a slot: larger goes first, ties to the lowest slot.
+//  LRU / FIFO: age in epochs of `stamp` (last touch / install); a slot hit in this block
+//              has age 0 (lru_cache.py:134-139).
+//  LFU       : `stamp` holds the use count; priority = kAgeMax - count, with this block's hit
+//              already counted (`count[cached_index] += 1` before topk, lfu_cache.py:159-163).
 __device__ inline uint32_t slot_age(const Ctx& c, uint32_t s) {
-  if (c.touched[s] == c.epoch_new) return 0;     // hit in this block
+  const bool hit = c.touched[s] == c.epoch_new;
+  if (c.policy == GF_CACHE_LFU) {
+    const uint32_t cnt = c.stamp[s] + (hit ? 1u : 0u);
+    return kAgeMax - (cnt < kAgeMax ? cnt : kAgeMax);
+  }
+  if (hit) return 0;     // hit in this block
   const uint32_t a = c.epoch_new - c.stamp[s];
   return a < kAgeMax ? a : kAgeMax;
 }
@@ -305,6 +320,7 @@ __global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(Round r, uint32_t 
     }
     return;
   }
+  if (c.policy == GF_CACHE_FIFO) return;   // victims come from the rotation pointer
   __shared__ uint32_t h[kBins1];
   for (int b = tid; b < kBins1; b += kWide) h[b] = 0;
   __syncthreads();
@@ -422,6 +438,13 @@ __global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(Round r) {
   const uint32_t n_unique = load_row_tile_prefix(c, tile_prefix);
   if (blockIdx.x == 0 && threadIdx.x == 0) c.ctr->n_unique = n_unique;   // for later kernels
   const uint32_t k = min(n_unique, c.capacity);
+  if (c.policy == GF_CACHE_FIFO && blockIdx.x == 0 && threadIdx.x == 0) {
+    // fifo_cache.py:96-105: the k slots after the pointer (wrapping) are refilled and the
+    // pointer moves to the last of them; k == capacity leaves it where it was
+    const uint32_t p = *c.fifo_ptr;
+    c.ctr->fifo_start = p + 1 == c.capacity ? 0u : p + 1;
+    *c.fifo_ptr = p + k >= c.capacity ? p + k - c.capacity : p + k;
+  }
   const bool chained = (c.n + kRowTile - 1) / kRowTile > kMaxRowTiles;
   const uint32_t stride = gridDim.x * kWide;
   for (uint32_t i = blockIdx.x * kWide + threadIdx.x; i < c.n; i += stride) {
@@ -435,6 +458,7 @@ __global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(Round r) {
       c.map[id] = kAbsent;
     }
   }
+  if (c.policy == GF_CACHE_FIFO) return;
   uint32_t b1, k_rem;
   find_bin_from_top<kBins1>(c.hist1, k, &b1, &k_rem);
   if (b1 < kFine) return;   // uniform across the context's workgroups
@@ -454,7 +478,7 @@ __global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(Round r) {
 // older than it (all of those are evicted)
 __global__ __launch_bounds__(kWide) void lru_tile_count_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
-  if (!needs_update(c)) return;
+  if (!needs_update(c) || c.policy == GF_CACHE_FIFO) return;
   __shared__ uint32_t cnt[2];
   const uint32_t k = min(c.ctr->n_unique, c.capacity);
   const Threshold th = find_threshold(c.hist1, c.hist2, k);
@@ -500,10 +524,16 @@ __device__ inline void install_body(const Ctx& c) {
   th.k_tie = c.ctr->th_k_tie;
   const uint32_t tiles = (c.capacity + kTile - 1) / kTile;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool fifo = c.policy == GF_CACHE_FIFO;
+  // FIFO: the victims are the arc [start, start + k) of the slot ring; in slot order the
+  // wrapped head [0, head) comes first, then [start, capacity) (fifo_cache.py:100-103)
+  const uint32_t start = fifo ? c.ctr->fifo_start : 0u;
+  const uint32_t head = fifo && start + k > c.capacity ? start + k - c.capacity : 0u;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     // bases = counts of all preceding tiles (summed by the whole workgroup)
     uint32_t pt = 0, po = 0;
-    for (uint32_t t = threadIdx.x; t < tile; t += kTile) { pt += c.tile_tie[t]; po += c.tile_old[t]; }
+    if (!fifo)
+      for (uint32_t t = threadIdx.x; t < tile; t += kTile) { pt += c.tile_tie[t]; po += c.tile_old[t]; }
     for (int d = 32; d > 0; d >>= 1) { pt += __shfl_down(pt, d, 64); po += __shfl_down(po, d, 64); }
     if (lane == 0) { red[0][wave] = pt; red[1][wave] = po; }
     if (threadIdx.x == 0) n_inst = 0;
@@ -525,22 +555,27 @@ __device__ inline void install_body(const Ctx& c) {
     uint32_t ties_before = tie_base + __popcll(mt & below);
     uint32_t old_before = old_base + __popcll(mo & below);
     for (int w = 0; w < wave; ++w) { ties_before += wave_tie[w]; old_before += wave_old[w]; }
-    const bool evict = k > 0 && (older || (tie && ties_before < th.k_tie));
+    bool evict = k > 0 && (older || (tie && ties_before < th.k_tie));
+    uint32_t v = old_before + min(ties_before, th.k_tie);   // rank in slot order
+    if (fifo) {
+      evict = in && (s < head || (s >= start && s - start < k));
+      v = s < head ? s : head + (s - start);
+    }
     bool stamped = false;
     if (evict) {
-      const uint32_t v = old_before + min(ties_before, th.k_tie);  // rank in slot order
       if (v < k) {
         const uint32_t row = c.rep_row[v];
         const int64_t nid = c.rep_id[v];
         if (old >= 0) c.map[old] = kAbsent;
         c.slot_id[s] = nid;
         c.map[nid] = static_cast<int32_t>(s);
-        c.stamp[s] = c.epoch_new;
+        c.stamp[s] = c.policy == GF_CACHE_LFU ? 1u : c.epoch_new;   // lfu: count = 1
         stamped = true;
         inst[atomicAdd(&n_inst, 1u)] = make_uint2(s, row);
       }
     }
-    if (hit && !stamped) c.stamp[s] = c.epoch_new;   // count[cached_index] = 0
+    if (hit && !stamped)   // lru: count[cached_index] = 0; lfu: count[cached_index] += 1
+      c.stamp[s] = c.policy == GF_CACHE_LFU ? c.stamp[s] + 1u : c.epoch_new;
     __syncthreads();
     // one wave per installed row
     const uint32_t m = n_inst;
@@ -563,7 +598,7 @@ __global__ __launch_bounds__(kTile) void lru_install_kernel(Round r) {
 
 __global__ void cache_fill_kernel(int32_t* map, uint64_t num_ids, int64_t* slot_id,
                                   uint32_t* stamp, uint32_t* touched, uint64_t capacity,
-                                  int identity) {
+                                  int identity, uint32_t stamp0) {
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < num_ids;
        i += stride)
@@ -571,7 +606,7 @@ __global__ void cache_fill_kernel(int32_t* map, uint64_t num_ids, int64_t* slot_
   for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; s < capacity;
        s += stride) {
     slot_id[s] = identity ? static_cast<int64_t>(s) : -1;
-    stamp[s] = 0;
+    stamp[s] = stamp0;
     touched[s] = 0;
   }
 }
@@ -702,9 +737,11 @@ FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const fl
   stamp_.reserve(std::max<size_t>(capacity * sizeof(uint32_t), 16));
   touched_.reserve(std::max<size_t>(capacity * sizeof(uint32_t), 16));
   state_.reserve(kRing * sizeof(Counters), 0, nullptr, true);
+  fifo_ptr_.reserve(16);
+  rewind_fifo(nullptr);
   cache_fill_kernel<<<dim3(1024), dim3(256), 0, nullptr>>>(
       map_.as<int32_t>(), num_ids_, slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
-      touched_.as<uint32_t>(), capacity_, 0);
+      touched_.as<uint32_t>(), capacity_, 0, 0u);
   GF_HIP(hipGetLastError());
   GF_HIP(hipMemsetAsync(buffer_.data(), 0, buffer_.bytes(), nullptr));
   GF_HIP(hipMemsetAsync(state_.data(), 0, state_.bytes(), nullptr));
@@ -718,12 +755,76 @@ void FeatureCache::init(hipStream_t stream) {
   DeviceGuard dg(device_);
   cache_fill_kernel<<<dim3(1024), dim3(256), 0, stream>>>(
       map_.as<int32_t>(), num_ids_, slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
-      touched_.as<uint32_t>(), capacity_, 1);
+      touched_.as<uint32_t>(), capacity_, 1,
+      policy_ == GF_CACHE_LFU ? 1u : 0u);   // LFUCache.init_cache: count += 1 (lfu_cache.py:80-84)
   GF_HIP(hipGetLastError());
   epoch_ = 0;
+  rewind_fifo(stream);
   if (capacity_)
     GF_HIP(hipMemcpyAsync(buffer_.data(), feats_, capacity_ * dim_ * sizeof(float),
                           hipMemcpyDefault, stream));
+}
+
+// FIFOCache.reset (fifo_cache.py:70-75) rewinds the rotation pointer and keeps the cached
+// ids: with install-epoch stamps that is "all slots equally old" -> refill from slot 0.
+// LFUCache.reset (lfu_cache.py:86-118) re-initialises and then zeroes the use counts.
+void FeatureCache::reset_order(hipStream_t stream) {
+  DeviceGuard dg(device_);
+  if (capacity_) {
+    GF_HIP(hipMemsetAsync(stamp_.data(), 0, capacity_ * sizeof(uint32_t), stream));
+    GF_HIP(hipMemsetAsync(touched_.data(), 0, capacity_ * sizeof(uint32_t), stream));
+  }
+  epoch_ = 0;
+  rewind_fifo(stream);
+}
+
+// cache_*_pointer = capacity - 1 (fifo_cache.py:63-69): the next refill starts at slot 0
+void FeatureCache::rewind_fifo(hipStream_t stream) {
+  GF_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fifo_ptr_.data()),
+                           capacity_ ? static_cast<int>(capacity_ - 1) : 0, 1, stream));
+}
+
+void FeatureCache::set_policy(int policy) {
+  GF_REQUIRE(policy == GF_CACHE_LRU || policy == GF_CACHE_LFU || policy == GF_CACHE_FIFO,
+             "cache: unknown replacement policy");
+  policy_ = policy;
+}
+
+namespace {
+__global__ void cache_install_ids_kernel(const int64_t* __restrict__ ids, uint64_t n,
+                                         uint64_t num_ids, uint32_t dim,
+                                         const float* __restrict__ feats, int32_t* map,
+                                         int64_t* slot_id, float* buffer) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (uint64_t s = wave; s < n; s += nwaves) {
+    const int64_t id = ids[s];
+    if (id < 0 || static_cast<uint64_t>(id) >= num_ids) continue;
+    if (lane == 0) { map[id] = static_cast<int32_t>(s); slot_id[s] = id; }
+    for (uint32_t c = lane; c < dim; c += 64)
+      buffer[s * dim + c] = feats[static_cast<uint64_t>(id) * dim + c];
+  }
+}
+}  // namespace
+
+// GNNLabStaticCache.init_cache (gnnlab_static_cache.py:87-168): slot i holds ids[i]
+void FeatureCache::init_ids(const int64_t* d_ids, size_t n, hipStream_t stream) {
+  GF_REQUIRE(n <= capacity_, "cache: more ids than slots");
+  GF_REQUIRE(d_ids != nullptr || n == 0, "cache: null id list");
+  DeviceGuard dg(device_);
+  cache_fill_kernel<<<dim3(1024), dim3(256), 0, stream>>>(
+      map_.as<int32_t>(), num_ids_, slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
+      touched_.as<uint32_t>(), capacity_, 0, 0u);
+  epoch_ = 0;
+  rewind_fifo(stream);
+  if (n) {
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>((n + 3) / 4, 4096));
+    cache_install_ids_kernel<<<dim3(grid), dim3(256), 0, stream>>>(
+        d_ids, n, num_ids_, static_cast<uint32_t>(dim_), feats_, map_.as<int32_t>(),
+        slot_id_.as<int64_t>(), buffer_.as<float>());
+  }
+  GF_HIP(hipGetLastError());
 }
 
 // Cache.resize (cache.py:197-221): grow the id space / capacity, keep the contents
@@ -821,6 +922,8 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
   c.touched = touched_.as<uint32_t>();
   c.capacity = static_cast<uint32_t>(capacity_);
   c.update = (update && capacity_ > 0) ? 1 : 0;
+  c.policy = policy_;
+  c.fifo_ptr = fifo_ptr_.as<uint32_t>();
   c.epoch_new = c.update ? ++epoch_ : epoch_;
   c.ctr = state_.as<Counters>() + (ring_pos_ % kRing);
   c.ctr_next = state_.as<Counters>() + ((ring_pos_ + 1) % kRing);

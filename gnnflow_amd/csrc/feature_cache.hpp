@@ -34,6 +34,10 @@ class FeatureCache {
   ~FeatureCache();
 
   void init(hipStream_t stream);
+  void init_ids(const int64_t* d_ids, size_t n, hipStream_t stream);
+  void set_policy(int policy);
+  void reset_order(hipStream_t stream);
+  void rewind_fifo(hipStream_t stream);
   void resize(size_t new_num_ids, size_t new_capacity, const float* d_feats, hipStream_t stream);
   void fetch(const int64_t* d_ids, size_t n, float* d_out, bool update, uint32_t* d_stats,
              hipStream_t stream);
@@ -61,10 +65,12 @@ class FeatureCache {
   DeviceBuffer stamp_;     // uint32[capacity]             epoch of last touch
   DeviceBuffer touched_;   // uint32[capacity]             epoch of the last hit (pending)
   DeviceBuffer state_;     // ring of per-fetch counter records
+  DeviceBuffer fifo_ptr_;  // uint32: FIFO rotation pointer
   DeviceBuffer ws_;        // per-fetch scratch
   size_t ws_rows_ = 0;
   uint32_t epoch_ = 0;     // fetches with update so far (host side; kernel argument)
   uint64_t ring_pos_ = 0;
+  int policy_ = GF_CACHE_LRU;
 };
 
 }  // namespace gf

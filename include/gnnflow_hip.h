@@ -187,6 +187,18 @@ typedef struct gf_cache gf_cache;
 GF_API int gf_cache_create(gf_cache** out, size_t num_ids, size_t capacity, size_t dim,
                            const float* d_feats, int device);
 GF_API int gf_cache_destroy(gf_cache* c);
+/* Replacement policy: LRU (lru_cache.py, the default), LFU (lfu_cache.py:
+ * a hit adds 1 to the slot's use count, the k smallest counts are evicted, a new entry
+ * starts at 1) or FIFO (fifo_cache.py: slots are refilled in rotation, hits change nothing).
+ * Set before the first fetch. */
+enum { GF_CACHE_LRU = 0, GF_CACHE_LFU = 1, GF_CACHE_FIFO = 2 };
+GF_API int gf_cache_set_policy(gf_cache* c, int policy);
+/* FIFOCache.reset (fifo_cache.py:70-75): forget the replacement order (next refill starts
+ * at slot 0 again) but keep the cached rows. */
+GF_API int gf_cache_reset_order(gf_cache* c, void* stream);
+/* GNNLabStaticCache.init_cache (gnnlab_static_cache.py:87-168): slot i caches d_ids[i]
+ * (n <= capacity, device array); used with update = 0 fetches. */
+GF_API int gf_cache_init_ids(gf_cache* c, const int64_t* d_ids, size_t n, void* stream);
 /* Cache.init_cache / LRUCache.reset (cache.py:157-195, lru_cache.py:74-105):
  * slots 0..capacity-1 hold ids 0..capacity-1, LRU state zeroed. */
 GF_API int gf_cache_init(gf_cache* c, void* stream);

@@ -24,7 +24,9 @@ import numpy as np
 class LRUKind:
     """One cache kind (node or edge): lru_cache.py state + one block of fetch_feature."""
 
-    def __init__(self, num_ids, capacity, feats, overflow_rule="first_seen"):
+    def __init__(self, num_ids, capacity, feats, overflow_rule="first_seen", policy="lru"):
+        self.policy = policy          # "lru" | "lfu" | "fifo"
+        self.pointer = int(capacity) - 1   # fifo_cache.py:66-69
         self.num_ids, self.capacity = int(num_ids), int(capacity)
         self.feats = np.ascontiguousarray(feats, np.float32)
         self.dim = self.feats.shape[1]
@@ -45,6 +47,11 @@ class LRUKind:
         self.flag[ids] = True
         self.index_to_id = ids.astype(np.int64)
         self.map[ids] = ids
+        self.count[:] = 1 if self.policy == "lfu" else 0     # lfu_cache.py:80-84
+        self.pointer = self.capacity - 1
+
+    def reset_order(self):   # fifo_cache.py:70-75 (pointer) / lfu_cache.py:118 (count.zero_())
+        self.pointer = self.capacity - 1
         self.count[:] = 0
 
     # one block of cache.py:269-323 (nodes) / :326-400 (edges)
@@ -67,19 +74,38 @@ class LRUKind:
             self._update(cached_index, uniq)
         return out, hits, n
 
-    # lru_cache.py:121-160
+    # lru_cache.py:121-160 / lfu_cache.py:134-172 / fifo_cache.py:77-119
     def _update(self, cached_index, uncached_ids):
         k = min(len(uncached_ids), self.capacity)
         ids_to_cache = uncached_ids[:k]
+        if self.policy == "fifo":
+            C, p = self.capacity, self.pointer
+            if p + k < C:
+                removing = np.arange(p + 1, p + k + 1)
+                self.pointer = p + k
+            else:
+                removing = np.concatenate([np.arange(k - (C - 1 - p)), np.arange(p + 1, C)])
+                self.pointer = k - (C - 1 - p) - 1
+            self._install(removing, ids_to_cache, None)
+            return
+        if self.policy == "lfu":
+            self.count[np.unique(cached_index)] += 1     # `count[idx] += 1`: once per slot
+            removing = np.sort(np.argsort(self.count, kind="stable")[:k])
+            self._install(removing, ids_to_cache, 1)
+            return
         self.count -= 1
         self.count[cached_index] = 0
         # topk(k, largest=False) with ties -> lowest slot index; the evicted slots are
         # refilled in slot order (the reference pairs ids with topk's output order,
         # which only matters through later ties)
         removing = np.sort(np.argsort(self.count, kind="stable")[:k])
+        self._install(removing, ids_to_cache, 0)
+
+    def _install(self, removing, ids_to_cache, new_count):
         removing_ids = self.index_to_id[removing]
         self.buffer[removing] = self.feats[ids_to_cache]
-        self.count[removing] = 0
+        if new_count is not None:
+            self.count[removing] = new_count
         live = removing_ids >= 0
         self.flag[removing_ids[live]] = False
         self.flag[ids_to_cache] = True
@@ -96,14 +122,15 @@ class OracleLRUCache:
 
     def __init__(self, edge_cache_ratio, node_cache_ratio, num_nodes, num_edges,
                  node_feats=None, edge_feats=None, dim_node_feat=0, dim_edge_feat=0,
-                 overflow_rule="first_seen"):
+                 overflow_rule="first_seen", policy="lru"):
         self.node = self.edge = None
         self.node_capacity = int(node_cache_ratio * num_nodes)   # cache.py:82
         self.edge_capacity = int(edge_cache_ratio * num_edges)   # cache.py:83
         if dim_node_feat:
-            self.node = LRUKind(num_nodes, self.node_capacity, node_feats, overflow_rule)
+            self.node = LRUKind(num_nodes, self.node_capacity, node_feats, overflow_rule, policy)
         if dim_edge_feat:
-            self.edge = LRUKind(num_edges, self.edge_capacity, edge_feats, overflow_rule)
+            self.edge = LRUKind(num_edges, self.edge_capacity, edge_feats, overflow_rule, policy)
+        self.policy = policy
         self.cache_node_ratio = 0
         self.cache_edge_ratio = 0
         self.target_edge_features = None
@@ -114,9 +141,12 @@ class OracleLRUCache:
         if self.edge:
             self.edge.init()
 
-    def reset(self):   # lru_cache.py:74-105: only the edge cache is reset
+    def reset(self):   # lru/lfu: only the edge cache is re-initialised; fifo: pointer rewind
         if self.edge:
-            self.edge.init()
+            if self.policy != "fifo":
+                self.edge.init()
+            if self.policy != "lru":
+                self.edge.reset_order()
 
     def fetch_feature(self, mfgs, eid=None, update_cache=True, target_edge_features=True):
         if self.node:

@@ -50,14 +50,15 @@ def import_reference_cache():
     cpkg = _stub("gnnflow.cache")
     cpkg.__path__ = [os.path.join(REF, "gnnflow", "cache")]
     mods = {}
-    for name in ("cache", "lru_cache"):
+    for name in ("cache", "lru_cache", "lfu_cache", "fifo_cache"):
         spec = importlib.util.spec_from_file_location(
             "gnnflow.cache." + name, os.path.join(REF, "gnnflow", "cache", name + ".py"))
         mod = importlib.util.module_from_spec(spec)
         sys.modules["gnnflow.cache." + name] = mod
         spec.loader.exec_module(mod)
         mods[name] = mod
-    return mods["lru_cache"].LRUCache
+    return {"lru": mods["lru_cache"].LRUCache, "lfu": mods["lfu_cache"].LFUCache,
+            "fifo": mods["fifo_cache"].FIFOCache}
 
 
 class FakeBlock:
@@ -69,7 +70,7 @@ class FakeBlock:
 
 def main():
     import torch
-    LRUCache = import_reference_cache()
+    classes = import_reference_cache()
     rng = np.random.RandomState(1234)
     out = {}
     scenarios = [
@@ -80,6 +81,11 @@ def main():
         ("bool_feats", 64, 256, 6, 6, 0.5, 3, 40, 80, 0.5),
         # capacity 1: torch.topk never has a tie to break -> whole ratio sequence pinned
         ("cap1_tie_free", 10, 10, 4, 4, 0.1, 10, 4, 5, 0.0),
+        # other policies (name prefix selects the reference class)
+        ("fifo_small", 200, 1000, 8, 12, 0.2, 8, 60, 150, 1.2),
+        ("fifo_overflow_wrap", 30, 60, 4, 4, 0.3, 8, 25, 40, 0.0),
+        ("lfu_small", 200, 1000, 8, 12, 0.2, 6, 60, 150, 1.2),
+        ("lfu_cap1_tie_free", 10, 10, 4, 4, 0.1, 10, 4, 5, 0.0),
     ]
     names = []
 
@@ -100,7 +106,14 @@ def main():
         if name == "bool_feats":
             nf = (nf > 0.5)
             ef = (ef > 0.5)
-        cache = LRUCache(ratio, ratio, N, E, torch.device("cpu:0"),
+        policy = name.split("_")[0] if name.split("_")[0] in ("fifo", "lfu") else "lru"
+        out[name + "/policy"] = np.array([policy])
+        # FIFOCache.reset() only rewinds the edge pointer: exercised mid-replay.  (The LRU /
+        # LFU reset() re-fills the slots without clearing the old id->slot map, so ids
+        # cached before it read stale rows afterwards; not recorded as golden behaviour.)
+        reset_after = 3 if name == "fifo_overflow_wrap" else -1
+        out[name + "/reset_after"] = np.array([reset_after], np.int64)
+        cache = classes[policy](ratio, ratio, N, E, torch.device("cpu:0"),
                          None if nf is None else torch.from_numpy(nf),
                          None if ef is None else torch.from_numpy(ef), dn, de)
         cache.init_cache()
@@ -146,6 +159,8 @@ def main():
                     torch.nonzero(cache.cache_edge_flag).flatten().numpy())
                 put_rows("{}/b{}/target".format(name, b),
                          cache.target_edge_features.numpy(), b)
+            if b == reset_after:
+                cache.reset()
     out["scenarios"] = np.array(names)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache_reference.npz")
     np.savez_compressed(path, **out)

@@ -6,17 +6,21 @@ feature placements."""
 import numpy as np
 import pytest
 
-from tests.test_oracle_cache import Blk, load, replay
+from tests.test_oracle_cache import Blk, load, policy_of, replay
 
 pytestmark = pytest.mark.gpu
 
 
-def _hip_cache(placement="device"):
+def _cls(policy):
+    import gnnflow_amd.cache as caches
+    return {"lru": caches.LRUCache, "lfu": caches.LFUCache, "fifo": caches.FIFOCache}[policy]
+
+
+def _hip_cache(placement="device", policy="lru"):
     import torch
-    from gnnflow_amd.cache import LRUCache
 
     def make(ratio, N, E, nf, ef, dn, de):
-        return LRUCache(ratio, ratio, N, E, "cuda:0",
+        return _cls(policy)(ratio, ratio, N, E, "cuda:0",
                         None if nf is None else torch.from_numpy(nf),
                         None if ef is None else torch.from_numpy(ef), dn, de,
                         feature_placement=placement)
@@ -38,21 +42,23 @@ def test_rows_match_reference_python(name, placement):
     z, _ = load()
     """Every fetched row equals the reference's own output (sha256 of each block,
     full arrays for batch 0); hit ratios are compared against the oracle below."""
-    for _ in replay(z, name, _hip_cache(placement), _to_ids, _to_np):
+    for _ in replay(z, name, _hip_cache(placement, policy_of(z, name)), _to_ids, _to_np):
         pass
 
 
-def _run_against_oracle(N, E, dn, de, ratio, batches, seed, skew=1.0):
+def _run_against_oracle(N, E, dn, de, ratio, batches, seed, skew=1.0, policy="lru",
+                        reset_after=()):
     import torch
-    from gnnflow_amd.cache import LRUCache
     from oracle.cache_oracle import OracleLRUCache
+    LRUCache = _cls(policy)
     rng = np.random.RandomState(seed)
     nf = rng.rand(N, dn).astype(np.float32) if dn else None
     ef = rng.rand(E, de).astype(np.float32) if de else None
     hip = LRUCache(ratio, ratio, N, E, "cuda:0",
                    None if nf is None else torch.from_numpy(nf),
                    None if ef is None else torch.from_numpy(ef), dn, de)
-    ora = OracleLRUCache(ratio, ratio, N, E, nf, ef, dn, de, overflow_rule="first_seen")
+    ora = OracleLRUCache(ratio, ratio, N, E, nf, ef, dn, de, overflow_rule="first_seen",
+                         policy=policy)
     hip.init_cache()
     ora.init_cache()
 
@@ -86,7 +92,82 @@ def _run_against_oracle(N, E, dn, de, ratio, batches, seed, skew=1.0):
             ids = hip._edge.slot_ids()
             assert np.array_equal(np.sort(ids[ids >= 0]), ora.edge.cached_ids()), bi
             assert np.array_equal(_to_np(hip.target_edge_features), ora.target_edge_features), bi
+        if bi in reset_after:
+            hip.reset()
+            ora.reset()
     return hip, ora
+
+
+@pytest.mark.parametrize("policy", ["lfu", "fifo"])
+def test_policy_sequence_matches_oracle(policy):
+    """LFUCache / FIFOCache (lfu_cache.py:134-210, fifo_cache.py:77-161) on the fused
+    gather: rows, hit ratios and cached-id sets equal the oracle's after every batch,
+    including a reset() in the middle (LFU: edge re-init with counts 0; FIFO: pointer
+    rewind only) and blocks with more distinct misses than slots."""
+    _run_against_oracle(N=3000, E=40000, dn=172, de=172, ratio=0.2,
+                        batches=[(5000, (6000, 700))] * 6, seed=11, skew=0.8, policy=policy,
+                        reset_after=(2,))
+    _run_against_oracle(N=400, E=400, dn=4, de=8, ratio=0.05,
+                        batches=[(300, (350, 60))] * 5, seed=12, skew=0.0, policy=policy,
+                        reset_after=(1,))
+    _run_against_oracle(N=500, E=3000, dn=7, de=13, ratio=0.3,
+                        batches=[(300, (400, 0)), (10, (1, 50)), (640, (64, 65))] * 3,
+                        seed=13, policy=policy)
+
+
+def test_gnnlab_static_cache_presamples_and_never_replaces():
+    """GNNLabStaticCache (gnnlab_static_cache.py:87-182): the cached ids are the most often
+    pre-sampled ones (counted per block as the reference's `count[ids] += 1` does), ties to
+    the lowest id; fetches never change the cache."""
+    import torch
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from gnnflow_amd.cache import GNNLabStaticCache
+    rng = np.random.RandomState(21)
+    N, E = 300, 6000
+    src = (rng.zipf(1.6, E) % N).astype(np.int64)
+    dst = rng.randint(0, N, E).astype(np.int64)
+    ts = np.sort(rng.rand(E).astype(np.float32))
+    g = DynamicGraph(1 << 20, 64 << 20, "cuda", 16, 64, "insert", device=0)
+    g.add_edges(src, dst, ts, add_reverse=True)
+    sampler = TemporalSampler(g, fanouts=[5, 5], sample_strategy="recent")
+    nf = rng.rand(N, 16).astype(np.float32)
+    ef = rng.rand(E, 12).astype(np.float32)
+    cache = GNNLabStaticCache(0.1, 0.1, N, E, "cuda:0", torch.from_numpy(nf),
+                              torch.from_numpy(ef), 16, 12)
+    train = {"src": src[:3000], "dst": dst[:3000], "time": ts[:3000]}
+    cache.init_cache(sampler=sampler, train_df=train, pre_sampling_rounds=2, batch_size=500)
+
+    node_cnt = np.zeros(N, np.int64)
+    edge_cnt = np.zeros(E, np.int64)
+    for _ in range(2):
+        for lo in range(0, 3000, 500):
+            roots = np.concatenate([src[lo:lo + 500], dst[lo:lo + 500]])
+            t = np.concatenate([ts[lo:lo + 500], ts[lo:lo + 500]])
+            mfgs = sampler.sample(roots, t)
+            node_cnt[np.unique(_to_np(mfgs[0][0].srcdata["ID"]))] += 1
+            for mfg in mfgs:
+                for b in mfg:
+                    if b.num_src_nodes() > b.num_dst_nodes():
+                        edge_cnt[np.unique(_to_np(b.edata["ID"]))] += 1
+    want_nodes = np.argsort(-node_cnt, kind="stable")[:cache.node_capacity]
+    want_edges = np.argsort(-edge_cnt, kind="stable")[:cache.edge_capacity]
+    assert np.array_equal(cache._node.slot_ids(), want_nodes)
+    assert np.array_equal(cache._edge.slot_ids(), want_edges)
+
+    roots = np.concatenate([src[3000:3600], dst[3000:3600]])
+    t = np.concatenate([ts[3000:3600], ts[3000:3600]])
+    for _ in range(2):
+        mfgs = sampler.sample(roots, t)
+        cache.fetch_feature(mfgs, np.arange(10))
+        ids = _to_np(mfgs[0][0].srcdata["ID"])
+        assert np.array_equal(_to_np(mfgs[0][0].srcdata["h"]), nf[ids])
+        assert float(cache.cache_node_ratio) == pytest.approx(
+            np.isin(ids, want_nodes).mean(), abs=1e-6)
+        eids = _to_np(mfgs[0][0].edata["ID"])
+        assert np.array_equal(_to_np(mfgs[0][0].edata["f"]), ef[eids])
+        assert np.array_equal(cache._node.slot_ids(), want_nodes)
+        assert np.array_equal(cache._edge.slot_ids(), want_edges)
+    assert cache.name == "gnnlab"
 
 
 def test_sequence_matches_oracle_reddit_like_dims():

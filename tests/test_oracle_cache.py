@@ -52,13 +52,20 @@ def replay(z, name, make_cache, to_ids=lambda a: a, to_np=lambda a: a):
                 check_rows(z, "{}/b{}/f{}".format(name, b, li), to_np(blocks[li][0].edata["f"]))
             check_rows(z, "{}/b{}/target".format(name, b), to_np(cache.target_edge_features))
         yield b, cache, blocks
+        if b == int(z[name + "/reset_after"][0]):
+            cache.reset()
 
 
-def _mk(rule):
+def policy_of(z, name):
+    return str(z[name + "/policy"][0])
+
+
+def _mk(rule, policy="lru"):
     def make(ratio, N, E, nf, ef, dn, de):
         nf = None if nf is None else nf.astype(np.float32)   # cache.py:71-74 bool -> f32
         ef = None if ef is None else ef.astype(np.float32)
-        return OracleLRUCache(ratio, ratio, N, E, nf, ef, dn, de, overflow_rule=rule)
+        return OracleLRUCache(ratio, ratio, N, E, nf, ef, dn, de, overflow_rule=rule,
+                              policy=policy)
     return make
 
 
@@ -68,7 +75,7 @@ def test_features_match_reference(name, rule):
     """Fetched rows are the reference's, bit for bit, in every block of every batch,
     whatever the cache state (both overflow rules)."""
     z, _ = load()
-    for _ in replay(z, name, _mk(rule)):
+    for _ in replay(z, name, _mk(rule, policy_of(z, name))):
         pass
 
 
@@ -80,7 +87,7 @@ def test_first_batch_hit_ratio_and_occupancy(name):
     unspecified tie order, so only batch-0-before-update state is compared)."""
     z, _ = load()
     N, E, dn, de, nb = (int(x) for x in z[name + "/meta"])
-    for b, cache, blocks in replay(z, name, _mk("smallest_ids")):
+    for b, cache, blocks in replay(z, name, _mk("smallest_ids", policy_of(z, name))):
         if dn:
             assert len(cache.node.cached_ids()) == len(z["{}/b{}/node_cached".format(name, b)])
             if b == 0:
@@ -90,12 +97,14 @@ def test_first_batch_hit_ratio_and_occupancy(name):
             assert len(cache.edge.cached_ids()) == len(z["{}/b{}/edge_cached".format(name, b)])
 
 
-def test_tie_free_sequence_matches_reference_ratios():
-    """Where torch.topk has no tie to break — a capacity-1 cache — the reference's whole
-    hit-ratio sequence and cached-id sets are reproduced exactly."""
+@pytest.mark.parametrize("name", ["cap1_tie_free", "lfu_cap1_tie_free", "fifo_small",
+                                  "fifo_overflow_wrap"])
+def test_tie_free_sequence_matches_reference_ratios(name):
+    """Where torch.topk has no tie to break — a capacity-1 LRU/LFU cache, and FIFO at any
+    capacity (its victims come from a pointer, fifo_cache.py:96-105) — the reference's
+    whole hit-ratio sequence and cached-id sets are reproduced exactly."""
     z, _ = load()
-    name = "cap1_tie_free"
-    for b, cache, blocks in replay(z, name, _mk("smallest_ids")):
+    for b, cache, blocks in replay(z, name, _mk("smallest_ids", policy_of(z, name))):
         assert cache.cache_node_ratio == pytest.approx(
             float(z["{}/b{}/node_ratio".format(name, b)][0]), abs=1e-7), b
         assert cache.cache_edge_ratio == pytest.approx(
