@@ -83,7 +83,8 @@ struct Counters {
   uint32_t th_age;    // eviction threshold (written by the tile-count kernel)
   uint32_t th_k_tie;
   uint32_t fifo_start;  // FIFO: first slot of this block's refill arc
-  uint32_t pad[28];
+  uint32_t ticket;      // workgroups of the rank kernel that finished their level-2 histogram
+  uint32_t pad[27];
 };
 constexpr uint32_t kCounterWords = sizeof(Counters) / 4;
 
@@ -406,37 +407,45 @@ __device__ inline void find_bin_from_top(const uint32_t* __restrict__ hist, uint
   __syncthreads();
 }
 
-struct Threshold { uint32_t age; uint32_t k_tie; };
-
 // eviction threshold: every slot older than `age` goes, plus the first k_tie slots
 // (slot order) of exactly that age
-__device__ inline Threshold find_threshold(const uint32_t* hist1, const uint32_t* hist2,
-                                           uint32_t k) {
-  uint32_t b1, k_rem;
-  find_bin_from_top<kBins1>(hist1, k, &b1, &k_rem);
-  Threshold t;
-  if (b1 < kFine) {
-    t.age = b1;
-    t.k_tie = k_rem;
-  } else {
-    uint32_t b2, k_tie;
-    find_bin_from_top<kBins2>(hist2, k_rem, &b2, &k_tie);
-    t.age = kFine + ((b1 - kFine) << 11) + b2;
-    t.k_tie = k_tie;
+struct Threshold { uint32_t age; uint32_t k_tie; };
+
+// per tile of kTile slots: how many sit exactly at the threshold age, and how many are
+// older than it (all of those are evicted).  Tiles first, first + step, ... of the context.
+__device__ inline void count_tiles(const Ctx& c, Threshold th, uint32_t first, uint32_t step) {
+  __shared__ uint32_t cnt[2];
+  const uint32_t tiles = (c.capacity + kTile - 1) / kTile;
+  for (uint32_t tile = first; tile < tiles; tile += step) {
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t s = tile * kTile + threadIdx.x;
+    const uint32_t a = s < c.capacity ? slot_age(c, s) : 0u;
+    const uint32_t t = __popcll(__ballot(s < c.capacity && a == th.age));
+    const uint32_t o = __popcll(__ballot(s < c.capacity && a > th.age));
+    if ((threadIdx.x & 63) == 0) {
+      if (t) atomicAdd(&cnt[0], t);
+      if (o) atomicAdd(&cnt[1], o);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { c.tile_tie[tile] = cnt[0]; c.tile_old[tile] = cnt[1]; }
+    __syncthreads();
   }
-  return t;
 }
 
 // rows: rank -> row table of the representatives that will be installed; the ones beyond
 // the capacity give their claim back ("we only cache the first self.capacity",
-// lru_cache.py:127-133).  slots: level-2 histogram, only when the threshold lies in a
-// coarse bin (a slot untouched for more than 2047 updates).
-__global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(Round r) {
+// lru_cache.py:127-133).  slots: the eviction threshold and the per-tile counts the install
+// kernel turns into ranks.  The threshold comes straight from the level-1 histogram unless
+// it lies in a coarse bin (a slot untouched for more than 2047 updates): then every
+// workgroup adds its share of the level-2 histogram and the LAST one to finish — told by a
+// ticket — resolves the threshold and counts all tiles alone (rare, so not parallel).
+__global__ __launch_bounds__(kWide) void lru_rank_tile_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
   if (!needs_update(c)) return;
   __shared__ uint32_t tile_prefix[kMaxRowTiles];
   const uint32_t n_unique = load_row_tile_prefix(c, tile_prefix);
-  if (blockIdx.x == 0 && threadIdx.x == 0) c.ctr->n_unique = n_unique;   // for later kernels
+  if (blockIdx.x == 0 && threadIdx.x == 0) c.ctr->n_unique = n_unique;   // for the install
   const uint32_t k = min(n_unique, c.capacity);
   if (c.policy == GF_CACHE_FIFO && blockIdx.x == 0 && threadIdx.x == 0) {
     // fifo_cache.py:96-105: the k slots after the pointer (wrapping) are refilled and the
@@ -458,11 +467,19 @@ __global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(Round r) {
       c.map[id] = kAbsent;
     }
   }
-  if (c.policy == GF_CACHE_FIFO) return;
+  if (c.policy == GF_CACHE_FIFO) return;   // victims come from the rotation pointer
   uint32_t b1, k_rem;
-  find_bin_from_top<kBins1>(c.hist1, k, &b1, &k_rem);
-  if (b1 < kFine) return;   // uniform across the context's workgroups
+  find_bin_from_top<kBins1>(c.hist1, k, &b1, &k_rem);   // uniform across the workgroups
+  Threshold th;
+  if (b1 < kFine) {
+    th.age = b1;
+    th.k_tie = k_rem;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c.ctr->th_age = th.age; c.ctr->th_k_tie = th.k_tie; }
+    count_tiles(c, th, blockIdx.x, gridDim.x);
+    return;
+  }
   __shared__ uint32_t h[kBins2];
+  __shared__ uint32_t last_s;
   for (int b = threadIdx.x; b < kBins2; b += kWide) h[b] = 0;
   __syncthreads();
   for (uint32_t s = blockIdx.x * kWide + threadIdx.x; s < c.capacity; s += stride) {
@@ -472,36 +489,23 @@ __global__ __launch_bounds__(kWide) void lru_rank_hist2_kernel(Round r) {
   __syncthreads();
   for (int b = threadIdx.x; b < kBins2; b += kWide)
     if (h[b]) atomicAdd(&c.hist2[b], h[b]);
-}
-
-// per tile of kTile slots: how many sit exactly at the threshold age, and how many are
-// older than it (all of those are evicted)
-__global__ __launch_bounds__(kWide) void lru_tile_count_kernel(Round r) {
-  const Ctx& c = r.c[blockIdx.y];
-  if (!needs_update(c) || c.policy == GF_CACHE_FIFO) return;
-  __shared__ uint32_t cnt[2];
-  const uint32_t k = min(c.ctr->n_unique, c.capacity);
-  const Threshold th = find_threshold(c.hist1, c.hist2, k);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {   // the install kernel reads it from here
-    c.ctr->th_age = th.age;
-    c.ctr->th_k_tie = th.k_tie;
+  // every add above is a device-scope atomic that has completed (vmcnt(0) at the barrier)
+  // before this workgroup takes its ticket
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last_s = atomicAdd(&c.ctr->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
   }
-  const uint32_t tiles = (c.capacity + kTile - 1) / kTile;
-  for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t s = tile * kTile + threadIdx.x;
-    const uint32_t a = s < c.capacity ? slot_age(c, s) : 0u;
-    const uint32_t t = __popcll(__ballot(s < c.capacity && a == th.age));
-    const uint32_t o = __popcll(__ballot(s < c.capacity && a > th.age));
-    if ((threadIdx.x & 63) == 0) {
-      if (t) atomicAdd(&cnt[0], t);
-      if (o) atomicAdd(&cnt[1], o);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { c.tile_tie[tile] = cnt[0]; c.tile_old[tile] = cnt[1]; }
-    __syncthreads();
-  }
+  __syncthreads();
+  if (!last_s) return;
+  for (int b = threadIdx.x; b < kBins2; b += kWide) h[b] = atomicAdd(&c.hist2[b], 0u);
+  __syncthreads();
+  uint32_t b2, k_tie;
+  find_bin_from_top<kBins2>(h, k_rem, &b2, &k_tie);
+  th.age = kFine + ((b1 - kFine) << 11) + b2;
+  th.k_tie = k_tie;
+  if (threadIdx.x == 0) { c.ctr->th_age = th.age; c.ctr->th_k_tie = th.k_tie; }
+  count_tiles(c, th, 0, 1);
 }
 
 // evict + install + copy (lru_cache.py:141-160 with a deterministic tie rule): every slot
@@ -671,8 +675,8 @@ void launch_round(Round& r, hipStream_t stream) {
       std::max<size_t>(1, std::min<size_t>((max_n + kRowTile - 1) / kRowTile, kMaxRowTiles)));
   lru_scan_hist_kernel<<<dim3(scan_blocks + slot_grid, r.count), dim3(kWide), 0, stream>>>(
       r, scan_blocks);
-  lru_rank_hist2_kernel<<<dim3(both_grid, r.count), dim3(kWide), 0, stream>>>(r);
-  lru_tile_count_kernel<<<dim3(tile_grid, r.count), dim3(kWide), 0, stream>>>(r);
+  lru_rank_tile_kernel<<<dim3(std::min(std::max(both_grid, tile_grid), 1024u), r.count),
+                         dim3(kWide), 0, stream>>>(r);
   lru_install_kernel<<<dim3(tile_grid, r.count), dim3(kTile), 0, stream>>>(r);
   GF_HIP(hipGetLastError());
 }

@@ -115,6 +115,41 @@ def test_policy_sequence_matches_oracle(policy):
                         seed=13, policy=policy)
 
 
+@pytest.mark.parametrize("policy", ["lru", "lfu"])
+def test_threshold_beyond_the_fine_histogram_bins(policy):
+    """Slots left untouched for more than 2047 updates put the eviction threshold into a
+    coarse level-1 bin: the level-2 histogram + last-workgroup path must pick exactly the
+    oracle's victims (4096 slots, one new id per update, > 2048 updates; LFU: counts are
+    far from the clamp, so this is its plain path over the same long sequence)."""
+    import torch
+    from oracle.cache_oracle import OracleLRUCache
+    N, d, cap = 20000, 4, 4096
+    rng = np.random.RandomState(31)
+    nf = rng.rand(N, d).astype(np.float32)
+    hip = _cls(policy)(0.0, cap / N, N, 16, "cuda:0", torch.from_numpy(nf), None, d, 0)
+    ora = OracleLRUCache(0.0, cap / N, N, 16, nf, None, d, 0, overflow_rule="first_seen",
+                         policy=policy)
+    assert hip.node_capacity == cap == ora.node_capacity
+    hip.init_cache()
+    ora.init_cache()
+    fresh = cap
+    for bi in range(2300):
+        # a few recently installed ids (hits), one or two never-seen ids (misses)
+        k_new = 1 + (bi % 97 == 0)
+        recent = np.arange(max(cap, fresh - 5), fresh)
+        ids = np.concatenate([recent, np.arange(fresh, fresh + k_new)]).astype(np.int64)
+        fresh += k_new
+        hb = [[Blk(_to_ids(ids), _to_ids(np.zeros(0, np.int64)))]]
+        ob = [[Blk(ids, np.zeros(0, np.int64))]]
+        hip.fetch_feature(hb, None, target_edge_features=False)
+        ora.fetch_feature(ob, None, target_edge_features=False)
+        if bi % 100 == 99 or bi > 2040:
+            assert np.array_equal(_to_np(hb[0][0].srcdata["h"]), ob[0][0].srcdata["h"]), bi
+            assert float(hip.cache_node_ratio) == pytest.approx(ora.cache_node_ratio, abs=1e-6), bi
+            got = hip._node.slot_ids()
+            assert np.array_equal(np.sort(got[got >= 0]), ora.node.cached_ids()), bi
+
+
 def test_gnnlab_static_cache_presamples_and_never_replaces():
     """GNNLabStaticCache (gnnlab_static_cache.py:87-182): the cached ids are the most often
     pre-sampled ones (counted per block as the reference's `count[ids] += 1` does), ties to
