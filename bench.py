@@ -56,6 +56,8 @@ def parse():
                          "an all-to-all exchange per layer (gnnflow_amd/dist.py)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap batch i+1's sample() with batch i's fetch_feature()")
+    ap.add_argument("--event-stride", type=int, default=5,
+                    help="time every n-th gather launch with HIP events (1 = all)")
     ap.add_argument("--breakdown", action="store_true",
                     help="extra untimed pass with per-kernel-family HIP-event times")
     return ap.parse_args()
@@ -197,7 +199,13 @@ def main():
     if cache is not None:
         cache.init_cache()
     lib.gf_profile_reset()
-    lib.gf_profile_enable(1 << _capi.PROFILE_SLOTS["gather"])   # HIP events on the gather
+    # HIP events around the gather launches of the timed region, on their stream.  Every
+    # 5th launch is timed (both rounds of a step get sampled in turn): an event pair costs
+    # ~5 us of stream time, which at ~90 us per step would distort the throughput measured
+    # in the same pass.
+    launches_before = cache.num_gather_launches if cache is not None else 0
+    lib.gf_profile_set_stride(args.event_stride)
+    lib.gf_profile_enable(1 << _capi.PROFILE_SLOTS["gather"])
     barrier()
     t0 = time.perf_counter()
     acc = {"edges": 0, "bytes": 0}
@@ -215,6 +223,7 @@ def main():
     edges, gather_bytes = acc["edges"], acc["bytes"]
     elapsed = time.perf_counter() - t0
     lib.gf_profile_enable(0)
+    lib.gf_profile_set_stride(1)
 
     import ctypes as C
     g_ms, g_n = C.c_double(0), C.c_uint64(0)
@@ -264,14 +273,19 @@ def main():
     }
     if cache is not None and g_n.value:
         # dominant kernel by bytes: the fused feature gather (one launch per block)
-        achieved = gather_bytes / (g_ms.value * 1e-3) / 1e9
+        # algorithmic bytes per launch (all launches) / average duration of the launches
+        # that carried events (every event_stride-th one)
+        n_launches = cache.num_gather_launches - launches_before
+        bytes_per_launch = gather_bytes / max(n_launches, 1)
+        avg_us = 1e3 * g_ms.value / g_n.value
+        achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
         out["roofline"] = {
             "bound": "hbm", "kernel": "gather_rows_kernel",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "launches": int(g_n.value),
-            "avg_launch_us": 1e3 * g_ms.value / g_n.value,
-            "algorithmic_bytes_per_launch": gather_bytes / g_n.value,
+            "launches": int(n_launches), "launches_timed": int(g_n.value),
+            "avg_launch_us": avg_us,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
         }
         # HBM traffic of the same kernel from PMC counters (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate passes of this command, gfx950 FETCH x2 correction);

@@ -12,12 +12,16 @@ Same constructor arguments, attributes read by callers (`cache_node_ratio`,
 """
 import ctypes as C
 import os
+import struct
 from typing import List, Optional, Union
 
 import numpy as np
 import torch
 
 from .. import _capi
+
+_DESC = struct.Struct("iiQQQQ")     # struct gf_fetch_desc: kind, update, d_ids, n, d_out, d_stats
+assert _DESC.size == C.sizeof(_capi.GfFetchDesc)
 
 
 class _Kind:
@@ -142,7 +146,9 @@ class Cache:
             if self.dim_edge_feat != 0:
                 self._edge = _Kind(self._lib, num_edges, self.edge_capacity, edge_feats,
                                    self.dim_edge_feat, device, placement, self._policy)
-        self._node_stats = self._edge_stats = None
+        self._stats_span = None
+        self._target_edge_thunk = None
+        self.num_gather_launches = 0   # gather launches issued so far (one per round)
 
     def __del__(self):
         for k in (getattr(self, "_node", None), getattr(self, "_edge", None)):
@@ -160,11 +166,17 @@ class Cache:
 
     @property
     def cache_node_ratio(self):
-        return self._ratio(self._node_stats)
+        if self._node is None or self._stats_span is None:
+            return 0
+        pos, n_node, n_cached, ring = self._stats_span
+        return self._ratio(ring[pos:pos + n_node])
 
     @property
     def cache_edge_ratio(self):
-        return self._ratio(self._edge_stats)
+        if self._edge is None or self._stats_span is None:
+            return 0
+        pos, n_node, n_cached, ring = self._stats_span
+        return self._ratio(ring[pos + n_node:pos + n_cached])
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -223,17 +235,18 @@ class Cache:
         return t
 
     def _stats_rows(self, n):
-        """n zeroed 16-word stats records from a ring that is re-zeroed when it wraps
-        (a torch.zeros per call is one more kernel launch on the critical path)."""
+        """Position of n zeroed 16-word stats records in a ring that is replaced by a fresh
+        zeroed one when it is used up (a torch.zeros per call is one more kernel launch on
+        the critical path)."""
         n = max(n, 1)
         ring = getattr(self, "_stats_ring", None)
         if ring is None or self._stats_pos + n > ring.shape[0]:
-            self._stats_ring = ring = torch.zeros((max(256, 4 * n), 16), dtype=torch.int32,
+            self._stats_ring = ring = torch.zeros((max(1024, 4 * n), 16), dtype=torch.int32,
                                                   device=self.device)
             self._stats_pos = 0
-        rows = ring[self._stats_pos:self._stats_pos + n]
+        pos = self._stats_pos
         self._stats_pos += n
-        return rows
+        return pos
 
     def wait_enqueued(self):
         """Blocks until the last asynchronous fetch_feature() has been enqueued on its
@@ -247,11 +260,14 @@ class Cache:
 
     @property
     def target_edge_features(self):
-        self.wait_enqueued()
+        if self._target_edge_features is None and self._target_edge_thunk is not None:
+            self._target_edge_features = self._target_edge_thunk()
+            self._target_edge_thunk = None
         return self._target_edge_features
 
     @target_edge_features.setter
     def target_edge_features(self, value):
+        self._target_edge_thunk = None
         self._target_edge_features = value
 
     def fetch_feature(self, mfgs: List[List], eid: Optional[np.ndarray] = None,
@@ -269,55 +285,95 @@ class Cache:
         call wait_enqueued()."""
         self.wait_enqueued()      # at most one submission in flight
         upd = 1 if update_cache else 0
-        jobs = []    # (kind, ids tensor, dim, setter)
+        dev = self.device
+        # jobs: (kind, ids address, n, dim, block, which, key, keepalive)
+        jobs = []
         if self._node is not None:
+            dim = self.dim_node_feat
             for b in mfgs[0]:
-                jobs.append((0, self._ids(b.srcdata['ID']), self.dim_node_feat, b.srcdata, 'h'))
+                jobs.append((0,) + self._id_array(b, "src") + (dim, b, "src", "h"))
         n_node = len(jobs)
         if self._edge is not None:
+            dim = self.dim_edge_feat
             for mfg in mfgs:
                 for b in mfg:
-                    if len(b.edata['ID']) > 0:
-                        jobs.append((1, self._ids(b.edata['ID']), self.dim_edge_feat,
-                                     b.edata, 'f'))
+                    job = (1,) + self._id_array(b, "e") + (dim, b, "e", "f")
+                    if job[2] > 0:
+                        jobs.append(job)
         n_cached = len(jobs)
         if self._edge is not None and target_edge_features and eid is not None:
-            jobs.append((2, self._ids(eid), self.dim_edge_feat, None, None))
+            t = self._ids(eid)
+            jobs.append((2, t.data_ptr(), int(t.shape[0]), t, self.dim_edge_feat, None, None, None))
         if not jobs:
             return mfgs
-        with torch.cuda.device(self.device):
-            stats = self._stats_rows(n_cached)
-            descs = (_capi.GfFetchDesc * len(jobs))()
-            stats_ptr = stats.data_ptr()
-            for i, (kind, ids, dim, store, key) in enumerate(jobs):
-                n = int(ids.shape[0])
-                out = torch.empty((n, dim), dtype=torch.float32, device=self.device)
-                d = descs[i]
-                d.kind, d.update, d.n = kind, upd, n
-                d.d_ids, d.d_out = ids.data_ptr(), out.data_ptr()
-                d.d_stats = stats_ptr + 64 * i if (kind != 2 and n) else None
-                lazy = async_enqueue and hasattr(store, "set_lazy")
-                if store is None:
-                    self._target_edge_features = out    # cache.py:411 `edge_feats[eid]`
-                elif lazy:
-                    store.pop(key, None)
-                    store.set_lazy(key, lambda out=out: (self.wait_enqueued(), out)[1])
-                else:
-                    store[key] = out
-            node_h = self._node.h if self._node is not None else None
-            edge_h = self._edge.h if self._edge is not None else None
-            if async_enqueue:
-                ticket = C.c_uint64(0)
-                _capi.check(self._lib.gf_cache_fetch_blocks_async(
-                    node_h, edge_h, descs, len(jobs), self._stream(), C.byref(ticket)))
-                self._ticket = ticket.value
-                # ids / outputs must outlive the enqueue
-                self._pending_refs = (jobs, descs, mfgs)
+        if torch.cuda.current_device() != dev.index:
+            with torch.cuda.device(dev):
+                return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue)
+        return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue)
+
+    def _id_array(self, b, which):
+        """(address, count, keepalive) of a block's id array: straight from the sampler's
+        output when the block still has it (no torch view is created), else the tensor."""
+        raw = b.raw_ids(which) if hasattr(b, "raw_ids") else None
+        if raw is not None:
+            return raw[0], raw[1], b
+        t = self._ids((b.srcdata if which == "src" else b.edata)['ID'])
+        return t.data_ptr(), int(t.shape[0]), t
+
+    def _submit(self, mfgs, jobs, n_node, n_cached, upd, async_enqueue):
+        # one output allocation for the whole call; every block's rows start 16-byte aligned
+        offs, total = [], 0
+        for job in jobs:
+            offs.append(total)
+            total += (job[2] * job[4] + 3) & ~3
+        out_all = torch.empty(total, dtype=torch.float32, device=self.device)
+        out_ptr = out_all.data_ptr()
+        stats_pos = self._stats_rows(n_cached)
+        stats_ptr = self._stats_ring.data_ptr() + 64 * stats_pos
+        nj = len(jobs)
+        descs = self._desc_buf(nj)
+        pack = _DESC.pack_into
+        for i, (kind, ids_ptr, n, _keep, dim, b, which, key) in enumerate(jobs):
+            off = offs[i]
+            pack(descs, i * _DESC.size, kind, upd, ids_ptr or 0, n, out_ptr + 4 * off,
+                 stats_ptr + 64 * i if (kind != 2 and n) else 0)
+
+            def rows(off=off, n=n, dim=dim, sync=async_enqueue):
+                if sync:
+                    self.wait_enqueued()
+                return out_all[off:off + n * dim].view(n, dim)
+            if b is None:
+                self._target_edge_thunk = rows      # cache.py:411 `edge_feats[eid]`
+                self._target_edge_features = None
+            elif hasattr(b, "set_lazy"):
+                b.set_lazy(which, key, rows)
             else:
-                _capi.check(self._lib.gf_cache_fetch_blocks(
-                    node_h, edge_h, descs, len(jobs), self._stream()))
-        if self._node is not None:
-            self._node_stats = stats[:n_node]
-        if self._edge is not None:
-            self._edge_stats = stats[n_node:n_cached]
+                (b.srcdata if which == "src" else b.edata)[key] = rows(sync=False)
+        node_h = self._node.h if self._node is not None else None
+        edge_h = self._edge.h if self._edge is not None else None
+        cdescs = _capi.GfFetchDesc.from_buffer(descs)
+        self.num_gather_launches += max(n_node, n_cached - n_node, 1)
+        if async_enqueue:
+            ticket = C.c_uint64(0)
+            _capi.check(self._lib.gf_cache_fetch_blocks_async(
+                node_h, edge_h, C.byref(cdescs), nj, self._stream(), C.byref(ticket)))
+            self._ticket = ticket.value
+            # ids / outputs / descriptors must outlive the enqueue
+            self._pending_refs = (jobs, descs, cdescs, mfgs, out_all)
+        else:
+            _capi.check(self._lib.gf_cache_fetch_blocks(
+                node_h, edge_h, C.byref(cdescs), nj, self._stream()))
+        self._stats_span = (stats_pos, n_node, n_cached, self._stats_ring)
         return mfgs
+
+    def _desc_buf(self, n):
+        """A fresh descriptor array from a small ring (the previous call's array may still be
+        read by the enqueue thread)."""
+        ring = getattr(self, "_desc_ring", None)
+        if ring is None:
+            ring = self._desc_ring = [bytearray(_DESC.size * 64) for _ in range(4)]
+            self._desc_next = 0
+        if n > 64:
+            return bytearray(_DESC.size * n)
+        self._desc_next = (self._desc_next + 1) % len(ring)
+        return ring[self._desc_next]

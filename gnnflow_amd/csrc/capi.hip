@@ -25,6 +25,18 @@ thread_local std::string g_last_error;
 struct ProfileRecord { int slot; hipEvent_t start, stop; };
 std::mutex g_prof_mu;
 unsigned g_prof_mask = 0;
+unsigned g_prof_stride = 1;               // time every n-th interval of a slot
+uint64_t g_prof_seq[kProfSlots] = {0};
+std::vector<hipEvent_t> g_prof_free;      // recycled events (creating one costs microseconds)
+hipEvent_t take_event() {
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_free.empty()) { hipEvent_t e = g_prof_free.back(); g_prof_free.pop_back(); return e; }
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
 std::vector<ProfileRecord> g_prof_pending;
 double g_prof_ms[kProfSlots] = {0};
 uint64_t g_prof_launches[kProfSlots] = {0};
@@ -37,8 +49,8 @@ void drain_profile_locked() {
       g_prof_ms[r.slot] += ms;
       g_prof_launches[r.slot]++;
     }
-    (void)hipEventDestroy(r.start);
-    (void)hipEventDestroy(r.stop);
+    g_prof_free.push_back(r.start);
+    g_prof_free.push_back(r.stop);
   }
   g_prof_pending.clear();
 }
@@ -49,14 +61,15 @@ bool profile_enabled() { return g_prof_mask != 0; }
 
 ProfileScope::ProfileScope(int slot_, hipStream_t stream_) : slot(slot_), stream(stream_) {
   if (!(g_prof_mask & (1u << slot))) return;
-  if (hipEventCreate(&start) != hipSuccess) { start = nullptr; return; }
-  (void)hipEventRecord(start, stream);
+  if (g_prof_seq[slot]++ % g_prof_stride != 0) return;
+  start = take_event();
+  if (start) (void)hipEventRecord(start, stream);
 }
 
 ProfileScope::~ProfileScope() {
   if (!start) return;
-  hipEvent_t stop = nullptr;
-  if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start); return; }
+  hipEvent_t stop = take_event();
+  if (!stop) { (void)hipEventDestroy(start); return; }
   (void)hipEventRecord(stop, stream);
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_pending.push_back({slot, start, stop});
@@ -457,7 +470,16 @@ int gf_profile_enable(int mask) {
 int gf_profile_reset(void) {
   std::lock_guard<std::mutex> lk(gf::g_prof_mu);
   gf::drain_profile_locked();
-  for (int i = 0; i < gf::kProfSlots; ++i) { gf::g_prof_ms[i] = 0; gf::g_prof_launches[i] = 0; }
+  for (int i = 0; i < gf::kProfSlots; ++i) {
+    gf::g_prof_ms[i] = 0;
+    gf::g_prof_launches[i] = 0;
+    gf::g_prof_seq[i] = 0;
+  }
+  return GF_OK;
+}
+int gf_profile_set_stride(unsigned stride) {
+  std::lock_guard<std::mutex> lk(gf::g_prof_mu);
+  gf::g_prof_stride = stride ? stride : 1;
   return GF_OK;
 }
 int gf_profile_get(int which, double* total_ms, uint64_t* launches) {

@@ -133,9 +133,6 @@ __device__ inline uint32_t total_miss(const Counters* c) {
   for (int i = 0; i < kShards; ++i) m += c->shard[i].n_miss;
   return m;
 }
-__device__ inline bool needs_update(const Ctx& c) {
-  return c.update && total_miss(c.ctr) != 0;
-}
 
 template <typename VecT> __device__ inline VecT vec_zero();
 template <> __device__ inline float vec_zero<float>() { return 0.0f; }
@@ -244,24 +241,22 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
 //              has age 0 (lru_cache.py:134-139).
 //  LFU       : `stamp` holds the use count; priority = kAgeMax - count, with this block's hit
 //              already counted (`count[cached_index] += 1` before topk, lfu_cache.py:159-163).
-__device__ inline uint32_t slot_age(const Ctx& c, uint32_t s) {
-  const bool hit = c.touched[s] == c.epoch_new;
+__device__ inline uint32_t slot_age_of(const Ctx& c, uint32_t touched, uint32_t stamp) {
+  const bool hit = touched == c.epoch_new;
   if (c.policy == GF_CACHE_LFU) {
-    const uint32_t cnt = c.stamp[s] + (hit ? 1u : 0u);
+    const uint32_t cnt = stamp + (hit ? 1u : 0u);
     return kAgeMax - (cnt < kAgeMax ? cnt : kAgeMax);
   }
   if (hit) return 0;     // hit in this block
-  const uint32_t a = c.epoch_new - c.stamp[s];
+  const uint32_t a = c.epoch_new - stamp;
   return a < kAgeMax ? a : kAgeMax;
+}
+__device__ inline uint32_t slot_age(const Ctx& c, uint32_t s) {
+  return slot_age_of(c, c.touched[s], c.stamp[s]);
 }
 __device__ inline uint32_t age_bin1(uint32_t a) {
   return a < kFine ? a : kFine + ((a - kFine) >> 11);
 }
-// first row of a distinct missed id: its claim survived the gather's atomicMax
-__device__ inline uint32_t is_rep(const Ctx& c, uint32_t i) {
-  return c.slot_of_row[i] == -1 && c.map[c.ids[i]] == -static_cast<int32_t>(i + 1);
-}
-
 // One launch, two kinds of workgroups (per context):
 //  * scan workgroups: each owns one tile of kRowTile rows, finds the representatives (first
 //    row of every distinct missed id) in it, ranks them inside the tile and publishes the
@@ -270,8 +265,10 @@ __device__ inline uint32_t is_rep(const Ctx& c, uint32_t i) {
 //  * histogram workgroups: level-1 histogram of the slot ages.
 __global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(Round r, uint32_t scan_blocks) {
   const Ctx& c = r.c[blockIdx.y];
-  if (!needs_update(c)) return;
+  if (!c.update) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Both kinds of workgroup issue their first batch of loads BEFORE they look at the miss
+  // count of the fetch record: one memory round trip instead of two on the critical path.
   if (blockIdx.x < scan_blocks) {
     __shared__ uint32_t wave_sums[kWide / 64];
     __shared__ uint32_t carry_s;
@@ -284,10 +281,21 @@ __global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(Round r, uint32_t 
     const uint32_t t_begin = chained ? 0 : blockIdx.x, t_end = chained ? row_tiles : blockIdx.x + 1;
     for (uint32_t t = t_begin; t < t_end; ++t) {
       uint32_t v[kItems], local = 0;
+      int32_t sr[kItems];
+      int64_t idv[kItems];
       const uint32_t i0 = t * kRowTile + tid * kItems;
 #pragma unroll
       for (uint32_t k = 0; k < kItems; ++k) {
-        v[k] = (i0 + k < c.n) ? is_rep(c, i0 + k) : 0u;
+        const bool ok = i0 + k < c.n;
+        sr[k] = ok ? c.slot_of_row[i0 + k] : 0;
+        idv[k] = ok ? c.ids[i0 + k] : 0;
+      }
+      if (t == t_begin && total_miss(c.ctr) == 0) return;   // uniform: nothing to update
+#pragma unroll
+      for (uint32_t k = 0; k < kItems; ++k) {
+        // first row of a distinct missed id: its claim survived the gather's atomicMax
+        v[k] = (i0 + k < c.n && sr[k] == -1 &&
+                c.map[idv[k]] == -static_cast<int32_t>(i0 + k + 1)) ? 1u : 0u;
         local += v[k];
       }
       uint32_t incl = local;
@@ -324,11 +332,29 @@ __global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(Round r, uint32_t 
   if (c.policy == GF_CACHE_FIFO) return;   // victims come from the rotation pointer
   __shared__ uint32_t h[kBins1];
   for (int b = tid; b < kBins1; b += kWide) h[b] = 0;
-  __syncthreads();
   const uint32_t hist_blocks = gridDim.x - scan_blocks;
   const uint32_t stride = hist_blocks * kWide;
-  for (uint32_t s = (blockIdx.x - scan_blocks) * kWide + tid; s < c.capacity; s += stride)
-    atomicAdd(&h[age_bin1(slot_age(c, s))], 1u);
+  constexpr int kBatch = 4;   // slots per thread whose loads are in flight together
+  bool first = true;
+  const uint32_t s_first = (blockIdx.x - scan_blocks) * kWide + tid;
+  for (uint32_t base = 0; base < c.capacity; base += kBatch * stride) {   // uniform trip count
+    uint32_t tv[kBatch], sv[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      const uint32_t s = base + s_first + j * stride;
+      tv[j] = s < c.capacity ? c.touched[s] : 0u;
+      sv[j] = s < c.capacity ? c.stamp[s] : 0u;
+    }
+    if (first) {
+      first = false;
+      if (total_miss(c.ctr) == 0) return;   // uniform across the launch
+      __syncthreads();                      // h[] is zero
+    }
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j)
+      if (base + s_first + j * stride < c.capacity)
+        atomicAdd(&h[age_bin1(slot_age_of(c, tv[j], sv[j]))], 1u);
+  }
   __syncthreads();
   for (int b = tid; b < kBins1; b += kWide)
     if (h[b]) atomicAdd(&c.hist1[b], h[b]);
@@ -336,14 +362,20 @@ __global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(Round r, uint32_t 
 
 // Exclusive prefix of the row-tile counts into LDS (every thread of the kWide-wide workgroup
 // calls it: one tile per thread, workgroup scan); returns the number of distinct missed ids.
-__device__ inline uint32_t load_row_tile_prefix(const Ctx& c, uint32_t* prefix /*[kMaxRowTiles]*/) {
+// `v` is the thread's own tile count, loaded by the caller with row_tile_count().
+__device__ inline uint32_t row_tile_count(const Ctx& c) {
+  const uint32_t row_tiles = (c.n + kRowTile - 1) / kRowTile;
+  const uint32_t m = row_tiles > kMaxRowTiles ? 1u : row_tiles;   // chained scan: one entry
+  return threadIdx.x < m ? c.row_tile_sum[threadIdx.x] : 0u;
+}
+__device__ inline uint32_t row_tile_prefix(const Ctx& c, uint32_t v,
+                                           uint32_t* prefix /*[kMaxRowTiles]*/) {
   __shared__ uint32_t wsum[kWide / 64];
   __shared__ uint32_t total_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t row_tiles = (c.n + kRowTile - 1) / kRowTile;
   const bool chained = row_tiles > kMaxRowTiles;   // one entry holding the total, base 0
   const uint32_t m = chained ? 1u : row_tiles;
-  const uint32_t v = static_cast<uint32_t>(tid) < m ? c.row_tile_sum[tid] : 0u;
   uint32_t incl = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -361,43 +393,57 @@ __device__ inline uint32_t load_row_tile_prefix(const Ctx& c, uint32_t* prefix /
 }
 
 // Finds the bin B (scanning from the oldest = highest bin) where the cumulative count
-// reaches k; returns B and k_rem = k - (count in bins > B).  Called by EVERY thread of
-// the workgroup (barriers inside); the first 256 threads do the work.
+// reaches k; returns B and k_rem = k - (count in bins > B).  bin_load() only issues the
+// loads (the first 256 threads own NBINS / 256 bins each, oldest bins first) so that a caller
+// can overlap them with its other loads; bin_resolve() is called by EVERY thread of the
+// workgroup (barriers inside).
 template <int NBINS>
-__device__ inline void find_bin_from_top(const uint32_t* __restrict__ hist, uint32_t k,
-                                         uint32_t* bin, uint32_t* k_rem) {
-  constexpr int kWorkers = 256;
-  constexpr int kPer = NBINS / kWorkers;
-  __shared__ uint32_t part[kWorkers];
-  __shared__ uint32_t res[2];
+struct BinLoad {
+  uint32_t mine[NBINS / 256];
+  uint32_t sum;
+};
+template <int NBINS>
+__device__ inline void bin_load(const uint32_t* __restrict__ hist, BinLoad<NBINS>& l) {
+  constexpr int kPer = NBINS / 256;
   const int t = threadIdx.x;
-  const bool worker = t < kWorkers;
-  // thread t owns bins [hi_first - kPer + 1, hi_first], hi_first descending with t
-  const int hi_first = NBINS - 1 - t * kPer;
-  uint32_t mine[kPer], sum = 0;
-  if (worker) {
+  l.sum = 0;
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-      mine[j] = hist[hi_first - j];
-      sum += mine[j];
-    }
-    part[t] = sum;
+  for (int j = 0; j < kPer; ++j) {
+    l.mine[j] = t < 256 ? hist[NBINS - 1 - t * kPer - j] : 0u;
+    l.sum += l.mine[j];
   }
+}
+template <int NBINS>
+__device__ inline void bin_resolve(const BinLoad<NBINS>& l, uint32_t k, uint32_t* bin,
+                                   uint32_t* k_rem) {
+  constexpr int kPer = NBINS / 256;
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t res[2];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool worker = t < 256;
+  const int hi_first = NBINS - 1 - t * kPer;
+  uint32_t incl = l.sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (worker && lane == 63) wsum[wave] = incl;
   if (t == 0) { res[0] = 0; res[1] = k; }
   __syncthreads();
   if (worker && k > 0) {
-    uint32_t before = 0;  // exclusive prefix over threads (older bins first)
-    for (int u = 0; u < t; ++u) before += part[u];
-    if (before < k && before + sum >= k) {
+    uint32_t before = incl - l.sum;  // exclusive prefix over threads (older bins first)
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (before < k && before + l.sum >= k) {
       uint32_t acc = before;
 #pragma unroll
       for (int j = 0; j < kPer; ++j) {
-        if (acc + mine[j] >= k) {
+        if (acc + l.mine[j] >= k) {
           res[0] = hi_first - j;
           res[1] = k - acc;
           break;
         }
-        acc += mine[j];
+        acc += l.mine[j];
       }
     }
   }
@@ -412,17 +458,21 @@ __device__ inline void find_bin_from_top(const uint32_t* __restrict__ hist, uint
 struct Threshold { uint32_t age; uint32_t k_tie; };
 
 // per tile of kTile slots: how many sit exactly at the threshold age, and how many are
-// older than it (all of those are evicted).  Tiles first, first + step, ... of the context.
-__device__ inline void count_tiles(const Ctx& c, Threshold th, uint32_t first, uint32_t step) {
+// older than it (all of those are evicted).  Tiles first, first + step, ... of the context;
+// the caller may hand over the first tile's slot state (tv0 / sv0) if it loaded it already.
+__device__ inline void count_tiles(const Ctx& c, Threshold th, uint32_t first, uint32_t step,
+                                   bool preloaded, uint32_t tv0, uint32_t sv0) {
   __shared__ uint32_t cnt[2];
   const uint32_t tiles = (c.capacity + kTile - 1) / kTile;
   for (uint32_t tile = first; tile < tiles; tile += step) {
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t s = tile * kTile + threadIdx.x;
-    const uint32_t a = s < c.capacity ? slot_age(c, s) : 0u;
-    const uint32_t t = __popcll(__ballot(s < c.capacity && a == th.age));
-    const uint32_t o = __popcll(__ballot(s < c.capacity && a > th.age));
+    const bool in = s < c.capacity;
+    uint32_t a = 0;
+    if (in) a = (preloaded && tile == first) ? slot_age_of(c, tv0, sv0) : slot_age(c, s);
+    const uint32_t t = __popcll(__ballot(in && a == th.age));
+    const uint32_t o = __popcll(__ballot(in && a > th.age));
     if ((threadIdx.x & 63) == 0) {
       if (t) atomicAdd(&cnt[0], t);
       if (o) atomicAdd(&cnt[1], o);
@@ -440,14 +490,33 @@ __device__ inline void count_tiles(const Ctx& c, Threshold th, uint32_t first, u
 // it lies in a coarse bin (a slot untouched for more than 2047 updates): then every
 // workgroup adds its share of the level-2 histogram and the LAST one to finish — told by a
 // ticket — resolves the threshold and counts all tiles alone (rare, so not parallel).
+// All first-pass loads (row flags, histogram, slot state, tile counts, fetch record) are
+// issued together before the first dependent use.
 __global__ __launch_bounds__(kWide) void lru_rank_tile_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
-  if (!needs_update(c)) return;
+  if (!c.update) return;
+  const bool fifo = c.policy == GF_CACHE_FIFO;
+  const uint32_t tiles = (c.capacity + kTile - 1) / kTile;
+  const uint32_t i_first = blockIdx.x * kWide + threadIdx.x;
+  uint32_t f0 = 0, rk0 = 0;
+  int64_t id0 = 0;
+  if (i_first < c.n) { f0 = c.rep_flag[i_first]; rk0 = c.rep_rank[i_first]; id0 = c.ids[i_first]; }
+  const uint32_t my_tile_count = row_tile_count(c);
+  BinLoad<kBins1> bl;
+  bl.sum = 0;
+  uint32_t tv0 = 0, sv0 = 0;
+  const uint32_t s_first = blockIdx.x * kTile + threadIdx.x;
+  if (!fifo) {
+    bin_load<kBins1>(c.hist1, bl);
+    if (blockIdx.x < tiles && s_first < c.capacity) { tv0 = c.touched[s_first]; sv0 = c.stamp[s_first]; }
+  }
+  if (total_miss(c.ctr) == 0) return;   // block without a miss: nothing to update
+
   __shared__ uint32_t tile_prefix[kMaxRowTiles];
-  const uint32_t n_unique = load_row_tile_prefix(c, tile_prefix);
+  const uint32_t n_unique = row_tile_prefix(c, my_tile_count, tile_prefix);
   if (blockIdx.x == 0 && threadIdx.x == 0) c.ctr->n_unique = n_unique;   // for the install
   const uint32_t k = min(n_unique, c.capacity);
-  if (c.policy == GF_CACHE_FIFO && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (fifo && blockIdx.x == 0 && threadIdx.x == 0) {
     // fifo_cache.py:96-105: the k slots after the pointer (wrapping) are refilled and the
     // pointer moves to the last of them; k == capacity leaves it where it was
     const uint32_t p = *c.fifo_ptr;
@@ -456,10 +525,17 @@ __global__ __launch_bounds__(kWide) void lru_rank_tile_kernel(Round r) {
   }
   const bool chained = (c.n + kRowTile - 1) / kRowTile > kMaxRowTiles;
   const uint32_t stride = gridDim.x * kWide;
-  for (uint32_t i = blockIdx.x * kWide + threadIdx.x; i < c.n; i += stride) {
-    if (!c.rep_flag[i]) continue;
-    const uint32_t rank = c.rep_rank[i] + (chained ? 0u : tile_prefix[i / kRowTile]);
-    const int64_t id = c.ids[i];
+  for (uint32_t i = i_first; i < c.n; i += stride) {
+    uint32_t f = f0, rk = rk0;
+    int64_t id = id0;
+    if (i != i_first) {
+      f = c.rep_flag[i];
+      if (!f) continue;
+      rk = c.rep_rank[i];
+      id = c.ids[i];
+    }
+    if (!f) continue;
+    const uint32_t rank = rk + (chained ? 0u : tile_prefix[i / kRowTile]);
     if (rank < k) {
       c.rep_row[rank] = i;
       c.rep_id[rank] = id;
@@ -467,15 +543,15 @@ __global__ __launch_bounds__(kWide) void lru_rank_tile_kernel(Round r) {
       c.map[id] = kAbsent;
     }
   }
-  if (c.policy == GF_CACHE_FIFO) return;   // victims come from the rotation pointer
+  if (fifo) return;   // victims come from the rotation pointer
   uint32_t b1, k_rem;
-  find_bin_from_top<kBins1>(c.hist1, k, &b1, &k_rem);   // uniform across the workgroups
+  bin_resolve<kBins1>(bl, k, &b1, &k_rem);   // uniform across the workgroups
   Threshold th;
   if (b1 < kFine) {
     th.age = b1;
     th.k_tie = k_rem;
     if (blockIdx.x == 0 && threadIdx.x == 0) { c.ctr->th_age = th.age; c.ctr->th_k_tie = th.k_tie; }
-    count_tiles(c, th, blockIdx.x, gridDim.x);
+    count_tiles(c, th, blockIdx.x, gridDim.x, true, tv0, sv0);
     return;
   }
   __shared__ uint32_t h[kBins2];
@@ -500,12 +576,14 @@ __global__ __launch_bounds__(kWide) void lru_rank_tile_kernel(Round r) {
   if (!last_s) return;
   for (int b = threadIdx.x; b < kBins2; b += kWide) h[b] = atomicAdd(&c.hist2[b], 0u);
   __syncthreads();
+  BinLoad<kBins2> b2l;
+  bin_load<kBins2>(h, b2l);
   uint32_t b2, k_tie;
-  find_bin_from_top<kBins2>(h, k_rem, &b2, &k_tie);
+  bin_resolve<kBins2>(b2l, k_rem, &b2, &k_tie);
   th.age = kFine + ((b1 - kFine) << 11) + b2;
   th.k_tie = k_tie;
   if (threadIdx.x == 0) { c.ctr->th_age = th.age; c.ctr->th_k_tie = th.k_tie; }
-  count_tiles(c, th, 0, 1);
+  count_tiles(c, th, 0, 1, false, 0, 0);
 }
 
 // evict + install + copy (lru_cache.py:141-160 with a deterministic tie rule): every slot
@@ -522,22 +600,37 @@ __device__ inline void install_body(const Ctx& c) {
   __shared__ uint32_t n_inst;
   const VecT* out = reinterpret_cast<const VecT*>(c.out);
   VecT* cache_buf = reinterpret_cast<VecT*>(c.cache_buf);
-  const uint32_t k = min(c.ctr->n_unique, c.capacity);
-  Threshold th;
-  th.age = c.ctr->th_age;
-  th.k_tie = c.ctr->th_k_tie;
   const uint32_t tiles = (c.capacity + kTile - 1) / kTile;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool fifo = c.policy == GF_CACHE_FIFO;
-  // FIFO: the victims are the arc [start, start + k) of the slot ring; in slot order the
-  // wrapped head [0, head) comes first, then [start, capacity) (fifo_cache.py:100-103)
-  const uint32_t start = fifo ? c.ctr->fifo_start : 0u;
-  const uint32_t head = fifo && start + k > c.capacity ? start + k - c.capacity : 0u;
+  const bool lfu = c.policy == GF_CACHE_LFU;
+  uint32_t k = 0, start = 0, head = 0;
+  Threshold th{0, 0};
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    // bases = counts of all preceding tiles (summed by the whole workgroup)
+    // Every load that does not depend on another one is issued up front — this tile's slot
+    // state, the preceding tiles' counts and (first pass) the fetch record — so the kernel
+    // pays one memory round trip for all of them instead of one each.
+    const uint32_t s = tile * kTile + threadIdx.x;
+    const bool in = s < c.capacity;
+    const uint32_t tv = in ? c.touched[s] : 0u;
+    const uint32_t sv = in ? c.stamp[s] : 0u;
+    const int64_t old = in ? c.slot_id[s] : -1;
     uint32_t pt = 0, po = 0;
     if (!fifo)
       for (uint32_t t = threadIdx.x; t < tile; t += kTile) { pt += c.tile_tie[t]; po += c.tile_old[t]; }
+    if (tile == blockIdx.x) {
+      const uint32_t miss = total_miss(c.ctr);
+      const uint32_t n_unique = c.ctr->n_unique;
+      th.age = c.ctr->th_age;
+      th.k_tie = c.ctr->th_k_tie;
+      start = c.ctr->fifo_start;
+      if (!c.update || miss == 0) return;   // block without a miss: nothing changes
+      k = min(n_unique, c.capacity);
+      // FIFO: the victims are the arc [start, start + k) of the slot ring; in slot order the
+      // wrapped head [0, head) comes first, then [start, capacity) (fifo_cache.py:100-103)
+      head = fifo && start + k > c.capacity ? start + k - c.capacity : 0u;
+    }
+    // bases = counts of all preceding tiles (summed by the whole workgroup)
     for (int d = 32; d > 0; d >>= 1) { pt += __shfl_down(pt, d, 64); po += __shfl_down(po, d, 64); }
     if (lane == 0) { red[0][wave] = pt; red[1][wave] = po; }
     if (threadIdx.x == 0) n_inst = 0;
@@ -545,11 +638,8 @@ __device__ inline void install_body(const Ctx& c) {
     uint32_t tie_base = 0, old_base = 0;
     for (int w = 0; w < kTile / 64; ++w) { tie_base += red[0][w]; old_base += red[1][w]; }
 
-    const uint32_t s = tile * kTile + threadIdx.x;
-    const bool in = s < c.capacity;
-    const bool hit = in && c.touched[s] == c.epoch_new;
-    const uint32_t a = in ? slot_age(c, s) : 0u;
-    const int64_t old = in ? c.slot_id[s] : -1;   // loaded for every slot: off the critical path
+    const bool hit = in && tv == c.epoch_new;
+    const uint32_t a = in ? slot_age_of(c, tv, sv) : 0u;
     const bool tie = in && a == th.age;
     const bool older = in && a > th.age;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -566,28 +656,26 @@ __device__ inline void install_body(const Ctx& c) {
       v = s < head ? s : head + (s - start);
     }
     bool stamped = false;
-    if (evict) {
-      if (v < k) {
-        const uint32_t row = c.rep_row[v];
-        const int64_t nid = c.rep_id[v];
-        if (old >= 0) c.map[old] = kAbsent;
-        c.slot_id[s] = nid;
-        c.map[nid] = static_cast<int32_t>(s);
-        c.stamp[s] = c.policy == GF_CACHE_LFU ? 1u : c.epoch_new;   // lfu: count = 1
-        stamped = true;
-        inst[atomicAdd(&n_inst, 1u)] = make_uint2(s, row);
-      }
+    if (evict && v < k) {
+      const uint32_t row = c.rep_row[v];
+      const int64_t nid = c.rep_id[v];
+      if (old >= 0) c.map[old] = kAbsent;
+      c.slot_id[s] = nid;
+      c.map[nid] = static_cast<int32_t>(s);
+      c.stamp[s] = lfu ? 1u : c.epoch_new;   // lfu: count = 1
+      stamped = true;
+      inst[atomicAdd(&n_inst, 1u)] = make_uint2(s, row);
     }
     if (hit && !stamped)   // lru: count[cached_index] = 0; lfu: count[cached_index] += 1
-      c.stamp[s] = c.policy == GF_CACHE_LFU ? c.stamp[s] + 1u : c.epoch_new;
+      c.stamp[s] = lfu ? sv + 1u : c.epoch_new;
     __syncthreads();
-    // one wave per installed row
-    const uint32_t m = n_inst;
-    for (uint32_t i = wave; i < m; i += kTile / 64) {
+    // copy the installed rows out of the block's output; the workgroup sweeps the m rows as
+    // one flat array so that all of them are in flight together
+    const uint32_t total = n_inst * c.dimv;
+    for (uint32_t f = threadIdx.x; f < total; f += kTile) {
+      const uint32_t i = f / c.dimv, cc = f - i * c.dimv;
       const uint2 p = inst[i];
-      const VecT* src = out + static_cast<uint64_t>(p.y) * c.dimv;
-      VecT* dst = cache_buf + static_cast<uint64_t>(p.x) * c.dimv;
-      for (uint32_t cc = lane; cc < c.dimv; cc += 64) dst[cc] = src[cc];
+      cache_buf[static_cast<uint64_t>(p.x) * c.dimv + cc] = out[static_cast<uint64_t>(p.y) * c.dimv + cc];
     }
     __syncthreads();
   }
@@ -595,7 +683,7 @@ __device__ inline void install_body(const Ctx& c) {
 
 __global__ __launch_bounds__(kTile) void lru_install_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
-  if (!needs_update(c)) return;
+  if (!c.update) return;
   if (c.vec4) install_body<float4>(c);
   else install_body<float>(c);
 }

@@ -59,20 +59,109 @@ class LazyTensorDict(dict):
 
 class MFGBlock:
     """Bipartite block: `num_dst_nodes` roots, `num_src_nodes` = roots ++ sampled
-    neighbours, edges (src index -> dst index) = (col, row) of the SamplingResult."""
+    neighbours, edges (src index -> dst index) = (col, row) of the SamplingResult.
 
-    def __init__(self, num_src_nodes: int, num_dst_nodes: int, col, row, keepalive=None,
-                 num_edges=None, device=None):
-        """col / row: tensors, or zero-argument callables that build them on first use."""
+    Blocks built by the sampler carry only the device addresses of their arrays
+    (`raw`); the torch views — `srcdata['ID' / 'ts']`, `edata['dt' / 'ID']`, `edges()` — and
+    the three data dicts themselves are created on first access, and the feature cache
+    reads the id arrays through `raw_ids()` without creating any."""
+
+    __slots__ = ("_num_src", "_num_dst", "_col", "_row", "_num_edges", "_device",
+                 "_srcdata", "_dstdata", "_edata", "_keepalive", "_raw", "_pending")
+
+    def __init__(self, num_src_nodes: int, num_dst_nodes: int, col=None, row=None,
+                 keepalive=None, num_edges=None, device=None, raw=None):
+        """col / row: tensors, or zero-argument callables that build them on first use.
+        raw: (view_fn, nodes_ptr, ts_ptr, dt_ptr, eid_ptr, col_ptr, row_ptr) with
+        view_fn(ptr, count, dtype, itemsize) -> tensor aliasing the sampler output."""
         self._num_src = int(num_src_nodes)
         self._num_dst = int(num_dst_nodes)
         self._col, self._row = col, row
         self._num_edges = int(num_edges) if num_edges is not None else int(row.shape[0])
         self._device = device if device is not None else row.device
-        self.srcdata: Dict[str, torch.Tensor] = LazyTensorDict()
-        self.dstdata: Dict[str, torch.Tensor] = LazyTensorDict()
-        self.edata: Dict[str, torch.Tensor] = LazyTensorDict()
+        self._srcdata = self._dstdata = self._edata = None
         self._keepalive = keepalive
+        self._raw = raw
+        self._pending = None     # [(which dict, key, thunk)] registered before the dicts exist
+
+    # ---- data dicts, created on demand ----------------------------------------------
+    def _make(self, which):
+        d = LazyTensorDict()
+        raw = self._raw
+        if raw is not None:
+            view = raw[0]
+            if which == "src":
+                ns = self._num_src
+                d.set_lazy('ID', lambda: view(raw[1], ns, torch.int64, 8))
+                d.set_lazy('ts', lambda: view(raw[2], ns, torch.float32, 4))
+            elif which == "e":
+                ne = self._num_edges
+                d.set_lazy('dt', lambda: view(raw[3], ne, torch.float32, 4))
+                d.set_lazy('ID', lambda: view(raw[4], ne, torch.int64, 8))
+        if self._pending:
+            keep = []
+            for w, key, thunk in self._pending:
+                if w == which:
+                    d.set_lazy(key, thunk)
+                else:
+                    keep.append((w, key, thunk))
+            self._pending = keep or None
+        return d
+
+    @property
+    def srcdata(self) -> Dict[str, torch.Tensor]:
+        if self._srcdata is None:
+            self._srcdata = self._make("src")
+        return self._srcdata
+
+    @srcdata.setter
+    def srcdata(self, value):
+        self._srcdata = value
+
+    @property
+    def dstdata(self) -> Dict[str, torch.Tensor]:
+        if self._dstdata is None:
+            self._dstdata = self._make("dst")
+        return self._dstdata
+
+    @dstdata.setter
+    def dstdata(self, value):
+        self._dstdata = value
+
+    @property
+    def edata(self) -> Dict[str, torch.Tensor]:
+        if self._edata is None:
+            self._edata = self._make("e")
+        return self._edata
+
+    @edata.setter
+    def edata(self, value):
+        self._edata = value
+
+    def set_lazy(self, which: str, key: str, thunk):
+        """Registers `thunk` as the producer of srcdata / edata [key] (which = 'src' | 'e')
+        without creating the dict."""
+        d = self._srcdata if which == "src" else self._edata
+        if d is not None and hasattr(d, "set_lazy"):
+            dict.pop(d, key, None)
+            d.set_lazy(key, thunk)
+        elif d is not None:
+            d[key] = thunk()
+        else:
+            if self._pending is None:
+                self._pending = []
+            self._pending.append((which, key, thunk))
+
+    def raw_ids(self, which: str):
+        """(device address, count) of srcdata['ID'] ('src') or edata['ID'] ('e') if they are
+        still the sampler's own arrays, else None (the caller then reads the tensor)."""
+        raw = self._raw
+        if raw is None:
+            return None
+        d = self._srcdata if which == "src" else self._edata
+        if d is not None and dict.__contains__(d, 'ID'):
+            return None        # materialised — possibly replaced by the caller
+        return (raw[1], self._num_src) if which == "src" else (raw[4], self._num_edges)
 
     def num_src_nodes(self) -> int:
         return self._num_src
@@ -85,6 +174,10 @@ class MFGBlock:
 
     def edges(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """(source node index, destination node index) per edge, as dgl's edges()."""
+        if self._col is None and self._raw is not None:
+            view, ne = self._raw[0], self._num_edges
+            self._col = view(self._raw[5], ne, torch.int64, 8)
+            self._row = view(self._raw[6], ne, torch.int64, 8)
         if callable(self._col):
             self._col = self._col()
         if callable(self._row):

@@ -76,6 +76,8 @@ class TemporalSampler:
         self._is_static = bool(kwargs.get('is_static', False))
         self._bytes_cache = {}
         self._inflight = None
+        self._slab = None
+        self._gf_blocks = (_capi.GfBlock * (self._num_layers * self._num_snapshots))()
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -109,31 +111,22 @@ class TemporalSampler:
             "target_vertices and timestamps must be 1D and of equal length"
         return nodes, ts
 
-    def _view(self, buf, base, ptr, count, dtype, itemsize):
-        if count == 0:
-            return torch.empty(0, dtype=dtype, device=self._device)
-        off = ptr - base
-        return buf[off:off + count * itemsize].view(dtype)
-
     def _block(self, buf, gb) -> MFGBlock:
         """MFG over one gf_block; the tensor views into `buf` are built on first access."""
-        base = buf.data_ptr()
-        ns, ne = gb.num_src_nodes, gb.num_edges
         if gb.all_nodes is None:
             raise RuntimeError("sampler returned a null block")
-        view = self._view
-        i64, f32 = torch.int64, torch.float32
-        col_p, row_p = gb.col, gb.row
-        nodes_p, ts_p, dt_p, eid_p = gb.all_nodes, gb.all_timestamps, gb.delta_timestamps, gb.eids
-        b = MFGBlock(ns, gb.num_dst_nodes,
-                     lambda: view(buf, base, col_p, ne, i64, 8),
-                     lambda: view(buf, base, row_p, ne, i64, 8),
-                     keepalive=buf, num_edges=ne, device=self._device)
-        b.srcdata.set_lazy('ID', lambda: view(buf, base, nodes_p, ns, i64, 8))
-        b.srcdata.set_lazy('ts', lambda: view(buf, base, ts_p, ns, f32, 4))
-        b.edata.set_lazy('dt', lambda: view(buf, base, dt_p, ne, f32, 4))
-        b.edata.set_lazy('ID', lambda: view(buf, base, eid_p, ne, i64, 8))
-        return b
+        base, device = buf.data_ptr(), self._device
+
+        def view(ptr, count, dtype, itemsize):
+            if count == 0:
+                return torch.empty(0, dtype=dtype, device=device)
+            off = ptr - base
+            return buf[off:off + count * itemsize].view(dtype)
+
+        return MFGBlock(gb.num_src_nodes, gb.num_dst_nodes, keepalive=buf,
+                        num_edges=gb.num_edges, device=device,
+                        raw=(view, gb.all_nodes, gb.all_timestamps, gb.delta_timestamps,
+                             gb.eids, gb.col, gb.row))
 
     def _empty_block(self) -> MFGBlock:
         e64 = torch.empty(0, dtype=torch.int64, device=self._device)
@@ -180,8 +173,7 @@ class TemporalSampler:
                 n = C.c_size_t(0)
                 _capi.check(self._lib.gf_sampler_output_bytes(self._h, R, C.byref(n)))
                 nbytes = self._bytes_cache[R] = n.value
-            with torch.cuda.stream(stream):
-                buf = torch.empty(nbytes, dtype=torch.uint8, device=self._device)
+            buf = self._output_buffer(nbytes, stream)
         begin = self._lib.gf_sampler_sample_begin_async if worker_enqueue \
             else self._lib.gf_sampler_sample_begin
         _capi.check(begin(
@@ -190,9 +182,27 @@ class TemporalSampler:
         self._inflight = PendingSample(self, buf, (nodes, ts), R)
         return self._inflight
 
+    def _output_buffer(self, nbytes, stream):
+        """Output memory for one sample(), owned by `stream` in the caching allocator.
+        Small outputs are carved out of a slab that is allocated once per 16 calls:
+        switching torch's current stream for a torch.empty costs more host time than a
+        batch-600 sampling kernel runs."""
+        per_slab = min(16, (32 << 20) // max(nbytes, 1))
+        if per_slab < 2:
+            with torch.cuda.stream(stream):
+                return torch.empty(nbytes, dtype=torch.uint8, device=self._device)
+        step = (nbytes + 255) & ~255
+        slab = self._slab
+        if slab is None or slab[1] != stream or slab[2] != step or slab[3] >= per_slab:
+            with torch.cuda.stream(stream):
+                mem = torch.empty(step * per_slab, dtype=torch.uint8, device=self._device)
+            slab = self._slab = [mem, stream, step, 0]
+        i = slab[3]
+        slab[3] = i + 1
+        return slab[0][i * step:i * step + nbytes]
+
     def _finish(self, buf, R) -> List[List[MFGBlock]]:
-        nblocks = self._num_layers * self._num_snapshots
-        blocks = (_capi.GfBlock * nblocks)()
+        blocks = self._gf_blocks
         _capi.check(self._lib.gf_sampler_sample_end(self._h, blocks))
         if R == 0:
             return [[self._empty_block() for _ in range(self._num_snapshots)]

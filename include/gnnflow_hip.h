@@ -291,6 +291,10 @@ GF_API int gf_cache_mem_bytes(const gf_cache* c, size_t* out);
 GF_API int gf_profile_enable(int mask);
 GF_API int gf_profile_reset(void);
 GF_API int gf_profile_get(int which, double* total_ms, uint64_t* launches);
+/* Time only every stride-th interval of a family (default 1 = all): an event pair costs
+ * host time and a few microseconds of stream time per launch, which a latency-bound
+ * workload feels; gf_profile_get then reports the sampled intervals. */
+GF_API int gf_profile_set_stride(unsigned stride);
 
 #ifdef __cplusplus
 }
