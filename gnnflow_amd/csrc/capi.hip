@@ -166,6 +166,22 @@ class EnqueueWorker {
 
 using gf::guarded;
 
+namespace gf {
+// block_ops.hip
+void segment_offsets(const int64_t* d_row, size_t num_edges, size_t num_dst, int64_t* d_offsets,
+                     int device, hipStream_t stream);
+void edge_softmax(const int64_t* d_offsets, size_t num_dst, size_t num_edges, size_t heads,
+                  const float* d_y_or_x, const float* d_grad_y, float* d_out, int device,
+                  hipStream_t stream);
+void segment_reduce_forward(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
+                            const float* d_src, size_t dim, const float* d_w, size_t heads,
+                            bool mean, float* d_out, int device, hipStream_t stream);
+void segment_reduce_backward(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
+                             const float* d_src, size_t dim, const float* d_w, size_t heads,
+                             bool mean, const float* d_grad_out, float* d_grad_src,
+                             size_t num_src, float* d_grad_w, int device, hipStream_t stream);
+}  // namespace gf
+
 extern "C" {
 
 const char* gf_last_error(void) { return gf::g_last_error.c_str(); }
@@ -462,6 +478,49 @@ int gf_cache_mem_bytes(const gf_cache* c, size_t* out) {
 }
 
 // ---- profiling ---------------------------------------------------------------------
+int gf_block_segment_offsets(const int64_t* d_row, size_t num_edges, size_t num_dst,
+                             int64_t* d_offsets, int device, void* stream) {
+  return guarded([&] {
+    gf::segment_offsets(d_row, num_edges, num_dst, d_offsets, device,
+                        static_cast<hipStream_t>(stream));
+  });
+}
+int gf_block_edge_softmax(const int64_t* d_offsets, size_t num_dst, size_t num_edges, size_t heads,
+                          const float* d_logits, float* d_out, int device, void* stream) {
+  return guarded([&] {
+    gf::edge_softmax(d_offsets, num_dst, num_edges, heads, d_logits, nullptr, d_out, device,
+                     static_cast<hipStream_t>(stream));
+  });
+}
+int gf_block_edge_softmax_backward(const int64_t* d_offsets, size_t num_dst, size_t num_edges,
+                                   size_t heads, const float* d_out, const float* d_grad_out,
+                                   float* d_grad_logits, int device, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(d_grad_out != nullptr || num_edges == 0, "edge_softmax backward: null gradient");
+    gf::edge_softmax(d_offsets, num_dst, num_edges, heads, d_out, d_grad_out, d_grad_logits,
+                     device, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_block_reduce(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
+                    const float* d_src, size_t dim, const float* d_edge_weight, size_t heads,
+                    int mean, float* d_out, int device, void* stream) {
+  return guarded([&] {
+    gf::segment_reduce_forward(d_offsets, num_dst, d_col, d_src, dim, d_edge_weight, heads,
+                               mean != 0, d_out, device, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_block_reduce_backward(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
+                             const float* d_src, size_t dim, const float* d_edge_weight,
+                             size_t heads, int mean, const float* d_grad_out, float* d_grad_src,
+                             size_t num_src, float* d_grad_edge_weight, int device,
+                             void* stream) {
+  return guarded([&] {
+    gf::segment_reduce_backward(d_offsets, num_dst, d_col, d_src, dim, d_edge_weight, heads,
+                                mean != 0, d_grad_out, d_grad_src, num_src, d_grad_edge_weight,
+                                device, static_cast<hipStream_t>(stream));
+  });
+}
+
 int gf_profile_enable(int mask) {
   std::lock_guard<std::mutex> lk(gf::g_prof_mu);
   gf::g_prof_mask = static_cast<unsigned>(mask);

@@ -67,7 +67,8 @@ class MFGBlock:
     reads the id arrays through `raw_ids()` without creating any."""
 
     __slots__ = ("_num_src", "_num_dst", "_col", "_row", "_num_edges", "_device",
-                 "_srcdata", "_dstdata", "_edata", "_keepalive", "_raw", "_pending")
+                 "_srcdata", "_dstdata", "_edata", "_keepalive", "_raw", "_pending",
+                 "_segments")
 
     def __init__(self, num_src_nodes: int, num_dst_nodes: int, col=None, row=None,
                  keepalive=None, num_edges=None, device=None, raw=None):
@@ -83,6 +84,7 @@ class MFGBlock:
         self._keepalive = keepalive
         self._raw = raw
         self._pending = None     # [(which dict, key, thunk)] registered before the dicts exist
+        self._segments = None    # (offsets[num_dst + 1], col grouped by destination, perm)
 
     # ---- data dicts, created on demand ----------------------------------------------
     def _make(self, which):
@@ -162,6 +164,44 @@ class MFGBlock:
         if d is not None and dict.__contains__(d, 'ID'):
             return None        # materialised — possibly replaced by the caller
         return (raw[1], self._num_src) if which == "src" else (raw[4], self._num_edges)
+
+    def segments(self):
+        """(offsets, col, perm): edges grouped by destination node — offsets[d]..offsets[d+1]
+        are the edges into d, `col` their source indices in that order, `perm` the edge
+        permutation that groups them (None when the edges already are, as the sampler's)."""
+        if self._segments is None:
+            import ctypes as C
+            from . import _capi
+            col, row = self.edges()
+            perm = None
+            if self._raw is None and self._num_edges > 1 and \
+                    not bool((row[1:] >= row[:-1]).all()):
+                perm = torch.argsort(row, stable=True)
+                col, row = col[perm], row[perm]
+            col, row = col.contiguous(), row.contiguous()
+            offsets = torch.empty(self._num_dst + 1, dtype=torch.int64, device=self._device)
+            with torch.cuda.device(self._device):
+                _capi.check(_capi.load().gf_block_segment_offsets(
+                    row.data_ptr() if self._num_edges else None, self._num_edges, self._num_dst,
+                    offsets.data_ptr(), self._device.index,
+                    C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)))
+            self._segments = (offsets, col, perm)
+        return self._segments
+
+    def update_all(self, message_func, reduce_func):
+        """dgl's block.update_all for the message / reduce pairs of gnnflow_amd.function:
+        dstdata[reduce.out] = reduce over in-edges of message (layers.py:159)."""
+        from . import ops
+        if reduce_func.msg != message_func.out:
+            raise KeyError("reducer reads '{}' but the message is '{}'".format(
+                reduce_func.msg, message_func.out))
+        weight = self.edata[message_func.edge] if message_func.kind == "u_mul_e" else None
+        self.dstdata[reduce_func.out] = ops.block_reduce(
+            self, self.srcdata[message_func.src], weight, mean=reduce_func.kind == "mean")
+
+    def in_degrees(self) -> torch.Tensor:
+        offsets = self.segments()[0]
+        return offsets[1:] - offsets[:-1]
 
     def num_src_nodes(self) -> int:
         return self._num_src

@@ -282,6 +282,36 @@ GF_API int gf_memory_update(float* d_node_memory, float* d_node_memory_ts, float
 GF_API int gf_cache_slot_ids(const gf_cache* c, int64_t* out, size_t capacity);
 GF_API int gf_cache_mem_bytes(const gf_cache* c, size_t* out);
 
+/* ---- message passing on a sampled block ---------------------- */
+/* The DGL calls of the reference's layers on an MFG (gnnflow/models/modules/layers.py:153-159,
+ * models/graphsage.py:27-31, models/gat.py:28-46), as segment operations: a block's edges are
+ * grouped by destination (`row` non-decreasing, as the sampler emits them).  fp32, device
+ * pointers, ordered on `stream`.
+ * offsets[d] = first edge with row >= d, d = 0..num_dst (so offsets[num_dst] = num_edges). */
+GF_API int gf_block_segment_offsets(const int64_t* d_row, size_t num_edges, size_t num_dst,
+                                    int64_t* d_offsets, int device, void* stream);
+/* dgl.ops.edge_softmax(block, logits[num_edges, heads]): softmax over each destination's edges */
+GF_API int gf_block_edge_softmax(const int64_t* d_offsets, size_t num_dst, size_t num_edges,
+                                 size_t heads, const float* d_logits, float* d_out, int device,
+                                 void* stream);
+GF_API int gf_block_edge_softmax_backward(const int64_t* d_offsets, size_t num_dst,
+                                          size_t num_edges, size_t heads, const float* d_out,
+                                          const float* d_grad_out, float* d_grad_logits,
+                                          int device, void* stream);
+/* update_all(copy_src | u_mul_e, sum | mean): out[d, :] = reduce over edges k of d of
+ * edge_weight[k, head] * src[col[k], :]  (d_edge_weight NULL: copy_src; else [num_edges, heads]
+ * with dim % heads == 0, each weight covering dim / heads consecutive columns). */
+GF_API int gf_block_reduce(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
+                           const float* d_src, size_t dim, const float* d_edge_weight,
+                           size_t heads, int mean, float* d_out, int device, void* stream);
+/* d_grad_src [num_src, dim] is zeroed then accumulated (NULL: skipped); d_grad_edge_weight
+ * [num_edges, heads] or NULL. */
+GF_API int gf_block_reduce_backward(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
+                                    const float* d_src, size_t dim, const float* d_edge_weight,
+                                    size_t heads, int mean, const float* d_grad_out,
+                                    float* d_grad_src, size_t num_src,
+                                    float* d_grad_edge_weight, int device, void* stream);
+
 /* ---- measurement support (bench.py) ---------------------------------------- */
 /* Accumulated device time of a kernel family since the last reset, measured with
  * HIP events recorded around each launch on the launching stream.

@@ -3,6 +3,7 @@
 
   python scripts/sweep.py gather     # fused gather kernel, rows x 172 floats, cache 0.2
   python scripts/sweep.py sampler    # uniform / recent sampling on a power-law graph
+  python scripts/sweep.py blockops   # edge_softmax / update_all on sampler-shaped blocks
 Prints one JSON object per line.  HIP-event timing via gf_profile_*.
 """
 import ctypes as C
@@ -124,6 +125,70 @@ def sampler_sweep():
                     "algorithmic_MB": alg / 1e6, "GBps_kernels": alg / (kern_ms * 1e-3) / 1e9}))
 
 
+def blockops_sweep():
+    """edge_softmax + update_all(copy_src, sum), forward and backward, on blocks shaped like
+    the sampler's (R roots x fanout 10, every edge a new source node), against the same ops
+    written with torch index_add / scatter_reduce.  torch.cuda events, 20 repetitions."""
+    from gnnflow_amd import MFGBlock, ops
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e3 / reps
+
+    H, D = 2, 50          # TGN/TGAT attention: 2 heads, dim_out 100
+    for R in (1800, 19800, 198000, 1980000):
+        E = R * 10
+        row = torch.arange(R, device=dev).repeat_interleave(10)
+        col = R + torch.arange(E, device=dev)
+        blk = MFGBlock(R + E, R, col, row)
+        blk.segments()
+        x = torch.randn(E, H, device=dev, requires_grad=True)
+        v = torch.randn(R + E, H * D, device=dev, requires_grad=True)
+        gy = torch.randn(E, H, device=dev)
+        gh = torch.randn(R, H * D, device=dev)
+
+        def hip_softmax():
+            ops.edge_softmax(blk, x).backward(gy)
+
+        def torch_softmax():
+            m = torch.full((R, H), -float("inf"), device=dev).scatter_reduce(
+                0, row[:, None].expand(E, H), x, "amax")
+            ex = torch.exp(x - m[row])
+            s = torch.zeros(R, H, device=dev).index_add(0, row, ex)
+            (ex / s[row]).backward(gy)
+
+        def hip_reduce():
+            ops.block_reduce(blk, v).backward(gh)
+
+        def torch_reduce():
+            torch.zeros(R, H * D, device=dev).index_add(0, row, v[col]).backward(gh)
+
+        out = {"sweep": "blockops", "roots": R, "edges": E, "heads": H, "dim": H * D}
+        out["edge_softmax_fwd_bwd_us"] = timed(hip_softmax)
+        out["edge_softmax_torch_us"] = timed(torch_softmax)
+        out["update_all_fwd_bwd_us"] = timed(hip_reduce)
+        out["update_all_torch_us"] = timed(torch_reduce)
+        # algorithmic bytes: softmax fwd reads x, writes y; bwd reads y, gy, writes gx (5 x 4 B
+        # per edge-head); reduce fwd reads E rows, writes R rows; bwd reads R rows (re-read per
+        # edge from cache), writes (R + E) rows (memset + adds on E of them)
+        sm_bytes = 5 * 4 * E * H
+        rd_bytes = 4 * H * D * (E + R + R + (R + E) + E)
+        out["edge_softmax_GBps"] = sm_bytes / out["edge_softmax_fwd_bwd_us"] / 1e3
+        out["update_all_GBps"] = rd_bytes / out["update_all_fwd_bwd_us"] / 1e3
+        print(json.dumps(out), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gather"
+    if what == "blockops":
+        blockops_sweep()
+        sys.exit(0)
     gather_sweep() if what == "gather" else sampler_sweep()
