@@ -75,6 +75,22 @@ ProfileScope::~ProfileScope() {
   g_prof_pending.push_back({slot, start, stop});
 }
 
+bool profile_begin(int slot, hipEvent_t* start, hipEvent_t* stop) {
+  if (!(g_prof_mask & (1u << slot))) return false;
+  if (g_prof_seq[slot]++ % g_prof_stride != 0) return false;
+  *start = take_event();
+  *stop = take_event();
+  if (*start && *stop) return true;
+  if (*start) (void)hipEventDestroy(*start);
+  if (*stop) (void)hipEventDestroy(*stop);
+  return false;
+}
+
+void profile_end(int slot, hipEvent_t start, hipEvent_t stop) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_pending.push_back({slot, start, stop});
+}
+
 }  // namespace gf
 
 namespace gf {

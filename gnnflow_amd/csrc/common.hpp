@@ -170,6 +170,14 @@ struct ProfileScope {
   ~ProfileScope();
 };
 
+// Kernel-attached timing: profile_begin() says whether this launch of `slot` is to be timed
+// and hands out two events for hipExtLaunchKernelGGL(start, stop) — they carry the
+// dispatch's own begin / end timestamps, so the interval is the kernel's execution time
+// (what rocprofv3 reports) without the stream-marker overhead of events recorded around it;
+// profile_end() queues the pair for gf_profile_get.
+bool profile_begin(int slot, hipEvent_t* start, hipEvent_t* stop);
+void profile_end(int slot, hipEvent_t start, hipEvent_t stop);
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace gf

@@ -45,6 +45,8 @@
 // changes LRU state if the block also had a miss, exactly as in the reference.
 #include "feature_cache.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
@@ -197,7 +199,8 @@ __device__ inline void gather_body(const Ctx& c) {
       const VecT* s = reinterpret_cast<const VecT*>(__shfl(src_bits, r, 64));
       return (*valid && s) ? s[cc] : vec_zero<VecT>();
     };
-    // 4 independent 16-byte loads in flight per lane
+    // 4 independent 16-byte loads in flight per lane (8 measured the same: the launch is
+    // latency-, not concurrency-limited at batch-600 sizes)
     for (uint32_t base = 0; base < total; base += 256) {
       const uint32_t f = base + lane;
       bool p0, p1, p2, p3;
@@ -747,8 +750,15 @@ void launch_round(Round& r, hipStream_t stream) {
     }
   }
   {
-    ProfileScope ps(kProfGather, stream);
-    gather_rows_kernel<<<dim3(ggrid, r.count), dim3(kThreads), 0, stream>>>(r);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile_begin(kProfGather, &e0, &e1)) {
+      // the events ride on the dispatch itself: its begin / end timestamps
+      hipExtLaunchKernelGGL(gather_rows_kernel, dim3(ggrid, r.count), dim3(kThreads), 0, stream,
+                            e0, e1, 0, r);
+      profile_end(kProfGather, e0, e1);
+    } else {
+      gather_rows_kernel<<<dim3(ggrid, r.count), dim3(kThreads), 0, stream>>>(r);
+    }
     GF_HIP(hipGetLastError());
   }
   if (!any_update) return;

@@ -43,7 +43,9 @@ def gather_sweep():
         for ratio in (0.0, 0.2):
             cache = LRUCache(ratio, 0.0, 10, table_rows, dev, None, feats, 0, d)
             cache.init_cache()
-            for n in (10000, 50000, 198000, 1000000, 4000000):
+            rows_list = [int(x) for x in os.environ.get(
+                "SWEEP_ROWS", "2000,10000,20000,50000,198000,1000000,4000000").split(",")]
+            for n in rows_list:
                 g = torch.Generator(device=dev).manual_seed(n)
                 ids = torch.randint(0, table_rows, (n,), generator=g, device=dev)
                 for _ in range(3):
