@@ -113,7 +113,7 @@ def main():
     t0 = time.time()
     ingest = graph
     if args.partition == "hash":
-        from gnnflow_amd.dist import PartitionedGraph, PartitionedSampler
+        from gnnflow_amd.dist import DevicePartitionedSampler, PartitionedGraph
         ingest = PartitionedGraph(graph, rank, world)
     for lo in range(0, g["num_edges"], 100000):   # benchmark_sampler.py:56-63
         hi = lo + 100000
@@ -122,11 +122,9 @@ def main():
     build_s = time.time() - t0
     sampler = gnnflow_amd.TemporalSampler(graph, fanouts, args.strategy, seed=1234)
     if args.partition == "hash":
-        # every rank owns a shard; roots are exchanged with two all-to-all-v per layer
-        local = sampler
-        sampler = PartitionedSampler(
-            lambda n, t, layer, snap: local.sample_layer(n, t, layer, snap),
-            fanouts, 1, device=dev)
+        # every rank owns a shard; per layer the roots are bucketed by owner, requests and
+        # replies travel as all-to-all-v, and the rank's own share is sampled meanwhile
+        sampler = DevicePartitionedSampler(sampler)
         args.no_pipeline = True
 
     gen = torch.Generator(device=dev).manual_seed(42)

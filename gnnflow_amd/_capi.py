@@ -113,6 +113,12 @@ PROTOTYPES = {
     "gf_gather_rows": (C.c_int, [_p, _sz, _sz, _p, _sz, _p, C.c_int, _p]),
     "gf_cache_slot_ids": (C.c_int, [_p, _p, _sz]),
     "gf_cache_mem_bytes": (C.c_int, [_p, C.POINTER(_sz)]),
+    "gf_partition_scratch_bytes": (C.c_int, [_sz, C.c_int, C.POINTER(_sz)]),
+    "gf_partition_plan": (C.c_int, [_p, _p, _sz, C.c_int, C.c_int, _p, _p, _p, _p, _sz, C.c_int,
+                                    _p]),
+    "gf_sampler_sample_layer_padded": (C.c_int, [_p, _p, _sz, C.c_uint32, C.c_uint32, _p, _p]),
+    "gf_sampler_merge_padded": (C.c_int, [_p, _p, _p, _sz, C.c_uint32, _p, _p, _p, _sz,
+                                          C.POINTER(GfBlock), _p]),
     "gf_block_segment_offsets": (C.c_int, [_p, _sz, _sz, _p, C.c_int, _p]),
     "gf_block_edge_softmax": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, C.c_int, _p]),
     "gf_block_edge_softmax_backward": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, _p, C.c_int, _p]),

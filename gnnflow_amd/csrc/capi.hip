@@ -183,6 +183,11 @@ class EnqueueWorker {
 using gf::guarded;
 
 namespace gf {
+// partition.hip
+size_t partition_scratch_bytes(size_t R, int world_size);
+void partition_plan(const int64_t* d_nodes, const float* d_ts, size_t R, int world_size, int rank,
+                    int64_t* d_requests, uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
+                    size_t scratch_bytes, int device, hipStream_t stream);
 // block_ops.hip
 void segment_offsets(const int64_t* d_row, size_t num_edges, size_t num_dst, int64_t* d_offsets,
                      int device, hipStream_t stream);
@@ -494,6 +499,39 @@ int gf_cache_mem_bytes(const gf_cache* c, size_t* out) {
 }
 
 // ---- profiling ---------------------------------------------------------------------
+int gf_partition_scratch_bytes(size_t num_roots, int world_size, size_t* out) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_partition_scratch_bytes: null output");
+    GF_REQUIRE(world_size >= 1, "partition: world size must be >= 1");
+    *out = gf::partition_scratch_bytes(num_roots, world_size);
+  });
+}
+int gf_partition_plan(const int64_t* d_nodes, const float* d_ts, size_t num_roots, int world_size,
+                      int rank, int64_t* d_requests, uint32_t* d_pos, uint64_t* d_counts,
+                      void* d_scratch, size_t scratch_bytes, int device, void* stream) {
+  return guarded([&] {
+    gf::partition_plan(d_nodes, d_ts, num_roots, world_size, rank, d_requests, d_pos, d_counts,
+                       d_scratch, scratch_bytes, device, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_sampler_sample_layer_padded(gf_sampler* s, const int64_t* d_requests, size_t n,
+                                   uint32_t layer, uint32_t snapshot, int64_t* d_out,
+                                   void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    s->impl.sample_layer_padded(d_requests, n, layer, snapshot, d_out,
+                                static_cast<hipStream_t>(stream));
+  });
+}
+int gf_sampler_merge_padded(gf_sampler* s, const int64_t* d_roots, const float* d_ts, size_t n,
+                            uint32_t layer, const int64_t* d_replies, const uint32_t* d_pos,
+                            void* d_out, size_t out_bytes, gf_block* block, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    s->impl.merge_padded(d_roots, d_ts, n, layer, d_replies, d_pos, d_out, out_bytes, block,
+                         static_cast<hipStream_t>(stream));
+  });
+}
 int gf_block_segment_offsets(const int64_t* d_row, size_t num_edges, size_t num_dst,
                              int64_t* d_offsets, int device, void* stream) {
   return guarded([&] {

@@ -447,6 +447,105 @@ __global__ __launch_bounds__(kEmitThreads) void sample_emit_prefix_kernel(
   }
 }
 
+// ---- partitioned sampling: fixed-slot replies and their merge ---------
+__device__ inline int64_t pack_f32_pair(float lo, float hi) {
+  return static_cast<int64_t>(static_cast<uint64_t>(__float_as_uint(lo)) |
+                              (static_cast<uint64_t>(__float_as_uint(hi)) << 32));
+}
+
+// Search + select in ONE launch: with `fanout` fixed slots per root there is no compaction,
+// hence no prefix sum between the two.  Same window / candidate / selection rules as
+// sample_search_kernel + sample_emit_kernel; the Philox counter is the slot index.
+template <int GROUP>
+__global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
+    GraphView g, const int64_t* __restrict__ req, uint64_t n, uint32_t snapshot_idx,
+    uint32_t num_snapshots, float window, uint32_t fanout, int uniform, int prop_time,
+    uint64_t seed, uint64_t call, int64_t* __restrict__ out) {
+  constexpr int kGroupsPerBlock = kSearchThreads / GROUP;
+  const int lane = threadIdx.x % GROUP;
+  const int group_in_wave = (threadIdx.x % 64) / GROUP;
+  const uint64_t group = static_cast<uint64_t>(blockIdx.x) * kGroupsPerBlock + threadIdx.x / GROUP;
+  const uint64_t num_groups = static_cast<uint64_t>(gridDim.x) * kGroupsPerBlock;
+  for (uint64_t r = group; r < n; r += num_groups) {
+    const int64_t nid = req[2 * r];
+    const float t = __uint_as_float(static_cast<uint32_t>(static_cast<uint64_t>(req[2 * r + 1])));
+    float start, end;
+    time_window(t, snapshot_idx, num_snapshots, window, &start, &end);
+    uint64_t end_off = 0;
+    uint32_t n_cand = 0;
+    if (nid >= 0 && static_cast<uint64_t>(nid) < g.table_len) {
+      const NodeEntry e = g.table[nid];
+      if (e.size > 0) {
+        const float* ts = g.ts_pool + e.start;
+        const float first = ts[0];
+        const uint32_t hi = lower_bound_group<GROUP>(ts, e.size, end, lane, group_in_wave);
+        uint32_t lo = 0;
+        if (start > first) lo = lower_bound_group<GROUP>(ts, hi, start, lane, group_in_wave);
+        n_cand = hi > lo ? hi - lo : 0;
+        end_off = e.start + hi;
+      }
+    }
+    const uint32_t valid = valid_slots(n_cand, fanout, uniform);
+    for (uint32_t j = lane; j < fanout; j += GROUP) {
+      const uint64_t slot = r * fanout + j;
+      int64_t* o = out + slot * 3;
+      if (j < valid) {
+        const uint32_t pick = uniform ? gf_philox4x32_10_first(seed, slot, call) % n_cand : j;
+        const uint64_t e = end_off - 1 - pick;
+        const float ets = g.ts_pool[e];
+        const EdgePair nb = g.nbr_pool[e];
+        o[0] = nb.dst;
+        o[1] = nb.eid;
+        o[2] = pack_f32_pair(prop_time ? t : ets, t - ets);
+      } else {
+        o[0] = -1;
+        o[1] = -1;
+        o[2] = -1;
+      }
+    }
+  }
+}
+
+// valid slots of root i's reply row (a prefix of the row for both policies)
+__global__ void merge_count_kernel(const int64_t* __restrict__ rep, const uint32_t* __restrict__ pos,
+                                   uint64_t R, uint32_t fanout, uint32_t* __restrict__ rec_cnt) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const int64_t* s = rep + static_cast<uint64_t>(pos[i]) * fanout * 3;
+  uint32_t c = 0;
+  for (uint32_t j = 0; j < fanout; ++j) c += s[3 * j] >= 0 ? 1u : 0u;
+  rec_cnt[i] = c;
+}
+
+__global__ __launch_bounds__(kEmitThreads) void merge_emit_kernel(
+    const int64_t* __restrict__ roots, const float* __restrict__ root_ts, uint64_t R,
+    uint32_t fanout, const int64_t* __restrict__ rep, const uint32_t* __restrict__ pos,
+    const uint32_t* __restrict__ rec_cnt, const uint32_t* __restrict__ base,
+    int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
+    int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col) {
+  const uint64_t total = R * fanout;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+       t += stride) {
+    if (t < R) {
+      all_nodes[t] = roots[t];
+      all_ts[t] = root_ts[t];
+    }
+    const uint64_t r = t / fanout;
+    const uint32_t j = static_cast<uint32_t>(t - r * fanout);
+    if (j >= rec_cnt[r]) continue;
+    const int64_t* s = rep + (static_cast<uint64_t>(pos[r]) * fanout + j) * 3;
+    const uint64_t packed = static_cast<uint64_t>(s[2]);
+    const uint64_t o = static_cast<uint64_t>(base[r]) + j;
+    all_nodes[R + o] = s[0];
+    all_ts[R + o] = __uint_as_float(static_cast<uint32_t>(packed));
+    dt[o] = __uint_as_float(static_cast<uint32_t>(packed >> 32));
+    eids[o] = s[1];
+    row[o] = static_cast<int64_t>(r);
+    col[o] = static_cast<int64_t>(R + o);
+  }
+}
+
 inline unsigned capped_grid(uint64_t work_items, unsigned per_block, unsigned cap) {
   uint64_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -746,6 +845,95 @@ void Sampler::sample_layer(const int64_t* d_roots, const float* d_ts, size_t R, 
   block->eids = ptrs.eids;
   block->row = ptrs.row;
   block->col = ptrs.col;
+  block->num_dst_nodes = hc[0];
+  block->num_edges = hc[1];
+  block->num_src_nodes = hc[0] + hc[1];
+}
+
+// ---- partitioned sampling ------------------------------------------------------------
+void Sampler::sample_layer_padded(const int64_t* d_requests, size_t n, uint32_t layer,
+                                  uint32_t snapshot, int64_t* d_out, hipStream_t stream) {
+  GF_REQUIRE(layer < fanouts_.size(), "sample_layer_padded: layer out of range");
+  GF_REQUIRE(snapshot < num_snapshots_, "sample_layer_padded: snapshot out of range");
+  const uint64_t call = calls_++;
+  if (n == 0) return;
+  GF_REQUIRE(d_requests && d_out, "sample_layer_padded: null device pointer");
+  const uint32_t F = fanouts_[layer];
+  GF_REQUIRE(static_cast<uint64_t>(n) * F < 0xFFFFFFFFull,
+             "sampler: more than 2^32-1 slots in one layer");
+  DeviceGuard dg(graph_->device());
+  const GraphView gv = graph_->view();
+  const int uniform = policy_ == GF_SAMPLING_POLICY_UNIFORM;
+  const unsigned roots_per_wg = kSearchThreads / search_group_;
+  const unsigned grid = capped_grid(n, roots_per_wg, 256 * 8);
+  ProfileScope ps(kProfSearch, stream);
+  if (search_group_ == 64) {
+    sample_padded_kernel<64><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(
+        gv, d_requests, n, snapshot, num_snapshots_, window_, F, uniform, prop_time_ ? 1 : 0,
+        seed_, call, d_out);
+  } else {
+    sample_padded_kernel<16><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(
+        gv, d_requests, n, snapshot, num_snapshots_, window_, F, uniform, prop_time_ ? 1 : 0,
+        seed_, call, d_out);
+  }
+  GF_HIP(hipGetLastError());
+}
+
+void Sampler::merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, uint32_t layer,
+                           const int64_t* d_replies, const uint32_t* d_pos, void* d_out,
+                           size_t out_bytes, gf_block* block, hipStream_t stream) {
+  GF_REQUIRE(layer < fanouts_.size(), "merge_padded: layer out of range");
+  GF_REQUIRE(block != nullptr, "merge_padded: null block");
+  if (R == 0) {
+    std::memset(block, 0, sizeof(gf_block));
+    return;
+  }
+  GF_REQUIRE(d_roots && d_ts && d_replies && d_pos && d_out, "merge_padded: null device pointer");
+  GF_REQUIRE(out_bytes >= layer_output_bytes(R, layer), "merge_padded: output buffer too small");
+  const uint32_t F = fanouts_[layer];
+  GF_REQUIRE(static_cast<uint64_t>(R) * F < 0xFFFFFFFFull,
+             "sampler: more than 2^32-1 slots in one layer");
+  DeviceGuard dg(graph_->device());
+  reserve_workspace(R, 2, stream);
+  char* w = ws_.as<char>();
+  w += align_up(ws_roots_ * 8, 16);                                   // rec_end: unused here
+  uint32_t* rec_cnt = reinterpret_cast<uint32_t*>(w); w += align_up(ws_roots_ * 4, 16);
+  uint32_t* base = reinterpret_cast<uint32_t*>(w);    w += align_up(ws_roots_ * 4, 16);
+  uint32_t* tile_scratch = reinterpret_cast<uint32_t*>(w); w += align_up(ws_roots_ * 4, 16);
+  uint64_t* d_counts = reinterpret_cast<uint64_t*>(w);
+  BlockPtrs out = carve(static_cast<char*>(d_out), R, F);
+  merge_count_kernel<<<dim3(static_cast<unsigned>((R + 255) / 256)), dim3(256), 0, stream>>>(
+      d_replies, d_pos, R, F, rec_cnt);
+  if (R <= 65536) {
+    sample_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
+        rec_cnt, base, nullptr, R, F, 0, d_counts, d_counts + 1, nullptr);
+  } else {
+    const size_t tiles = (R + kScanTile - 1) / kScanTile;
+    uint32_t* tile_sum = tile_scratch;
+    uint32_t* tile_base = tile_scratch + tiles;
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>(tiles, 2048));
+    sample_tile_sum_kernel<<<dim3(grid), dim3(kScanThreads), 0, stream>>>(rec_cnt, nullptr, R, F,
+                                                                         0, tile_sum);
+    sample_tile_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
+        tile_sum, tile_base, nullptr, R, d_counts, d_counts + 1, nullptr);
+    sample_tile_apply_kernel<<<dim3(grid), dim3(kScanThreads), 0, stream>>>(
+        rec_cnt, tile_base, nullptr, R, F, 0, base);
+  }
+  merge_emit_kernel<<<dim3(capped_grid(static_cast<uint64_t>(R) * F, kEmitThreads, 256 * 16)),
+                      dim3(kEmitThreads), 0, stream>>>(
+      d_roots, d_ts, R, F, d_replies, d_pos, rec_cnt, base, out.all_nodes, out.all_ts, out.dt,
+      out.eids, out.row, out.col);
+  GF_HIP(hipGetLastError());
+  GF_HIP(hipMemcpyAsync(h_counts_.data(), d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                        stream));
+  GF_HIP(hipStreamSynchronize(stream));
+  const uint64_t* hc = h_counts_.as<uint64_t>();
+  block->all_nodes = out.all_nodes;
+  block->all_timestamps = out.all_ts;
+  block->delta_timestamps = out.dt;
+  block->eids = out.eids;
+  block->row = out.row;
+  block->col = out.col;
   block->num_dst_nodes = hc[0];
   block->num_edges = hc[1];
   block->num_src_nodes = hc[0] + hc[1];

@@ -33,6 +33,17 @@ class Sampler {
   void sample_layer(const int64_t* d_roots, const float* d_ts, size_t R, uint32_t layer,
                     uint32_t snapshot, void* d_out, size_t out_bytes, gf_block* block,
                     hipStream_t stream);
+  // ---- partitioned sampling: the owner's and the requester's halves -------
+  // Owner: samples n packed requests (root id, root-ts bits) on this shard into a FIXED
+  // `fanout` slots per root: d_out[n][fanout][3] int64 = (dst, eid, ts | dt << 32), unused
+  // slots -1.  The output size follows from n, so nothing is read back: no host sync.
+  void sample_layer_padded(const int64_t* d_requests, size_t n, uint32_t layer,
+                           uint32_t snapshot, int64_t* d_out, hipStream_t stream);
+  // Requester: turns the replies (rows in owner-sorted order, d_pos[i] = row of root i) into
+  // the layer's block in the ORIGINAL root order, laid out like sample_layer's output.
+  void merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, uint32_t layer,
+                    const int64_t* d_replies, const uint32_t* d_pos, void* d_out,
+                    size_t out_bytes, gf_block* block, hipStream_t stream);
   // host-vector forms (reference calling convention)
   void sample_host(const int64_t* nodes, const float* ts, size_t R, gf_block* blocks);
   void sample_layer_host(const int64_t* nodes, const float* ts, size_t R, uint32_t layer,

@@ -6,11 +6,14 @@ Here the partitions are the GPUs of one node and the exchange is two all-to-all-
 over RCCL/xGMI (`torch.distributed`, backend "nccl" on ROCm; "gloo" in the CPU tests):
 
     1. bucket this rank's roots by owner(root) = splitmix64(root) mod P
-    2. all-to-all-v of packed (root id, root ts)             16 B / root
-    3. every rank samples the roots it received on its own shard (local HIP sampler)
-    4. all-to-all-v back: a fixed `fanout` slots per root of (dst, eid, ts|dt), invalid slots
-       marked -1, so the reply sizes follow from the request sizes (no count exchange)
-    5. the requester restores the original root order and keeps the valid slots
+    2. all-to-all-v of packed (root id, root ts) to the OTHER ranks   16 B / root, asynchronous
+    3. meanwhile the rank samples its OWN share of the roots on its shard (local HIP sampler):
+       the remote pull of a layer overlaps that layer's local sample
+    4. every rank samples the roots it received; all-to-all-v back: a fixed `fanout` slots per
+       root of (dst, eid, ts|dt), invalid slots marked -1, so the reply sizes follow from the
+       request sizes (no count exchange)
+    5. the requester splices its own share back in, restores the original root order and
+       keeps the valid slots
 
 Step 5 restores the original root order, so for most-recent sampling the MFG is
 bit-identical to what a single GPU holding the whole graph returns (the reference's merge
@@ -128,11 +131,16 @@ class LayerResult:
     def edges(self): return self._col, self._row
 
 
-def _all_to_all_v(send: torch.Tensor, send_counts: List[int], recv_counts: List[int], group):
+def _all_to_all_v(send: torch.Tensor, send_counts: List[int], recv_counts: List[int], group,
+                  async_op: bool = False):
+    """all-to-all-v of rows; async_op=True returns (recv, work): the collective runs on the
+    backend's own stream / thread and `work.wait()` orders the caller behind it, so whatever
+    the caller enqueues in between overlaps the exchange."""
     recv = send.new_empty((sum(recv_counts),) + tuple(send.shape[1:]))
-    dist.all_to_all_single(recv, send, output_split_sizes=recv_counts,
-                           input_split_sizes=send_counts, group=group)
-    return recv
+    work = dist.all_to_all_single(recv, send, output_split_sizes=recv_counts,
+                                  input_split_sizes=send_counts, group=group,
+                                  async_op=async_op)
+    return (recv, work) if async_op else recv
 
 
 def _pack_f32_pair(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -168,9 +176,29 @@ class PartitionedSampler:
         self._rank = dist.get_rank(group)
         self._device = device or torch.device("cpu")
 
+    def _sample_padded(self, nodes: torch.Tensor, ts: torch.Tensor, layer: int,
+                       snapshot: int) -> torch.Tensor:
+        """Samples `nodes` on the local shard and lays the result out as a FIXED `fanout`
+        slots per root: [n, F, 3] int64 = (dst, eid, packed(ts, dt)), unused slots -1."""
+        dev, F = self._device, self._fanouts[layer]
+        n = int(nodes.shape[0])
+        pad = torch.full((n, F, 3), -1, dtype=torch.int64, device=dev)
+        if n == 0:
+            return pad
+        blk = self._local(nodes, ts, layer, snapshot)
+        counts, dst, eid, ts_out, dt = _block_arrays(blk, dev)
+        if dst.shape[0]:
+            row_l = torch.repeat_interleave(torch.arange(n, device=dev), counts)
+            base_l = torch.cumsum(counts, 0) - counts
+            pos = torch.arange(dst.shape[0], device=dev) - base_l[row_l]
+            pad[row_l, pos, 0] = dst
+            pad[row_l, pos, 1] = eid
+            pad[row_l, pos, 2] = _pack_f32_pair(ts_out, dt)
+        return pad
+
     def sample_layer(self, nodes: torch.Tensor, ts: torch.Tensor, layer: int,
                      snapshot: int) -> LayerResult:
-        dev, P, F = self._device, self._P, self._fanouts[layer]
+        dev, P, F, me = self._device, self._P, self._fanouts[layer], self._rank
         nodes = nodes.to(dev, torch.int64)
         ts = ts.to(dev, torch.float32)
         R = int(nodes.shape[0])
@@ -178,28 +206,40 @@ class PartitionedSampler:
         dest = owner_of(nodes, P)
         order = torch.argsort(dest, stable=True)
         send_counts = torch.bincount(dest, minlength=P)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self._group)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()
-        # 2. requests: [n, 2] int64 = (root id, root ts bits)
-        req = torch.stack([nodes[order], _pack_f32_pair(ts[order], torch.zeros_like(ts))], dim=1)
-        got = _all_to_all_v(req, sc, rc, self._group)
-        got_nodes = got[:, 0].contiguous()
-        got_ts, _ = _unpack_f32_pair(got[:, 1])
-        Rr = int(got_nodes.shape[0])
-        # 3. local sample of everything this rank owns, re-laid out as F fixed slots per root
-        blk = self._local(got_nodes, got_ts, layer, snapshot)
-        counts, dst, eid, ts_out, dt = _block_arrays(blk, dev)
-        pad = torch.full((Rr, F, 3), -1, dtype=torch.int64, device=dev)
-        if dst.shape[0]:
-            row_l = torch.repeat_interleave(torch.arange(Rr, device=dev), counts)
-            base_l = torch.cumsum(counts, 0) - counts
-            pos = torch.arange(dst.shape[0], device=dev) - base_l[row_l]
-            pad[row_l, pos, 0] = dst
-            pad[row_l, pos, 1] = eid
-            pad[row_l, pos, 2] = _pack_f32_pair(ts_out, dt)
-        # 4. replies: F*3 words per requested root, same splits as the requests (reversed)
-        rep = _all_to_all_v(pad.reshape(Rr, F * 3), rc, sc, self._group).reshape(R, F, 3)
+        if P > 1:
+            recv_counts = torch.empty_like(send_counts)
+            dist.all_to_all_single(recv_counts, send_counts, group=self._group)
+            sc, rc = send_counts.tolist(), recv_counts.tolist()
+        else:
+            sc = rc = [R]
+        nodes_o, ts_o = nodes[order], ts[order]
+        lo = sum(sc[:me])
+        hi = lo + sc[me]            # [lo, hi) of the owner-sorted roots are this rank's own
+        # 2. requests to the OTHER ranks only: [n, 2] int64 = (root id, root ts bits).  The
+        #    exchange is started asynchronously ...
+        sc_net, rc_net = list(sc), list(rc)
+        sc_net[me] = rc_net[me] = 0
+        pending = None
+        if P > 1:
+            away_nodes = torch.cat([nodes_o[:lo], nodes_o[hi:]])
+            away_ts = torch.cat([ts_o[:lo], ts_o[hi:]])
+            req = torch.stack([away_nodes, _pack_f32_pair(away_ts, torch.zeros_like(away_ts))],
+                              dim=1)
+            pending = _all_to_all_v(req, sc_net, rc_net, self._group, async_op=True)
+        # 3. ... and overlaps with sampling this rank's own share on its shard
+        own_pad = self._sample_padded(nodes_o[lo:hi], ts_o[lo:hi], layer, snapshot)
+        if pending is not None:
+            got, work = pending
+            work.wait()
+            got_ts, _ = _unpack_f32_pair(got[:, 1])
+            # 4. sample what the other ranks asked for; replies: F*3 words per requested
+            #    root, same splits as the requests (reversed), so no second count exchange
+            remote_pad = self._sample_padded(got[:, 0].contiguous(), got_ts, layer, snapshot)
+            rep_net = _all_to_all_v(remote_pad.reshape(-1, F * 3), rc_net, sc_net,
+                                    self._group).reshape(R - (hi - lo), F, 3)
+            rep = torch.cat([rep_net[:lo], own_pad, rep_net[lo:]])
+        else:
+            rep = own_pad
         # 5. back to the ORIGINAL root order, then keep the valid slots (root-major order)
         inv = torch.empty_like(order)
         inv[order] = torch.arange(R, device=dev)
@@ -221,6 +261,125 @@ class PartitionedSampler:
         if not isinstance(ts, torch.Tensor):
             ts = torch.from_numpy(np.ascontiguousarray(ts, dtype=np.float32))
         results: List[List[LayerResult]] = []
+        for layer in range(self._L):
+            cur = []
+            for s in range(self._S):
+                if layer == 0:
+                    n, t = nodes, ts
+                else:
+                    prev = results[-1][s]
+                    n, t = prev.srcdata["ID"], prev.srcdata["ts"]
+                cur.append(self.sample_layer(n, t, layer, s))
+            results.append(cur)
+        results.reverse()
+        return results
+
+
+# ---- the same exchange on the native entry points (device-resident, HIP kernels) ---------
+def _backend_is_host_only(group) -> bool:
+    return dist.get_backend(group) == "gloo"
+
+
+def _exchange(out: torch.Tensor, send: torch.Tensor, out_splits, in_splits, group, async_op=False):
+    """all_to_all_single(out, send) for HBM tensors.  Over RCCL ("nccl") the device buffers go
+    straight in and async_op lets the caller overlap kernels with the transfer; a host-only
+    backend (gloo: CPU tests, several ranks sharing one GPU) is staged through host memory."""
+    if send.is_cuda and _backend_is_host_only(group):
+        recv_cpu = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(recv_cpu, send.cpu(), output_split_sizes=out_splits,
+                               input_split_sizes=in_splits, group=group)
+        out.copy_(recv_cpu)
+        return None
+    return dist.all_to_all_single(out, send, output_split_sizes=out_splits,
+                                  input_split_sizes=in_splits, group=group, async_op=async_op)
+
+
+class DevicePartitionedSampler:
+    """PartitionedSampler whose per-rank work is native: `gf_partition_plan` buckets the roots,
+    `gf_sampler_sample_layer_padded` serves this rank's own share (while the request
+    all-to-all-v is in flight) and the requests it receives, `gf_sampler_merge_padded` builds
+    the block.  Returns `gnnflow_amd.MFGBlock`s in HBM exactly like
+    `TemporalSampler.sample()` — for most-recent sampling bit-identical to one GPU holding the
+    whole graph — so `Cache.fetch_feature` takes them unchanged.
+
+    sampler: a gnnflow_amd.TemporalSampler over THIS rank's shard (edges whose source it
+    owns, see PartitionedGraph)."""
+
+    def __init__(self, sampler, group=None):
+        import ctypes as C
+        from . import _capi
+        self._C, self._capi = C, _capi
+        self._lib = _capi.load()
+        self._sampler = sampler
+        self._group = group
+        self._P = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._device = sampler._device
+        self._fanouts = list(sampler._fanouts)
+        self._L, self._S = sampler._num_layers, sampler._num_snapshots
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def _padded(self, req: torch.Tensor, n: int, layer: int, snapshot: int, out: torch.Tensor):
+        self._capi.check(self._lib.gf_sampler_sample_layer_padded(
+            self._sampler._h, req.data_ptr() if n else None, n, layer, snapshot,
+            out.data_ptr() if n else None, self._stream()))
+
+    def sample_layer(self, nodes: torch.Tensor, ts: torch.Tensor, layer: int, snapshot: int):
+        C, lib, check = self._C, self._lib, self._capi.check
+        dev, P, me, F = self._device, self._P, self._rank, self._fanouts[layer]
+        nodes = nodes.to(dev, torch.int64).contiguous()
+        ts = ts.to(dev, torch.float32).contiguous()
+        R = int(nodes.shape[0])
+        if R == 0:
+            return self._sampler._empty_block()
+        with torch.cuda.device(dev):
+            # 1. bucket by owner: requests ordered [other owners ascending | own share]
+            need = C.c_size_t(0)
+            check(lib.gf_partition_scratch_bytes(R, P, C.byref(need)))
+            scratch = torch.empty(need.value, dtype=torch.uint8, device=dev)
+            req = torch.empty((R, 2), dtype=torch.int64, device=dev)
+            pos = torch.empty(R, dtype=torch.int32, device=dev)
+            counts = torch.empty(P, dtype=torch.int64, device=dev)
+            check(lib.gf_partition_plan(nodes.data_ptr(), ts.data_ptr(), R, P, me, req.data_ptr(),
+                                        pos.data_ptr(), counts.data_ptr(), scratch.data_ptr(),
+                                        need.value, dev.index, self._stream()))
+            rep = torch.empty((R, F, 3), dtype=torch.int64, device=dev)
+            if P > 1:
+                recv_counts = torch.empty_like(counts)
+                _exchange(recv_counts, counts, None, None, self._group)
+                sc, rc = counts.tolist(), recv_counts.tolist()
+                n_own = sc[me]
+                n_net = R - n_own
+                sc[me] = rc[me] = 0
+                # 2. requests to the other ranks, asynchronously ...
+                got = torch.empty((sum(rc), 2), dtype=torch.int64, device=dev)
+                work = _exchange(got, req[:n_net], rc, sc, self._group, async_op=True)
+                # 3. ... overlapped with this rank's own share on its shard
+                self._padded(req[n_net:], n_own, layer, snapshot, rep[n_net:])
+                if work is not None:
+                    work.wait()
+                # 4. serve the received requests; replies land in the prefix of `rep`
+                served = torch.empty((got.shape[0], F, 3), dtype=torch.int64, device=dev)
+                self._padded(got, int(got.shape[0]), layer, snapshot, served)
+                _exchange(rep[:n_net].view(n_net, F * 3), served.view(-1, F * 3), sc, rc,
+                          self._group)
+            else:
+                self._padded(req, R, layer, snapshot, rep)
+            # 5. replies -> block in the original root order
+            nbytes = C.c_size_t(0)
+            check(lib.gf_sampler_layer_output_bytes(self._sampler._h, R, layer, C.byref(nbytes)))
+            buf = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            gb = self._capi.GfBlock()
+            check(lib.gf_sampler_merge_padded(
+                self._sampler._h, nodes.data_ptr(), ts.data_ptr(), R, layer, rep.data_ptr(),
+                pos.data_ptr(), buf.data_ptr(), nbytes.value, C.byref(gb), self._stream()))
+        return self._sampler._block(buf, gb)
+
+    def sample(self, nodes, ts):
+        nodes, ts = self._sampler._to_device(nodes, ts)
+        results = []
         for layer in range(self._L):
             cur = []
             for s in range(self._S):

@@ -282,6 +282,34 @@ GF_API int gf_memory_update(float* d_node_memory, float* d_node_memory_ts, float
 GF_API int gf_cache_slot_ids(const gf_cache* c, int64_t* out, size_t capacity);
 GF_API int gf_cache_mem_bytes(const gf_cache* c, size_t* out);
 
+/* ---- hash-partitioned sampling across the GPUs of a node ---------- */
+/* The reference buckets a layer's roots by partition on the host and samples remote ones over
+ * RPC (gnnflow/distributed/dist_sampler.py:159-314).  Here each rank runs, per layer:
+ *   gf_partition_plan            bucket the roots by owner(v) = splitmix64(v) mod world_size
+ *   (all-to-all-v of the request prefix — the caller's torch.distributed / RCCL call)
+ *   gf_sampler_sample_layer_padded   on its own share (overlapping the exchange) and on the
+ *                                    requests it received: fixed `fanout` slots per root
+ *   (all-to-all-v of the replies)
+ *   gf_sampler_merge_padded      replies -> the layer's block in the original root order,
+ *                                bit-identical to single-GPU sampling (most-recent policy).
+ * d_requests [n][2] int64 = (root id, root-ts bits in the low word), ordered
+ * [other owners ascending | this rank]; d_pos[i] = row of root i; d_counts[world_size] device
+ * words.  Replies [n][fanout][3] int64 = (dst, eid, ts | dt << 32), unused slots -1. */
+GF_API int gf_partition_scratch_bytes(size_t num_roots, int world_size, size_t* out);
+GF_API int gf_partition_plan(const int64_t* d_nodes, const float* d_ts, size_t num_roots,
+                             int world_size, int rank, int64_t* d_requests, uint32_t* d_pos,
+                             uint64_t* d_counts, void* d_scratch, size_t scratch_bytes,
+                             int device, void* stream);
+GF_API int gf_sampler_sample_layer_padded(gf_sampler* s, const int64_t* d_requests, size_t n,
+                                          uint32_t layer, uint32_t snapshot, int64_t* d_out,
+                                          void* stream);
+/* d_out / out_bytes / block as gf_sampler_sample_layer (gf_sampler_layer_output_bytes);
+ * synchronises `stream` once to read the edge count. */
+GF_API int gf_sampler_merge_padded(gf_sampler* s, const int64_t* d_roots, const float* d_ts,
+                                   size_t n, uint32_t layer, const int64_t* d_replies,
+                                   const uint32_t* d_pos, void* d_out, size_t out_bytes,
+                                   gf_block* block, void* stream);
+
 /* ---- message passing on a sampled block ---------------------- */
 /* The DGL calls of the reference's layers on an MFG (gnnflow/models/modules/layers.py:153-159,
  * models/graphsage.py:27-31, models/gat.py:28-46), as segment operations: a block's edges are

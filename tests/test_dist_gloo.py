@@ -93,6 +93,56 @@ def test_partitioned_sampler_matches_single_graph(cfg):
     assert dict(ret) == {0: True, 1: True}
 
 
+def test_partitioned_sampler_three_ranks_own_share_in_the_middle():
+    """world_size 3: on rank 1 the rank's own share sits in the MIDDLE of the owner-sorted
+    roots, so the splice of locally sampled and remotely pulled replies is exercised on
+    both sides (the own share never travels; the request exchange overlaps its sampling)."""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), CFGS[0], ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True, 2: True}
+
+
+def _single_rank_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnnflow_amd import dist as D
+        calls = []
+        orig = dist.all_to_all_single
+
+        def counting(*a, **k):
+            calls.append(1)
+            return orig(*a, **k)
+        dist.all_to_all_single = counting
+        from oracle import oracle as O
+        from tests import synth
+        src, dst, ts, eid = synth.powerlaw_graph(100, 2000, seed=1, tie_levels=50)
+        g = O.OracleGraph(minimum_block_size=8)
+        g.add_edges(src, dst, ts, eid)
+        s = O.OracleSampler(g, [3, 3], "recent")
+        ps = D.PartitionedSampler(
+            lambda n, t, layer, snap: s.sample_layer(n.numpy(), t.numpy(), layer, snap), [3, 3])
+        nodes, t = synth.random_roots(100, 50, 1000.0, seed=2)
+        got, want = ps.sample(nodes, t), s.sample(nodes, t)
+        same = all(np.array_equal(a.srcdata["ID"].numpy(), b.srcdata["ID"]) and
+                   np.array_equal(a.edata["ID"].numpy(), b.edata["ID"])
+                   for gl, wl in zip(got, want) for a, b in zip(gl, wl))
+        ret[rank] = (same, len(calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_partition_needs_no_collective():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_single_rank_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret[0] == (True, 0)
+
+
 def test_owner_hash_matches_between_torch_and_numpy():
     from gnnflow_amd.dist import owner_of, owner_of_np
     ids = np.concatenate([np.arange(0, 5000), np.random.RandomState(0).randint(0, 2**62, 5000)])

@@ -1,0 +1,136 @@
+"""GPU: native hash-partitioned sampling (gf_partition_plan, gf_sampler_sample_layer_padded,
+gf_sampler_merge_padded through gnnflow_amd.dist.DevicePartitionedSampler).
+  * one rank: the plan / padded / merge chain alone must reproduce TemporalSampler.sample()
+    bit for bit (all roots are the rank's own);
+  * the bucketing kernel against numpy for several world sizes and ranks (stable order,
+    "[other owners ascending | own]" layout, counts);
+  * two processes sharing the one GPU, exchanging through gloo (staged via host memory):
+    every rank's MFGs equal the CPU oracle over the whole graph."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _graph(seed=5, N=400, E=12000):
+    from tests import synth
+    return synth.powerlaw_graph(N, E, seed=seed, tie_levels=500)
+
+
+@pytest.mark.parametrize("P,rank", [(1, 0), (2, 0), (2, 1), (3, 1), (8, 5), (64, 63)])
+@pytest.mark.parametrize("R", [1, 255, 256, 257, 5000, 70000])
+def test_partition_plan_matches_numpy(P, rank, R):
+    import torch
+    from gnnflow_amd import _capi
+    from gnnflow_amd.dist import owner_of_np
+    lib = _capi.load()
+    rng = np.random.RandomState(R + P)
+    nodes = rng.randint(0, 1 << 40, R).astype(np.int64)
+    ts = rng.rand(R).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    dn, dt = torch.from_numpy(nodes).to(dev), torch.from_numpy(ts).to(dev)
+    need = C.c_size_t(0)
+    _capi.check(lib.gf_partition_scratch_bytes(R, P, C.byref(need)))
+    scratch = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    req = torch.empty((R, 2), dtype=torch.int64, device=dev)
+    pos = torch.empty(R, dtype=torch.int32, device=dev)
+    counts = torch.empty(P, dtype=torch.int64, device=dev)
+    _capi.check(lib.gf_partition_plan(dn.data_ptr(), dt.data_ptr(), R, P, rank, req.data_ptr(),
+                                      pos.data_ptr(), counts.data_ptr(), scratch.data_ptr(),
+                                      need.value, 0, None))
+    owner = owner_of_np(nodes, P)
+    key = np.where(owner == rank, P, owner)          # own share goes last
+    order = np.argsort(key, kind="stable")
+    want_pos = np.empty(R, np.int64)
+    want_pos[order] = np.arange(R)
+    assert np.array_equal(pos.cpu().numpy().astype(np.int64), want_pos)
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(owner, minlength=P))
+    got = req.cpu().numpy()
+    assert np.array_equal(got[:, 0], nodes[order])
+    assert np.array_equal(got[:, 1].astype(np.uint64).astype(np.uint32).view(np.float32), ts[order])
+
+
+@pytest.mark.parametrize("strategy,snapshots,window,prop_time",
+                         [("recent", 1, 0.0, False), ("recent", 2, 60.0, True)])
+def test_single_rank_chain_equals_plain_sampler(strategy, snapshots, window, prop_time):
+    import torch
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from gnnflow_amd.dist import DevicePartitionedSampler
+    from tests import synth
+    src, dst, ts, eid = _graph()
+    g = DynamicGraph(1 << 20, 64 << 20, "cuda", 8, 64, "insert")
+    g.add_edges(src, dst, ts, eid, add_reverse=True)
+    kw = dict(fanouts=[7, 5], sample_strategy=strategy, num_snapshots=snapshots,
+              snapshot_time_window=window, prop_time=prop_time)
+    plain = TemporalSampler(g, **kw)
+    part = DevicePartitionedSampler(TemporalSampler(g, **kw))
+    for it, R in enumerate([1, 97, 600, 3000]):
+        nodes, t = synth.random_roots(400, R, 1000.0, seed=it, extra_ids=[403])
+        got, want = part.sample(nodes, t), plain.sample(nodes, t)
+        for gl, wl in zip(got, want):
+            for gb, wb in zip(gl, wl):
+                assert gb.num_dst_nodes() == wb.num_dst_nodes()
+                for a, b in ((gb.srcdata["ID"], wb.srcdata["ID"]), (gb.srcdata["ts"], wb.srcdata["ts"]),
+                             (gb.edata["ID"], wb.edata["ID"]), (gb.edata["dt"], wb.edata["dt"]),
+                             (gb.edges()[0], wb.edges()[0]), (gb.edges()[1], wb.edges()[1])):
+                    assert torch.equal(a, b)
+    assert part.sample(np.zeros(0, np.int64), np.zeros(0, np.float32))[0][0].num_edges() == 0
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnnflow_amd import DynamicGraph, TemporalSampler
+        from gnnflow_amd.dist import DevicePartitionedSampler, PartitionedGraph
+        from oracle import oracle as O
+        from tests import synth
+        src, dst, ts, eid = _graph()
+        full = O.OracleGraph(minimum_block_size=8)
+        shard = DynamicGraph(1 << 20, 64 << 20, "cuda", 8, 64, "insert")
+        pg = PartitionedGraph(shard, rank, world)
+        for lo in range(0, len(src), 2500):
+            sl = slice(lo, lo + 2500)
+            full.add_edges(src[sl], dst[sl], ts[sl], eid[sl], add_reverse=True)
+            pg.add_edges(src[sl], dst[sl], ts[sl], eid[sl], add_reverse=True)
+        ref = O.OracleSampler(full, [6, 4], "recent")
+        part = DevicePartitionedSampler(TemporalSampler(shard, [6, 4], "recent"))
+        ok = True
+        for it, R in enumerate([0, 1, 97, 600, 2000]):
+            nodes, t = synth.random_roots(400, R, 1000.0, seed=1000 * rank + it, extra_ids=[403])
+            got, want = part.sample(nodes, t), ref.sample(nodes, t)
+            for gl, wl in zip(got, want):
+                for gb, wb in zip(gl, wl):
+                    ok &= np.array_equal(gb.srcdata["ID"].cpu().numpy(), wb.srcdata["ID"])
+                    ok &= np.array_equal(gb.srcdata["ts"].cpu().numpy(), wb.srcdata["ts"])
+                    ok &= np.array_equal(gb.edata["ID"].cpu().numpy(), wb.edata["ID"])
+                    ok &= np.array_equal(gb.edata["dt"].cpu().numpy().view(np.uint8),
+                                         np.asarray(wb.edata["dt"]).view(np.uint8))
+                    ok &= np.array_equal(gb.edges()[0].cpu().numpy(), wb.edges()[0])
+                    ok &= np.array_equal(gb.edges()[1].cpu().numpy(), wb.edges()[1])
+        torch.cuda.synchronize()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_match_the_oracle(world):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
