@@ -4,16 +4,43 @@
 #include "edge_store.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <numeric>
+#include <thread>
 
 namespace gf {
 
 namespace {
 
 constexpr size_t kBlockSpace = 20;       // common.h:23-24 bytes per edge
+// fn(begin, end) over [0, n) on up to 8 host threads; chunks of at least `grain` items, inline
+// when one chunk covers everything.  Ingest is host-bound (gathers through a permutation), so
+// the threads are what the 10^7-edge chunks of a graph build spend their time in.
+template <typename F>
+void parallel_for(size_t n, size_t grain, F&& fn) {
+  static const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  const size_t parts = std::min<size_t>(hw, (n + grain - 1) / std::max<size_t>(grain, 1));
+  if (parts <= 1) { fn(size_t(0), n); return; }
+  std::vector<std::thread> th;
+  std::exception_ptr err;
+  std::mutex mu;
+  const size_t step = (n + parts - 1) / parts;
+  for (size_t p = 0; p < parts; ++p) {
+    const size_t a = p * step, b = std::min(n, a + step);
+    if (a >= b) break;
+    th.emplace_back([&, a, b] {
+      try { fn(a, b); } catch (...) { std::lock_guard<std::mutex> lk(mu); err = std::current_exception(); }
+    });
+  }
+  for (auto& t : th) t.join();
+  if (err) std::rethrow_exception(err);
+}
+
 constexpr size_t kIngestChunk = 1 << 23; // edges per staging upload
 
 inline uint64_t pow2_ceil(uint64_t n) {
@@ -240,6 +267,46 @@ LogicalBlock EdgeStore::new_block(size_t size) {
 
 // dynamic_graph.cu:206-287 AddEdgesForOneNode + utils.cu:33-63 CopyEdgesToBlock,
 // replayed on block headers only (the bytes live in the node's flat segment).
+// bump_eid for a whole batch: one growth decision for the dense counters (from the batch's
+// largest id) instead of a check per edge; ids they do not cover (negative, or far beyond
+// what has been inserted) go through the sparse map.
+void EdgeStore::bump_eids(const int64_t* eids, size_t n) {
+  int64_t mx = -1;
+  {
+    std::mutex mu;
+    parallel_for(n, 1 << 16, [&](size_t i0, size_t i1) {
+      int64_t m = -1;
+      for (size_t i = i0; i < i1; ++i) m = std::max(m, eids[i]);
+      std::lock_guard<std::mutex> lk(mu);
+      mx = std::max(mx, m);
+    });
+  }
+  const uint64_t budget = 64 + 8 * (eids_inserted_ + n);   // dense only while reasonably full
+  if (mx >= 0 && static_cast<uint64_t>(mx) >= eid_dense_.size() &&
+      static_cast<uint64_t>(mx) < budget) {
+    const size_t nsz = static_cast<size_t>(mx) + 1;
+    eid_dense_.resize(nsz, 0);
+    for (auto it = eid_sparse_.begin(); it != eid_sparse_.end();) {   // keep "eid <
+      if (it->first >= 0 && static_cast<uint64_t>(it->first) < nsz) {  // dense.size() =>
+        eid_dense_[it->first] += static_cast<uint32_t>(it->second);    // counted densely"
+        it = eid_sparse_.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  const uint64_t dense = eid_dense_.size();
+  for (size_t i = 0; i < n; ++i) {
+    const int64_t e = eids[i];
+    if (e >= 0 && static_cast<uint64_t>(e) < dense) {
+      if (eid_dense_[e]++ == 0) num_live_eids_++;
+    } else if (eid_sparse_[e]++ == 0) {
+      num_live_eids_++;
+    }
+  }
+  eids_inserted_ += n;
+}
+
 void EdgeStore::simulate_blocks(NodeState& st, const float* ts, size_t n) {
   auto copy_to = [&](LogicalBlock& b, size_t start_idx, size_t cnt) {
     b.size += cnt;
@@ -302,11 +369,40 @@ void EdgeStore::upload_entries(const std::vector<int64_t>& ids) {
 }
 
 // ---- ingest: DynamicGraph::AddEdges, dynamic_graph.cu:77-138 -------------------
+namespace {
+// GNNFLOW_INGEST_PROFILE=1: per-phase host time of add_edges on stderr
+struct PhaseTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  const char* names[8];
+  double us[8];
+  int k = 0;
+  PhaseTimer() : on(std::getenv("GNNFLOW_INGEST_PROFILE") != nullptr),
+                 t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* name) {
+    if (!on || k >= 8) return;
+    auto t1 = std::chrono::steady_clock::now();
+    names[k] = name;
+    us[k++] = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    t0 = t1;
+  }
+  void report(size_t n) {
+    if (!on) return;
+    double tot = 0;
+    for (int i = 0; i < k; ++i) tot += us[i];
+    std::fprintf(stderr, "add_edges n=%zu %.1f ms (%.1f M edges/s):", n, tot / 1e3, n / tot);
+    for (int i = 0; i < k; ++i) std::fprintf(stderr, " %s %.1f", names[i], us[i] / 1e3);
+    std::fprintf(stderr, "\n");
+  }
+};
+}  // namespace
+
 void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* ts,
                           const int64_t* eids, size_t n) {
   GF_REQUIRE(n > 0, "add_edges: empty batch (reference: CHECK_GT(src_nodes.size(), 0))");
   GF_REQUIRE(src && dst && ts && eids, "add_edges: null array");
   DeviceGuard dg(device_);
+  PhaseTimer pt;
 
   int64_t max_node = 0;
   for (size_t i = 0; i < n; ++i) {
@@ -314,61 +410,88 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     max_node = std::max(max_node, std::max(src[i], dst[i]));
   }
 
+  pt.mark("scan");
   // 1. order by (source, timestamp, input position): the reference groups by
   //    source in input order and stable-sorts each group by timestamp
-  //    (dynamic_graph.cu:105-128, utils.h:16-27).
-  std::vector<size_t> perm(n);
+  //    (dynamic_graph.cu:105-128, utils.h:16-27).  `perm` is that order, `s_ts` the
+  //    timestamps in it (gathered once, by several threads, so that everything after this
+  //    reads them sequentially), `groups` the runs of equal source.
+  GF_REQUIRE(n < 0xFFFFFFFFull, "add_edges: more than 2^32-1 edges in one call");
+  struct Group { int64_t v; size_t begin, end; };
+  std::vector<uint32_t> perm(n);
+  std::vector<float> s_ts(n);
+  std::vector<Group> groups;
   {
-    size_t table_len = static_cast<size_t>(max_node) + 1;
+    const size_t table_len = static_cast<size_t>(max_node) + 1;
     if (table_len <= 4 * n + (1u << 16)) {
-      // counting sort by source (stable), then fix up unsorted groups by time
-      std::vector<size_t> head(table_len + 1, 0);
+      // counting sort by source (stable), then fix up unsorted groups by time.  (Splitting
+      // the two passes over threads by source range or with atomics measured slower than this
+      // plain loop: 72 ms vs 95-125 ms per 10^7 edges.)
+      std::vector<uint32_t> head(table_len + 1, 0);
       for (size_t i = 0; i < n; ++i) head[src[i] + 1]++;
       for (size_t v = 0; v < table_len; ++v) head[v + 1] += head[v];
-      std::vector<size_t> cur(head.begin(), head.end() - 1);
-      for (size_t i = 0; i < n; ++i) perm[cur[src[i]]++] = i;
-      for (size_t v = 0; v < table_len; ++v) {
-        size_t a = head[v], b = head[v + 1];
-        if (b - a < 2) continue;
-        bool sorted = true;
-        for (size_t k = a + 1; k < b && sorted; ++k) sorted = !(ts[perm[k]] < ts[perm[k - 1]]);
-        if (!sorted)
-          std::stable_sort(perm.begin() + a, perm.begin() + b,
-                           [&](size_t x, size_t y) { return ts[x] < ts[y]; });
+      {
+        std::vector<uint32_t> cur(head.begin(), head.end() - 1);
+        for (size_t i = 0; i < n; ++i) perm[cur[src[i]]++] = static_cast<uint32_t>(i);
       }
+      parallel_for(table_len, 1 << 14, [&](size_t v0, size_t v1) {
+        for (size_t v = v0; v < v1; ++v) {
+          const size_t a = head[v], b = head[v + 1];
+          bool sorted = true;
+          for (size_t k = a; k < b; ++k) {
+            s_ts[k] = ts[perm[k]];
+            if (k > a && s_ts[k] < s_ts[k - 1]) sorted = false;
+          }
+          if (!sorted) {
+            std::stable_sort(perm.begin() + a, perm.begin() + b,
+                             [&](uint32_t x, uint32_t y) { return ts[x] < ts[y]; });
+            for (size_t k = a; k < b; ++k) s_ts[k] = ts[perm[k]];
+          }
+        }
+      });
+      for (size_t v = 0; v < table_len; ++v)
+        if (head[v + 1] > head[v]) groups.push_back({static_cast<int64_t>(v), head[v], head[v + 1]});
     } else {
-      std::iota(perm.begin(), perm.end(), 0);
-      std::sort(perm.begin(), perm.end(), [&](size_t x, size_t y) {
+      std::iota(perm.begin(), perm.end(), 0u);
+      std::sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) {
         if (src[x] != src[y]) return src[x] < src[y];
         if (ts[x] < ts[y]) return true;
         if (ts[y] < ts[x]) return false;
         return x < y;
       });
+      parallel_for(n, 1 << 16, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) s_ts[k] = ts[perm[k]];
+      });
+      for (size_t i = 0; i < n;) {
+        const int64_t v = src[perm[i]];
+        size_t j = i;
+        while (j < n && src[perm[j]] == v) ++j;
+        groups.push_back({v, i, j});
+        i = j;
+      }
     }
   }
 
+  pt.mark("sort");
   // 2. validate before mutating anything: a group's oldest new edge must not be
   //    older than the node's newest stored edge (reference: CHECK_LE ->
   //    abort, utils.cu:42-43; the docstring promises ValueError,
   //    gnnflow/dynamic_graph.py:99-101).
-  for (size_t i = 0; i < n;) {
-    int64_t v = src[perm[i]];
-    size_t j = i;
-    while (j < n && src[perm[j]] == v) ++j;
-    if (static_cast<size_t>(v) < nodes_.size()) {
-      const NodeState& st = nodes_[v];
-      if (ts[perm[i]] < st.last_ts) {
+  for (const Group& gr : groups) {
+    if (static_cast<size_t>(gr.v) < nodes_.size()) {
+      const NodeState& st = nodes_[gr.v];
+      if (s_ts[gr.begin] < st.last_ts) {
         throw Error(GF_ERR_TIMESTAMP_ORDER,
-                    "add_edges: vertex " + std::to_string(v) + " got an edge at t=" +
-                        std::to_string(ts[perm[i]]) + " older than its newest stored edge t=" +
+                    "add_edges: vertex " + std::to_string(gr.v) + " got an edge at t=" +
+                        std::to_string(s_ts[gr.begin]) + " older than its newest stored edge t=" +
                         std::to_string(st.last_ts));
       }
-      GF_REQUIRE(st.live_size + (j - i) < 0xFFFFFFFFull,
+      GF_REQUIRE(st.live_size + (gr.end - gr.begin) < 0xFFFFFFFFull,
                  "add_edges: more than 2^32-1 live edges on one vertex");
     }
-    i = j;
   }
 
+  pt.mark("validate");
   // 3. bookkeeping sets (dynamic_graph.cu:89-103)
   add_nodes(max_node);
   for (size_t i = 0; i < n; ++i) {
@@ -377,25 +500,21 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     if (!(s & 2)) { s |= 2; num_src_nodes_++; }
     uint8_t& d = seen_[dst[i]];
     if (!(d & 1)) { d |= 1; num_nodes_++; }
-    bump_eid(eids[i]);
   }
+  bump_eids(eids, n);
 
-  // 4. plan: logical blocks, physical segments, per-edge destinations
+  pt.mark("sets");
+  // 4. plan: logical blocks, physical segments, per-group destinations
   std::vector<uint64_t> dest(n);
   std::vector<Move> moves;
   std::vector<std::pair<uint64_t, uint64_t>> deferred_free;
   std::vector<int64_t> touched;
-  std::vector<float> group_ts;
+  touched.reserve(groups.size());
   const uint64_t min_phys = pow2_ceil(std::max<size_t>(minimum_block_size_, 1));
-  for (size_t i = 0; i < n;) {
-    int64_t v = src[perm[i]];
-    size_t j = i;
-    while (j < n && src[perm[j]] == v) ++j;
-    size_t cnt = j - i;
-    NodeState& st = nodes_[v];
-    group_ts.resize(cnt);
-    for (size_t k = 0; k < cnt; ++k) group_ts[k] = ts[perm[i + k]];
-    simulate_blocks(st, group_ts.data(), cnt);
+  for (const Group& gr : groups) {
+    const size_t cnt = gr.end - gr.begin;
+    NodeState& st = nodes_[gr.v];
+    simulate_blocks(st, s_ts.data() + gr.begin, cnt);
 
     uint64_t need = st.live_size + cnt;
     if (st.seg_cap == 0) {
@@ -412,14 +531,14 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
       st.live_off = 0;
     }
     uint64_t base = st.seg_start + st.live_off + st.live_size;
-    for (size_t k = 0; k < cnt; ++k) dest[i + k] = base + k;
+    for (size_t k = 0; k < cnt; ++k) dest[gr.begin + k] = base + k;
     st.live_size = need;
-    st.last_ts = group_ts[cnt - 1];
-    touched.push_back(v);
-    i = j;
+    st.last_ts = s_ts[gr.end - 1];
+    touched.push_back(gr.v);
   }
   ensure_pool(bump_);
 
+  pt.mark("plan");
   // 5. device: relocate grown segments, then scatter the batch, then publish entries
   if (!moves.empty()) {
     size_t bytes = moves.size() * sizeof(MoveDesc);
@@ -444,13 +563,15 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     int64_t* h_dst = reinterpret_cast<int64_t*>(h + o_dst);
     int64_t* h_eid = reinterpret_cast<int64_t*>(h + o_eid);
     float* h_ts = reinterpret_cast<float*>(h + o_ts);
-    for (size_t k = 0; k < m; ++k) {
-      size_t p = perm[off + k];
-      h_dest[k] = dest[off + k];
-      h_dst[k] = dst[p];
-      h_eid[k] = eids[p];
-      h_ts[k] = ts[p];
-    }
+    parallel_for(m, 1 << 16, [&](size_t k0, size_t k1) {
+      for (size_t k = k0; k < k1; ++k) {
+        const size_t p = perm[off + k];
+        h_dest[k] = dest[off + k];
+        h_dst[k] = dst[p];
+        h_eid[k] = eids[p];
+        h_ts[k] = s_ts[off + k];
+      }
+    });
     GF_HIP(hipMemcpyAsync(staging_.data(), h, bytes, hipMemcpyHostToDevice, stream_));
     char* d = staging_.as<char>();
     unsigned grid = static_cast<unsigned>(std::min<size_t>((m + 255) / 256, 8192));
@@ -461,8 +582,11 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     GF_HIP(hipGetLastError());
     GF_HIP(hipStreamSynchronize(stream_));  // the pinned chunk is refilled next
   }
+  pt.mark("device");
   for (auto& f : deferred_free) seg_free(f.first, f.second);
   upload_entries(touched);  // ends with the stream sync of dynamic_graph.cu:135-137
+  pt.mark("publish");
+  pt.report(n);
 }
 
 // ---- DynamicGraph::OffloadOldBlocks, dynamic_graph.cu:382-411 --------------------

@@ -95,6 +95,7 @@ class EdgeStore {
 
   void add_nodes(int64_t max_node);
   void bump_eid(int64_t eid);
+  void bump_eids(const int64_t* eids, size_t n);
   void drop_eid(int64_t eid);
   uint64_t seg_alloc(uint64_t cap);
   void seg_free(uint64_t start, uint64_t cap);
