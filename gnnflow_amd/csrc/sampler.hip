@@ -31,6 +31,8 @@
 // end-1-j on that sequence.  tests/ proves it against the block-walking oracle.
 #include "sampler.hpp"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -790,6 +792,9 @@ void Sampler::sample_end(gf_block* blocks) {
   for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
     if (*flag == publish_seq_) { seen = true; break; }
     __builtin_ia32_pause();
+    // a short pure spin covers the usual few microseconds; beyond that give the core away
+    // (8 ranks per node each have a spinner and an enqueue thread)
+    if (spin > 4096 && (spin & 63) == 0) sched_yield();
   }
   if (!seen) GF_HIP(hipEventSynchronize(done_ev_));
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
