@@ -114,7 +114,10 @@ __global__ void edge_softmax_bwd_wave(const int64_t* __restrict__ offsets, uint6
 
 // ---- per-destination reduction of source rows ------------------------------------------
 // out[d, :] = sum (or mean) over the edges k of segment d of  w[k, head(c)] * src[col[k], :]
-// (w == nullptr: plain copy_src).  One wave per destination, lanes over the row; every
+// (w == nullptr: plain copy_src).  col == nullptr means the sampler's layout, col[k] =
+// num_dst + k (roots first, then one new source node per edge): the k-th edge reads row
+// num_dst + k, a destination's sources are one contiguous run, and the backward pass needs
+// neither atomics nor a full memset.  One wave per destination, lanes over the row; every
 // load is a contiguous run of the source row.  `per_head` = dim / heads columns share one
 // edge weight (GATConv's u_mul_e with [E, H, 1] weights).
 __global__ void segment_reduce_fwd(const int64_t* __restrict__ offsets, uint64_t num_dst,
@@ -132,7 +135,8 @@ __global__ void segment_reduce_fwd(const int64_t* __restrict__ offsets, uint64_t
     const uint32_t h = w ? c / per_head : 0u;
     float acc = 0.f;
     for (int64_t k = b; k < e; ++k) {
-      const float v = src[static_cast<uint64_t>(col[k]) * dim + c];
+      const uint64_t s = col ? static_cast<uint64_t>(col[k]) : num_dst + static_cast<uint64_t>(k);
+      const float v = src[s * dim + c];
       acc += w ? v * w[k * heads + h] : v;
     }
     out[d * dim + c] = acc * scale;
@@ -155,11 +159,13 @@ __global__ void segment_reduce_bwd(const int64_t* __restrict__ offsets, uint64_t
   const uint32_t per_head = w ? dim / heads : dim;
   const float scale = (mean && e > b) ? 1.f / static_cast<float>(e - b) : 1.f;
   for (int64_t k = b; k < e; ++k) {
-    const uint64_t s = static_cast<uint64_t>(col[k]);
+    const uint64_t s = col ? static_cast<uint64_t>(col[k]) : num_dst + static_cast<uint64_t>(k);
     if (gsrc) {
       for (uint32_t c = lane; c < dim; c += 64) {
         const float g = gout[d * dim + c] * scale;
-        atomicAdd(&gsrc[s * dim + c], w ? g * w[k * heads + c / per_head] : g);
+        const float v = w ? g * w[k * heads + c / per_head] : g;
+        if (col) atomicAdd(&gsrc[s * dim + c], v);
+        else gsrc[s * dim + c] = v;          // every source row feeds exactly one edge
       }
     }
     if (gw) {
@@ -237,8 +243,12 @@ void segment_reduce_backward(const int64_t* d_offsets, size_t num_dst, const int
                              bool mean, const float* d_grad_out, float* d_grad_src,
                              size_t num_src, float* d_grad_w, int device, hipStream_t stream) {
   DeviceGuard dg(device);
-  if (d_grad_src && num_src && dim)
-    GF_HIP(hipMemsetAsync(d_grad_src, 0, num_src * dim * sizeof(float), stream));
+  if (d_grad_src && num_src && dim) {
+    // general blocks accumulate into zeros; the sampler layout writes every edge's row
+    // exactly once, so only the rows of the destination nodes themselves are cleared
+    const size_t rows = d_col ? num_src : std::min(num_dst, num_src);
+    if (rows) GF_HIP(hipMemsetAsync(d_grad_src, 0, rows * dim * sizeof(float), stream));
+  }
   if (num_dst == 0 || dim == 0) return;
   GF_REQUIRE(d_offsets && d_grad_out, "segment_reduce backward: null pointer");
   GF_REQUIRE(!d_grad_w || (d_w && d_src), "segment_reduce backward: weight gradient needs w and src");

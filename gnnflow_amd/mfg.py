@@ -167,13 +167,15 @@ class MFGBlock:
 
     def segments(self):
         """(offsets, col, perm): edges grouped by destination node — offsets[d]..offsets[d+1]
-        are the edges into d, `col` their source indices in that order, `perm` the edge
-        permutation that groups them (None when the edges already are, as the sampler's)."""
+        are the edges into d, `col` their source indices in that order (None for the sampler's
+        own layout, source of edge k = node num_dst + k), `perm` the edge permutation that
+        groups them (None when the edges already are, as the sampler's)."""
         if self._segments is None:
             import ctypes as C
             from . import _capi
             col, row = self.edges()
             perm = None
+            sampler_layout = self._raw is not None   # col[k] = num_dst + k by construction
             if self._raw is None and self._num_edges > 1 and \
                     not bool((row[1:] >= row[:-1]).all()):
                 perm = torch.argsort(row, stable=True)
@@ -185,7 +187,7 @@ class MFGBlock:
                     row.data_ptr() if self._num_edges else None, self._num_edges, self._num_dst,
                     offsets.data_ptr(), self._device.index,
                     C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)))
-            self._segments = (offsets, col, perm)
+            self._segments = (offsets, None if sampler_layout else col, perm)
         return self._segments
 
     def update_all(self, message_func, reduce_func):

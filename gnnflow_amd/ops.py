@@ -61,7 +61,8 @@ class _EdgeSoftmax(torch.autograd.Function):
 
 class _BlockReduce(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, weight, offsets, col, num_dst, mean):
+    def forward(ctx, src, weight, offsets, col, num_dst, mean, num_edges):
+        # col is None for the sampler's layout (source of edge k = row num_dst + k)
         s = _f32(src)
         num_src = s.shape[0]
         dim = s.numel() // num_src if num_src else 0
@@ -74,34 +75,34 @@ class _BlockReduce(torch.autograd.Function):
                 raise ValueError("feature size {} is not a multiple of the {} edge-weight heads"
                                  .format(dim, heads))
         out = torch.zeros((num_dst,) + tuple(s.shape[1:]), dtype=torch.float32, device=s.device)
-        if num_dst and dim and col.numel():
+        if num_dst and dim and num_edges:
             with torch.cuda.device(s.device):
                 _capi.check(_capi.load().gf_block_reduce(
-                    offsets.data_ptr(), num_dst, col.data_ptr(), s.data_ptr(), dim, _ptr(w), heads,
+                    offsets.data_ptr(), num_dst, _ptr(col), s.data_ptr(), dim, _ptr(w), heads,
                     1 if mean else 0, out.data_ptr(), s.device.index, _stream(s.device)))
         ctx.save_for_backward(s, w, offsets, col)
-        ctx.meta = (num_dst, mean, heads, dim)
+        ctx.meta = (num_dst, mean, heads, dim, num_edges)
         return out
 
     @staticmethod
     def backward(ctx, grad):
         s, w, offsets, col = ctx.saved_tensors
-        num_dst, mean, heads, dim = ctx.meta
+        num_dst, mean, heads, dim, num_edges = ctx.meta
         g = _f32(grad)
         need_src, need_w = ctx.needs_input_grad[0], w is not None and ctx.needs_input_grad[1]
         gs = torch.empty_like(s) if need_src else None
         gw = torch.zeros_like(w) if need_w else None
         if (need_src or need_w) and dim:
-            if col.numel() == 0 or num_dst == 0:
+            if num_edges == 0 or num_dst == 0:
                 if gs is not None:
                     gs.zero_()
             else:
                 with torch.cuda.device(s.device):
                     _capi.check(_capi.load().gf_block_reduce_backward(
-                        offsets.data_ptr(), num_dst, col.data_ptr(), s.data_ptr(), dim, _ptr(w),
+                        offsets.data_ptr(), num_dst, _ptr(col), s.data_ptr(), dim, _ptr(w),
                         heads, 1 if mean else 0, g.data_ptr(), _ptr(gs), s.shape[0], _ptr(gw),
                         s.device.index, _stream(s.device)))
-        return gs, gw, None, None, None, None
+        return gs, gw, None, None, None, None, None
 
 
 def edge_softmax(block, logits: torch.Tensor) -> torch.Tensor:
@@ -125,4 +126,5 @@ def block_reduce(block, src: torch.Tensor, edge_weight=None, mean: bool = False)
     offsets, col, perm = block.segments()
     if edge_weight is not None and perm is not None:
         edge_weight = edge_weight[perm]
-    return _BlockReduce.apply(src, edge_weight, offsets, col, block.num_dst_nodes(), mean)
+    return _BlockReduce.apply(src, edge_weight, offsets, col, block.num_dst_nodes(), mean,
+                              block.num_edges())

@@ -328,7 +328,9 @@ GF_API int gf_block_edge_softmax_backward(const int64_t* d_offsets, size_t num_d
                                           int device, void* stream);
 /* update_all(copy_src | u_mul_e, sum | mean): out[d, :] = reduce over edges k of d of
  * edge_weight[k, head] * src[col[k], :]  (d_edge_weight NULL: copy_src; else [num_edges, heads]
- * with dim % heads == 0, each weight covering dim / heads consecutive columns). */
+ * with dim % heads == 0, each weight covering dim / heads consecutive columns).
+ * d_col NULL = the sampler's own layout col[k] = num_dst + k (then num_src must be
+ * num_dst + num_edges): contiguous reads, and a backward pass without atomics. */
 GF_API int gf_block_reduce(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
                            const float* d_src, size_t dim, const float* d_edge_weight,
                            size_t heads, int mean, float* d_out, int device, void* stream);

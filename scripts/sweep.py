@@ -146,12 +146,21 @@ def blockops_sweep():
         return a.elapsed_time(b) * 1e3 / reps
 
     H, D = 2, 50          # TGN/TGAT attention: 2 heads, dim_out 100
+    # real sampler output (so the ops see the sampler's layout, col[k] = num_dst + k): every
+    # node of this graph has 16 edges, hence 10 sampled edges per root
+    N = 100000
+    g = gnnflow_amd.DynamicGraph(1 << 26, 1 << 30, "cuda", 16, 1024, "insert")
+    src = np.repeat(np.arange(N, dtype=np.int64), 16)
+    rs = np.random.RandomState(0)
+    g.add_edges(src, rs.randint(0, N, len(src)).astype(np.int64),
+                np.tile(np.arange(16, dtype=np.float32), N))
+    sampler = gnnflow_amd.TemporalSampler(g, [10], "recent")
     for R in (1800, 19800, 198000, 1980000):
         E = R * 10
-        row = torch.arange(R, device=dev).repeat_interleave(10)
-        col = R + torch.arange(E, device=dev)
-        blk = MFGBlock(R + E, R, col, row)
-        blk.segments()
+        blk = sampler.sample(rs.randint(0, N, R).astype(np.int64),
+                             np.full(R, 100.0, np.float32))[0][0]
+        assert blk.num_edges() == E and blk.segments()[1] is None
+        col, row = blk.edges()
         x = torch.randn(E, H, device=dev, requires_grad=True)
         v = torch.randn(R + E, H * D, device=dev, requires_grad=True)
         gy = torch.randn(E, H, device=dev)
