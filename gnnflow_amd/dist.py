@@ -317,64 +317,87 @@ class DevicePartitionedSampler:
         self._device = sampler._device
         self._fanouts = list(sampler._fanouts)
         self._L, self._S = sampler._num_layers, sampler._num_snapshots
+        self._size_cache = {}
+        self._gb = _capi.GfBlock()
 
     def _stream(self):
         return self._C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
 
-    def _padded(self, req: torch.Tensor, n: int, layer: int, snapshot: int, out: torch.Tensor):
-        self._capi.check(self._lib.gf_sampler_sample_layer_padded(
-            self._sampler._h, req.data_ptr() if n else None, n, layer, snapshot,
-            out.data_ptr() if n else None, self._stream()))
+    def _sizes(self, R: int, layer: int):
+        """(partition scratch bytes, block output bytes) for R roots, cached."""
+        key = (R, layer)
+        hit = self._size_cache.get(key)
+        if hit is None:
+            C = self._C
+            a, b = C.c_size_t(0), C.c_size_t(0)
+            self._capi.check(self._lib.gf_partition_scratch_bytes(R, self._P, C.byref(a)))
+            self._capi.check(self._lib.gf_sampler_layer_output_bytes(self._sampler._h, R, layer,
+                                                                     C.byref(b)))
+            hit = self._size_cache[key] = (a.value, b.value)
+        return hit
 
     def sample_layer(self, nodes: torch.Tensor, ts: torch.Tensor, layer: int, snapshot: int):
         C, lib, check = self._C, self._lib, self._capi.check
         dev, P, me, F = self._device, self._P, self._rank, self._fanouts[layer]
-        nodes = nodes.to(dev, torch.int64).contiguous()
-        ts = ts.to(dev, torch.float32).contiguous()
+        if nodes.device != dev or nodes.dtype != torch.int64 or not nodes.is_contiguous():
+            nodes = nodes.to(dev, torch.int64).contiguous()
+        if ts.device != dev or ts.dtype != torch.float32 or not ts.is_contiguous():
+            ts = ts.to(dev, torch.float32).contiguous()
         R = int(nodes.shape[0])
         if R == 0:
             return self._sampler._empty_block()
-        with torch.cuda.device(dev):
-            # 1. bucket by owner: requests ordered [other owners ascending | own share]
-            need = C.c_size_t(0)
-            check(lib.gf_partition_scratch_bytes(R, P, C.byref(need)))
-            scratch = torch.empty(need.value, dtype=torch.uint8, device=dev)
-            req = torch.empty((R, 2), dtype=torch.int64, device=dev)
-            pos = torch.empty(R, dtype=torch.int32, device=dev)
-            counts = torch.empty(P, dtype=torch.int64, device=dev)
-            check(lib.gf_partition_plan(nodes.data_ptr(), ts.data_ptr(), R, P, me, req.data_ptr(),
-                                        pos.data_ptr(), counts.data_ptr(), scratch.data_ptr(),
-                                        need.value, dev.index, self._stream()))
-            rep = torch.empty((R, F, 3), dtype=torch.int64, device=dev)
-            if P > 1:
-                recv_counts = torch.empty_like(counts)
-                _exchange(recv_counts, counts, None, None, self._group)
-                sc, rc = counts.tolist(), recv_counts.tolist()
-                n_own = sc[me]
-                n_net = R - n_own
-                sc[me] = rc[me] = 0
-                # 2. requests to the other ranks, asynchronously ...
-                got = torch.empty((sum(rc), 2), dtype=torch.int64, device=dev)
-                work = _exchange(got, req[:n_net], rc, sc, self._group, async_op=True)
-                # 3. ... overlapped with this rank's own share on its shard
-                self._padded(req[n_net:], n_own, layer, snapshot, rep[n_net:])
-                if work is not None:
-                    work.wait()
-                # 4. serve the received requests; replies land in the prefix of `rep`
-                served = torch.empty((got.shape[0], F, 3), dtype=torch.int64, device=dev)
-                self._padded(got, int(got.shape[0]), layer, snapshot, served)
-                _exchange(rep[:n_net].view(n_net, F * 3), served.view(-1, F * 3), sc, rc,
-                          self._group)
-            else:
-                self._padded(req, R, layer, snapshot, rep)
-            # 5. replies -> block in the original root order
-            nbytes = C.c_size_t(0)
-            check(lib.gf_sampler_layer_output_bytes(self._sampler._h, R, layer, C.byref(nbytes)))
-            buf = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-            gb = self._capi.GfBlock()
-            check(lib.gf_sampler_merge_padded(
-                self._sampler._h, nodes.data_ptr(), ts.data_ptr(), R, layer, rep.data_ptr(),
-                pos.data_ptr(), buf.data_ptr(), nbytes.value, C.byref(gb), self._stream()))
+        if torch.cuda.current_device() != dev.index:
+            with torch.cuda.device(dev):
+                return self.sample_layer(nodes, ts, layer, snapshot)
+        scratch_bytes, out_bytes = self._sizes(R, layer)
+        # one workspace allocation: [requests R x 16 | replies R x F x 24 | counts P x 8 |
+        # positions R x 4 | partition scratch]
+        o_rep = R * 16
+        o_cnt = o_rep + R * F * 24
+        o_pos = o_cnt + P * 8
+        o_scr = (o_pos + R * 4 + 15) & ~15
+        ws = torch.empty(o_scr + scratch_bytes, dtype=torch.uint8, device=dev)
+        base = ws.data_ptr()
+        stream = self._stream()
+        # 1. bucket by owner: requests ordered [other owners ascending | own share]
+        check(lib.gf_partition_plan(nodes.data_ptr(), ts.data_ptr(), R, P, me, base,
+                                    base + o_pos, base + o_cnt, base + o_scr, scratch_bytes,
+                                    dev.index, stream))
+        if P > 1:
+            req = ws[:o_rep].view(torch.int64).view(R, 2)
+            rep = ws[o_rep:o_cnt].view(torch.int64).view(R, F * 3)
+            counts = ws[o_cnt:o_pos].view(torch.int64)
+            recv_counts = torch.empty_like(counts)
+            _exchange(recv_counts, counts, None, None, self._group)
+            sc, rc = counts.tolist(), recv_counts.tolist()
+            n_own = sc[me]
+            n_net = R - n_own
+            sc[me] = rc[me] = 0
+            # 2. requests to the other ranks, asynchronously ...
+            got = torch.empty((sum(rc), 2), dtype=torch.int64, device=dev)
+            work = _exchange(got, req[:n_net], rc, sc, self._group, async_op=True)
+            # 3. ... overlapped with this rank's own share on its shard
+            check(lib.gf_sampler_sample_layer_padded(
+                self._sampler._h, base + n_net * 16 if n_own else None, n_own, layer, snapshot,
+                base + o_rep + n_net * F * 24 if n_own else None, stream))
+            if work is not None:
+                work.wait()
+            # 4. serve the received requests; replies land in the prefix of `rep`
+            n_got = int(got.shape[0])
+            served = torch.empty((n_got, F * 3), dtype=torch.int64, device=dev)
+            check(lib.gf_sampler_sample_layer_padded(
+                self._sampler._h, got.data_ptr() if n_got else None, n_got, layer, snapshot,
+                served.data_ptr() if n_got else None, stream))
+            _exchange(rep[:n_net], served, sc, rc, self._group)
+        else:
+            check(lib.gf_sampler_sample_layer_padded(self._sampler._h, base, R, layer, snapshot,
+                                                     base + o_rep, stream))
+        # 5. replies -> block in the original root order
+        buf = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
+        gb = self._gb
+        check(lib.gf_sampler_merge_padded(
+            self._sampler._h, nodes.data_ptr(), ts.data_ptr(), R, layer, base + o_rep,
+            base + o_pos, buf.data_ptr(), out_bytes, C.byref(gb), stream))
         return self._sampler._block(buf, gb)
 
     def sample(self, nodes, ts):
