@@ -175,36 +175,6 @@ void EdgeStore::add_nodes(int64_t max_node) {
   any_node_ = true;
 }
 
-// `edges_[eid]++` (dynamic_graph.cu:93-95).  Dense counters for the usual
-// non-negative, roughly contiguous eids; a hash map for everything else.
-void EdgeStore::bump_eid(int64_t eid) {
-  eids_inserted_++;
-  if (eid >= 0) {
-    uint64_t u = static_cast<uint64_t>(eid);
-    if (u >= eid_dense_.size() && u < 64 + 8 * eids_inserted_) {
-      size_t nsz = std::max<size_t>(u + 1, eid_dense_.size() * 2);
-      nsz = std::min<size_t>(nsz, 64 + 8 * eids_inserted_);
-      nsz = std::max<size_t>(nsz, u + 1);
-      eid_dense_.resize(nsz, 0);
-      if (!eid_sparse_.empty()) {  // keep "eid < dense.size() => counted densely"
-        for (auto it = eid_sparse_.begin(); it != eid_sparse_.end();) {
-          if (it->first >= 0 && static_cast<uint64_t>(it->first) < nsz) {
-            eid_dense_[it->first] += static_cast<uint32_t>(it->second);
-            it = eid_sparse_.erase(it);
-          } else {
-            ++it;
-          }
-        }
-      }
-    }
-    if (u < eid_dense_.size()) {
-      if (eid_dense_[u]++ == 0) num_live_eids_++;
-      return;
-    }
-  }
-  if (eid_sparse_[eid]++ == 0) num_live_eids_++;
-}
-
 // `if (--edges_[eid] == 0) edges_.erase(eid)` (dynamic_graph.cu:393-397)
 void EdgeStore::drop_eid(int64_t eid) {
   if (eid >= 0 && static_cast<uint64_t>(eid) < eid_dense_.size()) {
@@ -265,11 +235,10 @@ LogicalBlock EdgeStore::new_block(size_t size) {
   return b;
 }
 
-// dynamic_graph.cu:206-287 AddEdgesForOneNode + utils.cu:33-63 CopyEdgesToBlock,
-// replayed on block headers only (the bytes live in the node's flat segment).
-// bump_eid for a whole batch: one growth decision for the dense counters (from the batch's
-// largest id) instead of a check per edge; ids they do not cover (negative, or far beyond
-// what has been inserted) go through the sparse map.
+// `edges_[eid]++` for a batch (dynamic_graph.cu:93-95; num_edges() = distinct ids).  Dense
+// counters for the usual non-negative, roughly contiguous eids, grown once per batch from the
+// batch's largest id; ids they do not cover (negative, or far beyond what has been inserted)
+// go through a hash map.
 void EdgeStore::bump_eids(const int64_t* eids, size_t n) {
   int64_t mx = -1;
   {
@@ -307,6 +276,8 @@ void EdgeStore::bump_eids(const int64_t* eids, size_t n) {
   eids_inserted_ += n;
 }
 
+// dynamic_graph.cu:206-287 AddEdgesForOneNode + utils.cu:33-63 CopyEdgesToBlock,
+// replayed on block headers only (the bytes live in the node's flat segment).
 void EdgeStore::simulate_blocks(NodeState& st, const float* ts, size_t n) {
   auto copy_to = [&](LogicalBlock& b, size_t start_idx, size_t cnt) {
     b.size += cnt;

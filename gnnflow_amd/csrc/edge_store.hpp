@@ -94,7 +94,6 @@ class EdgeStore {
   struct Move { uint64_t src, dst, count; };
 
   void add_nodes(int64_t max_node);
-  void bump_eid(int64_t eid);
   void bump_eids(const int64_t* eids, size_t n);
   void drop_eid(int64_t eid);
   uint64_t seg_alloc(uint64_t cap);
@@ -106,7 +105,9 @@ class EdgeStore {
 
   // config
   size_t initial_pool_size_, maximum_pool_size_, minimum_block_size_;
-  int mem_resource_type_, insertion_policy_, device_;
+  // every MemoryResourceType places the store in HBM; kept for introspection
+  [[maybe_unused]] int mem_resource_type_;
+  int insertion_policy_, device_;
   bool adaptive_;
 
   hipStream_t stream_ = nullptr;
