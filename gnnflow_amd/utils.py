@@ -280,3 +280,31 @@ def get_pinned_buffers(fanouts, sample_history, batch_size, dim_node, dim_edge):
     (gnnflow/utils.py:484-501); the HIP gather reads the feature tables directly, so none are
     needed — empty lists keep `Cache(...)` call sites unchanged."""
     return [], []
+
+
+class EarlyStopMonitor:
+    """Stops training when the monitored value has not improved (relatively, by more than
+    `tolerance`) for `max_round` consecutive epochs (gnnflow/utils.py:532-561; imported by
+    scripts/offline_edge_prediction.py)."""
+
+    def __init__(self, max_round=5, higher_better=True, tolerance=1e-10):
+        self.max_round = max_round
+        self.num_round = 0
+        self.epoch_count = 0
+        self.best_epoch = 0
+        self.last_best = None
+        self.higher_better = higher_better
+        self.tolerance = tolerance
+
+    def early_stop_check(self, curr_val):
+        value = curr_val if self.higher_better else -curr_val
+        if self.last_best is None:
+            self.last_best = value
+        elif (value - self.last_best) / np.abs(self.last_best) > self.tolerance:
+            self.last_best = value
+            self.num_round = 0
+            self.best_epoch = self.epoch_count
+        else:
+            self.num_round += 1
+        self.epoch_count += 1
+        return self.num_round >= self.max_round

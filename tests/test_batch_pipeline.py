@@ -185,3 +185,11 @@ def test_distributed_samplers_gloo_world2():
         # RandomStartBatchSampler(world_size=2): identical batches on both ranks
         assert a["rand"][epoch] == b["rand"][epoch]
         assert sum(a["rand"][epoch], []) == list(range(1000))
+
+
+def test_early_stop_monitor():
+    m = U.EarlyStopMonitor(max_round=2)
+    assert [m.early_stop_check(v) for v in (0.5, 0.6, 0.6, 0.59)] == [False, False, False, True]
+    assert m.best_epoch == 1 and m.epoch_count == 4
+    low = U.EarlyStopMonitor(max_round=1, higher_better=False)
+    assert [low.early_stop_check(v) for v in (1.0, 0.5, 0.7)] == [False, False, True]
