@@ -58,3 +58,22 @@ def test_python_layer_rejects_bad_strings():
         gnnflow_amd.DynamicGraph(1 << 20, 1 << 21, "bogus", 64, 128, "insert")
     with pytest.raises(ValueError):
         gnnflow_amd.DynamicGraph(1 << 20, 1 << 21, "cuda", 64, 128, "bogus")
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary must be bindable from C / cgo / JNI: both headers compile as C99 with
+    no C++ or torch types in any signature."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "gnnflow_hip.h"\n#include "gnnflow_rng.h"\n'
+                   'int main(void) { return (int)gf_philox4x32_10_first(1, 2, 3) & 0; }\n')
+    p = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I",
+                        os.path.join(root, "include"), "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
