@@ -134,3 +134,30 @@ def test_ranks_sharing_one_gpu_match_the_oracle(world):
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_uniform_policy_through_the_padded_kernel_is_uniform():
+    """Partitioned uniform sampling is distribution-matched (each owner draws from its own
+    Philox stream): every in-window edge equally likely, all `fanout` slots filled (sampling
+    with replacement), successive calls use fresh draws."""
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from gnnflow_amd.dist import DevicePartitionedSampler
+    n = 16
+    g = DynamicGraph(1 << 20, 64 << 20, "cuda", 4, 64, "insert")
+    g.add_edges(np.zeros(n, np.int64), np.arange(1, n + 1), np.arange(n, dtype=np.float32))
+    part = DevicePartitionedSampler(TemporalSampler(g, [8], "uniform", seed=2024))
+    R = 20000
+    roots, ts = np.zeros(R, np.int64), np.full(R, 12.0, np.float32)
+    b = part.sample(roots, ts)[0][0]
+    picked = b.srcdata["ID"][R:].cpu().numpy()
+    assert len(picked) == R * 8
+    counts = np.bincount(picked, minlength=n + 1)[1:13]   # 12 candidates: dst 1..12
+    assert counts.sum() == R * 8
+    expected = R * 8 / 12.0
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    assert chi2 < 40.0, chi2   # 11 dof: P(chi2 > 40) ~ 4e-5
+    again = part.sample(roots, ts)[0][0].srcdata["ID"][R:].cpu().numpy()
+    assert not np.array_equal(picked, again)
+    # a root without candidates gets no slot at all
+    empty = part.sample(np.array([0, 5]), np.array([0.0, 12.0], np.float32))[0][0]
+    assert empty.num_edges() == 0
