@@ -180,6 +180,40 @@ __global__ void segment_reduce_bwd(const int64_t* __restrict__ offsets, uint64_t
   }
 }
 
+// out[d, c] = max over the edges k of d of src[col[k], c]  (0 for a destination without
+// in-edges, as dgl's max reducer leaves it); arg[d, c] = the edge that won (-1: none), lowest
+// edge index on ties — the backward pass routes grad_out[d, c] to that edge's source row.
+__global__ void segment_max_fwd(const int64_t* __restrict__ offsets, uint64_t num_dst,
+                                const int64_t* __restrict__ col, const float* __restrict__ src,
+                                uint32_t dim, float* __restrict__ out, int64_t* __restrict__ arg) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t d = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  if (d >= num_dst) return;
+  const int64_t b = offsets[d], e = offsets[d + 1];
+  for (uint32_t c = lane; c < dim; c += 64) {
+    float best = 0.f;
+    int64_t who = -1;
+    for (int64_t k = b; k < e; ++k) {
+      const uint64_t s = col ? static_cast<uint64_t>(col[k]) : num_dst + static_cast<uint64_t>(k);
+      const float v = src[s * dim + c];
+      if (who < 0 || v > best) { best = v; who = k; }
+    }
+    out[d * dim + c] = best;
+    arg[d * dim + c] = who;
+  }
+}
+
+__global__ void segment_max_bwd(uint64_t num_dst, const int64_t* __restrict__ col, uint32_t dim,
+                                const float* __restrict__ gout, const int64_t* __restrict__ arg,
+                                float* __restrict__ gsrc) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= num_dst * dim) return;
+  const int64_t k = arg[i];
+  if (k < 0) return;
+  const uint64_t s = col ? static_cast<uint64_t>(col[k]) : num_dst + static_cast<uint64_t>(k);
+  atomicAdd(&gsrc[s * dim + (i % dim)], gout[i]);
+}
+
 inline unsigned blocks_for(uint64_t threads) {
   return static_cast<unsigned>((threads + kThreads - 1) / kThreads);
 }
@@ -235,6 +269,32 @@ void segment_reduce_forward(const int64_t* d_offsets, size_t num_dst, const int6
                        stream>>>(d_offsets, num_dst, d_col, d_src, static_cast<uint32_t>(dim),
                                  d_w, static_cast<uint32_t>(heads ? heads : 1), mean ? 1 : 0,
                                  d_out);
+  GF_HIP(hipGetLastError());
+}
+
+void segment_max_forward(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
+                         const float* d_src, size_t dim, float* d_out, int64_t* d_arg, int device,
+                         hipStream_t stream) {
+  if (num_dst == 0 || dim == 0) return;
+  GF_REQUIRE(d_offsets && d_src && d_out && d_arg, "segment_max: null pointer");
+  DeviceGuard dg(device);
+  segment_max_fwd<<<dim3(blocks_for(static_cast<uint64_t>(num_dst) * 64)), dim3(kThreads), 0,
+                    stream>>>(d_offsets, num_dst, d_col, d_src, static_cast<uint32_t>(dim), d_out,
+                              d_arg);
+  GF_HIP(hipGetLastError());
+}
+
+void segment_max_backward(size_t num_dst, const int64_t* d_col, size_t dim,
+                          const float* d_grad_out, const int64_t* d_arg, float* d_grad_src,
+                          size_t num_src, int device, hipStream_t stream) {
+  GF_REQUIRE(d_grad_src != nullptr || num_src == 0, "segment_max backward: null gradient");
+  DeviceGuard dg(device);
+  if (num_src && dim) GF_HIP(hipMemsetAsync(d_grad_src, 0, num_src * dim * sizeof(float), stream));
+  if (num_dst == 0 || dim == 0) return;
+  GF_REQUIRE(d_grad_out && d_arg, "segment_max backward: null pointer");
+  segment_max_bwd<<<dim3(blocks_for(static_cast<uint64_t>(num_dst) * dim)), dim3(kThreads), 0,
+                    stream>>>(num_dst, d_col, static_cast<uint32_t>(dim), d_grad_out, d_arg,
+                              d_grad_src);
   GF_HIP(hipGetLastError());
 }
 

@@ -201,6 +201,12 @@ void segment_reduce_backward(const int64_t* d_offsets, size_t num_dst, const int
                              const float* d_src, size_t dim, const float* d_w, size_t heads,
                              bool mean, const float* d_grad_out, float* d_grad_src,
                              size_t num_src, float* d_grad_w, int device, hipStream_t stream);
+void segment_max_forward(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
+                         const float* d_src, size_t dim, float* d_out, int64_t* d_arg, int device,
+                         hipStream_t stream);
+void segment_max_backward(size_t num_dst, const int64_t* d_col, size_t dim,
+                          const float* d_grad_out, const int64_t* d_arg, float* d_grad_src,
+                          size_t num_src, int device, hipStream_t stream);
 }  // namespace gf
 
 extern "C" {
@@ -572,6 +578,23 @@ int gf_block_reduce_backward(const int64_t* d_offsets, size_t num_dst, const int
     gf::segment_reduce_backward(d_offsets, num_dst, d_col, d_src, dim, d_edge_weight, heads,
                                 mean != 0, d_grad_out, d_grad_src, num_src, d_grad_edge_weight,
                                 device, static_cast<hipStream_t>(stream));
+  });
+}
+
+int gf_block_reduce_max(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
+                        const float* d_src, size_t dim, float* d_out, int64_t* d_arg, int device,
+                        void* stream) {
+  return guarded([&] {
+    gf::segment_max_forward(d_offsets, num_dst, d_col, d_src, dim, d_out, d_arg, device,
+                            static_cast<hipStream_t>(stream));
+  });
+}
+int gf_block_reduce_max_backward(size_t num_dst, const int64_t* d_col, size_t dim,
+                                 const float* d_grad_out, const int64_t* d_arg, float* d_grad_src,
+                                 size_t num_src, int device, void* stream) {
+  return guarded([&] {
+    gf::segment_max_backward(num_dst, d_col, dim, d_grad_out, d_arg, d_grad_src, num_src, device,
+                             static_cast<hipStream_t>(stream));
   });
 }
 

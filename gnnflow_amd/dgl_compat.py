@@ -74,7 +74,8 @@ def install(force: bool = False):
     dgl.heterograph = module("dgl.heterograph", DGLBlock=MFGBlock)
     dgl.ops = module("dgl.ops", edge_softmax=ops.edge_softmax)
     dgl.function = module("dgl.function", copy_src=function.copy_src, copy_u=function.copy_u,
-                          u_mul_e=function.u_mul_e, sum=function.sum, mean=function.mean)
+                          u_mul_e=function.u_mul_e, sum=function.sum, mean=function.mean,
+                          max=function.max)
     dgl.nn = module("dgl.nn", SAGEConv=nn.SAGEConv, GATConv=nn.GATConv)
     dgl.utils = module("dgl.utils", __path__=[])
     dgl.utils.shared_mem = module("dgl.utils.shared_mem",

@@ -25,3 +25,7 @@ def sum(msg, out):   # noqa: A001 - dgl's name
 
 def mean(msg, out):
     return Reduce("mean", msg, out)
+
+
+def max(msg, out):   # noqa: A001 - dgl's name
+    return Reduce("max", msg, out)

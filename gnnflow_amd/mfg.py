@@ -198,6 +198,11 @@ class MFGBlock:
             raise KeyError("reducer reads '{}' but the message is '{}'".format(
                 reduce_func.msg, message_func.out))
         weight = self.edata[message_func.edge] if message_func.kind == "u_mul_e" else None
+        if reduce_func.kind == "max":
+            if weight is not None:
+                raise NotImplementedError("update_all(u_mul_e, max)")
+            self.dstdata[reduce_func.out] = ops.block_max(self, self.srcdata[message_func.src])
+            return
         self.dstdata[reduce_func.out] = ops.block_reduce(
             self, self.srcdata[message_func.src], weight, mean=reduce_func.kind == "mean")
 

@@ -13,20 +13,22 @@ from . import ops
 
 class SAGEConv(nn.Module):
     """GraphSAGE layer: h_i' = W_self h_i + W_neigh * AGG_{j in N(i)} h_j + b.
-    aggregator_type 'mean' or 'gcn' ('pool' / 'lstm' need reducers this build does not have)."""
+    aggregator_type 'mean', 'gcn' or 'pool' ('lstm' is not built)."""
 
     def __init__(self, in_feats, out_feats, aggregator_type, feat_drop=0., bias=True, norm=None,
                  activation=None):
         super().__init__()
-        if aggregator_type not in ('mean', 'gcn'):
+        if aggregator_type not in ('mean', 'gcn', 'pool'):
             raise NotImplementedError(
-                "SAGEConv aggregator '{}' (only 'mean' and 'gcn')".format(aggregator_type))
+                "SAGEConv aggregator '{}' (only 'mean', 'gcn' and 'pool')".format(aggregator_type))
         self._in_src_feats = self._in_dst_feats = in_feats
         self._out_feats = out_feats
         self._aggre_type = aggregator_type
         self.norm = norm
         self.feat_drop = nn.Dropout(feat_drop)
         self.activation = activation
+        if aggregator_type == 'pool':
+            self.fc_pool = nn.Linear(in_feats, in_feats)
         self.fc_neigh = nn.Linear(in_feats, out_feats, bias=False)
         if aggregator_type != 'gcn':
             self.fc_self = nn.Linear(in_feats, out_feats, bias=False)
@@ -38,6 +40,8 @@ class SAGEConv(nn.Module):
 
     def reset_parameters(self):
         gain = nn.init.calculate_gain('relu')
+        if self._aggre_type == 'pool':
+            nn.init.xavier_uniform_(self.fc_pool.weight, gain=gain)
         if self._aggre_type != 'gcn':
             nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
         nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
@@ -60,6 +64,10 @@ class SAGEConv(nn.Module):
                 h_neigh = ops.block_reduce(graph, src, w, mean=True)
                 if not lin_before_mp:
                     h_neigh = self.fc_neigh(h_neigh)
+            elif self._aggre_type == 'pool':   # max over relu(fc_pool(h_j))
+                if w is not None:
+                    raise NotImplementedError("SAGEConv('pool') with edge weights")
+                h_neigh = self.fc_neigh(ops.block_max(graph, F.relu(self.fc_pool(feat_src))))
             else:   # gcn: (sum of neighbours + self) / (degree + 1)
                 src = self.fc_neigh(feat_src) if lin_before_mp else feat_src
                 dst = src[:graph.num_dst_nodes()]

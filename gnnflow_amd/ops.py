@@ -105,6 +105,46 @@ class _BlockReduce(torch.autograd.Function):
         return gs, gw, None, None, None, None, None
 
 
+class _BlockMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, offsets, col, num_dst, num_edges):
+        s = _f32(src)
+        num_src = s.shape[0]
+        dim = s.numel() // num_src if num_src else 0
+        out = torch.zeros((num_dst,) + tuple(s.shape[1:]), dtype=torch.float32, device=s.device)
+        arg = torch.full((num_dst, max(dim, 1)), -1, dtype=torch.int64, device=s.device)
+        if num_dst and dim and num_edges:
+            with torch.cuda.device(s.device):
+                _capi.check(_capi.load().gf_block_reduce_max(
+                    offsets.data_ptr(), num_dst, _ptr(col), s.data_ptr(), dim, out.data_ptr(),
+                    arg.data_ptr(), s.device.index, _stream(s.device)))
+        ctx.save_for_backward(arg, col)
+        ctx.meta = (num_dst, dim, tuple(s.shape))
+        ctx.mark_non_differentiable(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        arg, col = ctx.saved_tensors
+        num_dst, dim, shape = ctx.meta
+        g = _f32(grad)
+        gs = torch.empty(shape, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _capi.check(_capi.load().gf_block_reduce_max_backward(
+                num_dst, _ptr(col), dim, _ptr(g), arg.data_ptr(), gs.data_ptr(), shape[0],
+                g.device.index, _stream(g.device)))
+        return gs, None, None, None, None
+
+
+def block_max(block, src: torch.Tensor) -> torch.Tensor:
+    """out[d] = element-wise max over the edges into d of src[source(k)] (0 without in-edges):
+    update_all(copy_src, max)."""
+    if src.shape[0] != block.num_src_nodes():
+        raise ValueError("src must have one row per source node")
+    offsets, col, _ = block.segments()
+    return _BlockMax.apply(src, offsets, col, block.num_dst_nodes(), block.num_edges())
+
+
 def edge_softmax(block, logits: torch.Tensor) -> torch.Tensor:
     """Softmax of `logits[num_edges, ...]` over the edges that share a destination node
     (dgl.ops.edge_softmax with the default norm_by='dst')."""

@@ -342,6 +342,17 @@ GF_API int gf_block_reduce_backward(const int64_t* d_offsets, size_t num_dst, co
                                     float* d_grad_src, size_t num_src,
                                     float* d_grad_edge_weight, int device, void* stream);
 
+/* update_all(copy_src, max) — dgl.nn.SAGEConv's 'pool' aggregator: out[d, c] = max over the
+ * in-edges of src[col[k], c] (0 without in-edges); d_arg [num_dst, dim] receives the winning
+ * edge per element (-1: none), which the backward pass routes the gradient through. */
+GF_API int gf_block_reduce_max(const int64_t* d_offsets, size_t num_dst, const int64_t* d_col,
+                               const float* d_src, size_t dim, float* d_out, int64_t* d_arg,
+                               int device, void* stream);
+GF_API int gf_block_reduce_max_backward(size_t num_dst, const int64_t* d_col, size_t dim,
+                                        const float* d_grad_out, const int64_t* d_arg,
+                                        float* d_grad_src, size_t num_src, int device,
+                                        void* stream);
+
 /* ---- measurement support (bench.py) ---------------------------------------- */
 /* Accumulated device time of a kernel family since the last reset, measured with
  * HIP events recorded around each launch on the launching stream.

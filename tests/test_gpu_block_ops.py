@@ -185,3 +185,52 @@ def test_sage_and_gat_layers_match_torch_reference():
     # gradients flow to every parameter through the HIP ops
     got.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in gat.parameters())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_max_reducer_forward_backward(case):
+    """update_all(copy_src, max) — the reducer behind SAGEConv('pool'): element-wise max over
+    in-edges, 0 for destinations without any, gradient to the winning source only."""
+    import torch
+    import gnnflow_amd.function as fn
+    rng = np.random.RandomState(9)
+    degs = rng.randint(0, case["maxdeg"] + 1, case["num_dst"])
+    b = _block(case["num_dst"], degs, 10, case["shuffle"], case["sampler_like"])
+    col, row = b.edges()
+    nd, D = b.num_dst_nodes(), 24
+    v = torch.randn(b.num_src_nodes(), D, device="cuda").requires_grad_()
+    vr = v.detach().clone().requires_grad_()
+    b.srcdata["v"] = v
+    b.update_all(fn.copy_src("v", "m"), fn.max("m", "h"))
+    out = b.dstdata["h"]
+    want = torch.zeros(nd, D, device="cuda")
+    if b.num_edges():
+        want = want.scatter_reduce(0, row[:, None].expand(-1, D), vr[col], "amax",
+                                   include_self=False)
+    assert torch.equal(out, want)
+    g = torch.randn_like(out)
+    out.backward(g)
+    if b.num_edges():
+        want.backward(g)
+        assert torch.allclose(v.grad, vr.grad, **TOL)
+    else:
+        assert torch.count_nonzero(v.grad) == 0
+
+
+def test_sage_pool_layer_matches_torch_reference():
+    import torch
+    import torch.nn.functional as F
+    from gnnflow_amd import nn as gnn
+    torch.manual_seed(1)
+    degs = np.random.RandomState(11).randint(0, 8, 200)
+    b = _block(200, degs, 12)
+    col, row = b.edges()
+    x = torch.randn(b.num_src_nodes(), 20, device="cuda")
+    layer = gnn.SAGEConv(20, 16, "pool").cuda()
+    got = layer(b, x)
+    pooled = torch.zeros(200, 20, device="cuda").scatter_reduce(
+        0, row[:, None].expand(-1, 20), F.relu(layer.fc_pool(x))[col], "amax", include_self=False)
+    want = layer.fc_self(x[:200]) + layer.fc_neigh(pooled) + layer.bias
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4)
+    got.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
