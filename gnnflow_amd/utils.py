@@ -7,10 +7,9 @@ Root layout of a batch (gnnflow/utils.py:371-395, gnnflow/data.py:36-52):
     roots = [src(B) | dst(B) | neg_dst(B)] int64,  ts = [t | t | t] float32,  eid[B]
 """
 import ctypes as C
-import logging
 import os
 import weakref
-from typing import List, Optional, Tuple, Union
+from typing import List, Optional, Union
 
 import numpy as np
 import torch
