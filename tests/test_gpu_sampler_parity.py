@@ -221,3 +221,46 @@ def test_offload_to_file_writes_reference_record_layout(tmp_path, monkeypatch):
         assert eid.tolist() == eids
         assert len(raw) == off + 16      # prev, next
     assert g.num_edges() == o.num_edges() == 4
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzzed_configurations_bit_exact(seed):
+    """Randomly drawn graph shapes, block sizes, insertion policies, chunkings, fan-outs,
+    snapshot / window / prop_time settings, policies and root batches — HIP vs oracle, every
+    array bit for bit, including an offload in the middle of the stream."""
+    import gnnflow_amd
+    from oracle import oracle as O
+    rng = np.random.RandomState(1000 + seed)
+    N = int(rng.choice([5, 50, 700, 4000]))
+    E = int(rng.choice([40, 900, 20000]))
+    ties = int(rng.choice([3, 60, 5000]))
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=seed, alpha=float(rng.choice([0.0, 1.0, 1.6])),
+                                             tie_levels=ties)
+    policy = str(rng.choice(["insert", "replace"]))
+    g, o = _graphs(min_block=int(rng.choice([1, 4, 62])), policy=policy,
+                   adaptive=bool(rng.randint(2)))
+    chunk = int(rng.choice([7, 333, 6000]))
+    reverse = bool(rng.randint(2))
+    half = (E // 2 // chunk) * chunk
+    synth.ingest_chunks(g, src[:half], dst[:half], ts[:half], eid[:half], chunk, add_reverse=reverse)
+    synth.ingest_chunks(o, src[:half], dst[:half], ts[:half], eid[:half], chunk, add_reverse=reverse)
+    if rng.randint(2) and half:
+        cut = float(ts[half // 2])
+        assert g.offload_old_blocks(cut) == o.offload_old_blocks(cut)
+    synth.ingest_chunks(g, src[half:], dst[half:], ts[half:], eid[half:], chunk, add_reverse=reverse)
+    synth.ingest_chunks(o, src[half:], dst[half:], ts[half:], eid[half:], chunk, add_reverse=reverse)
+    layers = int(rng.randint(1, 4))
+    snaps = int(rng.choice([1, 1, 2, 3]))
+    cfg = dict(fanouts=[int(x) for x in rng.randint(1, 12, layers)],
+               sample_strategy=str(rng.choice(["recent", "recent", "uniform"])),
+               num_snapshots=snaps,
+               snapshot_time_window=float(rng.choice([25.0, 200.0])) if snaps > 1
+               else float(rng.choice([0.0, 0.0, 80.0])),
+               prop_time=bool(rng.randint(2)), seed=int(rng.randint(1, 1 << 30)))
+    hs = gnnflow_amd.TemporalSampler(g, **cfg)
+    os_ = O.OracleSampler(o, **cfg)
+    for it in range(3):
+        R = int(rng.choice([1, 17, 300, 1500]))
+        nodes, t = synth.random_roots(N, R, 1000.0, seed=seed * 10 + it, extra_ids=[N + 2])
+        _cmp_blocks(hs.sample(nodes, t), os_.sample(nodes, t), "seed={} cfg={}".format(seed, cfg))
+    assert g.num_edges() == o.num_edges() and g.num_vertices() == o.num_vertices()
