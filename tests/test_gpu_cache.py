@@ -338,3 +338,27 @@ def test_huge_block_takes_chained_scan_path():
         assert float(hip.cache_edge_ratio) == pytest.approx(ora.cache_edge_ratio, abs=1e-6)
         sid = hip._edge.slot_ids()
         assert np.array_equal(np.sort(sid[sid >= 0]), ora.edge.cached_ids())
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzzed_cache_sequences_match_oracle(seed):
+    """Random table sizes, row widths (vectorised and scalar paths), cache ratios down to a
+    single slot, skews, block sizes incl. empty and overflowing ones, replacement policies and
+    resets — rows, hit ratios and cached-id sets against the oracle after every batch."""
+    rng = np.random.RandomState(500 + seed)
+    N = int(rng.choice([8, 130, 2500]))
+    E = int(rng.choice([16, 900, 30000]))
+    dn = int(rng.choice([0, 3, 8, 172]))
+    de = int(rng.choice([1, 4, 13, 172])) if dn == 0 or rng.randint(2) else 0
+    if dn == 0 and de == 0:
+        de = 4
+    ratio = float(rng.choice([0.01, 0.07, 0.3, 1.0]))
+    policy = str(rng.choice(["lru", "lru", "lfu", "fifo"]))
+    nb = int(rng.randint(3, 9))
+    batches = []
+    for _ in range(nb):
+        nsrc = int(rng.choice([1, 40, 700, 4000]))
+        batches.append((nsrc, (int(rng.choice([0, 1, 65, 3000])), int(rng.choice([0, 7, 500])))))
+    resets = tuple(int(x) for x in rng.choice(nb, size=int(rng.randint(0, 2)), replace=False))
+    _run_against_oracle(N=N, E=E, dn=dn, de=de, ratio=ratio, batches=batches, seed=seed,
+                        skew=float(rng.choice([0.0, 0.7, 1.4])), policy=policy, reset_after=resets)
