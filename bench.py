@@ -320,43 +320,89 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores(cap=32):
+    """Host threads this process can really run at once: the affinity mask, cut down to the
+    container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) — a GPU box exposes all of the
+    host's logical CPUs to a container that may only use a few of them."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota)))
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather):
-    """The CPU oracle (oracle/gnnflow_oracle.c: single-threaded C port of the reference's
-    block-walking sampler + cache-free gather) on a bounded sample of the same batches,
-    evenly spread over the replay.  Reported baseline, not the target."""
+    """The CPU oracle (oracle/gnnflow_oracle.c: C port of the reference's block-walking
+    sampler + cache-free gather) on a bounded sample of the same batches — whole
+    chronological replays — once on one thread and once on all the host cores this process
+    may use (OpenMP over the roots / rows; same routine, identical output).  `value` is the
+    faster of the two with its `cores`.  Reported baseline, not the target."""
     from oracle import oracle as O
     og = O.OracleGraph(minimum_block_size=62, insertion_policy="insert")
     for lo in range(0, g["num_edges"], 100000):
         hi = lo + 100000
         og.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
                      add_reverse=args.undirected)
-    osamp = O.OracleSampler(og, fanouts, args.strategy, seed=1234)
-    # whole chronological replays, repeated until ~cpu_seconds of CPU work are done
-    edges, t_total, n_done = 0, 0.0, 0
-    while t_total < args.cpu_seconds:
-        for bi in range(len(batches)):
-            r, t, e = batches[bi]
-            t0 = time.perf_counter()
-            mfgs = osamp.sample(r, t)
-            if with_gather:
-                for blk in mfgs[0]:
-                    blk.srcdata["h"] = O.gather_rows(node_feats, blk.srcdata["ID"])
-                for mfg in mfgs:
-                    for blk in mfg:
-                        if blk.num_edges():
-                            blk.edata["f"] = O.gather_rows(edge_feats, blk.edata["ID"])
-                O.gather_rows(edge_feats, e)     # target_edge_features
-            t_total += time.perf_counter() - t0
-            edges += sum(b.num_edges() for mfg in mfgs for b in mfg)
-            n_done += 1
-            if t_total > args.cpu_seconds and n_done >= 200:
-                break
+    all_cores = usable_cores()
+
+    def run(threads, budget_s):
+        osamp = O.OracleSampler(og, fanouts, args.strategy, seed=1234, threads=threads)
+        edges, t_total, n_done = 0, 0.0, 0
+        while t_total < budget_s:
+            for bi in range(len(batches)):
+                r, t, e = batches[bi]
+                t0 = time.perf_counter()
+                mfgs = osamp.sample(r, t)
+                if with_gather:
+                    for blk in mfgs[0]:
+                        blk.srcdata["h"] = O.gather_rows(node_feats, blk.srcdata["ID"], threads)
+                    for mfg in mfgs:
+                        for blk in mfg:
+                            if blk.num_edges():
+                                blk.edata["f"] = O.gather_rows(edge_feats, blk.edata["ID"], threads)
+                    O.gather_rows(edge_feats, e, threads)     # target_edge_features
+                t_total += time.perf_counter() - t0
+                edges += sum(b.num_edges() for mfg in mfgs for b in mfg)
+                n_done += 1
+                if t_total > budget_s and (n_done >= 200 or t_total > 2 * budget_s):
+                    break
+        return dict(value=edges / t_total, cores=threads, batches=n_done, seconds=t_total,
+                    ms_per_step=1e3 * t_total / max(n_done, 1))
+
+    one = run(1, args.cpu_seconds / 2)
+    runs = [one]
+    if all_cores > 1:
+        runs.append(run(all_cores, args.cpu_seconds / 2))
+    best = max(runs, key=lambda r: r["value"])
     return {
-        "value": edges / t_total, "unit": "edges/s", "cores": 1, "kind": "port",
-        "sample": "{} batches = {:.2f} chronological replays of the same {}-batch stream "
-                  "({:.1f} s of CPU work; oracle sample() + cache-free gather, gcc -O2, "
-                  "single thread)".format(n_done, n_done / len(batches), len(batches), t_total),
-        "ms_per_step": 1e3 * t_total / max(n_done, 1),
+        "value": best["value"], "unit": "edges/s", "cores": best["cores"], "kind": "port",
+        "sample": "{} batches = {:.2f} chronological replays of the same {}-batch stream per run "
+                  "({:.1f} s of CPU work in all; oracle sample() + cache-free gather, gcc -O2 "
+                  "-fopenmp): {}".format(
+                      best["batches"], best["batches"] / len(batches), len(batches),
+                      sum(r["seconds"] for r in runs),
+                      "; ".join("{} thread{}: {:.2f} M edges/s".format(
+                          r["cores"], "" if r["cores"] == 1 else "s", r["value"] / 1e6) for r in runs)),
+        "ms_per_step": best["ms_per_step"],
+        "single_thread_value": one["value"],
     }
 
 

@@ -609,6 +609,73 @@ int gfo_sample_layer(const gfo_graph* g, int policy, uint32_t fanout,
   return GFO_OK;
 }
 
+/*
+ * The same layer on several host threads (OpenMP), for bench.py's cpu_baseline only: roots
+ * are independent, so pass 1 fills fixed slots per root in parallel with the SAME per-slot
+ * routine (sample_slot) and pass 2 is the same stable compaction, serial.  Outputs are
+ * identical to gfo_sample_layer (tests/test_oracle_golden.py checks that).
+ */
+int gfo_sample_layer_mt(const gfo_graph* g, int policy, uint32_t fanout,
+                        uint32_t num_snapshots, uint32_t snapshot_idx, ts_t window,
+                        int prop_time, uint64_t seed, uint64_t call, const nid_t* roots,
+                        const ts_t* root_ts, size_t R, nid_t* all_nodes, ts_t* all_ts,
+                        ts_t* dt, eid_t* eids, nid_t* row, nid_t* col,
+                        size_t* num_sampled, int threads) {
+  size_t slots = R * (size_t)fanout;
+  nid_t* sd = (nid_t*)malloc((slots ? slots : 1) * sizeof(nid_t));
+  eid_t* se = (eid_t*)malloc((slots ? slots : 1) * sizeof(eid_t));
+  ts_t* st = (ts_t*)malloc((slots ? slots : 1) * sizeof(ts_t));
+  if (!sd || !se || !st) { free(sd); free(se); free(st); return GFO_ERR_NOMEM; }
+  long long r;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads > 0 ? threads : 1)
+  for (r = 0; r < (long long)R; ++r) {
+    ts_t start, end;
+    time_window(root_ts[r], snapshot_idx, num_snapshots, window, &start, &end);
+    for (uint32_t j = 0; j < fanout; ++j) {
+      uint64_t tid = (uint64_t)r * fanout + j;
+      nid_t d; eid_t e; ts_t t;
+      if (sample_slot(g, policy == 1, roots[r], start, end, j, seed, tid, call, &d, &e, &t)) {
+        sd[tid] = d; se[tid] = e; st[tid] = t;
+      } else {
+        sd[tid] = -1;
+      }
+    }
+  }
+  size_t S = 0;
+  for (size_t i = 0; i < R; ++i) {
+    all_nodes[i] = roots[i];
+    all_ts[i] = root_ts[i];
+  }
+  for (size_t i = 0; i < R; ++i) {
+    for (uint32_t j = 0; j < fanout; ++j) {
+      size_t tid = i * fanout + j;
+      if (sd[tid] < 0) continue;
+      all_nodes[R + S] = sd[tid];
+      all_ts[R + S] = prop_time ? root_ts[i] : st[tid];
+      dt[S] = root_ts[i] - st[tid];
+      eids[S] = se[tid];
+      row[S] = (nid_t)i;
+      col[S] = (nid_t)(R + S);
+      S++;
+    }
+  }
+  free(sd); free(se); free(st);
+  *num_sampled = S;
+  return GFO_OK;
+}
+
+int gfo_gather_rows_mt(const float* feats, size_t num_rows, size_t dim,
+                       const int64_t* ids, size_t n, float* out, int threads) {
+  int bad = 0;
+  long long i;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+  for (i = 0; i < (long long)n; ++i) {
+    if (ids[i] < 0 || (size_t)ids[i] >= num_rows) { bad = 1; continue; }
+    memcpy(out + (size_t)i * dim, feats + (size_t)ids[i] * dim, dim * sizeof(float));
+  }
+  return bad ? GFO_ERR_ARG : GFO_OK;
+}
+
 /* Cache-free feature gather, gnnflow/utils.py:465-474 prepare_input:
  * out[i, :] = feats[ids[i], :] (float32 rows). */
 int gfo_gather_rows(const float* feats, size_t num_rows, size_t dim,

@@ -83,8 +83,12 @@ def lib():
         C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int,
         C.c_uint64, C.c_uint64, _i64p, _f32p, C.c_size_t,
         _i64p, _f32p, _f32p, _i64p, _i64p, _i64p, C.POINTER(C.c_size_t)]
+    L.gfo_sample_layer_mt.restype = C.c_int
+    L.gfo_sample_layer_mt.argtypes = L.gfo_sample_layer.argtypes + [C.c_int]
     L.gfo_gather_rows.restype = C.c_int
     L.gfo_gather_rows.argtypes = [_f32p, C.c_size_t, C.c_size_t, _i64p, C.c_size_t, _f32p]
+    L.gfo_gather_rows_mt.restype = C.c_int
+    L.gfo_gather_rows_mt.argtypes = L.gfo_gather_rows.argtypes + [C.c_int]
     L.gfo_philox_first.restype = C.c_uint32
     L.gfo_philox_first.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
     _lib = L
@@ -260,6 +264,8 @@ class OracleSampler:
         self._seed = int(seed)
         self._is_static = bool(kwargs.get("is_static", False))
         self._calls = 0  # RNG call counter (include/gnnflow_rng.h)
+        # > 1: the OpenMP form of the same routine (bench.py's cpu_baseline); identical output
+        self.threads = int(kwargs.get("threads", 1))
 
     def sample_layer_raw(self, nodes, ts, layer, snapshot) -> OracleResult:
         nodes = np.ascontiguousarray(nodes, np.int64)
@@ -275,10 +281,13 @@ class OracleSampler:
         S = C.c_size_t(0)
         call = self._calls
         self._calls += 1
-        rc = lib().gfo_sample_layer(
-            self._g._h, self._policy, F, self._num_snapshots, snapshot,
-            self._window, int(self._prop_time), self._seed, call, nodes, ts, R,
-            all_nodes, all_ts, dt, eids, row, col, C.byref(S))
+        args = (self._g._h, self._policy, F, self._num_snapshots, snapshot,
+                self._window, int(self._prop_time), self._seed, call, nodes, ts, R,
+                all_nodes, all_ts, dt, eids, row, col, C.byref(S))
+        if self.threads > 1:
+            rc = lib().gfo_sample_layer_mt(*args, self.threads)
+        else:
+            rc = lib().gfo_sample_layer(*args)
         if rc != 0:
             raise OracleError("sample_layer failed with code {}".format(rc))
         S = S.value
@@ -316,12 +325,16 @@ class OracleSampler:
                                                  layer, snapshot))
 
 
-def gather_rows(feats: np.ndarray, ids: np.ndarray) -> np.ndarray:
+def gather_rows(feats: np.ndarray, ids: np.ndarray, threads: int = 1) -> np.ndarray:
     """gnnflow/utils.py:465-474 prepare_input: feats[ids].float()."""
     feats = np.ascontiguousarray(feats, np.float32)
     ids = np.ascontiguousarray(ids, np.int64)
     out = np.empty((len(ids), feats.shape[1]), np.float32)
-    rc = lib().gfo_gather_rows(feats, feats.shape[0], feats.shape[1], ids, len(ids), out)
+    if threads > 1:
+        rc = lib().gfo_gather_rows_mt(feats, feats.shape[0], feats.shape[1], ids, len(ids), out,
+                                      int(threads))
+    else:
+        rc = lib().gfo_gather_rows(feats, feats.shape[0], feats.shape[1], ids, len(ids), out)
     if rc != 0:
         raise OracleError("gather_rows: id out of range")
     return out

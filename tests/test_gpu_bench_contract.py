@@ -45,7 +45,8 @@ def test_single_gpu_line_with_roofline_and_cpu_baseline():
     assert 0 < r["frac"] < 1 and r["launches_timed"] > 0 and r["avg_launch_us"] > 0
     assert r["traffic"] is None          # PMC traffic is attached to the default workload only
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "edges/s" and c["value"] > 0
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "edges/s" and c["value"] > 0
+    assert c["single_thread_value"] > 0
     assert isinstance(c["sample"], str) and c["sample"]
     assert d["value"] > c["value"]
 

@@ -73,3 +73,28 @@ def test_uniform_is_with_replacement_and_in_window():
     # a second call advances the stream
     b2 = s.sample(np.array([0, 0]), np.array([20.0, 0.0]))[0][0]
     assert b2.edata["ID"].tolist() != b.edata["ID"].tolist()
+
+
+def test_threaded_oracle_is_identical_to_the_scalar_one():
+    """bench.py's cpu_baseline may run the oracle's OpenMP form; it must be the same function."""
+    import numpy as np
+    from oracle import oracle as O
+    from tests import synth
+    src, dst, ts, eid = synth.powerlaw_graph(300, 9000, seed=4, tie_levels=200)
+    g = O.OracleGraph(minimum_block_size=8)
+    synth.ingest_chunks(g, src, dst, ts, eid, 1000, add_reverse=True)
+    for strategy in ("recent", "uniform"):
+        a = O.OracleSampler(g, [7, 3], strategy, num_snapshots=2, snapshot_time_window=80.0)
+        b = O.OracleSampler(g, [7, 3], strategy, num_snapshots=2, snapshot_time_window=80.0,
+                            threads=4)
+        nodes, t = synth.random_roots(300, 500, 1000.0, seed=1, extra_ids=[305])
+        for la, lb in zip(a.sample(nodes, t), b.sample(nodes, t)):
+            for x, y in zip(la, lb):
+                for k in ("ID", "ts"):
+                    assert np.array_equal(x.srcdata[k], y.srcdata[k])
+                for k in ("ID", "dt"):
+                    assert np.array_equal(x.edata[k], y.edata[k])
+                assert np.array_equal(x.edges()[1], y.edges()[1])
+    feats = np.random.RandomState(0).rand(50, 9).astype(np.float32)
+    ids = np.random.RandomState(1).randint(0, 50, 1000)
+    assert np.array_equal(O.gather_rows(feats, ids), O.gather_rows(feats, ids, threads=4))
