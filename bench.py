@@ -55,7 +55,7 @@ def parse():
                          "an all-to-all exchange per layer (gnnflow_amd/dist.py)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap batch i+1's sample() with batch i's fetch_feature()")
-    ap.add_argument("--event-stride", type=int, default=5,
+    ap.add_argument("--event-stride", type=int, default=17,
                     help="time every n-th gather launch with HIP events (1 = all)")
     ap.add_argument("--breakdown", action="store_true",
                     help="extra untimed pass with per-kernel-family HIP-event times")
@@ -197,7 +197,8 @@ def main():
         cache.init_cache()
     lib.gf_profile_reset()
     # HIP events around the gather launches of the timed region, on their stream.  Every
-    # 5th launch is timed (both rounds of a step get sampled in turn): an event pair costs
+    # 17th launch is timed (odd stride: both rounds of a step get sampled in turn; timing
+    # every 5th cost 9 us per step, every 17th < 1 us): an event pair costs
     # ~5 us of stream time, which at ~90 us per step would distort the throughput measured
     # in the same pass.
     launches_before = cache.num_gather_launches if cache is not None else 0
