@@ -617,7 +617,6 @@ __device__ inline void install_body(const Ctx& c) {
     const bool in = s < c.capacity;
     const uint32_t tv = in ? c.touched[s] : 0u;
     const uint32_t sv = in ? c.stamp[s] : 0u;
-    const int64_t old = in ? c.slot_id[s] : -1;
     uint32_t pt = 0, po = 0;
     if (!fifo)
       for (uint32_t t = threadIdx.x; t < tile; t += kTile) { pt += c.tile_tie[t]; po += c.tile_old[t]; }
@@ -660,8 +659,10 @@ __device__ inline void install_body(const Ctx& c) {
     }
     bool stamped = false;
     if (evict && v < k) {
+      // three independent loads, only in the (few) evicting lanes
       const uint32_t row = c.rep_row[v];
       const int64_t nid = c.rep_id[v];
+      const int64_t old = c.slot_id[s];
       if (old >= 0) c.map[old] = kAbsent;
       c.slot_id[s] = nid;
       c.map[nid] = static_cast<int32_t>(s);
