@@ -201,7 +201,6 @@ def main():
     # every 5th cost 9 us per step, every 17th < 1 us): an event pair costs
     # ~5 us of stream time, which at ~90 us per step would distort the throughput measured
     # in the same pass.
-    launches_before = cache.num_gather_launches if cache is not None else 0
     lib.gf_profile_set_stride(args.event_stride)
     lib.gf_profile_enable(1 << _capi.PROFILE_SLOTS["gather"])
     barrier()
@@ -224,8 +223,9 @@ def main():
     lib.gf_profile_set_stride(1)
 
     import ctypes as C
-    g_ms, g_n = C.c_double(0), C.c_uint64(0)
+    g_ms, g_n, g_all = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
     lib.gf_profile_get(_capi.PROFILE_SLOTS["gather"], C.byref(g_ms), C.byref(g_n))
+    lib.gf_profile_launches(_capi.PROFILE_SLOTS["gather"], C.byref(g_all))
 
     stats = torch.tensor([elapsed, float(edges)], dtype=torch.float64,
                          device=dev if backend == "nccl" else "cpu")
@@ -273,7 +273,7 @@ def main():
         # dominant kernel by bytes: the fused feature gather (one launch per block)
         # algorithmic bytes per launch (all launches) / average duration of the launches
         # that carried events (every event_stride-th one)
-        n_launches = cache.num_gather_launches - launches_before
+        n_launches = int(g_all.value)
         bytes_per_launch = gather_bytes / max(n_launches, 1)
         avg_us = 1e3 * g_ms.value / g_n.value
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9

@@ -131,6 +131,7 @@ PROTOTYPES = {
     "gf_profile_reset": (C.c_int, []),
     "gf_profile_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "gf_profile_set_stride": (C.c_int, [C.c_uint]),
+    "gf_profile_launches": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

@@ -613,6 +613,13 @@ int gf_profile_reset(void) {
   }
   return GF_OK;
 }
+int gf_profile_launches(int which, uint64_t* launches) {
+  return guarded([&] {
+    GF_REQUIRE(which >= 0 && which < gf::kProfSlots && launches, "gf_profile_launches: bad argument");
+    std::lock_guard<std::mutex> lk(gf::g_prof_mu);
+    *launches = gf::g_prof_seq[which];
+  });
+}
 int gf_profile_set_stride(unsigned stride) {
   std::lock_guard<std::mutex> lk(gf::g_prof_mu);
   gf::g_prof_stride = stride ? stride : 1;

@@ -1073,6 +1073,13 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
   }
   const int device = node ? node->device() : (edge ? edge->device() : 0);
   DeviceGuard dg(device);
+  // size each cache's scratch for its largest block up front: no reallocation (and device
+  // synchronisation) between the rounds of one fetch
+  size_t max_node_rows = 0, max_edge_rows = 0;
+  for (const gf_fetch_desc* d : nodes) max_node_rows = std::max(max_node_rows, d->n);
+  for (const gf_fetch_desc* d : edges) max_edge_rows = std::max(max_edge_rows, d->n);
+  if (node && max_node_rows) node->reserve_workspace(max_node_rows);
+  if (edge && max_edge_rows) edge->reserve_workspace(max_edge_rows);
   size_t pi = 0;
   const size_t rounds = std::max(nodes.size(), edges.size());
   for (size_t i = 0; i < rounds; ++i) {

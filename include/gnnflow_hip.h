@@ -366,6 +366,8 @@ GF_API int gf_profile_get(int which, double* total_ms, uint64_t* launches);
  * host time and a few microseconds of stream time per launch, which a latency-bound
  * workload feels; gf_profile_get then reports the sampled intervals. */
 GF_API int gf_profile_set_stride(unsigned stride);
+/* All launches of a family seen since the last reset while it was enabled, timed or not. */
+GF_API int gf_profile_launches(int which, uint64_t* launches);
 
 #ifdef __cplusplus
 }

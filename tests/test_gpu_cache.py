@@ -362,3 +362,13 @@ def test_fuzzed_cache_sequences_match_oracle(seed):
     resets = tuple(int(x) for x in rng.choice(nb, size=int(rng.randint(0, 2)), replace=False))
     _run_against_oracle(N=N, E=E, dn=dn, de=de, ratio=ratio, batches=batches, seed=seed,
                         skew=float(rng.choice([0.0, 0.7, 1.4])), policy=policy, reset_after=resets)
+
+
+@pytest.mark.parametrize("policy", ["lru", "lfu", "fifo"])
+@pytest.mark.parametrize("second", [4096, 4097, 6000, 16385])
+def test_two_large_blocks_per_fetch_around_the_row_tile_size(policy, second):
+    """Two edge blocks per fetch whose second one sits at / just over one scan row tile (4096)
+    and at several tiles: duplicates, overflow of the capacity, resets, all three policies."""
+    _run_against_oracle(N=900, E=20000, dn=8, de=12, ratio=0.05,
+                        batches=[(500, (7000, second)), (300, (50, second)), (900, (9000, 1))] * 2,
+                        seed=40 + second % 7, skew=0.9, policy=policy, reset_after=(2,))
