@@ -465,14 +465,24 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   pt.mark("validate");
   // 3. bookkeeping sets (dynamic_graph.cu:89-103)
   add_nodes(max_node);
-  for (size_t i = 0; i < n; ++i) {
-    uint8_t& s = seen_[src[i]];
-    if (!(s & 1)) { s |= 1; num_nodes_++; }
-    if (!(s & 2)) { s |= 2; num_src_nodes_++; }
-    uint8_t& d = seen_[dst[i]];
-    if (!(d & 1)) { d |= 1; num_nodes_++; }
-  }
-  bump_eids(eids, n);
+  auto update_sets = [&] {
+    for (size_t i = 0; i < n; ++i) {
+      uint8_t& s = seen_[src[i]];
+      if (!(s & 1)) { s |= 1; num_nodes_++; }
+      if (!(s & 2)) { s |= 2; num_src_nodes_++; }
+      uint8_t& d = seen_[dst[i]];
+      if (!(d & 1)) { d |= 1; num_nodes_++; }
+    }
+    bump_eids(eids, n);
+  };
+  // The id sets share nothing with the planning below (seen_ / eid counters vs nodes_ and the
+  // segment allocator), so big batches update them on a helper thread meanwhile.
+  struct Joiner {
+    std::thread t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } sets_thread;
+  if (n >= (size_t(1) << 18)) sets_thread.t = std::thread(update_sets);
+  else update_sets();
 
   pt.mark("sets");
   // 4. plan: logical blocks, physical segments, per-group destinations
@@ -508,6 +518,7 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     touched.push_back(gr.v);
   }
   ensure_pool(bump_);
+  if (sets_thread.t.joinable()) sets_thread.t.join();
 
   pt.mark("plan");
   // 5. device: relocate grown segments, then scatter the batch, then publish entries
