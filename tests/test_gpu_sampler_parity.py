@@ -264,3 +264,33 @@ def test_fuzzed_configurations_bit_exact(seed):
         nodes, t = synth.random_roots(N, R, 1000.0, seed=seed * 10 + it, extra_ids=[N + 2])
         _cmp_blocks(hs.sample(nodes, t), os_.sample(nodes, t), "seed={} cfg={}".format(seed, cfg))
     assert g.num_edges() == o.num_edges() and g.num_vertices() == o.num_vertices()
+
+
+def test_million_edge_batch_in_one_call():
+    """One add_edges call of > 2^20 edges (threaded gathers, id sets on the helper thread):
+    unsorted timestamps inside the batch, ties, reverse edges, a sparse high source id — graph
+    state and samples must equal the oracle's."""
+    import gnnflow_amd
+    from oracle import oracle as O
+    N, E = 40000, 700000            # x2 with reverse edges = 1.4 M per call
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=77, tie_levels=2000)
+    rng = np.random.RandomState(1)
+    p = rng.permutation(E)          # arbitrary order inside the batch
+    src, dst, ts, eid = src[p], dst[p], ts[p], eid[p]
+    src[:3] = N + 70000             # far beyond the dense id range: several empty buckets
+    g, o = _graphs(min_block=16)
+    g.add_edges(src, dst, ts, eid, add_reverse=True)
+    o.add_edges(src, dst, ts, eid, add_reverse=True)
+    assert g.num_edges() == o.num_edges() and g.num_vertices() == o.num_vertices()
+    assert g.num_source_vertices() == o.num_source_vertices()
+    assert g.max_vertex_id() == o.max_vertex_id()
+    ids = rng.randint(0, N, 2000)
+    assert np.array_equal(g.out_degree(ids), o.out_degree(ids))
+    assert g.get_graph_memory_usage() == o.get_graph_memory_usage()
+    for v in [int(ids[0]), int(src[0]), int(np.bincount(src[3:]).argmax())]:
+        for a, b in zip(g.get_temporal_neighbors(v), o.get_temporal_neighbors(v)):
+            assert np.array_equal(a, b), v
+    hs = gnnflow_amd.TemporalSampler(g, [10, 5])
+    os_ = O.OracleSampler(o, [10, 5])
+    nodes, t = synth.random_roots(N, 3000, 1000.0, seed=5, extra_ids=[N + 70000])
+    _cmp_blocks(hs.sample(nodes, t), os_.sample(nodes, t), "after a 1.4 M-edge batch")
