@@ -26,6 +26,7 @@ class LRUKind:
 
     def __init__(self, num_ids, capacity, feats, overflow_rule="first_seen", policy="lru"):
         self.policy = policy          # "lru" | "lfu" | "fifo"
+        self.updates = 0              # update_*_cache calls since init (LRU: -count of an untouched slot)
         self.pointer = int(capacity) - 1   # fifo_cache.py:66-69
         self.num_ids, self.capacity = int(num_ids), int(capacity)
         self.feats = np.ascontiguousarray(feats, np.float32)
@@ -48,6 +49,7 @@ class LRUKind:
         self.index_to_id = ids.astype(np.int64)
         self.map[ids] = ids
         self.count[:] = 1 if self.policy == "lfu" else 0     # lfu_cache.py:80-84
+        self.updates = 0
         self.pointer = self.capacity - 1
 
     def reset_order(self):   # fifo_cache.py:70-75 (pointer) / lfu_cache.py:118 (count.zero_())
@@ -78,6 +80,7 @@ class LRUKind:
     def _update(self, cached_index, uncached_ids):
         k = min(len(uncached_ids), self.capacity)
         ids_to_cache = uncached_ids[:k]
+        self.updates += 1
         if self.policy == "fifo":
             C, p = self.capacity, self.pointer
             if p + k < C:
@@ -116,6 +119,23 @@ class LRUKind:
     def cached_ids(self):
         return np.sort(self.index_to_id[self.index_to_id >= 0])
 
+    # Cache.resize / LRUCache.resize (cache.py:197-221, lru_cache.py:107-119).  The reference
+    # grows its tensors with torch's resize_, which leaves the new elements UNINITIALISED;
+    # the deterministic completion used here and in the HIP path: new ids are uncached, new
+    # slots are empty and as old as a slot never touched since init_cache (LRU), unused
+    # (LFU, count 0), or simply further along the ring (FIFO, pointer unchanged).
+    def resize(self, num_ids, capacity, feats):
+        num_ids, capacity = int(num_ids), max(int(capacity), self.capacity)
+        add_ids, add_slots = num_ids - self.num_ids, capacity - self.capacity
+        self.feats = np.ascontiguousarray(feats, np.float32)
+        self.flag = np.concatenate([self.flag, np.zeros(add_ids, bool)])
+        self.map = np.concatenate([self.map, np.full(add_ids, -1, np.int64)])
+        self.buffer = np.concatenate([self.buffer, np.zeros((add_slots, self.dim), np.float32)])
+        self.index_to_id = np.concatenate([self.index_to_id, np.full(add_slots, -1, np.int64)])
+        fill = -self.updates if self.policy == "lru" else 0
+        self.count = np.concatenate([self.count, np.full(add_slots, fill, np.int32)])
+        self.num_ids, self.capacity = num_ids, capacity
+
 
 class OracleLRUCache:
     """Cache + LRUCache protocol over MFG-like blocks with numpy srcdata/edata."""
@@ -124,6 +144,8 @@ class OracleLRUCache:
                  node_feats=None, edge_feats=None, dim_node_feat=0, dim_edge_feat=0,
                  overflow_rule="first_seen", policy="lru"):
         self.node = self.edge = None
+        self.node_cache_ratio, self.edge_cache_ratio = node_cache_ratio, edge_cache_ratio
+        self.num_nodes, self.num_edges = int(num_nodes), int(num_edges)
         self.node_capacity = int(node_cache_ratio * num_nodes)   # cache.py:82
         self.edge_capacity = int(edge_cache_ratio * num_edges)   # cache.py:83
         if dim_node_feat:
@@ -140,6 +162,16 @@ class OracleLRUCache:
             self.node.init()
         if self.edge:
             self.edge.init()
+
+    def resize(self, new_num_nodes, new_num_edges, node_feats=None, edge_feats=None):
+        if self.node and new_num_nodes > self.num_nodes:
+            self.num_nodes = new_num_nodes
+            self.node_capacity = max(int(self.node_cache_ratio * new_num_nodes), self.node_capacity)
+            self.node.resize(new_num_nodes, self.node_capacity, node_feats)
+        if self.edge and new_num_edges > self.num_edges:
+            self.num_edges = new_num_edges
+            self.edge_capacity = max(int(self.edge_cache_ratio * new_num_edges), self.edge_capacity)
+            self.edge.resize(new_num_edges, self.edge_capacity, edge_feats)
 
     def reset(self):   # lru/lfu: only the edge cache is re-initialised; fifo: pointer rewind
         if self.edge:

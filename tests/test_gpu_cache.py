@@ -372,3 +372,57 @@ def test_two_large_blocks_per_fetch_around_the_row_tile_size(policy, second):
     _run_against_oracle(N=900, E=20000, dn=8, de=12, ratio=0.05,
                         batches=[(500, (7000, second)), (300, (50, second)), (900, (9000, 1))] * 2,
                         seed=40 + second % 7, skew=0.9, policy=policy, reset_after=(2,))
+
+
+@pytest.mark.parametrize("policy", ["lru", "lfu", "fifo"])
+def test_resize_grows_id_space_and_capacity_keeping_the_contents(policy):
+    """Cache.resize (cache.py:197-221): after the graph has grown, cached ids still hit with
+    the right rows, the new ids are served from the new tables and get cached, the capacity
+    follows the ratio, and the replacement order continues (new slots are empty and oldest /
+    unused / next on the FIFO ring).  The reference leaves the new elements uninitialised
+    (torch resize_); the oracle holds the deterministic completion."""
+    import torch
+    from oracle.cache_oracle import OracleLRUCache
+    rng = np.random.RandomState(71)
+    N0, E0, N1, E1, dn, de = 200, 1000, 330, 1700, 8, 12
+    nf = rng.rand(N1, dn).astype(np.float32)
+    ef = rng.rand(E1, de).astype(np.float32)
+    hip = _cls(policy)(0.2, 0.2, N0, E0, "cuda:0", torch.from_numpy(nf[:N0]),
+                       torch.from_numpy(ef[:E0]), dn, de)
+    ora = OracleLRUCache(0.2, 0.2, N0, E0, nf[:N0], ef[:E0], dn, de,
+                         overflow_rule="first_seen", policy=policy)
+    hip.init_cache()
+    ora.init_cache()
+
+    def batch(N, E, bi):
+        src = rng.randint(0, N, 150).astype(np.int64)
+        e0 = rng.randint(0, E, 260).astype(np.int64)
+        e1 = rng.randint(0, E, 40).astype(np.int64)
+        eid = rng.randint(0, E, 9).astype(np.int64)
+        hb = [[Blk(_to_ids(src), _to_ids(e0))], [Blk(_to_ids(src[:30]), _to_ids(e1))]]
+        ob = [[Blk(src, e0)], [Blk(src[:30], e1)]]
+        hip.fetch_feature(hb, eid)
+        ora.fetch_feature(ob, eid)
+        assert np.array_equal(_to_np(hb[0][0].srcdata["h"]), ob[0][0].srcdata["h"]), bi
+        for li in range(2):
+            assert np.array_equal(_to_np(hb[li][0].edata["f"]), ob[li][0].edata["f"]), bi
+        assert float(hip.cache_node_ratio) == pytest.approx(ora.cache_node_ratio, abs=1e-6), bi
+        assert float(hip.cache_edge_ratio) == pytest.approx(ora.cache_edge_ratio, abs=1e-6), bi
+        for kind, okind in ((hip._node, ora.node), (hip._edge, ora.edge)):
+            ids = kind.slot_ids()
+            assert np.array_equal(np.sort(ids[ids >= 0]), okind.cached_ids()), bi
+
+    for bi in range(4):
+        batch(N0, E0, bi)
+    hip.node_feats, hip.edge_feats = torch.from_numpy(nf), torch.from_numpy(ef)
+    before = hip.get_mem_size()
+    hip.resize(N1, E1)
+    ora.resize(N1, E1, nf, ef)
+    assert (hip.num_nodes, hip.num_edges) == (N1, E1)
+    assert (hip.node_capacity, hip.edge_capacity) == (int(0.2 * N1), int(0.2 * E1)) == \
+        (ora.node_capacity, ora.edge_capacity)
+    assert hip.get_mem_size() > before
+    for bi in range(4, 10):
+        batch(N1, E1, bi)
+    with pytest.raises(ValueError):        # the caller must supply tables that cover the new ids
+        hip.resize(N1 + 50, E1)
