@@ -193,3 +193,18 @@ def test_early_stop_monitor():
     assert m.best_epoch == 1 and m.epoch_count == 4
     low = U.EarlyStopMonitor(max_round=1, higher_better=False)
     assert [low.early_stop_check(v) for v in (1.0, 0.5, 0.7)] == [False, False, True]
+
+
+def test_small_helpers(tmp_path):
+    import pandas as pd
+    os.makedirs(tmp_path / "TOY")
+    pd.DataFrame({"src": [0, 1, 2], "dst": [3, 4, 5], "time": [0.1, 0.2, 0.3],
+                  "ext_roll": [0, 1, 2]}).to_csv(tmp_path / "TOY" / "edges.csv")
+    chunks = list(U.load_dataset_in_chunks("TOY", data_dir=str(tmp_path), chunksize=2))
+    assert [len(c) for c in chunks] == [2, 1]
+    assert set(chunks[0].columns) == {"src", "dst", "time", "Unnamed: 0", "ext_roll"}
+    with pytest.raises(ValueError):
+        U.load_dataset_in_chunks("NOPE", data_dir=str(tmp_path))
+    assert U.get_pinned_buffers([10, 10], 1, 600, 172, 172) == ([], [])
+    assert os.path.isdir(os.path.join(U.get_project_root_dir(), "gnnflow_amd"))
+    assert U.get_node_feats() is None
