@@ -11,6 +11,17 @@ stream: TemporalSampler.sample() (2 layers, fanout [10,10], most-recent, 1800 ro
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+The workload is the CHRONOLOGICAL REPLAY of the whole stream (1121 batches): early
+batches sample almost nothing and late ones ~25k edges, and the LRU cache only behaves
+like the real thing when consecutive batches follow each other.  So the timed region is
+`repeats` back-to-back windows of K consecutive batches, starting at batch 0 on a freshly
+initialised cache and wrapping around at the end of the stream, with
+repeats = ceil(4 * 1121 / K) unless --repeats says otherwise: whatever K is, the region
+covers >= 4 whole replays (>= 0.2 s) and edges_per_step is the full-replay mean.
+ms_per_step = elapsed / (K * repeats).  The loop itself is
+gnnflow_amd.pipeline.ReplayPipeline.run — the function tests/test_gpu_pipeline_parity.py
+checks against the oracle.
+
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline":     feature-gather kernel, algorithmic bytes / HIP-event time vs 8 TB/s
   "cpu_baseline": the CPU oracle (C port of the reference algorithm) timed on this
@@ -31,6 +42,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+PMC_TRAFFIC_FILE = "r02_pmc_gather_traffic.json"
+
+
+def workload_key(args, repeats):
+    """What a committed PMC traffic measurement must have been taken with to be quoted."""
+    return {"steps": args.steps, "repeats": repeats, "warmup": args.warmup,
+            "batch_size": args.batch_size, "fanouts": args.fanouts, "strategy": args.strategy,
+            "cache_ratio": args.cache_ratio, "undirected": bool(args.undirected),
+            "feature_placement": args.feature_placement, "partition": args.partition,
+            "pipelined": not args.no_pipeline, "sample_only": bool(args.sample_only)}
 
 
 def parse():
@@ -38,6 +59,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1121)   # one full chronological replay
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="windows of --steps consecutive batches in the timed region "
+                         "(0 = enough for --min-replays whole replays of the stream)")
+    ap.add_argument("--min-replays", type=float, default=4.0)
     ap.add_argument("--batch-size", type=int, default=600)
     ap.add_argument("--fanouts", type=str, default="10,10")
     ap.add_argument("--strategy", type=str, default="recent")
@@ -60,17 +85,6 @@ def parse():
     ap.add_argument("--breakdown", action="store_true",
                     help="extra untimed pass with per-kernel-family HIP-event times")
     return ap.parse_args()
-
-
-def algorithmic_bytes_gather(mfgs, d_e, d_n):
-    """sum_blocks E_b*(8 + 2*4*d_e) + N_src(mfgs[0])*(8 + 2*4*d_n)."""
-    b = 0
-    for mfg in mfgs:
-        for blk in mfg:
-            b += blk.num_edges() * (8 + 8 * d_e)
-    for blk in mfgs[0]:
-        b += blk.num_src_nodes() * (8 + 8 * d_n)
-    return b
 
 
 def main():
@@ -138,87 +152,57 @@ def main():
 
     # this rank's share of the chronological replay, resident in HBM
     batches = list(synthetic.replay_batches(g, args.batch_size, seed=42))
-    mine = batches[rank::world] if world > 1 else batches
-    need = args.steps + args.warmup
-    dev_batches = []
-    for i in range(min(need, len(mine))):
-        r, t, e = mine[i]
-        dev_batches.append((torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev),
-                            torch.from_numpy(e).to(dev)))
-
-    def step(i):
-        r, t, e = dev_batches[i % len(dev_batches)]
-        mfgs = sampler.sample(r, t)
-        if cache is not None:
-            cache.fetch_feature(mfgs, e)
-        return mfgs
+    nb = len(batches) // world            # same on every rank (a longer share loses its tail)
+    mine = (batches[rank::world] if world > 1 else batches)[:nb]
+    dev_batches = [(torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev),
+                    torch.from_numpy(e).to(dev)) for r, t, e in mine]
+    repeats = args.repeats if args.repeats > 0 else \
+        max(1, -(-int(args.min_replays * nb) // max(args.steps, 1)))
+    timed_steps = args.steps * repeats
 
     # Software pipeline (the reference's training loop prefetches the next batch's
     # sample() on a Python thread, scripts/offline_edge_prediction.py:343-346,397-399):
-    # batch i+1's sample() is enqueued on a side HIP stream (sample_async) before batch
-    # i's fetch_feature() is issued on the main stream, so the two overlap on the GPU.
-    # Every batch still goes through the same calls; nothing is skipped or cached.
-    pipelined = cache is not None and not args.no_pipeline
-    side = torch.cuda.Stream(device=dev) if pipelined else None
-
-    def run_steps(first, count, on_step=None):
-        """Runs `count` steps starting at batch `first`; calls on_step(mfgs) after each."""
-        if not pipelined:
-            for i in range(first, first + count):
-                mfgs = step(i)
-                if on_step:
-                    on_step(mfgs)
-            return
-        main = torch.cuda.current_stream(dev)
-        nb = len(dev_batches)
-        pending = sampler.sample_async(dev_batches[first % nb][0], dev_batches[first % nb][1],
-                                       stream=side, worker_enqueue=True)
-        for i in range(first, first + count):
-            mfgs = pending.wait()
-            if i + 1 < first + count:
-                r, t, _ = dev_batches[(i + 1) % nb]
-                pending = sampler.sample_async(r, t, stream=side, worker_enqueue=True)
-            for mfg in mfgs:
-                for b in mfg:
-                    b.record_stream(main)
-            cache.fetch_feature(mfgs, dev_batches[i % nb][2], async_enqueue=True)
-            if on_step:
-                on_step(mfgs)
-        cache.wait_enqueued()
+    # batch i+1's sample() is enqueued on a side HIP stream before batch i's
+    # fetch_feature() is issued on the main stream.  Every batch goes through the same
+    # calls; nothing is skipped or cached.  gnnflow_amd/pipeline.py, parity-tested.
+    from gnnflow_amd.pipeline import ReplayPipeline
+    pipe = ReplayPipeline(sampler, cache, dev_batches, dev,
+                          pipelined=cache is not None and not args.no_pipeline)
+    pipelined = pipe.pipelined
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(0, args.warmup)
-    # the timed region replays from the first batch again: LRU state starts from reset
+    pipe.run(0, args.warmup)
+    # the timed region replays from the first batch on a freshly initialised cache
     if cache is not None:
         cache.init_cache()
+        cache.algorithmic_bytes = 0
     lib.gf_profile_reset()
-    # HIP events around the gather launches of the timed region, on their stream.  Every
-    # 17th launch is timed (odd stride: both rounds of a step get sampled in turn; timing
-    # every 5th cost 9 us per step, every 17th < 1 us): an event pair costs
-    # ~5 us of stream time, which at ~90 us per step would distort the throughput measured
-    # in the same pass.
+    # HIP events on the gather launches of the timed region, on their stream.  Every 17th
+    # launch is timed: an event pair costs stream time, which at ~50 us per step would
+    # distort the throughput measured in the same pass.
     lib.gf_profile_set_stride(args.event_stride)
     lib.gf_profile_enable(1 << _capi.PROFILE_SLOTS["gather"])
     barrier()
     t0 = time.perf_counter()
-    acc = {"edges": 0, "bytes": 0}
+    acc = {"edges": 0}
 
-    def account(mfgs):
+    def account(_i, mfgs):
         for mfg in mfgs:
             for b in mfg:
                 acc["edges"] += b.num_edges()
-        if cache is not None:
-            acc["bytes"] += algorithmic_bytes_gather(mfgs, d_e, d_n) + \
-                args.batch_size * 8 * d_e   # target_edge_features rows (read + write)
 
-    run_steps(0, args.steps, account)
+    pipe.run(0, timed_steps, account)
     barrier()
-    edges, gather_bytes = acc["edges"], acc["bytes"]
     elapsed = time.perf_counter() - t0
+    edges = acc["edges"]
+    # rows x (8 B id + 2 x 4 x d B row read + write), summed by the cache
+    # over the rows its gather launches really moved (a block served as a prefix of
+    # another block's rows moves nothing and counts nothing)
+    gather_bytes = cache.algorithmic_bytes if cache is not None else 0
     lib.gf_profile_enable(0)
     lib.gf_profile_set_stride(1)
 
@@ -238,14 +222,19 @@ def main():
     else:
         elapsed_max, edges_all = elapsed, float(edges)
 
+    share = "" if world == 1 else " of this rank's share (every {}th batch)".format(world)
+    window = "batches 0..{}{} in chronological order, {:.2f} times over".format(
+        nb - 1, share, timed_steps / nb) if timed_steps >= nb else \
+        "batches 0..{}{} in chronological order".format(timed_steps - 1, share)
     out = {
         "metric": "sampled_edges_per_s",
         "value": edges_all / elapsed_max,
         "unit": "edges/s",
         "n_gpus": world,
         "steps": args.steps,
+        "repeats": repeats,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed_max / args.steps,
+        "ms_per_step": 1e3 * elapsed_max / timed_steps,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -253,16 +242,22 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "REDDIT-shaped synthetic (10984 nodes, 672447 edges, directed), "
-                        "2-layer fanout [{}] {} sampling, batch {} (1800 roots), "
+                        "2-layer fanout [{}] {} sampling, batch {} ({} roots), "
                         "LRUCache ratio {} + 172-d edge/node feature gather; "
-                        "step = sample() + fetch_feature()".format(
-                            args.fanouts, args.strategy, args.batch_size, args.cache_ratio)
+                        "step = sample() + fetch_feature(); timed region = {} windows of {} "
+                        "consecutive steps: {}".format(
+                            args.fanouts, args.strategy, args.batch_size, 3 * args.batch_size,
+                            args.cache_ratio, repeats, args.steps, window)
             if cache is not None else
             "REDDIT-shaped synthetic, 2-layer fanout [{}] {} sampling, batch {}; "
-            "step = sample() only".format(args.fanouts, args.strategy, args.batch_size),
+            "step = sample() only; timed region = {} windows of {} consecutive steps: "
+            "{}".format(args.fanouts, args.strategy, args.batch_size, repeats, args.steps,
+                        window),
             "batch_size": args.batch_size,
             "roots_per_step": 3 * args.batch_size,
-            "edges_per_step": edges / max(args.steps, 1),
+            "timed_steps": timed_steps,
+            "timed_seconds": elapsed_max,
+            "edges_per_step": edges / max(timed_steps, 1),
             "feature_placement": args.feature_placement,
             "graph_build_s": round(build_s, 3),
             "parallelism": "{}-dp{}".format(args.partition, world),
@@ -270,7 +265,7 @@ def main():
         },
     }
     if cache is not None and g_n.value:
-        # dominant kernel by bytes: the fused feature gather (one launch per block)
+        # dominant kernel by bytes: the fused feature gather (one launch per fetch round):
         # algorithmic bytes per launch (all launches) / average duration of the launches
         # that carried events (every event_stride-th one)
         n_launches = int(g_all.value)
@@ -286,23 +281,23 @@ def main():
             "algorithmic_bytes_per_launch": bytes_per_launch,
         }
         # HBM traffic of the same kernel from PMC counters (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate passes of this command, gfx950 FETCH x2 correction);
-        # collected offline by scripts/rocprof_pmc.sh and committed under profiles/
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gather_traffic.json")
-        default_cfg = (args.steps == 1121 and args.batch_size == 600 and args.fanouts == "10,10"
-                       and args.strategy == "recent" and args.cache_ratio == 0.2
-                       and not args.undirected and args.feature_placement == "device")
-        if default_cfg and os.path.exists(pmc):
+        # WRITE_SIZE in separate passes over THIS command line, gfx950 FETCH x2 correction;
+        # scripts/rocprof_pmc.sh).  Attached only when the committed measurement was taken
+        # with the arguments of this run.
+        pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+        if os.path.exists(pmc):
             with open(pmc) as f:
-                out["roofline"]["traffic"] = json.load(f)["hbm_traffic_bytes_per_dispatch"]
-            out["roofline"]["traffic_source"] = "profiles/r01_pmc_gather_traffic.json"
+                rec = json.load(f)
+            if rec.get("bench_args") == workload_key(args, repeats):
+                out["roofline"]["traffic"] = rec["hbm_traffic_bytes_per_dispatch"]
+                out["roofline"]["traffic_source"] = "profiles/" + PMC_TRAFFIC_FILE
         out["cache_edge_ratio"] = float(cache.cache_edge_ratio)
         out["cache_node_ratio"] = float(cache.cache_node_ratio)
 
     if args.breakdown and rank == 0:
         lib.gf_profile_reset()
         lib.gf_profile_enable(0x1F)
-        run_steps(0, min(args.steps, 200))
+        pipe.run(0, min(timed_steps, 200))
         torch.cuda.synchronize()
         lib.gf_profile_enable(0)
         bd = {}
@@ -313,8 +308,9 @@ def main():
         out["kernel_breakdown_200_steps"] = bd
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(g, batches, fanouts, args, edge_feats.cpu().numpy(),
-                                           node_feats.cpu().numpy(), cache is not None)
+        out["cpu_baseline"] = cpu_baseline(g, batches[:min(timed_steps, nb)], fanouts, args,
+                                           edge_feats.cpu().numpy(), node_feats.cpu().numpy(),
+                                           cache is not None)
     if rank == 0:
         print(json.dumps(out))
     if dist.is_initialized():
@@ -352,10 +348,10 @@ def usable_cores(cap=32):
 
 def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather):
     """The CPU oracle (oracle/gnnflow_oracle.c: C port of the reference's block-walking
-    sampler + cache-free gather) on a bounded sample of the same batches — whole
-    chronological replays — once on one thread and once on all the host cores this process
-    may use (OpenMP over the roots / rows; same routine, identical output).  `value` is the
-    faster of the two with its `cores`.  Reported baseline, not the target."""
+    sampler + cache-free gather) on exactly the batches of the GPU's timed region, in whole
+    passes — once on one thread and once on all the host cores this process may use (OpenMP
+    over the roots / rows; same routine, identical output).  `value` is the faster of the two
+    with its `cores`.  Reported baseline, not the target."""
     from oracle import oracle as O
     og = O.OracleGraph(minimum_block_size=62, insertion_policy="insert")
     for lo in range(0, g["num_edges"], 100000):
@@ -365,11 +361,12 @@ def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather)
     all_cores = usable_cores()
 
     def run(threads, budget_s):
+        """Whole passes over `batches` (the batch sequence of the GPU's timed region, so
+        edges per step are the same on both sides) until the budget is spent; >= 1 pass."""
         osamp = O.OracleSampler(og, fanouts, args.strategy, seed=1234, threads=threads)
-        edges, t_total, n_done = 0, 0.0, 0
-        while t_total < budget_s:
-            for bi in range(len(batches)):
-                r, t, e = batches[bi]
+        edges, t_total, n_done, passes = 0, 0.0, 0, 0
+        while passes == 0 or t_total < budget_s:
+            for r, t, e in batches:
                 t0 = time.perf_counter()
                 mfgs = osamp.sample(r, t)
                 if with_gather:
@@ -383,10 +380,10 @@ def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather)
                 t_total += time.perf_counter() - t0
                 edges += sum(b.num_edges() for mfg in mfgs for b in mfg)
                 n_done += 1
-                if t_total > budget_s and (n_done >= 200 or t_total > 2 * budget_s):
-                    break
-        return dict(value=edges / t_total, cores=threads, batches=n_done, seconds=t_total,
-                    ms_per_step=1e3 * t_total / max(n_done, 1))
+            passes += 1
+        return dict(value=edges / t_total, cores=threads, batches=n_done, passes=passes,
+                    seconds=t_total, ms_per_step=1e3 * t_total / max(n_done, 1),
+                    edges_per_step=edges / max(n_done, 1))
 
     one = run(1, args.cpu_seconds / 2)
     runs = [one]
@@ -395,14 +392,16 @@ def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather)
     best = max(runs, key=lambda r: r["value"])
     return {
         "value": best["value"], "unit": "edges/s", "cores": best["cores"], "kind": "port",
-        "sample": "{} batches = {:.2f} chronological replays of the same {}-batch stream per run "
-                  "({:.1f} s of CPU work in all; oracle sample() + cache-free gather, gcc -O2 "
-                  "-fopenmp): {}".format(
-                      best["batches"], best["batches"] / len(batches), len(batches),
-                      sum(r["seconds"] for r in runs),
-                      "; ".join("{} thread{}: {:.2f} M edges/s".format(
-                          r["cores"], "" if r["cores"] == 1 else "s", r["value"] / 1e6) for r in runs)),
+        "sample": "batches 0..{} of the chronological replay — the batch sequence of the GPU's "
+                  "timed region — in whole passes ({:.1f} s of CPU work in all; oracle sample() "
+                  "+ cache-free gather of every block, no LRU bookkeeping; gcc -O2 -fopenmp): "
+                  "{}".format(
+                      len(batches) - 1, sum(r["seconds"] for r in runs),
+                      "; ".join("{} thread{}: {} pass{} = {:.2f} M edges/s".format(
+                          r["cores"], "" if r["cores"] == 1 else "s", r["passes"],
+                          "" if r["passes"] == 1 else "es", r["value"] / 1e6) for r in runs)),
         "ms_per_step": best["ms_per_step"],
+        "edges_per_step": best["edges_per_step"],
         "single_thread_value": one["value"],
     }
 

@@ -136,6 +136,9 @@ class Cache:
         self._ticket = 0
         self._pending_refs = None
         self.feature_placement = placement
+        # serve an edge block that is a prefix of the previously fetched one from that
+        # block's rows (LRU only; fetch_feature); GNNFLOW_PREFIX_ALIAS=0 turns it off
+        self.prefix_alias = os.environ.get('GNNFLOW_PREFIX_ALIAS', '1') != '0'
 
         self._lib = _capi.load()
         self._node = self._edge = None
@@ -149,6 +152,9 @@ class Cache:
         self._stats_span = None
         self._target_edge_thunk = None
         self.num_gather_launches = 0   # gather launches issued so far (one per round)
+        # rows x (8 B id + 2 x 4 x dim B) over every row the gather launches moved so far
+        # (SURVEY.md 8(d) algorithmic bytes; read by bench.py's roofline)
+        self.algorithmic_bytes = 0
 
     def __del__(self):
         for k in (getattr(self, "_node", None), getattr(self, "_edge", None)):
@@ -157,26 +163,30 @@ class Cache:
 
     # ---- hit ratios: mean over blocks of hits/len (cache.py:277,323,337,400) ---------
     @staticmethod
-    def _ratio(stats):
-        # stats[b] = 16 x int32: hits in the even words (8 shards), n in word 1
+    def _ratio(stats, all_hit_blocks=0):
+        # stats[b] = 16 x int32: hits in the even words (8 shards), n in word 1;
+        # all_hit_blocks: blocks served as a prefix of another block's rows (ratio 1 each)
         if stats is None or stats.shape[0] == 0:
-            return 0
+            return 1.0 if all_hit_blocks else 0
         s = stats.to(torch.float32)
-        return (s[:, 0::2].sum(dim=1) / s[:, 1]).mean()
+        r = s[:, 0::2].sum(dim=1) / s[:, 1]
+        if all_hit_blocks:
+            return (r.sum() + all_hit_blocks) / (r.shape[0] + all_hit_blocks)
+        return r.mean()
 
     @property
     def cache_node_ratio(self):
         if self._node is None or self._stats_span is None:
             return 0
-        pos, n_node, n_cached, ring = self._stats_span
+        pos, n_node, n_cached, ring, _ = self._stats_span
         return self._ratio(ring[pos:pos + n_node])
 
     @property
     def cache_edge_ratio(self):
         if self._edge is None or self._stats_span is None:
             return 0
-        pos, n_node, n_cached, ring = self._stats_span
-        return self._ratio(ring[pos + n_node:pos + n_cached])
+        pos, n_node, n_cached, ring, n_alias = self._stats_span
+        return self._ratio(ring[pos + n_node:pos + n_cached], n_alias)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -293,13 +303,37 @@ class Cache:
             for b in mfgs[0]:
                 jobs.append((0,) + self._id_array(b, "src") + (dim, b, "src", "h"))
         n_node = len(jobs)
+        aliases = []      # (block, index of the job whose output rows start with this block's, n)
         if self._edge is not None:
             dim = self.dim_edge_feat
+            # Edge blocks are fetched in the reference's order (cache.py:329-331).  A block
+            # whose edge ids are a prefix of the block fetched just before it (see
+            # TemporalSampler._finish) needs no second lookup under LRU: after the outer
+            # block's update every id of that block is cached as long as the block has no
+            # more rows than the cache has slots (hit slots carry the newest stamp, so the
+            # k = #distinct misses <= capacity - #hit slots victims are all other slots and
+            # every miss is installed) -> the inner block is all hits, which changes no
+            # replacement state (cache.py:318-321,395-398) and fetches rows equal to the
+            # first rows of the outer block's output.  Its rows alias that output and its
+            # hit ratio is 1.  DESIGN.md 3.4c.
+            can_alias = (upd and self._policy == "lru" and self.prefix_alias
+                         and all(len(mfg) == 1 for mfg in mfgs))
+            prev = None   # (block, owner job index) of the previous edge block
             for mfg in mfgs:
                 for b in mfg:
                     job = (1,) + self._id_array(b, "e") + (dim, b, "e", "f")
-                    if job[2] > 0:
-                        jobs.append(job)
+                    n = job[2]
+                    if n <= 0:
+                        prev = None
+                        continue
+                    if can_alias and prev is not None and job[3] is b \
+                            and getattr(b, "_edge_prefix_of", None) is prev[0] \
+                            and n <= jobs[prev[1]][2] <= self.edge_capacity:
+                        aliases.append((b, prev[1], n))
+                        prev = (b, prev[1])
+                        continue
+                    jobs.append(job)
+                    prev = (b, len(jobs) - 1) if job[3] is b else None
         n_cached = len(jobs)
         if self._edge is not None and target_edge_features and eid is not None:
             t = self._ids(eid)
@@ -308,8 +342,8 @@ class Cache:
             return mfgs
         if torch.cuda.current_device() != dev.index:
             with torch.cuda.device(dev):
-                return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue)
-        return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue)
+                return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
+        return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
 
     def _id_array(self, b, which):
         """(address, count, keepalive) of a block's id array: straight from the sampler's
@@ -320,7 +354,7 @@ class Cache:
         t = self._ids((b.srcdata if which == "src" else b.edata)['ID'])
         return t.data_ptr(), int(t.shape[0]), t
 
-    def _submit(self, mfgs, jobs, n_node, n_cached, upd, async_enqueue):
+    def _submit(self, mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases=()):
         # one output allocation for the whole call; every block's rows start 16-byte aligned
         offs, total = [], 0
         for job in jobs:
@@ -331,6 +365,7 @@ class Cache:
         stats_pos = self._stats_rows(n_cached)
         stats_ptr = self._stats_ring.data_ptr() + 64 * stats_pos
         nj = len(jobs)
+        self.algorithmic_bytes += sum(job[2] * (8 + 8 * job[4]) for job in jobs)
         descs = self._desc_buf(nj)
         pack = _DESC.pack_into
         for i, (kind, ids_ptr, n, _keep, dim, b, which, key) in enumerate(jobs):
@@ -349,6 +384,12 @@ class Cache:
                 b.set_lazy(which, key, rows)
             else:
                 (b.srcdata if which == "src" else b.edata)[key] = rows(sync=False)
+        for b, owner, n in aliases:
+            def prefix_rows(off=offs[owner], n=n, dim=jobs[owner][4], sync=async_enqueue):
+                if sync:
+                    self.wait_enqueued()
+                return out_all[off:off + n * dim].view(n, dim)
+            b.set_lazy("e", "f", prefix_rows)
         node_h = self._node.h if self._node is not None else None
         edge_h = self._edge.h if self._edge is not None else None
         cdescs = _capi.GfFetchDesc.from_buffer(descs)
@@ -363,7 +404,7 @@ class Cache:
         else:
             _capi.check(self._lib.gf_cache_fetch_blocks(
                 node_h, edge_h, C.byref(cdescs), nj, self._stream()))
-        self._stats_span = (stats_pos, n_node, n_cached, self._stats_ring)
+        self._stats_span = (stats_pos, n_node, n_cached, self._stats_ring, len(aliases))
         return mfgs
 
     def _desc_buf(self, n):

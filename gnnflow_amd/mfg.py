@@ -68,7 +68,7 @@ class MFGBlock:
 
     __slots__ = ("_num_src", "_num_dst", "_col", "_row", "_num_edges", "_device",
                  "_srcdata", "_dstdata", "_edata", "_keepalive", "_raw", "_pending",
-                 "_segments")
+                 "_segments", "_edge_prefix_of")
 
     def __init__(self, num_src_nodes: int, num_dst_nodes: int, col=None, row=None,
                  keepalive=None, num_edges=None, device=None, raw=None):
@@ -85,6 +85,10 @@ class MFGBlock:
         self._raw = raw
         self._pending = None     # [(which dict, key, thunk)] registered before the dicts exist
         self._segments = None    # (offsets[num_dst + 1], col grouped by destination, perm)
+        # set by TemporalSampler: the block of the NEXT sampled layer whose edge arrays start
+        # with this block's edge arrays (same roots, same windows, same fanout); see
+        # Cache.fetch_feature
+        self._edge_prefix_of = None
 
     # ---- data dicts, created on demand ----------------------------------------------
     def _make(self, which):

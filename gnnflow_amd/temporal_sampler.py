@@ -62,6 +62,7 @@ class TemporalSampler:
             raise ValueError("strategy must be 'recent' or 'uniform'")
 
         self._lib = _capi.load()
+        self._strategy = sample_strategy
         self._graph = graph  # keep the graph alive (temporal_sampler.h:62 holds a ref)
         self._device = torch.device("cuda", graph.device)
         self._fanouts = [int(f) for f in fanouts]
@@ -210,6 +211,16 @@ class TemporalSampler:
         ns = self._num_snapshots
         mfgs = [[self._block(buf, blocks[layer * ns + s]) for s in range(ns)]
                 for layer in range(self._num_layers)]
+        if self._strategy == "recent":
+            # Layer l+1's roots start with layer l's roots (all_nodes = roots ++ neighbours,
+            # temporal_sampler.cu:294-299) carrying the same timestamps, so with the same
+            # fanout most-recent sampling picks the same edges for them again and emits them
+            # first (root-major order): block l's edge arrays are a PREFIX of block l+1's.
+            fan = self._fanouts
+            for layer in range(self._num_layers - 1):
+                if fan[layer] == fan[layer + 1]:
+                    for s in range(ns):
+                        mfgs[layer][s]._edge_prefix_of = mfgs[layer + 1][s]
         mfgs.reverse()
         return mfgs
 

@@ -43,12 +43,30 @@ def test_single_gpu_line_with_roofline_and_cpu_baseline():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
     assert 0 < r["frac"] < 1 and r["launches_timed"] > 0 and r["avg_launch_us"] > 0
-    assert r["traffic"] is None          # PMC traffic is attached to the default workload only
+    # PMC traffic is attached only to the command line it was measured with (the driver's)
+    assert r["traffic"] is None
+    # the timed region covers whole chronological replays whatever --steps is ...
+    assert d["repeats"] == 75 and d["config"]["timed_steps"] == 60 * 75
+    assert d["ms_per_step"] == pytest.approx(1e3 * d["config"]["timed_seconds"] / (60 * 75))
+    assert d["config"]["timed_seconds"] >= 0.1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "edges/s" and c["value"] > 0
     assert c["single_thread_value"] > 0
     assert isinstance(c["sample"], str) and c["sample"]
     assert d["value"] > c["value"]
+    # ... and the CPU baseline ran the same batches: same sampled edges per step
+    assert c["edges_per_step"] == pytest.approx(d["config"]["edges_per_step"], rel=0.02)
+
+
+def test_driver_command_line_is_representative():
+    """`--steps 20 --warmup 5` (what the driver runs): full-replay mean edges per step."""
+    d = _run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    _check_common(d, 1, 20, 5)
+    assert d["repeats"] == 225
+    full = _run([sys.executable, "bench.py", "--no-cpu-baseline"])
+    assert full["repeats"] == 4
+    assert d["config"]["edges_per_step"] == pytest.approx(full["config"]["edges_per_step"],
+                                                         rel=0.02)
 
 
 def test_two_ranks_through_torchrun():

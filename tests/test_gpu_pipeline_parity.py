@@ -1,0 +1,237 @@
+"""GPU parity of the path bench.py TIMES: gnnflow_amd.pipeline.ReplayPipeline.run — side-stream
+sample_async with the library's enqueue thread, record_stream, fetch_feature(async_enqueue) —
+on BASELINE config 2 itself (REDDIT-shaped stream, minimum block 62, fanout [10,10] most-recent,
+LRUCache 0.2, 172-d node and edge features), against the CPU oracle:
+
+  * every MFG array of every block bit-for-bit (OracleSampler),
+  * every `h` / `f` / target-edge row equal to feats[ids] (and to the oracle cache's output),
+  * hit counts of every block at every step, cached-id sets (OracleLRUCache),
+
+over hundreds of consecutive batches, i.e. many roll-overs of the sampler's 16-call output
+slab.  Reference loop: scripts/offline_edge_prediction.py:343-346,397-405.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+D = 172
+MiB = 1 << 20
+
+
+class _World:
+    """Config 2 on both sides: HIP graph / sampler / cache and their oracles."""
+
+    def __init__(self, first_batch, num_batches, policy="recent", fanouts=(10, 10),
+                 cache_ratio=0.2, prefix_alias=True):
+        import torch
+        import gnnflow_amd
+        from gnnflow_amd import synthetic
+        from gnnflow_amd.cache import LRUCache
+        from oracle import oracle as O
+        from oracle.cache_oracle import OracleLRUCache
+        self.torch = torch
+        g = synthetic.reddit_like(seed=42)
+        N, E = g["num_nodes"], g["num_edges"]
+        self.graph = gnnflow_amd.DynamicGraph(20 * MiB, 1000 * MiB, "cuda", 62, 1024, "insert")
+        self.ograph = O.OracleGraph(minimum_block_size=62, insertion_policy="insert")
+        for lo in range(0, E, 100000):
+            hi = lo + 100000
+            for gr in (self.graph, self.ograph):
+                gr.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi])
+        self.sampler = gnnflow_amd.TemporalSampler(self.graph, list(fanouts), policy, seed=1234)
+        self.osampler = O.OracleSampler(self.ograph, list(fanouts), policy, seed=1234, threads=8)
+        rng = np.random.RandomState(7)
+        self.efeat = rng.rand(E, D).astype(np.float32)
+        self.nfeat = rng.rand(N, D).astype(np.float32)
+        dev = torch.device("cuda", 0)
+        self.cache = LRUCache(cache_ratio, cache_ratio, N, E, dev, torch.from_numpy(self.nfeat),
+                              torch.from_numpy(self.efeat), D, D)
+        self.cache.prefix_alias = prefix_alias
+        self.cache.init_cache()
+        self.ocache = OracleLRUCache(cache_ratio, cache_ratio, N, E, self.nfeat, self.efeat, D, D)
+        self.ocache.init_cache()
+        all_batches = list(synthetic.replay_batches(g, 600, seed=42))
+        self.host_batches = all_batches[first_batch:first_batch + num_batches]
+        self.dev_batches = [(torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev),
+                             torch.from_numpy(e).to(dev)) for r, t, e in self.host_batches]
+        self.dev = dev
+
+
+def _snapshot(cache, mfgs):
+    """Device-side copies of everything one step produced (stream-ordered on the current
+    stream, no host synchronisation), so the sampler's output slab is free to roll over."""
+    blocks = []
+    for mfg in mfgs:
+        for b in mfg:
+            col, row = b.edges()
+            rec = dict(nsrc=b.num_src_nodes(), ndst=b.num_dst_nodes(), ne=b.num_edges(),
+                       ID=b.srcdata["ID"].clone(), ts=b.srcdata["ts"].clone(),
+                       eid=b.edata["ID"].clone(), dt=b.edata["dt"].clone(),
+                       col=col.clone(), row=row.clone(),
+                       f=b.edata["f"].clone() if b.num_edges() else None,
+                       h=b.srcdata["h"].clone() if "h" in b.srcdata else None)
+            blocks.append(rec)
+    return dict(blocks=blocks, target=cache.target_edge_features.clone(),
+                span=cache._stats_span)
+
+
+def _hits_of(span):
+    """Integer hit counts (node blocks, edge blocks) and #aliased blocks from the stats ring."""
+    pos, n_node, n_cached, ring, n_alias = span
+    rows = ring[pos:pos + n_cached].cpu().numpy().astype(np.int64)
+    hits = rows[:, 0::2].sum(axis=1)
+    return hits[:n_node], hits[n_node:], rows[:, 1], n_alias
+
+
+def _check_step(w, bi, snap):
+    """Runs the oracle on batch `bi` (advancing its cache) and compares the snapshot."""
+    r, t, e = w.host_batches[bi]
+    om = w.osampler.sample(r, t)
+    oblocks = [b for mfg in om for b in mfg]
+    assert len(oblocks) == len(snap["blocks"])
+    # oracle cache: block by block in the reference's order, recording per-block hits
+    node_hits, edge_hits = [], []
+    for b in om[0]:
+        out, hits, n = w.ocache.node.fetch(b.srcdata["ID"], True)
+        b.srcdata["h"] = out
+        node_hits.append(hits)
+    for mfg in om:
+        for b in mfg:
+            if len(b.edata["ID"]):
+                out, hits, n = w.ocache.edge.fetch(b.edata["ID"], True)
+                b.edata["f"] = out
+                edge_hits.append((hits, n))
+    for k, (s, ob) in enumerate(zip(snap["blocks"], oblocks)):
+        where = "batch {} block {}".format(bi, k)
+        assert (s["nsrc"], s["ndst"], s["ne"]) == (ob.num_src_nodes(), ob.num_dst_nodes(),
+                                                   ob.num_edges()), where
+        assert np.array_equal(s["ID"].cpu().numpy(), ob.srcdata["ID"]), where
+        assert np.array_equal(s["ts"].cpu().numpy(), ob.srcdata["ts"]), where
+        assert np.array_equal(s["eid"].cpu().numpy(), ob.edata["ID"]), where
+        assert np.array_equal(s["dt"].cpu().numpy(), ob.edata["dt"]), where
+        ocol, orow = ob.edges()
+        assert np.array_equal(s["col"].cpu().numpy(), ocol), where
+        assert np.array_equal(s["row"].cpu().numpy(), orow), where
+        if s["ne"]:
+            f = s["f"].cpu().numpy()
+            assert np.array_equal(f, w.efeat[ob.edata["ID"]]), where + " f"
+            assert np.array_equal(f, ob.edata["f"]), where + " f vs oracle cache"
+        if k < len(om[0]):
+            h = s["h"].cpu().numpy()
+            assert np.array_equal(h, w.nfeat[ob.srcdata["ID"]]), where + " h"
+        else:
+            assert s["h"] is None
+    assert np.array_equal(snap["target"].cpu().numpy(), w.efeat[e]), "batch {} target".format(bi)
+    hn, he, counts, n_alias = _hits_of(snap["span"])
+    assert list(hn) == node_hits, "batch {} node hits".format(bi)
+    # blocks served as a prefix of the previous block's rows are all hits by construction
+    got = [(int(h), int(c)) for h, c in zip(he, counts[len(hn):])]
+    assert got == edge_hits[:len(got)], "batch {} edge hits".format(bi)
+    assert len(got) + n_alias == len(edge_hits)
+    for hits, n in edge_hits[len(got):]:
+        assert hits == n, "batch {}: aliased block is not all hits in the oracle".format(bi)
+
+
+def _cached_sets_equal(w):
+    assert np.array_equal(np.sort(w.cache._edge.slot_ids()), w.ocache.edge.cached_ids())
+    assert np.array_equal(np.sort(w.cache._node.slot_ids()), w.ocache.node.cached_ids())
+
+
+@pytest.mark.parametrize("first_batch", [0, 700])
+def test_pipelined_replay_bit_exact_on_config2(first_batch):
+    """The free-running pipeline (exactly bench.py's loop): step i's results are copied on
+    the device while step i+1 is already in flight; compared in chunks of 32 steps."""
+    from gnnflow_amd.pipeline import ReplayPipeline
+    steps, chunk = 224, 32          # 14 roll-overs of the 16-call output slab
+    w = _World(first_batch, steps)
+    pipe = ReplayPipeline(w.sampler, w.cache, w.dev_batches, w.dev, pipelined=True)
+    assert pipe.pipelined
+    for c0 in range(0, steps, chunk):
+        snaps, held = [], []
+
+        def on_step(i, mfgs):
+            # snapshot the PREVIOUS step: its fetch was enqueued long ago, so no extra host
+            # wait is introduced into the loop being tested
+            if held:
+                pi, pm = held.pop()
+                snaps.append((pi, _snapshot(w.cache_prev, pm)))
+            held.append((i, mfgs))
+            w.cache_prev = _StepView(w.cache)
+
+        pipe.run(c0, chunk, on_step)
+        pi, pm = held.pop()
+        snaps.append((pi, _snapshot(w.cache_prev, pm)))
+        w.torch.cuda.synchronize()
+        assert [i for i, _ in snaps] == list(range(c0, c0 + chunk))
+        for i, snap in snaps:
+            _check_step(w, i, snap)
+        _cached_sets_equal(w)
+    if first_batch == 700:
+        # late batches: the roots' layer really is a prefix and really was aliased
+        assert w.cache.prefix_alias and snaps[-1][1]["span"][4] == 1
+
+
+class _StepView:
+    """What Cache exposes about the fetch_feature() call that was just issued, frozen so it
+    can be read one step later (the next call replaces these attributes)."""
+
+    def __init__(self, cache):
+        self._cache = cache
+        self._thunk = cache._target_edge_thunk
+        self._value = cache._target_edge_features
+        self._stats_span = cache._stats_span
+
+    @property
+    def target_edge_features(self):
+        if self._value is None:
+            self._value = self._thunk()
+        return self._value
+
+
+def test_stepwise_cached_sets_and_alias_equivalence():
+    """Same loop with a host check after every step (cached-id sets at EVERY step), once with
+    the prefix alias and once without: both must agree with the oracle, hence with each
+    other."""
+    from gnnflow_amd.pipeline import ReplayPipeline
+    for alias in (True, False):
+        w = _World(900, 48, prefix_alias=alias)
+        pipe = ReplayPipeline(w.sampler, w.cache, w.dev_batches, w.dev, pipelined=True)
+
+        def on_step(i, mfgs):
+            snap = _snapshot(w.cache, mfgs)
+            w.torch.cuda.synchronize()
+            _check_step(w, i, snap)
+            _cached_sets_equal(w)
+            assert snap["span"][4] == (1 if alias else 0)
+
+        pipe.run(0, 48, on_step)
+
+
+@pytest.mark.parametrize("fanouts,policy", [((10, 10, 10), "recent"), ((10, 5), "recent"),
+                                            ((5, 10), "recent"), ((10, 10), "uniform")])
+def test_prefix_property_only_where_it_holds(fanouts, policy):
+    """3 equal layers alias twice; unequal fanouts and uniform sampling never alias; rows,
+    hits and cached sets match the oracle in every case (small cache: blocks larger than
+    the capacity must fall back to a real lookup)."""
+    from gnnflow_amd.pipeline import ReplayPipeline
+    for ratio in (0.2, 0.002):
+        w = _World(1000, 6, policy=policy, fanouts=fanouts, cache_ratio=ratio)
+        if policy == "uniform":
+            # uniform draws differ from the oracle's only in nothing: same Philox stream
+            pass
+        pipe = ReplayPipeline(w.sampler, w.cache, w.dev_batches, w.dev, pipelined=False)
+        seen = []
+
+        def on_step(i, mfgs):
+            snap = _snapshot(w.cache, mfgs)
+            w.torch.cuda.synchronize()
+            _check_step(w, i, snap)
+            _cached_sets_equal(w)
+            seen.append(snap["span"][4])
+
+        pipe.run(0, 6, on_step)
+        if policy == "uniform" or fanouts in ((10, 5), (5, 10)):
+            assert set(seen) == {0}
+        elif ratio == 0.2:
+            assert set(seen) == {len(fanouts) - 1}
