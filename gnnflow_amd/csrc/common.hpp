@@ -123,6 +123,44 @@ class DeviceBuffer {
   size_t bytes_ = 0;
 };
 
+// Device buffers that were replaced while kernels queued on a stream may still use them:
+// each waits behind an event recorded on that stream and is freed by a later collect().
+class RetiredBuffers {
+ public:
+  RetiredBuffers() = default;
+  RetiredBuffers(const RetiredBuffers&) = delete;
+  RetiredBuffers& operator=(const RetiredBuffers&) = delete;
+  ~RetiredBuffers() {
+    for (Item& it : items_) {
+      (void)hipEventSynchronize(it.done);
+      (void)hipEventDestroy(it.done);
+    }
+  }
+  void retire(DeviceBuffer&& b, hipStream_t stream) {
+    if (!b.data()) return;
+    Item it;
+    it.buf = std::move(b);
+    GF_HIP(hipEventCreateWithFlags(&it.done, hipEventDisableTiming));
+    GF_HIP(hipEventRecord(it.done, stream));
+    items_.push_back(std::move(it));
+  }
+  void collect() {
+    for (size_t i = 0; i < items_.size();) {
+      if (hipEventQuery(items_[i].done) == hipSuccess) {
+        (void)hipEventDestroy(items_[i].done);
+        items_[i] = std::move(items_.back());
+        items_.pop_back();
+      } else {
+        ++i;
+      }
+    }
+  }
+
+ private:
+  struct Item { DeviceBuffer buf; hipEvent_t done = nullptr; };
+  std::vector<Item> items_;
+};
+
 // Pinned host staging buffer (grow-only).
 class PinnedBuffer {
  public:

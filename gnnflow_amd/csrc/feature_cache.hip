@@ -38,11 +38,29 @@
 //              HBM) into the cache and turns this epoch's touch marks into stamps.
 //              No atomics: fully deterministic.
 //
-// `count` of the reference is kept as an epoch stamp per slot (count == stamp - epoch);
-// the k smallest counts are found with a histogram select (no sort, no topk); ties go to
-// the lowest slot index.  The four bookkeeping kernels return at once for a context whose
-// block had no miss (the reference skips update_*_cache then too, cache.py:318); a hit only
-// changes LRU state if the block also had a miss, exactly as in the reference.
+// The scan / rank / count / install chain above serves LFU (and, without the histogram
+// half, FIFO): `stamp` holds the use count and the k smallest are found with a histogram
+// select (no sort, no topk); ties go to the lowest slot index.
+//
+// LRU — the policy on the hot path — needs no selection at all: the reference's `count`
+// only ever changes to "newest" (hit or install: count = 0 while all others sink by one,
+// lru_cache.py:134-160), so the eviction order is a LIST, least recently refreshed slot
+// first, that every update permutes in the same simple way: the slots hit by the block move
+// behind the others, the first k = #distinct misses entries are the victims and go, refilled,
+// to the very back.  `queue` holds that list (a permutation of the slots, double-buffered);
+// no stamps, no histogram, no threshold, no atomics, and ties are resolved STABLY — slots of
+// equal `count` keep their relative order, what a stable sort by `count` yields (the
+// reference leaves it to torch.topk's unspecified tie-breaking).  Two launches per round:
+//   list scan   : row-tile workgroups rank the representatives of the distinct missed ids;
+//                 list-tile workgroups count the hit slots per tile of the list; one more
+//                 workgroup reads the victims off the front of the list.
+//   list install: one thread per block row installs the m-th missed id in the m-th victim's
+//                 slot (map / slot_id / row copy from the freshly gathered output — spread
+//                 over as many workgroups as the block has rows); list-tile workgroups write
+//                 the permuted list into the other buffer.
+// All bookkeeping kernels return at once for a context whose block had no miss (the
+// reference skips update_*_cache then too, cache.py:318); a hit only changes replacement
+// state if the block also had a miss, exactly as in the reference.
 #include "feature_cache.hpp"
 
 #include <hip/hip_ext.h>
@@ -69,6 +87,7 @@ constexpr int kRing = 32;               // per-fetch counter records
 constexpr int kMaxCtx = 4;              // contexts per round
 constexpr uint32_t kRowTile = 4096;     // rows per scan workgroup (kWide threads x 4)
 constexpr uint32_t kMaxRowTiles = 1024; // more row tiles than this: chained single-workgroup scan
+constexpr uint32_t kQGroup = 64;        // LRU: list tiles per group sum
 
 // One record per fetch.  hits / misses are accumulated once per workgroup into one of 8
 // shards that sit on separate 128-byte lines: same-address atomics retire at only
@@ -86,11 +105,15 @@ struct Counters {
   uint32_t th_k_tie;
   uint32_t fifo_start;  // FIFO: first slot of this block's refill arc
   uint32_t ticket;      // workgroups of the rank kernel that finished their level-2 histogram
-  uint32_t pad[27];
+  uint32_t q_parity;    // LRU list: buffer that is current during this update
+  uint32_t q_found;     // LRU list: not-hit victims found by the list scan
+  uint32_t pad[25];
 };
 constexpr uint32_t kCounterWords = sizeof(Counters) / 4;
 
 // Everything one block fetch needs on the device.  `update` == 0: gather only.
+struct QueueState { uint32_t parity, pad[3]; };
+
 struct Ctx {
   const int64_t* ids;
   uint32_t n;
@@ -103,8 +126,11 @@ struct Ctx {
   int32_t* map;             // null: no cache (plain gather)
   float* cache_buf;
   int64_t* slot_id;
-  uint32_t* stamp;
-  uint32_t* touched;
+  uint32_t* stamp;          // LFU: use count (FIFO: install epoch; LRU: unused)
+  uint32_t* touched;        // epoch of the slot's last hit (pending until the block misses)
+  uint32_t* queue[2];       // LRU: the slots, least recently refreshed first (double buffer)
+  QueueState* qstate;       // LRU: which buffer is current, device resident
+  uint32_t tiles_per_wg;    // LRU: row tiles per scan workgroup (1 unless > 4M rows)
   uint32_t capacity;
   uint32_t epoch_new;
   int update;
@@ -116,6 +142,7 @@ struct Ctx {
   uint32_t* rep_row;        // rank -> row of the representative
   int64_t* rep_id;          // rank -> id (saves the install kernel a dependent load)
   uint32_t* row_tile_sum;   // [ceil(n / kRowTile)] representatives per row tile
+                            // (LRU: per scan workgroup)
   uint32_t* hist1;
   uint32_t* hist2;
   uint32_t* tile_tie;
@@ -148,8 +175,12 @@ __device__ inline void gather_body(const Ctx& c) {
   const uint32_t nthreads = gridDim.x * kThreads;
   // housekeeping for later launches: this fetch's histograms and the NEXT fetch's counter
   // record are cleared here (neither is in use by anyone else at this point)
-  if (c.update)
+  if (c.update && c.policy == GF_CACHE_LRU) {   // per-group hit counts of the list scan
+    const uint32_t groups = ((c.capacity + kRowTile - 1) / kRowTile + kQGroup - 1) / kQGroup;
+    for (uint32_t i = gtid; i < groups; i += nthreads) c.tile_old[i] = 0;
+  } else if (c.update) {
     for (uint32_t i = gtid; i < kBins1 + kBins2; i += nthreads) c.hist1[i] = 0;  // hist2 follows
+  }
   if (c.ctr_next) {
     uint32_t* nxt = reinterpret_cast<uint32_t*>(c.ctr_next);
     for (uint32_t i = gtid; i < kCounterWords; i += nthreads) nxt[i] = 0;
@@ -174,7 +205,7 @@ __device__ inline void gather_body(const Ctx& c) {
         if (slot >= 0) {
           src = cache_buf + static_cast<uint64_t>(slot) * dimv;
           // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
-          // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161)
+          // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161).
           if (c.update && c.policy != GF_CACHE_FIFO) c.touched[slot] = c.epoch_new;
         } else {
           slot = -1;
@@ -239,20 +270,13 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
 }
 
 // ---- LRU bookkeeping ---------------------------------------------------------------
-// Eviction priority of a slot: larger goes first, ties to the lowest slot.
-//  LRU / FIFO: age in epochs of `stamp` (last touch / install); a slot hit in this block
-//              has age 0 (lru_cache.py:134-139).
-//  LFU       : `stamp` holds the use count; priority = kAgeMax - count, with this block's hit
-//              already counted (`count[cached_index] += 1` before topk, lfu_cache.py:159-163).
+// Eviction priority of a slot under LFU: larger goes first, ties to the lowest slot.
+// `stamp` holds the use count; priority = kAgeMax - count, with this block's hit already
+// counted (`count[cached_index] += 1` before topk, lfu_cache.py:159-163).  (FIFO takes its
+// victims from the rotation pointer and LRU from its queue; neither gets here.)
 __device__ inline uint32_t slot_age_of(const Ctx& c, uint32_t touched, uint32_t stamp) {
-  const bool hit = touched == c.epoch_new;
-  if (c.policy == GF_CACHE_LFU) {
-    const uint32_t cnt = stamp + (hit ? 1u : 0u);
-    return kAgeMax - (cnt < kAgeMax ? cnt : kAgeMax);
-  }
-  if (hit) return 0;     // hit in this block
-  const uint32_t a = c.epoch_new - stamp;
-  return a < kAgeMax ? a : kAgeMax;
+  const uint32_t cnt = stamp + (touched == c.epoch_new ? 1u : 0u);
+  return kAgeMax - (cnt < kAgeMax ? cnt : kAgeMax);
 }
 __device__ inline uint32_t slot_age(const Ctx& c, uint32_t s) {
   return slot_age_of(c, c.touched[s], c.stamp[s]);
@@ -268,7 +292,7 @@ __device__ inline uint32_t age_bin1(uint32_t a) {
 //  * histogram workgroups: level-1 histogram of the slot ages.
 __global__ __launch_bounds__(kWide) void lru_scan_hist_kernel(Round r, uint32_t scan_blocks) {
   const Ctx& c = r.c[blockIdx.y];
-  if (!c.update) return;
+  if (!c.update || c.policy == GF_CACHE_LRU) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Both kinds of workgroup issue their first batch of loads BEFORE they look at the miss
   // count of the fetch record: one memory round trip instead of two on the critical path.
@@ -497,7 +521,7 @@ __device__ inline void count_tiles(const Ctx& c, Threshold th, uint32_t first, u
 // issued together before the first dependent use.
 __global__ __launch_bounds__(kWide) void lru_rank_tile_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
-  if (!c.update) return;
+  if (!c.update || c.policy == GF_CACHE_LRU) return;
   const bool fifo = c.policy == GF_CACHE_FIFO;
   const uint32_t tiles = (c.capacity + kTile - 1) / kTile;
   const uint32_t i_first = blockIdx.x * kWide + threadIdx.x;
@@ -687,9 +711,297 @@ __device__ inline void install_body(const Ctx& c) {
 
 __global__ __launch_bounds__(kTile) void lru_install_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
-  if (!c.update) return;
+  if (!c.update || c.policy == GF_CACHE_LRU) return;
   if (c.vec4) install_body<float4>(c);
   else install_body<float>(c);
+}
+
+// ---- LRU as a list ------------------------------------------------------------------
+// (see the file header).  c.touched[slot] = epoch of the slot's last hit (plain stores by the
+// gather); c.queue[0 / 1] are the two list buffers, qstate->parity says which one is current.
+constexpr uint32_t kRepMiss = 1u << 31, kRepRank = kRepMiss - 1u;
+
+// Exclusive scan of one value per thread over a kWide-wide workgroup; *total gets the sum.
+// Every thread calls it (barriers inside); `ws` is kWide / 64 words of LDS.
+__device__ inline uint32_t wide_excl_scan(uint32_t v, uint32_t* ws, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  __syncthreads();            // ws may still be read from a previous call
+  if (lane == 63) ws[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, sum = 0;
+#pragma unroll
+  for (int w = 0; w < kWide / 64; ++w) {
+    const uint32_t x = ws[w];
+    if (w < wave) base += x;
+    sum += x;
+  }
+  *total = sum;
+  return base + incl - v;
+}
+
+// sum of one value per thread over the workgroup (every thread calls it and gets the sum)
+__device__ inline uint32_t wide_sum(uint32_t v, uint32_t* ws) {
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint32_t sum = 0;
+#pragma unroll
+  for (int w = 0; w < kWide / 64; ++w) sum += ws[w];
+  return sum;
+}
+
+// One launch, three kinds of workgroups (per context), all reading what the gather left:
+//  * row workgroups   [0, row_blocks): each owns `tiles_per_wg` consecutive tiles of kRowTile
+//    rows, finds the representatives of the distinct missed ids in them (the row whose claim
+//    on map[id] survived the gather's atomicMax), ranks them in row order inside its span and
+//    publishes the span's count;
+//  * list workgroups  [row_blocks, row_blocks + list_blocks): count, per tile of kRowTile list
+//    entries, the slots hit by this block (they will move behind the others);
+//  * the victim workgroup (last) walks the list from its front and writes down the first
+//    not-hit entries — as many as the block has missed ROWS (an upper bound of the distinct
+//    missed ids, which only the next kernel knows) — and the hit entries it passes on the way
+//    (the next victims if a block needs more slots than its own hits leave over).
+__global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t row_blocks,
+                                                              uint32_t list_blocks) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (!c.update || c.policy != GF_CACHE_LRU) return;
+  const int tid = threadIdx.x;
+  __shared__ uint32_t ws[kWide / 64];
+  const uint32_t parity = c.qstate->parity;
+  const uint32_t* list = c.queue[parity & 1u];
+  constexpr uint32_t kItems = kRowTile / kWide;
+  if (blockIdx.x < row_blocks) {
+    __shared__ uint32_t carry;
+    const uint32_t row_tiles = (c.n + kRowTile - 1) / kRowTile;
+    const uint32_t t_begin = blockIdx.x * c.tiles_per_wg;
+    if (t_begin >= row_tiles) return;
+    const uint32_t t_end = min(t_begin + c.tiles_per_wg, row_tiles);
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+      const uint32_t i0 = t * kRowTile + tid * kItems;
+      int32_t sr[kItems];
+      int64_t idv[kItems];
+#pragma unroll
+      for (uint32_t k = 0; k < kItems; ++k) {
+        const bool ok = i0 + k < c.n;
+        sr[k] = ok ? c.slot_of_row[i0 + k] : -2;
+        idv[k] = ok ? c.ids[i0 + k] : 0;
+      }
+      if (t == t_begin && total_miss(c.ctr) == 0) return;   // uniform: nothing to update
+      uint32_t fm[kItems], lm = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kItems; ++k) {
+        fm[k] = (sr[k] == -1 && c.map[idv[k]] == -static_cast<int32_t>(i0 + k + 1)) ? 1u : 0u;
+        lm += fm[k];
+      }
+      uint32_t tm;
+      uint32_t run = carry + wide_excl_scan(lm, ws, &tm);
+#pragma unroll
+      for (uint32_t k = 0; k < kItems; ++k) {
+        if (i0 + k < c.n) c.rep_flag[i0 + k] = fm[k] ? (kRepMiss | run) : 0u;
+        run += fm[k];
+      }
+      __syncthreads();
+      if (tid == 0) carry += tm;
+      __syncthreads();
+    }
+    if (tid == 0) c.row_tile_sum[blockIdx.x] = carry;
+    return;
+  }
+  const uint32_t cap = c.capacity;
+  if (blockIdx.x < row_blocks + list_blocks) {
+    const uint32_t list_tiles = (cap + kRowTile - 1) / kRowTile;
+    bool first = true;
+    for (uint32_t t = blockIdx.x - row_blocks; t < list_tiles; t += list_blocks) {
+      const uint32_t p0 = t * kRowTile + tid * kItems;
+      uint32_t sl[kItems], local = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < kItems; ++j) sl[j] = p0 + j < cap ? list[p0 + j] : 0u;
+      if (first) {
+        first = false;
+        if (total_miss(c.ctr) == 0) return;   // uniform across the launch
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < kItems; ++j)
+        local += (p0 + j < cap && c.touched[sl[j]] == c.epoch_new) ? 1u : 0u;
+      const uint32_t total = wide_sum(local, ws);
+      if (tid == 0) {
+        c.tile_tie[t] = total;
+        if (total) atomicAdd(&c.tile_old[t / kQGroup], total);   // zeroed by the gather
+      }
+    }
+    return;
+  }
+  if (blockIdx.x != row_blocks + list_blocks) return;
+  const uint32_t want = min(total_miss(c.ctr), cap);
+  if (tid == 0) c.ctr->q_parity = parity;
+  if (want == 0) return;
+  uint32_t* kept = c.rep_row;     // victims: not-hit entries from the front of the list
+  uint32_t* moved = c.rep_rank;   // hit entries passed on the way
+  uint32_t found = 0, found_hit = 0;
+  for (uint32_t base = 0; base < cap && found < want; base += kRowTile) {
+    const uint32_t p0 = base + tid * kItems;
+    uint32_t sl[kItems], hit[kItems], lk = 0, lh = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kItems; ++j) sl[j] = p0 + j < cap ? list[p0 + j] : 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < kItems; ++j) {
+      const bool in = p0 + j < cap;
+      hit[j] = in ? (c.touched[sl[j]] == c.epoch_new ? 1u : 0u) : 2u;
+      lk += hit[j] == 0u;
+      lh += hit[j] == 1u;
+    }
+    uint32_t tk, th;
+    uint32_t ik = found + wide_excl_scan(lk, ws, &tk);
+    uint32_t ih = found_hit + wide_excl_scan(lh, ws, &th);
+#pragma unroll
+    for (uint32_t j = 0; j < kItems; ++j) {
+      if (hit[j] == 0u) { if (ik < want) kept[ik] = sl[j]; ++ik; }
+      else if (hit[j] == 1u) { if (ih < want) moved[ih] = sl[j]; ++ih; }
+    }
+    found += tk;
+    found_hit += th;
+  }
+  if (tid == 0) c.ctr->q_found = min(found, want);
+}
+
+// Applies the update; two kinds of workgroups:
+//  * row workgroups [0, row_blocks), one thread per block row: the m-th distinct missed id
+//    (m < k = min(#distinct misses, capacity)) takes the m-th victim's slot — map / slot_id /
+//    row copy from the freshly gathered output; the others give their claim on map[id] back;
+//  * list workgroups rewrite the list into the other buffer: with L = not-hit entries ++ hit
+//    entries (both in list order), the first k of L are the victims and go, in that order, to
+//    the back; everything else moves up by k.  The last one flips the parity.
+__global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32_t row_blocks,
+                                                                 uint32_t list_blocks) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (!c.update || c.policy != GF_CACHE_LRU) return;
+  const int tid = threadIdx.x;
+  __shared__ uint32_t ws[kWide / 64];
+  const uint32_t row_tiles = (c.n + kRowTile - 1) / kRowTile;
+  const uint32_t spans = (row_tiles + c.tiles_per_wg - 1) / c.tiles_per_wg;
+  const uint32_t cap = c.capacity;
+  if (blockIdx.x < row_blocks) {
+    __shared__ uint2 inst[kWide];   // {slot, row} installed by this workgroup
+    __shared__ uint32_t n_inst;
+    const uint32_t span_rows = c.tiles_per_wg * kRowTile;
+    const uint32_t chunks = (c.n + kWide - 1) / kWide;
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += row_blocks) {
+      const uint32_t i = chunk * kWide + tid;
+      const bool in = i < c.n;
+      // every independent load first: the row's code and id, the span counts, the record
+      const uint32_t code = in ? c.rep_flag[i] : 0u;
+      const int64_t id = in ? c.ids[i] : 0;
+      const uint32_t w = (chunk * kWide) / span_rows;   // scan workgroup of these rows
+      uint32_t pm = 0, tm = 0;
+      for (uint32_t t = tid; t < spans; t += kWide) {
+        const uint32_t m = c.row_tile_sum[t];
+        tm += m;
+        if (t < w) pm += m;
+      }
+      const uint32_t q_found = c.ctr->q_found;
+      if (chunk == blockIdx.x && total_miss(c.ctr) == 0) return;   // uniform
+      pm = wide_sum(pm, ws);
+      tm = wide_sum(tm, ws);
+      if (tid == 0) n_inst = 0;
+      __syncthreads();
+      const uint32_t k = min(tm, cap);
+      if (code & kRepMiss) {
+        const uint32_t m = pm + (code & kRepRank);
+        if (m < k) {
+          const uint32_t slot = m < q_found ? c.rep_row[m] : c.rep_rank[m - q_found];
+          const int64_t old = c.slot_id[slot];
+          if (old >= 0) c.map[old] = kAbsent;
+          c.slot_id[slot] = id;
+          c.map[id] = static_cast<int32_t>(slot);
+          inst[atomicAdd(&n_inst, 1u)] = make_uint2(slot, i);
+        } else {
+          c.map[id] = kAbsent;   // "we only cache the first self.capacity", lru_cache.py:127-133
+        }
+      }
+      __syncthreads();
+      // copy the installed rows out of the block's output, as one flat array
+      const uint32_t total = n_inst * c.dimv;
+      if (c.vec4) {
+        const float4* out = reinterpret_cast<const float4*>(c.out);
+        float4* buf = reinterpret_cast<float4*>(c.cache_buf);
+        for (uint32_t f = tid; f < total; f += kWide) {
+          const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
+          const uint2 pr = inst[j];
+          buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] = out[static_cast<uint64_t>(pr.y) * c.dimv + cc];
+        }
+      } else {
+        for (uint32_t f = tid; f < total; f += kWide) {
+          const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
+          const uint2 pr = inst[j];
+          c.cache_buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] = c.out[static_cast<uint64_t>(pr.y) * c.dimv + cc];
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  if (blockIdx.x >= row_blocks + list_blocks) return;
+  const uint32_t parity = c.ctr->q_parity;
+  const uint32_t* list = c.queue[parity & 1u];
+  uint32_t* next = c.queue[(parity & 1u) ^ 1u];
+  constexpr uint32_t kItems = kRowTile / kWide;
+  const uint32_t list_tiles = (cap + kRowTile - 1) / kRowTile;
+  const uint32_t groups = (list_tiles + kQGroup - 1) / kQGroup;
+  // #distinct misses and #hit slots of the whole block
+  uint32_t tm = 0, th = 0;
+  for (uint32_t t = tid; t < spans; t += kWide) tm += c.row_tile_sum[t];
+  for (uint32_t g = tid; g < groups; g += kWide) th += c.tile_old[g];
+  if (total_miss(c.ctr) == 0) return;   // block without a miss: the list stays as it is
+  tm = wide_sum(tm, ws);
+  th = wide_sum(th, ws);
+  const uint32_t k = min(tm, cap), n_kept = cap - th;
+  for (uint32_t t = blockIdx.x - row_blocks; t < list_tiles; t += list_blocks) {
+    const uint32_t p0 = t * kRowTile + tid * kItems;
+    uint32_t sl[kItems], hit[kItems], local = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kItems; ++j) sl[j] = p0 + j < cap ? list[p0 + j] : 0u;
+    // hit entries before this tile: whole groups, then the tiles of this tile's group
+    uint32_t before = 0;
+    const uint32_t g0 = t / kQGroup;
+    for (uint32_t g = tid; g < g0; g += kWide) before += c.tile_old[g];
+    for (uint32_t u = g0 * kQGroup + tid; u < t; u += kWide) before += c.tile_tie[u];
+#pragma unroll
+    for (uint32_t j = 0; j < kItems; ++j) {
+      hit[j] = (p0 + j < cap && c.touched[sl[j]] == c.epoch_new) ? 1u : 0u;
+      local += hit[j];
+    }
+    before = wide_sum(before, ws);
+    uint32_t total;
+    uint32_t hb = before + wide_excl_scan(local, ws, &total);   // hit entries before p
+#pragma unroll
+    for (uint32_t j = 0; j < kItems; ++j) {
+      const uint32_t p = p0 + j;
+      if (p < cap) {
+        const uint32_t l = hit[j] ? n_kept + hb : p - hb;   // index in L
+        next[l < k ? cap - k + l : l - k] = sl[j];
+      }
+      hb += hit[j];
+    }
+  }
+  if (blockIdx.x == row_blocks && tid == 0) c.qstate->parity = parity ^ 1u;
+}
+
+// list of a freshly initialised cache: slot order; `prefix` new slots [first, first + prefix)
+// go in front of the `old_n` entries of `old` (Cache.resize)
+__global__ void list_fill_kernel(uint32_t* list, uint32_t first, uint32_t prefix,
+                                 const uint32_t* old, uint32_t old_n) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < prefix + old_n; j += stride)
+    list[j] = j < prefix ? first + j : old[j - prefix];
 }
 
 __global__ void cache_fill_kernel(int32_t* map, uint64_t num_ids, int64_t* slot_id,
@@ -764,6 +1076,33 @@ void launch_round(Round& r, hipStream_t stream) {
   }
   if (!any_update) return;
   ProfileScope ps(kProfLru, stream);
+  size_t q_scan_blocks = 0, q_rows = 0, q_cap = 0, h_n = 0, h_cap = 0, h_tiles = 0;
+  for (int i = 0; i < r.count; ++i) {
+    const Ctx& c = r.c[i];
+    if (!c.update) continue;
+    if (c.policy == GF_CACHE_LRU) {
+      const size_t row_tiles = (c.n + kRowTile - 1) / kRowTile;
+      q_scan_blocks = std::max(q_scan_blocks, (row_tiles + c.tiles_per_wg - 1) / c.tiles_per_wg);
+      q_rows = std::max<size_t>(q_rows, c.n);
+      q_cap = std::max<size_t>(q_cap, c.capacity);
+    } else {
+      h_n = std::max<size_t>(h_n, c.n);
+      h_cap = std::max<size_t>(h_cap, c.capacity);
+      h_tiles = std::max<size_t>(h_tiles, (c.capacity + kTile - 1) / kTile);
+    }
+  }
+  if (q_rows) {   // LRU: list scan + list install
+    const unsigned rb = static_cast<unsigned>(q_scan_blocks);
+    const unsigned lb = static_cast<unsigned>(
+        std::max<size_t>(1, std::min<size_t>((q_cap + kRowTile - 1) / kRowTile, 1024)));
+    lru_list_scan_kernel<<<dim3(rb + lb + 1, r.count), dim3(kWide), 0, stream>>>(r, rb, lb);
+    const unsigned ib = static_cast<unsigned>(
+        std::max<size_t>(1, std::min<size_t>((q_rows + kWide - 1) / kWide, 2048)));
+    lru_list_install_kernel<<<dim3(ib + lb, r.count), dim3(kWide), 0, stream>>>(r, ib, lb);
+    GF_HIP(hipGetLastError());
+  }
+  if (!h_cap) return;
+  max_n = h_n; max_cap = h_cap; max_tiles = h_tiles;
   const unsigned slot_grid = static_cast<unsigned>(
       std::max<size_t>(1, std::min<size_t>((max_cap + 4 * kWide - 1) / (4 * kWide), 1024)));
   const unsigned both_grid = static_cast<unsigned>(std::max<size_t>(
@@ -841,11 +1180,13 @@ FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const fl
   touched_.reserve(std::max<size_t>(capacity * sizeof(uint32_t), 16));
   state_.reserve(kRing * sizeof(Counters), 0, nullptr, true);
   fifo_ptr_.reserve(16);
+  qstate_.reserve(sizeof(QueueState));
   rewind_fifo(nullptr);
   cache_fill_kernel<<<dim3(1024), dim3(256), 0, nullptr>>>(
       map_.as<int32_t>(), num_ids_, slot_id_.as<int64_t>(), stamp_.as<uint32_t>(),
       touched_.as<uint32_t>(), capacity_, 0, 0u);
   GF_HIP(hipGetLastError());
+  init_queue(nullptr);
   GF_HIP(hipMemsetAsync(buffer_.data(), 0, buffer_.bytes(), nullptr));
   GF_HIP(hipMemsetAsync(state_.data(), 0, state_.bytes(), nullptr));
   GF_HIP(hipStreamSynchronize(nullptr));
@@ -863,9 +1204,25 @@ void FeatureCache::init(hipStream_t stream) {
   GF_HIP(hipGetLastError());
   epoch_ = 0;
   rewind_fifo(stream);
+  init_queue(stream);
   if (capacity_)
     GF_HIP(hipMemcpyAsync(buffer_.data(), feats_, capacity_ * dim_ * sizeof(float),
                           hipMemcpyDefault, stream));
+}
+
+// ---- LRU list, host side -----------------------------------------------------------------
+// slot order: the order of a freshly initialised cache (every `count` equal)
+void FeatureCache::init_queue(hipStream_t stream) {
+  if (policy_ != GF_CACHE_LRU) return;
+  const size_t bytes = std::max<size_t>(capacity_ * sizeof(uint32_t), 16);
+  queue_.reserve(bytes, 0, stream);
+  queue_alt_.reserve(bytes, 0, stream);
+  if (capacity_) {
+    list_fill_kernel<<<dim3(1024), dim3(256), 0, stream>>>(
+        queue_.as<uint32_t>(), 0u, static_cast<uint32_t>(capacity_), nullptr, 0u);
+    GF_HIP(hipGetLastError());
+  }
+  GF_HIP(hipMemsetAsync(qstate_.data(), 0, sizeof(QueueState), stream));
 }
 
 // FIFOCache.reset (fifo_cache.py:70-75) rewinds the rotation pointer and keeps the cached
@@ -890,7 +1247,20 @@ void FeatureCache::rewind_fifo(hipStream_t stream) {
 void FeatureCache::set_policy(int policy) {
   GF_REQUIRE(policy == GF_CACHE_LRU || policy == GF_CACHE_LFU || policy == GF_CACHE_FIFO,
              "cache: unknown replacement policy");
+  if (policy == policy_) return;
   policy_ = policy;
+  // the per-slot words mean different things per policy (LRU: queue position / hit claim)
+  DeviceGuard dg(device_);
+  if (capacity_) {
+    GF_HIP(hipMemsetAsync(stamp_.data(), 0, capacity_ * sizeof(uint32_t), nullptr));
+    GF_HIP(hipMemsetAsync(touched_.data(), 0, capacity_ * sizeof(uint32_t), nullptr));
+  }
+  init_queue(nullptr);
+  GF_HIP(hipStreamSynchronize(nullptr));
+  if (policy_ != GF_CACHE_LRU) {   // only LRU keeps a queue
+    queue_.release();
+    queue_alt_.release();
+  }
 }
 
 namespace {
@@ -921,6 +1291,7 @@ void FeatureCache::init_ids(const int64_t* d_ids, size_t n, hipStream_t stream) 
       touched_.as<uint32_t>(), capacity_, 0, 0u);
   epoch_ = 0;
   rewind_fifo(stream);
+  init_queue(stream);
   if (n) {
     const unsigned grid = static_cast<unsigned>(std::min<size_t>((n + 3) / 4, 4096));
     cache_install_ids_kernel<<<dim3(grid), dim3(256), 0, stream>>>(
@@ -973,29 +1344,55 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
     std::swap(stamp_, nst);
     std::swap(touched_, ntc);
   }
+  const size_t old_capacity = capacity_;
   num_ids_ = new_num_ids;
   capacity_ = new_capacity;
   ws_rows_ = 0;   // tile arrays depend on the capacity
+  if (policy_ == GF_CACHE_LRU && new_capacity > old_capacity) {
+    // the new (empty) slots are the first to be refilled, in slot order: they go to the front
+    // of the list, the old entries follow in their order
+    QueueState qs;
+    GF_HIP(hipMemcpyAsync(&qs, qstate_.data(), sizeof(qs), hipMemcpyDeviceToHost, stream));
+    GF_HIP(hipStreamSynchronize(stream));
+    DeviceBuffer& cur = (qs.parity & 1u) ? queue_alt_ : queue_;
+    DeviceBuffer na, nb;
+    na.reserve(new_capacity * sizeof(uint32_t));
+    nb.reserve(new_capacity * sizeof(uint32_t));
+    list_fill_kernel<<<dim3(1024), dim3(256), 0, stream>>>(
+        na.as<uint32_t>(), static_cast<uint32_t>(old_capacity),
+        static_cast<uint32_t>(new_capacity - old_capacity), cur.as<uint32_t>(),
+        static_cast<uint32_t>(old_capacity));
+    GF_HIP(hipGetLastError());
+    GF_HIP(hipMemsetAsync(qstate_.data(), 0, sizeof(QueueState), stream));
+    GF_HIP(hipStreamSynchronize(stream));
+    std::swap(queue_, na);
+    std::swap(queue_alt_, nb);
+  }
 }
 
-void FeatureCache::reserve_workspace(size_t n) {
+void FeatureCache::reserve_workspace(size_t n, hipStream_t stream) {
+  retired_.collect();
   if (n <= ws_rows_ && ws_.data()) return;
   ws_rows_ = std::max(ws_rows_, n);
   const size_t tiles = (capacity_ + kTile - 1) / kTile + 1;
   size_t bytes = (kBins1 + kBins2) * sizeof(uint32_t) + 4 * align_up(ws_rows_ * 4, 16) +
                  align_up(ws_rows_ * 8, 16) + 2 * align_up(tiles * 4, 16) +
                  align_up((kMaxRowTiles + 1) * 4, 16) + 64;
-  // a reallocation must not pull the buffer from under kernels that are still queued
-  GF_HIP(hipDeviceSynchronize());
-  ws_.reserve(bytes, 0, nullptr);
+  // Kernels already queued on `stream` may still use the old scratch: it is retired behind
+  // an event on that stream and freed once the event has completed — a stream-ordered swap,
+  // no device-wide stall when a larger block arrives mid-run.
+  DeviceBuffer fresh;
+  fresh.reserve(bytes, 0, stream);
+  std::swap(ws_, fresh);
+  retired_.retire(std::move(fresh), stream);
 }
 
 // Fills the device context of one block fetch and advances this cache's host-side state
 // (epoch, counter ring).  The caller launches the round.
 void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool update,
-                           uint32_t* d_stats, void* ctx_out) {
+                           uint32_t* d_stats, void* ctx_out, hipStream_t stream) {
   GF_REQUIRE(d_ids && d_out, "cache fetch: null pointer");
-  reserve_workspace(n);
+  reserve_workspace(n, stream);
   const size_t tiles = (capacity_ + kTile - 1) / kTile;
   Ctx& c = *static_cast<Ctx*>(ctx_out);
   std::memset(&c, 0, sizeof(c));
@@ -1032,6 +1429,13 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
   c.ctr_next = state_.as<Counters>() + ((ring_pos_ + 1) % kRing);
   ring_pos_++;
   c.stats = d_stats;
+  if (c.update && policy_ == GF_CACHE_LRU) {
+    const size_t row_tiles = (n + kRowTile - 1) / kRowTile;
+    c.tiles_per_wg = static_cast<uint32_t>((row_tiles + kMaxRowTiles - 1) / kMaxRowTiles);
+    c.queue[0] = queue_.as<uint32_t>();
+    c.queue[1] = queue_alt_.as<uint32_t>();
+    c.qstate = qstate_.as<QueueState>();
+  }
 }
 
 // One block of Cache.fetch_feature (cache.py:269-323 / :326-400)
@@ -1041,7 +1445,7 @@ void FeatureCache::fetch(const int64_t* d_ids, size_t n, float* d_out, bool upda
   DeviceGuard dg(device_);
   Round r;
   r.count = 1;
-  prepare(d_ids, n, d_out, update, d_stats, &r.c[0]);
+  prepare(d_ids, n, d_out, update, d_stats, &r.c[0], stream);
   launch_round(r, stream);
 }
 
@@ -1078,8 +1482,8 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
   size_t max_node_rows = 0, max_edge_rows = 0;
   for (const gf_fetch_desc* d : nodes) max_node_rows = std::max(max_node_rows, d->n);
   for (const gf_fetch_desc* d : edges) max_edge_rows = std::max(max_edge_rows, d->n);
-  if (node && max_node_rows) node->reserve_workspace(max_node_rows);
-  if (edge && max_edge_rows) edge->reserve_workspace(max_edge_rows);
+  if (node && max_node_rows) node->reserve_workspace(max_node_rows, stream);
+  if (edge && max_edge_rows) edge->reserve_workspace(max_edge_rows, stream);
   size_t pi = 0;
   const size_t rounds = std::max(nodes.size(), edges.size());
   for (size_t i = 0; i < rounds; ++i) {
@@ -1087,11 +1491,11 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
     r.count = 0;
     if (i < nodes.size()) {
       const gf_fetch_desc& d = *nodes[i];
-      node->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &r.c[r.count++]);
+      node->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &r.c[r.count++], stream);
     }
     if (i < edges.size()) {
       const gf_fetch_desc& d = *edges[i];
-      edge->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &r.c[r.count++]);
+      edge->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &r.c[r.count++], stream);
     }
     while (pi < plain.size() && r.count < kMaxCtx) {
       const gf_fetch_desc& d = *plain[pi++];

@@ -49,11 +49,12 @@ class FeatureCache {
  private:
   friend void fetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
                            hipStream_t);
-  void reserve_workspace(size_t n);
+  void reserve_workspace(size_t n, hipStream_t stream);
   // fills a device context (feature_cache.hip: struct Ctx) for one block fetch and advances
-  // the host-side epoch / counter ring
+  // the host-side epoch / counter ring (LRU: schedules a queue compaction when due)
   void prepare(const int64_t* d_ids, size_t n, float* d_out, bool update, uint32_t* d_stats,
-               void* ctx_out);
+               void* ctx_out, hipStream_t stream);
+  void init_queue(hipStream_t stream);   // LRU list (feature_cache.hip header)
 
   size_t num_ids_, capacity_, dim_;
   const float* feats_;
@@ -62,8 +63,12 @@ class FeatureCache {
   DeviceBuffer buffer_;    // float[capacity * dim]        cache rows
   DeviceBuffer map_;       // int32[num_ids]               id -> slot (kAbsent if none)
   DeviceBuffer slot_id_;   // int64[capacity]              slot -> id (-1 empty)
-  DeviceBuffer stamp_;     // uint32[capacity]             epoch of last touch
-  DeviceBuffer touched_;   // uint32[capacity]             epoch of the last hit (pending)
+  DeviceBuffer stamp_;     // uint32[capacity]  LFU: use count; FIFO: install epoch
+  DeviceBuffer touched_;   // uint32[capacity]  epoch of the last hit (pending)
+  DeviceBuffer queue_, queue_alt_;   // uint32[capacity]  LRU: slots, least recently refreshed
+                                     // first; two buffers, the device knows which is current
+  DeviceBuffer qstate_;    // LRU: parity of the current list buffer, device resident
+  RetiredBuffers retired_; // scratch replaced while kernels may still use it
   DeviceBuffer state_;     // ring of per-fetch counter records
   DeviceBuffer fifo_ptr_;  // uint32: FIFO rotation pointer
   DeviceBuffer ws_;        // per-fetch scratch

@@ -10,9 +10,13 @@ dgl / libgnnflow; tests/golden/make_cache_fixtures.py -> tests/golden/cache_refe
 fetched features bit-exact, hit ratios exact wherever the reference's `torch.topk` has no
 tie to break.  Two places where the reference is under-specified are made deterministic
 here and in the HIP path the same way:
-  * eviction ties (equal `count`): lowest slot index first (torch.topk's tie order is
-    unspecified and differs between its CPU and CUDA kernels), and the evicted slots
-    receive the new ids in slot order;
+  * eviction ties (equal `count`; torch.topk's tie order is unspecified and differs between
+    its CPU and CUDA kernels).  LRU: STABLE — slots with equal `count` keep the relative
+    order they had before (slot order after init_cache()), i.e. the cache is an LRU list:
+    an update moves the hit slots, in list order, behind the others, evicts the first k of
+    that list and appends them, refilled, in eviction order (the i-th victim receives the
+    i-th new id) — what a stable sort by `count` yields.  LFU: lowest slot index first,
+    evicted slots refilled in slot order;
   * overflow_rule: when a block has more distinct missed ids than the cache has slots,
     the reference keeps the `capacity` smallest ids (an artefact of torch.unique
     sorting); "first_seen" keeps the first `capacity` distinct missed ids in block order,
@@ -37,6 +41,8 @@ class LRUKind:
         self.map = np.full(self.num_ids, -1, np.int64)
         self.index_to_id = np.full(self.capacity, -1, np.int64)
         self.count = np.zeros(self.capacity, np.int32)
+        # LRU list: slots, least recently refreshed first (primary order == `count`)
+        self.order = np.arange(self.capacity, dtype=np.int64)
 
     # cache.py:175-195 / lru_cache.py:91-105
     def init(self):
@@ -51,6 +57,7 @@ class LRUKind:
         self.count[:] = 1 if self.policy == "lfu" else 0     # lfu_cache.py:80-84
         self.updates = 0
         self.pointer = self.capacity - 1
+        self.order = np.arange(c, dtype=np.int64)
 
     def reset_order(self):   # fifo_cache.py:70-75 (pointer) / lfu_cache.py:118 (count.zero_())
         self.pointer = self.capacity - 1
@@ -98,11 +105,18 @@ class LRUKind:
             return
         self.count -= 1
         self.count[cached_index] = 0
-        # topk(k, largest=False) with ties -> lowest slot index; the evicted slots are
-        # refilled in slot order (the reference pairs ids with topk's output order,
-        # which only matters through later ties)
-        removing = np.sort(np.argsort(self.count, kind="stable")[:k])
+        # topk(k, largest=False): the k least recently refreshed slots, ties resolved
+        # stably: the hit slots move behind the others keeping their order, the first k of
+        # the list are evicted and re-appended, refilled, in that order.
+        hit = np.zeros(self.capacity, bool)
+        hit[cached_index] = True
+        in_order = hit[self.order]
+        lst = np.concatenate([self.order[~in_order], self.order[in_order]])
+        removing = lst[:k]
+        assert np.array_equal(np.sort(self.count[removing]),
+                              np.sort(np.partition(self.count, k - 1)[:k]))   # a valid topk
         self._install(removing, ids_to_cache, 0)
+        self.order = np.concatenate([lst[k:], removing])
 
     def _install(self, removing, ids_to_cache, new_count):
         removing_ids = self.index_to_id[removing]
@@ -122,8 +136,8 @@ class LRUKind:
     # Cache.resize / LRUCache.resize (cache.py:197-221, lru_cache.py:107-119).  The reference
     # grows its tensors with torch's resize_, which leaves the new elements UNINITIALISED;
     # the deterministic completion used here and in the HIP path: new ids are uncached, new
-    # slots are empty and as old as a slot never touched since init_cache (LRU), unused
-    # (LFU, count 0), or simply further along the ring (FIFO, pointer unchanged).
+    # slots are empty and the first to be refilled, in slot order (LRU), unused (LFU, count
+    # 0), or simply further along the ring (FIFO, pointer unchanged).
     def resize(self, num_ids, capacity, feats):
         num_ids, capacity = int(num_ids), max(int(capacity), self.capacity)
         add_ids, add_slots = num_ids - self.num_ids, capacity - self.capacity
@@ -132,8 +146,10 @@ class LRUKind:
         self.map = np.concatenate([self.map, np.full(add_ids, -1, np.int64)])
         self.buffer = np.concatenate([self.buffer, np.zeros((add_slots, self.dim), np.float32)])
         self.index_to_id = np.concatenate([self.index_to_id, np.full(add_slots, -1, np.int64)])
-        fill = -self.updates if self.policy == "lru" else 0
+        fill = -self.updates - 1 if self.policy == "lru" else 0
         self.count = np.concatenate([self.count, np.full(add_slots, fill, np.int32)])
+        self.order = np.concatenate([np.arange(self.capacity, capacity, dtype=np.int64),
+                                     self.order])
         self.num_ids, self.capacity = num_ids, capacity
 
 
