@@ -51,7 +51,8 @@ def workload_key(args, repeats):
             "batch_size": args.batch_size, "fanouts": args.fanouts, "strategy": args.strategy,
             "cache_ratio": args.cache_ratio, "undirected": bool(args.undirected),
             "feature_placement": args.feature_placement, "partition": args.partition,
-            "pipelined": not args.no_pipeline, "sample_only": bool(args.sample_only)}
+            "pipelined": not args.no_pipeline, "pipeline_depth": args.pipeline_depth,
+            "sample_only": bool(args.sample_only)}
 
 
 def parse():
@@ -80,6 +81,8 @@ def parse():
                          "an all-to-all exchange per layer (gnnflow_amd/dist.py)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap batch i+1's sample() with batch i's fetch_feature()")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="batches whose sample() is in flight ahead of the fetch (1..3)")
     ap.add_argument("--event-stride", type=int, default=17,
                     help="time every n-th gather launch with HIP events (1 = all)")
     ap.add_argument("--breakdown", action="store_true",
@@ -167,7 +170,8 @@ def main():
     # calls; nothing is skipped or cached.  gnnflow_amd/pipeline.py, parity-tested.
     from gnnflow_amd.pipeline import ReplayPipeline
     pipe = ReplayPipeline(sampler, cache, dev_batches, dev,
-                          pipelined=cache is not None and not args.no_pipeline)
+                          pipelined=cache is not None and not args.no_pipeline,
+                          depth=args.pipeline_depth)
     pipelined = pipe.pipelined
 
     def barrier():
@@ -262,6 +266,7 @@ def main():
             "graph_build_s": round(build_s, 3),
             "parallelism": "{}-dp{}".format(args.partition, world),
             "pipelined": bool(pipelined),
+            "pipeline_depth": pipe.depth if pipelined else 0,
         },
     }
     if cache is not None and g_n.value:
@@ -353,6 +358,11 @@ def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather)
     over the roots / rows; same routine, identical output).  `value` is the faster of the two
     with its `cores`.  Reported baseline, not the target."""
     from oracle import oracle as O
+    import numpy as np
+    # fresh host copies: the arrays that came back from the GPU sit in pages first touched by
+    # the runtime's copy threads (measured 1.5x / 3x slower for the gathers at 1 / 16 threads
+    # on the 2-socket GPU box); the CPU side gets its tables in memory it touched itself
+    edge_feats, node_feats = np.array(edge_feats, copy=True), np.array(node_feats, copy=True)
     og = O.OracleGraph(minimum_block_size=62, insertion_policy="insert")
     for lo in range(0, g["num_edges"], 100000):
         hi = lo + 100000
@@ -364,8 +374,9 @@ def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather)
         """Whole passes over `batches` (the batch sequence of the GPU's timed region, so
         edges per step are the same on both sides) until the budget is spent; >= 1 pass."""
         osamp = O.OracleSampler(og, fanouts, args.strategy, seed=1234, threads=threads)
-        edges, t_total, n_done, passes = 0, 0.0, 0, 0
+        t_total, passes, best = 0.0, 0, None
         while passes == 0 or t_total < budget_s:
+            edges, t_pass = 0, 0.0
             for r, t, e in batches:
                 t0 = time.perf_counter()
                 mfgs = osamp.sample(r, t)
@@ -377,27 +388,31 @@ def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather)
                             if blk.num_edges():
                                 blk.edata["f"] = O.gather_rows(edge_feats, blk.edata["ID"], threads)
                     O.gather_rows(edge_feats, e, threads)     # target_edge_features
-                t_total += time.perf_counter() - t0
+                t_pass += time.perf_counter() - t0
                 edges += sum(b.num_edges() for mfg in mfgs for b in mfg)
-                n_done += 1
             passes += 1
-        return dict(value=edges / t_total, cores=threads, batches=n_done, passes=passes,
-                    seconds=t_total, ms_per_step=1e3 * t_total / max(n_done, 1),
-                    edges_per_step=edges / max(n_done, 1))
+            t_total += t_pass
+            # the GPU box is shared with other tenants: the FASTEST pass is the baseline
+            if best is None or t_pass < best[1]:
+                best = (edges, t_pass)
+        return dict(value=best[0] / best[1], cores=threads, batches=len(batches), passes=passes,
+                    seconds=t_total, ms_per_step=1e3 * best[1] / max(len(batches), 1),
+                    edges_per_step=best[0] / max(len(batches), 1))
 
-    one = run(1, args.cpu_seconds / 2)
+    # the box is shared: more passes for the all-core run, whose time varies most
+    one = run(1, args.cpu_seconds / 3)
     runs = [one]
     if all_cores > 1:
-        runs.append(run(all_cores, args.cpu_seconds / 2))
+        runs.append(run(all_cores, 2 * args.cpu_seconds / 3))
     best = max(runs, key=lambda r: r["value"])
     return {
         "value": best["value"], "unit": "edges/s", "cores": best["cores"], "kind": "port",
         "sample": "batches 0..{} of the chronological replay — the batch sequence of the GPU's "
-                  "timed region — in whole passes ({:.1f} s of CPU work in all; oracle sample() "
-                  "+ cache-free gather of every block, no LRU bookkeeping; gcc -O2 -fopenmp): "
-                  "{}".format(
+                  "timed region — in whole passes, fastest pass reported ({:.1f} s of CPU work in "
+                  "all; oracle sample() + cache-free gather of every block, no LRU bookkeeping; "
+                  "gcc -O2 -fopenmp): {}".format(
                       len(batches) - 1, sum(r["seconds"] for r in runs),
-                      "; ".join("{} thread{}: {} pass{} = {:.2f} M edges/s".format(
+                      "; ".join("{} thread{}: best of {} pass{} = {:.2f} M edges/s".format(
                           r["cores"], "" if r["cores"] == 1 else "s", r["passes"],
                           "" if r["passes"] == 1 else "es", r["value"] / 1e6) for r in runs)),
         "ms_per_step": best["ms_per_step"],

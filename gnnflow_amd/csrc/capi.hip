@@ -3,7 +3,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <atomic>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -14,7 +16,7 @@
 #include "sampler.hpp"
 
 struct gf_graph { gf::EdgeStore impl; template <typename... A> explicit gf_graph(A&&... a) : impl(std::forward<A>(a)...) {} };
-struct gf_sampler { gf::Sampler impl; uint64_t begin_ticket = 0; template <typename... A> explicit gf_sampler(A&&... a) : impl(std::forward<A>(a)...) {} };
+struct gf_sampler { gf::Sampler impl; std::deque<uint64_t> begin_tickets; /* 0 = begun synchronously */ template <typename... A> explicit gf_sampler(A&&... a) : impl(std::forward<A>(a)...) {} };
 struct gf_cache { gf::FeatureCache impl; template <typename... A> explicit gf_cache(A&&... a) : impl(std::forward<A>(a)...) {} };
 
 namespace gf {
@@ -24,9 +26,10 @@ thread_local std::string g_last_error;
 
 struct ProfileRecord { int slot; hipEvent_t start, stop; };
 std::mutex g_prof_mu;
-unsigned g_prof_mask = 0;
-unsigned g_prof_stride = 1;               // time every n-th interval of a slot
-uint64_t g_prof_seq[kProfSlots] = {0};
+// read by the launching threads (caller + enqueue thread) without the mutex
+std::atomic<unsigned> g_prof_mask{0};
+std::atomic<unsigned> g_prof_stride{1};   // time every n-th interval of a slot
+std::atomic<uint64_t> g_prof_seq[kProfSlots];
 std::vector<hipEvent_t> g_prof_free;      // recycled events (creating one costs microseconds)
 hipEvent_t take_event() {
   {
@@ -57,11 +60,12 @@ void drain_profile_locked() {
 }  // namespace
 
 void set_last_error(const std::string& msg) { g_last_error = msg; }
-bool profile_enabled() { return g_prof_mask != 0; }
+bool profile_enabled() { return g_prof_mask.load(std::memory_order_relaxed) != 0; }
 
 ProfileScope::ProfileScope(int slot_, hipStream_t stream_) : slot(slot_), stream(stream_) {
-  if (!(g_prof_mask & (1u << slot))) return;
-  if (g_prof_seq[slot]++ % g_prof_stride != 0) return;
+  if (!(g_prof_mask.load(std::memory_order_relaxed) & (1u << slot))) return;
+  if (g_prof_seq[slot].fetch_add(1, std::memory_order_relaxed) %
+          g_prof_stride.load(std::memory_order_relaxed) != 0) return;
   start = take_event();
   if (start) (void)hipEventRecord(start, stream);
 }
@@ -76,8 +80,9 @@ ProfileScope::~ProfileScope() {
 }
 
 bool profile_begin(int slot, hipEvent_t* start, hipEvent_t* stop) {
-  if (!(g_prof_mask & (1u << slot))) return false;
-  if (g_prof_seq[slot]++ % g_prof_stride != 0) return false;
+  if (!(g_prof_mask.load(std::memory_order_relaxed) & (1u << slot))) return false;
+  if (g_prof_seq[slot].fetch_add(1, std::memory_order_relaxed) %
+          g_prof_stride.load(std::memory_order_relaxed) != 0) return false;
   *start = take_event();
   *stop = take_event();
   if (*start && *stop) return true;
@@ -109,23 +114,32 @@ class EnqueueWorker {
     return *w;
   }
   uint64_t submit(Job&& job) {
-    std::unique_lock<std::mutex> lk(mu_);
-    q_.push_back(std::move(job));
-    const uint64_t ticket = ++submitted_;
-    cv_job_.notify_one();
+    bool wake;
+    uint64_t ticket;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      q_.push_back(std::move(job));
+      ticket = ++submitted_;
+      wake = sleeping_;
+    }
+    pending_.fetch_add(1, std::memory_order_release);
+    if (wake) cv_job_.notify_one();   // a futex wake costs microseconds: only when needed
     return ticket;
   }
-  // status of the submission `ticket` once it has been enqueued
+  // status of the submission `ticket` — its own, not an earlier job's — once it has been
+  // enqueued
   int wait(uint64_t ticket, std::string* err) {
+    // the enqueue usually finishes within microseconds: poll before sleeping on the condvar
+    for (int i = 0; i < 20000 && done_.load(std::memory_order_acquire) < ticket; ++i)
+      __builtin_ia32_pause();
     std::unique_lock<std::mutex> lk(mu_);
     cv_done_.wait(lk, [&] { return completed_ >= ticket; });
-    if (first_error_ticket_ && first_error_ticket_ <= ticket) {
-      *err = error_;
-      const int rc = error_code_;
-      first_error_ticket_ = 0;
-      return rc;
-    }
-    return GF_OK;
+    auto it = failed_.find(ticket);
+    if (it == failed_.end()) return GF_OK;
+    const int rc = it->second.first;
+    *err = std::move(it->second.second);
+    failed_.erase(it);
+    return rc;
   }
 
  private:
@@ -133,12 +147,28 @@ class EnqueueWorker {
   void run() {
     for (;;) {
       Job job;
+      // In a running pipeline the next job arrives within tens of microseconds: poll for it
+      // (bounded, ~100 us) before sleeping, so that the submitter does not pay a futex wake
+      // and this thread does not pay the wake-up latency.
+      {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; pending_.load(std::memory_order_acquire) == 0; ++i) {
+          __builtin_ia32_pause();
+          if ((i & 255) == 255 &&
+              std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
+        }
+      }
       {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_job_.wait(lk, [&] { return !q_.empty(); });
+        if (q_.empty()) {
+          sleeping_ = true;
+          cv_job_.wait(lk, [&] { return !q_.empty(); });
+          sleeping_ = false;
+        }
         job = std::move(q_.front());
         q_.pop_front();
       }
+      pending_.fetch_sub(1, std::memory_order_relaxed);
       int rc = GF_OK;
       std::string msg;
       const auto t0 = std::chrono::steady_clock::now();
@@ -153,10 +183,10 @@ class EnqueueWorker {
       std::unique_lock<std::mutex> lk(mu_);
       busy_us_ += std::chrono::duration<double, std::micro>(t1 - t0).count();
       ++completed_;
-      if (rc != GF_OK && !first_error_ticket_) {
-        first_error_ticket_ = completed_;
-        error_code_ = rc;
-        error_ = msg;
+      done_.store(completed_, std::memory_order_release);
+      if (rc != GF_OK) {
+        failed_[completed_] = std::make_pair(rc, msg);   // jobs complete in ticket order
+        while (failed_.size() > 64) failed_.erase(failed_.begin());   // never waited for
       }
       cv_done_.notify_all();
     }
@@ -164,9 +194,11 @@ class EnqueueWorker {
   std::mutex mu_;
   std::condition_variable cv_job_, cv_done_;
   std::deque<Job> q_;
-  uint64_t submitted_ = 0, completed_ = 0, first_error_ticket_ = 0;
-  int error_code_ = GF_OK;
-  std::string error_;
+  uint64_t submitted_ = 0, completed_ = 0;
+  bool sleeping_ = false;                 // worker is (about to be) blocked on cv_job_
+  std::atomic<uint64_t> pending_{0};      // jobs queued and not yet taken
+  std::atomic<uint64_t> done_{0};         // == completed_, readable without the mutex
+  std::map<uint64_t, std::pair<int, std::string>> failed_;   // ticket -> status of that job
 
  public:
   double busy_us_ = 0;   // time spent issuing work (diagnostics)
@@ -319,6 +351,7 @@ int gf_sampler_sample(gf_sampler* s, const int64_t* d_roots, const float* d_root
                       void* stream) {
   return guarded([&] {
     GF_S(s);
+    GF_REQUIRE(s->begin_tickets.empty(), "sample: asynchronous samples are still in flight");
     s->impl.sample(d_roots, d_root_ts, num_roots, d_out, out_bytes, blocks,
                    static_cast<hipStream_t>(stream));
   });
@@ -327,8 +360,11 @@ int gf_sampler_sample_begin(gf_sampler* s, const int64_t* d_roots, const float* 
                             size_t num_roots, void* d_out, size_t out_bytes, void* stream) {
   return guarded([&] {
     GF_S(s);
+    GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
+               "sample_begin: earlier samples were begun through the enqueue thread");
     s->impl.sample_begin(d_roots, d_root_ts, num_roots, d_out, out_bytes,
                          static_cast<hipStream_t>(stream));
+    s->begin_tickets.push_back(0);
   });
 }
 int gf_sampler_sample_begin_async(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
@@ -336,22 +372,25 @@ int gf_sampler_sample_begin_async(gf_sampler* s, const int64_t* d_roots, const f
                                   void* stream) {
   return guarded([&] {
     GF_S(s);
-    GF_REQUIRE(s->begin_ticket == 0, "sample_begin_async: a sample is already in flight");
+    GF_REQUIRE(s->begin_tickets.size() < gf::Sampler::kMaxInFlight,
+               "sample_begin_async: too many samples in flight on this sampler");
     gf::Sampler* impl = &s->impl;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    s->begin_ticket = gf::EnqueueWorker::get().submit(
+    s->begin_tickets.push_back(gf::EnqueueWorker::get().submit(
         [impl, d_roots, d_root_ts, num_roots, d_out, out_bytes, st]() {
           impl->sample_begin(d_roots, d_root_ts, num_roots, d_out, out_bytes, st);
-        });
+        }));
   });
 }
 int gf_sampler_sample_end(gf_sampler* s, gf_block* blocks) {
-  if (s && s->begin_ticket) {   // begun through the enqueue thread: wait for the enqueue
-    std::string err;
-    const uint64_t t = s->begin_ticket;
-    s->begin_ticket = 0;
-    const int rc = gf::EnqueueWorker::get().wait(t, &err);
-    if (rc != GF_OK) { gf::set_last_error(err); return rc; }
+  if (s && !s->begin_tickets.empty()) {
+    const uint64_t t = s->begin_tickets.front();
+    s->begin_tickets.pop_front();
+    if (t) {   // begun through the enqueue thread: wait for the enqueue of THIS sample
+      std::string err;
+      const int rc = gf::EnqueueWorker::get().wait(t, &err);
+      if (rc != GF_OK) { gf::set_last_error(err); return rc; }
+    }
   }
   return guarded([&] { GF_S(s); s->impl.sample_end(blocks); });
 }

@@ -88,6 +88,7 @@ constexpr int kMaxCtx = 4;              // contexts per round
 constexpr uint32_t kRowTile = 4096;     // rows per scan workgroup (kWide threads x 4)
 constexpr uint32_t kMaxRowTiles = 1024; // more row tiles than this: chained single-workgroup scan
 constexpr uint32_t kQGroup = 64;        // LRU: list tiles per group sum
+constexpr uint32_t kInstRows = 256;     // LRU: block rows per install workgroup
 
 // One record per fetch.  hits / misses are accumulated once per workgroup into one of 8
 // shards that sit on separate 128-byte lines: same-address atomics retire at only
@@ -890,17 +891,20 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
   const uint32_t spans = (row_tiles + c.tiles_per_wg - 1) / c.tiles_per_wg;
   const uint32_t cap = c.capacity;
   if (blockIdx.x < row_blocks) {
-    __shared__ uint2 inst[kWide];   // {slot, row} installed by this workgroup
+    // kInstRows rows per workgroup, one thread each; ALL kWide threads then copy the
+    // installed rows, so the copy of a block's ~thousands of missed rows is spread over
+    // n / kInstRows workgroups with 4 rows' worth of loads in flight per installing thread
+    __shared__ uint2 inst[kInstRows];   // {slot, row} installed by this workgroup
     __shared__ uint32_t n_inst;
     const uint32_t span_rows = c.tiles_per_wg * kRowTile;
-    const uint32_t chunks = (c.n + kWide - 1) / kWide;
+    const uint32_t chunks = (c.n + kInstRows - 1) / kInstRows;
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += row_blocks) {
-      const uint32_t i = chunk * kWide + tid;
-      const bool in = i < c.n;
+      const uint32_t i = chunk * kInstRows + tid;
+      const bool in = tid < static_cast<int>(kInstRows) && i < c.n;
       // every independent load first: the row's code and id, the span counts, the record
       const uint32_t code = in ? c.rep_flag[i] : 0u;
       const int64_t id = in ? c.ids[i] : 0;
-      const uint32_t w = (chunk * kWide) / span_rows;   // scan workgroup of these rows
+      const uint32_t w = (chunk * kInstRows) / span_rows;   // scan workgroup of these rows
       uint32_t pm = 0, tm = 0;
       for (uint32_t t = tid; t < spans; t += kWide) {
         const uint32_t m = c.row_tile_sum[t];
@@ -933,10 +937,15 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
       if (c.vec4) {
         const float4* out = reinterpret_cast<const float4*>(c.out);
         float4* buf = reinterpret_cast<float4*>(c.cache_buf);
-        for (uint32_t f = tid; f < total; f += kWide) {
+        for (uint32_t f = tid; f < total; f += 2 * kWide) {
+          const uint32_t f2 = f + kWide;
           const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
-          const uint2 pr = inst[j];
-          buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] = out[static_cast<uint64_t>(pr.y) * c.dimv + cc];
+          const uint32_t j2 = f2 < total ? f2 / c.dimv : j, cc2 = f2 < total ? f2 - j2 * c.dimv : cc;
+          const uint2 pr = inst[j], pr2 = inst[j2];
+          const float4 v = out[static_cast<uint64_t>(pr.y) * c.dimv + cc];
+          const float4 v2 = out[static_cast<uint64_t>(pr2.y) * c.dimv + cc2];
+          buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] = v;
+          if (f2 < total) buf[static_cast<uint64_t>(pr2.x) * c.dimv + cc2] = v2;
         }
       } else {
         for (uint32_t f = tid; f < total; f += kWide) {
@@ -1097,7 +1106,7 @@ void launch_round(Round& r, hipStream_t stream) {
         std::max<size_t>(1, std::min<size_t>((q_cap + kRowTile - 1) / kRowTile, 1024)));
     lru_list_scan_kernel<<<dim3(rb + lb + 1, r.count), dim3(kWide), 0, stream>>>(r, rb, lb);
     const unsigned ib = static_cast<unsigned>(
-        std::max<size_t>(1, std::min<size_t>((q_rows + kWide - 1) / kWide, 2048)));
+        std::max<size_t>(1, std::min<size_t>((q_rows + kInstRows - 1) / kInstRows, 4096)));
     lru_list_install_kernel<<<dim3(ib + lb, r.count), dim3(kWide), 0, stream>>>(r, ib, lb);
     GF_HIP(hipGetLastError());
   }

@@ -585,13 +585,22 @@ Sampler::Sampler(EdgeStore* graph, const uint32_t* fanouts, size_t num_layers, i
     const char* v = std::getenv("GNNFLOW_SAMPLER_FUSED_SCAN");
     fused_scan_ = !(v && std::atoi(v) == 0);
   }
-  GF_HIP(hipEventCreateWithFlags(&done_ev_, hipEventDisableTiming));
   DeviceGuard dg(graph_->device());
+  for (InFlight& f : ring_) GF_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+  rec_words_ = 1 + 2 * num_layers * num_snapshots;
+  h_counts_.reserve(kMaxInFlight * rec_words_ * sizeof(uint64_t));
+  std::memset(h_counts_.data(), 0, kMaxInFlight * rec_words_ * sizeof(uint64_t));
+  h_layer_counts_.reserve(2 * sizeof(uint64_t));
   GF_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
 }
 
 Sampler::~Sampler() {
-  if (done_ev_) (void)hipEventDestroy(done_ev_);
+  for (InFlight& f : ring_) {
+    if (f.done) {
+      (void)hipEventSynchronize(f.done);
+      (void)hipEventDestroy(f.done);
+    }
+  }
   if (own_stream_) {
     (void)hipStreamSynchronize(own_stream_);
     (void)hipStreamDestroy(own_stream_);
@@ -636,9 +645,13 @@ void Sampler::reserve_workspace(size_t Rb, size_t num_blocks, hipStream_t stream
   ws_blocks_ = std::max(ws_blocks_, num_blocks);
   size_t bytes = align_up(ws_roots_ * 8, 16) + 3 * align_up(ws_roots_ * 4, 16) +
                  ws_blocks_ * 2 * sizeof(uint64_t) + 64;
-  (void)stream;
-  ws_.reserve(bytes, 0, nullptr);
-  h_counts_.reserve((ws_blocks_ * 2 + 1) * sizeof(uint64_t));
+  // kernels of earlier samples may still be queued on `stream` with the old workspace: it
+  // is retired behind an event and freed later (stream-ordered swap, no stall)
+  retired_.collect();
+  DeviceBuffer fresh;
+  fresh.reserve(bytes, 0, stream);
+  std::swap(ws_, fresh);
+  retired_.retire(std::move(fresh), stream);
 }
 
 void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb,
@@ -722,12 +735,25 @@ void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb
 void Sampler::sample_begin(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                            size_t out_bytes, hipStream_t stream) {
   const size_t L = fanouts_.size(), NS = num_snapshots_;
-  GF_REQUIRE(!pending_, "sample_begin: a sample is already in flight on this sampler");
-  pending_ptrs_.assign(L * NS, BlockPtrs{});
-  pending_roots_ = R;
+  InFlight* slot;
+  {
+    std::lock_guard<std::mutex> lk(ring_mu_);
+    GF_REQUIRE(ring_count_ < kMaxInFlight, "sample_begin: too many samples in flight on this sampler");
+    if (ring_count_ > 0) {
+      const InFlight& newest = ring_[(ring_head_ + ring_count_ - 1) % kMaxInFlight];
+      GF_REQUIRE(newest.roots == 0 || R == 0 || newest.stream == stream,
+                 "sample_begin: samples in flight on one sampler must share a stream");
+    }
+    slot = &ring_[(ring_head_ + ring_count_) % kMaxInFlight];
+  }
+  // (only this thread begins samples: the slot stays free until ring_count_ is bumped below)
+  slot->ptrs.assign(L * NS, BlockPtrs{});
+  slot->roots = R;
+  slot->stream = stream;
   if (R == 0) {  // temporal_sampler.cu:107-114
     calls_ += L * NS;
-    pending_ = true;
+    std::lock_guard<std::mutex> lk(ring_mu_);
+    ++ring_count_;
     return;
   }
   GF_REQUIRE(d_roots && d_ts && d_out, "sample: null device pointer");
@@ -737,7 +763,7 @@ void Sampler::sample_begin(const int64_t* d_roots, const float* d_ts, size_t R, 
   uint64_t* d_counts = reinterpret_cast<uint64_t*>(
       ws_.as<char>() + align_up(ws_roots_ * 8, 16) + 3 * align_up(ws_roots_ * 4, 16));
 
-  std::vector<BlockPtrs>& ptrs = pending_ptrs_;
+  std::vector<BlockPtrs>& ptrs = slot->ptrs;
   char* p = static_cast<char*>(d_out);
   for (size_t l = 0; l < L; ++l) {
     const size_t Rb = root_bound(R, l);
@@ -750,67 +776,90 @@ void Sampler::sample_begin(const int64_t* d_roots, const float* d_ts, size_t R, 
     const size_t Rb = root_bound(R, l);
     for (size_t s = 0; s < NS; ++s) {
       const size_t b = l * NS + s;
-      uint64_t* slot = d_counts + 2 * b;
+      uint64_t* cslot = d_counts + 2 * b;
       // the next layer of the same snapshot reads its root count R + S from next_R
-      uint64_t* next_R = (l + 1 < L) ? slot + 2 * NS : nullptr;
+      uint64_t* next_R = (l + 1 < L) ? cslot + 2 * NS : nullptr;
       if (l == 0) {
-        enqueue_layer(d_roots, d_ts, Rb, nullptr, R, l, s, ptrs[b], slot, next_R, stream);
+        enqueue_layer(d_roots, d_ts, Rb, nullptr, R, l, s, ptrs[b], cslot, next_R, stream);
       } else {
         const BlockPtrs& prev = ptrs[(l - 1) * NS + s];
-        enqueue_layer(prev.all_nodes, prev.all_ts, Rb, slot, 0, l, s, ptrs[b], slot, next_R,
+        enqueue_layer(prev.all_nodes, prev.all_ts, Rb, cslot, 0, l, s, ptrs[b], cslot, next_R,
                       stream);
       }
     }
   }
-  *h_counts_.as<volatile uint64_t>() = 0;   // no publish is pending: one sample in flight
+  slot->seq = ++publish_seq_;
+  uint64_t* rec = h_counts_.as<uint64_t>() + (slot->seq % kMaxInFlight) * rec_words_;
+  *reinterpret_cast<volatile uint64_t*>(rec) = 0;   // this record's publish is pending
   Publish pub;
   pub.d_counts = d_counts;
-  pub.h_counts = h_counts_.as<uint64_t>() + 1;   // word 0 is the sequence flag
-  pub.h_flag = h_counts_.as<uint64_t>();
-  pub.seq = ++publish_seq_;
+  pub.h_counts = rec + 1;   // word 0 is the sequence flag
+  pub.h_flag = rec;
+  pub.seq = slot->seq;
   pub.num_words = static_cast<uint32_t>(L * NS * 2);
   sample_publish_kernel<<<dim3(1), dim3(64), 0, stream>>>(pub);
   GF_HIP(hipGetLastError());
-  GF_HIP(hipEventRecord(done_ev_, stream));
-  pending_ = true;
+  GF_HIP(hipEventRecord(slot->done, stream));
+  std::lock_guard<std::mutex> lk(ring_mu_);
+  ++ring_count_;
+}
+
+size_t Sampler::in_flight() const {
+  std::lock_guard<std::mutex> lk(ring_mu_);
+  return ring_count_;
 }
 
 void Sampler::sample_end(gf_block* blocks) {
   const size_t L = fanouts_.size(), NS = num_snapshots_;
   GF_REQUIRE(blocks != nullptr, "sample: null blocks array");
-  GF_REQUIRE(pending_, "sample_end: no sample in flight");
-  pending_ = false;
-  if (pending_roots_ == 0) {
+  InFlight* slot;
+  {
+    std::lock_guard<std::mutex> lk(ring_mu_);
+    GF_REQUIRE(ring_count_ > 0, "sample_end: no sample in flight");
+    slot = &ring_[ring_head_];
+  }
+  auto pop = [&] {
+    std::lock_guard<std::mutex> lk(ring_mu_);
+    ring_head_ = (ring_head_ + 1) % kMaxInFlight;
+    --ring_count_;
+  };
+  if (slot->roots == 0) {
     for (size_t b = 0; b < L * NS; ++b) std::memset(&blocks[b], 0, sizeof(gf_block));
+    pop();
     return;
   }
   DeviceGuard dg(graph_->device());
   // spin on the pinned sequence word (sub-microsecond reaction); fall back to the event
   // if the kernel has not published after a generous number of polls
-  volatile uint64_t* flag = h_counts_.as<volatile uint64_t>();
+  const uint64_t* rec = h_counts_.as<uint64_t>() + (slot->seq % kMaxInFlight) * rec_words_;
+  volatile const uint64_t* flag = rec;
   bool seen = false;
   for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
-    if (*flag == publish_seq_) { seen = true; break; }
+    if (*flag == slot->seq) { seen = true; break; }
     __builtin_ia32_pause();
     // a short pure spin covers the usual few microseconds; beyond that give the core away
     // (8 ranks per node each have a spinner and an enqueue thread)
     if (spin > 4096 && (spin & 63) == 0) sched_yield();
   }
-  if (!seen) GF_HIP(hipEventSynchronize(done_ev_));
+  if (!seen) {
+    const hipError_t e = hipEventSynchronize(slot->done);
+    if (e != hipSuccess) { pop(); GF_HIP(e); }
+  }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  const uint64_t* hc = h_counts_.as<uint64_t>() + 1;
+  const uint64_t* hc = rec + 1;
   for (size_t b = 0; b < L * NS; ++b) {
     gf_block& o = blocks[b];
-    o.all_nodes = pending_ptrs_[b].all_nodes;
-    o.all_timestamps = pending_ptrs_[b].all_ts;
-    o.delta_timestamps = pending_ptrs_[b].dt;
-    o.eids = pending_ptrs_[b].eids;
-    o.row = pending_ptrs_[b].row;
-    o.col = pending_ptrs_[b].col;
+    o.all_nodes = slot->ptrs[b].all_nodes;
+    o.all_timestamps = slot->ptrs[b].all_ts;
+    o.delta_timestamps = slot->ptrs[b].dt;
+    o.eids = slot->ptrs[b].eids;
+    o.row = slot->ptrs[b].row;
+    o.col = slot->ptrs[b].col;
     o.num_dst_nodes = hc[2 * b];
     o.num_edges = hc[2 * b + 1];
     o.num_src_nodes = o.num_dst_nodes + o.num_edges;
   }
+  pop();
 }
 
 void Sampler::sample(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
@@ -840,10 +889,10 @@ void Sampler::sample_layer(const int64_t* d_roots, const float* d_ts, size_t R, 
       ws_.as<char>() + align_up(ws_roots_ * 8, 16) + 3 * align_up(ws_roots_ * 4, 16));
   BlockPtrs ptrs = carve(static_cast<char*>(d_out), R, fanouts_[layer]);
   enqueue_layer(d_roots, d_ts, R, nullptr, R, layer, snapshot, ptrs, d_counts, nullptr, stream);
-  GF_HIP(hipMemcpyAsync(h_counts_.data(), d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                        stream));
+  GF_HIP(hipMemcpyAsync(h_layer_counts_.data(), d_counts, 2 * sizeof(uint64_t),
+                        hipMemcpyDeviceToHost, stream));
   GF_HIP(hipStreamSynchronize(stream));
-  const uint64_t* hc = h_counts_.as<uint64_t>();
+  const uint64_t* hc = h_layer_counts_.as<uint64_t>();
   block->all_nodes = ptrs.all_nodes;
   block->all_timestamps = ptrs.all_ts;
   block->delta_timestamps = ptrs.dt;
@@ -929,10 +978,10 @@ void Sampler::merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, 
       d_roots, d_ts, R, F, d_replies, d_pos, rec_cnt, base, out.all_nodes, out.all_ts, out.dt,
       out.eids, out.row, out.col);
   GF_HIP(hipGetLastError());
-  GF_HIP(hipMemcpyAsync(h_counts_.data(), d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                        stream));
+  GF_HIP(hipMemcpyAsync(h_layer_counts_.data(), d_counts, 2 * sizeof(uint64_t),
+                        hipMemcpyDeviceToHost, stream));
   GF_HIP(hipStreamSynchronize(stream));
-  const uint64_t* hc = h_counts_.as<uint64_t>();
+  const uint64_t* hc = h_layer_counts_.as<uint64_t>();
   block->all_nodes = out.all_nodes;
   block->all_timestamps = out.all_ts;
   block->delta_timestamps = out.dt;

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -27,9 +28,15 @@ class Sampler {
 
   void sample(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
               size_t out_bytes, gf_block* blocks, hipStream_t stream);
+  // Split form: begin() enqueues every kernel plus the size read-back and returns; end()
+  // waits for the OLDEST begun sample and reports its block sizes.  Up to kMaxInFlight
+  // samples may be begun before the first end() — they must all use the same stream (the
+  // kernels share one workspace, which stream order keeps consistent).
+  static constexpr size_t kMaxInFlight = 4;
   void sample_begin(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                     size_t out_bytes, hipStream_t stream);
   void sample_end(gf_block* blocks);
+  size_t in_flight() const;
   void sample_layer(const int64_t* d_roots, const float* d_ts, size_t R, uint32_t layer,
                     uint32_t snapshot, void* d_out, size_t out_bytes, gf_block* block,
                     hipStream_t stream);
@@ -72,15 +79,26 @@ class Sampler {
   uint64_t calls_ = 0;  // sample_layer invocations so far (uniform RNG counter)
   int search_group_ = 16;
   bool fused_scan_ = true;
-  hipEvent_t done_ev_ = nullptr;
-  bool pending_ = false;
+  // begun, not yet ended samples (FIFO).  begin() may run on the library's enqueue thread
+  // while end() runs on the caller's: the ring bookkeeping is under ring_mu_.
+  struct InFlight {
+    size_t roots = 0;
+    uint64_t seq = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    std::vector<BlockPtrs> ptrs;
+  };
+  InFlight ring_[kMaxInFlight];
+  size_t ring_head_ = 0, ring_count_ = 0;
+  mutable std::mutex ring_mu_;
   uint64_t publish_seq_ = 0;
-  size_t pending_roots_ = 0;
-  std::vector<BlockPtrs> pending_ptrs_;
+  size_t rec_words_ = 0;   // uint64 words per pinned publish record: flag + 2 per block
 
   DeviceBuffer ws_;        // per-root search records + scan scratch + counters
   size_t ws_roots_ = 0, ws_blocks_ = 0;
-  PinnedBuffer h_counts_;
+  PinnedBuffer h_counts_;        // kMaxInFlight publish records (flag + block sizes)
+  PinnedBuffer h_layer_counts_;  // blocking single-layer calls
+  RetiredBuffers retired_;       // workspace replaced while kernels may still use it
   DeviceBuffer host_io_;   // device buffers behind the *_host entry points
   hipStream_t own_stream_ = nullptr;
 };

@@ -68,7 +68,7 @@ class MFGBlock:
 
     __slots__ = ("_num_src", "_num_dst", "_col", "_row", "_num_edges", "_device",
                  "_srcdata", "_dstdata", "_edata", "_keepalive", "_raw", "_pending",
-                 "_segments", "_edge_prefix_of")
+                 "_segments", "_edge_prefix_of", "_stream_marks")
 
     def __init__(self, num_src_nodes: int, num_dst_nodes: int, col=None, row=None,
                  keepalive=None, num_edges=None, device=None, raw=None):
@@ -89,6 +89,9 @@ class MFGBlock:
         # with this block's edge arrays (same roots, same windows, same fanout); see
         # Cache.fetch_feature
         self._edge_prefix_of = None
+        # shared by all blocks carved out of one sampler output slab: streams that were
+        # already told (record_stream) that they use that allocation
+        self._stream_marks = None
 
     # ---- data dicts, created on demand ----------------------------------------------
     def _make(self, which):
@@ -243,8 +246,16 @@ class MFGBlock:
         """Marks the sampler output buffer behind this block as in use on `stream`
         (needed when the block was sampled on a side stream, e.g. by a prefetch thread,
         and is consumed on another one)."""
-        if self._keepalive is not None:
-            self._keepalive.record_stream(stream)
+        if self._keepalive is None:
+            return
+        marks = self._stream_marks
+        if marks is not None:
+            # record_stream works on the whole allocation (the slab): once per slab and stream
+            key = stream.cuda_stream
+            if key in marks:
+                return
+            marks.add(key)
+        self._keepalive.record_stream(stream)
 
     def to(self, device, **kwargs):
         device = torch.device(device)

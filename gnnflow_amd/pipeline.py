@@ -12,6 +12,7 @@ the GPU.  Every batch goes through the same calls as the plain loop; nothing is 
 bench.py times this loop and tests/test_gpu_pipeline_parity.py checks THIS loop — the same
 function — against the CPU oracle, so the path that is measured is the path that is tested.
 """
+from collections import deque
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -21,20 +22,23 @@ class ReplayPipeline:
     """Replays device-resident batches `(roots, timestamps, eids)` through
     `sampler.sample` + `cache.fetch_feature`.
 
-    pipelined=True : sample_async(stream=side, worker_enqueue=True) one batch ahead,
-                     fetch_feature(async_enqueue=True) on the current stream.
+    pipelined=True : sample_async(stream=side, worker_enqueue=True) `depth` batches ahead
+                     (2: the sampling of batch i+2 is issued before batch i+1's is waited
+                     for, which takes the sampler's issue + execution latency off the
+                     critical path), fetch_feature(async_enqueue=True) on the current stream.
     pipelined=False: the plain loop `mfgs = sampler.sample(r, t); cache.fetch_feature(mfgs, e)`.
     cache=None     : sampling only.
     """
 
     def __init__(self, sampler, cache, batches: Sequence[Tuple[torch.Tensor, torch.Tensor,
                                                                 torch.Tensor]],
-                 device: torch.device, pipelined: bool = True):
+                 device: torch.device, pipelined: bool = True, depth: int = 2):
         self.sampler, self.cache, self.batches = sampler, cache, batches
         self.device = torch.device(device)
         self.pipelined = bool(pipelined) and cache is not None and \
             hasattr(sampler, "sample_async")
         self.side = torch.cuda.Stream(device=self.device) if self.pipelined else None
+        self.depth = max(1, min(int(depth), 3))   # the sampler holds 4 begun samples at most
 
     def step(self, i: int):
         r, t, e = self.batches[i % len(self.batches)]
@@ -57,18 +61,25 @@ class ReplayPipeline:
                     on_step(i % nb, mfgs)
             return
         sampler, cache, side = self.sampler, self.cache, self.side
+        batches = self.batches
         main = torch.cuda.current_stream(self.device)
-        r, t, _ = self.batches[first % nb]
-        pending = sampler.sample_async(r, t, stream=side, worker_enqueue=True)
-        for i in range(first, first + count):
-            mfgs = pending.wait()
-            if i + 1 < first + count:
-                r, t, _ = self.batches[(i + 1) % nb]
-                pending = sampler.sample_async(r, t, stream=side, worker_enqueue=True)
+        last = first + count
+        pending = deque()
+        nxt = first
+        while nxt < last and len(pending) < self.depth:
+            r, t, _ = batches[nxt % nb]
+            pending.append(sampler.sample_async(r, t, stream=side, worker_enqueue=True))
+            nxt += 1
+        for i in range(first, last):
+            mfgs = pending.popleft().wait()
+            if nxt < last:
+                r, t, _ = batches[nxt % nb]
+                pending.append(sampler.sample_async(r, t, stream=side, worker_enqueue=True))
+                nxt += 1
             for mfg in mfgs:
                 for b in mfg:
                     b.record_stream(main)
-            cache.fetch_feature(mfgs, self.batches[i % nb][2], async_enqueue=True)
+            cache.fetch_feature(mfgs, batches[i % nb][2], async_enqueue=True)
             if on_step:
                 on_step(i % nb, mfgs)
         cache.wait_enqueued()

@@ -3,6 +3,7 @@ reference's Python wrapper (gnnflow/temporal_sampler.py:14-177); all layers and
 snapshots are sampled in one device-resident call (gf_sampler_sample) and the returned
 blocks hold torch tensors in HBM, so mfgs_to_cuda (gnnflow/utils.py:477-481) is a no-op."""
 import ctypes as C
+from collections import deque
 from typing import List, Union
 
 import numpy as np
@@ -11,6 +12,11 @@ import torch
 from . import _capi
 from .dynamic_graph import DynamicGraph
 from .mfg import MFGBlock
+
+
+class _NullCtx:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
 
 
 class SamplingResult:
@@ -32,18 +38,32 @@ class SamplingResult:
 
 
 class PendingSample:
-    """Handle of an in-flight TemporalSampler.sample_async()."""
+    """Handle of an in-flight TemporalSampler.sample_async().  Samples complete in the
+    order they were begun: wait() first completes the older ones."""
 
-    def __init__(self, sampler, buf, inputs, num_roots):
+    def __init__(self, sampler, buf, inputs, num_roots, marks):
         self._sampler, self._buf, self._inputs, self._R = sampler, buf, inputs, num_roots
+        self._marks = marks
         self._result = None
+        self._error = None
 
     def wait(self) -> List[List[MFGBlock]]:
-        if self._result is None:
-            self._result = self._sampler._finish(self._buf, self._R)
-            self._inputs = None
-            if self._sampler._inflight is self:
-                self._sampler._inflight = None
+        if self._error is not None:
+            raise self._error
+        q = self._sampler._inflight
+        while self._result is None:
+            head = q[0]
+            if head is not self:
+                head.wait()      # older sample first (native FIFO)
+                continue
+            q.popleft()          # whatever happens, the native side has popped it too
+            try:
+                self._result = self._sampler._finish(self._buf, self._R, self._marks)
+            except Exception as e:   # the failed sample must not wedge the sampler
+                self._error = e
+                raise
+            finally:
+                self._inputs = None
         return self._result
 
 
@@ -76,7 +96,8 @@ class TemporalSampler:
             float(snapshot_time_window), 1 if prop_time else 0, int(seed)))
         self._is_static = bool(kwargs.get('is_static', False))
         self._bytes_cache = {}
-        self._inflight = None
+        self._inflight = deque()       # PendingSamples, oldest first
+        self._max_inflight = 4         # gf::Sampler::kMaxInFlight
         self._slab = None
         self._gf_blocks = (_capi.GfBlock * (self._num_layers * self._num_snapshots))()
 
@@ -87,32 +108,39 @@ class TemporalSampler:
             self._h = None
 
     # ---- helpers ------------------------------------------------------------------
-    def _to_device(self, target_vertices, timestamps):
-        if isinstance(target_vertices, torch.Tensor):
-            nodes = target_vertices
-            if nodes.device != self._device or nodes.dtype != torch.int64 \
-                    or not nodes.is_contiguous():
-                nodes = nodes.to(self._device, torch.int64).contiguous()
-        else:
-            nodes = torch.from_numpy(
-                np.ascontiguousarray(target_vertices, dtype=np.int64)).to(self._device)
-        if self._is_static:
-            # gnnflow/temporal_sampler.py:72-76
-            ts = torch.full((nodes.shape[0],), float(np.finfo(np.float32).max),
-                            dtype=torch.float32, device=self._device)
-        elif isinstance(timestamps, torch.Tensor):
-            ts = timestamps
-            if ts.device != self._device or ts.dtype != torch.float32 \
-                    or not ts.is_contiguous():
-                ts = ts.to(self._device, torch.float32).contiguous()
-        else:
-            ts = torch.from_numpy(
-                np.ascontiguousarray(timestamps, dtype=np.float32)).to(self._device)
+    def _to_device(self, target_vertices, timestamps, stream=None):
+        """int64 roots / float32 timestamps on the device, contiguous.  Any conversion is
+        issued on `stream` — the stream the sampling kernels will read them on."""
+        nodes, ts = target_vertices, timestamps
+        ok_n = isinstance(nodes, torch.Tensor) and nodes.device == self._device and \
+            nodes.dtype == torch.int64 and nodes.is_contiguous()
+        ok_t = self._is_static or (
+            isinstance(ts, torch.Tensor) and ts.device == self._device and
+            ts.dtype == torch.float32 and ts.is_contiguous())
+        if not (ok_n and ok_t) or self._is_static:
+            ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
+            with ctx:
+                if not ok_n:
+                    if isinstance(nodes, torch.Tensor):
+                        nodes = nodes.to(self._device, torch.int64).contiguous()
+                    else:
+                        nodes = torch.from_numpy(
+                            np.ascontiguousarray(nodes, dtype=np.int64)).to(self._device)
+                if self._is_static:
+                    # gnnflow/temporal_sampler.py:72-76
+                    ts = torch.full((nodes.shape[0],), float(np.finfo(np.float32).max),
+                                    dtype=torch.float32, device=self._device)
+                elif not ok_t:
+                    if isinstance(ts, torch.Tensor):
+                        ts = ts.to(self._device, torch.float32).contiguous()
+                    else:
+                        ts = torch.from_numpy(
+                            np.ascontiguousarray(ts, dtype=np.float32)).to(self._device)
         assert nodes.dim() == 1 and ts.shape == nodes.shape, \
             "target_vertices and timestamps must be 1D and of equal length"
         return nodes, ts
 
-    def _block(self, buf, gb) -> MFGBlock:
+    def _block(self, buf, gb, marks=None) -> MFGBlock:
         """MFG over one gf_block; the tensor views into `buf` are built on first access."""
         if gb.all_nodes is None:
             raise RuntimeError("sampler returned a null block")
@@ -124,10 +152,12 @@ class TemporalSampler:
             off = ptr - base
             return buf[off:off + count * itemsize].view(dtype)
 
-        return MFGBlock(gb.num_src_nodes, gb.num_dst_nodes, keepalive=buf,
-                        num_edges=gb.num_edges, device=device,
-                        raw=(view, gb.all_nodes, gb.all_timestamps, gb.delta_timestamps,
-                             gb.eids, gb.col, gb.row))
+        b = MFGBlock(gb.num_src_nodes, gb.num_dst_nodes, keepalive=buf,
+                     num_edges=gb.num_edges, device=device,
+                     raw=(view, gb.all_nodes, gb.all_timestamps, gb.delta_timestamps,
+                          gb.eids, gb.col, gb.row))
+        b._stream_marks = marks
+        return b
 
     def _empty_block(self) -> MFGBlock:
         e64 = torch.empty(0, dtype=torch.int64, device=self._device)
@@ -160,28 +190,28 @@ class TemporalSampler:
         training of batch i (the reference uses a prefetch thread for this,
         scripts/offline_edge_prediction.py:343-346).  One sample in flight per sampler.
         worker_enqueue=True lets the library's enqueue thread issue the launches."""
-        prev = getattr(self, "_inflight", None)
-        if prev is not None:       # an earlier sample_async() was never waited for
-            prev.wait()
-        nodes, ts = self._to_device(target_vertices, timestamps)
-        R = int(nodes.shape[0])
+        if len(self._inflight) >= self._max_inflight:
+            self._inflight[0].wait()   # the native ring holds kMaxInFlight begun samples
         if stream is None:
             stream = torch.cuda.current_stream(self._device)
-        buf, nbytes = None, 0
+        nodes, ts = self._to_device(target_vertices, timestamps, stream)
+        R = int(nodes.shape[0])
+        buf, nbytes, marks = None, 0, None
         if R:
             nbytes = self._bytes_cache.get(R)
             if nbytes is None:
                 n = C.c_size_t(0)
                 _capi.check(self._lib.gf_sampler_output_bytes(self._h, R, C.byref(n)))
                 nbytes = self._bytes_cache[R] = n.value
-            buf = self._output_buffer(nbytes, stream)
+            buf, marks = self._output_buffer(nbytes, stream)
         begin = self._lib.gf_sampler_sample_begin_async if worker_enqueue \
             else self._lib.gf_sampler_sample_begin
         _capi.check(begin(
             self._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
             buf.data_ptr() if R else None, nbytes, C.c_void_p(stream.cuda_stream)))
-        self._inflight = PendingSample(self, buf, (nodes, ts), R)
-        return self._inflight
+        pending = PendingSample(self, buf, (nodes, ts), R, marks)
+        self._inflight.append(pending)
+        return pending
 
     def _output_buffer(self, nbytes, stream):
         """Output memory for one sample(), owned by `stream` in the caching allocator.
@@ -191,25 +221,26 @@ class TemporalSampler:
         per_slab = min(16, (32 << 20) // max(nbytes, 1))
         if per_slab < 2:
             with torch.cuda.stream(stream):
-                return torch.empty(nbytes, dtype=torch.uint8, device=self._device)
+                return torch.empty(nbytes, dtype=torch.uint8, device=self._device), set()
         step = (nbytes + 255) & ~255
         slab = self._slab
         if slab is None or slab[1] != stream or slab[2] != step or slab[3] >= per_slab:
             with torch.cuda.stream(stream):
                 mem = torch.empty(step * per_slab, dtype=torch.uint8, device=self._device)
-            slab = self._slab = [mem, stream, step, 0]
+            # slab[4]: streams already told (record_stream) that they use this allocation
+            slab = self._slab = [mem, stream, step, 0, set()]
         i = slab[3]
         slab[3] = i + 1
-        return slab[0][i * step:i * step + nbytes]
+        return slab[0][i * step:i * step + nbytes], slab[4]
 
-    def _finish(self, buf, R) -> List[List[MFGBlock]]:
+    def _finish(self, buf, R, marks=None) -> List[List[MFGBlock]]:
         blocks = self._gf_blocks
         _capi.check(self._lib.gf_sampler_sample_end(self._h, blocks))
         if R == 0:
             return [[self._empty_block() for _ in range(self._num_snapshots)]
                     for _ in range(self._num_layers)]
         ns = self._num_snapshots
-        mfgs = [[self._block(buf, blocks[layer * ns + s]) for s in range(ns)]
+        mfgs = [[self._block(buf, blocks[layer * ns + s], marks) for s in range(ns)]
                 for layer in range(self._num_layers)]
         if self._strategy == "recent":
             # Layer l+1's roots start with layer l's roots (all_nodes = roots ++ neighbours,
