@@ -464,6 +464,53 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     }
   }
 
+  // Dry run of everything that can fail later: the logical block bytes the batch adds
+  // (simulate_blocks / new_block, i.e. dynamic_graph.cu:206-287 against the rmm pool limit)
+  // and the pool elements its new segments need (seg_alloc, free lists included).  A batch
+  // that does not fit is rejected HERE — no vertex, counter, block list or allocator state
+  // has been touched yet, so the graph stays exactly as it was.
+  {
+    auto cap_of = [&](size_t s) { return s < minimum_block_size_ ? minimum_block_size_ : s; };
+    const uint64_t min_phys_dry = pow2_ceil(std::max<size_t>(minimum_block_size_, 1));
+    std::vector<size_t> avail(free_lists_.size());
+    for (size_t c = 0; c < free_lists_.size(); ++c) avail[c] = free_lists_[c].size();
+    size_t add_bytes = 0;
+    uint64_t extra = 0;
+    for (const Group& gr : groups) {
+      const size_t cnt = gr.end - gr.begin;
+      const NodeState* st =
+          static_cast<size_t>(gr.v) < nodes_.size() ? &nodes_[gr.v] : nullptr;
+      if (!st || st->num_blocks() == 0) {
+        add_bytes += cap_of(cnt) * kBlockSpace;
+      } else {
+        const LogicalBlock& tail = st->blocks.back();
+        if (tail.size + cnt > tail.capacity) {
+          if (insertion_policy_ == GF_INSERTION_POLICY_INSERT) {
+            const size_t num = cnt - (tail.capacity - tail.size);
+            const size_t avg = st->num_insertions == 0 ? num : st->num_edges / st->num_insertions;
+            add_bytes += cap_of(adaptive_ ? pow2_ceil(std::max(num, avg)) : num) * kBlockSpace;
+          } else {
+            add_bytes += (cap_of(tail.size + cnt) - tail.capacity) * kBlockSpace;
+          }
+        }
+      }
+      const uint64_t need = (st ? st->live_size : 0) + cnt;
+      if (!st || st->seg_cap == 0 || st->live_off + need > st->seg_cap) {
+        const uint64_t cap = pow2_ceil(std::max<uint64_t>(need, min_phys_dry));
+        const size_t cls = static_cast<size_t>(log2_exact(cap));
+        if (cls < avail.size() && avail[cls] > 0) avail[cls]--;
+        else extra += cap;
+      }
+    }
+    if (logical_bytes_ + add_bytes > maximum_pool_size_) {
+      throw Error(GF_ERR_OUT_OF_MEMORY,
+                  "maximum_pool_size exceeded: temporal blocks need " +
+                      std::to_string(logical_bytes_ + add_bytes) + " bytes > " +
+                      std::to_string(maximum_pool_size_) + " (batch rejected, graph unchanged)");
+    }
+    ensure_pool(bump_ + extra);   // a failing hipMalloc also surfaces before any mutation
+  }
+
   pt.mark("validate");
   // 3. bookkeeping sets (dynamic_graph.cu:89-103)
   add_nodes(max_node);

@@ -65,6 +65,54 @@ def test_add_edges_shape_and_value_errors_leave_the_graph_intact(graph):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["insert", "replace"])
+def test_rejected_batch_leaves_the_same_graph_intact(policy):
+    """A batch that would exceed maximum_pool_size is rejected before anything is mutated:
+    the SAME graph object keeps answering like the oracle that never saw the batch, and keeps
+    ingesting (reference: rmm pool exhaustion -> abort, dynamic_graph.cu:164-166)."""
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from oracle import oracle as O
+    from tests import synth
+    N = 60
+    src, dst, ts, eid = synth.powerlaw_graph(N, 3000, seed=5, tie_levels=200)
+    g = DynamicGraph(1024, 100 * 1024, "cuda", 8, 1, policy)   # 100 KiB of logical blocks
+    o = O.OracleGraph(minimum_block_size=8, insertion_policy=policy)
+    for gr in (g, o):
+        gr.add_edges(src[:1500], dst[:1500], ts[:1500], eid[:1500])
+    mem = g.get_graph_memory_usage()
+
+    def same_as_oracle():
+        assert (g.num_edges(), g.num_vertices(), g.num_source_vertices()) == \
+               (o.num_edges(), o.num_vertices(), o.num_source_vertices())
+        assert g.max_vertex_id() == o.max_vertex_id()
+        assert np.array_equal(g.out_degree(np.arange(N)), o.out_degree(np.arange(N)))
+        for v in (0, 7, 31, N - 1):
+            for a, b in zip(g.get_temporal_neighbors(v), o.get_temporal_neighbors(v)):
+                assert np.array_equal(a, b)
+        roots, rts = synth.random_roots(N, 200, 1000.0, seed=11)
+        hm = TemporalSampler(g, [4, 4]).sample(roots, rts)
+        om = O.OracleSampler(o, [4, 4]).sample(roots, rts)
+        for hl, ol in zip(hm, om):
+            assert np.array_equal(hl[0].edata["ID"].cpu().numpy(), ol[0].edata["ID"])
+            assert np.array_equal(hl[0].srcdata["ID"].cpu().numpy(), ol[0].srcdata["ID"])
+
+    same_as_oracle()
+    # a batch far beyond the limit, touching old vertices and new ones (ids up to 4999)
+    big = 20000
+    rng = np.random.RandomState(1)
+    with pytest.raises(MemoryError):
+        g.add_edges(rng.randint(0, 5000, big), rng.randint(0, 5000, big),
+                    np.sort(rng.uniform(2000, 3000, big)).astype(np.float32),
+                    np.arange(10 ** 6, 10 ** 6 + big))
+    assert g.get_graph_memory_usage() == mem
+    same_as_oracle()
+    # ... and the graph keeps ingesting what fits
+    for gr in (g, o):
+        gr.add_edges(src[1500:1800], dst[1500:1800], ts[1500:1800], eid[1500:1800])
+    same_as_oracle()
+
+
+@pytest.mark.gpu
 def test_pool_limit_is_a_memory_error_not_an_abort():
     from gnnflow_amd import DynamicGraph
     g = DynamicGraph(1024, 4096, "cuda", 64, 1, "insert")       # 4 KiB of logical edge blocks
