@@ -67,6 +67,8 @@ __global__ void scatter_edges_kernel(const uint64_t* __restrict__ dest,
     EdgePair p;
     p.dst = dst[i];
     p.eid = eid[i];
+    p.ts = ts[i];
+    p.pad[0] = p.pad[1] = p.pad[2] = 0;
     nbr_pool[d] = p;
   }
 }

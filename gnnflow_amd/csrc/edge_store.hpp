@@ -4,7 +4,7 @@
 //
 // Layout (DESIGN.md "Data layout in HBM"):
 //   ts_pool  : float   [pool_elems]   edge timestamps
-//   nbr_pool : EdgePair[pool_elems]   {dst node, edge id}, 16 B, one load per edge
+//   nbr_pool : EdgePair[pool_elems]   {dst node, edge id, timestamp}, one 32 B sector per edge
 //   table    : NodeEntry[max_node_id+1] {start element, live edge count}
 // Each node owns ONE contiguous, chronologically sorted segment of the two pools
 // (power-of-two capacity, moved to a twice-larger segment when it fills), so a
@@ -31,9 +31,16 @@ struct NodeEntry {   // device node table entry, 16 B
   uint32_t reserved;
 };
 
-struct EdgePair {    // 16 B, 16-byte aligned: one global_load_dwordx4
+// One neighbour record, 32 B and 32-byte aligned: everything the emit kernels need about a
+// selected edge sits in ONE 32-byte DRAM sector.  (With the timestamp only in ts_pool a
+// uniformly sampled edge cost two random sectors; on the 10 M-node / 200 M-edge graph the
+// emit kernel ran at the random-access rate of HBM, not at its bandwidth.  288 GB of HBM pays
+// for the 12 extra bytes per edge: 36 B/edge -> 7.8 G edges per GPU.)
+struct alignas(32) EdgePair {
   int64_t dst;
   int64_t eid;
+  float ts;          // copy of ts_pool[i] (ts_pool stays dense for the window search)
+  uint32_t pad[3];
 };
 
 // What a sampling kernel needs from the graph (all device pointers).

@@ -6,7 +6,7 @@
 // (temporal_sampler.cu:236-274) with three launches per (layer, snapshot), all
 // device resident:
 //
-//   1. search : one 16- or 64-lane group per root.  Resolves the root's time
+//   1. search : one 16-lane group per root (4 lanes in large layers).  Resolves the root's time
 //               window ONCE (the reference repeats the block walk and both binary
 //               searches in each of the F slot threads) with a group-wide k-ary
 //               search over the node's flat timestamp segment: every round the
@@ -17,8 +17,8 @@
 //               shuffles + LDS), which gives every root its base in the compacted
 //               output and the layer's edge count S (and R' = R + S, the next
 //               layer's root count, which never leaves HBM).
-//   3. emit   : one thread per (root, slot): reads the selected edge (4 B
-//               timestamp + one 16 B {dst, eid} pair) and writes the final MFG
+//   3. emit   : one thread per (root, slot): reads the selected edge (one 32 B
+//               {dst, eid, ts} record = one DRAM sector) and writes the final MFG
 //               arrays (all_nodes, all_timestamps, delta_timestamps, eids, row, col)
 //               directly at base[root] + slot, i.e. already compacted, root-major,
 //               newest first — the order thrust's stable remove_if leaves.
@@ -49,6 +49,8 @@ constexpr int kEmitThreads = 256;
 constexpr int kScanThreads = 1024;
 constexpr int kScanItems = 4;  // per thread per tile
 constexpr size_t kSmallRoots = 32768;  // layers up to this many roots skip the scan launch
+constexpr size_t kLaneSearchRoots = 1u << 20;  // layers from this many roots: lane-per-root pass
+constexpr uint32_t kMaxHubSegs = 2048;         // = the lane pass's largest grid
 
 // sampling_kernels.cu:28-40
 __device__ inline void time_window(float root_ts, uint32_t snapshot_idx,
@@ -131,17 +133,60 @@ __global__ __launch_bounds__(kSearchThreads) void sample_search_kernel(
     const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t snapshot_idx,
     uint32_t num_snapshots, float window, uint64_t* __restrict__ rec_end,
     uint32_t* __restrict__ rec_cnt, uint32_t fanout, int uniform,
-    uint32_t* __restrict__ wg_sum) {
+    uint32_t* __restrict__ wg_sum, const uint32_t* __restrict__ list,
+    const uint32_t* __restrict__ seg_count, uint32_t num_segs, uint32_t seg_cap) {
   __shared__ uint32_t s_sum;
+  __shared__ uint32_t seg_prefix[kMaxHubSegs + 1];
   if (wg_sum && threadIdx.x == 0) s_sum = 0;
   if (wg_sum) __syncthreads();
-  const uint64_t R = d_R ? *d_R : R_host;
+  // list != null: only the hubs the lane-per-root pass of a large layer left over — segment
+  // s of the worklist holds seg_count[s] root indices at list[s * seg_cap ...]; every
+  // workgroup builds the exclusive prefix of the counts (<= kMaxHubSegs words) in LDS and
+  // finds the segment of its i-th hub by binary search, so the hubs are spread evenly over
+  // the groups wherever they sat in the batch.
+  uint64_t R = d_R ? *d_R : R_host;
+  if (list) {
+    __shared__ uint32_t wtot[kSearchThreads / 64];
+    uint32_t carry = 0;
+    for (uint32_t s0 = 0; s0 < num_segs; s0 += kSearchThreads) {   // uniform trip count
+      const uint32_t sidx = s0 + threadIdx.x;
+      const uint32_t v = sidx < num_segs ? seg_count[sidx] : 0u;
+      uint32_t incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if ((threadIdx.x & 63) >= d) incl += up;
+      }
+      __syncthreads();
+      if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      uint32_t wbase = 0, tot = 0;
+      for (int w = 0; w < kSearchThreads / 64; ++w) {
+        if (w < (threadIdx.x >> 6)) wbase += wtot[w];
+        tot += wtot[w];
+      }
+      if (sidx < num_segs) seg_prefix[sidx] = carry + wbase + incl - v;
+      carry += tot;
+    }
+    if (threadIdx.x == 0) seg_prefix[num_segs] = carry;
+    __syncthreads();
+    R = seg_prefix[num_segs];
+  }
   constexpr int kGroupsPerBlock = kSearchThreads / GROUP;
   const int lane = threadIdx.x % GROUP;
   const int group_in_wave = (threadIdx.x % 64) / GROUP;
   const uint64_t group = static_cast<uint64_t>(blockIdx.x) * kGroupsPerBlock + threadIdx.x / GROUP;
   const uint64_t num_groups = static_cast<uint64_t>(gridDim.x) * kGroupsPerBlock;
-  for (uint64_t r = group; r < R; r += num_groups) {
+  for (uint64_t i = group; i < R; i += num_groups) {
+    uint64_t r = i;
+    if (list) {   // largest segment s with seg_prefix[s] <= i
+      uint32_t lo_s = 0, hi_s = num_segs;
+      while (hi_s - lo_s > 1) {
+        const uint32_t mid = (lo_s + hi_s) >> 1;
+        if (seg_prefix[mid] <= i) lo_s = mid; else hi_s = mid;
+      }
+      r = list[static_cast<uint64_t>(lo_s) * seg_cap + (i - seg_prefix[lo_s])];
+    }
     const int64_t nid = roots[r];
     const float t = root_ts[r];
     float start, end;
@@ -173,6 +218,88 @@ __global__ __launch_bounds__(kSearchThreads) void sample_search_kernel(
     __syncthreads();
     if (threadIdx.x == 0) wg_sum[blockIdx.x] = s_sum;
   }
+}
+
+// ---- 1b. search for large layers: lane per root, then groups for the hubs ----------------
+// A 16-lane group per root keeps only 4 roots per wave in flight, and a root is a chain of
+// 2-7 dependent random reads (table entry -> pivots ...): at 10^5-10^7 roots per layer the
+// kernel is bound by that latency, not by HBM (measured on the 10 M-node / 200 M-edge graph:
+// 32 G random reads/s against > 100 G/s in the emit kernel).  On a power-law graph > 90 % of
+// the roots have at most one 64-byte line of timestamps, so a first pass gives every LANE a
+// root (64 table entries in flight per wave) and resolves it on the spot if its segment has
+// <= kLaneDeg timestamps (all loads independent: one more round trip); the roots with longer
+// segments are appended to the workgroup's own segment of a worklist (an LDS counter: one
+// global atomic per wave on a shared counter would serialise at ~88 per microsecond) that a
+// second launch of the cooperative k-ary search works off, evenly spread over its groups
+// whatever their position in the batch.
+constexpr uint32_t kLaneDeg = 16;
+
+__global__ __launch_bounds__(kSearchThreads) void sample_search_lanes_kernel(
+    GraphView g, const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t snapshot_idx,
+    uint32_t num_snapshots, float window, uint64_t* __restrict__ rec_end,
+    uint32_t* __restrict__ rec_cnt, uint32_t* __restrict__ hub_list,
+    uint32_t* __restrict__ seg_count, uint32_t seg_cap) {
+  __shared__ uint32_t s_seg_n;
+  if (threadIdx.x == 0) s_seg_n = 0;
+  __syncthreads();
+  uint32_t* seg = hub_list + static_cast<uint64_t>(blockIdx.x) * seg_cap;
+  const uint64_t R = d_R ? *d_R : R_host;
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * kSearchThreads + threadIdx.x) >> 6;
+  const uint64_t num_waves = (static_cast<uint64_t>(gridDim.x) * kSearchThreads) >> 6;
+  const uint64_t chunks = (R + 63) / 64;
+  for (uint64_t chunk = wave; chunk < chunks; chunk += num_waves) {   // wave-uniform trip count
+    const uint64_t r = chunk * 64 + lane;
+    const bool in = r < R;
+    int64_t nid = -1;
+    float start = 0.f, end = 0.f;
+    if (in) {
+      nid = roots[r];
+      time_window(root_ts[r], snapshot_idx, num_snapshots, window, &start, &end);
+    }
+    NodeEntry e;
+    e.start = 0;
+    e.size = 0;
+    if (in && nid >= 0 && static_cast<uint64_t>(nid) < g.table_len) e = g.table[nid];
+    const bool big = e.size > kLaneDeg;
+    if (in && !big) {
+      uint32_t hi = 0, lo = 0;
+      if (e.size > 0) {
+        const float* ts = g.ts_pool + e.start;
+        float v[kLaneDeg];
+        if ((e.start & 3u) == 0) {
+          // 16-byte loads (segments start 64-byte aligned unless a prefix was offloaded):
+          // a quarter of the L2 requests of the scalar form, which bound this pass
+          const float4* t4 = reinterpret_cast<const float4*>(ts);
+#pragma unroll
+          for (uint32_t q = 0; q < kLaneDeg / 4; ++q) {
+            const float4 x = 4 * q < e.size ? t4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+          }
+        } else {
+#pragma unroll
+          for (uint32_t i = 0; i < kLaneDeg; ++i) v[i] = i < e.size ? ts[i] : 0.f;   // independent
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kLaneDeg; ++i) {
+          hi += (i < e.size && v[i] < end) ? 1u : 0u;
+          lo += (i < e.size && v[i] < start) ? 1u : 0u;
+        }
+      }
+      rec_end[r] = e.start + hi;
+      rec_cnt[r] = hi > lo ? hi - lo : 0;
+    }
+    const unsigned long long hubs = __ballot(big);
+    if (hubs) {   // append to this workgroup's segment: LDS counter, no global atomic
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(&s_seg_n, static_cast<uint32_t>(__popcll(hubs)));
+      at = __shfl(at, 0, 64);
+      if (big) seg[at + __popcll(hubs & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(r);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) seg_count[blockIdx.x] = s_seg_n;
 }
 
 // ---- 2. scan -----------------------------------------------------------------------
@@ -351,8 +478,8 @@ __global__ __launch_bounds__(kEmitThreads) void sample_emit_kernel(
     if (j >= valid_slots(n, fanout, uniform)) continue;
     const uint32_t pick = uniform ? gf_philox4x32_10_first(seed, t, call) % n : j;
     const uint64_t e = rec_end[r] - 1 - pick;
-    const float ets = g.ts_pool[e];
     const EdgePair nb = g.nbr_pool[e];
+    const float ets = nb.ts;
     const float rts = root_ts[r];
     const uint64_t o = static_cast<uint64_t>(base[r]) + j;
     all_nodes[R + o] = nb.dst;
@@ -428,8 +555,8 @@ __global__ __launch_bounds__(kEmitThreads) void sample_emit_prefix_kernel(
     if (j < valid_slots(n, fanout, uniform)) {
       const uint32_t pick = uniform ? gf_philox4x32_10_first(seed, t, call) % n : j;
       const uint64_t e = rec_end[r] - 1 - pick;
-      const float ets = g.ts_pool[e];
       const EdgePair nb = g.nbr_pool[e];
+      const float ets = nb.ts;
       const float rts = root_ts[r];
       const uint64_t o = static_cast<uint64_t>(lbase[r - r_first]) + j;
       all_nodes[R + o] = nb.dst;
@@ -494,8 +621,8 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
       if (j < valid) {
         const uint32_t pick = uniform ? gf_philox4x32_10_first(seed, slot, call) % n_cand : j;
         const uint64_t e = end_off - 1 - pick;
-        const float ets = g.ts_pool[e];
         const EdgePair nb = g.nbr_pool[e];
+        const float ets = nb.ts;
         o[0] = nb.dst;
         o[1] = nb.eid;
         o[2] = pack_f32_pair(prop_time ? t : ets, t - ets);
@@ -554,12 +681,36 @@ inline unsigned capped_grid(uint64_t work_items, unsigned per_block, unsigned ca
   return static_cast<unsigned>(std::min<uint64_t>(g, cap));
 }
 
-// lanes cooperating on one root in the search kernel (16 or 64); read when a
-// sampler is created so tests and benches can compare both
-int search_group_width_from_env() {
-  const char* v = std::getenv("GNNFLOW_SEARCH_GROUP");
-  int g = v ? std::atoi(v) : 16;
-  return (g == 64) ? 64 : 16;
+// Lanes cooperating on one root in the search kernels.  A small layer (<= 32 768 roots,
+// every root in flight at once) is a pure latency chain, so it wants FEW rounds: 16 lanes,
+// log16(deg) + 1 dependent reads.  A large layer is bound by how many roots the resident
+// waves keep in flight, so it wants NARROW groups: 4 lanes put 16 roots in flight per wave
+// and issue 40 probes per 10^7-edge segment instead of 96 (measured on the 10 M-node /
+// 200 M-edge graph, profiles/).  Read when a sampler is created so tests can compare widths.
+int group_width_from_env(const char* name, int fallback) {
+  const char* v = std::getenv(name);
+  const int g = v ? std::atoi(v) : fallback;
+  return (g == 2 || g == 4 || g == 8 || g == 16) ? g : fallback;
+}
+
+template <typename... Args>
+void launch_search(int width, unsigned grid, hipStream_t stream, Args... args) {
+  switch (width) {
+    case 2: sample_search_kernel<2><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
+    case 4: sample_search_kernel<4><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
+    case 8: sample_search_kernel<8><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
+    default: sample_search_kernel<16><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
+  }
+}
+
+template <typename... Args>
+void launch_padded(int width, unsigned grid, hipStream_t stream, Args... args) {
+  switch (width) {
+    case 2: sample_padded_kernel<2><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
+    case 4: sample_padded_kernel<4><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
+    case 8: sample_padded_kernel<8><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
+    default: sample_padded_kernel<16><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
+  }
 }
 
 }  // namespace
@@ -580,10 +731,13 @@ Sampler::Sampler(EdgeStore* graph, const uint32_t* fanouts, size_t num_layers, i
   GF_REQUIRE(policy == GF_SAMPLING_POLICY_RECENT || policy == GF_SAMPLING_POLICY_UNIFORM,
              "sampler: invalid sampling policy");
   GF_REQUIRE(num_snapshots >= 1, "sampler: num_snapshots must be >= 1");
-  search_group_ = search_group_width_from_env();
+  search_group_ = group_width_from_env("GNNFLOW_SEARCH_GROUP", 16);
+  large_group_ = group_width_from_env("GNNFLOW_SEARCH_GROUP_LARGE", 4);
   {
     const char* v = std::getenv("GNNFLOW_SAMPLER_FUSED_SCAN");
     fused_scan_ = !(v && std::atoi(v) == 0);
+    v = std::getenv("GNNFLOW_SAMPLER_HYBRID_SEARCH");   // tests / A-B runs
+    hybrid_search_ = !(v && std::atoi(v) == 0);
   }
   DeviceGuard dg(graph_->device());
   for (InFlight& f : ring_) GF_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
@@ -676,14 +830,35 @@ void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb
     ProfileScope ps(kProfSearch, stream);
     const unsigned grid = small ? static_cast<unsigned>((Rb + roots_per_wg - 1) / roots_per_wg)
                                 : capped_grid(Rb, roots_per_wg, 256 * 8);
-    if (search_group_ == 64) {
-      sample_search_kernel<64><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(
-          gv, d_roots, d_ts, d_R, R_host, snapshot, num_snapshots_, window_, rec_end, rec_cnt, F,
-          uniform, small ? wg_sum : nullptr);
+    if (hybrid_search_ && Rb >= kLaneSearchRoots) {
+      // worklist: segment w (of the lane pass's workgroup w) can hold every root that
+      // workgroup looks at; seg_count lives in the tile scratch (wg_sum), unused until the scan.
+      const unsigned lgrid = capped_grid(Rb, kSearchThreads, kMaxHubSegs);
+      const uint64_t chunks_per_wg = ((Rb + 63) / 64 + (lgrid * 4ull) - 1) / (lgrid * 4ull);
+      const uint32_t seg_cap = static_cast<uint32_t>(chunks_per_wg * 4 * 64);
+      const size_t hub_bytes = static_cast<size_t>(seg_cap) * lgrid * sizeof(uint32_t);
+      if (hub_bytes > hub_buf_.bytes()) {   // stream-ordered swap, as for the workspace
+        DeviceBuffer fresh;
+        fresh.reserve(hub_bytes, 0, stream);
+        std::swap(hub_buf_, fresh);
+        retired_.retire(std::move(fresh), stream);
+      }
+      uint32_t* hub_list_ = hub_buf_.as<uint32_t>();
+      uint32_t* seg_count = wg_sum;
+      sample_search_lanes_kernel<<<dim3(lgrid), dim3(kSearchThreads), 0, stream>>>(
+          gv, d_roots, d_ts, d_R, R_host, snapshot, num_snapshots_, window_, rec_end, rec_cnt,
+          hub_list_, seg_count, seg_cap);
+      launch_search(large_group_, capped_grid(Rb / 4, kSearchThreads / large_group_, 256 * 8),
+                    stream, gv, d_roots, d_ts, nullptr, 0, snapshot, num_snapshots_, window_,
+                    rec_end, rec_cnt, F, uniform, nullptr, hub_list_, seg_count, lgrid, seg_cap);
+    } else if (small) {
+      launch_search(search_group_, grid, stream, gv, d_roots, d_ts, d_R, R_host, snapshot,
+                    num_snapshots_, window_, rec_end, rec_cnt, F, uniform, wg_sum, nullptr,
+                    nullptr, 0, 0);
     } else {
-      sample_search_kernel<16><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(
-          gv, d_roots, d_ts, d_R, R_host, snapshot, num_snapshots_, window_, rec_end, rec_cnt, F,
-          uniform, small ? wg_sum : nullptr);
+      launch_search(large_group_, capped_grid(Rb, kSearchThreads / large_group_, 256 * 8), stream,
+                    gv, d_roots, d_ts, d_R, R_host, snapshot, num_snapshots_, window_, rec_end,
+                    rec_cnt, F, uniform, nullptr, nullptr, nullptr, 0, 0);
     }
     GF_HIP(hipGetLastError());
   }
@@ -918,18 +1093,11 @@ void Sampler::sample_layer_padded(const int64_t* d_requests, size_t n, uint32_t 
   DeviceGuard dg(graph_->device());
   const GraphView gv = graph_->view();
   const int uniform = policy_ == GF_SAMPLING_POLICY_UNIFORM;
-  const unsigned roots_per_wg = kSearchThreads / search_group_;
-  const unsigned grid = capped_grid(n, roots_per_wg, 256 * 8);
+  const int width = n > kSmallRoots ? large_group_ : search_group_;
+  const unsigned grid = capped_grid(n, kSearchThreads / width, 256 * 8);
   ProfileScope ps(kProfSearch, stream);
-  if (search_group_ == 64) {
-    sample_padded_kernel<64><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(
-        gv, d_requests, n, snapshot, num_snapshots_, window_, F, uniform, prop_time_ ? 1 : 0,
-        seed_, call, d_out);
-  } else {
-    sample_padded_kernel<16><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(
-        gv, d_requests, n, snapshot, num_snapshots_, window_, F, uniform, prop_time_ ? 1 : 0,
-        seed_, call, d_out);
-  }
+  launch_padded(width, grid, stream, gv, d_requests, static_cast<uint64_t>(n), snapshot,
+                num_snapshots_, window_, F, uniform, prop_time_ ? 1 : 0, seed_, call, d_out);
   GF_HIP(hipGetLastError());
 }
 

@@ -77,8 +77,10 @@ class Sampler {
   bool prop_time_;
   uint64_t seed_;
   uint64_t calls_ = 0;  // sample_layer invocations so far (uniform RNG counter)
-  int search_group_ = 16;
+  int search_group_ = 16;   // lanes per root, layers of <= 32 768 roots
+  int large_group_ = 4;     // lanes per root, larger layers (sampler.hip: group_width_from_env)
   bool fused_scan_ = true;
+  bool hybrid_search_ = true;   // large layers: lane-per-root search, groups for the hubs
   // begun, not yet ended samples (FIFO).  begin() may run on the library's enqueue thread
   // while end() runs on the caller's: the ring bookkeeping is under ring_mu_.
   struct InFlight {
@@ -95,6 +97,7 @@ class Sampler {
   size_t rec_words_ = 0;   // uint64 words per pinned publish record: flag + 2 per block
 
   DeviceBuffer ws_;        // per-root search records + scan scratch + counters
+  DeviceBuffer hub_buf_;   // large layers: worklist of the roots with long segments
   size_t ws_roots_ = 0, ws_blocks_ = 0;
   PinnedBuffer h_counts_;        // kMaxInFlight publish records (flag + block sizes)
   PinnedBuffer h_layer_counts_;  // blocking single-layer calls

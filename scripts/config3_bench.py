@@ -1,0 +1,95 @@
+"""BASELINE config 3: sampler roofline sweep on the synthetic power-law graph (10 M nodes /
+200 M edges unless --nodes/--edges say otherwise).  One JSON line per (policy, batch):
+kernel times from dispatch-free HIP-event scopes (gf_profile_*), algorithmic bytes per
+SURVEY.md 8(d).  Run under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes) for
+the counter traffic of sample_search_kernel / sample_emit_kernel (scripts/rocprof_config3.sh).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import gnnflow_amd
+from gnnflow_amd import _capi, synthetic
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nodes", type=int, default=10_000_000)
+ap.add_argument("--edges", type=int, default=200_000_000)
+ap.add_argument("--batches", default="600,6000,60000,300000")
+ap.add_argument("--policies", default="uniform,recent")
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--sort-roots", action="store_true")
+args = ap.parse_args()
+
+dev = torch.device("cuda", 0)
+lib = _capi.load()
+N, E = args.nodes, args.edges
+t0 = time.time()
+g = synthetic.powerlaw_device(N, E, dev, seed=42)
+gen_s = time.time() - t0
+graph = gnnflow_amd.DynamicGraph(1 << 30, 64 << 30, "cuda", 16, 1024, "insert")
+t0 = time.time()
+for lo in range(0, E, 10_000_000):
+    hi = lo + 10_000_000
+    graph.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi])
+ingest_s = time.time() - t0
+print(json.dumps({"sweep": "config3-build", "nodes": N, "edges": E, "gen_s": round(gen_s, 2),
+                  "ingest_s": round(ingest_s, 2), "ingest_Medges_per_s": E / ingest_s / 1e6}), flush=True)
+deg = torch.bincount(g["device"]["src"], minlength=N)
+
+
+def prof(slot):
+    ms, n = C.c_double(0), C.c_uint64(0)
+    lib.gf_profile_get(_capi.PROFILE_SLOTS[slot], C.byref(ms), C.byref(n))
+    return ms.value, n.value
+
+
+for policy in args.policies.split(","):
+    s = gnnflow_amd.TemporalSampler(graph, [10, 10], policy)
+    for B in [int(x) for x in args.batches.split(",")]:
+        rng = np.random.RandomState(B)
+        pick = rng.randint(int(E * 0.99), E, B)
+        roots = np.concatenate([g["src"][pick], g["dst"][pick], rng.randint(0, N, B)]).astype(np.int64)
+        ts = np.tile(g["ts"][pick], 3).astype(np.float32)
+        r, t = torch.from_numpy(roots).to(dev), torch.from_numpy(ts).to(dev)
+        for _ in range(2):
+            m = s.sample(r, t)
+        torch.cuda.synchronize()
+        lib.gf_profile_reset()
+        lib.gf_profile_enable(0b1011)
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            m = s.sample(r, t)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / args.reps
+        lib.gf_profile_enable(0)
+        blocks = [b for mfg in m for b in mfg]
+        edges = sum(b.num_edges() for b in blocks)
+        roots_total = sum(b.num_dst_nodes() for b in blocks)
+        # per root 12 (id, ts) + 16 (table entry) + 8 * ceil(log2 deg) + 4 (count);
+        # per edge 20 read + 40 written
+        search_bytes = 0.0
+        for b in blocks:
+            ids = b.srcdata["ID"][:b.num_dst_nodes()]
+            d = deg[ids].clamp(min=2).to(torch.float64)
+            search_bytes += float((28 + 4 + 8 * torch.ceil(torch.log2(d))).sum())
+        emit_bytes = edges * 60.0
+        ms_s, _ = prof("search")
+        ms_e, _ = prof("emit")
+        ms_c, _ = prof("scan")
+        us = lambda ms: 1e3 * ms / args.reps
+        print(json.dumps({
+            "sweep": "config3", "policy": policy, "batch": B, "roots": int(roots_total),
+            "edges": int(edges), "wall_us": 1e6 * wall, "Gedges_per_s_wall": edges / wall / 1e9,
+            "search_us": us(ms_s), "emit_us": us(ms_e), "scan_us": us(ms_c),
+            "search_alg_MB": search_bytes / 1e6, "emit_alg_MB": emit_bytes / 1e6,
+            "search_GBps": search_bytes / (us(ms_s) * 1e-6) / 1e9 if ms_s else None,
+            "emit_GBps": emit_bytes / (us(ms_e) * 1e-6) / 1e9 if ms_e else None,
+            "all_GBps": (search_bytes + emit_bytes) / ((us(ms_s) + us(ms_e) + us(ms_c)) * 1e-6) / 1e9}),
+            flush=True)

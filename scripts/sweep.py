@@ -88,7 +88,7 @@ def sampler_sweep():
                       "ingest_s": build_s, "ingest_Medges_per_s": E / build_s / 1e6}))
     tail = int(E * 0.99)
     for strategy in ("uniform", "recent"):
-        for group in ("16", "64"):
+        for group in ("16", "4"):
             os.environ["GNNFLOW_SEARCH_GROUP"] = group
             s = gnnflow_amd.TemporalSampler(graph, [10, 10], strategy)
             for B in (600, 6000, 60000, 300000):
