@@ -79,6 +79,8 @@ def parse():
                     help="multi-GPU mode: per-GPU replicas of the graph (default; what the "
                          "reference does inside one machine) or hash-partitioned shards with "
                          "an all-to-all exchange per layer (gnnflow_amd/dist.py)")
+    ap.add_argument("--no-hash-leg", action="store_true",
+                    help="skip the second timed run over the hash-partitioned graph")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap batch i+1's sample() with batch i's fetch_feature()")
     ap.add_argument("--pipeline-depth", type=int, default=2,
@@ -141,7 +143,6 @@ def main():
         # every rank owns a shard; per layer the roots are bucketed by owner, requests and
         # replies travel as all-to-all-v, and the rank's own share is sampled meanwhile
         sampler = DevicePartitionedSampler(sampler)
-        args.no_pipeline = True
 
     gen = torch.Generator(device=dev).manual_seed(42)
     edge_feats = torch.rand((g["num_edges"], d_e), generator=gen, device=dev)
@@ -299,6 +300,16 @@ def main():
         out["cache_edge_ratio"] = float(cache.cache_edge_ratio)
         out["cache_node_ratio"] = float(cache.cache_node_ratio)
 
+    if cache is not None and args.partition == "replica" and not args.no_hash_leg:
+        # north_star's split, in the same line: the graph hash-partitioned over the ranks
+        # (owner(v) = splitmix64(v) mod P, gnnflow_amd/dist.py), remote neighbours pulled by
+        # all-to-all-v per layer, the same batches, cache and pipeline.  One chronological
+        # replay.  (At P = 1 every root is the rank's own: the figure then prices the
+        # bucketing / fixed-slot / merge kernels against the plain sampler above.)
+        hash_leg.pending_line = out
+        out["hash_partition"] = hash_leg(args, rank, world, local_rank, backend, g, fanouts, cache,
+                                         dev_batches, dev, nb, barrier)
+
     if args.breakdown and rank == 0:
         lib.gf_profile_reset()
         lib.gf_profile_enable(0x1F)
@@ -320,6 +331,79 @@ def main():
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def hash_leg(args, rank, world, local_rank, backend, g, fanouts, cache, dev_batches, dev, nb,
+             barrier):
+    import threading
+    import torch
+    import torch.distributed as dist
+    import gnnflow_amd
+    from gnnflow_amd.dist import DevicePartitionedSampler, PartitionedGraph
+    from gnnflow_amd.pipeline import ReplayPipeline
+    # RCCL with more than one rank has never run on this code path before the first scaling
+    # run: a watchdog ends every rank cleanly if a collective hangs, and rank 0 still prints
+    # the line it has (the caller prints `pending_line` with an error note).
+    limit = float(os.environ.get("GNNFLOW_HASH_LEG_TIMEOUT", "180"))
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(limit):
+            if rank == 0 and hash_leg.pending_line is not None:
+                hash_leg.pending_line["hash_partition"] = {
+                    "error": "timed out after {} s".format(limit)}
+                print(json.dumps(hash_leg.pending_line), flush=True)
+            os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        MiB = 1 << 20
+        shard = gnnflow_amd.DynamicGraph(20 * MiB, 1000 * MiB, "cuda", 62, 1024, "insert",
+                                         device=local_rank)
+        pg = PartitionedGraph(shard, rank, world)
+        for lo in range(0, g["num_edges"], 100000):
+            hi = lo + 100000
+            pg.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
+                         add_reverse=args.undirected)
+        sampler = DevicePartitionedSampler(
+            gnnflow_amd.TemporalSampler(shard, fanouts, args.strategy, seed=1234))
+        pipe = ReplayPipeline(sampler, cache, dev_batches, dev,
+                              pipelined=not args.no_pipeline, depth=args.pipeline_depth)
+        steps = nb
+        pipe.run(0, min(args.warmup, steps))
+        cache.init_cache()
+        barrier()
+        t0 = time.perf_counter()
+        acc = {"edges": 0}
+
+        def account(_i, mfgs):
+            for mfg in mfgs:
+                for b in mfg:
+                    acc["edges"] += b.num_edges()
+
+        pipe.run(0, steps, account)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        stats = torch.tensor([elapsed, float(acc["edges"])], dtype=torch.float64,
+                             device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            tmax = stats[0:1].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            esum = stats[1:2].clone()
+            dist.all_reduce(esum, op=dist.ReduceOp.SUM)
+            elapsed, edges_all = float(tmax), float(esum)
+        else:
+            edges_all = float(acc["edges"])
+        return {"value": edges_all / elapsed, "unit": "edges/s", "ms_per_step": 1e3 * elapsed / steps,
+                "steps": steps, "world_size": world, "pipelined": bool(pipe.pipelined),
+                "exchange": "none (one rank: every root is its own)" if world == 1 else
+                "2 all-to-all-v per layer over {}".format("RCCL" if backend == "nccl" else backend)}
+    except Exception as e:   # the replica figure above must survive a failing exchange
+        return {"error": "{}: {}".format(type(e).__name__, e)}
+    finally:
+        done.set()
+
+
+hash_leg.pending_line = None
 
 
 def usable_cores(cap=32):

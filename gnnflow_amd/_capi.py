@@ -53,6 +53,13 @@ class GfFetchDesc(C.Structure):
     ]
 
 
+class GfPartLayout(C.Structure):
+    """struct gf_part_layout (include/gnnflow_hip.h): byte offsets inside the workspace of
+    one (layer, snapshot) of a chained partitioned sample."""
+    _fields_ = [(n, C.c_size_t) for n in ("root_bound", "requests", "replies", "counts", "pos",
+                                          "scratch", "scratch_bytes", "total")]
+
+
 # every symbol include/gnnflow_hip.h declares: name -> (restype, argtypes)
 _p = C.c_void_p
 _sz = C.c_size_t
@@ -119,6 +126,14 @@ PROTOTYPES = {
     "gf_sampler_sample_layer_padded": (C.c_int, [_p, _p, _sz, C.c_uint32, C.c_uint32, _p, _p]),
     "gf_sampler_merge_padded": (C.c_int, [_p, _p, _p, _sz, C.c_uint32, _p, _p, _p, _sz,
                                           C.POINTER(GfBlock), _p]),
+    "gf_sampler_part_layout": (C.c_int, [_p, _sz, C.c_uint32, C.c_int, C.POINTER(GfPartLayout)]),
+    "gf_sampler_part_begin": (C.c_int, [_p, _p, _p, _sz, _p, _sz, C.c_int, C.c_int, _p]),
+    "gf_sampler_part_plan_own": (C.c_int, [_p, C.c_uint32, C.c_uint32, _p, _sz, C.c_int]),
+    "gf_sampler_part_merge": (C.c_int, [_p, C.c_uint32, C.c_uint32, _p, _sz]),
+    "gf_sampler_part_commit": (C.c_int, [_p]),
+    "gf_sampler_part_abort": (C.c_int, [_p]),
+    "gf_sampler_sample_partitioned": (C.c_int, [_p, _p, _p, _sz, _p, _sz, _p, _sz, _p]),
+    "gf_sampler_sample_partitioned_async": (C.c_int, [_p, _p, _p, _sz, _p, _sz, _p, _sz, _p]),
     "gf_block_segment_offsets": (C.c_int, [_p, _sz, _sz, _p, C.c_int, _p]),
     "gf_block_edge_softmax": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, C.c_int, _p]),
     "gf_block_edge_softmax_backward": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, _p, C.c_int, _p]),

@@ -577,6 +577,82 @@ int gf_sampler_merge_padded(gf_sampler* s, const int64_t* d_roots, const float* 
                          static_cast<hipStream_t>(stream));
   });
 }
+int gf_sampler_part_layout(const gf_sampler* s, size_t num_roots, uint32_t layer, int world_size,
+                           gf_part_layout* out) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    GF_REQUIRE(world_size >= 1 && world_size <= 64, "partition: world size must be 1..64");
+    s->impl.part_layout(std::max<size_t>(num_roots, 1), layer, world_size, out);
+  });
+}
+int gf_sampler_part_begin(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
+                          size_t num_roots, void* d_out, size_t out_bytes, int world_size,
+                          int rank, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
+               "part_begin: earlier samples were begun through the enqueue thread");
+    s->impl.part_begin(d_roots, d_root_ts, num_roots, d_out, out_bytes, world_size, rank,
+                       static_cast<hipStream_t>(stream));
+  });
+}
+int gf_sampler_part_plan_own(gf_sampler* s, uint32_t layer, uint32_t snapshot, void* d_ws,
+                             size_t ws_bytes, int phases) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    GF_REQUIRE(phases >= 1 && phases <= 3, "part_plan_own: phases must be 1, 2 or 3");
+    s->impl.part_plan_own(layer, snapshot, d_ws, ws_bytes, phases);
+  });
+}
+int gf_sampler_part_merge(gf_sampler* s, uint32_t layer, uint32_t snapshot, void* d_ws,
+                          size_t ws_bytes) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    s->impl.part_merge(layer, snapshot, d_ws, ws_bytes);
+  });
+}
+int gf_sampler_part_commit(gf_sampler* s) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    s->impl.part_commit();
+    s->begin_tickets.push_back(0);
+  });
+}
+int gf_sampler_part_abort(gf_sampler* s) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    s->impl.part_abort();
+  });
+}
+int gf_sampler_sample_partitioned(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
+                                  size_t num_roots, void* d_out, size_t out_bytes, void* d_ws,
+                                  size_t ws_bytes, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
+               "sample_partitioned: earlier samples were begun through the enqueue thread");
+    s->impl.sample_partitioned(d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws, ws_bytes,
+                               static_cast<hipStream_t>(stream));
+    s->begin_tickets.push_back(0);
+  });
+}
+int gf_sampler_sample_partitioned_async(gf_sampler* s, const int64_t* d_roots,
+                                        const float* d_root_ts, size_t num_roots, void* d_out,
+                                        size_t out_bytes, void* d_ws, size_t ws_bytes,
+                                        void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    GF_REQUIRE(s->begin_tickets.size() < gf::Sampler::kMaxInFlight,
+               "sample_partitioned_async: too many samples in flight on this sampler");
+    gf::Sampler* impl = &s->impl;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    s->begin_tickets.push_back(gf::EnqueueWorker::get().submit(
+        [impl, d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws, ws_bytes, st]() {
+          impl->sample_partitioned(d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws,
+                                   ws_bytes, st);
+        }));
+  });
+}
 int gf_block_segment_offsets(const int64_t* d_row, size_t num_edges, size_t num_dst,
                              int64_t* d_offsets, int device, void* stream) {
   return guarded([&] {

@@ -30,8 +30,10 @@ __device__ inline uint32_t owner_of(int64_t v, uint32_t P) {
 
 // tile_counts[tile][o] = roots of owner o in the tile
 __global__ __launch_bounds__(kTileThreads) void partition_count_kernel(
-    const int64_t* __restrict__ nodes, uint64_t R, uint32_t P, uint32_t* __restrict__ tile_counts) {
+    const int64_t* __restrict__ nodes, const uint64_t* __restrict__ d_R, uint64_t R_host,
+    uint32_t P, uint32_t* __restrict__ tile_counts) {
   __shared__ uint32_t wave_cnt[kTileThreads / 64][kMaxParts];
+  const uint64_t R = d_R ? *d_R : R_host;   // device-resident count: a chained layer
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kTileThreads + threadIdx.x;
   const uint32_t o = i < R ? owner_of(nodes[i], P) : P;   // P = "no root"
@@ -96,10 +98,12 @@ __global__ __launch_bounds__(1024) void partition_scan_kernel(
 }
 
 __global__ __launch_bounds__(kTileThreads) void partition_scatter_kernel(
-    const int64_t* __restrict__ nodes, const float* __restrict__ ts, uint64_t R, uint32_t P,
+    const int64_t* __restrict__ nodes, const float* __restrict__ ts,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t P,
     const uint32_t* __restrict__ tile_base, int64_t* __restrict__ requests,
     uint32_t* __restrict__ pos) {
   __shared__ uint32_t wave_cnt[kTileThreads / 64][kMaxParts];
+  const uint64_t R = d_R ? *d_R : R_host;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kTileThreads + threadIdx.x;
   const int64_t v = i < R ? nodes[i] : 0;
@@ -126,34 +130,44 @@ size_t partition_scratch_bytes(size_t R, int world_size) {
   return 2 * align_up(std::max<size_t>(tiles, 1) * world_size * sizeof(uint32_t), 16);
 }
 
-void partition_plan(const int64_t* d_nodes, const float* d_ts, size_t R, int world_size, int rank,
-                    int64_t* d_requests, uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
-                    size_t scratch_bytes, int device, hipStream_t stream) {
+// R_bound sizes the grids and the scratch; the kernels take the real count from *d_R when it
+// is given (a chained layer: the previous layer's R + S never left the device).
+void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_t* d_R,
+                        size_t R_bound, int world_size, int rank, int64_t* d_requests,
+                        uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
+                        size_t scratch_bytes, int device, hipStream_t stream) {
   GF_REQUIRE(world_size >= 1 && world_size <= kMaxParts, "partition: world size must be 1..64");
   GF_REQUIRE(rank >= 0 && rank < world_size, "partition: rank out of range");
   GF_REQUIRE(d_counts != nullptr, "partition: null counts");
-  GF_REQUIRE(R < 0xFFFFFFFFull, "partition: more than 2^32-1 roots");
+  GF_REQUIRE(R_bound < 0xFFFFFFFFull, "partition: more than 2^32-1 roots");
   DeviceGuard dg(device);
-  if (R == 0) {
+  if (R_bound == 0) {
     GF_HIP(hipMemsetAsync(d_counts, 0, world_size * sizeof(uint64_t), stream));
     return;
   }
   GF_REQUIRE(d_nodes && d_ts && d_requests && d_pos && d_scratch, "partition: null pointer");
-  GF_REQUIRE(scratch_bytes >= partition_scratch_bytes(R, world_size),
+  GF_REQUIRE(scratch_bytes >= partition_scratch_bytes(R_bound, world_size),
              "partition: scratch buffer too small");
-  const size_t tiles = (R + kTileThreads - 1) / kTileThreads;
+  const size_t tiles = (R_bound + kTileThreads - 1) / kTileThreads;
   uint32_t* tile_counts = static_cast<uint32_t*>(d_scratch);
   uint32_t* tile_base = reinterpret_cast<uint32_t*>(
       static_cast<char*>(d_scratch) + align_up(tiles * world_size * sizeof(uint32_t), 16));
   const uint32_t P = static_cast<uint32_t>(world_size);
   partition_count_kernel<<<dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream>>>(
-      d_nodes, R, P, tile_counts);
+      d_nodes, d_R, R_bound, P, tile_counts);
   partition_scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(tile_counts, tiles, P,
                                                             static_cast<uint32_t>(rank), tile_base,
                                                             d_counts);
   partition_scatter_kernel<<<dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream>>>(
-      d_nodes, d_ts, R, P, tile_base, d_requests, d_pos);
+      d_nodes, d_ts, d_R, R_bound, P, tile_base, d_requests, d_pos);
   GF_HIP(hipGetLastError());
+}
+
+void partition_plan(const int64_t* d_nodes, const float* d_ts, size_t R, int world_size, int rank,
+                    int64_t* d_requests, uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
+                    size_t scratch_bytes, int device, hipStream_t stream) {
+  partition_plan_dev(d_nodes, d_ts, nullptr, R, world_size, rank, d_requests, d_pos, d_counts,
+                     d_scratch, scratch_bytes, device, stream);
 }
 
 }  // namespace gf

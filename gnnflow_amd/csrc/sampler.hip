@@ -589,7 +589,17 @@ template <int GROUP>
 __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
     GraphView g, const int64_t* __restrict__ req, uint64_t n, uint32_t snapshot_idx,
     uint32_t num_snapshots, float window, uint32_t fanout, int uniform, int prop_time,
-    uint64_t seed, uint64_t call, int64_t* __restrict__ out) {
+    uint64_t seed, uint64_t call, int64_t* __restrict__ out,
+    const uint64_t* __restrict__ d_own, const uint64_t* __restrict__ d_total,
+    uint64_t total_host) {
+  // d_own != null: "this rank's own share" of a chained partitioned layer — the last *d_own
+  // of the layer's R request rows (R = *d_total, or total_host), counts still on the device
+  if (d_own) {
+    n = *d_own;
+    const uint64_t skip = (d_total ? *d_total : total_host) - n;
+    req += 2 * skip;
+    out += skip * fanout * 3;
+  }
   constexpr int kGroupsPerBlock = kSearchThreads / GROUP;
   const int lane = threadIdx.x % GROUP;
   const int group_in_wave = (threadIdx.x % 64) / GROUP;
@@ -637,7 +647,9 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
 
 // valid slots of root i's reply row (a prefix of the row for both policies)
 __global__ void merge_count_kernel(const int64_t* __restrict__ rep, const uint32_t* __restrict__ pos,
-                                   uint64_t R, uint32_t fanout, uint32_t* __restrict__ rec_cnt) {
+                                   const uint64_t* __restrict__ d_R, uint64_t R_host,
+                                   uint32_t fanout, uint32_t* __restrict__ rec_cnt) {
+  const uint64_t R = d_R ? *d_R : R_host;
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= R) return;
   const int64_t* s = rep + static_cast<uint64_t>(pos[i]) * fanout * 3;
@@ -647,11 +659,13 @@ __global__ void merge_count_kernel(const int64_t* __restrict__ rep, const uint32
 }
 
 __global__ __launch_bounds__(kEmitThreads) void merge_emit_kernel(
-    const int64_t* __restrict__ roots, const float* __restrict__ root_ts, uint64_t R,
+    const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
+    const uint64_t* __restrict__ d_R, uint64_t R_host,
     uint32_t fanout, const int64_t* __restrict__ rep, const uint32_t* __restrict__ pos,
     const uint32_t* __restrict__ rec_cnt, const uint32_t* __restrict__ base,
     int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
     int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col) {
+  const uint64_t R = d_R ? *d_R : R_host;
   const uint64_t total = R * fanout;
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
   for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
@@ -1097,7 +1111,9 @@ void Sampler::sample_layer_padded(const int64_t* d_requests, size_t n, uint32_t 
   const unsigned grid = capped_grid(n, kSearchThreads / width, 256 * 8);
   ProfileScope ps(kProfSearch, stream);
   launch_padded(width, grid, stream, gv, d_requests, static_cast<uint64_t>(n), snapshot,
-                num_snapshots_, window_, F, uniform, prop_time_ ? 1 : 0, seed_, call, d_out);
+                num_snapshots_, window_, F, uniform, prop_time_ ? 1 : 0, seed_, call, d_out,
+                static_cast<const uint64_t*>(nullptr), static_cast<const uint64_t*>(nullptr),
+                static_cast<uint64_t>(0));
   GF_HIP(hipGetLastError());
 }
 
@@ -1125,7 +1141,7 @@ void Sampler::merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, 
   uint64_t* d_counts = reinterpret_cast<uint64_t*>(w);
   BlockPtrs out = carve(static_cast<char*>(d_out), R, F);
   merge_count_kernel<<<dim3(static_cast<unsigned>((R + 255) / 256)), dim3(256), 0, stream>>>(
-      d_replies, d_pos, R, F, rec_cnt);
+      d_replies, d_pos, nullptr, R, F, rec_cnt);
   if (R <= 65536) {
     sample_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
         rec_cnt, base, nullptr, R, F, 0, d_counts, d_counts + 1, nullptr);
@@ -1143,8 +1159,8 @@ void Sampler::merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, 
   }
   merge_emit_kernel<<<dim3(capped_grid(static_cast<uint64_t>(R) * F, kEmitThreads, 256 * 16)),
                       dim3(kEmitThreads), 0, stream>>>(
-      d_roots, d_ts, R, F, d_replies, d_pos, rec_cnt, base, out.all_nodes, out.all_ts, out.dt,
-      out.eids, out.row, out.col);
+      d_roots, d_ts, nullptr, R, F, d_replies, d_pos, rec_cnt, base, out.all_nodes, out.all_ts,
+      out.dt, out.eids, out.row, out.col);
   GF_HIP(hipGetLastError());
   GF_HIP(hipMemcpyAsync(h_layer_counts_.data(), d_counts, 2 * sizeof(uint64_t),
                         hipMemcpyDeviceToHost, stream));
@@ -1159,6 +1175,248 @@ void Sampler::merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, 
   block->num_dst_nodes = hc[0];
   block->num_edges = hc[1];
   block->num_src_nodes = hc[0] + hc[1];
+}
+
+// ---- partitioned sampling, chained on the device ------------------------------------------
+// part_begin -> for every (layer, snapshot): part_plan_own, [the caller's exchange: request
+// all-to-all-v, sample_layer_padded for what it received, reply all-to-all-v], part_merge ->
+// part_commit.  Every kernel takes the layer's root count from device memory (it is the
+// previous layer's R + S), so nothing is read back between the layers; part_commit publishes
+// the block sizes like sample_begin does and sample_end() returns them.  With one rank there
+// is no exchange and sample_partitioned() issues the whole chain in one call.
+void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_t* d_R,
+                        size_t R_bound, int world_size, int rank, int64_t* d_requests,
+                        uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
+                        size_t scratch_bytes, int device, hipStream_t stream);
+size_t partition_scratch_bytes(size_t R, int world_size);
+
+void Sampler::part_layout(size_t R0, uint32_t layer, int world_size, gf_part_layout* out) const {
+  GF_REQUIRE(layer < fanouts_.size(), "part_layout: layer out of range");
+  GF_REQUIRE(out != nullptr, "part_layout: null output");
+  const size_t Rb = root_bound(R0, layer), F = fanouts_[layer];
+  out->root_bound = Rb;
+  out->requests = 0;
+  out->replies = Rb * 16;
+  out->counts = out->replies + Rb * F * 24;
+  out->pos = out->counts + align_up(static_cast<size_t>(world_size) * 8, 16);
+  out->scratch = align_up(out->pos + Rb * 4, 16);
+  out->scratch_bytes = partition_scratch_bytes(Rb, world_size);
+  out->total = align_up(out->scratch + out->scratch_bytes, 256);
+}
+
+void Sampler::part_begin(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
+                         size_t out_bytes, int world_size, int rank, hipStream_t stream) {
+  const size_t L = fanouts_.size(), NS = num_snapshots_;
+  GF_REQUIRE(!part_.active, "part_begin: a partitioned sample is already being built");
+  GF_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "part_begin: bad rank / world");
+  GF_REQUIRE(R == 0 || (d_roots && d_ts), "part_begin: null device pointer");
+  // layers chain through worst-case-sized blocks even when this rank has no root of its own
+  // (R = 0): it still plans, serves the other ranks' requests and merges empty blocks
+  const size_t Rs = std::max<size_t>(R, 1);
+  GF_REQUIRE(d_out && out_bytes >= output_bytes(Rs), "part_begin: output buffer too small");
+  InFlight* slot;
+  {
+    std::lock_guard<std::mutex> lk(ring_mu_);
+    GF_REQUIRE(ring_count_ < kMaxInFlight, "part_begin: too many samples in flight on this sampler");
+    slot = &ring_[(ring_head_ + ring_count_) % kMaxInFlight];
+  }
+  DeviceGuard dg(graph_->device());
+  reserve_workspace(root_bound(Rs, L - 1), L * NS, stream);
+  slot->ptrs.assign(L * NS, BlockPtrs{});
+  slot->roots = Rs;          // never the "R = 0 short-circuit" record: sizes come from the device
+  slot->stream = stream;
+  char* p = static_cast<char*>(d_out);
+  for (size_t l = 0; l < L; ++l) {
+    const size_t Rb = root_bound(Rs, l);
+    for (size_t s = 0; s < NS; ++s) {
+      slot->ptrs[l * NS + s] = carve(p, Rb, fanouts_[l]);
+      p += layer_output_bytes(Rb, l);
+    }
+  }
+  part_ = PartState{};
+  part_.active = true;
+  part_.slot = slot;
+  part_.d_roots = d_roots;
+  part_.d_ts = d_ts;
+  part_.R = R;
+  part_.Rs = Rs;
+  part_.world = world_size;
+  part_.rank = rank;
+  part_.stream = stream;
+}
+
+uint64_t* Sampler::part_counts() const {
+  return reinterpret_cast<uint64_t*>(ws_.as<char>() + align_up(ws_roots_ * 8, 16) +
+                                     3 * align_up(ws_roots_ * 4, 16));
+}
+
+// roots of (layer, snapshot): the caller's for layer 0, else the previous layer's block
+void Sampler::part_roots(uint32_t layer, uint32_t snapshot, const int64_t** roots,
+                         const float** ts, const uint64_t** d_R, uint64_t* R_host) const {
+  const size_t NS = num_snapshots_;
+  if (layer == 0) {
+    *roots = part_.d_roots;
+    *ts = part_.d_ts;
+    *d_R = nullptr;
+    *R_host = part_.R;
+  } else {
+    const BlockPtrs& prev = part_.slot->ptrs[(layer - 1) * NS + snapshot];
+    *roots = prev.all_nodes;
+    *ts = prev.all_ts;
+    *d_R = part_counts() + 2 * (layer * NS + snapshot);   // written by the previous merge
+    *R_host = 0;
+  }
+}
+
+void Sampler::part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes,
+                            int phases) {
+  GF_REQUIRE(part_.active, "part_plan_own: no partitioned sample is being built");
+  GF_REQUIRE(layer < fanouts_.size() && snapshot < num_snapshots_, "part_plan_own: out of range");
+  gf_part_layout lay;
+  part_layout(part_.Rs, layer, part_.world, &lay);
+  GF_REQUIRE(d_ws && ws_bytes >= lay.total, "part_plan_own: workspace too small");
+  DeviceGuard dg(graph_->device());
+  char* w = static_cast<char*>(d_ws);
+  const int64_t* roots; const float* ts; const uint64_t* d_R; uint64_t R_host;
+  part_roots(layer, snapshot, &roots, &ts, &d_R, &R_host);
+  hipStream_t stream = part_.stream;
+  const size_t Rb = lay.root_bound;
+  uint64_t* d_counts = reinterpret_cast<uint64_t*>(w + lay.counts);
+  if (!(phases & 1)) {
+    // planned by an earlier call
+  } else if (layer == 0 && part_.R == 0) {
+    GF_HIP(hipMemsetAsync(d_counts, 0, part_.world * sizeof(uint64_t), stream));
+  } else {
+    partition_plan_dev(roots, ts, d_R, layer == 0 ? part_.R : Rb, part_.world, part_.rank,
+                       reinterpret_cast<int64_t*>(w + lay.requests),
+                       reinterpret_cast<uint32_t*>(w + lay.pos), d_counts, w + lay.scratch,
+                       lay.scratch_bytes, graph_->device(), stream);
+  }
+  if (!(phases & 2)) return;
+  // this rank's own share: the last counts[rank] request rows; the kernel takes the count
+  // from the device, so with one rank nothing is read back, and with several the caller
+  // issues it right after starting the request all-to-all-v, which it then overlaps
+  const uint64_t call = calls_++;
+  const uint32_t F = fanouts_[layer];
+  const size_t n_bound = layer == 0 ? part_.R : Rb;
+  if (n_bound) {
+    const int width = n_bound > kSmallRoots ? large_group_ : search_group_;
+    const unsigned grid = capped_grid(n_bound, kSearchThreads / width, 256 * 8);
+    ProfileScope ps(kProfSearch, stream);
+    launch_padded(width, grid, stream, graph_->view(),
+                  reinterpret_cast<const int64_t*>(w + lay.requests), static_cast<uint64_t>(0),
+                  snapshot, num_snapshots_, window_, F, policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0,
+                  prop_time_ ? 1 : 0, seed_, call, reinterpret_cast<int64_t*>(w + lay.replies),
+                  static_cast<const uint64_t*>(d_counts + part_.rank), d_R,
+                  static_cast<uint64_t>(R_host));
+    GF_HIP(hipGetLastError());
+  }
+}
+
+void Sampler::part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes) {
+  GF_REQUIRE(part_.active, "part_merge: no partitioned sample is being built");
+  GF_REQUIRE(layer < fanouts_.size() && snapshot < num_snapshots_, "part_merge: out of range");
+  gf_part_layout lay;
+  part_layout(part_.Rs, layer, part_.world, &lay);
+  GF_REQUIRE(d_ws && ws_bytes >= lay.total, "part_merge: workspace too small");
+  DeviceGuard dg(graph_->device());
+  const size_t L = fanouts_.size(), NS = num_snapshots_;
+  char* w = static_cast<char*>(d_ws);
+  const int64_t* roots; const float* ts; const uint64_t* d_R; uint64_t R_host;
+  part_roots(layer, snapshot, &roots, &ts, &d_R, &R_host);
+  hipStream_t stream = part_.stream;
+  const size_t Rb = layer == 0 ? part_.R : lay.root_bound;
+  const uint32_t F = fanouts_[layer];
+  const size_t b = layer * NS + snapshot;
+  uint64_t* slot = part_counts() + 2 * b;
+  uint64_t* next_R = (layer + 1 < L) ? slot + 2 * NS : nullptr;
+  const BlockPtrs& out = part_.slot->ptrs[b];
+  char* sw = ws_.as<char>();
+  sw += align_up(ws_roots_ * 8, 16);                                   // rec_end: unused here
+  uint32_t* rec_cnt = reinterpret_cast<uint32_t*>(sw); sw += align_up(ws_roots_ * 4, 16);
+  uint32_t* base = reinterpret_cast<uint32_t*>(sw);    sw += align_up(ws_roots_ * 4, 16);
+  uint32_t* tile_scratch = reinterpret_cast<uint32_t*>(sw);
+  const int64_t* rep = reinterpret_cast<const int64_t*>(w + lay.replies);
+  const uint32_t* pos = reinterpret_cast<const uint32_t*>(w + lay.pos);
+  if (Rb == 0) {   // layer 0 of a rank without roots: an empty block, R = S = 0
+    GF_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(uint64_t), stream));
+    if (next_R) GF_HIP(hipMemsetAsync(next_R, 0, sizeof(uint64_t), stream));
+    return;
+  }
+  ProfileScope ps(kProfEmit, stream);
+  merge_count_kernel<<<dim3(static_cast<unsigned>((Rb + 255) / 256)), dim3(256), 0, stream>>>(
+      rep, pos, d_R, R_host, F, rec_cnt);
+  if (Rb <= 65536) {
+    sample_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
+        rec_cnt, base, d_R, R_host, F, 0, slot, slot + 1, next_R);
+  } else {
+    const size_t tiles = (Rb + kScanTile - 1) / kScanTile;
+    uint32_t* tile_sum = tile_scratch;
+    uint32_t* tile_base = tile_scratch + tiles;
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>(tiles, 2048));
+    sample_tile_sum_kernel<<<dim3(grid), dim3(kScanThreads), 0, stream>>>(rec_cnt, d_R, R_host, F,
+                                                                         0, tile_sum);
+    sample_tile_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
+        tile_sum, tile_base, d_R, R_host, slot, slot + 1, next_R);
+    sample_tile_apply_kernel<<<dim3(grid), dim3(kScanThreads), 0, stream>>>(
+        rec_cnt, tile_base, d_R, R_host, F, 0, base);
+  }
+  merge_emit_kernel<<<dim3(capped_grid(static_cast<uint64_t>(Rb) * F, kEmitThreads, 256 * 16)),
+                      dim3(kEmitThreads), 0, stream>>>(
+      roots, ts, d_R, R_host, F, rep, pos, rec_cnt, base, out.all_nodes, out.all_ts, out.dt,
+      out.eids, out.row, out.col);
+  GF_HIP(hipGetLastError());
+}
+
+void Sampler::part_commit() {
+  GF_REQUIRE(part_.active, "part_commit: no partitioned sample is being built");
+  const size_t L = fanouts_.size(), NS = num_snapshots_;
+  DeviceGuard dg(graph_->device());
+  InFlight* slot = part_.slot;
+  hipStream_t stream = part_.stream;
+  part_.active = false;
+  slot->seq = ++publish_seq_;
+  uint64_t* rec = h_counts_.as<uint64_t>() + (slot->seq % kMaxInFlight) * rec_words_;
+  *reinterpret_cast<volatile uint64_t*>(rec) = 0;
+  Publish pub;
+  pub.d_counts = part_counts();
+  pub.h_counts = rec + 1;
+  pub.h_flag = rec;
+  pub.seq = slot->seq;
+  pub.num_words = static_cast<uint32_t>(L * NS * 2);
+  sample_publish_kernel<<<dim3(1), dim3(64), 0, stream>>>(pub);
+  GF_HIP(hipGetLastError());
+  GF_HIP(hipEventRecord(slot->done, stream));
+  std::lock_guard<std::mutex> lk(ring_mu_);
+  ++ring_count_;
+}
+
+void Sampler::part_abort() { part_.active = false; }
+
+// one rank: no exchange — the whole chain in one call (begin form: sample_end() completes it)
+void Sampler::sample_partitioned(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
+                                 size_t out_bytes, void* d_ws, size_t ws_bytes,
+                                 hipStream_t stream) {
+  const size_t L = fanouts_.size(), NS = num_snapshots_;
+  part_begin(d_roots, d_ts, R, d_out, out_bytes, 1, 0, stream);
+  try {
+    char* w = static_cast<char*>(d_ws);
+    size_t off = 0;
+    for (size_t l = 0; l < L; ++l) {
+      gf_part_layout lay;
+      part_layout(part_.Rs, static_cast<uint32_t>(l), 1, &lay);
+      for (size_t s = 0; s < NS; ++s) {
+        GF_REQUIRE(off + lay.total <= ws_bytes, "sample_partitioned: workspace too small");
+        part_plan_own(static_cast<uint32_t>(l), static_cast<uint32_t>(s), w + off, lay.total, 3);
+        part_merge(static_cast<uint32_t>(l), static_cast<uint32_t>(s), w + off, lay.total);
+        off += lay.total;
+      }
+    }
+    part_commit();
+  } catch (...) {
+    part_abort();
+    throw;
+  }
 }
 
 // Copies device-resident blocks into freshly malloc'ed host arrays

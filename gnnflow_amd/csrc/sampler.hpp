@@ -51,6 +51,17 @@ class Sampler {
   void merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, uint32_t layer,
                     const int64_t* d_replies, const uint32_t* d_pos, void* d_out,
                     size_t out_bytes, gf_block* block, hipStream_t stream);
+  // ---- the same, chained on the device (no read-back between layers; sampler.hip) --------
+  void part_layout(size_t R0, uint32_t layer, int world_size, gf_part_layout* out) const;
+  void part_begin(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
+                  size_t out_bytes, int world_size, int rank, hipStream_t stream);
+  // phases: 1 = bucket the roots, 2 = sample this rank's own share, 3 = both
+  void part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes, int phases);
+  void part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes);
+  void part_commit();
+  void part_abort();
+  void sample_partitioned(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
+                          size_t out_bytes, void* d_ws, size_t ws_bytes, hipStream_t stream);
   // host-vector forms (reference calling convention)
   void sample_host(const int64_t* nodes, const float* ts, size_t R, gf_block* blocks);
   void sample_layer_host(const int64_t* nodes, const float* ts, size_t R, uint32_t layer,
@@ -90,9 +101,22 @@ class Sampler {
     hipEvent_t done = nullptr;
     std::vector<BlockPtrs> ptrs;
   };
+  struct PartState {
+    bool active = false;
+    InFlight* slot = nullptr;
+    const int64_t* d_roots = nullptr;
+    const float* d_ts = nullptr;
+    size_t R = 0, Rs = 1;
+    int world = 1, rank = 0;
+    hipStream_t stream = nullptr;
+  };
+  uint64_t* part_counts() const;
+  void part_roots(uint32_t layer, uint32_t snapshot, const int64_t** roots, const float** ts,
+                  const uint64_t** d_R, uint64_t* R_host) const;
   InFlight ring_[kMaxInFlight];
   size_t ring_head_ = 0, ring_count_ = 0;
   mutable std::mutex ring_mu_;
+  PartState part_;
   uint64_t publish_seq_ = 0;
   size_t rec_words_ = 0;   // uint64 words per pinned publish record: flag + 2 per block
 

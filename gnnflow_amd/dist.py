@@ -295,12 +295,20 @@ def _exchange(out: torch.Tensor, send: torch.Tensor, out_splits, in_splits, grou
 
 
 class DevicePartitionedSampler:
-    """PartitionedSampler whose per-rank work is native: `gf_partition_plan` buckets the roots,
-    `gf_sampler_sample_layer_padded` serves this rank's own share (while the request
-    all-to-all-v is in flight) and the requests it receives, `gf_sampler_merge_padded` builds
-    the block.  Returns `gnnflow_amd.MFGBlock`s in HBM exactly like
-    `TemporalSampler.sample()` — for most-recent sampling bit-identical to one GPU holding the
-    whole graph — so `Cache.fetch_feature` takes them unchanged.
+    """PartitionedSampler whose per-rank work is native and chained on the device
+    (include/gnnflow_hip.h "Chained form"): per layer `gf_sampler_part_plan_own` buckets the
+    roots — their count is the previous layer's R + S and never leaves HBM — and samples this
+    rank's own share while the request all-to-all-v is in flight, the received requests are
+    served by `gf_sampler_sample_layer_padded`, `gf_sampler_part_merge` builds the block.
+    Returns `gnnflow_amd.MFGBlock`s in HBM exactly like `TemporalSampler.sample()` — for
+    most-recent sampling bit-identical to one GPU holding the whole graph — so
+    `Cache.fetch_feature` takes them unchanged.
+
+    Host synchronisation: with P ranks ONE per layer (the owner counts are the split sizes of
+    the all-to-all-v) plus the final size read-back; with one rank only the read-back — the
+    whole chain is a single native call that `sample_async` can hand to the enqueue thread
+    like the plain sampler's.  A rank whose batch is empty still takes part in every
+    collective (its peers would otherwise block in them).
 
     sampler: a gnnflow_amd.TemporalSampler over THIS rank's shard (edges whose source it
     owns, see PartitionedGraph)."""
@@ -317,101 +325,128 @@ class DevicePartitionedSampler:
         self._device = sampler._device
         self._fanouts = list(sampler._fanouts)
         self._L, self._S = sampler._num_layers, sampler._num_snapshots
-        self._size_cache = {}
-        self._gb = _capi.GfBlock()
+        self._layouts = {}     # R0 -> ([layouts per layer], [workspace offsets], total bytes)
+        self._ws_ring = [None, None, None, None]   # one workspace per in-flight sample
+        self._ws_next = 0
 
-    def _stream(self):
-        return self._C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+    # the plain sampler's attributes the pipeline / cache helpers look at
+    @property
+    def _inflight(self):
+        return self._sampler._inflight
 
-    def _sizes(self, R: int, layer: int):
-        """(partition scratch bytes, block output bytes) for R roots, cached."""
-        key = (R, layer)
-        hit = self._size_cache.get(key)
+    def _plan(self, R0: int):
+        hit = self._layouts.get(R0)
         if hit is None:
             C = self._C
-            a, b = C.c_size_t(0), C.c_size_t(0)
-            self._capi.check(self._lib.gf_partition_scratch_bytes(R, self._P, C.byref(a)))
-            self._capi.check(self._lib.gf_sampler_layer_output_bytes(self._sampler._h, R, layer,
-                                                                     C.byref(b)))
-            hit = self._size_cache[key] = (a.value, b.value)
+            lays, offs, total = [], [], 0
+            for layer in range(self._L):
+                lay = self._capi.GfPartLayout()
+                self._capi.check(self._lib.gf_sampler_part_layout(
+                    self._sampler._h, R0, layer, self._P, C.byref(lay)))
+                lays.append(lay)
+                row = []
+                for _ in range(self._S):
+                    row.append(total)
+                    total += lay.total
+                offs.append(row)
+            hit = self._layouts[R0] = (lays, offs, total)
         return hit
 
-    def sample_layer(self, nodes: torch.Tensor, ts: torch.Tensor, layer: int, snapshot: int):
+    def _workspace(self, nbytes: int, stream) -> torch.Tensor:
+        """grow-only scratch, one per sample that can be in flight at a time"""
+        i = self._ws_next
+        self._ws_next = (i + 1) % len(self._ws_ring)
+        ws = self._ws_ring[i]
+        if ws is None or ws.numel() < nbytes:
+            with torch.cuda.stream(stream):
+                ws = self._ws_ring[i] = torch.empty(max(nbytes, 1), dtype=torch.uint8,
+                                                    device=self._device)
+        return ws
+
+    def sample_async(self, nodes, ts, stream=None, worker_enqueue=False):
+        """TemporalSampler.sample_async for the partitioned graph: returns a PendingSample;
+        `.wait()` gives the MFGs.  With more than one rank the collectives run inside this
+        call (one host synchronisation per layer); the final kernels and the size read-back
+        are asynchronous either way."""
+        from .temporal_sampler import PendingSample
         C, lib, check = self._C, self._lib, self._capi.check
-        dev, P, me, F = self._device, self._P, self._rank, self._fanouts[layer]
-        if nodes.device != dev or nodes.dtype != torch.int64 or not nodes.is_contiguous():
-            nodes = nodes.to(dev, torch.int64).contiguous()
-        if ts.device != dev or ts.dtype != torch.float32 or not ts.is_contiguous():
-            ts = ts.to(dev, torch.float32).contiguous()
+        smp, dev, P, me = self._sampler, self._device, self._P, self._rank
+        if len(smp._inflight) >= smp._max_inflight:
+            smp._inflight[0].wait()
+        if stream is None:
+            stream = torch.cuda.current_stream(dev)
+        nodes, ts = smp._to_device(nodes, ts, stream)
         R = int(nodes.shape[0])
-        if R == 0:
-            return self._sampler._empty_block()
-        if torch.cuda.current_device() != dev.index:
-            with torch.cuda.device(dev):
-                return self.sample_layer(nodes, ts, layer, snapshot)
-        scratch_bytes, out_bytes = self._sizes(R, layer)
-        # one workspace allocation: [requests R x 16 | replies R x F x 24 | counts P x 8 |
-        # positions R x 4 | partition scratch]
-        o_rep = R * 16
-        o_cnt = o_rep + R * F * 24
-        o_pos = o_cnt + P * 8
-        o_scr = (o_pos + R * 4 + 15) & ~15
-        ws = torch.empty(o_scr + scratch_bytes, dtype=torch.uint8, device=dev)
-        base = ws.data_ptr()
-        stream = self._stream()
-        # 1. bucket by owner: requests ordered [other owners ascending | own share]
-        check(lib.gf_partition_plan(nodes.data_ptr(), ts.data_ptr(), R, P, me, base,
-                                    base + o_pos, base + o_cnt, base + o_scr, scratch_bytes,
-                                    dev.index, stream))
-        if P > 1:
-            req = ws[:o_rep].view(torch.int64).view(R, 2)
-            rep = ws[o_rep:o_cnt].view(torch.int64).view(R, F * 3)
-            counts = ws[o_cnt:o_pos].view(torch.int64)
-            recv_counts = torch.empty_like(counts)
-            _exchange(recv_counts, counts, None, None, self._group)
-            sc, rc = counts.tolist(), recv_counts.tolist()
-            n_own = sc[me]
-            n_net = R - n_own
-            sc[me] = rc[me] = 0
-            # 2. requests to the other ranks, asynchronously ...
-            got = torch.empty((sum(rc), 2), dtype=torch.int64, device=dev)
-            work = _exchange(got, req[:n_net], rc, sc, self._group, async_op=True)
-            # 3. ... overlapped with this rank's own share on its shard
-            check(lib.gf_sampler_sample_layer_padded(
-                self._sampler._h, base + n_net * 16 if n_own else None, n_own, layer, snapshot,
-                base + o_rep + n_net * F * 24 if n_own else None, stream))
-            if work is not None:
-                work.wait()
-            # 4. serve the received requests; replies land in the prefix of `rep`
-            n_got = int(got.shape[0])
-            served = torch.empty((n_got, F * 3), dtype=torch.int64, device=dev)
-            check(lib.gf_sampler_sample_layer_padded(
-                self._sampler._h, got.data_ptr() if n_got else None, n_got, layer, snapshot,
-                served.data_ptr() if n_got else None, stream))
-            _exchange(rep[:n_net], served, sc, rc, self._group)
+        lays, offs, ws_bytes = self._plan(max(R, 1))
+        nbytes = smp._bytes_cache.get(max(R, 1))
+        if nbytes is None:
+            n = C.c_size_t(0)
+            check(lib.gf_sampler_output_bytes(smp._h, max(R, 1), C.byref(n)))
+            nbytes = smp._bytes_cache[max(R, 1)] = n.value
+        buf, marks = smp._output_buffer(nbytes, stream)
+        ws = self._workspace(ws_bytes, stream)
+        sptr = C.c_void_p(stream.cuda_stream)
+        if P == 1:
+            call = lib.gf_sampler_sample_partitioned_async if worker_enqueue \
+                else lib.gf_sampler_sample_partitioned
+            check(call(smp._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
+                       buf.data_ptr(), nbytes, ws.data_ptr(), ws_bytes, sptr))
         else:
-            check(lib.gf_sampler_sample_layer_padded(self._sampler._h, base, R, layer, snapshot,
-                                                     base + o_rep, stream))
-        # 5. replies -> block in the original root order
-        buf = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
-        gb = self._gb
-        check(lib.gf_sampler_merge_padded(
-            self._sampler._h, nodes.data_ptr(), ts.data_ptr(), R, layer, base + o_rep,
-            base + o_pos, buf.data_ptr(), out_bytes, C.byref(gb), stream))
-        return self._sampler._block(buf, gb)
+            with torch.cuda.stream(stream):
+                check(lib.gf_sampler_part_begin(
+                    smp._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
+                    buf.data_ptr(), nbytes, P, me, sptr))
+                try:
+                    for layer in range(self._L):
+                        for s in range(self._S):
+                            self._exchange_layer(layer, s, lays[layer], ws, offs[layer][s], sptr)
+                    check(lib.gf_sampler_part_commit(smp._h))
+                except Exception:
+                    lib.gf_sampler_part_abort(smp._h)
+                    raise
+        # R = 0 still yields real (empty) blocks whose sizes come from the device
+        pending = PendingSample(smp, buf, (nodes, ts, ws), max(R, 1), marks)
+        smp._inflight.append(pending)
+        return pending
+
+    def _exchange_layer(self, layer, snapshot, lay, ws, off, sptr):
+        """One (layer, snapshot) with P > 1 ranks, on the current stream."""
+        C, lib, check = self._C, self._lib, self._capi.check
+        smp, dev, P, me, F = self._sampler, self._device, self._P, self._rank, self._fanouts[layer]
+        base = ws.data_ptr() + off
+        # 1. bucket by owner (the layer's root count is still on the device)
+        check(lib.gf_sampler_part_plan_own(smp._h, layer, snapshot, base, lay.total, 1))
+        counts = ws[off + lay.counts: off + lay.counts + 8 * P].view(torch.int64)
+        recv_counts = torch.empty_like(counts)
+        _exchange(recv_counts, counts, None, None, self._group)
+        sc, rc = counts.tolist(), recv_counts.tolist()      # the layer's one host sync
+        R = sum(sc)
+        n_net = R - sc[me]
+        sc[me] = rc[me] = 0
+        req = ws[off + lay.requests: off + lay.requests + 16 * R].view(torch.int64).view(R, 2)
+        rep = ws[off + lay.replies: off + lay.replies + 24 * F * R].view(torch.int64).view(R, F * 3)
+        # 2. requests to the other ranks ...
+        n_got = sum(rc)
+        got = torch.empty((n_got, 2), dtype=torch.int64, device=dev)
+        work = _exchange(got, req[:n_net], rc, sc, self._group, async_op=True)
+        # ... overlapped with this rank's own share on its shard
+        check(lib.gf_sampler_part_plan_own(smp._h, layer, snapshot, base, lay.total, 2))
+        if work is not None:
+            work.wait()
+        # 3. the received requests, served from this rank's shard; replies land in the prefix
+        #    of `rep`
+        served = torch.empty((n_got, F * 3), dtype=torch.int64, device=dev)
+        check(lib.gf_sampler_sample_layer_padded(
+            smp._h, got.data_ptr() if n_got else None, n_got, layer, snapshot,
+            served.data_ptr() if n_got else None, sptr))
+        _exchange(rep[:n_net], served, sc, rc, self._group)
+        # 4. replies -> block in the original root order; sizes stay on the device
+        check(lib.gf_sampler_part_merge(smp._h, layer, snapshot, base, lay.total))
 
     def sample(self, nodes, ts):
-        nodes, ts = self._sampler._to_device(nodes, ts)
-        results = []
-        for layer in range(self._L):
-            cur = []
-            for s in range(self._S):
-                if layer == 0:
-                    n, t = nodes, ts
-                else:
-                    prev = results[-1][s]
-                    n, t = prev.srcdata["ID"], prev.srcdata["ts"]
-                cur.append(self.sample_layer(n, t, layer, s))
-            results.append(cur)
-        results.reverse()
-        return results
+        return self.sample_async(nodes, ts).wait()
+
+    def sample_layer(self, nodes, ts, layer: int, snapshot: int):
+        raise NotImplementedError(
+            "DevicePartitionedSampler samples whole MFGs (sample / sample_async): the layers "
+            "of a partitioned sample are chained on the device")

@@ -310,6 +310,52 @@ GF_API int gf_sampler_merge_padded(gf_sampler* s, const int64_t* d_roots, const 
                                    const uint32_t* d_pos, void* d_out, size_t out_bytes,
                                    gf_block* block, void* stream);
 
+/* Chained form of the same exchange — no read-back between the layers (reference loop:
+ * gnnflow/distributed/dist_sampler.py:129-157 sample(), one RPC round per layer):
+ *   gf_sampler_part_begin
+ *   for every (layer, snapshot):
+ *     gf_sampler_part_plan_own    bucket the layer's roots (their count is device resident:
+ *                                 the previous layer's R + S) and sample this rank's own share
+ *     — the caller exchanges: counts, request rows [0, R - counts[rank]) of the workspace out,
+ *       gf_sampler_sample_layer_padded on what it received, reply rows back into the workspace —
+ *     gf_sampler_part_merge       replies -> the layer's block, sizes stay on the device
+ *   gf_sampler_part_commit        publishes the sizes; gf_sampler_sample_end returns the blocks
+ * A rank with no roots (R = 0) still takes part in every step.  With one rank
+ * gf_sampler_sample_partitioned issues the whole chain (`d_ws`: the layouts' totals, layer
+ * after layer, snapshot after snapshot).  Offsets of one (layer, snapshot) workspace: */
+typedef struct gf_part_layout {
+  size_t root_bound;     /* worst-case roots of the layer when sample() starts from R0 roots */
+  size_t requests;       /* [root_bound][2] int64, ordered [other owners ascending | own] */
+  size_t replies;        /* [root_bound][fanout][3] int64, same row order */
+  size_t counts;         /* [world_size] uint64: roots per owner */
+  size_t pos;            /* [root_bound] uint32: row of root i */
+  size_t scratch;
+  size_t scratch_bytes;
+  size_t total;          /* bytes of this workspace */
+} gf_part_layout;
+GF_API int gf_sampler_part_layout(const gf_sampler* s, size_t num_roots, uint32_t layer,
+                                  int world_size, gf_part_layout* out);
+GF_API int gf_sampler_part_begin(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
+                                 size_t num_roots, void* d_out, size_t out_bytes,
+                                 int world_size, int rank, void* stream);
+/* phases: 1 = bucket the roots, 2 = sample this rank's own share (call it right after starting
+ * the request all-to-all-v: the two overlap), 3 = both */
+GF_API int gf_sampler_part_plan_own(gf_sampler* s, uint32_t layer, uint32_t snapshot, void* d_ws,
+                                    size_t ws_bytes, int phases);
+GF_API int gf_sampler_part_merge(gf_sampler* s, uint32_t layer, uint32_t snapshot, void* d_ws,
+                                 size_t ws_bytes);
+GF_API int gf_sampler_part_commit(gf_sampler* s);
+GF_API int gf_sampler_part_abort(gf_sampler* s);
+GF_API int gf_sampler_sample_partitioned(gf_sampler* s, const int64_t* d_roots,
+                                         const float* d_root_ts, size_t num_roots, void* d_out,
+                                         size_t out_bytes, void* d_ws, size_t ws_bytes,
+                                         void* stream);
+/* ... the same, issued by the library's enqueue thread (see gf_sampler_sample_begin_async) */
+GF_API int gf_sampler_sample_partitioned_async(gf_sampler* s, const int64_t* d_roots,
+                                               const float* d_root_ts, size_t num_roots,
+                                               void* d_out, size_t out_bytes, void* d_ws,
+                                               size_t ws_bytes, void* stream);
+
 /* ---- message passing on a sampled block ---------------------- */
 /* The DGL calls of the reference's layers on an MFG (gnnflow/models/modules/layers.py:153-159,
  * models/graphsage.py:27-31, models/gat.py:28-46), as segment operations: a block's edges are

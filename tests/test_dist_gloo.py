@@ -52,7 +52,10 @@ def _worker(rank, world, port, cfg, ret):
 
         ps = PartitionedSampler(local_layer, cfg["fanouts"], cfg["snapshots"])
         ok = True
-        for it, R in enumerate(cfg["batches"]):
+        for it in range(len(cfg["batches"])):
+            # rotated per rank: whenever the list holds a 0, ONE rank has an empty batch in
+            # that round while its peers do not — it must still join the layer's collectives
+            R = cfg["batches"][(it + rank) % len(cfg["batches"])]
             nodes, t = synth.random_roots(N, R, 1000.0, seed=1000 * rank + it,
                                           extra_ids=[N + 3])
             got = ps.sample(nodes, t)

@@ -56,6 +56,10 @@ def test_single_gpu_line_with_roofline_and_cpu_baseline():
     assert d["value"] > c["value"]
     # ... and the CPU baseline ran the same batches: same sampled edges per step
     assert c["edges_per_step"] == pytest.approx(d["config"]["edges_per_step"], rel=0.02)
+    # north_star's hash-partitioned split rides in the same line (one rank: no exchange)
+    h = d["hash_partition"]
+    assert "error" not in h and h["world_size"] == 1 and h["value"] > 0 and h["steps"] == 1121
+    assert h["value"] > 0.5 * d["value"]         # the hash path is not a second-class citizen
 
 
 def test_driver_command_line_is_representative():
@@ -77,3 +81,5 @@ def test_two_ranks_through_torchrun():
     _check_common(d, 2, 40, 5)
     assert d["config"]["parallelism"] == "replica-dp2"
     assert "cpu_baseline" not in d       # rank 0 at N = 1 only
+    h = d["hash_partition"]              # both ranks exchange roots / replies (gloo here)
+    assert "error" not in h and h["world_size"] == 2 and h["value"] > 0

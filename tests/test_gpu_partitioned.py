@@ -1,5 +1,6 @@
-"""GPU: native hash-partitioned sampling (gf_partition_plan, gf_sampler_sample_layer_padded,
-gf_sampler_merge_padded through gnnflow_amd.dist.DevicePartitionedSampler).
+"""GPU: native hash-partitioned sampling (the chained gf_sampler_part_* calls and
+gf_sampler_sample_layer_padded through gnnflow_amd.dist.DevicePartitionedSampler; the
+one-layer gf_partition_plan directly).
   * one rank: the plan / padded / merge chain alone must reproduce TemporalSampler.sample()
     bit for bit (all roots are the rank's own);
   * the bucketing kernel against numpy for several world sizes and ranks (stable order,
@@ -80,7 +81,19 @@ def test_single_rank_chain_equals_plain_sampler(strategy, snapshots, window, pro
                              (gb.edata["ID"], wb.edata["ID"]), (gb.edata["dt"], wb.edata["dt"]),
                              (gb.edges()[0], wb.edges()[0]), (gb.edges()[1], wb.edges()[1])):
                     assert torch.equal(a, b)
-    assert part.sample(np.zeros(0, np.int64), np.zeros(0, np.float32))[0][0].num_edges() == 0
+    empty = part.sample(np.zeros(0, np.int64), np.zeros(0, np.float32))
+    assert all(b.num_edges() == 0 and b.num_src_nodes() == 0 for mfg in empty for b in mfg)
+    # pipelined use: several samples in flight, handed to the enqueue thread, FIFO results
+    side = torch.cuda.Stream()
+    reqs = [synth.random_roots(400, R, 1000.0, seed=50 + R) for R in (300, 2, 1500)]
+    pend = [part.sample_async(torch.from_numpy(n).cuda(), torch.from_numpy(t).cuda(),
+                              stream=side, worker_enqueue=True) for n, t in reqs]
+    for (n, t), p in zip(reqs, pend):
+        got, want = p.wait(), plain.sample(n, t)
+        for gl, wl in zip(got, want):
+            for gb, wb in zip(gl, wl):
+                assert torch.equal(gb.edata["ID"], wb.edata["ID"])
+                assert torch.equal(gb.srcdata["ID"], wb.srcdata["ID"])
 
 
 def _worker(rank, world, port, ret):
@@ -106,7 +119,11 @@ def _worker(rank, world, port, ret):
         ref = O.OracleSampler(full, [6, 4], "recent")
         part = DevicePartitionedSampler(TemporalSampler(shard, [6, 4], "recent"))
         ok = True
-        for it, R in enumerate([0, 1, 97, 600, 2000]):
+        sizes = [0, 1, 97, 600, 2000]
+        for it in range(len(sizes)):
+            # rotated per rank: in every round a different rank has an EMPTY batch and must
+            # still take part in the layer's collectives (its peers would block otherwise)
+            R = sizes[(it + rank) % len(sizes)]
             nodes, t = synth.random_roots(400, R, 1000.0, seed=1000 * rank + it, extra_ids=[403])
             got, want = part.sample(nodes, t), ref.sample(nodes, t)
             for gl, wl in zip(got, want):
