@@ -108,6 +108,9 @@ PROTOTYPES = {
     "gf_cache_init": (C.c_int, [_p, _p]),
     "gf_cache_resize": (C.c_int, [_p, _sz, _sz, _p, _p]),
     "gf_cache_fetch": (C.c_int, [_p, _p, _sz, _p, C.c_int, _p, _p]),
+    "gf_cache_probe": (C.c_int, [_p, _p, _sz, _p, _p]),
+    "gf_cache_fetch_pulled": (C.c_int, [_p, _p, _sz, _p, C.c_int, _p, _p, _p, _p]),
+    "gf_cache_init_rows": (C.c_int, [_p, _p, _sz, _p, _p]),
     "gf_cache_fetch_blocks": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p]),
     "gf_cache_fetch_blocks_async": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p,
                                               C.POINTER(C.c_uint64)]),

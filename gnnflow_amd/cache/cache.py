@@ -37,6 +37,7 @@ class _Kind:
             feats = feats.to(torch.float32)       # cache.py:71-74 (bool -> float32)
         assert feats.dim() == 2 and feats.shape[1] == self.dim, \
             "feature table must be [num_ids, dim]"
+        self.local_rows = int(feats.shape[0])
         if placement == "pinned":
             feats = feats.cpu().contiguous()
             self.table = feats if feats.is_pinned() else feats.pin_memory()
@@ -91,11 +92,18 @@ class Cache:
                  feature_placement: Optional[str] = None):
         if device == 'cpu' or device == torch.device('cpu'):
             raise ValueError('Cache must be on GPU')
+        shards = None
         if distributed:
-            raise NotImplementedError(
-                'the multi-machine KVStore feature path is out of scope of gnnflow_amd '
-                '(single node: features are sharded / replicated in HBM)')
-        if node_feats is None and edge_feats is None:
+            # the feature tables are sharded over the GPUs by owner (gnnflow_amd.dist.
+            # ShardedFeatures as `kvstore_client`); misses are pulled with all-to-all-v
+            shards = kvstore_client
+            if shards is None or not (hasattr(shards, "node") and hasattr(shards, "edge")):
+                raise ValueError('distributed=True needs kvstore_client=gnnflow_amd.dist.'
+                                 'ShardedFeatures(node=..., edge=...)')
+            if shards.node is None and shards.edge is None:
+                raise ValueError('At least one of node and edge shards must be provided')
+            node_feats = edge_feats = None
+        elif node_feats is None and edge_feats is None:
             raise ValueError('At least one of node_feats and edge_feats must be provided')
         if node_feats is not None and node_feats.shape[0] != num_nodes:
             raise ValueError(
@@ -126,11 +134,15 @@ class Cache:
         self.node_feats, self.edge_feats = node_feats, edge_feats
         self.dim_node_feat = dim_node_feat if node_feats is not None else 0
         self.dim_edge_feat = dim_edge_feat if edge_feats is not None else 0
+        if shards is not None:
+            self.dim_node_feat = shards.node.dim if shards.node is not None else 0
+            self.dim_edge_feat = shards.edge.dim if shards.edge is not None else 0
         self.device = device
         self.pinned_nfeat_buffs = pinned_nfeat_buffs   # accepted, unused: misses never
         self.pinned_efeat_buffs = pinned_efeat_buffs   # stage through the host here
         self.kvstore_client = kvstore_client
-        self.distributed = False
+        self.distributed = bool(distributed)
+        self._shards = shards
         self.neg_sample_ratio = neg_sample_ratio
         self._target_edge_features = None
         self._ticket = 0
@@ -143,12 +155,25 @@ class Cache:
         self._lib = _capi.load()
         self._node = self._edge = None
         with torch.cuda.device(device):
-            if self.dim_node_feat != 0:
-                self._node = _Kind(self._lib, num_nodes, self.node_capacity, node_feats,
-                                   self.dim_node_feat, device, placement, self._policy)
-            if self.dim_edge_feat != 0:
-                self._edge = _Kind(self._lib, num_edges, self.edge_capacity, edge_feats,
-                                   self.dim_edge_feat, device, placement, self._policy)
+            if shards is not None:
+                # no local table: a missed row always comes out of the pulled rows
+                def stub(dim):
+                    return torch.zeros((1, dim), dtype=torch.float32)
+                if self.dim_node_feat != 0:
+                    self._node = _Kind(self._lib, num_nodes, self.node_capacity,
+                                       stub(self.dim_node_feat), self.dim_node_feat, device,
+                                       "device", self._policy)
+                if self.dim_edge_feat != 0:
+                    self._edge = _Kind(self._lib, num_edges, self.edge_capacity,
+                                       stub(self.dim_edge_feat), self.dim_edge_feat, device,
+                                       "device", self._policy)
+            else:
+                if self.dim_node_feat != 0:
+                    self._node = _Kind(self._lib, num_nodes, self.node_capacity, node_feats,
+                                       self.dim_node_feat, device, placement, self._policy)
+                if self.dim_edge_feat != 0:
+                    self._edge = _Kind(self._lib, num_edges, self.edge_capacity, edge_feats,
+                                       self.dim_edge_feat, device, placement, self._policy)
         self._stats_span = None
         self._target_edge_thunk = None
         self.num_gather_launches = 0   # gather launches issued so far (one per round)
@@ -169,6 +194,9 @@ class Cache:
         if stats is None or stats.shape[0] == 0:
             return 1.0 if all_hit_blocks else 0
         s = stats.to(torch.float32)
+        s = s[s[:, 1] > 0]               # a block without ids fetched nothing (reference: skipped)
+        if s.shape[0] == 0:
+            return 1.0 if all_hit_blocks else 0
         r = s[:, 0::2].sum(dim=1) / s[:, 1]
         if all_hit_blocks:
             return (r.sum() + all_hit_blocks) / (r.shape[0] + all_hit_blocks)
@@ -197,6 +225,8 @@ class Cache:
 
     def init_cache(self, *args, **kwargs):
         """Fill the cache with the first `capacity` rows (cache.py:157-195)."""
+        if self.distributed:
+            return self._init_cache_distributed()
         with torch.cuda.device(self.device):
             for k in (self._node, self._edge):
                 if k is not None:
@@ -205,6 +235,8 @@ class Cache:
     def resize(self, new_num_nodes: int, new_num_edges: int):
         """Grow the id spaces (cache.py:197-221).  The caller must have replaced
         `node_feats` / `edge_feats` with tables covering the new ids."""
+        if self.distributed:
+            raise NotImplementedError("resize of a cache over sharded feature tables")
         with torch.cuda.device(self.device):
             if self._node is not None and new_num_nodes > self.num_nodes:
                 self._regrow("_node", self.node_feats, new_num_nodes,
@@ -294,6 +326,8 @@ class Cache:
         for the enqueue on first access (blocks built by gnnflow_amd.TemporalSampler), or
         call wait_enqueued()."""
         self.wait_enqueued()      # at most one submission in flight
+        if self.distributed:
+            return self._fetch_distributed(mfgs, eid, update_cache, target_edge_features)
         upd = 1 if update_cache else 0
         dev = self.device
         # jobs: (kind, ids address, n, dim, block, which, key, keepalive)
@@ -344,6 +378,102 @@ class Cache:
             with torch.cuda.device(dev):
                 return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
         return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
+
+    # ---- sharded feature tables (distributed=True) ----------------------------------------
+    def _init_cache_distributed(self):
+        """cache.py:161-173: the edge cache starts with the first `capacity` edges of THIS
+        rank's shard (no exchange), the node cache starts empty."""
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            if self._node is not None:
+                _capi.check(self._lib.gf_cache_init_rows(self._node.h, None, 0, None, st))
+            if self._edge is not None:
+                sh = self._shards.edge
+                n = min(self.edge_capacity, int(sh.local_ids.shape[0]))
+                ids = sh.local_ids[:n].contiguous()
+                rows = sh.rows[:n].contiguous()
+                _capi.check(self._lib.gf_cache_init_rows(
+                    self._edge.h, ids.data_ptr() if n else None, n,
+                    rows.data_ptr() if n else None, st))
+                self._init_refs = (ids, rows)
+
+    def _fetch_pulled(self, kind, shards, ids, keys, upd, stats_row):
+        """One block over a sharded table: probe the cache, pull the distinct missed rows from
+        their owners (a collective: called for EVERY block on every rank, with no ids when
+        the block is empty), then the usual fused gather + replacement with the pulled rows
+        standing in for the local table.  Returns the block's rows."""
+        lib, dev, st = self._lib, self.device, self._stream()
+        n = int(ids.shape[0])
+        slot = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        if n:
+            _capi.check(lib.gf_cache_probe(kind.h, ids.data_ptr(), n, slot.data_ptr(), st))
+        miss_pos = torch.nonzero(slot[:n] == -1).flatten()
+        miss_ids = ids[miss_pos]
+        uniq, inverse = torch.unique(miss_ids, return_inverse=True)
+        key_u = torch.empty_like(uniq)
+        key_u[inverse] = keys[miss_pos]          # every occurrence of an id has the same key
+        rows_u = shards.pull(uniq, key_u)        # collective
+        out = torch.empty((n, kind.dim), dtype=torch.float32, device=dev)
+        if n:
+            if rows_u.shape[0] == 0:             # all hits: the kernel still wants a pointer
+                rows_u = torch.zeros((1, kind.dim), dtype=torch.float32, device=dev)
+            miss_index = torch.zeros(n, dtype=torch.int32, device=dev)
+            miss_index[miss_pos] = inverse.to(torch.int32)
+            _capi.check(lib.gf_cache_fetch_pulled(
+                kind.h, ids.data_ptr(), n, out.data_ptr(), upd, stats_row, rows_u.data_ptr(),
+                miss_index.data_ptr(), st))
+            # rows_u / miss_index are read by kernels already queued on this stream; the
+            # allocator reuses their memory only behind them on the same stream
+        return out
+
+    def _fetch_distributed(self, mfgs, eid, update_cache, target_edge_features):
+        """fetch_feature over sharded tables (cache.py:288-313,351-388,403-411): same rows,
+        same per-block cache semantics; every (layer, snapshot) block issues exactly one pull
+        per kind so that the ranks stay in lock step whatever their block sizes."""
+        dev = self.device
+        upd = 1 if update_cache else 0
+        with torch.cuda.device(dev):
+            n_node = sum(len(mfgs[0]) for _ in (0,)) if self._node is not None else 0
+            n_edge = sum(len(mfg) for mfg in mfgs) if self._edge is not None else 0
+            pos = self._stats_rows(n_node + n_edge)
+            ring = self._stats_ring
+            k = 0
+            if self._node is not None:
+                for b in mfgs[0]:
+                    ids = self._ids(b.srcdata['ID'])
+                    out = self._fetch_pulled(self._node, self._shards.node, ids, ids, upd,
+                                             ring.data_ptr() + 64 * (pos + k))
+                    b.srcdata['h'] = out
+                    k += 1
+            empty_edge_blocks = 0
+            if self._edge is not None:
+                for mfg in mfgs:
+                    for b in mfg:
+                        ids = self._ids(b.edata['ID'])
+                        if ids.shape[0]:
+                            # owner of an edge's features: its source node = the block's root
+                            keys = self._ids(b.srcdata['ID'])[b.edges()[1]]
+                        else:
+                            keys = ids
+                            empty_edge_blocks += 1
+                        out = self._fetch_pulled(self._edge, self._shards.edge, ids, keys, upd,
+                                                 ring.data_ptr() + 64 * (pos + k))
+                        if ids.shape[0]:
+                            b.edata['f'] = out
+                        k += 1
+                if target_edge_features and eid is not None:
+                    t = self._ids(eid)
+                    # cache.py:403-409: the batch's source nodes are the first roots
+                    num = mfgs[-1][0].num_dst_nodes() // (self.neg_sample_ratio + 2)
+                    nid = self._ids(mfgs[-1][0].srcdata['ID'])[:num]
+                    if nid.shape[0] != t.shape[0]:
+                        raise ValueError("target edge ids and the batch's source roots differ "
+                                         "in length")
+                    self._target_edge_thunk = None
+                    self._target_edge_features = self._shards.edge.pull(t, nid)
+            self._stats_span = (pos, n_node, n_node + n_edge, ring, 0)
+            self._empty_stat_rows = empty_edge_blocks
+        return mfgs
 
     def _id_array(self, b, which):
         """(address, count, keepalive) of a block's id array: straight from the sampler's

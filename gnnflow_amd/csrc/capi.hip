@@ -467,6 +467,29 @@ int gf_cache_fetch(gf_cache* c, const int64_t* d_ids, size_t n, float* d_out, in
     c->impl.fetch(d_ids, n, d_out, update != 0, d_stats, static_cast<hipStream_t>(stream));
   });
 }
+int gf_cache_init_rows(gf_cache* c, const int64_t* d_ids, size_t n, const float* d_rows,
+                       void* stream) {
+  return guarded([&] {
+    GF_C(c);
+    GF_REQUIRE(d_rows != nullptr || n == 0, "cache: null rows");
+    c->impl.init_ids(d_ids, n, static_cast<hipStream_t>(stream), d_rows);
+  });
+}
+int gf_cache_probe(gf_cache* c, const int64_t* d_ids, size_t n, int32_t* d_slot, void* stream) {
+  return guarded([&] {
+    GF_C(c);
+    c->impl.probe(d_ids, n, d_slot, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_cache_fetch_pulled(gf_cache* c, const int64_t* d_ids, size_t n, float* d_out, int update,
+                          uint32_t* d_stats, const float* d_miss_rows,
+                          const uint32_t* d_miss_index, void* stream) {
+  return guarded([&] {
+    GF_C(c);
+    c->impl.fetch_pulled(d_ids, n, d_out, update != 0, d_stats, d_miss_rows, d_miss_index,
+                         static_cast<hipStream_t>(stream));
+  });
+}
 int gf_cache_fetch_blocks(gf_cache* node_cache, gf_cache* edge_cache, const gf_fetch_desc* descs,
                           size_t n, void* stream) {
   return guarded([&] {

@@ -123,6 +123,10 @@ struct Ctx {
   uint32_t tile_rows;       // rows per wave in the gather
   float* out;
   const float* feats;
+  // sharded feature tables (Cache(distributed=True)): a missed row i is read from row
+  // miss_index[i] of miss_rows — the rows the caller pulled from their owners — not from feats
+  const float* miss_rows;
+  const uint32_t* miss_index;
   uint64_t num_ids;
   int32_t* map;             // null: no cache (plain gather)
   float* cache_buf;
@@ -210,7 +214,10 @@ __device__ inline void gather_body(const Ctx& c) {
           if (c.update && c.policy != GF_CACHE_FIFO) c.touched[slot] = c.epoch_new;
         } else {
           slot = -1;
-          src = feats + static_cast<uint64_t>(id) * dimv;
+          src = c.miss_rows
+                    ? reinterpret_cast<const VecT*>(c.miss_rows) +
+                          static_cast<uint64_t>(c.miss_index[row0 + lane]) * dimv
+                    : feats + static_cast<uint64_t>(id) * dimv;
           if (c.update) atomicMax(&c.map[id], -static_cast<int32_t>(row0 + lane + 1));
         }
       }
@@ -1028,6 +1035,24 @@ __global__ void cache_fill_kernel(int32_t* map, uint64_t num_ids, int64_t* slot_
   }
 }
 
+// slot of every id (>= 0: cached there, -1: not cached, -2: out of range): what a caller
+// that pulls missed rows from their owners needs to know before the fetch
+__global__ void cache_probe_kernel(const int64_t* __restrict__ ids, uint64_t n,
+                                   const int32_t* __restrict__ map, uint64_t num_ids,
+                                   int32_t* __restrict__ slot) {
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += stride) {
+    const int64_t id = ids[i];
+    int32_t v = -2;
+    if (id >= 0 && static_cast<uint64_t>(id) < num_ids) {
+      v = map ? map[id] : kAbsent;
+      if (v < 0) v = -1;
+    }
+    slot[i] = v;
+  }
+}
+
 inline bool vec4_ok(size_t dim, const void* a, const void* b, const void* c) {
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   return dim % 4 == 0 && al(a) && al(b) && al(c);
@@ -1275,7 +1300,8 @@ void FeatureCache::set_policy(int policy) {
 namespace {
 __global__ void cache_install_ids_kernel(const int64_t* __restrict__ ids, uint64_t n,
                                          uint64_t num_ids, uint32_t dim,
-                                         const float* __restrict__ feats, int32_t* map,
+                                         const float* __restrict__ feats,
+                                         const float* __restrict__ rows, int32_t* map,
                                          int64_t* slot_id, float* buffer) {
   const int lane = threadIdx.x & 63;
   const uint64_t wave = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -1285,13 +1311,14 @@ __global__ void cache_install_ids_kernel(const int64_t* __restrict__ ids, uint64
     if (id < 0 || static_cast<uint64_t>(id) >= num_ids) continue;
     if (lane == 0) { map[id] = static_cast<int32_t>(s); slot_id[s] = id; }
     for (uint32_t c = lane; c < dim; c += 64)
-      buffer[s * dim + c] = feats[static_cast<uint64_t>(id) * dim + c];
+      buffer[s * dim + c] = rows ? rows[s * dim + c] : feats[static_cast<uint64_t>(id) * dim + c];
   }
 }
 }  // namespace
 
 // GNNLabStaticCache.init_cache (gnnlab_static_cache.py:87-168): slot i holds ids[i]
-void FeatureCache::init_ids(const int64_t* d_ids, size_t n, hipStream_t stream) {
+void FeatureCache::init_ids(const int64_t* d_ids, size_t n, hipStream_t stream,
+                            const float* d_rows) {
   GF_REQUIRE(n <= capacity_, "cache: more ids than slots");
   GF_REQUIRE(d_ids != nullptr || n == 0, "cache: null id list");
   DeviceGuard dg(device_);
@@ -1304,7 +1331,7 @@ void FeatureCache::init_ids(const int64_t* d_ids, size_t n, hipStream_t stream) 
   if (n) {
     const unsigned grid = static_cast<unsigned>(std::min<size_t>((n + 3) / 4, 4096));
     cache_install_ids_kernel<<<dim3(grid), dim3(256), 0, stream>>>(
-        d_ids, n, num_ids_, static_cast<uint32_t>(dim_), feats_, map_.as<int32_t>(),
+        d_ids, n, num_ids_, static_cast<uint32_t>(dim_), feats_, d_rows, map_.as<int32_t>(),
         slot_id_.as<int64_t>(), buffer_.as<float>());
   }
   GF_HIP(hipGetLastError());
@@ -1455,6 +1482,37 @@ void FeatureCache::fetch(const int64_t* d_ids, size_t n, float* d_out, bool upda
   Round r;
   r.count = 1;
   prepare(d_ids, n, d_out, update, d_stats, &r.c[0], stream);
+  launch_round(r, stream);
+}
+
+// Cache(distributed=True): the slots of a block's ids, so that the caller can pull the
+// missed rows from their owners ...
+void FeatureCache::probe(const int64_t* d_ids, size_t n, int32_t* d_slot, hipStream_t stream) {
+  if (n == 0) return;
+  GF_REQUIRE(d_ids && d_slot, "cache probe: null pointer");
+  DeviceGuard dg(device_);
+  const unsigned grid = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 4096));
+  cache_probe_kernel<<<dim3(grid), dim3(256), 0, stream>>>(
+      d_ids, n, capacity_ ? map_.as<int32_t>() : nullptr, num_ids_, d_slot);
+  GF_HIP(hipGetLastError());
+}
+
+// ... and the block's fetch with those rows standing in for the local feature table
+void FeatureCache::fetch_pulled(const int64_t* d_ids, size_t n, float* d_out, bool update,
+                                uint32_t* d_stats, const float* d_miss_rows,
+                                const uint32_t* d_miss_index, hipStream_t stream) {
+  if (n == 0) return;
+  GF_REQUIRE(d_miss_rows && d_miss_index, "cache fetch: null pulled rows");
+  DeviceGuard dg(device_);
+  Round r;
+  r.count = 1;
+  prepare(d_ids, n, d_out, update, d_stats, &r.c[0], stream);
+  r.c[0].miss_rows = d_miss_rows;
+  r.c[0].miss_index = d_miss_index;
+  if (r.c[0].vec4 && (reinterpret_cast<uintptr_t>(d_miss_rows) & 15u)) {
+    r.c[0].vec4 = 0;
+    r.c[0].dimv = static_cast<uint32_t>(dim_);
+  }
   launch_round(r, stream);
 }
 

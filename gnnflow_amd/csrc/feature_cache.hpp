@@ -34,7 +34,13 @@ class FeatureCache {
   ~FeatureCache();
 
   void init(hipStream_t stream);
-  void init_ids(const int64_t* d_ids, size_t n, hipStream_t stream);
+  // slot i caches d_ids[i]; its row comes from d_rows[i] if given, else from the feature table
+  void init_ids(const int64_t* d_ids, size_t n, hipStream_t stream,
+                const float* d_rows = nullptr);
+  void probe(const int64_t* d_ids, size_t n, int32_t* d_slot, hipStream_t stream);
+  void fetch_pulled(const int64_t* d_ids, size_t n, float* d_out, bool update,
+                    uint32_t* d_stats, const float* d_miss_rows, const uint32_t* d_miss_index,
+                    hipStream_t stream);
   void set_policy(int policy);
   void reset_order(hipStream_t stream);
   void rewind_fifo(hipStream_t stream);

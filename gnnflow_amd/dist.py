@@ -450,3 +450,83 @@ class DevicePartitionedSampler:
         raise NotImplementedError(
             "DevicePartitionedSampler samples whole MFGs (sample / sample_async): the layers "
             "of a partitioned sample are chained on the device")
+
+
+# ---- feature tables sharded by owner (SURVEY.md 8(e) "Features") --------------------------
+class FeatureShards:
+    """One kind's feature table (node or edge features) sharded over the ranks: rank
+    owner(key) holds the row, key = the node id for node features and the edge's SOURCE node
+    for edge features — where the reference's KVStore keeps them
+    (gnnflow/distributed/kvstore.py:70-126; `pull(mode='edge', nid=...)`, :300-308).
+
+    `pull(ids, keys)` is the reference's `KVStoreClient.pull` as one all-to-all-v of ids and
+    one of rows over the process group (RCCL on HBM tensors; gloo on CPU tensors or staged):
+    a COLLECTIVE — every rank calls it the same number of times, with zero ids if it needs
+    nothing.  Rows come back in the order of `ids`.
+    """
+
+    def __init__(self, num_ids: int, local_ids: torch.Tensor, local_rows: torch.Tensor,
+                 group=None):
+        self.num_ids = int(num_ids)
+        self.device = local_rows.device
+        self.dim = int(local_rows.shape[1])
+        self.group = group
+        self.P = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.local_ids = local_ids.to(self.device, torch.int64)
+        self.rows = local_rows.to(torch.float32).contiguous()
+        # global id -> local row (dense: 4 B per id of the GLOBAL id space on every rank)
+        self.index = torch.full((self.num_ids,), -1, dtype=torch.int32, device=self.device)
+        self.index[self.local_ids] = torch.arange(self.local_ids.shape[0], dtype=torch.int32,
+                                                  device=self.device)
+        self.bytes_sent = 0       # ids out + rows back, for the traffic figures in DESIGN.md
+        self.rows_pulled = 0
+
+    @classmethod
+    def from_full(cls, feats, keys, rank: int, world_size: int, device, group=None):
+        """Keeps the rows this rank owns out of a full table (tests, benches, loaders that
+        read the whole file): feats [num_ids, dim], keys [num_ids] = the node id that decides
+        each row's owner (nodes: arange(num_ids); edges: the edge's source node)."""
+        feats = torch.as_tensor(feats)
+        keys_np = np.asarray(keys, dtype=np.int64)
+        own = np.nonzero(owner_of_np(keys_np, world_size) == rank)[0]
+        ids = torch.from_numpy(own)
+        return cls(feats.shape[0], ids.to(device), feats[ids].to(device, torch.float32), group)
+
+    def pull(self, ids: torch.Tensor, keys: torch.Tensor) -> torch.Tensor:
+        dev, P = self.device, self.P
+        ids = ids.to(dev, torch.int64)
+        n = int(ids.shape[0])
+        if P == 1:
+            local = self.index[ids].long()
+            if n and bool((local < 0).any()):
+                raise KeyError("FeatureShards.pull: id without a row on its owner")
+            return self.rows[local]
+        owners = owner_of(keys.to(dev, torch.int64), P)
+        order = torch.argsort(owners, stable=True)
+        counts = torch.bincount(owners, minlength=P)
+        recv_counts = torch.empty_like(counts)
+        _exchange(recv_counts, counts, None, None, self.group)
+        sc, rc = counts.tolist(), recv_counts.tolist()
+        got = torch.empty(sum(rc), dtype=torch.int64, device=dev)
+        _exchange(got, ids[order].contiguous(), rc, sc, self.group)
+        local = self.index[got].long()
+        if got.shape[0] and bool((local < 0).any()):
+            raise KeyError("FeatureShards.pull: asked for an id this rank does not own")
+        served = self.rows[local]
+        back = torch.empty((n, self.dim), dtype=torch.float32, device=dev)
+        _exchange(back, served, sc, rc, self.group)
+        out = torch.empty_like(back)
+        out[order] = back
+        me = self.rank
+        self.bytes_sent += 8 * (n - sc[me]) + 4 * self.dim * (sum(rc) - rc[me])
+        self.rows_pulled += n - sc[me]
+        return out
+
+
+class ShardedFeatures:
+    """What `Cache(distributed=True, kvstore_client=...)` takes: the node and / or edge
+    feature shards of this rank."""
+
+    def __init__(self, node: Optional[FeatureShards] = None, edge: Optional[FeatureShards] = None):
+        self.node, self.edge = node, edge

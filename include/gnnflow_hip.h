@@ -216,6 +216,22 @@ GF_API int gf_cache_resize(gf_cache* c, size_t new_num_ids, size_t new_capacity,
 GF_API int gf_cache_fetch(gf_cache* c, const int64_t* d_ids, size_t n, float* d_out,
                           int update, uint32_t* d_stats, void* stream);
 
+/* Sharded feature tables (Cache(distributed=True): cache.py:293-312,351-388 pull the missed
+ * rows from the owning machine's KVStore, gnnflow/distributed/kvstore.py:70-126; here the
+ * owners are the GPUs of the node and the pull is the caller's all-to-all-v):
+ *   gf_cache_probe        d_slot[i] = slot of d_ids[i] (>= 0), -1 not cached, -2 out of range
+ *   gf_cache_fetch_pulled as gf_cache_fetch, but the row of a missed id i is
+ *                         d_miss_rows[d_miss_index[i]] (the pulled rows), not d_feats[id]
+ *   gf_cache_init_rows    slot i caches d_ids[i] with row d_rows[i] (init_cache when the first
+ *                         `capacity` rows live on other GPUs, cache.py:175-195) */
+GF_API int gf_cache_probe(gf_cache* c, const int64_t* d_ids, size_t n, int32_t* d_slot,
+                          void* stream);
+GF_API int gf_cache_fetch_pulled(gf_cache* c, const int64_t* d_ids, size_t n, float* d_out,
+                                 int update, uint32_t* d_stats, const float* d_miss_rows,
+                                 const uint32_t* d_miss_index, void* stream);
+GF_API int gf_cache_init_rows(gf_cache* c, const int64_t* d_ids, size_t n, const float* d_rows,
+                              void* stream);
+
 /* All fetches of one Cache.fetch_feature() call (cache.py:255-413) in one call.
  * kind 0: block of node ids through node_cache (srcdata['h'], cache.py:269-323);
  * kind 1: block of edge ids through edge_cache (edata['f'], cache.py:326-400), executed

@@ -1,0 +1,108 @@
+"""GPU: Cache(distributed=True) over owner-sharded feature tables — two and three ranks
+sharing the one GPU of the test box (exchange staged through gloo) and the one-rank case:
+every fetched row (`h`, `f`, target edge features) equals the full table's row, i.e. the
+single-rank gather; hit statistics behave like a cache (second fetch of the same blocks hits).
+Reference: gnnflow/cache/cache.py:288-313,351-388,403-411."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tables(N, E, d):
+    rng = np.random.RandomState(3)
+    return (rng.rand(N, d).astype(np.float32), rng.rand(E, d).astype(np.float32))
+
+
+def _run(rank, world, ratio):
+    import torch
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from gnnflow_amd.cache import LRUCache
+    from gnnflow_amd.dist import FeatureShards, ShardedFeatures
+    from tests import synth
+    N, E, d = 400, 12000, 20
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=5, tie_levels=500)
+    nfeat, efeat = _tables(N, E, d)
+    dev = torch.device("cuda", 0)
+    # every rank samples on the whole graph here (replica); only the FEATURES are sharded
+    g = DynamicGraph(1 << 20, 64 << 20, "cuda", 8, 64, "insert")
+    g.add_edges(src, dst, ts, eid)
+    sampler = TemporalSampler(g, [6, 6], "recent")
+    shards = ShardedFeatures(node=FeatureShards.from_full(nfeat, np.arange(N), rank, world, dev),
+                             edge=FeatureShards.from_full(efeat, src, rank, world, dev))
+    cache = LRUCache(ratio, ratio, N, E, dev, None, None, d, d, kvstore_client=shards,
+                     distributed=True)
+    cache.init_cache()
+    ok = True
+    sizes = [0, 60, 300, 900]
+    for it in range(len(sizes)):
+        B = sizes[(it + rank) % len(sizes)]              # uneven, sometimes empty batches
+        rng = np.random.RandomState(1000 * rank + it)
+        pick = rng.randint(0, E, B)
+        roots = np.concatenate([src[pick], dst[pick], rng.randint(0, N, B)]).astype(np.int64)
+        rts = np.tile(ts[pick] + 1.0, 3).astype(np.float32)
+        mfgs = sampler.sample(roots, rts)
+        cache.fetch_feature(mfgs, eid[pick])
+        for b in mfgs[0]:
+            ids = b.srcdata["ID"].cpu().numpy()
+            assert np.array_equal(b.srcdata["h"].cpu().numpy(), nfeat[ids]), ("h", it, B)
+        for mfg in mfgs:
+            for b in mfg:
+                if b.num_edges():
+                    assert np.array_equal(b.edata["f"].cpu().numpy(),
+                                          efeat[b.edata["ID"].cpu().numpy()]), ("f", it, B)
+        assert np.array_equal(cache.target_edge_features.cpu().numpy(), efeat[eid[pick]]), "target"
+        cache.fetch_feature(mfgs, eid[pick])   # same blocks again (all ranks: lock step)
+        if B and ratio == 1.0:                 # a cache as large as the id space kept them all
+            assert float(cache.cache_edge_ratio) == 1.0, "edge ratio"
+            assert float(cache.cache_node_ratio) == 1.0, "node ratio"
+        elif B:
+            assert 0.0 <= float(cache.cache_edge_ratio) <= 1.0
+    torch.cuda.synchronize()
+    return bool(ok)
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        try:
+            ret[rank] = _run(rank, world, 0.1) and _run(rank, world, 1.0)
+        except Exception as e:      # surface the reason in the parent's assertion
+            import traceback
+            ret[rank] = "{}: {}\n{}".format(type(e).__name__, e, traceback.format_exc()[-1500:])
+            raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_features_ranks_sharing_one_gpu(world):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+@pytest.mark.parametrize("ratio", [0.1, 1.0])
+def test_sharded_features_one_rank(ratio):
+    assert _run(0, 1, ratio)
+
+
+def test_distributed_needs_shards():
+    import torch
+    from gnnflow_amd.cache import LRUCache
+    with pytest.raises(ValueError):
+        LRUCache(0.1, 0.1, 10, 10, "cuda:0", None, None, 4, 4, distributed=True)
