@@ -268,6 +268,7 @@ def main():
             "parallelism": "{}-dp{}".format(args.partition, world),
             "pipelined": bool(pipelined),
             "pipeline_depth": pipe.depth if pipelined else 0,
+            "workload_key": workload_key(args, repeats),
         },
     }
     if cache is not None and g_n.value:

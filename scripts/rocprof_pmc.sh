@@ -1,18 +1,24 @@
 # HBM traffic of the gather kernel from PMC counters, one counter per pass (TCC has 4
 # slots: FETCH_SIZE costs 3, WRITE_SIZE 2), per /opt/skills/guides/MI355X_MICROARCH.md.
+#   bash scripts/rocprof_pmc.sh <tag> [bench args]     default: the driver's command line
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=${1:-r1}
+shift
+ARGS="${*:---steps 20 --warmup 5}"
 mkdir -p gpurun_out/pmc
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc -o ${TAG}_$C -- python3 bench.py --no-cpu-baseline --no-pipeline > gpurun_out/pmc/${TAG}_$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc -o ${TAG}_$C -- python3 bench.py --no-cpu-baseline --no-hash-leg $ARGS > gpurun_out/pmc/${TAG}_$C.log 2>&1
 done
 ls gpurun_out/pmc | head
 python3 - <<PY
 import csv, collections, re, glob, json
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (one counter per pass) -- python3 bench.py "
-                  "--no-cpu-baseline --no-pipeline  (default workload: 20 warmup + 1121 timed steps)",
+                  "--no-cpu-baseline --no-hash-leg $ARGS",
        "kernel": "gather_rows_kernel", "all_kernels": {}}
+for line in open("gpurun_out/pmc/${TAG}_FETCH_SIZE.log"):
+    if line.startswith("{"):
+        out["bench_args"] = json.loads(line)["config"]["workload_key"]
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("gpurun_out/pmc/${TAG}_%s_counter_collection.csv" % c)
     if not f:
