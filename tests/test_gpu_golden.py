@@ -1,6 +1,8 @@
 """GPU parity, part 1: the HIP product path against the reference's own known-answer
-tests (the same fixtures that pin the oracle), for all four memory resource types the
-reference parameterises over."""
+tests (the same fixtures that pin the oracle).  The reference parameterises every case over
+four memory resource types; here they all place the edge store in HBM (one code path,
+INTEGRATION.md 4), so the cases run once and a single test checks that the other three type
+names are accepted and behave the same."""
 import pytest
 
 from tests.golden_runner import load_cases, run_case
@@ -27,9 +29,15 @@ def _make_sampler(g, **kw):
     return gnnflow_amd.TemporalSampler(g, **kw)
 
 
-@pytest.mark.parametrize("mem", ["cuda", "unified", "pinned", "shared"])
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-def test_hip_matches_reference_golden(case, mem):
+def test_hip_matches_reference_golden(case):
+    run_case(case, _make_graph("cuda"), _make_sampler)
+
+
+@pytest.mark.parametrize("mem", ["unified", "pinned", "shared"])
+def test_other_memory_resource_types_are_accepted(mem):
+    """Same result through every type name (one representative multi-layer case each)."""
+    case = next(c for c in CASES if c["name"] == "sampler/sample_multi_layers_multi_snapshots")
     run_case(case, _make_graph(mem), _make_sampler)
 
 
