@@ -2,6 +2,7 @@
 // move bytes.  See edge_store.hpp for the layout; reference lines are cited on
 // each function that restates reference behaviour.
 #include "edge_store.hpp"
+#include "ingest_sort.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -23,7 +24,7 @@ constexpr size_t kBlockSpace = 20;       // common.h:23-24 bytes per edge
 // the threads are what the 10^7-edge chunks of a graph build spend their time in.
 template <typename F>
 void parallel_for(size_t n, size_t grain, F&& fn) {
-  static const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  static const unsigned hw = std::max(1u, std::min(12u, std::thread::hardware_concurrency()));
   const size_t parts = std::min<size_t>(hw, (n + grain - 1) / std::max<size_t>(grain, 1));
   if (parts <= 1) { fn(size_t(0), n); return; }
   std::vector<std::thread> th;
@@ -220,20 +221,16 @@ void EdgeStore::ensure_pool(uint64_t elems) {
 }
 
 // temporal_block_allocator.cu:83-88,134-149 (AlignUp + AllocateInternal header init)
-LogicalBlock EdgeStore::new_block(size_t size) {
+// (the pool limit was checked for the whole batch before anything was mutated, add_edges 2.;
+// the byte / block counters are accumulated per thread in `delta` and applied by the caller)
+LogicalBlock EdgeStore::new_block(size_t size, BlockDelta* delta) {
   LogicalBlock b;
   b.size = 0;
   b.capacity = size < minimum_block_size_ ? minimum_block_size_ : size;
   b.start_ts = std::numeric_limits<float>::max();
   b.end_ts = 0;
-  logical_bytes_ += b.capacity * kBlockSpace;
-  logical_blocks_++;
-  if (logical_bytes_ > maximum_pool_size_) {
-    throw Error(GF_ERR_OUT_OF_MEMORY,
-                "maximum_pool_size exceeded: temporal blocks need " +
-                    std::to_string(logical_bytes_) + " bytes > " +
-                    std::to_string(maximum_pool_size_));
-  }
+  delta->bytes_added += b.capacity * kBlockSpace;
+  delta->blocks_added++;
   return b;
 }
 
@@ -267,20 +264,29 @@ void EdgeStore::bump_eids(const int64_t* eids, size_t n) {
     }
   }
   const uint64_t dense = eid_dense_.size();
-  for (size_t i = 0; i < n; ++i) {
-    const int64_t e = eids[i];
-    if (e >= 0 && static_cast<uint64_t>(e) < dense) {
-      if (eid_dense_[e]++ == 0) num_live_eids_++;
-    } else if (eid_sparse_[e]++ == 0) {
-      num_live_eids_++;
+  std::mutex mu;
+  parallel_for(n, 1 << 16, [&](size_t i0, size_t i1) {
+    size_t fresh = 0;
+    std::vector<int64_t> sparse;
+    for (size_t i = i0; i < i1; ++i) {
+      const int64_t e = eids[i];
+      if (e >= 0 && static_cast<uint64_t>(e) < dense) {
+        if (__atomic_fetch_add(&eid_dense_[e], 1u, __ATOMIC_RELAXED) == 0) fresh++;
+      } else {
+        sparse.push_back(e);
+      }
     }
-  }
+    std::lock_guard<std::mutex> lk(mu);
+    num_live_eids_ += fresh;
+    for (int64_t e : sparse)
+      if (eid_sparse_[e]++ == 0) num_live_eids_++;
+  });
   eids_inserted_ += n;
 }
 
 // dynamic_graph.cu:206-287 AddEdgesForOneNode + utils.cu:33-63 CopyEdgesToBlock,
 // replayed on block headers only (the bytes live in the node's flat segment).
-void EdgeStore::simulate_blocks(NodeState& st, const float* ts, size_t n) {
+void EdgeStore::simulate_blocks(NodeState& st, const float* ts, size_t n, BlockDelta* delta) {
   auto copy_to = [&](LogicalBlock& b, size_t start_idx, size_t cnt) {
     b.size += cnt;
     b.start_ts = std::min(b.start_ts, ts[start_idx]);
@@ -288,7 +294,7 @@ void EdgeStore::simulate_blocks(NodeState& st, const float* ts, size_t n) {
   };
   size_t num = n, start_idx = 0;
   if (st.num_blocks() == 0) {
-    st.blocks.push_back(new_block(num));           // case 1: empty list
+    st.blocks.push_back(new_block(num, delta));    // case 1: empty list
   } else {
     LogicalBlock& tail = st.blocks.back();
     if (tail.size + num > tail.capacity) {         // case 2: tail overflows
@@ -301,14 +307,12 @@ void EdgeStore::simulate_blocks(NodeState& st, const float* ts, size_t n) {
         }
         size_t avg = st.num_insertions == 0 ? num : st.num_edges / st.num_insertions;
         size_t new_size = adaptive_ ? pow2_ceil(std::max(num, avg)) : num;
-        st.blocks.push_back(new_block(new_size));
+        st.blocks.push_back(new_block(new_size, delta));
       } else {                                     // replace: Reallocate(size + n)
-        logical_bytes_ -= tail.capacity * kBlockSpace;
+        delta->bytes_removed += tail.capacity * kBlockSpace;
         size_t want = tail.size + num;
         tail.capacity = want < minimum_block_size_ ? minimum_block_size_ : want;
-        logical_bytes_ += tail.capacity * kBlockSpace;
-        if (logical_bytes_ > maximum_pool_size_)
-          throw Error(GF_ERR_OUT_OF_MEMORY, "maximum_pool_size exceeded");
+        delta->bytes_added += tail.capacity * kBlockSpace;
       }
     }                                              // case 3: fits in the tail
   }
@@ -325,13 +329,15 @@ void EdgeStore::upload_entries(const std::vector<int64_t>& ids) {
   staging_.reserve(bytes, 0, stream_);
   int64_t* h_ids = pinned_.as<int64_t>();
   NodeEntry* h_ent = reinterpret_cast<NodeEntry*>(h_ids + k);
-  for (size_t i = 0; i < k; ++i) {
-    const NodeState& st = nodes_[ids[i]];
-    h_ids[i] = ids[i];
-    h_ent[i].start = st.seg_start + st.live_off;
-    h_ent[i].size = static_cast<uint32_t>(st.live_size);
-    h_ent[i].reserved = 0;
-  }
+  parallel_for(k, 1 << 15, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; ++i) {
+      const NodeState& st = nodes_[ids[i]];
+      h_ids[i] = ids[i];
+      h_ent[i].start = st.seg_start + st.live_off;
+      h_ent[i].size = static_cast<uint32_t>(st.live_size);
+      h_ent[i].reserved = 0;
+    }
+  });
   GF_HIP(hipMemcpyAsync(staging_.data(), pinned_.data(), bytes, hipMemcpyHostToDevice, stream_));
   int64_t* d_ids = staging_.as<int64_t>();
   NodeEntry* d_ent = reinterpret_cast<NodeEntry*>(d_ids + k);
@@ -374,32 +380,77 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
                           const int64_t* eids, size_t n) {
   GF_REQUIRE(n > 0, "add_edges: empty batch (reference: CHECK_GT(src_nodes.size(), 0))");
   GF_REQUIRE(src && dst && ts && eids, "add_edges: null array");
+  GF_REQUIRE(n < 0xFFFFFFFFull, "add_edges: more than 2^32-1 edges in one call");
   DeviceGuard dg(device_);
   PhaseTimer pt;
 
   int64_t max_node = 0;
-  for (size_t i = 0; i < n; ++i) {
-    GF_REQUIRE(src[i] >= 0 && dst[i] >= 0, "add_edges: negative vertex id");
-    max_node = std::max(max_node, std::max(src[i], dst[i]));
+  {
+    std::mutex mu;
+    bool negative = false;
+    parallel_for(n, 1 << 16, [&](size_t i0, size_t i1) {
+      int64_t m = 0;
+      bool neg = false;
+      for (size_t i = i0; i < i1; ++i) {
+        neg |= (src[i] < 0) | (dst[i] < 0);
+        m = std::max(m, std::max(src[i], dst[i]));
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      max_node = std::max(max_node, m);
+      negative |= neg;
+    });
+    GF_REQUIRE(!negative, "add_edges: negative vertex id");
   }
 
   pt.mark("scan");
   // 1. order by (source, timestamp, input position): the reference groups by
   //    source in input order and stable-sorts each group by timestamp
-  //    (dynamic_graph.cu:105-128, utils.h:16-27).  `perm` is that order, `s_ts` the
-  //    timestamps in it (gathered once, by several threads, so that everything after this
-  //    reads them sequentially), `groups` the runs of equal source.
-  GF_REQUIRE(n < 0xFFFFFFFFull, "add_edges: more than 2^32-1 edges in one call");
+  //    (dynamic_graph.cu:105-128, utils.h:16-27).  `groups` are the runs of equal source in
+  //    that order and `s_ts` the timestamps in it; everything after this works per GROUP.
+  //    Batches worth it are ordered on the device (ingest_sort.hip: radix sort + group table;
+  //    the per-edge permutation then never exists on the host), small ones — the online
+  //    600-edge ingests, where a sort launch chain would cost more than the whole call — by
+  //    the host counting sort.
   struct Group { int64_t v; size_t begin, end; };
-  std::vector<uint32_t> perm(n);
-  std::vector<float> s_ts(n);
   std::vector<Group> groups;
-  {
+  std::vector<uint32_t> perm;        // host path only
+  std::vector<float> s_ts_vec;
+  const float* s_ts = nullptr;
+  static const size_t device_sort_min = [] {
+    const char* v = std::getenv("GNNFLOW_INGEST_DEVICE_SORT_MIN");   // tests: 0 = always
+    return v ? static_cast<size_t>(std::atoll(v)) : (size_t(1) << 17);
+  }();
+  const bool on_device = n >= device_sort_min && n < 0x7FFFFFFFull &&
+                         static_cast<uint64_t>(max_node) < 0xFFFFFFFFull;
+  if (on_device && !sorter_holder_) sorter_holder_.reset(new IngestSorter());
+  IngestSorter* const sorter = sorter_holder_.get();   // only used when on_device
+  if (on_device) {
+    unsigned node_bits = 1;
+    while (node_bits < 32 && (static_cast<uint64_t>(max_node) >> node_bits)) ++node_bits;
+    const size_t G = sorter->order(src, dst, ts, eids, n, node_bits, stream_);
+    pt.mark("dsort");
+    // pinned landing buffers: a pageable D2H of the 40 MB of sorted timestamps alone costs
+    // more than the sort
+    const size_t o_start = align_up(G * 4, 64), o_sts = o_start + align_up((G + 1) * 4, 64);
+    order_pinned_.reserve(o_sts + n * 4);
+    uint32_t* g_src = order_pinned_.as<uint32_t>();
+    uint32_t* g_start = reinterpret_cast<uint32_t*>(order_pinned_.as<char>() + o_start);
+    float* h_sts = reinterpret_cast<float*>(order_pinned_.as<char>() + o_sts);
+    sorter->download(g_src, g_start, h_sts, stream_);
+    g_start[G] = static_cast<uint32_t>(n);
+    s_ts = h_sts;
+    groups.resize(G);
+    parallel_for(G, 1 << 16, [&](size_t g0, size_t g1) {
+      for (size_t g = g0; g < g1; ++g) groups[g] = {static_cast<int64_t>(g_src[g]), g_start[g], g_start[g + 1]};
+    });
+    pt.mark("groups");
+  } else {
+    perm.resize(n);
+    s_ts_vec.resize(n);
+    std::vector<float>& st = s_ts_vec;
     const size_t table_len = static_cast<size_t>(max_node) + 1;
     if (table_len <= 4 * n + (1u << 16)) {
-      // counting sort by source (stable), then fix up unsorted groups by time.  (Threaded
-      // variants — per-thread source ranges, atomics, a two-level bucketed sort — all measured
-      // the same or slower than this plain loop on the GPU box's host: 45-55 ms per 10^7 edges.)
+      // counting sort by source (stable), then fix up unsorted groups by time
       std::vector<uint32_t> head(table_len + 1, 0);
       for (size_t i = 0; i < n; ++i) head[src[i] + 1]++;
       for (size_t v = 0; v < table_len; ++v) head[v + 1] += head[v];
@@ -413,13 +464,13 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
           const size_t a = head[v], b = head[v + 1];
           bool sorted = true;
           for (size_t k = a; k < b; ++k) {
-            s_ts[k] = ts[perm[k]];
-            if (k > a && s_ts[k] < s_ts[k - 1]) sorted = false;
+            st[k] = ts[perm[k]];
+            if (k > a && st[k] < st[k - 1]) sorted = false;
           }
           if (!sorted) {
             std::stable_sort(perm.begin() + a, perm.begin() + b,
                              [&](uint32_t x, uint32_t y) { return ts[x] < ts[y]; });
-            for (size_t k = a; k < b; ++k) s_ts[k] = ts[perm[k]];
+            for (size_t k = a; k < b; ++k) st[k] = ts[perm[k]];
           }
         }
       });
@@ -435,7 +486,7 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
         return x < y;
       });
       parallel_for(n, 1 << 16, [&](size_t k0, size_t k1) {
-        for (size_t k = k0; k < k1; ++k) s_ts[k] = ts[perm[k]];
+        for (size_t k = k0; k < k1; ++k) st[k] = ts[perm[k]];
       });
       for (size_t i = 0; i < n;) {
         const int64_t v = src[perm[i]];
@@ -445,89 +496,123 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
         i = j;
       }
     }
+    s_ts = s_ts_vec.data();
+    pt.mark("sort");
   }
+  const size_t G = groups.size();
 
-  pt.mark("sort");
   // 2. validate before mutating anything: a group's oldest new edge must not be
   //    older than the node's newest stored edge (reference: CHECK_LE ->
   //    abort, utils.cu:42-43; the docstring promises ValueError,
-  //    gnnflow/dynamic_graph.py:99-101).
-  for (const Group& gr : groups) {
-    if (static_cast<size_t>(gr.v) < nodes_.size()) {
-      const NodeState& st = nodes_[gr.v];
-      if (s_ts[gr.begin] < st.last_ts) {
-        throw Error(GF_ERR_TIMESTAMP_ORDER,
-                    "add_edges: vertex " + std::to_string(gr.v) + " got an edge at t=" +
-                        std::to_string(s_ts[gr.begin]) + " older than its newest stored edge t=" +
-                        std::to_string(st.last_ts));
-      }
-      GF_REQUIRE(st.live_size + (gr.end - gr.begin) < 0xFFFFFFFFull,
-                 "add_edges: more than 2^32-1 live edges on one vertex");
-    }
-  }
-
-  // Dry run of everything that can fail later: the logical block bytes the batch adds
-  // (simulate_blocks / new_block, i.e. dynamic_graph.cu:206-287 against the rmm pool limit)
-  // and the pool elements its new segments need (seg_alloc, free lists included).  A batch
-  // that does not fit is rejected HERE — no vertex, counter, block list or allocator state
-  // has been touched yet, so the graph stays exactly as it was.
+  //    gnnflow/dynamic_graph.py:99-101) — and a dry run of everything that can fail later:
+  //    the logical block bytes the batch adds (simulate_blocks / new_block, i.e.
+  //    dynamic_graph.cu:206-287 against the rmm pool limit) and the pool elements its new
+  //    segments need (seg_alloc, free lists included).  A batch that does not fit is rejected
+  //    HERE — no vertex, counter, block list or allocator state has been touched yet, so the
+  //    graph stays exactly as it was.
+  const uint64_t min_phys = pow2_ceil(std::max<size_t>(minimum_block_size_, 1));
   {
-    auto cap_of = [&](size_t s) { return s < minimum_block_size_ ? minimum_block_size_ : s; };
-    const uint64_t min_phys_dry = pow2_ceil(std::max<size_t>(minimum_block_size_, 1));
-    std::vector<size_t> avail(free_lists_.size());
-    for (size_t c = 0; c < free_lists_.size(); ++c) avail[c] = free_lists_[c].size();
+    auto cap_of = [&](size_t x) { return x < minimum_block_size_ ? minimum_block_size_ : x; };
+    std::mutex mu;
     size_t add_bytes = 0;
-    uint64_t extra = 0;
-    for (const Group& gr : groups) {
-      const size_t cnt = gr.end - gr.begin;
-      const NodeState* st =
-          static_cast<size_t>(gr.v) < nodes_.size() ? &nodes_[gr.v] : nullptr;
-      if (!st || st->num_blocks() == 0) {
-        add_bytes += cap_of(cnt) * kBlockSpace;
-      } else {
-        const LogicalBlock& tail = st->blocks.back();
-        if (tail.size + cnt > tail.capacity) {
-          if (insertion_policy_ == GF_INSERTION_POLICY_INSERT) {
-            const size_t num = cnt - (tail.capacity - tail.size);
-            const size_t avg = st->num_insertions == 0 ? num : st->num_edges / st->num_insertions;
-            add_bytes += cap_of(adaptive_ ? pow2_ceil(std::max(num, avg)) : num) * kBlockSpace;
-          } else {
-            add_bytes += (cap_of(tail.size + cnt) - tail.capacity) * kBlockSpace;
+    std::vector<uint64_t> demand(free_lists_.size(), 0);   // new segments per size class
+    std::string first_error;
+    int first_code = GF_OK;
+    size_t first_at = G;
+    parallel_for(G, 1 << 14, [&](size_t g0, size_t g1) {
+      size_t bytes = 0;
+      std::vector<uint64_t> dem(free_lists_.size(), 0);
+      for (size_t g = g0; g < g1; ++g) {
+        const Group& gr = groups[g];
+        const size_t cnt = gr.end - gr.begin;
+        const NodeState* st =
+            static_cast<size_t>(gr.v) < nodes_.size() ? &nodes_[gr.v] : nullptr;
+        if (st) {
+          int code = GF_OK;
+          std::string msg;
+          if (s_ts[gr.begin] < st->last_ts) {
+            code = GF_ERR_TIMESTAMP_ORDER;
+            msg = "add_edges: vertex " + std::to_string(gr.v) + " got an edge at t=" +
+                  std::to_string(s_ts[gr.begin]) + " older than its newest stored edge t=" +
+                  std::to_string(st->last_ts);
+          } else if (st->live_size + cnt >= 0xFFFFFFFFull) {
+            code = GF_ERR_INVALID_ARGUMENT;
+            msg = "add_edges: more than 2^32-1 live edges on one vertex";
+          }
+          if (code != GF_OK) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (g < first_at) { first_at = g; first_code = code; first_error = msg; }
+            continue;
           }
         }
+        if (!st || st->num_blocks() == 0) {
+          bytes += cap_of(cnt) * kBlockSpace;
+        } else {
+          const LogicalBlock& tail = st->blocks.back();
+          if (tail.size + cnt > tail.capacity) {
+            if (insertion_policy_ == GF_INSERTION_POLICY_INSERT) {
+              const size_t num = cnt - (tail.capacity - tail.size);
+              const size_t avg = st->num_insertions == 0 ? num : st->num_edges / st->num_insertions;
+              bytes += cap_of(adaptive_ ? pow2_ceil(std::max(num, avg)) : num) * kBlockSpace;
+            } else {
+              bytes += (cap_of(tail.size + cnt) - tail.capacity) * kBlockSpace;
+            }
+          }
+        }
+        const uint64_t need = (st ? st->live_size : 0) + cnt;
+        if (!st || st->seg_cap == 0 || st->live_off + need > st->seg_cap)
+          dem[log2_exact(pow2_ceil(std::max<uint64_t>(need, min_phys)))]++;
       }
-      const uint64_t need = (st ? st->live_size : 0) + cnt;
-      if (!st || st->seg_cap == 0 || st->live_off + need > st->seg_cap) {
-        const uint64_t cap = pow2_ceil(std::max<uint64_t>(need, min_phys_dry));
-        const size_t cls = static_cast<size_t>(log2_exact(cap));
-        if (cls < avail.size() && avail[cls] > 0) avail[cls]--;
-        else extra += cap;
-      }
-    }
+      std::lock_guard<std::mutex> lk(mu);
+      add_bytes += bytes;
+      for (size_t c = 0; c < dem.size(); ++c) demand[c] += dem[c];
+    });
+    if (first_code != GF_OK) throw Error(first_code, first_error);
     if (logical_bytes_ + add_bytes > maximum_pool_size_) {
       throw Error(GF_ERR_OUT_OF_MEMORY,
                   "maximum_pool_size exceeded: temporal blocks need " +
                       std::to_string(logical_bytes_ + add_bytes) + " bytes > " +
                       std::to_string(maximum_pool_size_) + " (batch rejected, graph unchanged)");
     }
+    uint64_t extra = 0;   // what the free lists cannot serve comes off the bump pointer
+    for (size_t c = 0; c < demand.size(); ++c)
+      if (demand[c] > free_lists_[c].size()) extra += (demand[c] - free_lists_[c].size()) << c;
     ensure_pool(bump_ + extra);   // a failing hipMalloc also surfaces before any mutation
   }
 
   pt.mark("validate");
-  // 3. bookkeeping sets (dynamic_graph.cu:89-103)
+  // 3. bookkeeping sets (dynamic_graph.cu:89-103): several threads, atomic test-and-set on the
+  //    per-vertex bytes / per-edge-id counters; they share nothing with the planning below
+  //    (seen_ / eid counters vs nodes_ and the segment allocator), so big batches update them
+  //    on helper threads meanwhile.
   add_nodes(max_node);
   auto update_sets = [&] {
-    for (size_t i = 0; i < n; ++i) {
-      uint8_t& s = seen_[src[i]];
-      if (!(s & 1)) { s |= 1; num_nodes_++; }
-      if (!(s & 2)) { s |= 2; num_src_nodes_++; }
-      uint8_t& d = seen_[dst[i]];
-      if (!(d & 1)) { d |= 1; num_nodes_++; }
-    }
+    // A locked read-modify-write on a cold line costs ~10x a load, and after the first
+    // batches nearly every vertex has been seen: test with a plain load, set only when a bit
+    // is missing.  Sources are marked once per GROUP (distinct source), not once per edge.
+    std::mutex mu;
+    auto mark = [&](int64_t v, uint8_t bits, size_t* nn, size_t* ns) {
+      uint8_t cur = __atomic_load_n(&seen_[v], __ATOMIC_RELAXED);
+      if ((cur & bits) == bits) return;
+      cur = __atomic_fetch_or(&seen_[v], bits, __ATOMIC_RELAXED);
+      *nn += !(cur & 1);
+      if (bits & 2) *ns += !(cur & 2);
+    };
+    parallel_for(G, 1 << 14, [&](size_t g0, size_t g1) {
+      size_t nn = 0, ns = 0;
+      for (size_t g = g0; g < g1; ++g) mark(groups[g].v, 3, &nn, &ns);
+      std::lock_guard<std::mutex> lk(mu);
+      num_nodes_ += nn;
+      num_src_nodes_ += ns;
+    });
+    parallel_for(n, 1 << 16, [&](size_t i0, size_t i1) {
+      size_t nn = 0, ns = 0;
+      for (size_t i = i0; i < i1; ++i) mark(dst[i], 1, &nn, &ns);
+      std::lock_guard<std::mutex> lk(mu);
+      num_nodes_ += nn;
+    });
     bump_eids(eids, n);
   };
-  // The id sets share nothing with the planning below (seen_ / eid counters vs nodes_ and the
-  // segment allocator), so big batches update them on a helper thread meanwhile.
   struct Joiner {
     std::thread t;
     ~Joiner() { if (t.joinable()) t.join(); }
@@ -536,42 +621,73 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   else update_sets();
 
   pt.mark("sets");
-  // 4. plan: logical blocks, physical segments, per-group destinations
-  std::vector<uint64_t> dest(n);
+  // 4. plan: logical blocks, physical segments, one base destination per group.
+  //    Pass A (parallel over groups — every group is another vertex): replay the block policy
+  //    and decide whether the vertex needs a larger segment.  Pass B (serial, only the groups
+  //    that do): the segment allocator.  Pass C (parallel): bases, live ranges.
+  std::vector<uint64_t> gbase(G);
+  std::vector<uint64_t> newcap(G, 0);
   std::vector<Move> moves;
   std::vector<std::pair<uint64_t, uint64_t>> deferred_free;
-  std::vector<int64_t> touched;
-  touched.reserve(groups.size());
-  const uint64_t min_phys = pow2_ceil(std::max<size_t>(minimum_block_size_, 1));
-  for (const Group& gr : groups) {
-    const size_t cnt = gr.end - gr.begin;
-    NodeState& st = nodes_[gr.v];
-    simulate_blocks(st, s_ts.data() + gr.begin, cnt);
-
-    uint64_t need = st.live_size + cnt;
-    if (st.seg_cap == 0) {
-      st.seg_cap = pow2_ceil(std::max<uint64_t>(need, min_phys));
-      st.seg_start = seg_alloc(st.seg_cap);
-      st.live_off = 0;
-    } else if (st.live_off + need > st.seg_cap) {
-      uint64_t cap = pow2_ceil(std::max<uint64_t>(need, min_phys));
-      uint64_t ns = seg_alloc(cap);
+  std::vector<int64_t> touched(G);
+  {
+    std::mutex mu;
+    size_t d_bytes_pos = 0, d_bytes_neg = 0, d_blocks = 0;
+    parallel_for(G, 1 << 13, [&](size_t g0, size_t g1) {
+      BlockDelta delta;
+      for (size_t g = g0; g < g1; ++g) {
+        const Group& gr = groups[g];
+        const size_t cnt = gr.end - gr.begin;
+        NodeState& st = nodes_[gr.v];
+        simulate_blocks(st, s_ts + gr.begin, cnt, &delta);
+        const uint64_t need = st.live_size + cnt;
+        if (st.seg_cap == 0 || st.live_off + need > st.seg_cap)
+          newcap[g] = pow2_ceil(std::max<uint64_t>(need, min_phys));
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      d_bytes_pos += delta.bytes_added;
+      d_bytes_neg += delta.bytes_removed;
+      d_blocks += delta.blocks_added;
+    });
+    logical_bytes_ += d_bytes_pos;
+    logical_bytes_ -= d_bytes_neg;
+    logical_blocks_ += d_blocks;
+  }
+  pt.mark("planA");
+  for (size_t g = 0; g < G; ++g) {
+    if (!newcap[g]) continue;
+    NodeState& st = nodes_[groups[g].v];
+    const uint64_t ns = seg_alloc(newcap[g]);
+    if (st.seg_cap) {
       if (st.live_size) moves.push_back({st.seg_start + st.live_off, ns, st.live_size});
       deferred_free.emplace_back(st.seg_start, st.seg_cap);
-      st.seg_start = ns;
-      st.seg_cap = cap;
-      st.live_off = 0;
     }
-    uint64_t base = st.seg_start + st.live_off + st.live_size;
-    for (size_t k = 0; k < cnt; ++k) dest[gr.begin + k] = base + k;
-    st.live_size = need;
-    st.last_ts = s_ts[gr.end - 1];
-    touched.push_back(gr.v);
+    st.seg_start = ns;
+    st.seg_cap = newcap[g];
+    st.live_off = 0;
   }
-  ensure_pool(bump_);
+  pt.mark("planB");
+  std::vector<uint64_t> dest;          // host path: per-edge destinations for the staging copy
+  if (!on_device) dest.resize(n);
+  parallel_for(G, 1 << 13, [&](size_t g0, size_t g1) {
+    for (size_t g = g0; g < g1; ++g) {
+      const Group& gr = groups[g];
+      const size_t cnt = gr.end - gr.begin;
+      NodeState& st = nodes_[gr.v];
+      const uint64_t base = st.seg_start + st.live_off + st.live_size;
+      gbase[g] = base;
+      if (!on_device)
+        for (size_t k = 0; k < cnt; ++k) dest[gr.begin + k] = base + k;
+      st.live_size += cnt;
+      st.last_ts = s_ts[gr.end - 1];
+      touched[g] = gr.v;
+    }
+  });
+  GF_REQUIRE(bump_ <= pool_elems_, "add_edges: internal error: pool smaller than planned");
+  pt.mark("planC");
   if (sets_thread.t.joinable()) sets_thread.t.join();
 
-  pt.mark("plan");
+  pt.mark("join");
   // 5. device: relocate grown segments, then scatter the batch, then publish entries
   if (!moves.empty()) {
     size_t bytes = moves.size() * sizeof(MoveDesc);
@@ -585,35 +701,40 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     GF_HIP(hipGetLastError());
     GF_HIP(hipStreamSynchronize(stream_));  // staging is reused below
   }
-  for (size_t off = 0; off < n; off += kIngestChunk) {
-    size_t m = std::min(kIngestChunk, n - off);
-    size_t o_dst = m * sizeof(uint64_t), o_eid = o_dst + m * sizeof(int64_t),
-           o_ts = o_eid + m * sizeof(int64_t), bytes = o_ts + m * sizeof(float);
-    pinned_.reserve(bytes);
-    staging_.reserve(bytes, 0, stream_);
-    char* h = pinned_.as<char>();
-    uint64_t* h_dest = reinterpret_cast<uint64_t*>(h);
-    int64_t* h_dst = reinterpret_cast<int64_t*>(h + o_dst);
-    int64_t* h_eid = reinterpret_cast<int64_t*>(h + o_eid);
-    float* h_ts = reinterpret_cast<float*>(h + o_ts);
-    parallel_for(m, 1 << 16, [&](size_t k0, size_t k1) {
-      for (size_t k = k0; k < k1; ++k) {
-        const size_t p = perm[off + k];
-        h_dest[k] = dest[off + k];
-        h_dst[k] = dst[p];
-        h_eid[k] = eids[p];
-        h_ts[k] = s_ts[off + k];
-      }
-    });
-    GF_HIP(hipMemcpyAsync(staging_.data(), h, bytes, hipMemcpyHostToDevice, stream_));
-    char* d = staging_.as<char>();
-    unsigned grid = static_cast<unsigned>(std::min<size_t>((m + 255) / 256, 8192));
-    scatter_edges_kernel<<<dim3(grid), dim3(256), 0, stream_>>>(
-        reinterpret_cast<uint64_t*>(d), reinterpret_cast<int64_t*>(d + o_dst),
-        reinterpret_cast<int64_t*>(d + o_eid), reinterpret_cast<float*>(d + o_ts), m,
-        ts_pool_.as<float>(), nbr_pool_.as<EdgePair>());
-    GF_HIP(hipGetLastError());
-    GF_HIP(hipStreamSynchronize(stream_));  // the pinned chunk is refilled next
+  if (on_device) {
+    sorter->scatter(gbase.data(), ts_pool_.as<float>(), nbr_pool_.as<EdgePair>(), stream_);
+    GF_HIP(hipStreamSynchronize(stream_));   // gbase is a host vector
+  } else {
+    for (size_t off = 0; off < n; off += kIngestChunk) {
+      size_t m = std::min(kIngestChunk, n - off);
+      size_t o_dst = m * sizeof(uint64_t), o_eid = o_dst + m * sizeof(int64_t),
+             o_ts = o_eid + m * sizeof(int64_t), bytes = o_ts + m * sizeof(float);
+      pinned_.reserve(bytes);
+      staging_.reserve(bytes, 0, stream_);
+      char* h = pinned_.as<char>();
+      uint64_t* h_dest = reinterpret_cast<uint64_t*>(h);
+      int64_t* h_dst = reinterpret_cast<int64_t*>(h + o_dst);
+      int64_t* h_eid = reinterpret_cast<int64_t*>(h + o_eid);
+      float* h_ts = reinterpret_cast<float*>(h + o_ts);
+      parallel_for(m, 1 << 16, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
+          const size_t p = perm[off + k];
+          h_dest[k] = dest[off + k];
+          h_dst[k] = dst[p];
+          h_eid[k] = eids[p];
+          h_ts[k] = s_ts[off + k];
+        }
+      });
+      GF_HIP(hipMemcpyAsync(staging_.data(), h, bytes, hipMemcpyHostToDevice, stream_));
+      char* d = staging_.as<char>();
+      unsigned grid = static_cast<unsigned>(std::min<size_t>((m + 255) / 256, 8192));
+      scatter_edges_kernel<<<dim3(grid), dim3(256), 0, stream_>>>(
+          reinterpret_cast<uint64_t*>(d), reinterpret_cast<int64_t*>(d + o_dst),
+          reinterpret_cast<int64_t*>(d + o_eid), reinterpret_cast<float*>(d + o_ts), m,
+          ts_pool_.as<float>(), nbr_pool_.as<EdgePair>());
+      GF_HIP(hipGetLastError());
+      GF_HIP(hipStreamSynchronize(stream_));  // the pinned chunk is refilled next
+    }
   }
   pt.mark("device");
   for (auto& f : deferred_free) seg_free(f.first, f.second);

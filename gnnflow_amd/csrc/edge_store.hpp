@@ -18,12 +18,15 @@
 
 #include <cstdint>
 #include <limits>
+#include <memory>
 #include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
 
 namespace gf {
+
+class IngestSorter;   // ingest_sort.hpp
 
 struct NodeEntry {   // device node table entry, 16 B
   uint64_t start;    // first live element in the pools
@@ -106,8 +109,9 @@ class EdgeStore {
   uint64_t seg_alloc(uint64_t cap);
   void seg_free(uint64_t start, uint64_t cap);
   void ensure_pool(uint64_t elems);
-  void simulate_blocks(NodeState& st, const float* ts, size_t n);
-  LogicalBlock new_block(size_t size);
+  struct BlockDelta { size_t bytes_added = 0, bytes_removed = 0, blocks_added = 0; };
+  void simulate_blocks(NodeState& st, const float* ts, size_t n, BlockDelta* delta);
+  LogicalBlock new_block(size_t size, BlockDelta* delta);
   void upload_entries(const std::vector<int64_t>& ids);
 
   // config
@@ -124,8 +128,10 @@ class EdgeStore {
   uint64_t pool_elems_ = 0;   // capacity of the pools, in elements
   uint64_t bump_ = 0;         // high-water mark of the segment allocator
   uint64_t table_cap_ = 0;    // entries allocated in table_
+  std::unique_ptr<IngestSorter> sorter_holder_;   // device-side ordering of large batches
   DeviceBuffer staging_;      // ingest staging (device)
   PinnedBuffer pinned_;       // ingest staging (host)
+  PinnedBuffer order_pinned_; // device-ordered batch: group table + sorted timestamps (host)
 
   // host state
   std::vector<NodeState> nodes_;
