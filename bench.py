@@ -119,6 +119,10 @@ def main():
     import gnnflow_amd
     from gnnflow_amd import _capi, synthetic
     from gnnflow_amd.cache import LRUCache
+    from gnnflow_amd.utils import bind_to_device_cpus
+    # one process per GPU, on the CPUs of that GPU's NUMA node (the launches are issued from
+    # there; gnnflow_amd/utils.py).  The CPU baseline below runs inside the same mask.
+    bound = bind_to_device_cpus(local_rank)
 
     lib = _capi.load()
     fanouts = [int(x) for x in args.fanouts.split(",")]
@@ -269,6 +273,7 @@ def main():
             "pipelined": bool(pipelined),
             "pipeline_depth": pipe.depth if pipelined else 0,
             "workload_key": workload_key(args, repeats),
+            "cpus_bound_to_gpu_node": len(bound) if bound else None,
         },
     }
     if cache is not None and g_n.value:

@@ -4,6 +4,7 @@
 #include <condition_variable>
 #include <deque>
 #include <atomic>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -109,9 +110,19 @@ namespace {
 class EnqueueWorker {
  public:
   using Job = std::function<void()>;
-  static EnqueueWorker& get() {
-    static EnqueueWorker* w = new EnqueueWorker();   // intentionally leaked: no exit-order issues
-    return *w;
+  // lane 0: feature fetches, lane 1: sampling.  Two issuers by default: the sampling launches
+  // (side stream) and the fetch launches (caller's stream) of a pipelined step go to different
+  // HIP queues, and one thread issuing all 8 is the step's bottleneck whenever the host is
+  // busy; GNNFLOW_ENQUEUE_LANES=1 puts both on one thread.
+  static EnqueueWorker& get(int lane = 0) {
+    static const bool two = [] {
+      const char* v = std::getenv("GNNFLOW_ENQUEUE_LANES");
+      return !(v && std::atoi(v) == 1);
+    }();
+    static EnqueueWorker* w0 = new EnqueueWorker();   // intentionally leaked: no exit-order issues
+    if (lane == 0 || !two) return *w0;
+    static EnqueueWorker* w1 = new EnqueueWorker();
+    return *w1;
   }
   uint64_t submit(Job&& job) {
     bool wake;
@@ -376,7 +387,7 @@ int gf_sampler_sample_begin_async(gf_sampler* s, const int64_t* d_roots, const f
                "sample_begin_async: too many samples in flight on this sampler");
     gf::Sampler* impl = &s->impl;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    s->begin_tickets.push_back(gf::EnqueueWorker::get().submit(
+    s->begin_tickets.push_back(gf::EnqueueWorker::get(1).submit(
         [impl, d_roots, d_root_ts, num_roots, d_out, out_bytes, st]() {
           impl->sample_begin(d_roots, d_root_ts, num_roots, d_out, out_bytes, st);
         }));
@@ -388,7 +399,7 @@ int gf_sampler_sample_end(gf_sampler* s, gf_block* blocks) {
     s->begin_tickets.pop_front();
     if (t) {   // begun through the enqueue thread: wait for the enqueue of THIS sample
       std::string err;
-      const int rc = gf::EnqueueWorker::get().wait(t, &err);
+      const int rc = gf::EnqueueWorker::get(1).wait(t, &err);
       if (rc != GF_OK) { gf::set_last_error(err); return rc; }
     }
   }
@@ -549,7 +560,14 @@ int gf_memory_update(float* d_node_memory, float* d_node_memory_ts, float* d_mai
 int gf_worker_stats(double* busy_us, uint64_t* jobs) {
   return guarded([&] {
     GF_REQUIRE(busy_us && jobs, "gf_worker_stats: null output");
-    gf::EnqueueWorker::get().stats(busy_us, jobs);
+    gf::EnqueueWorker::get(0).stats(busy_us, jobs);
+    double b1 = 0;
+    uint64_t j1 = 0;
+    if (&gf::EnqueueWorker::get(1) != &gf::EnqueueWorker::get(0)) {
+      gf::EnqueueWorker::get(1).stats(&b1, &j1);
+      *busy_us += b1;
+      *jobs += j1;
+    }
   });
 }
 int gf_gather_rows(const float* d_feats, size_t num_rows, size_t dim, const int64_t* d_ids,
@@ -669,7 +687,7 @@ int gf_sampler_sample_partitioned_async(gf_sampler* s, const int64_t* d_roots,
                "sample_partitioned_async: too many samples in flight on this sampler");
     gf::Sampler* impl = &s->impl;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    s->begin_tickets.push_back(gf::EnqueueWorker::get().submit(
+    s->begin_tickets.push_back(gf::EnqueueWorker::get(1).submit(
         [impl, d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws, ws_bytes, st]() {
           impl->sample_partitioned(d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws,
                                    ws_bytes, st);
