@@ -433,7 +433,7 @@ class Cache:
         dev = self.device
         upd = 1 if update_cache else 0
         with torch.cuda.device(dev):
-            n_node = sum(len(mfgs[0]) for _ in (0,)) if self._node is not None else 0
+            n_node = len(mfgs[0]) if self._node is not None else 0
             n_edge = sum(len(mfg) for mfg in mfgs) if self._edge is not None else 0
             pos = self._stats_rows(n_node + n_edge)
             ring = self._stats_ring
@@ -445,7 +445,6 @@ class Cache:
                                              ring.data_ptr() + 64 * (pos + k))
                     b.srcdata['h'] = out
                     k += 1
-            empty_edge_blocks = 0
             if self._edge is not None:
                 for mfg in mfgs:
                     for b in mfg:
@@ -455,7 +454,6 @@ class Cache:
                             keys = self._ids(b.srcdata['ID'])[b.edges()[1]]
                         else:
                             keys = ids
-                            empty_edge_blocks += 1
                         out = self._fetch_pulled(self._edge, self._shards.edge, ids, keys, upd,
                                                  ring.data_ptr() + 64 * (pos + k))
                         if ids.shape[0]:
@@ -472,7 +470,6 @@ class Cache:
                     self._target_edge_thunk = None
                     self._target_edge_features = self._shards.edge.pull(t, nid)
             self._stats_span = (pos, n_node, n_node + n_edge, ring, 0)
-            self._empty_stat_rows = empty_edge_blocks
         return mfgs
 
     def _id_array(self, b, which):
@@ -490,8 +487,7 @@ class Cache:
         for job in jobs:
             offs.append(total)
             total += (job[2] * job[4] + 3) & ~3
-        out_all = self._out_buffer(total)
-        out_ptr = out_all.data_ptr()
+        out_all, out_base, out_ptr = self._out_buffer(total)
         stats_pos = self._stats_rows(n_cached)
         stats_ptr = self._stats_ring.data_ptr() + 64 * stats_pos
         nj = len(jobs)
@@ -503,7 +499,7 @@ class Cache:
             pack(descs, i * _DESC.size, kind, upd, ids_ptr or 0, n, out_ptr + 4 * off,
                  stats_ptr + 64 * i if (kind != 2 and n) else 0)
 
-            def rows(off=off, n=n, dim=dim, sync=async_enqueue):
+            def rows(off=out_base + off, n=n, dim=dim, sync=async_enqueue):
                 if sync:
                     self.wait_enqueued()
                 return out_all[off:off + n * dim].view(n, dim)
@@ -515,7 +511,8 @@ class Cache:
             else:
                 (b.srcdata if which == "src" else b.edata)[key] = rows(sync=False)
         for b, owner, n in aliases:
-            def prefix_rows(off=offs[owner], n=n, dim=jobs[owner][4], sync=async_enqueue):
+            def prefix_rows(off=out_base + offs[owner], n=n, dim=jobs[owner][4],
+                            sync=async_enqueue):
                 if sync:
                     self.wait_enqueued()
                 return out_all[off:off + n * dim].view(n, dim)
@@ -538,15 +535,14 @@ class Cache:
         return mfgs
 
     def _out_buffer(self, total):
-        """Output rows of one fetch_feature() call.  Carved out of a slab that is allocated
+        """Output rows of one fetch_feature() call: (slab tensor, first float of this call's
+        share, its device address).  Carved out of a slab that is allocated
         once per 8 calls with a power-of-two size per call: block sizes differ from batch to
         batch, and a fresh `torch.empty` of a never-seen size is a real hipMalloc in the
         caching allocator — during the first replays of a stream those serialised the enqueue
         thread (38 us of launch work per step instead of 26).  Uniform slabs are recycled by
         the allocator as soon as the MFGs of an old slab are gone; a slab is never reused
         while any of its views is alive."""
-        if os.environ.get("GNNFLOW_OUT_SLAB", "1") == "0":
-            return torch.empty(total, dtype=torch.float32, device=self.device)
         slab = getattr(self, "_out_slab", None)
         if slab is None or total > slab[1] or slab[2] >= slab[3]:
             cap = 1 << max(int(total - 1).bit_length(), 16)
@@ -554,10 +550,11 @@ class Cache:
                 cap = max(cap, slab[1])
             count = max(1, min(8, (1 << 28) // cap))        # at most 1 GiB of floats per slab
             mem = torch.empty(cap * count, dtype=torch.float32, device=self.device)
-            slab = self._out_slab = [mem, cap, 0, count]
+            slab = self._out_slab = [mem, cap, 0, count, mem.data_ptr()]
         i = slab[2]
         slab[2] = i + 1
-        return slab[0][i * slab[1]: i * slab[1] + total]
+        base = i * slab[1]
+        return slab[0], base, slab[4] + 4 * base
 
     def _desc_buf(self, n):
         """A fresh descriptor array from a small ring (the previous call's array may still be

@@ -383,19 +383,20 @@ class DevicePartitionedSampler:
             n = C.c_size_t(0)
             check(lib.gf_sampler_output_bytes(smp._h, max(R, 1), C.byref(n)))
             nbytes = smp._bytes_cache[max(R, 1)] = n.value
-        buf, marks = smp._output_buffer(nbytes, stream)
+        slab, off = smp._output_buffer(nbytes, stream)
+        out_ptr = slab[5] + off
         ws = self._workspace(ws_bytes, stream)
-        sptr = C.c_void_p(stream.cuda_stream)
+        sptr = slab[6]
         if P == 1:
             call = lib.gf_sampler_sample_partitioned_async if worker_enqueue \
                 else lib.gf_sampler_sample_partitioned
             check(call(smp._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
-                       buf.data_ptr(), nbytes, ws.data_ptr(), ws_bytes, sptr))
+                       out_ptr, nbytes, ws.data_ptr(), ws_bytes, sptr))
         else:
             with torch.cuda.stream(stream):
                 check(lib.gf_sampler_part_begin(
                     smp._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
-                    buf.data_ptr(), nbytes, P, me, sptr))
+                    out_ptr, nbytes, P, me, sptr))
                 try:
                     for layer in range(self._L):
                         for s in range(self._S):
@@ -405,7 +406,7 @@ class DevicePartitionedSampler:
                     lib.gf_sampler_part_abort(smp._h)
                     raise
         # R = 0 still yields real (empty) blocks whose sizes come from the device
-        pending = PendingSample(smp, buf, (nodes, ts, ws), max(R, 1), marks)
+        pending = PendingSample(smp, slab, (nodes, ts, ws), max(R, 1), None)
         smp._inflight.append(pending)
         return pending
 

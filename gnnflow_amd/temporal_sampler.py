@@ -140,11 +140,14 @@ class TemporalSampler:
             "target_vertices and timestamps must be 1D and of equal length"
         return nodes, ts
 
-    def _block(self, buf, gb, marks=None) -> MFGBlock:
-        """MFG over one gf_block; the tensor views into `buf` are built on first access."""
+    def _block(self, buf, gb, marks=None, base=None) -> MFGBlock:
+        """MFG over one gf_block; the tensor views into `buf` (the output buffer, or the slab
+        it was carved from, whose address is `base`) are built on first access."""
         if gb.all_nodes is None:
             raise RuntimeError("sampler returned a null block")
-        base, device = buf.data_ptr(), self._device
+        device = self._device
+        if base is None:
+            base = buf.data_ptr()
 
         def view(ptr, count, dtype, itemsize):
             if count == 0:
@@ -196,51 +199,62 @@ class TemporalSampler:
             stream = torch.cuda.current_stream(self._device)
         nodes, ts = self._to_device(target_vertices, timestamps, stream)
         R = int(nodes.shape[0])
-        buf, nbytes, marks = None, 0, None
+        slab = None
         if R:
             nbytes = self._bytes_cache.get(R)
             if nbytes is None:
                 n = C.c_size_t(0)
                 _capi.check(self._lib.gf_sampler_output_bytes(self._h, R, C.byref(n)))
                 nbytes = self._bytes_cache[R] = n.value
-            buf, marks = self._output_buffer(nbytes, stream)
-        begin = self._lib.gf_sampler_sample_begin_async if worker_enqueue \
-            else self._lib.gf_sampler_sample_begin
-        _capi.check(begin(
-            self._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
-            buf.data_ptr() if R else None, nbytes, C.c_void_p(stream.cuda_stream)))
-        pending = PendingSample(self, buf, (nodes, ts), R, marks)
+            slab, off = self._output_buffer(nbytes, stream)
+            begin = self._lib.gf_sampler_sample_begin_async if worker_enqueue \
+                else self._lib.gf_sampler_sample_begin
+            rc = begin(self._h, nodes.data_ptr(), ts.data_ptr(), R, slab[5] + off, nbytes, slab[6])
+        else:
+            begin = self._lib.gf_sampler_sample_begin_async if worker_enqueue \
+                else self._lib.gf_sampler_sample_begin
+            rc = begin(self._h, None, None, 0, None, 0, C.c_void_p(stream.cuda_stream))
+        if rc:
+            _capi.check(rc)
+        pending = PendingSample(self, slab, (nodes, ts), R, None)
         self._inflight.append(pending)
         return pending
 
     def _output_buffer(self, nbytes, stream):
-        """Output memory for one sample(), owned by `stream` in the caching allocator.
-        Small outputs are carved out of a slab that is allocated once per 16 calls:
-        switching torch's current stream for a torch.empty costs more host time than a
-        batch-600 sampling kernel runs."""
+        """Output memory for one sample(), owned by `stream` in the caching allocator: a slab
+        record [tensor, stream, step, used, stream marks, address, stream handle] and the byte
+        offset of this call's share.  Small outputs share a slab that is allocated once per 16
+        calls (switching torch's current stream for a torch.empty costs more host time than a
+        batch-600 sampling kernel runs); no per-call tensor is created — the blocks' views are
+        cut out of the slab when they are first read."""
         per_slab = min(16, (32 << 20) // max(nbytes, 1))
-        if per_slab < 2:
-            with torch.cuda.stream(stream):
-                return torch.empty(nbytes, dtype=torch.uint8, device=self._device), set()
         step = (nbytes + 255) & ~255
+        if per_slab < 2:
+            per_slab, step = 1, nbytes
         slab = self._slab
         if slab is None or slab[1] != stream or slab[2] != step or slab[3] >= per_slab:
             with torch.cuda.stream(stream):
                 mem = torch.empty(step * per_slab, dtype=torch.uint8, device=self._device)
             # slab[4]: streams already told (record_stream) that they use this allocation
-            slab = self._slab = [mem, stream, step, 0, set()]
+            slab = self._slab = [mem, stream, step, 0, set(), mem.data_ptr(),
+                                 C.c_void_p(stream.cuda_stream)]
         i = slab[3]
         slab[3] = i + 1
-        return slab[0][i * step:i * step + nbytes], slab[4]
+        return slab, i * step
 
     def _finish(self, buf, R, marks=None) -> List[List[MFGBlock]]:
         blocks = self._gf_blocks
-        _capi.check(self._lib.gf_sampler_sample_end(self._h, blocks))
+        rc = self._lib.gf_sampler_sample_end(self._h, blocks)
+        if rc:
+            _capi.check(rc)
         if R == 0:
             return [[self._empty_block() for _ in range(self._num_snapshots)]
                     for _ in range(self._num_layers)]
         ns = self._num_snapshots
-        mfgs = [[self._block(buf, blocks[layer * ns + s], marks) for s in range(ns)]
+        base = None
+        if isinstance(buf, list):          # a slab record of _output_buffer
+            buf, marks, base = buf[0], buf[4], buf[5]
+        mfgs = [[self._block(buf, blocks[layer * ns + s], marks, base) for s in range(ns)]
                 for layer in range(self._num_layers)]
         if self._strategy == "recent":
             # Layer l+1's roots start with layer l's roots (all_nodes = roots ++ neighbours,

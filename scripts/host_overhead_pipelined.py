@@ -14,30 +14,35 @@ sampler = gnnflow_amd.TemporalSampler(graph, [10, 10])
 ef = torch.rand((g["num_edges"], 172), device=dev); nf = torch.rand((g["num_nodes"], 172), device=dev)
 cache = LRUCache(0.2, 0.2, g["num_nodes"], g["num_edges"], dev, nf, ef, 172, 172); cache.init_cache()
 batches = [(torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev), torch.from_numpy(e).to(dev))
-           for r, t, e in list(synthetic.replay_batches(g, 600))[400:1000]]
+           for r, t, e in list(synthetic.replay_batches(g, 600))]
 side = torch.cuda.Stream(device=dev); main = torch.cuda.current_stream(dev)
+from collections import deque
 T = dict(wait=0.0, begin=0.0, rec=0.0, fetch=0.0, wq=0.0)
 orig_wait = cache.wait_enqueued
 def timed_wait():
     t0 = time.perf_counter(); orig_wait(); T["wq"] += time.perf_counter() - t0
 cache.wait_enqueued = timed_wait
-for rep in range(2):
+DEPTH = 2
+for rep in range(3):
     for k in T: T[k] = 0.0
+    cache.init_cache()
     torch.cuda.synchronize(); t00 = time.perf_counter()
-    pending = sampler.sample_async(batches[0][0], batches[0][1], stream=side, worker_enqueue=True)
+    pending = deque(); nxt = 0
+    while nxt < len(batches) and len(pending) < DEPTH:
+        pending.append(sampler.sample_async(batches[nxt][0], batches[nxt][1], stream=side, worker_enqueue=True)); nxt += 1
     for i in range(len(batches)):
-        t0 = time.perf_counter(); mfgs = pending.wait(); T["wait"] += time.perf_counter() - t0
-        if i + 1 < len(batches):
-            t0 = time.perf_counter(); pending = sampler.sample_async(batches[i+1][0], batches[i+1][1], stream=side, worker_enqueue=True); T["begin"] += time.perf_counter() - t0
+        t0 = time.perf_counter(); mfgs = pending.popleft().wait(); T["wait"] += time.perf_counter() - t0
+        if nxt < len(batches):
+            t0 = time.perf_counter(); pending.append(sampler.sample_async(batches[nxt][0], batches[nxt][1], stream=side, worker_enqueue=True)); nxt += 1; T["begin"] += time.perf_counter() - t0
         t0 = time.perf_counter()
         for mfg in mfgs:
             for b in mfg: b.record_stream(main)
         T["rec"] += time.perf_counter() - t0
         t0 = time.perf_counter(); cache.fetch_feature(mfgs, batches[i][2], async_enqueue=True); T["fetch"] += time.perf_counter() - t0
     cache.wait_enqueued(); torch.cuda.synchronize(); tot = time.perf_counter() - t00
-n = len(batches)
+    n = len(batches)
+    print("per step us: total %.1f | sample.wait %.1f | sample_async %.1f | record_stream %.1f | fetch_feature %.1f (of which wait_enqueued %.1f)" % (
+        1e6*tot/n, 1e6*T["wait"]/n, 1e6*T["begin"]/n, 1e6*T["rec"]/n, 1e6*T["fetch"]/n, 1e6*T["wq"]/n))
 import ctypes as C
 lib = _capi.load(); bu, jb = C.c_double(0), C.c_uint64(0); lib.gf_worker_stats(C.byref(bu), C.byref(jb))
-print("worker: %.1f us busy per job over %d jobs (all reps)" % (bu.value / max(jb.value, 1), jb.value))
-print("per step us: total %.1f | sample.wait %.1f | sample_async %.1f | record_stream %.1f | fetch_feature %.1f (of which wait_enqueued %.1f)" % (
-    1e6*tot/n, 1e6*T["wait"]/n, 1e6*T["begin"]/n, 1e6*T["rec"]/n, 1e6*T["fetch"]/n, 1e6*T["wq"]/n))
+print("workers: %.1f us busy per job over %d jobs (all reps, both lanes)" % (bu.value / max(jb.value, 1), jb.value))
