@@ -13,6 +13,7 @@
 #include "common.hpp"
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace gf {
 namespace {
@@ -123,6 +124,120 @@ __global__ __launch_bounds__(kTileThreads) void partition_scatter_kernel(
   pos[i] = p;
 }
 
+// Small layers (<= 30 720 roots, <= 16 owners): the whole plan in ONE launch of one
+// workgroup — three launches and two kernel boundaries less than the tiled form, which at
+// batch-600 sizes is most of its time.  One CU has to touch every root, so every global access
+// is coalesced and everything per-root lives in LDS (one uint16 per root):
+//   1. thread t hashes roots t, t + 1024, ... (coalesced loads, all issued up front) and
+//      stores the owners in LDS;
+//   2. thread t counts the owners of the CONTIGUOUS roots [t*c, (t+1)*c) — contiguous chunks
+//      keep every owner's roots in their original order — in 16-bit fields packed four to a
+//      64-bit word; one workgroup scan per word gives its base inside every owner's run;
+//   3. it walks its chunk again and replaces each owner in LDS by the root's output row;
+//   4. coalesced again: root i's id / timestamp go to requests[row_i], pos[i] = row_i.
+constexpr int kSmallPlanThreads = 1024;
+constexpr uint32_t kSmallPlanRoots = 30 * 1024;
+constexpr uint32_t kSmallPlanParts = 16;
+constexpr uint32_t kSmallPlanLaunchRoots = 4096;   // largest layer that takes this path
+
+__global__ __launch_bounds__(kSmallPlanThreads) void partition_plan_small_kernel(
+    const int64_t* __restrict__ nodes, const float* __restrict__ ts,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t P, uint32_t rank,
+    int64_t* __restrict__ requests, uint32_t* __restrict__ pos, uint64_t* __restrict__ counts) {
+  __shared__ uint16_t per_root[kSmallPlanRoots];   // owner, then output row
+  __shared__ unsigned long long wave_tot[kSmallPlanParts / 4][kSmallPlanThreads / 64];
+  __shared__ uint32_t start_s[kSmallPlanParts];
+  const uint32_t R = static_cast<uint32_t>(d_R ? *d_R : R_host);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr uint32_t kRounds = kSmallPlanRoots / kSmallPlanThreads;
+  // 1. owners, coalesced
+  {
+    int64_t v[kRounds];
+#pragma unroll
+    for (uint32_t k = 0; k < kRounds; ++k) {
+      const uint32_t i = k * kSmallPlanThreads + tid;
+      v[k] = i < R ? nodes[i] : 0;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kRounds; ++k) {
+      const uint32_t i = k * kSmallPlanThreads + tid;
+      if (i < R) per_root[i] = static_cast<uint16_t>(owner_of(v[k], P));
+    }
+  }
+  __syncthreads();
+  // 2. per-thread counts over its contiguous chunk, packed; workgroup scan
+  const uint32_t c = (R + kSmallPlanThreads - 1) / kSmallPlanThreads;
+  const uint32_t i0 = min(R, tid * c), i1 = min(R, i0 + c);
+  const uint32_t words = (P + 3) / 4;
+  unsigned long long w[kSmallPlanParts / 4] = {0, 0, 0, 0};
+  for (uint32_t i = i0; i < i1; ++i) {
+    const uint32_t o = per_root[i];
+    const unsigned long long inc = 1ull << (16 * (o & 3));
+#pragma unroll
+    for (uint32_t j = 0; j < kSmallPlanParts / 4; ++j) w[j] += (o >> 2) == j ? inc : 0ull;
+  }
+  unsigned long long excl[kSmallPlanParts / 4], total[kSmallPlanParts / 4];
+  for (uint32_t j = 0; j < words; ++j) {
+    unsigned long long incl = w[j];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_tot[j][wave] = incl;
+    excl[j] = incl - w[j];
+  }
+  __syncthreads();
+  for (uint32_t j = 0; j < words; ++j) {
+    unsigned long long base = 0, tot = 0;
+    for (int x = 0; x < kSmallPlanThreads / 64; ++x) {
+      const unsigned long long v = wave_tot[j][x];
+      if (x < wave) base += v;
+      tot += v;
+    }
+    excl[j] += base;
+    total[j] = tot;
+  }
+  if (tid == 0) {
+    uint32_t at = 0;
+    for (uint32_t o = 0; o < P; ++o) {
+      const uint32_t n = static_cast<uint32_t>((total[o >> 2] >> (16 * (o & 3))) & 0xFFFFu);
+      counts[o] = n;
+      if (o != rank) { start_s[o] = at; at += n; }
+    }
+    start_s[rank] = at;
+  }
+  __syncthreads();
+  // 3. output row of every root of the chunk (in place of its owner)
+  unsigned long long seen[kSmallPlanParts / 4] = {0, 0, 0, 0};
+  for (uint32_t i = i0; i < i1; ++i) {
+    const uint32_t o = per_root[i];
+    const uint32_t sh = 16 * (o & 3);
+    unsigned long long e = 0, sn = 0;    // selects, not dynamic indexing: registers, no scratch
+#pragma unroll
+    for (uint32_t j = 0; j < kSmallPlanParts / 4; ++j) {
+      const bool mine = (o >> 2) == j;
+      e = mine ? excl[j] : e;
+      sn = mine ? seen[j] : sn;
+      seen[j] += mine ? (1ull << sh) : 0ull;
+    }
+    per_root[i] = static_cast<uint16_t>(start_s[o] + static_cast<uint32_t>((e >> sh) & 0xFFFFu) +
+                                        static_cast<uint32_t>((sn >> sh) & 0xFFFFu));
+  }
+  __syncthreads();
+  // 4. write-out, coalesced reads
+#pragma unroll
+  for (uint32_t k = 0; k < kRounds; ++k) {
+    const uint32_t i = k * kSmallPlanThreads + tid;
+    if (i < R) {
+      const uint32_t p = per_root[i];
+      requests[2 * static_cast<uint64_t>(p)] = nodes[i];
+      requests[2 * static_cast<uint64_t>(p) + 1] = static_cast<int64_t>(__float_as_uint(ts[i]));
+      pos[i] = p;
+    }
+  }
+}
+
 }  // namespace
 
 size_t partition_scratch_bytes(size_t R, int world_size) {
@@ -148,11 +263,23 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
   GF_REQUIRE(d_nodes && d_ts && d_requests && d_pos && d_scratch, "partition: null pointer");
   GF_REQUIRE(scratch_bytes >= partition_scratch_bytes(R_bound, world_size),
              "partition: scratch buffer too small");
+  const uint32_t P = static_cast<uint32_t>(world_size);
+  static const bool small_plan = [] {
+    const char* v = std::getenv("GNNFLOW_PARTITION_SMALL_PLAN");   // tests: 0 = tiled form only
+    return !(v && std::atoi(v) == 0);
+  }();
+  // one CU has to touch every root: measured 6.5 us at 1 800 roots (the tiled form: ~12) but
+  // 20-40 us at 19 800, so only the first layers of a sample take this path
+  if (small_plan && R_bound <= kSmallPlanLaunchRoots && P <= kSmallPlanParts) {
+    partition_plan_small_kernel<<<dim3(1), dim3(kSmallPlanThreads), 0, stream>>>(
+        d_nodes, d_ts, d_R, R_bound, P, static_cast<uint32_t>(rank), d_requests, d_pos, d_counts);
+    GF_HIP(hipGetLastError());
+    return;
+  }
   const size_t tiles = (R_bound + kTileThreads - 1) / kTileThreads;
   uint32_t* tile_counts = static_cast<uint32_t*>(d_scratch);
   uint32_t* tile_base = reinterpret_cast<uint32_t*>(
       static_cast<char*>(d_scratch) + align_up(tiles * world_size * sizeof(uint32_t), 16));
-  const uint32_t P = static_cast<uint32_t>(world_size);
   partition_count_kernel<<<dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream>>>(
       d_nodes, d_R, R_bound, P, tile_counts);
   partition_scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(tile_counts, tiles, P,

@@ -689,6 +689,110 @@ __global__ __launch_bounds__(kEmitThreads) void merge_emit_kernel(
   }
 }
 
+// Small layers: count + per-workgroup sums in one launch, then an emit that derives its own
+// prefix from them (as sample_emit_prefix_kernel does) — two launches instead of count / scan /
+// emit.  The layer's root count may be device resident and may be 0 (a rank without roots).
+__global__ __launch_bounds__(kEmitThreads) void merge_count_sums_kernel(
+    const int64_t* __restrict__ rep, const uint32_t* __restrict__ pos,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t fanout,
+    uint32_t* __restrict__ rec_cnt, uint32_t* __restrict__ wg_sum) {
+  __shared__ uint32_t red[kEmitThreads / 64];
+  const uint64_t R = d_R ? *d_R : R_host;
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kEmitThreads + threadIdx.x;
+  uint32_t c = 0;
+  if (i < R) {
+    const int64_t* s = rep + static_cast<uint64_t>(pos[i]) * fanout * 3;
+    for (uint32_t j = 0; j < fanout; ++j) c += s[3 * j] >= 0 ? 1u : 0u;
+    rec_cnt[i] = c;
+  }
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < kEmitThreads / 64; ++w) t += red[w];
+    wg_sum[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kEmitThreads) void merge_emit_prefix_kernel(
+    const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t fanout,
+    const int64_t* __restrict__ rep, const uint32_t* __restrict__ pos,
+    const uint32_t* __restrict__ rec_cnt, const uint32_t* __restrict__ wg_sum,
+    int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
+    int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col,
+    uint64_t* out_R, uint64_t* out_S, uint64_t* next_R) {
+  __shared__ uint32_t red[kEmitThreads / 64];
+  __shared__ uint32_t lbase[kEmitThreads];
+  __shared__ uint32_t wave_tot[kEmitThreads / 64];
+  const uint64_t R = d_R ? *d_R : R_host;
+  const uint64_t total = R * fanout;
+  if (total == 0) {   // nobody owns "the last slot": workgroup 0 reports the empty block
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *out_R = 0;
+      *out_S = 0;
+      if (next_R) *next_R = 0;
+    }
+    return;
+  }
+  const uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kEmitThreads;
+  if (t0 >= total) return;   // uniform for the workgroup
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t t_last = min(t0 + kEmitThreads - 1, total - 1);
+  const uint32_t r_first = static_cast<uint32_t>(t0 / fanout);
+  const uint32_t r_last = static_cast<uint32_t>(t_last / fanout);
+  const uint32_t nroots = r_last - r_first + 1;   // <= kEmitThreads
+  const uint32_t b_first = r_first / kEmitThreads;   // count workgroups of kEmitThreads roots
+  uint32_t part = 0;
+  for (uint32_t b = tid; b < b_first; b += kEmitThreads) part += wg_sum[b];
+  for (uint32_t r = b_first * kEmitThreads + tid; r < r_first; r += kEmitThreads) part += rec_cnt[r];
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+  if (lane == 0) red[wave] = part;
+  const uint32_t mine = tid < static_cast<int>(nroots) ? rec_cnt[r_first + tid] : 0u;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+#pragma unroll
+  for (int w = 0; w < kEmitThreads / 64; ++w) base += red[w];
+  uint32_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+  lbase[tid] = base + wbase + incl - mine;
+  __syncthreads();
+  const uint64_t t = t0 + tid;
+  if (t < total) {
+    if (t < R) {
+      all_nodes[t] = roots[t];
+      all_ts[t] = root_ts[t];
+    }
+    const uint32_t r = static_cast<uint32_t>(t / fanout);
+    const uint32_t j = static_cast<uint32_t>(t - static_cast<uint64_t>(r) * fanout);
+    if (j < rec_cnt[r]) {
+      const int64_t* s = rep + (static_cast<uint64_t>(pos[r]) * fanout + j) * 3;
+      const uint64_t packed = static_cast<uint64_t>(s[2]);
+      const uint64_t o = static_cast<uint64_t>(lbase[r - r_first]) + j;
+      all_nodes[R + o] = s[0];
+      all_ts[R + o] = __uint_as_float(static_cast<uint32_t>(packed));
+      dt[o] = __uint_as_float(static_cast<uint32_t>(packed >> 32));
+      eids[o] = s[1];
+      row[o] = static_cast<int64_t>(r);
+      col[o] = static_cast<int64_t>(R + o);
+    }
+  }
+  if (t_last == total - 1 && tid == static_cast<int>(nroots) - 1) {
+    const uint64_t S = static_cast<uint64_t>(lbase[tid]) + mine;
+    *out_R = R;
+    *out_S = S;
+    if (next_R) *next_R = R + S;
+  }
+}
+
 inline unsigned capped_grid(uint64_t work_items, unsigned per_block, unsigned cap) {
   uint64_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -1344,6 +1448,20 @@ void Sampler::part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
     return;
   }
   ProfileScope ps(kProfEmit, stream);
+  if (fused_scan_ && Rb <= kSmallRoots) {
+    // rec_cnt / wg_sum live in the sampler workspace (base is not needed: no scan launch)
+    uint32_t* wg_sum = tile_scratch;
+    const unsigned cgrid = static_cast<unsigned>((Rb + kEmitThreads - 1) / kEmitThreads);
+    merge_count_sums_kernel<<<dim3(cgrid), dim3(kEmitThreads), 0, stream>>>(
+        rep, pos, d_R, R_host, F, rec_cnt, wg_sum);
+    const unsigned egrid = static_cast<unsigned>(
+        (static_cast<uint64_t>(Rb) * F + kEmitThreads - 1) / kEmitThreads);
+    merge_emit_prefix_kernel<<<dim3(egrid), dim3(kEmitThreads), 0, stream>>>(
+        roots, ts, d_R, R_host, F, rep, pos, rec_cnt, wg_sum, out.all_nodes, out.all_ts, out.dt,
+        out.eids, out.row, out.col, slot, slot + 1, next_R);
+    GF_HIP(hipGetLastError());
+    return;
+  }
   merge_count_kernel<<<dim3(static_cast<unsigned>((Rb + 255) / 256)), dim3(256), 0, stream>>>(
       rep, pos, d_R, R_host, F, rec_cnt);
   if (Rb <= 65536) {
