@@ -219,12 +219,20 @@ class Cache:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def slot_ids(self, kind: str) -> np.ndarray:
+        """ids cached per slot (-1: empty) of the 'node' or 'edge' cache, on the host
+        (diagnostics / tests; synchronises)."""
+        self.wait_enqueued()
+        k = self._node if kind == "node" else self._edge
+        return k.slot_ids()
+
     def get_mem_size(self) -> int:
         """Memory size of the cache in bytes (cache.py:136-155)."""
         return sum(k.mem_bytes() for k in (self._node, self._edge) if k is not None)
 
     def init_cache(self, *args, **kwargs):
         """Fill the cache with the first `capacity` rows (cache.py:157-195)."""
+        self.wait_enqueued()      # an asynchronous fetch may still be with the enqueue thread
         if self.distributed:
             return self._init_cache_distributed()
         with torch.cuda.device(self.device):
@@ -235,6 +243,7 @@ class Cache:
     def resize(self, new_num_nodes: int, new_num_edges: int):
         """Grow the id spaces (cache.py:197-221).  The caller must have replaced
         `node_feats` / `edge_feats` with tables covering the new ids."""
+        self.wait_enqueued()
         if self.distributed:
             raise NotImplementedError("resize of a cache over sharded feature tables")
         with torch.cuda.device(self.device):

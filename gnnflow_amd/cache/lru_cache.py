@@ -17,6 +17,7 @@ class LRUCache(Cache):
 
     def reset(self):
         """Reset the cache — NB: only the edge cache is reset (lru_cache.py:74-105)."""
+        self.wait_enqueued()
         if self._edge is not None:
             with torch.cuda.device(self.device):
                 self._edge.init(self._stream())

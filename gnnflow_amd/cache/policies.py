@@ -23,6 +23,7 @@ class LFUCache(Cache):
     def reset(self):
         """NB: only the edge cache is reset, and its use counts restart at 0 — not at the 1
         init_cache() leaves (lfu_cache.py:86-118)."""
+        self.wait_enqueued()
         if self._edge is not None:
             with torch.cuda.device(self.device):
                 self._edge.init(self._stream())
@@ -43,6 +44,7 @@ class FIFOCache(Cache):
     def reset(self):
         """The reference only rewinds the edge pointer (fifo_cache.py:70-75): the cached
         ids stay, the rotation restarts at slot 0."""
+        self.wait_enqueued()
         if self._edge is not None:
             with torch.cuda.device(self.device):
                 _capi.check(self._lib.gf_cache_reset_order(self._edge.h, self._stream()))
