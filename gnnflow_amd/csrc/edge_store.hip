@@ -44,6 +44,23 @@ void parallel_for(size_t n, size_t grain, F&& fn) {
 
 constexpr size_t kIngestChunk = 1 << 23; // edges per staging upload
 
+// The per-group passes of add_edges walk `nodes_` in increasing vertex order but with gaps:
+// nearly every group is a cache miss on its NodeState and a second one on its block list.
+// Two-stage software prefetch: the NodeState of the group 16 ahead, the tail of the block list
+// of the group 8 ahead (whose NodeState is in cache by then).
+template <typename Groups>
+inline void prefetch_groups(const std::vector<NodeState>& nodes, const Groups& groups, size_t g,
+                            size_t g_end) {
+  if (g + 16 < g_end) {
+    const size_t v = static_cast<size_t>(groups[g + 16].v);
+    if (v < nodes.size()) __builtin_prefetch(&nodes[v], 1, 1);
+  }
+  if (g + 8 < g_end) {
+    const size_t v = static_cast<size_t>(groups[g + 8].v);
+    if (v < nodes.size() && !nodes[v].blocks.empty()) __builtin_prefetch(&nodes[v].blocks.back(), 1, 1);
+  }
+}
+
 inline uint64_t pow2_ceil(uint64_t n) {
   uint64_t p = 1;
   while (p < n) p <<= 1;
@@ -331,6 +348,7 @@ void EdgeStore::upload_entries(const std::vector<int64_t>& ids) {
   NodeEntry* h_ent = reinterpret_cast<NodeEntry*>(h_ids + k);
   parallel_for(k, 1 << 15, [&](size_t i0, size_t i1) {
     for (size_t i = i0; i < i1; ++i) {
+      if (i + 16 < i1) __builtin_prefetch(&nodes_[ids[i + 16]], 0, 1);
       const NodeState& st = nodes_[ids[i]];
       h_ids[i] = ids[i];
       h_ent[i].start = st.seg_start + st.live_off;
@@ -523,6 +541,7 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
       size_t bytes = 0;
       std::vector<uint64_t> dem(free_lists_.size(), 0);
       for (size_t g = g0; g < g1; ++g) {
+        prefetch_groups(nodes_, groups, g, g1);
         const Group& gr = groups[g];
         const size_t cnt = gr.end - gr.begin;
         const NodeState* st =
@@ -636,6 +655,7 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     parallel_for(G, 1 << 13, [&](size_t g0, size_t g1) {
       BlockDelta delta;
       for (size_t g = g0; g < g1; ++g) {
+        prefetch_groups(nodes_, groups, g, g1);
         const Group& gr = groups[g];
         const size_t cnt = gr.end - gr.begin;
         NodeState& st = nodes_[gr.v];
@@ -654,8 +674,12 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     logical_blocks_ += d_blocks;
   }
   pt.mark("planA");
-  for (size_t g = 0; g < G; ++g) {
-    if (!newcap[g]) continue;
+  std::vector<uint32_t> grow;   // the groups whose vertex needs a (larger) segment
+  for (size_t g = 0; g < G; ++g)
+    if (newcap[g]) grow.push_back(static_cast<uint32_t>(g));
+  for (size_t k = 0; k < grow.size(); ++k) {
+    if (k + 16 < grow.size()) __builtin_prefetch(&nodes_[groups[grow[k + 16]].v], 1, 1);
+    const size_t g = grow[k];
     NodeState& st = nodes_[groups[g].v];
     const uint64_t ns = seg_alloc(newcap[g]);
     if (st.seg_cap) {
@@ -671,6 +695,7 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   if (!on_device) dest.resize(n);
   parallel_for(G, 1 << 13, [&](size_t g0, size_t g1) {
     for (size_t g = g0; g < g1; ++g) {
+      if (g + 16 < g1) __builtin_prefetch(&nodes_[groups[g + 16].v], 1, 1);
       const Group& gr = groups[g];
       const size_t cnt = gr.end - gr.begin;
       NodeState& st = nodes_[gr.v];
