@@ -116,6 +116,13 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "--gpus must match the launched world size"
 
+    # Host threads per rank in the pipelined loop: Python + two polling enqueue lanes.  When the
+    # ranks of this node have fewer than 4 usable cores each (a CPU-quota'd container), fall
+    # back to one sleeping lane: slower steps, but no rank starves another.
+    per_rank = usable_cores(cap=1 << 20) / max(int(os.environ.get("LOCAL_WORLD_SIZE", world)), 1)
+    if per_rank < 4:
+        os.environ.setdefault("GNNFLOW_ENQUEUE_LANES", "1")
+        os.environ.setdefault("GNNFLOW_ENQUEUE_SPIN_US", "0")
     import gnnflow_amd
     from gnnflow_amd import _capi, synthetic
     from gnnflow_amd.cache import LRUCache
@@ -274,6 +281,7 @@ def main():
             "pipeline_depth": pipe.depth if pipelined else 0,
             "workload_key": workload_key(args, repeats),
             "cpus_bound_to_gpu_node": len(bound) if bound else None,
+            "usable_cores_per_rank": per_rank,
         },
     }
     if cache is not None and g_n.value:

@@ -161,12 +161,18 @@ class EnqueueWorker {
       // In a running pipeline the next job arrives within tens of microseconds: poll for it
       // (bounded, ~100 us) before sleeping, so that the submitter does not pay a futex wake
       // and this thread does not pay the wake-up latency.
-      {
+      // (GNNFLOW_ENQUEUE_SPIN_US=0 turns the polling off: one busy thread less per lane when
+      // many ranks share few cores.)
+      static const long spin_us = [] {
+        const char* v = std::getenv("GNNFLOW_ENQUEUE_SPIN_US");
+        return v ? std::atol(v) : 100L;
+      }();
+      if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; pending_.load(std::memory_order_acquire) == 0; ++i) {
           __builtin_ia32_pause();
           if ((i & 255) == 255 &&
-              std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
+              std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
         }
       }
       {
