@@ -323,3 +323,48 @@ def test_million_edge_batch_in_one_call():
     os_ = O.OracleSampler(o, [10, 5])
     nodes, t = synth.random_roots(N, 3000, 1000.0, seed=5, extra_ids=[N + 70000])
     _cmp_blocks(hs.sample(nodes, t), os_.sample(nodes, t), "after a 1.4 M-edge batch")
+
+
+def test_many_asynchronous_samples_in_flight_and_a_failing_one():
+    """Up to 4 samples may be begun before the first is waited for (more: the oldest is
+    completed first); results come back in order and equal the synchronous call.  A sample
+    whose enqueue fails raises from ITS wait() only and leaves the sampler usable."""
+    import torch
+    import gnnflow_amd
+    N, E = 3000, 90000
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=17, tie_levels=3000)
+    g = gnnflow_amd.DynamicGraph(1 << 20, 1 << 28, "cuda", 16, 128, "insert")
+    synth.ingest_chunks(g, src, dst, ts, eid, 30000)
+    s = gnnflow_amd.TemporalSampler(g, [6, 4], "recent")
+    side = torch.cuda.Stream()
+    reqs = [synth.random_roots(N, 400 + 37 * k, 1000.0, seed=k) for k in range(9)]
+    dev = [(torch.from_numpy(n).cuda(), torch.from_numpy(t).cuda()) for n, t in reqs]
+    for worker in (False, True):
+        pend = [s.sample_async(n, t, stream=side, worker_enqueue=worker) for n, t in dev]
+        got = [p.wait() for p in reversed(pend)][::-1]      # waited newest first on purpose
+        for (n, t), mf in zip(reqs, got):
+            want = s.sample(n, t)
+            for gl, wl in zip(mf, want):
+                assert torch.equal(gl[0].edata["ID"], wl[0].edata["ID"])
+                assert torch.equal(gl[0].srcdata["ID"], wl[0].srcdata["ID"])
+                assert torch.equal(gl[0].edges()[1], wl[0].edges()[1])
+    # a failing enqueue in the middle of a pipeline
+    R_bad = 777
+    nb, tb = synth.random_roots(N, R_bad, 1000.0, seed=99)
+    s._bytes_cache[R_bad] = 64                       # far too small: the native begin refuses
+    ok1 = s.sample_async(*dev[0], stream=side, worker_enqueue=True)
+    bad = s.sample_async(torch.from_numpy(nb).cuda(), torch.from_numpy(tb).cuda(), stream=side,
+                         worker_enqueue=True)
+    ok2 = s.sample_async(*dev[1], stream=side, worker_enqueue=True)
+    a = ok1.wait()
+    with pytest.raises(ValueError):
+        bad.wait()
+    with pytest.raises(ValueError):
+        bad.wait()                                   # and again: the error sticks to ITS handle
+    b = ok2.wait()
+    del s._bytes_cache[R_bad]
+    for mf, (n, t) in ((a, reqs[0]), (b, reqs[1])):
+        want = s.sample(n, t)
+        assert torch.equal(mf[0][0].edata["ID"], want[0][0].edata["ID"])
+    assert len(s._inflight) == 0
+    assert s.sample(nb, tb)[0][0].num_dst_nodes() > 0   # the same roots work once sized right
