@@ -90,6 +90,10 @@ constexpr uint32_t kRowTile = 4096;     // rows per scan workgroup (kWide thread
 constexpr uint32_t kMaxRowTiles = 1024; // more row tiles than this: chained single-workgroup scan
 constexpr uint32_t kQGroup = 64;        // LRU: list tiles per group sum
 constexpr uint32_t kInstRows = 256;     // LRU: block rows per install workgroup
+// LRU: block rows per scan workgroup.  One row per thread: the row role is a handful of
+// scattered loads per row, which a CU retires at ~one 64-line instruction per 64 cycles, so a
+// 20 k-row block wants 20 CUs on it, not 5 (kRowTile rows per workgroup).
+constexpr uint32_t kLruRows = 1024;
 
 // One record per fetch.  hits / misses are accumulated once per workgroup into one of 8
 // shards that sit on separate 128-byte lines: same-address atomics retire at only
@@ -109,12 +113,14 @@ struct Counters {
   uint32_t ticket;      // workgroups of the rank kernel that finished their level-2 histogram
   uint32_t q_parity;    // LRU list: buffer that is current during this update
   uint32_t q_found;     // LRU list: not-hit victims found by the list scan
-  uint32_t pad[25];
+  uint32_t q_head;      // LRU queue: head / tail of the queue during this update
+  uint32_t q_tail;
+  uint32_t pad[23];
 };
 constexpr uint32_t kCounterWords = sizeof(Counters) / 4;
 
 // Everything one block fetch needs on the device.  `update` == 0: gather only.
-struct QueueState { uint32_t parity, pad[3]; };
+struct QueueState { uint32_t parity, head, tail, pad; };
 
 struct Ctx {
   const int64_t* ids;
@@ -137,7 +143,18 @@ struct Ctx {
   uint32_t* touched;        // epoch of the slot's last hit (pending until the block misses)
   uint32_t* queue[2];       // LRU: the slots, least recently refreshed first (double buffer)
   QueueState* qstate;       // LRU: which buffer is current, device resident
-  uint32_t tiles_per_wg;    // LRU: row tiles per scan workgroup (1 unless > 4M rows)
+  uint32_t tiles_per_wg;    // LRU: row tiles per scan workgroup (1 unless > 1M rows)
+  // LRU of a LARGE cache (queue form, see "LRU as a queue" below); qmode == 0: list form
+  int qmode;                // this update appends to the queue instead of rewriting the list
+  int q_rebuild;            // list-form update of a queue-capable cache: rebuild qpos afterwards
+  uint32_t* qpos;           // [capacity] position of the slot's live queue entry
+  uint32_t* hit_rep;        // [capacity] one of the rows that hit the slot in this block
+  uint32_t* qbits;          // one bit per queue position: entry of a slot hit by this block
+                            // (all zero between updates)
+  uint32_t v_chunks;        // victim walk: chunks of kRowTile queue entries behind the head
+  uint32_t* v_slot;         // [(v_chunks * kRowTile) + n] candidates per chunk (+ the lone walk's)
+  uint32_t* v_pos;          // their queue positions
+  uint32_t* v_count;        // [v_chunks + 1]
   uint32_t capacity;
   uint32_t epoch_new;
   int update;
@@ -214,6 +231,9 @@ __device__ inline void gather_body(const Ctx& c) {
           // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
           // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161).
           if (c.update && c.policy != GF_CACHE_FIFO) c.touched[slot] = c.epoch_new;
+          // queue form: any ONE of the rows that hit the slot stands for it (plain stores of
+          // different values to one word: exactly one of them remains)
+          if (c.qmode) c.hit_rep[slot] = row0 + lane;
         } else {
           slot = -1;
           src = c.miss_rows
@@ -774,6 +794,30 @@ __device__ inline uint32_t wide_sum(uint32_t v, uint32_t* ws) {
   return sum;
 }
 
+// Queue form: four consecutive queue entries from p0 (16-byte aligned); bit j of the result:
+// entry p0 + j is live (qpos points at it) and its slot was not hit by this block.
+__device__ inline uint32_t victim_walk4(const Ctx& c, const uint32_t* list, uint32_t head,
+                                        uint32_t tail, uint32_t p0, uint32_t* sl) {
+  // the buffers are allocated 16 entries past queue_cap: a whole vector is readable
+  const uint4 v = p0 < tail ? *reinterpret_cast<const uint4*>(list + p0)
+                            : make_uint4(0u, 0u, 0u, 0u);
+  uint32_t qp[4], tc[4], mask = 0;
+  sl[0] = v.x; sl[1] = v.y; sl[2] = v.z; sl[3] = v.w;
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j) {
+    const bool in = p0 + j >= head && p0 + j < tail;
+    if (!in) sl[j] = 0u;   // beyond the tail: not initialised
+    qp[j] = c.qpos[sl[j]];
+    tc[j] = c.touched[sl[j]];
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j) {
+    const bool in = p0 + j >= head && p0 + j < tail;
+    if (in && qp[j] == p0 + j && tc[j] != c.epoch_new) mask |= 1u << j;
+  }
+  return mask;
+}
+
 // One launch, three kinds of workgroups (per context), all reading what the gather left:
 //  * row workgroups   [0, row_blocks): each owns `tiles_per_wg` consecutive tiles of kRowTile
 //    rows, finds the representatives of the distinct missed ids in them (the row whose claim
@@ -786,7 +830,8 @@ __device__ inline uint32_t wide_sum(uint32_t v, uint32_t* ws) {
 //    missed ids, which only the next kernel knows) — and the hit entries it passes on the way
 //    (the next victims if a block needs more slots than its own hits leave over).
 __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t row_blocks,
-                                                              uint32_t list_blocks) {
+                                                              uint32_t list_blocks,
+                                                              uint32_t victim_blocks) {
   const Ctx& c = r.c[blockIdx.y];
   if (!c.update || c.policy != GF_CACHE_LRU) return;
   const int tid = threadIdx.x;
@@ -796,14 +841,15 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
   constexpr uint32_t kItems = kRowTile / kWide;
   if (blockIdx.x < row_blocks) {
     __shared__ uint32_t carry;
-    const uint32_t row_tiles = (c.n + kRowTile - 1) / kRowTile;
+    const uint32_t row_tiles = (c.n + kLruRows - 1) / kLruRows;
+    constexpr uint32_t kItems = kLruRows / kWide;   // shadows the list role's
     const uint32_t t_begin = blockIdx.x * c.tiles_per_wg;
     if (t_begin >= row_tiles) return;
     const uint32_t t_end = min(t_begin + c.tiles_per_wg, row_tiles);
     if (tid == 0) carry = 0;
     __syncthreads();
     for (uint32_t t = t_begin; t < t_end; ++t) {
-      const uint32_t i0 = t * kRowTile + tid * kItems;
+      const uint32_t i0 = t * kLruRows + tid * kItems;
       int32_t sr[kItems];
       int64_t idv[kItems];
 #pragma unroll
@@ -818,6 +864,20 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
       for (uint32_t k = 0; k < kItems; ++k) {
         fm[k] = (sr[k] == -1 && c.map[idv[k]] == -static_cast<int32_t>(i0 + k + 1)) ? 1u : 0u;
         lm += fm[k];
+      }
+      if (c.qmode) {
+        // every distinct hit slot marks the queue position of its entry, once (the row that
+        // stands for the slot does it: different slots rarely share a word)
+        uint32_t rep[kItems], pos[kItems];
+#pragma unroll
+        for (uint32_t k = 0; k < kItems; ++k) {
+          rep[k] = sr[k] >= 0 ? c.hit_rep[sr[k]] : ~0u;
+          pos[k] = sr[k] >= 0 ? c.qpos[sr[k]] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kItems; ++k)
+          if (sr[k] >= 0 && rep[k] == i0 + k)
+            atomicOr(&c.qbits[pos[k] >> 5], 1u << (pos[k] & 31u));
       }
       uint32_t tm;
       uint32_t run = carry + wide_excl_scan(lm, ws, &tm);
@@ -835,6 +895,7 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
   }
   const uint32_t cap = c.capacity;
   if (blockIdx.x < row_blocks + list_blocks) {
+    if (c.qmode) return;   // queue form: nothing is proportional to the capacity
     const uint32_t list_tiles = (cap + kRowTile - 1) / kRowTile;
     bool first = true;
     for (uint32_t t = blockIdx.x - row_blocks; t < list_tiles; t += list_blocks) {
@@ -857,8 +918,37 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
     }
     return;
   }
-  if (blockIdx.x != row_blocks + list_blocks) return;
   const uint32_t want = min(total_miss(c.ctr), cap);
+  if (c.qmode) {
+    // queue form: the victims are the first LIVE entries from the head that the block did
+    // not hit (the host only chooses this form for blocks of <= capacity / 4 rows, so there
+    // are always enough).  The walk is spread over the victim workgroups — one CU alone is
+    // bound by its 64-line-per-instruction address rate on the two scattered loads per entry
+    // (measured 27-37 us for 20 k victims) — in chunks of kRowTile entries: every chunk leaves
+    // its candidates and their count, the count kernel packs the chunks.  The chunks cover
+    // 2 * rows + 2 tiles from the head; should that not yield `want` candidates (many dead
+    // entries right behind the head), one workgroup of the count kernel walks on alone.
+    // (No "last workgroup" ticket here: the __threadfence() it needs writes the XCD's whole
+    // L2 back on this part — measured +15 us.)
+    const uint32_t vb = blockIdx.x - row_blocks - list_blocks;
+    const uint32_t head = c.qstate->head, tail = c.qstate->tail;
+    if (vb == 0 && tid == 0) { c.ctr->q_parity = parity; c.ctr->q_head = head; c.ctr->q_tail = tail; }
+    if (want == 0) return;
+    const uint32_t hbase = head & ~3u, chunks = c.v_chunks;
+    for (uint32_t ch = vb; ch < chunks; ch += victim_blocks) {
+      const uint32_t p0 = hbase + ch * kRowTile + tid * 4;
+      uint32_t sl[4];
+      const uint32_t mask = victim_walk4(c, list, head, tail, p0, sl);
+      uint32_t total;
+      uint32_t at = ch * kRowTile + wide_excl_scan(__popc(mask), ws, &total);
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j)
+        if (mask & (1u << j)) { c.v_slot[at] = sl[j]; c.v_pos[at] = p0 + j; ++at; }
+      if (tid == 0) c.v_count[ch] = total;
+    }
+    return;
+  }
+  if (blockIdx.x != row_blocks + list_blocks) return;
   if (tid == 0) c.ctr->q_parity = parity;
   if (want == 0) return;
   uint32_t* kept = c.rep_row;     // victims: not-hit entries from the front of the list
@@ -890,6 +980,74 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
   if (tid == 0) c.ctr->q_found = min(found, want);
 }
 
+// Queue form, between the two kernels:
+//  * hit entries per tile of kWide words of qbits (the queue positions [head, tail) only) and
+//    per group of kQGroup tiles;
+//  * the victim candidates of the chunks, packed in queue order: rep_row[m] = slot of the m-th
+//    candidate, rep_rank[m] = its queue position.
+__global__ __launch_bounds__(kWide) void lru_queue_count_kernel(Round r) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (!c.update || c.policy != GF_CACHE_LRU || !c.qmode) return;
+  const int tid = threadIdx.x;
+  __shared__ uint32_t ws[kWide / 64];
+  const uint32_t head = c.ctr->q_head, tail = c.ctr->q_tail;
+  const uint32_t want = min(total_miss(c.ctr), c.capacity);
+  if (want == 0) return;
+  const uint32_t w_lo = head >> 5, w_hi = (tail + 31u) >> 5;
+  const uint32_t t0 = w_lo / kWide;
+  const uint32_t btiles = (w_hi + kWide - 1) / kWide - t0;
+  for (uint32_t t = blockIdx.x; t < btiles; t += gridDim.x) {
+    const uint32_t local = __popc(c.qbits[static_cast<size_t>(t0 + t) * kWide + tid]);
+    const uint32_t total = wide_sum(local, ws);
+    if (tid == 0) {
+      c.tile_tie[t] = total;
+      if (total) atomicAdd(&c.tile_old[t / kQGroup], total);   // zeroed by the gather
+    }
+  }
+  const uint32_t chunks = c.v_chunks;
+  for (uint32_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+    uint32_t before = 0;
+    for (uint32_t u = tid; u < ch; u += kWide) before += c.v_count[u];
+    before = wide_sum(before, ws);
+    const uint32_t cnt = c.v_count[ch];
+    for (uint32_t i = tid; i < cnt && before + i < want; i += kWide) {
+      const uint32_t slot = c.v_slot[ch * kRowTile + i];
+      c.rep_row[before + i] = slot;
+      c.rep_rank[before + i] = c.v_pos[ch * kRowTile + i];
+      c.rep_id[before + i] = c.slot_id[slot];   // the id it evicts: one hop less when installing
+    }
+  }
+  if (blockIdx.x != gridDim.x - 1) return;
+  // the last workgroup: did the chunks yield enough?  If not (many dead entries right behind
+  // the head) it walks on alone, tile by tile
+  uint32_t sum = 0;
+  for (uint32_t u = tid; u < chunks; u += kWide) sum += c.v_count[u];
+  uint32_t found = wide_sum(sum, ws);
+  const uint32_t parity = c.ctr->q_parity;
+  const uint32_t* list = c.queue[parity & 1u];
+  for (uint32_t base = (head & ~3u) + chunks * kRowTile; base < tail && found < want;
+       base += kRowTile) {
+    const uint32_t p0 = base + tid * 4;
+    uint32_t sl[4];
+    const uint32_t mask = victim_walk4(c, list, head, tail, p0, sl);
+    uint32_t total;
+    uint32_t at = found + wide_excl_scan(__popc(mask), ws, &total);
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      if (mask & (1u << j)) {
+        if (at < want) {
+          c.rep_row[at] = sl[j];
+          c.rep_rank[at] = p0 + j;
+          c.rep_id[at] = c.slot_id[sl[j]];
+        }
+        ++at;
+      }
+    }
+    found += total;
+  }
+  if (tid == 0) c.ctr->q_found = min(found, want);
+}
+
 // Applies the update; two kinds of workgroups:
 //  * row workgroups [0, row_blocks), one thread per block row: the m-th distinct missed id
 //    (m < k = min(#distinct misses, capacity)) takes the m-th victim's slot — map / slot_id /
@@ -903,7 +1061,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
   if (!c.update || c.policy != GF_CACHE_LRU) return;
   const int tid = threadIdx.x;
   __shared__ uint32_t ws[kWide / 64];
-  const uint32_t row_tiles = (c.n + kRowTile - 1) / kRowTile;
+  const uint32_t row_tiles = (c.n + kLruRows - 1) / kLruRows;
   const uint32_t spans = (row_tiles + c.tiles_per_wg - 1) / c.tiles_per_wg;
   const uint32_t cap = c.capacity;
   if (blockIdx.x < row_blocks) {
@@ -912,7 +1070,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
     // n / kInstRows workgroups with 4 rows' worth of loads in flight per installing thread
     __shared__ uint2 inst[kInstRows];   // {slot, row} installed by this workgroup
     __shared__ uint32_t n_inst;
-    const uint32_t span_rows = c.tiles_per_wg * kRowTile;
+    const uint32_t span_rows = c.tiles_per_wg * kLruRows;
     const uint32_t chunks = (c.n + kInstRows - 1) / kInstRows;
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += row_blocks) {
       const uint32_t i = chunk * kInstRows + tid;
@@ -933,12 +1091,12 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
       tm = wide_sum(tm, ws);
       if (tid == 0) n_inst = 0;
       __syncthreads();
-      const uint32_t k = min(tm, cap);
+      const uint32_t k = c.qmode ? min(min(tm, cap), q_found) : min(tm, cap);
       if (code & kRepMiss) {
         const uint32_t m = pm + (code & kRepRank);
         if (m < k) {
           const uint32_t slot = m < q_found ? c.rep_row[m] : c.rep_rank[m - q_found];
-          const int64_t old = c.slot_id[slot];
+          const int64_t old = c.qmode ? c.rep_id[m] : c.slot_id[slot];
           if (old >= 0) c.map[old] = kAbsent;
           c.slot_id[slot] = id;
           c.map[id] = static_cast<int32_t>(slot);
@@ -976,6 +1134,88 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
   }
   if (blockIdx.x >= row_blocks + list_blocks) return;
   const uint32_t parity = c.ctr->q_parity;
+  if (c.qmode) {
+    // queue form: the distinct hit slots (in the order of their old entries = list order:
+    // the set bits of qbits, ascending) and then the k victims (in victim order) are
+    // APPENDED; the old entries of both die — qpos[] now points at the new ones — and the
+    // head moves behind the k-th victim
+    uint32_t* q = c.queue[parity & 1u];
+    const uint32_t head = c.ctr->q_head, tail = c.ctr->q_tail, q_found = c.ctr->q_found;
+    const uint32_t w_lo = head >> 5, w_hi = (tail + 31u) >> 5;
+    const uint32_t t0 = w_lo / kWide;
+    const uint32_t btiles = (w_hi + kWide - 1) / kWide - t0;
+    const uint32_t bgroups = (btiles + kQGroup - 1) / kQGroup;
+    uint32_t tm = 0, th = 0;
+    for (uint32_t t = tid; t < spans; t += kWide) tm += c.row_tile_sum[t];
+    for (uint32_t g = tid; g < bgroups; g += kWide) th += c.tile_old[g];
+    if (total_miss(c.ctr) == 0) return;
+    tm = wide_sum(tm, ws);
+    th = wide_sum(th, ws);
+    const uint32_t k = min(min(tm, cap), q_found);
+    // bitmap tiles (kWide words, 32 queue positions per word, one word per thread) are dealt
+    // round-robin — the hit entries sit close together near the tail, so neighbouring tiles
+    // must not land in one workgroup — and the empty ones, nearly all, are skipped
+    __shared__ uint32_t s_cnt[kWide], s_word[kWide], s_rank[kWide];
+    const uint32_t wg = blockIdx.x - row_blocks;
+    for (uint32_t tbase = wg; tbase < btiles; tbase += kWide * list_blocks) {
+      __syncthreads();
+      const uint32_t mine = tbase + tid * list_blocks;
+      s_cnt[tid] = mine < btiles ? c.tile_tie[mine] : 0u;
+      __syncthreads();
+      const uint32_t mine_n =
+          min(static_cast<uint32_t>(kWide), (btiles - tbase + list_blocks - 1) / list_blocks);
+      for (uint32_t i = 0; i < mine_n; ++i) {
+        if (s_cnt[i] == 0) continue;   // uniform
+        const uint32_t t = tbase + i * list_blocks;
+        const size_t wi = static_cast<size_t>(t0 + t) * kWide + tid;
+        const uint32_t word = c.qbits[wi];
+        uint32_t before = 0;
+        const uint32_t g0 = t / kQGroup;
+        for (uint32_t g = tid; g < g0; g += kWide) before += c.tile_old[g];
+        for (uint32_t u = g0 * kQGroup + tid; u < t; u += kWide) before += c.tile_tie[u];
+        before = wide_sum(before, ws);
+        uint32_t total;
+        const uint32_t rank = before + wide_excl_scan(__popc(word), ws, &total);
+        // expand the tile's set bits, lanes on consecutive queue positions (coalesced reads
+        // of the old entries and writes of the new ones), eight positions per thread in flight
+        __syncthreads();
+        s_word[tid] = word;
+        s_rank[tid] = rank;
+        if (word) c.qbits[wi] = 0u;   // all zero again for the next update
+        __syncthreads();
+        const uint32_t pos0 = static_cast<uint32_t>((t0 + t) * kWide) << 5;
+        const uint32_t bit = tid & 31u, below = (1u << bit) - 1u;
+        for (uint32_t j0 = 0; j0 < 32; j0 += 8) {
+          uint32_t slot[8], at[8];
+#pragma unroll
+          for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t rel = (j0 + j) * kWide + tid;
+            const uint32_t w = s_word[rel >> 5];
+            at[j] = (w >> bit) & 1u ? tail + s_rank[rel >> 5] + __popc(w & below) : ~0u;
+            slot[j] = at[j] != ~0u ? q[pos0 + rel] : 0u;
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < 8; ++j) {
+            if (at[j] != ~0u) {
+              q[at[j]] = slot[j];
+              c.qpos[slot[j]] = at[j];
+            }
+          }
+        }
+      }
+    }
+    const uint32_t stride = list_blocks * kWide;
+    for (uint32_t m = (blockIdx.x - row_blocks) * kWide + tid; m < k; m += stride) {
+      const uint32_t slot = c.rep_row[m];
+      q[tail + th + m] = slot;
+      c.qpos[slot] = tail + th + m;
+    }
+    if (blockIdx.x == row_blocks && tid == 0) {
+      c.qstate->tail = tail + th + k;
+      c.qstate->head = k ? c.rep_rank[k - 1] + 1u : head;
+    }
+    return;
+  }
   const uint32_t* list = c.queue[parity & 1u];
   uint32_t* next = c.queue[(parity & 1u) ^ 1u];
   constexpr uint32_t kItems = kRowTile / kWide;
@@ -1029,6 +1269,107 @@ __global__ void list_fill_kernel(uint32_t* list, uint32_t first, uint32_t prefix
     list[j] = j < prefix ? first + j : old[j - prefix];
 }
 
+// ---- LRU as a queue (large caches) --------------------------------------------------------
+// The list passes above cost O(capacity) per update: 343 us for a 30 k-row block on a 40 M-slot
+// cache (GDELT scale) against 17 us for the gather itself.  From queue_min_capacity() slots on
+// (2 M), the SAME list is therefore kept as a queue with dead entries: `queue` holds entries
+// [head, tail) (capacity * 3/2 allocated), qpos[slot] is the position of the slot's one LIVE
+// entry, and an update only appends — the distinct hit slots in the order of their old entries,
+// then the k victims, which are the first k live, not-hit entries from the head.  Old entries
+// die because qpos[] moves on.  Reading the live entries from head to tail gives exactly the
+// list of the list form, so both forms — and the oracle — make the same decisions.
+//   gather       : additionally leaves, per hit slot, one of the rows that hit it (hit_rep)
+//   list scan    : row role — the row that stands for a hit slot sets the bit of the slot's
+//                  queue position in `qbits` (so the hit slots come out deduplicated AND in
+//                  queue order without a sort: a 7-launch device radix sort cost 35 us here);
+//                  victim role — chunks of the queue behind the head, one workgroup each,
+//                  keep their live, not-hit entries
+//   queue count  : set bits per bitmap tile (the bitmap is 1/32 of the queue: 7.5 MB at 40 M
+//                  slots) and the chunks' candidates packed into one victim list
+//   list install : row role as in the list form; append role — the non-empty bitmap tiles
+//                  are expanded to the tail, the victims follow, head / tail move
+// When the queue's tail would pass its allocation it is compacted into the other buffer (two
+// launches, O(capacity), once per ~capacity / (2 * block rows) updates); a block of more than
+// capacity / 4 rows is handled by the list form on the compacted queue (its passes are no
+// longer the larger term then) and qpos[] is rebuilt behind it.
+struct CompactState { uint32_t parity, tail, pad[2]; };
+
+__global__ __launch_bounds__(kWide) void lru_queue_compact_count_kernel(
+    const uint32_t* q0, const uint32_t* q1, const QueueState* qs, const uint32_t* qpos,
+    unsigned long long* live_bits, uint32_t* tile_cnt, uint32_t* group_sum, CompactState* st) {
+  const int tid = threadIdx.x;
+  __shared__ uint32_t ws[kWide / 64];
+  const uint32_t parity = qs->parity, tail = qs->tail;
+  const uint32_t* q = (parity & 1u) ? q1 : q0;
+  if (blockIdx.x == 0 && tid == 0) { st->parity = parity; st->tail = tail; }
+  constexpr uint32_t kItems = kRowTile / kWide;
+  const uint32_t tiles = (tail + kRowTile - 1) / kRowTile;
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    uint32_t local = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kItems; ++j) {
+      const uint32_t p = t * kRowTile + j * kWide + tid;
+      bool live = false;
+      if (p < tail) live = qpos[q[p]] == p;
+      const unsigned long long b = __ballot(live);
+      if ((tid & 63) == 0) live_bits[p >> 6] = b;
+      local += live ? 1u : 0u;
+    }
+    const uint32_t total = wide_sum(local, ws);
+    if (tid == 0) {
+      tile_cnt[t] = total;
+      if (total) atomicAdd(&group_sum[t / kQGroup], total);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kWide) void lru_queue_compact_write_kernel(
+    uint32_t* q0, uint32_t* q1, QueueState* qs, uint32_t* qpos,
+    const unsigned long long* live_bits, const uint32_t* tile_cnt, const uint32_t* group_sum,
+    const CompactState* st, uint32_t capacity) {
+  const int tid = threadIdx.x;
+  __shared__ uint32_t ws[kWide / 64];
+  const uint32_t parity = st->parity, tail = st->tail;
+  const uint32_t* q = (parity & 1u) ? q1 : q0;
+  uint32_t* next = (parity & 1u) ? q0 : q1;
+  constexpr uint32_t kItems = kRowTile / kWide;
+  const uint32_t tiles = (tail + kRowTile - 1) / kRowTile;
+  for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    uint32_t before = 0;
+    const uint32_t g0 = t / kQGroup;
+    for (uint32_t g = tid; g < g0; g += kWide) before += group_sum[g];
+    for (uint32_t u = g0 * kQGroup + tid; u < t; u += kWide) before += tile_cnt[u];
+    uint32_t run = wide_sum(before, ws);
+#pragma unroll
+    for (uint32_t j = 0; j < kItems; ++j) {
+      const uint32_t p = t * kRowTile + j * kWide + tid;
+      const uint32_t live = static_cast<uint32_t>((live_bits[p >> 6] >> (tid & 63)) & 1ull);
+      uint32_t total;
+      const uint32_t at = run + wide_excl_scan(live, ws, &total);
+      if (live) {
+        const uint32_t s = q[p];
+        next[at] = s;
+        qpos[s] = at;
+      }
+      run += total;
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    qs->parity = parity ^ 1u;
+    qs->head = 0;
+    qs->tail = capacity;   // every slot has exactly one live entry
+  }
+}
+
+// qpos of a dense list (after init, resize, or a list-form update of a queue-capable cache)
+__global__ void lru_queue_index_kernel(const uint32_t* q0, const uint32_t* q1,
+                                       const QueueState* qs, uint32_t* qpos, uint32_t capacity) {
+  const uint32_t* list = (qs->parity & 1u) ? q1 : q0;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < capacity; p += stride)
+    qpos[list[p]] = p;
+}
+
 __global__ void cache_fill_kernel(int32_t* map, uint64_t num_ids, int64_t* slot_id,
                                   uint32_t* stamp, uint32_t* touched, uint64_t capacity,
                                   int identity, uint32_t stamp0) {
@@ -1065,6 +1406,25 @@ __global__ void cache_probe_kernel(const int64_t* __restrict__ ids, uint64_t n,
 inline bool vec4_ok(size_t dim, const void* a, const void* b, const void* c) {
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   return dim % 4 == 0 && al(a) && al(b) && al(c);
+}
+
+// LRU caches of at least this many slots are kept as a queue (O(block rows) updates): a
+// 30 k-row fetch with update costs 38 / 47 / 75 / 150 / 343 us in the list form at 0.13 / 1 / 4
+// / 16 / 40 M slots and 48 / 50 / 54 us in the queue form at 4 / 16 / 40 M
+// (profiles/r02_lru_capacity_sweep.jsonl)
+inline size_t queue_min_capacity() {
+  const char* v = std::getenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY");   // tuning / tests
+  return v ? static_cast<size_t>(std::atoll(v)) : (size_t{2} << 20);
+}
+
+// chunks of kRowTile queue entries the victim walk covers behind the head: twice the rows
+// of the block (at most that many victims are needed) + 2
+inline size_t victim_chunks(size_t n) { return (2 * n + kRowTile - 1) / kRowTile + 2; }
+
+// bitmap over the queue positions, in whole tiles of kRowTile words (+ one tile)
+inline size_t qbits_bytes(size_t queue_cap) {
+  const size_t words = (queue_cap + 64 + 31) / 32;
+  return ((words + kRowTile - 1) / kRowTile + 1) * kRowTile * sizeof(uint32_t);
 }
 
 // rows per wave: 64 for big blocks; fewer for small ones so the block still spreads
@@ -1127,15 +1487,27 @@ void launch_round(Round& r, hipStream_t stream) {
   }
   if (!any_update) return;
   ProfileScope ps(kProfLru, stream);
-  size_t q_scan_blocks = 0, q_rows = 0, q_cap = 0, h_n = 0, h_cap = 0, h_tiles = 0;
+  size_t q_scan_blocks = 0, q_rows = 0, q_cap = 0, q_bit_tiles = 0, q_victim_blocks = 1;
+  size_t q_append_blocks = 0;
+  size_t h_n = 0, h_cap = 0, h_tiles = 0;
   for (int i = 0; i < r.count; ++i) {
     const Ctx& c = r.c[i];
     if (!c.update) continue;
     if (c.policy == GF_CACHE_LRU) {
-      const size_t row_tiles = (c.n + kRowTile - 1) / kRowTile;
+      const size_t row_tiles = (c.n + kLruRows - 1) / kLruRows;
       q_scan_blocks = std::max(q_scan_blocks, (row_tiles + c.tiles_per_wg - 1) / c.tiles_per_wg);
       q_rows = std::max<size_t>(q_rows, c.n);
-      q_cap = std::max<size_t>(q_cap, c.capacity);
+      if (c.qmode) {
+        // queue form: bitmap tiles of kWide words (32 queue positions per word; the tail is
+        // below 1.5 * capacity + 64)
+        const size_t bit_tiles = ((size_t{c.capacity} * 3 / 2 + 128) / 32 + kWide - 1) / kWide + 1;
+        q_bit_tiles = std::max(q_bit_tiles, std::max<size_t>(bit_tiles, c.v_chunks) + 1);
+        q_victim_blocks = std::max<size_t>(q_victim_blocks, std::min<size_t>(c.v_chunks, 1024));
+        q_append_blocks = std::max(q_append_blocks,
+                                   std::min<size_t>(std::max<size_t>(bit_tiles / 4, 16), 256));
+      } else {
+        q_cap = std::max<size_t>(q_cap, c.capacity);
+      }
     } else {
       h_n = std::max<size_t>(h_n, c.n);
       h_cap = std::max<size_t>(h_cap, c.capacity);
@@ -1144,13 +1516,29 @@ void launch_round(Round& r, hipStream_t stream) {
   }
   if (q_rows) {   // LRU: list scan + list install
     const unsigned rb = static_cast<unsigned>(q_scan_blocks);
-    const unsigned lb = static_cast<unsigned>(
-        std::max<size_t>(1, std::min<size_t>((q_cap + kRowTile - 1) / kRowTile, 1024)));
-    lru_list_scan_kernel<<<dim3(rb + lb + 1, r.count), dim3(kWide), 0, stream>>>(r, rb, lb);
+    // list workgroups: per kRowTile list entries of the list-form contexts (none: queue form
+    // only); the install kernel's also append for the queue-form contexts
+    const unsigned lb_list = static_cast<unsigned>(
+        std::min<size_t>((q_cap + kRowTile - 1) / kRowTile, 1024));
+    const unsigned lb = std::max<unsigned>(1, std::max(lb_list, static_cast<unsigned>(q_append_blocks)));
+    const unsigned vb = static_cast<unsigned>(q_victim_blocks);
+    lru_list_scan_kernel<<<dim3(rb + lb_list + vb, r.count), dim3(kWide), 0, stream>>>(
+        r, rb, lb_list, vb);
+    if (q_bit_tiles)
+      lru_queue_count_kernel<<<dim3(static_cast<unsigned>(std::min<size_t>(q_bit_tiles, 1024)),
+                                    r.count), dim3(kWide), 0, stream>>>(r);
     const unsigned ib = static_cast<unsigned>(
         std::max<size_t>(1, std::min<size_t>((q_rows + kInstRows - 1) / kInstRows, 4096)));
     lru_list_install_kernel<<<dim3(ib + lb, r.count), dim3(kWide), 0, stream>>>(r, ib, lb);
     GF_HIP(hipGetLastError());
+    for (int i = 0; i < r.count; ++i) {
+      const Ctx& c = r.c[i];
+      if (c.update && c.q_rebuild) {
+        lru_queue_index_kernel<<<dim3(2048), dim3(256), 0, stream>>>(
+            c.queue[0], c.queue[1], c.qstate, c.qpos, c.capacity);
+        GF_HIP(hipGetLastError());
+      }
+    }
   }
   if (!h_cap) return;
   max_n = h_n; max_cap = h_cap; max_tiles = h_tiles;
@@ -1266,7 +1654,9 @@ void FeatureCache::init(hipStream_t stream) {
 // slot order: the order of a freshly initialised cache (every `count` equal)
 void FeatureCache::init_queue(hipStream_t stream) {
   if (policy_ != GF_CACHE_LRU) return;
-  const size_t bytes = std::max<size_t>(capacity_ * sizeof(uint32_t), 16);
+  queue_form_ = capacity_ >= queue_min_capacity();
+  queue_cap_ = queue_form_ ? capacity_ + capacity_ / 2 + 64 : capacity_;
+  const size_t bytes = (queue_cap_ + 16) * sizeof(uint32_t);   // + one 16-byte vector past the end
   queue_.reserve(bytes, 0, stream);
   queue_alt_.reserve(bytes, 0, stream);
   if (capacity_) {
@@ -1274,7 +1664,61 @@ void FeatureCache::init_queue(hipStream_t stream) {
         queue_.as<uint32_t>(), 0u, static_cast<uint32_t>(capacity_), nullptr, 0u);
     GF_HIP(hipGetLastError());
   }
-  GF_HIP(hipMemsetAsync(qstate_.data(), 0, sizeof(QueueState), stream));
+  const QueueState qs{0u, 0u, static_cast<uint32_t>(capacity_), 0u};
+  GF_HIP(hipMemcpyAsync(qstate_.data(), &qs, sizeof(qs), hipMemcpyHostToDevice, stream));
+  GF_HIP(hipStreamSynchronize(stream));   // qs is a stack variable
+  tail_bound_ = capacity_;
+  if (queue_form_) {
+    qpos_.reserve(capacity_ * sizeof(uint32_t), 0, stream);
+    hit_rep_.reserve(capacity_ * sizeof(uint32_t), 0, stream);
+    qbits_.reserve(qbits_bytes(queue_cap_), 0, stream);
+    GF_HIP(hipMemsetAsync(qbits_.data(), 0, qbits_bytes(queue_cap_), stream));
+    const size_t tiles = (queue_cap_ + kRowTile - 1) / kRowTile + 1;
+    const size_t groups = (tiles + kQGroup - 1) / kQGroup + 1;
+    compact_.reserve(align_up(tiles * (kRowTile / 64) * 8, 256) + align_up(tiles * 4, 256) +
+                     align_up(groups * 4, 256) + 256, 0, stream);
+    index_queue(stream);
+  } else {
+    qpos_.release();
+    hit_rep_.release();
+    qbits_.release();
+    compact_.release();
+  }
+}
+
+// qpos[] of a dense list
+void FeatureCache::index_queue(hipStream_t stream) {
+  if (!queue_form_ || !capacity_) return;
+  lru_queue_index_kernel<<<dim3(2048), dim3(256), 0, stream>>>(
+      queue_.as<uint32_t>(), queue_alt_.as<uint32_t>(), qstate_.as<QueueState>(),
+      qpos_.as<uint32_t>(), static_cast<uint32_t>(capacity_));
+  GF_HIP(hipGetLastError());
+}
+
+// Queue form: drops the dead entries (dense list in the other buffer, head = 0, tail = capacity)
+void FeatureCache::compact_queue(hipStream_t stream) {
+  if (!queue_form_ || tail_bound_ == capacity_) return;
+  const size_t tiles = (tail_bound_ + kRowTile - 1) / kRowTile;
+  const size_t groups = (tiles + kQGroup - 1) / kQGroup;
+  char* p = compact_.as<char>();
+  auto* live_bits = reinterpret_cast<unsigned long long*>(p);
+  p += align_up(((queue_cap_ + kRowTile - 1) / kRowTile + 1) * (kRowTile / 64) * 8, 256);
+  auto* tile_cnt = reinterpret_cast<uint32_t*>(p);
+  p += align_up(((queue_cap_ + kRowTile - 1) / kRowTile + 1) * 4, 256);
+  auto* group_sum = reinterpret_cast<uint32_t*>(p);
+  p += align_up((((queue_cap_ + kRowTile - 1) / kRowTile + 1 + kQGroup - 1) / kQGroup + 1) * 4, 256);
+  auto* st = reinterpret_cast<CompactState*>(p);
+  GF_HIP(hipMemsetAsync(group_sum, 0, groups * 4, stream));
+  const unsigned grid = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(tiles, 2048)));
+  lru_queue_compact_count_kernel<<<dim3(grid), dim3(kWide), 0, stream>>>(
+      queue_.as<uint32_t>(), queue_alt_.as<uint32_t>(), qstate_.as<QueueState>(),
+      qpos_.as<uint32_t>(), live_bits, tile_cnt, group_sum, st);
+  lru_queue_compact_write_kernel<<<dim3(grid), dim3(kWide), 0, stream>>>(
+      queue_.as<uint32_t>(), queue_alt_.as<uint32_t>(), qstate_.as<QueueState>(),
+      qpos_.as<uint32_t>(), live_bits, tile_cnt, group_sum, st,
+      static_cast<uint32_t>(capacity_));
+  GF_HIP(hipGetLastError());
+  tail_bound_ = capacity_;
 }
 
 // FIFOCache.reset (fifo_cache.py:70-75) rewinds the rotation pointer and keeps the cached
@@ -1312,6 +1756,11 @@ void FeatureCache::set_policy(int policy) {
   if (policy_ != GF_CACHE_LRU) {   // only LRU keeps a queue
     queue_.release();
     queue_alt_.release();
+    qpos_.release();
+    hit_rep_.release();
+    qbits_.release();
+    compact_.release();
+    queue_form_ = false;
   }
 }
 
@@ -1364,6 +1813,7 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
              "cache: invalid capacity");
   DeviceGuard dg(device_);
   if (d_feats) feats_ = d_feats;
+  if (policy_ == GF_CACHE_LRU && new_capacity > capacity_) compact_queue(stream);   // dense list
   if (new_num_ids > num_ids_) {
     DeviceBuffer nmap;
     nmap.reserve(new_num_ids * sizeof(int32_t));
@@ -1409,18 +1859,39 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
     GF_HIP(hipMemcpyAsync(&qs, qstate_.data(), sizeof(qs), hipMemcpyDeviceToHost, stream));
     GF_HIP(hipStreamSynchronize(stream));
     DeviceBuffer& cur = (qs.parity & 1u) ? queue_alt_ : queue_;
+    queue_form_ = new_capacity >= queue_min_capacity();
+    queue_cap_ = queue_form_ ? new_capacity + new_capacity / 2 + 64 : new_capacity;
     DeviceBuffer na, nb;
-    na.reserve(new_capacity * sizeof(uint32_t));
-    nb.reserve(new_capacity * sizeof(uint32_t));
+    na.reserve((queue_cap_ + 16) * sizeof(uint32_t));
+    nb.reserve((queue_cap_ + 16) * sizeof(uint32_t));
     list_fill_kernel<<<dim3(1024), dim3(256), 0, stream>>>(
         na.as<uint32_t>(), static_cast<uint32_t>(old_capacity),
         static_cast<uint32_t>(new_capacity - old_capacity), cur.as<uint32_t>(),
         static_cast<uint32_t>(old_capacity));
     GF_HIP(hipGetLastError());
-    GF_HIP(hipMemsetAsync(qstate_.data(), 0, sizeof(QueueState), stream));
+    const QueueState fresh{0u, 0u, static_cast<uint32_t>(new_capacity), 0u};
+    GF_HIP(hipMemcpyAsync(qstate_.data(), &fresh, sizeof(fresh), hipMemcpyHostToDevice, stream));
     GF_HIP(hipStreamSynchronize(stream));
     std::swap(queue_, na);
     std::swap(queue_alt_, nb);
+    tail_bound_ = new_capacity;
+    if (queue_form_) {
+      DeviceBuffer np, nh, nc, nbits;
+      np.reserve(new_capacity * sizeof(uint32_t));
+      nh.reserve(new_capacity * sizeof(uint32_t));
+      nbits.reserve(qbits_bytes(queue_cap_));
+      GF_HIP(hipMemsetAsync(nbits.data(), 0, qbits_bytes(queue_cap_), stream));
+      std::swap(qbits_, nbits);
+      const size_t tiles = (queue_cap_ + kRowTile - 1) / kRowTile + 1;
+      const size_t groups = (tiles + kQGroup - 1) / kQGroup + 1;
+      nc.reserve(align_up(tiles * (kRowTile / 64) * 8, 256) + align_up(tiles * 4, 256) +
+                 align_up(groups * 4, 256) + 256);
+      std::swap(qpos_, np);
+      std::swap(hit_rep_, nh);
+      std::swap(compact_, nc);
+      index_queue(stream);
+      GF_HIP(hipStreamSynchronize(stream));
+    }
   }
 }
 
@@ -1432,6 +1903,9 @@ void FeatureCache::reserve_workspace(size_t n, hipStream_t stream) {
   size_t bytes = (kBins1 + kBins2) * sizeof(uint32_t) + 4 * align_up(ws_rows_ * 4, 16) +
                  align_up(ws_rows_ * 8, 16) + 2 * align_up(tiles * 4, 16) +
                  align_up((kMaxRowTiles + 1) * 4, 16) + 64;
+  if (queue_form_ && policy_ == GF_CACHE_LRU)   // victim candidates per chunk, chunk counts
+    bytes += 2 * align_up((victim_chunks(ws_rows_) * kRowTile + ws_rows_) * 4, 256) +
+             align_up((victim_chunks(ws_rows_) + 2) * 4, 256) + 256;
   // Kernels already queued on `stream` may still use the old scratch: it is retired behind
   // an event on that stream and freed once the event has completed — a stream-ordered swap,
   // no device-wide stall when a larger block arrives mid-run.
@@ -1460,7 +1934,8 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
   c.rep_id = reinterpret_cast<int64_t*>(p);         p += align_up(ws_rows_ * 8, 16);
   c.tile_tie = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
   c.tile_old = reinterpret_cast<uint32_t*>(p);      p += align_up((tiles + 1) * 4, 16);
-  c.row_tile_sum = reinterpret_cast<uint32_t*>(p);
+  c.row_tile_sum = reinterpret_cast<uint32_t*>(p);  p += align_up((kMaxRowTiles + 1) * 4, 16);
+  char* qscratch = reinterpret_cast<char*>(align_up(reinterpret_cast<uintptr_t>(p), 256));
   c.ids = d_ids;
   c.n = static_cast<uint32_t>(n);
   c.vec4 = vec4_ok(dim_, buffer_.data(), feats_, d_out) ? 1 : 0;
@@ -1485,11 +1960,32 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
   ring_pos_++;
   c.stats = d_stats;
   if (c.update && policy_ == GF_CACHE_LRU) {
-    const size_t row_tiles = (n + kRowTile - 1) / kRowTile;
+    const size_t row_tiles = (n + kLruRows - 1) / kLruRows;
     c.tiles_per_wg = static_cast<uint32_t>((row_tiles + kMaxRowTiles - 1) / kMaxRowTiles);
     c.queue[0] = queue_.as<uint32_t>();
     c.queue[1] = queue_alt_.as<uint32_t>();
     c.qstate = qstate_.as<QueueState>();
+    if (queue_form_) {
+      c.qpos = qpos_.as<uint32_t>();
+      c.hit_rep = hit_rep_.as<uint32_t>();
+      if (n <= capacity_ / 4) {
+        // appends at most n entries (#distinct hit slots + #victims <= rows)
+        if (tail_bound_ + n > queue_cap_) compact_queue(stream);
+        tail_bound_ += n;
+        c.qmode = 1;
+        c.qbits = qbits_.as<uint32_t>();
+        c.v_chunks = static_cast<uint32_t>(victim_chunks(n));
+        const size_t stage = align_up((victim_chunks(ws_rows_) * kRowTile + ws_rows_) * 4, 256);
+        c.v_slot = reinterpret_cast<uint32_t*>(qscratch);
+        c.v_pos = reinterpret_cast<uint32_t*>(qscratch + stage);
+        c.v_count = reinterpret_cast<uint32_t*>(qscratch + 2 * stage);
+      } else {
+        // a block this large is cheaper in the list form: on the dense list, and qpos[] is
+        // rebuilt behind it
+        compact_queue(stream);
+        c.q_rebuild = 1;
+      }
+    }
   }
 }
 

@@ -73,7 +73,19 @@ class FeatureCache {
   DeviceBuffer touched_;   // uint32[capacity]  epoch of the last hit (pending)
   DeviceBuffer queue_, queue_alt_;   // uint32[capacity]  LRU: slots, least recently refreshed
                                      // first; two buffers, the device knows which is current
-  DeviceBuffer qstate_;    // LRU: parity of the current list buffer, device resident
+  DeviceBuffer qstate_;    // LRU: parity of the current list buffer (+ head / tail of the
+                           // queue form), device resident
+  // LRU of a large cache is kept as a queue with dead entries (feature_cache.hip, "LRU as a
+  // queue"): updates cost O(block rows), not O(capacity)
+  DeviceBuffer qpos_;      // uint32[capacity]  position of the slot's live queue entry
+  DeviceBuffer hit_rep_;   // uint32[capacity]  a row of the current block that hit the slot
+  DeviceBuffer qbits_;     // one bit per queue position: entries hit by the current block
+  DeviceBuffer compact_;   // scratch of the (rare) queue compaction
+  bool queue_form_ = false;
+  size_t queue_cap_ = 0;   // entries allocated per queue buffer (capacity if list form)
+  size_t tail_bound_ = 0;  // host-side upper bound of the device-resident queue tail
+  void compact_queue(hipStream_t stream);
+  void index_queue(hipStream_t stream);
   RetiredBuffers retired_; // scratch replaced while kernels may still use it
   DeviceBuffer state_;     // ring of per-fetch counter records
   DeviceBuffer fifo_ptr_;  // uint32: FIFO rotation pointer

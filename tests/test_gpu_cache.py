@@ -11,6 +11,20 @@ from tests.test_oracle_cache import Blk, load, policy_of, replay
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["list", "queue"])
+def lru_form(request, monkeypatch):
+    """Every test of this module runs twice: with the LRU order kept as a list (small caches)
+    and as a queue with dead entries (what caches of >= 2 M slots use; forced here by lowering
+    that bound to 1 slot, which also exercises its compaction every other update and the
+    fall-back to the list form for blocks of more than capacity / 4 rows).  Both must make
+    the oracle's decisions."""
+    if request.param == "queue":
+        monkeypatch.setenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", "1")
+    else:
+        monkeypatch.delenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", raising=False)
+    return request.param
+
+
 def _cls(policy):
     import gnnflow_amd.cache as caches
     return {"lru": caches.LRUCache, "lfu": caches.LFUCache, "fifo": caches.FIFOCache}[policy]
