@@ -123,6 +123,7 @@ PROTOTYPES = {
     "gf_gather_rows": (C.c_int, [_p, _sz, _sz, _p, _sz, _p, C.c_int, _p]),
     "gf_cache_slot_ids": (C.c_int, [_p, _p, _sz]),
     "gf_cache_mem_bytes": (C.c_int, [_p, C.POINTER(_sz)]),
+    "gf_cache_lru_state": (C.c_int, [_p, C.POINTER(C.c_uint64)]),
     "gf_partition_scratch_bytes": (C.c_int, [_sz, C.c_int, C.POINTER(_sz)]),
     "gf_partition_plan": (C.c_int, [_p, _p, _sz, C.c_int, C.c_int, _p, _p, _p, _p, _sz, C.c_int,
                                     _p]),

@@ -64,6 +64,14 @@ class _Kind:
         _capi.check(self.lib.gf_cache_mem_bytes(self.h, C.byref(n)))
         return n.value
 
+    def lru_state(self) -> dict:
+        """gf_cache_lru_state: form of the LRU order and its counters (diagnostics / tests)."""
+        out = (C.c_uint64 * 7)()
+        _capi.check(self.lib.gf_cache_lru_state(self.h, out))
+        keys = ("queue_form", "queue_entries", "head", "tail", "compactions",
+                "list_form_updates", "lone_walks")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def slot_ids(self) -> np.ndarray:
         out = np.zeros(self.capacity, np.int64)
         if self.capacity:

@@ -589,6 +589,13 @@ int gf_cache_slot_ids(const gf_cache* c, int64_t* out, size_t capacity) {
 int gf_cache_mem_bytes(const gf_cache* c, size_t* out) {
   return guarded([&] { GF_C(c); *out = c->impl.mem_bytes(); });
 }
+int gf_cache_lru_state(const gf_cache* c, uint64_t out[7]) {
+  return guarded([&] {
+    GF_C(c);
+    GF_REQUIRE(out != nullptr, "gf_cache_lru_state: null output");
+    c->impl.lru_state(out);
+  });
+}
 
 // ---- profiling ---------------------------------------------------------------------
 int gf_partition_scratch_bytes(size_t num_roots, int world_size, size_t* out) {

@@ -120,7 +120,7 @@ struct Counters {
 constexpr uint32_t kCounterWords = sizeof(Counters) / 4;
 
 // Everything one block fetch needs on the device.  `update` == 0: gather only.
-struct QueueState { uint32_t parity, head, tail, pad; };
+struct QueueState { uint32_t parity, head, tail, lone_walks; };
 
 struct Ctx {
   const int64_t* ids;
@@ -1025,8 +1025,10 @@ __global__ __launch_bounds__(kWide) void lru_queue_count_kernel(Round r) {
   uint32_t found = wide_sum(sum, ws);
   const uint32_t parity = c.ctr->q_parity;
   const uint32_t* list = c.queue[parity & 1u];
+  bool walked = false;
   for (uint32_t base = (head & ~3u) + chunks * kRowTile; base < tail && found < want;
        base += kRowTile) {
+    walked = true;
     const uint32_t p0 = base + tid * 4;
     uint32_t sl[4];
     const uint32_t mask = victim_walk4(c, list, head, tail, p0, sl);
@@ -1045,7 +1047,10 @@ __global__ __launch_bounds__(kWide) void lru_queue_count_kernel(Round r) {
     }
     found += total;
   }
-  if (tid == 0) c.ctr->q_found = min(found, want);
+  if (tid == 0) {
+    c.ctr->q_found = min(found, want);
+    if (walked) c.qstate->lone_walks += 1u;
+  }
 }
 
 // Applies the update; two kinds of workgroups:
@@ -1719,6 +1724,7 @@ void FeatureCache::compact_queue(hipStream_t stream) {
       static_cast<uint32_t>(capacity_));
   GF_HIP(hipGetLastError());
   tail_bound_ = capacity_;
+  ++compactions_;
 }
 
 // FIFOCache.reset (fifo_cache.py:70-75) rewinds the rotation pointer and keeps the cached
@@ -1984,6 +1990,7 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
         // rebuilt behind it
         compact_queue(stream);
         c.q_rebuild = 1;
+        ++list_form_updates_;
       }
     }
   }
@@ -2102,6 +2109,22 @@ void FeatureCache::slot_ids(int64_t* out, size_t capacity) const {
   DeviceGuard dg(device_);
   GF_HIP(hipDeviceSynchronize());
   GF_HIP(hipMemcpy(out, slot_id_.data(), capacity_ * sizeof(int64_t), hipMemcpyDeviceToHost));
+}
+
+void FeatureCache::lru_state(uint64_t out[7]) const {
+  for (int i = 0; i < 7; ++i) out[i] = 0;
+  if (policy_ != GF_CACHE_LRU || !capacity_) return;
+  DeviceGuard dg(device_);
+  GF_HIP(hipDeviceSynchronize());
+  QueueState qs;
+  GF_HIP(hipMemcpy(&qs, qstate_.data(), sizeof(qs), hipMemcpyDeviceToHost));
+  out[0] = queue_form_ ? 1 : 0;
+  out[1] = queue_cap_;
+  out[2] = qs.head;
+  out[3] = qs.tail;
+  out[4] = compactions_;
+  out[5] = list_form_updates_;
+  out[6] = qs.lone_walks;
 }
 
 size_t FeatureCache::mem_bytes() const {

@@ -49,6 +49,7 @@ class FeatureCache {
              hipStream_t stream);
   void gather_plain(const int64_t* d_ids, size_t n, float* d_out, hipStream_t stream);
   void slot_ids(int64_t* out, size_t capacity) const;
+  void lru_state(uint64_t out[7]) const;   // gf_cache_lru_state
   size_t mem_bytes() const;
   int device() const { return device_; }
 
@@ -84,6 +85,7 @@ class FeatureCache {
   bool queue_form_ = false;
   size_t queue_cap_ = 0;   // entries allocated per queue buffer (capacity if list form)
   size_t tail_bound_ = 0;  // host-side upper bound of the device-resident queue tail
+  uint64_t compactions_ = 0, list_form_updates_ = 0;
   void compact_queue(hipStream_t stream);
   void index_queue(hipStream_t stream);
   RetiredBuffers retired_; // scratch replaced while kernels may still use it

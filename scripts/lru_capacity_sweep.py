@@ -4,6 +4,7 @@ steady fraction of each block hits), capacity swept from the config-2 size to GD
 Prints one JSON line per capacity: µs per fetch with and without the update.
 
   python scripts/lru_capacity_sweep.py [--rows 30000] [--dim 16]
+  GNNFLOW_LRU_QUEUE_MIN_CAPACITY=4000000000 python scripts/lru_capacity_sweep.py   # list form only
 """
 import argparse
 import json
@@ -64,7 +65,8 @@ def main():
         print(json.dumps({"capacity": cap, "rows": args.rows, "dim": args.dim,
                           "us_per_fetch_with_update": round(out["update"], 1),
                           "us_per_fetch_lookup_only": round(out["lookup_only"], 1),
-                          "hit_ratio": round(float(cache.cache_edge_ratio), 3)}), flush=True)
+                          "lru_form": "queue" if cache._edge.lru_state()["queue_form"] else "list",
+                          "lru_state": cache._edge.lru_state()}), flush=True)
         del cache, feats
         torch.cuda.empty_cache()
 

@@ -440,3 +440,76 @@ def test_resize_grows_id_space_and_capacity_keeping_the_contents(policy):
         batch(N1, E1, bi)
     with pytest.raises(ValueError):        # the caller must supply tables that cover the new ids
         hip.resize(N1 + 50, E1)
+
+
+def _edge_only_pair(E, cap_ratio, d=4, seed=11):
+    import torch
+    from gnnflow_amd.cache import LRUCache
+    from oracle.cache_oracle import OracleLRUCache
+    ef = np.random.RandomState(seed).rand(E, d).astype(np.float32)
+    hip = LRUCache(cap_ratio, 0.0, 1, E, "cuda:0", None, torch.from_numpy(ef), 0, d)
+    ora = OracleLRUCache(cap_ratio, 0.0, 1, E, None, ef, 0, d, overflow_rule="first_seen")
+    hip.init_cache()
+    ora.init_cache()
+    return hip, ora, ef
+
+
+def _fetch_both(hip, ora, ef, ids, step):
+    ids = np.ascontiguousarray(ids, np.int64)
+    none = np.zeros(0, np.int64)
+    hb = [[Blk(_to_ids(none), _to_ids(ids))]]
+    ob = [[Blk(none, ids)]]
+    hip.fetch_feature(hb, None, target_edge_features=False)
+    ora.fetch_feature(ob, None)
+    assert np.array_equal(_to_np(hb[0][0].edata["f"]), ef[ids]), step
+    assert float(hip.cache_edge_ratio) == pytest.approx(ora.cache_edge_ratio, abs=1e-7), step
+    got = hip._edge.slot_ids()
+    assert np.array_equal(np.sort(got[got >= 0]), ora.edge.cached_ids()), step
+
+
+def test_dead_entries_right_behind_the_head(lru_form):
+    """Queue form: a block that hits ~14000 of the oldest entries but not the very oldest one
+    leaves 14000 dead entries right behind the new head; the next, small block needs more
+    victims than the three chunks (12288 entries) behind the head hold, so one workgroup has
+    to walk on alone.
+    (List form: the same sequence, same decisions.)"""
+    cap = 65536
+    hip, ora, ef = _edge_only_pair(E=4 * cap, cap_ratio=0.25)
+    assert hip.edge_capacity == cap
+    step = 0
+    # initial order = slot order = ids 0..cap-1
+    _fetch_both(hip, ora, ef, np.concatenate([np.arange(10, 14000), [cap + 0]]), step); step += 1
+    # 50 misses, 50 hits far from the head: victims = entries 1..9 and then beyond the dead run
+    _fetch_both(hip, ora, ef, np.concatenate([np.arange(cap + 1, cap + 51),
+                                              np.arange(60000, 60050)]), step); step += 1
+    st = hip._edge.lru_state()
+    assert st["queue_form"] == (1 if lru_form == "queue" else 0)
+    if lru_form == "queue":
+        assert st["lone_walks"] == 1 and st["head"] > 14000 and st["tail"] > cap
+    rng = np.random.RandomState(5)
+    for _ in range(6):
+        ids = np.concatenate([rng.randint(0, 4 * cap, 300), rng.randint(14000, 14200, 100)])
+        _fetch_both(hip, ora, ef, ids, step); step += 1
+
+
+def test_many_updates_cross_several_compactions(lru_form):
+    """400 updates of ~1000 rows on a 8192-slot cache: in the queue form the tail passes the
+    allocation (capacity * 3/2) every few updates and the queue is compacted; blocks of more
+    than capacity / 4 rows take the list form in between."""
+    cap = 8192
+    hip, ora, ef = _edge_only_pair(E=8 * cap, cap_ratio=0.125, seed=12)
+    assert hip.edge_capacity == cap
+    rng = np.random.RandomState(8)
+    for step in range(400):
+        n = 3000 if step % 37 == 36 else int(rng.randint(1, 2000))
+        lo = int(rng.randint(0, 7 * cap))
+        ids = np.concatenate([rng.randint(lo, lo + cap, n), rng.randint(0, 8 * cap, n // 8 + 1)])
+        _fetch_both(hip, ora, ef, ids, step)
+    st = hip._edge.lru_state()
+    if lru_form == "queue":
+        assert st["queue_form"] == 1 and st["queue_entries"] == cap + cap // 2 + 64
+        assert st["compactions"] >= 20 and st["list_form_updates"] >= 10
+        assert st["tail"] - st["head"] >= cap
+    else:
+        assert st == dict(queue_form=0, queue_entries=cap, head=0, tail=cap, compactions=0,
+                          list_form_updates=0, lone_walks=0)

@@ -194,11 +194,18 @@ class _StepView:
         return self._value
 
 
-def test_stepwise_cached_sets_and_alias_equivalence():
+@pytest.mark.parametrize("lru_form", ["list", "queue"])
+def test_stepwise_cached_sets_and_alias_equivalence(lru_form, monkeypatch):
     """Same loop with a host check after every step (cached-id sets at EVERY step), once with
     the prefix alias and once without: both must agree with the oracle, hence with each
-    other."""
+    other.  Also with the LRU order kept as a queue (the form of caches of >= 2 M slots,
+    forced here): the edge cache then appends, the node cache — blocks larger than a quarter
+    of its 2196 slots — goes through the list form and re-indexes, in the same launches."""
     from gnnflow_amd.pipeline import ReplayPipeline
+    if lru_form == "queue":
+        monkeypatch.setenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", "1")
+    else:
+        monkeypatch.delenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", raising=False)
     for alias in (True, False):
         w = _World(900, 48, prefix_alias=alias)
         pipe = ReplayPipeline(w.sampler, w.cache, w.dev_batches, w.dev, pipelined=True)
