@@ -8,8 +8,9 @@
 //     rank's own share is the contiguous suffix it samples locally while the exchange runs;
 //   * pos[i] = row of root i in that order (the merge kernel reads replies through it);
 //   * counts[P] = roots per owner.
-// Three short launches: per-tile owner histograms (wave ballots), one-workgroup scan of the
-// tile table, stable scatter.  Integer / byte work, HBM-bound, no atomics.
+// Layers of up to 32 768 roots: one launch (partition_plan_fused_kernel).  Larger ones: three
+// short launches — per-tile owner histograms (wave ballots), one-workgroup scan of the tile
+// table, stable scatter.  Integer / byte work, no atomics.
 #include "common.hpp"
 
 #include <cstdint>
@@ -21,23 +22,34 @@ namespace {
 constexpr int kTileThreads = 256;      // one root per thread per tile
 constexpr int kMaxParts = 64;
 
-__device__ inline uint32_t owner_of(int64_t v, uint32_t P) {
+// z mod P without the 64-bit division routine (~150 instructions on this ISA): with
+// m = floor(2^64 / P), q = mulhi(z, m) is floor(z / P) or one less, so one conditional
+// subtraction makes the remainder exact.  P == 1 (m does not fit): owner 0.
+struct OwnerDiv { uint32_t P; uint64_t m; };
+inline OwnerDiv owner_div(uint32_t P) {
+  return OwnerDiv{P, P > 1 ? static_cast<uint64_t>((static_cast<unsigned __int128>(1) << 64) / P) : 0};
+}
+__device__ inline uint32_t owner_of(int64_t v, OwnerDiv d) {
   uint64_t z = static_cast<uint64_t>(v) + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);
-  return static_cast<uint32_t>(z % P);
+  if (d.P == 1) return 0;
+  uint64_t r = z - __umul64hi(z, d.m) * d.P;
+  if (r >= d.P) r -= d.P;
+  return static_cast<uint32_t>(r);
 }
 
 // tile_counts[tile][o] = roots of owner o in the tile
 __global__ __launch_bounds__(kTileThreads) void partition_count_kernel(
     const int64_t* __restrict__ nodes, const uint64_t* __restrict__ d_R, uint64_t R_host,
-    uint32_t P, uint32_t* __restrict__ tile_counts) {
+    OwnerDiv od, uint32_t* __restrict__ tile_counts) {
+  const uint32_t P = od.P;
   __shared__ uint32_t wave_cnt[kTileThreads / 64][kMaxParts];
   const uint64_t R = d_R ? *d_R : R_host;   // device-resident count: a chained layer
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kTileThreads + threadIdx.x;
-  const uint32_t o = i < R ? owner_of(nodes[i], P) : P;   // P = "no root"
+  const uint32_t o = i < R ? owner_of(nodes[i], od) : P;   // P = "no root"
   for (uint32_t q = 0; q < P; ++q) {
     const unsigned long long m = __ballot(o == q);
     if (lane == 0) wave_cnt[wave][q] = __popcll(m);
@@ -100,15 +112,16 @@ __global__ __launch_bounds__(1024) void partition_scan_kernel(
 
 __global__ __launch_bounds__(kTileThreads) void partition_scatter_kernel(
     const int64_t* __restrict__ nodes, const float* __restrict__ ts,
-    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t P,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, OwnerDiv od,
     const uint32_t* __restrict__ tile_base, int64_t* __restrict__ requests,
     uint32_t* __restrict__ pos) {
+  const uint32_t P = od.P;
   __shared__ uint32_t wave_cnt[kTileThreads / 64][kMaxParts];
   const uint64_t R = d_R ? *d_R : R_host;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kTileThreads + threadIdx.x;
   const int64_t v = i < R ? nodes[i] : 0;
-  const uint32_t o = i < R ? owner_of(v, P) : P;
+  const uint32_t o = i < R ? owner_of(v, od) : P;
   uint32_t before_in_wave = 0;
   for (uint32_t q = 0; q < P; ++q) {
     const unsigned long long m = __ballot(o == q);
@@ -124,118 +137,98 @@ __global__ __launch_bounds__(kTileThreads) void partition_scatter_kernel(
   pos[i] = p;
 }
 
-// Small layers (<= 30 720 roots, <= 16 owners): the whole plan in ONE launch of one
-// workgroup — three launches and two kernel boundaries less than the tiled form, which at
-// batch-600 sizes is most of its time.  One CU has to touch every root, so every global access
-// is coalesced and everything per-root lives in LDS (one uint16 per root):
-//   1. thread t hashes roots t, t + 1024, ... (coalesced loads, all issued up front) and
-//      stores the owners in LDS;
-//   2. thread t counts the owners of the CONTIGUOUS roots [t*c, (t+1)*c) — contiguous chunks
-//      keep every owner's roots in their original order — in 16-bit fields packed four to a
-//      64-bit word; one workgroup scan per word gives its base inside every owner's run;
-//   3. it walks its chunk again and replaces each owner in LDS by the root's output row;
-//   4. coalesced again: root i's id / timestamp go to requests[row_i], pos[i] = row_i.
-constexpr int kSmallPlanThreads = 1024;
-constexpr uint32_t kSmallPlanRoots = 30 * 1024;
-constexpr uint32_t kSmallPlanParts = 16;
-constexpr uint32_t kSmallPlanLaunchRoots = 4096;   // largest layer that takes this path
+// Layers of up to 32 768 roots: the whole plan in ONE launch, no scratch, no kernel boundary.
+// A workgroup owns a tile of 1024 consecutive roots, and instead of waiting for the other
+// tiles' histograms it RECOUNTS them: it hashes every root of the layer itself (coalesced
+// 8-byte loads out of L2 — 20 workgroups x 160 KB for a 19 800-root layer — and ~10 integer
+// ops per root), keeping per owner the number of roots in the tiles before its own and in the
+// whole layer.  That is O(R^2 / 1024) hashes in all, 0.4 M for that layer: less time than one
+// kernel boundary, and three launches (count / scan / scatter: 11.4 us on the device, ~14 us
+// of host enqueue) become one.  Lane q of every wave keeps owner q's two counters, so up to 64
+// owners need no LDS atomics.
+constexpr int kFusedThreads = 1024;
+constexpr uint32_t kFusedPlanRoots = 32768;
 
-__global__ __launch_bounds__(kSmallPlanThreads) void partition_plan_small_kernel(
+__global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
     const int64_t* __restrict__ nodes, const float* __restrict__ ts,
-    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t P, uint32_t rank,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, OwnerDiv od, uint32_t rank,
     int64_t* __restrict__ requests, uint32_t* __restrict__ pos, uint64_t* __restrict__ counts) {
-  __shared__ uint16_t per_root[kSmallPlanRoots];   // owner, then output row
-  __shared__ unsigned long long wave_tot[kSmallPlanParts / 4][kSmallPlanThreads / 64];
-  __shared__ uint32_t start_s[kSmallPlanParts];
+  const uint32_t P = od.P;
+  __shared__ uint32_t s_before[kFusedThreads / 64][kMaxParts];
+  __shared__ uint32_t s_total[kFusedThreads / 64][kMaxParts];
+  __shared__ uint32_t s_tile[kFusedThreads / 64][kMaxParts];   // this tile, per wave
+  __shared__ uint32_t s_start[kMaxParts];                       // first output row per owner
   const uint32_t R = static_cast<uint32_t>(d_R ? *d_R : R_host);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr uint32_t kRounds = kSmallPlanRoots / kSmallPlanThreads;
-  // 1. owners, coalesced
-  {
-    int64_t v[kRounds];
+  const uint32_t tile = blockIdx.x;
+  if (tile * kFusedThreads >= R && !(tile == 0)) return;   // uniform; tile 0 still reports counts
+  // 1. every root of the layer, tile by tile; my own tile's owner stays in a register
+  uint32_t acc_before = 0, acc_total = 0;   // lane q: owner q, over the roots this WAVE hashed
+  uint32_t my_owner = P;
+  int64_t my_node = 0;
+  const uint32_t tiles = (R + kFusedThreads - 1) / kFusedThreads;
+  constexpr uint32_t kBatch = 8;   // tiles whose loads are in flight together
+  for (uint32_t k0 = 0; k0 < tiles; k0 += kBatch) {
+    int64_t v[kBatch];
 #pragma unroll
-    for (uint32_t k = 0; k < kRounds; ++k) {
-      const uint32_t i = k * kSmallPlanThreads + tid;
-      v[k] = i < R ? nodes[i] : 0;
+    for (uint32_t b = 0; b < kBatch; ++b) {
+      const uint32_t i = (k0 + b) * kFusedThreads + tid;
+      v[b] = i < R ? nodes[i] : 0;
     }
 #pragma unroll
-    for (uint32_t k = 0; k < kRounds; ++k) {
-      const uint32_t i = k * kSmallPlanThreads + tid;
-      if (i < R) per_root[i] = static_cast<uint16_t>(owner_of(v[k], P));
+    for (uint32_t b = 0; b < kBatch; ++b) {
+      const uint32_t k = k0 + b;
+      const uint32_t i = k * kFusedThreads + tid;
+      const uint32_t o = i < R ? owner_of(v[b], od) : P;   // P = "no root"
+      if (k == tile) { my_owner = o; my_node = v[b]; }
+      uint32_t mine = 0;
+      for (uint32_t q = 0; q < P; ++q) {
+        const uint32_t c = __popcll(__ballot(o == q));
+        mine = lane == static_cast<int>(q) ? c : mine;
+      }
+      acc_total += mine;
+      if (k < tile) acc_before += mine;
     }
+  }
+  if (lane < static_cast<int>(P)) {
+    s_before[wave][lane] = acc_before;
+    s_total[wave][lane] = acc_total;
+  }
+  // 2. my tile: roots of the same owner before me
+  uint32_t before_in_wave = 0;
+  for (uint32_t q = 0; q < P; ++q) {
+    const unsigned long long m = __ballot(my_owner == q);
+    if (lane == 0) s_tile[wave][q] = __popcll(m);
+    if (my_owner == q) before_in_wave = __popcll(m & ((1ull << lane) - 1ull));
   }
   __syncthreads();
-  // 2. per-thread counts over its contiguous chunk, packed; workgroup scan
-  const uint32_t c = (R + kSmallPlanThreads - 1) / kSmallPlanThreads;
-  const uint32_t i0 = min(R, tid * c), i1 = min(R, i0 + c);
-  const uint32_t words = (P + 3) / 4;
-  unsigned long long w[kSmallPlanParts / 4] = {0, 0, 0, 0};
-  for (uint32_t i = i0; i < i1; ++i) {
-    const uint32_t o = per_root[i];
-    const unsigned long long inc = 1ull << (16 * (o & 3));
-#pragma unroll
-    for (uint32_t j = 0; j < kSmallPlanParts / 4; ++j) w[j] += (o >> 2) == j ? inc : 0ull;
-  }
-  unsigned long long excl[kSmallPlanParts / 4], total[kSmallPlanParts / 4];
-  for (uint32_t j = 0; j < words; ++j) {
-    unsigned long long incl = w[j];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned long long up = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += up;
+  // 3. owner q's run starts behind the runs of the owners that precede it in the output order
+  //    (other owners ascending, then `rank`); thread q < P adds up the waves' counters
+  if (tid < static_cast<int>(P)) {
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < kFusedThreads / 64; ++w) {
+      before += s_before[w][tid];
+      total += s_total[w][tid];
     }
-    if (lane == 63) wave_tot[j][wave] = incl;
-    excl[j] = incl - w[j];
+    s_before[0][tid] = before;
+    s_total[0][tid] = total;
+    if (tile == 0) counts[tid] = total;
   }
   __syncthreads();
-  for (uint32_t j = 0; j < words; ++j) {
-    unsigned long long base = 0, tot = 0;
-    for (int x = 0; x < kSmallPlanThreads / 64; ++x) {
-      const unsigned long long v = wave_tot[j][x];
-      if (x < wave) base += v;
-      tot += v;
-    }
-    excl[j] += base;
-    total[j] = tot;
-  }
   if (tid == 0) {
     uint32_t at = 0;
-    for (uint32_t o = 0; o < P; ++o) {
-      const uint32_t n = static_cast<uint32_t>((total[o >> 2] >> (16 * (o & 3))) & 0xFFFFu);
-      counts[o] = n;
-      if (o != rank) { start_s[o] = at; at += n; }
-    }
-    start_s[rank] = at;
+    for (uint32_t o = 0; o < P; ++o)
+      if (o != rank) { s_start[o] = at; at += s_total[0][o]; }
+    s_start[rank] = at;
   }
   __syncthreads();
-  // 3. output row of every root of the chunk (in place of its owner)
-  unsigned long long seen[kSmallPlanParts / 4] = {0, 0, 0, 0};
-  for (uint32_t i = i0; i < i1; ++i) {
-    const uint32_t o = per_root[i];
-    const uint32_t sh = 16 * (o & 3);
-    unsigned long long e = 0, sn = 0;    // selects, not dynamic indexing: registers, no scratch
-#pragma unroll
-    for (uint32_t j = 0; j < kSmallPlanParts / 4; ++j) {
-      const bool mine = (o >> 2) == j;
-      e = mine ? excl[j] : e;
-      sn = mine ? seen[j] : sn;
-      seen[j] += mine ? (1ull << sh) : 0ull;
-    }
-    per_root[i] = static_cast<uint16_t>(start_s[o] + static_cast<uint32_t>((e >> sh) & 0xFFFFu) +
-                                        static_cast<uint32_t>((sn >> sh) & 0xFFFFu));
-  }
-  __syncthreads();
-  // 4. write-out, coalesced reads
-#pragma unroll
-  for (uint32_t k = 0; k < kRounds; ++k) {
-    const uint32_t i = k * kSmallPlanThreads + tid;
-    if (i < R) {
-      const uint32_t p = per_root[i];
-      requests[2 * static_cast<uint64_t>(p)] = nodes[i];
-      requests[2 * static_cast<uint64_t>(p) + 1] = static_cast<int64_t>(__float_as_uint(ts[i]));
-      pos[i] = p;
-    }
-  }
+  const uint32_t i = tile * kFusedThreads + tid;
+  if (i >= R) return;
+  uint32_t p = s_start[my_owner] + s_before[0][my_owner] + before_in_wave;
+  for (int w = 0; w < wave; ++w) p += s_tile[w][my_owner];
+  requests[2 * static_cast<uint64_t>(p)] = my_node;
+  requests[2 * static_cast<uint64_t>(p) + 1] = static_cast<int64_t>(__float_as_uint(ts[i]));
+  pos[i] = p;
 }
 
 }  // namespace
@@ -264,15 +257,15 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
   GF_REQUIRE(scratch_bytes >= partition_scratch_bytes(R_bound, world_size),
              "partition: scratch buffer too small");
   const uint32_t P = static_cast<uint32_t>(world_size);
-  static const bool small_plan = [] {
+  const OwnerDiv od = owner_div(P);
+  static const bool fused_plan = [] {
     const char* v = std::getenv("GNNFLOW_PARTITION_SMALL_PLAN");   // tests: 0 = tiled form only
     return !(v && std::atoi(v) == 0);
   }();
-  // one CU has to touch every root: measured 6.5 us at 1 800 roots (the tiled form: ~12) but
-  // 20-40 us at 19 800, so only the first layers of a sample take this path
-  if (small_plan && R_bound <= kSmallPlanLaunchRoots && P <= kSmallPlanParts) {
-    partition_plan_small_kernel<<<dim3(1), dim3(kSmallPlanThreads), 0, stream>>>(
-        d_nodes, d_ts, d_R, R_bound, P, static_cast<uint32_t>(rank), d_requests, d_pos, d_counts);
+  if (fused_plan && R_bound <= kFusedPlanRoots) {
+    const unsigned grid = static_cast<unsigned>((R_bound + kFusedThreads - 1) / kFusedThreads);
+    partition_plan_fused_kernel<<<dim3(grid), dim3(kFusedThreads), 0, stream>>>(
+        d_nodes, d_ts, d_R, R_bound, od, static_cast<uint32_t>(rank), d_requests, d_pos, d_counts);
     GF_HIP(hipGetLastError());
     return;
   }
@@ -281,12 +274,12 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
   uint32_t* tile_base = reinterpret_cast<uint32_t*>(
       static_cast<char*>(d_scratch) + align_up(tiles * world_size * sizeof(uint32_t), 16));
   partition_count_kernel<<<dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream>>>(
-      d_nodes, d_R, R_bound, P, tile_counts);
+      d_nodes, d_R, R_bound, od, tile_counts);
   partition_scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(tile_counts, tiles, P,
                                                             static_cast<uint32_t>(rank), tile_base,
                                                             d_counts);
   partition_scatter_kernel<<<dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream>>>(
-      d_nodes, d_ts, d_R, R_bound, P, tile_base, d_requests, d_pos);
+      d_nodes, d_ts, d_R, R_bound, od, tile_base, d_requests, d_pos);
   GF_HIP(hipGetLastError());
 }
 
