@@ -94,6 +94,7 @@ constexpr uint32_t kInstRows = 256;     // LRU: block rows per install workgroup
 // scattered loads per row, which a CU retires at ~one 64-line instruction per 64 cycles, so a
 // 20 k-row block wants 20 CUs on it, not 5 (kRowTile rows per workgroup).
 constexpr uint32_t kLruRows = 1024;
+constexpr uint32_t kMaxStageTiles = 1024;   // LRU list form: list tiles that stage their victims
 
 // One record per fetch.  hits / misses are accumulated once per workgroup into one of 8
 // shards that sit on separate 128-byte lines: same-address atomics retire at only
@@ -151,6 +152,12 @@ struct Ctx {
   uint32_t* hit_rep;        // [capacity] one of the rows that hit the slot in this block
   uint32_t* qbits;          // one bit per queue position: entry of a slot hit by this block
                             // (all zero between updates)
+  // list form: the first stage_tiles list tiles leave their not-hit entries (the victims, in
+  // list order) packed per tile in v_slot and — if that is the whole list — their hit entries
+  // in v_pos (the next victims when a block needs more slots than its hits leave over);
+  // 0: one workgroup walks the list instead (more than kMaxStageTiles tiles needed)
+  uint32_t stage_tiles;
+  int stage_hits;
   uint32_t v_chunks;        // victim walk: chunks of kRowTile queue entries behind the head
   uint32_t* v_slot;         // [(v_chunks * kRowTile) + n] candidates per chunk (+ the lone walk's)
   uint32_t* v_pos;          // their queue positions
@@ -185,6 +192,16 @@ __device__ inline uint32_t total_miss(const Counters* c) {
 #pragma unroll
   for (int i = 0; i < kShards; ++i) m += c->shard[i].n_miss;
   return m;
+}
+
+// LRU list form: a block that missed more rows than this finds its victims through the list
+// tiles' staged entries; fewer (one or two trips) are cheaper for the one-workgroup walk
+// (headline workload, ~5 k missed rows per block: 39.6-40.0 us per step with the walk,
+// 40.4-41.0 staged; 30 k-row blocks with 15-30 k misses: 37.7 us per fetch with the walk, 29.4
+// staged).  The same counter is read by both kernels, so they agree.
+constexpr uint32_t kStageMinWant = 8192;
+__device__ inline bool use_staged_victims(uint32_t stage_tiles, uint32_t missed_rows) {
+  return stage_tiles != 0 && missed_rows > kStageMinWant;
 }
 
 template <typename VecT> __device__ inline VecT vec_zero();
@@ -897,20 +914,53 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
   if (blockIdx.x < row_blocks + list_blocks) {
     if (c.qmode) return;   // queue form: nothing is proportional to the capacity
     const uint32_t list_tiles = (cap + kRowTile - 1) / kRowTile;
-    bool first = true;
+    if (blockIdx.x == row_blocks && tid == 0) c.ctr->q_parity = parity;
+    bool first = true, staged = false;
     for (uint32_t t = blockIdx.x - row_blocks; t < list_tiles; t += list_blocks) {
       const uint32_t p0 = t * kRowTile + tid * kItems;
-      uint32_t sl[kItems], local = 0;
-#pragma unroll
-      for (uint32_t j = 0; j < kItems; ++j) sl[j] = p0 + j < cap ? list[p0 + j] : 0u;
+      uint32_t sl[kItems], hit[kItems], local = 0;
       if (first) {
+        // the first tile is read from BOTH buffers while the parity word is still on its
+        // way (one dependent hop less on the kernel's critical chain)
+        uint32_t alt[kItems];
+#pragma unroll
+        for (uint32_t j = 0; j < kItems; ++j) {
+          sl[j] = p0 + j < cap ? c.queue[0][p0 + j] : 0u;
+          alt[j] = p0 + j < cap ? c.queue[1][p0 + j] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kItems; ++j) sl[j] = (parity & 1u) ? alt[j] : sl[j];
         first = false;
-        if (total_miss(c.ctr) == 0) return;   // uniform across the launch
+        const uint32_t missed = total_miss(c.ctr);
+        if (missed == 0) return;   // uniform across the launch
+        staged = use_staged_victims(c.stage_tiles, missed);
+      } else {
+#pragma unroll
+        for (uint32_t j = 0; j < kItems; ++j) sl[j] = p0 + j < cap ? list[p0 + j] : 0u;
       }
 #pragma unroll
-      for (uint32_t j = 0; j < kItems; ++j)
-        local += (p0 + j < cap && c.touched[sl[j]] == c.epoch_new) ? 1u : 0u;
-      const uint32_t total = wide_sum(local, ws);
+      for (uint32_t j = 0; j < kItems; ++j) {
+        hit[j] = (p0 + j < cap && c.touched[sl[j]] == c.epoch_new) ? 1u : 0u;
+        local += hit[j];
+      }
+      uint32_t total;
+      if (staged && t < c.stage_tiles) {
+        // the victims come off the FRONT of the list: the first tiles leave their not-hit
+        // entries packed, in list order (thread order = list order); the install kernel
+        // finds the m-th one through the per-tile hit counts
+        uint32_t before_hits = wide_excl_scan(local, ws, &total);
+        uint32_t at_keep = t * kRowTile + tid * kItems - before_hits;   // not-hit before me
+        uint32_t at_hit = t * kRowTile + before_hits;
+#pragma unroll
+        for (uint32_t j = 0; j < kItems; ++j) {
+          if (p0 + j < cap) {
+            if (!hit[j]) c.v_slot[at_keep++] = sl[j];
+            else if (c.stage_hits) c.v_pos[at_hit++] = sl[j];
+          }
+        }
+      } else {
+        total = wide_sum(local, ws);
+      }
       if (tid == 0) {
         c.tile_tie[t] = total;
         if (total) atomicAdd(&c.tile_old[t / kQGroup], total);   // zeroed by the gather
@@ -948,8 +998,8 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
     }
     return;
   }
-  if (blockIdx.x != row_blocks + list_blocks) return;
-  if (tid == 0) c.ctr->q_parity = parity;
+  if (blockIdx.x != row_blocks + list_blocks ||
+      use_staged_victims(c.stage_tiles, total_miss(c.ctr))) return;
   if (want == 0) return;
   uint32_t* kept = c.rep_row;     // victims: not-hit entries from the front of the list
   uint32_t* moved = c.rep_rank;   // hit entries passed on the way
@@ -1075,6 +1125,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
     // n / kInstRows workgroups with 4 rows' worth of loads in flight per installing thread
     __shared__ uint2 inst[kInstRows];   // {slot, row} installed by this workgroup
     __shared__ uint32_t n_inst;
+    __shared__ uint32_t s_keep[kMaxStageTiles], s_hitp[kMaxStageTiles], s_nonhit;
     const uint32_t span_rows = c.tiles_per_wg * kLruRows;
     const uint32_t chunks = (c.n + kInstRows - 1) / kInstRows;
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += row_blocks) {
@@ -1091,17 +1142,56 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
         if (t < w) pm += m;
       }
       const uint32_t q_found = c.ctr->q_found;
+      const bool staged = !c.qmode && use_staged_victims(c.stage_tiles, total_miss(c.ctr));
+      uint32_t stage_hit = 0, stage_len = 0, th_part = 0;
+      if (staged && chunk == blockIdx.x) {
+        // list form: hit counts of the tiles that staged their entries, and of the whole list
+        if (tid < static_cast<int>(c.stage_tiles)) {
+          stage_hit = c.tile_tie[tid];
+          stage_len = min(kRowTile, cap - tid * kRowTile);
+        }
+        const uint32_t groups = ((cap + kRowTile - 1) / kRowTile + kQGroup - 1) / kQGroup;
+        for (uint32_t g = tid; g < groups; g += kWide) th_part += c.tile_old[g];
+      }
       if (chunk == blockIdx.x && total_miss(c.ctr) == 0) return;   // uniform
       pm = wide_sum(pm, ws);
       tm = wide_sum(tm, ws);
+      if (staged && chunk == blockIdx.x) {
+        uint32_t unused;
+        const uint32_t th = wide_sum(th_part, ws);
+        const uint32_t keep_before = wide_excl_scan(stage_len - stage_hit, ws, &unused);
+        const uint32_t hit_before = wide_excl_scan(stage_hit, ws, &unused);
+        if (tid < static_cast<int>(kMaxStageTiles)) {
+          s_keep[tid] = keep_before;
+          s_hitp[tid] = hit_before;
+        }
+        if (tid == 0) s_nonhit = cap - th;
+      }
       if (tid == 0) n_inst = 0;
       __syncthreads();
       const uint32_t k = c.qmode ? min(min(tm, cap), q_found) : min(tm, cap);
       if (code & kRepMiss) {
         const uint32_t m = pm + (code & kRepRank);
         if (m < k) {
-          const uint32_t slot = m < q_found ? c.rep_row[m] : c.rep_rank[m - q_found];
-          const int64_t old = c.qmode ? c.rep_id[m] : c.slot_id[slot];
+          uint32_t slot;
+          int64_t old;
+          if (staged) {
+            // the m-th entry of (not-hit entries ++ hit entries), both in list order
+            const bool keep = m < s_nonhit;
+            const uint32_t x = keep ? m : m - s_nonhit;
+            const uint32_t* pref = keep ? s_keep : s_hitp;
+            uint32_t lo = 0, hi = c.stage_tiles;   // largest tile with pref[tile] <= x
+            while (hi - lo > 1) {
+              const uint32_t mid = (lo + hi) >> 1;
+              if (pref[mid] <= x) lo = mid; else hi = mid;
+            }
+            const uint32_t at = lo * kRowTile + (x - pref[lo]);
+            slot = (keep ? c.v_slot : c.v_pos)[at];
+            old = c.slot_id[slot];
+          } else {
+            slot = m < q_found ? c.rep_row[m] : c.rep_rank[m - q_found];
+            old = c.qmode ? c.rep_id[m] : c.slot_id[slot];
+          }
           if (old >= 0) c.map[old] = kAbsent;
           c.slot_id[slot] = id;
           c.map[id] = static_cast<int32_t>(slot);
@@ -1226,19 +1316,44 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
   constexpr uint32_t kItems = kRowTile / kWide;
   const uint32_t list_tiles = (cap + kRowTile - 1) / kRowTile;
   const uint32_t groups = (list_tiles + kQGroup - 1) / kQGroup;
+  // The first tile's entries are read from BOTH buffers right away, together with the parity
+  // word and the counts, and its touch marks before the sums: two dependent hops less on the
+  // kernel's critical chain.
+  const uint32_t t_first = blockIdx.x - row_blocks;
+  uint32_t sl0[kItems], tc0[kItems];
+  {
+    uint32_t alt[kItems];
+    const uint32_t p0 = t_first * kRowTile + tid * kItems;
+#pragma unroll
+    for (uint32_t j = 0; j < kItems; ++j) {
+      sl0[j] = p0 + j < cap ? c.queue[0][p0 + j] : 0u;
+      alt[j] = p0 + j < cap ? c.queue[1][p0 + j] : 0u;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kItems; ++j) sl0[j] = (parity & 1u) ? alt[j] : sl0[j];
+  }
   // #distinct misses and #hit slots of the whole block
   uint32_t tm = 0, th = 0;
   for (uint32_t t = tid; t < spans; t += kWide) tm += c.row_tile_sum[t];
   for (uint32_t g = tid; g < groups; g += kWide) th += c.tile_old[g];
   if (total_miss(c.ctr) == 0) return;   // block without a miss: the list stays as it is
+#pragma unroll
+  for (uint32_t j = 0; j < kItems; ++j) tc0[j] = c.touched[sl0[j]];
   tm = wide_sum(tm, ws);
   th = wide_sum(th, ws);
   const uint32_t k = min(tm, cap), n_kept = cap - th;
-  for (uint32_t t = blockIdx.x - row_blocks; t < list_tiles; t += list_blocks) {
+  for (uint32_t t = t_first; t < list_tiles; t += list_blocks) {
     const uint32_t p0 = t * kRowTile + tid * kItems;
-    uint32_t sl[kItems], hit[kItems], local = 0;
+    uint32_t sl[kItems], tc[kItems], hit[kItems], local = 0;
+    if (t == t_first) {
 #pragma unroll
-    for (uint32_t j = 0; j < kItems; ++j) sl[j] = p0 + j < cap ? list[p0 + j] : 0u;
+      for (uint32_t j = 0; j < kItems; ++j) { sl[j] = sl0[j]; tc[j] = tc0[j]; }
+    } else {
+#pragma unroll
+      for (uint32_t j = 0; j < kItems; ++j) sl[j] = p0 + j < cap ? list[p0 + j] : 0u;
+#pragma unroll
+      for (uint32_t j = 0; j < kItems; ++j) tc[j] = c.touched[sl[j]];
+    }
     // hit entries before this tile: whole groups, then the tiles of this tile's group
     uint32_t before = 0;
     const uint32_t g0 = t / kQGroup;
@@ -1246,7 +1361,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
     for (uint32_t u = g0 * kQGroup + tid; u < t; u += kWide) before += c.tile_tie[u];
 #pragma unroll
     for (uint32_t j = 0; j < kItems; ++j) {
-      hit[j] = (p0 + j < cap && c.touched[sl[j]] == c.epoch_new) ? 1u : 0u;
+      hit[j] = (p0 + j < cap && tc[j] == c.epoch_new) ? 1u : 0u;
       local += hit[j];
     }
     before = wide_sum(before, ws);
@@ -1425,6 +1540,25 @@ inline size_t queue_min_capacity() {
 // chunks of kRowTile queue entries the victim walk covers behind the head: twice the rows
 // of the block (at most that many victims are needed) + 2
 inline size_t victim_chunks(size_t n) { return (2 * n + kRowTile - 1) / kRowTile + 2; }
+
+// list form: blocks that need more list tiles than this for their victims fall back to the
+// one-workgroup walk (kMaxStageTiles: the install kernel keeps the tile prefix in LDS)
+inline size_t max_stage_tiles() {
+  static const size_t v = [] {
+    const char* e = std::getenv("GNNFLOW_LRU_STAGE_TILES_MAX");   // tuning / tests; 0: always walk
+    const size_t x = e ? static_cast<size_t>(std::atoll(e)) : kMaxStageTiles;
+    return std::min<size_t>(x, kMaxStageTiles);
+  }();
+  return v;
+}
+
+// entries of the victim staging arrays: list form — the tiles at the front of the list (at most
+// the whole list, at most kMaxStageTiles); queue form — the chunks behind the head
+inline size_t stage_entries(size_t n, size_t capacity) {
+  const size_t list_tiles = (capacity + kRowTile - 1) / kRowTile;
+  const size_t list_form = std::min<size_t>(std::min(list_tiles, victim_chunks(n)), kMaxStageTiles);
+  return std::max(list_form, victim_chunks(n)) * kRowTile + n;
+}
 
 // bitmap over the queue positions, in whole tiles of kRowTile words (+ one tile)
 inline size_t qbits_bytes(size_t queue_cap) {
@@ -1909,8 +2043,8 @@ void FeatureCache::reserve_workspace(size_t n, hipStream_t stream) {
   size_t bytes = (kBins1 + kBins2) * sizeof(uint32_t) + 4 * align_up(ws_rows_ * 4, 16) +
                  align_up(ws_rows_ * 8, 16) + 2 * align_up(tiles * 4, 16) +
                  align_up((kMaxRowTiles + 1) * 4, 16) + 64;
-  if (queue_form_ && policy_ == GF_CACHE_LRU)   // victim candidates per chunk, chunk counts
-    bytes += 2 * align_up((victim_chunks(ws_rows_) * kRowTile + ws_rows_) * 4, 256) +
+  if (policy_ == GF_CACHE_LRU)   // staged victims per list tile / queue chunk, chunk counts
+    bytes += 2 * align_up(stage_entries(ws_rows_, capacity_) * 4, 256) +
              align_up((victim_chunks(ws_rows_) + 2) * 4, 256) + 256;
   // Kernels already queued on `stream` may still use the old scratch: it is retired behind
   // an event on that stream and freed once the event has completed — a stream-ordered swap,
@@ -1971,6 +2105,17 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
     c.queue[0] = queue_.as<uint32_t>();
     c.queue[1] = queue_alt_.as<uint32_t>();
     c.qstate = qstate_.as<QueueState>();
+    {
+      const size_t stage = align_up(stage_entries(ws_rows_, capacity_) * 4, 256);
+      c.v_slot = reinterpret_cast<uint32_t*>(qscratch);
+      c.v_pos = reinterpret_cast<uint32_t*>(qscratch + stage);
+      c.v_count = reinterpret_cast<uint32_t*>(qscratch + 2 * stage);
+      // list form: the tiles at the front of the list that stage their entries
+      const size_t list_tiles = (capacity_ + kRowTile - 1) / kRowTile;
+      const size_t st = std::min(list_tiles, (2 * n + kRowTile - 1) / kRowTile + 2);
+      c.stage_tiles = st <= max_stage_tiles() ? static_cast<uint32_t>(st) : 0u;
+      c.stage_hits = st == list_tiles ? 1 : 0;
+    }
     if (queue_form_) {
       c.qpos = qpos_.as<uint32_t>();
       c.hit_rep = hit_rep_.as<uint32_t>();
@@ -1981,10 +2126,7 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
         c.qmode = 1;
         c.qbits = qbits_.as<uint32_t>();
         c.v_chunks = static_cast<uint32_t>(victim_chunks(n));
-        const size_t stage = align_up((victim_chunks(ws_rows_) * kRowTile + ws_rows_) * 4, 256);
-        c.v_slot = reinterpret_cast<uint32_t*>(qscratch);
-        c.v_pos = reinterpret_cast<uint32_t*>(qscratch + stage);
-        c.v_count = reinterpret_cast<uint32_t*>(qscratch + 2 * stage);
+        c.stage_tiles = 0;
       } else {
         // a block this large is cheaper in the list form: on the dense list, and qpos[] is
         // rebuilt behind it
