@@ -23,9 +23,10 @@ constexpr size_t kBlockSpace = 20;       // common.h:23-24 bytes per edge
 // when one chunk covers everything.  Ingest is host-bound (gathers through a permutation), so
 // the threads are what the 10^7-edge chunks of a graph build spend their time in.
 template <typename F>
-void parallel_for(size_t n, size_t grain, F&& fn) {
+void parallel_for(size_t n, size_t grain, unsigned max_threads, F&& fn) {
   static const unsigned hw = std::max(1u, std::min(12u, std::thread::hardware_concurrency()));
-  const size_t parts = std::min<size_t>(hw, (n + grain - 1) / std::max<size_t>(grain, 1));
+  const size_t parts = std::min<size_t>(std::min(hw, std::max(1u, max_threads)),
+                                        (n + grain - 1) / std::max<size_t>(grain, 1));
   if (parts <= 1) { fn(size_t(0), n); return; }
   std::vector<std::thread> th;
   std::exception_ptr err;
@@ -42,22 +43,23 @@ void parallel_for(size_t n, size_t grain, F&& fn) {
   if (err) std::rethrow_exception(err);
 }
 
+template <typename F>
+void parallel_for(size_t n, size_t grain, F&& fn) {
+  parallel_for(n, grain, ~0u, std::forward<F>(fn));
+}
+
 constexpr size_t kIngestChunk = 1 << 23; // edges per staging upload
 
 // The per-group passes of add_edges walk `nodes_` in increasing vertex order but with gaps:
-// nearly every group is a cache miss on its NodeState and a second one on its block list.
-// Two-stage software prefetch: the NodeState of the group 16 ahead, the tail of the block list
+// nearly every group is a cache miss on its NodeState (its newest block sits inline in it).
+// Software prefetch: the NodeState of the group 16 ahead, the tail of the block list
 // of the group 8 ahead (whose NodeState is in cache by then).
 template <typename Groups>
-inline void prefetch_groups(const std::vector<NodeState>& nodes, const Groups& groups, size_t g,
+inline void prefetch_groups(const NodeTable& nodes, const Groups& groups, size_t g,
                             size_t g_end) {
   if (g + 16 < g_end) {
     const size_t v = static_cast<size_t>(groups[g + 16].v);
     if (v < nodes.size()) __builtin_prefetch(&nodes[v], 1, 1);
-  }
-  if (g + 8 < g_end) {
-    const size_t v = static_cast<size_t>(groups[g + 8].v);
-    if (v < nodes.size() && !nodes[v].blocks.empty()) __builtin_prefetch(&nodes[v].blocks.back(), 1, 1);
   }
 }
 
@@ -179,10 +181,21 @@ GraphView EdgeStore::view() const {
 
 // ---- bookkeeping ----------------------------------------------------------------
 // dynamic_graph.cu:140-147 AddNodes
+void NodeTable::resize(size_t n) {
+  if (n <= size_) return;
+  const size_t have = chunks_.size(), want = (n + kChunk - 1) >> kShift;
+  chunks_.resize(want);
+  parallel_for(want - have, 1, [&](size_t c0, size_t c1) {
+    for (size_t c = c0; c < c1; ++c) chunks_[have + c].reset(new NodeState[kChunk]);
+  });
+  size_ = n;
+}
+
 void EdgeStore::add_nodes(int64_t max_node) {
   size_t need = static_cast<size_t>(max_node) + 1;
   if (any_node_ && need <= nodes_.size()) return;
   nodes_.resize(need);
+  if (need > seen_.capacity()) seen_.reserve(need + need / 4);
   seen_.resize(need, 0);
   if (need > table_cap_) {
     size_t cap = table_cap_ ? table_cap_ : 1024;
@@ -232,8 +245,16 @@ void EdgeStore::ensure_pool(uint64_t elems) {
   while (cap < elems) cap *= 2;
   // the whole used prefix [0, old bump) is preserved across the reallocation
   uint64_t keep = std::min<uint64_t>(pool_elems_, bump_);
+  const auto t0 = std::chrono::steady_clock::now();
   ts_pool_.reserve(cap * sizeof(float), keep * sizeof(float), stream_);
+  const auto t1 = std::chrono::steady_clock::now();
   nbr_pool_.reserve(cap * sizeof(EdgePair), keep * sizeof(EdgePair), stream_);
+  const auto t2 = std::chrono::steady_clock::now();
+  if (std::getenv("GNNFLOW_INGEST_PROFILE"))
+    std::fprintf(stderr, "ensure_pool: %llu -> %llu elems (keep %llu): ts %.1f ms, nbr %.1f ms\n",
+                 (unsigned long long)pool_elems_, (unsigned long long)cap, (unsigned long long)keep,
+                 std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                 std::chrono::duration<double, std::milli>(t2 - t1).count());
   pool_elems_ = cap;
 }
 
@@ -257,20 +278,27 @@ LogicalBlock EdgeStore::new_block(size_t size, BlockDelta* delta) {
 // go through a hash map.
 void EdgeStore::bump_eids(const int64_t* eids, size_t n) {
   int64_t mx = -1;
+  bool consecutive = n > 0;   // eids[i] == eids[0] + i for the whole batch (a running counter)
   {
     std::mutex mu;
     parallel_for(n, 1 << 16, [&](size_t i0, size_t i1) {
       int64_t m = -1;
-      for (size_t i = i0; i < i1; ++i) m = std::max(m, eids[i]);
+      bool run = true;
+      const int64_t base = eids[0] - 0;
+      for (size_t i = i0; i < i1; ++i) {
+        m = std::max(m, eids[i]);
+        run &= eids[i] == base + static_cast<int64_t>(i);
+      }
       std::lock_guard<std::mutex> lk(mu);
       mx = std::max(mx, m);
+      consecutive = consecutive && run;
     });
   }
   const uint64_t budget = 64 + 8 * (eids_inserted_ + n);   // dense only while reasonably full
   if (mx >= 0 && static_cast<uint64_t>(mx) >= eid_dense_.size() &&
       static_cast<uint64_t>(mx) < budget) {
     const size_t nsz = static_cast<size_t>(mx) + 1;
-    eid_dense_.resize(nsz, 0);
+    eid_dense_.resize(nsz);
     for (auto it = eid_sparse_.begin(); it != eid_sparse_.end();) {   // keep "eid <
       if (it->first >= 0 && static_cast<uint64_t>(it->first) < nsz) {  // dense.size() =>
         eid_dense_[it->first] += static_cast<uint32_t>(it->second);    // counted densely"
@@ -282,6 +310,19 @@ void EdgeStore::bump_eids(const int64_t* eids, size_t n) {
   }
   const uint64_t dense = eid_dense_.size();
   std::mutex mu;
+  if (consecutive && eids[0] >= 0 && static_cast<uint64_t>(eids[0]) + n <= dense) {
+    // the batch's ids are one run of the dense counters: every thread owns its part of the
+    // run, no locked read-modify-write (10^7 of those are ~50 ms on four threads)
+    const size_t first = static_cast<size_t>(eids[0]);
+    parallel_for(n, 1 << 16, [&](size_t i0, size_t i1) {
+      size_t fresh = 0;
+      for (size_t i = i0; i < i1; ++i) fresh += eid_dense_[first + i]++ == 0 ? 1 : 0;
+      std::lock_guard<std::mutex> lk(mu);
+      num_live_eids_ += fresh;
+    });
+    eids_inserted_ += n;
+    return;
+  }
   parallel_for(n, 1 << 16, [&](size_t i0, size_t i1) {
     size_t fresh = 0;
     std::vector<int64_t> sparse;
@@ -617,14 +658,9 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
       *nn += !(cur & 1);
       if (bits & 2) *ns += !(cur & 2);
     };
-    parallel_for(G, 1 << 14, [&](size_t g0, size_t g1) {
-      size_t nn = 0, ns = 0;
-      for (size_t g = g0; g < g1; ++g) mark(groups[g].v, 3, &nn, &ns);
-      std::lock_guard<std::mutex> lk(mu);
-      num_nodes_ += nn;
-      num_src_nodes_ += ns;
-    });
-    parallel_for(n, 1 << 16, [&](size_t i0, size_t i1) {
+    // (the sources are marked by pass A below, which visits every group anyway; a handful
+    // of threads here: the planning passes run at the same time)
+    parallel_for(n, 1 << 16, 4, [&](size_t i0, size_t i1) {
       size_t nn = 0, ns = 0;
       for (size_t i = i0; i < i1; ++i) mark(dst[i], 1, &nn, &ns);
       std::lock_guard<std::mutex> lk(mu);
@@ -642,18 +678,20 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   pt.mark("sets");
   // 4. plan: logical blocks, physical segments, one base destination per group.
   //    Pass A (parallel over groups — every group is another vertex): replay the block policy
-  //    and decide whether the vertex needs a larger segment.  Pass B (serial, only the groups
-  //    that do): the segment allocator.  Pass C (parallel): bases, live ranges.
+  //    and decide whether the vertex needs a larger segment.  Pass B (only the groups that do):
+  //    the segment allocator.  Pass C (parallel): bases, live ranges.
   std::vector<uint64_t> gbase(G);
   std::vector<uint64_t> newcap(G, 0);
   std::vector<Move> moves;
   std::vector<std::pair<uint64_t, uint64_t>> deferred_free;
   std::vector<int64_t> touched(G);
+  size_t planA_nodes = 0, planA_srcs = 0;   // added to the counters once the helper has joined
   {
     std::mutex mu;
-    size_t d_bytes_pos = 0, d_bytes_neg = 0, d_blocks = 0;
+    size_t d_bytes_pos = 0, d_bytes_neg = 0, d_blocks = 0, src_nodes_new = 0, src_srcs_new = 0;
     parallel_for(G, 1 << 13, [&](size_t g0, size_t g1) {
       BlockDelta delta;
+      size_t new_nodes = 0, new_srcs = 0;
       for (size_t g = g0; g < g1; ++g) {
         prefetch_groups(nodes_, groups, g, g1);
         const Group& gr = groups[g];
@@ -663,32 +701,91 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
         const uint64_t need = st.live_size + cnt;
         if (st.seg_cap == 0 || st.live_off + need > st.seg_cap)
           newcap[g] = pow2_ceil(std::max<uint64_t>(need, min_phys));
+        // bookkeeping sets, source side (dynamic_graph.cu:89-103): once per distinct source
+        uint8_t cur = __atomic_load_n(&seen_[gr.v], __ATOMIC_RELAXED);
+        if ((cur & 3) != 3) {
+          cur = __atomic_fetch_or(&seen_[gr.v], 3, __ATOMIC_RELAXED);
+          new_nodes += !(cur & 1);
+          new_srcs += !(cur & 2);
+        }
       }
       std::lock_guard<std::mutex> lk(mu);
       d_bytes_pos += delta.bytes_added;
       d_bytes_neg += delta.bytes_removed;
       d_blocks += delta.blocks_added;
+      src_nodes_new += new_nodes;
+      src_srcs_new += new_srcs;
     });
     logical_bytes_ += d_bytes_pos;
     logical_bytes_ -= d_bytes_neg;
     logical_blocks_ += d_blocks;
+    planA_nodes = src_nodes_new;
+    planA_srcs = src_srcs_new;
   }
   pt.mark("planA");
-  std::vector<uint32_t> grow;   // the groups whose vertex needs a (larger) segment
-  for (size_t g = 0; g < G; ++g)
-    if (newcap[g]) grow.push_back(static_cast<uint32_t>(g));
-  for (size_t k = 0; k < grow.size(); ++k) {
-    if (k + 16 < grow.size()) __builtin_prefetch(&nodes_[groups[grow[k + 16]].v], 1, 1);
-    const size_t g = grow[k];
-    NodeState& st = nodes_[groups[g].v];
-    const uint64_t ns = seg_alloc(newcap[g]);
-    if (st.seg_cap) {
-      if (st.live_size) moves.push_back({st.seg_start + st.live_off, ns, st.live_size});
-      deferred_free.emplace_back(st.seg_start, st.seg_cap);
+  // Pass B, the segment allocator, in parallel too: the requests of one size class are ranked
+  // in group order (per-chunk counts, then a prefix over the chunks); the first ones take the
+  // class's free list from its back — what seg_alloc() would have handed out — and the rest
+  // share one run off the bump pointer, class after class.  Where a segment lies is not
+  // observable, only that every vertex gets one of the right size.
+  {
+    constexpr size_t kChunk = 1 << 13;
+    const size_t nchunks = (G + kChunk - 1) / kChunk;
+    const size_t ncls = free_lists_.size();
+    std::vector<uint32_t> rank0(nchunks * ncls, 0);   // requests per (chunk, class), then ranks
+    parallel_for(nchunks, 1, [&](size_t c0, size_t c1) {
+      for (size_t c = c0; c < c1; ++c) {
+        uint32_t* cnt = &rank0[c * ncls];
+        const size_t g1 = std::min(G, (c + 1) * kChunk);
+        for (size_t g = c * kChunk; g < g1; ++g)
+          if (newcap[g]) cnt[log2_exact(newcap[g])]++;
+      }
+    });
+    std::vector<uint64_t> total(ncls, 0), from_free(ncls, 0), bump_base(ncls, 0);
+    for (size_t c = 0; c < nchunks; ++c)
+      for (size_t k = 0; k < ncls; ++k) {
+        const uint32_t here = rank0[c * ncls + k];
+        rank0[c * ncls + k] = static_cast<uint32_t>(total[k]);
+        total[k] += here;
+      }
+    uint64_t bump = bump_;
+    for (size_t k = 0; k < ncls; ++k) {
+      from_free[k] = std::min<uint64_t>(total[k], free_lists_[k].size());
+      bump_base[k] = bump;
+      bump += (total[k] - from_free[k]) << k;
     }
-    st.seg_start = ns;
-    st.seg_cap = newcap[g];
-    st.live_off = 0;
+    std::vector<std::vector<Move>> chunk_moves(nchunks);
+    std::vector<std::vector<std::pair<uint64_t, uint64_t>>> chunk_free(nchunks);
+    parallel_for(nchunks, 1, [&](size_t c0, size_t c1) {
+      std::vector<uint32_t> next(ncls);
+      for (size_t c = c0; c < c1; ++c) {
+        for (size_t k = 0; k < ncls; ++k) next[k] = rank0[c * ncls + k];
+        const size_t g1 = std::min(G, (c + 1) * kChunk);
+        for (size_t g = c * kChunk; g < g1; ++g) {
+          if (!newcap[g]) continue;
+          const int k = log2_exact(newcap[g]);
+          const uint64_t j = next[k]++;
+          const auto& fl = free_lists_[k];
+          const uint64_t ns = j < from_free[k] ? fl[fl.size() - 1 - j]
+                                               : bump_base[k] + ((j - from_free[k]) << k);
+          NodeState& st = nodes_[groups[g].v];
+          if (st.seg_cap) {
+            if (st.live_size) chunk_moves[c].push_back({st.seg_start + st.live_off, ns, st.live_size});
+            chunk_free[c].emplace_back(st.seg_start, st.seg_cap);
+          }
+          st.seg_start = ns;
+          st.seg_cap = newcap[g];
+          st.live_off = 0;
+        }
+      }
+    });
+    for (size_t k = 0; k < ncls; ++k)
+      free_lists_[k].resize(free_lists_[k].size() - from_free[k]);
+    bump_ = bump;
+    for (size_t c = 0; c < nchunks; ++c) {
+      moves.insert(moves.end(), chunk_moves[c].begin(), chunk_moves[c].end());
+      deferred_free.insert(deferred_free.end(), chunk_free[c].begin(), chunk_free[c].end());
+    }
   }
   pt.mark("planB");
   std::vector<uint64_t> dest;          // host path: per-edge destinations for the staging copy
@@ -710,9 +807,6 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   });
   GF_REQUIRE(bump_ <= pool_elems_, "add_edges: internal error: pool smaller than planned");
   pt.mark("planC");
-  if (sets_thread.t.joinable()) sets_thread.t.join();
-
-  pt.mark("join");
   // 5. device: relocate grown segments, then scatter the batch, then publish entries
   if (!moves.empty()) {
     size_t bytes = moves.size() * sizeof(MoveDesc);
@@ -765,6 +859,11 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   for (auto& f : deferred_free) seg_free(f.first, f.second);
   upload_entries(touched);  // ends with the stream sync of dynamic_graph.cu:135-137
   pt.mark("publish");
+  // the bookkeeping helper shares nothing with the device phase either: joined last
+  if (sets_thread.t.joinable()) sets_thread.t.join();
+  num_nodes_ += planA_nodes;
+  num_src_nodes_ += planA_srcs;
+  pt.mark("join");
   pt.report(n);
 }
 

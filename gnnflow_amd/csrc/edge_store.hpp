@@ -17,6 +17,10 @@
 #pragma once
 
 #include <cstdint>
+#include <algorithm>
+#include <new>
+#include <cstring>
+#include <cstdlib>
 #include <limits>
 #include <memory>
 #include <unordered_map>
@@ -61,6 +65,61 @@ struct LogicalBlock {
   float start_ts, end_ts;
 };
 
+// The chronological logical blocks of one vertex.  The ingest only ever looks at the NEWEST
+// block (fill it, or open another one), so that one sits inline in the vertex record — no heap
+// allocation for the many vertices with a single block, no second cache miss per vertex on
+// the planning passes; older blocks go to a vector that exists only once there are any.
+class BlockList {
+ public:
+  BlockList() = default;
+  BlockList(BlockList&& o) noexcept : tail_(o.tail_), older_(o.older_), n_(o.n_) {
+    o.older_ = nullptr;
+    o.n_ = 0;
+  }
+  BlockList& operator=(BlockList&& o) noexcept {
+    if (this != &o) {
+      delete older_;
+      tail_ = o.tail_; older_ = o.older_; n_ = o.n_;
+      o.older_ = nullptr; o.n_ = 0;
+    }
+    return *this;
+  }
+  BlockList(const BlockList& o) : tail_(o.tail_), n_(o.n_) {
+    if (o.older_) older_ = new std::vector<LogicalBlock>(*o.older_);
+  }
+  BlockList& operator=(const BlockList& o) {
+    if (this != &o) { BlockList tmp(o); *this = std::move(tmp); }
+    return *this;
+  }
+  ~BlockList() { delete older_; }
+
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  LogicalBlock& back() { return tail_; }
+  const LogicalBlock& back() const { return tail_; }
+  LogicalBlock& operator[](size_t i) { return i + 1 == n_ ? tail_ : (*older_)[i]; }
+  const LogicalBlock& operator[](size_t i) const { return i + 1 == n_ ? tail_ : (*older_)[i]; }
+  void push_back(const LogicalBlock& b) {
+    if (n_ > 0) {
+      if (!older_) older_ = new std::vector<LogicalBlock>();
+      older_->push_back(tail_);
+    }
+    tail_ = b;
+    ++n_;
+  }
+  void clear() {
+    delete older_;
+    older_ = nullptr;
+    n_ = 0;
+  }
+  size_t heap_bytes() const { return older_ ? older_->capacity() * sizeof(LogicalBlock) : 0; }
+
+ private:
+  LogicalBlock tail_{};
+  std::vector<LogicalBlock>* older_ = nullptr;
+  uint32_t n_ = 0;
+};
+
 struct NodeState {
   uint64_t seg_start = 0, seg_cap = 0;   // physical segment (elements)
   uint64_t live_off = 0, live_size = 0;  // live range inside the segment
@@ -69,8 +128,52 @@ struct NodeState {
   float last_ts = -std::numeric_limits<float>::infinity();
   uint32_t first_block = 0;              // blocks[first_block..] are live
   uint32_t saved_blocks = 0;             // offload-to-file counter
-  std::vector<LogicalBlock> blocks;      // oldest first
+  BlockList blocks;                      // oldest first
   size_t num_blocks() const { return blocks.size() - first_block; }
+};
+
+// Zero-initialised uint32 counters in chunks of 2^22 that never move: calloc hands out
+// untouched zero pages, so a batch that extends the edge-id counters by 10^7 entries pays
+// neither a serial 40 MB memset nor a copy of the old ones — only for the pages it actually
+// increments, on the threads that do.
+class ZeroedU32 {
+ public:
+  static constexpr size_t kShift = 22, kChunk = size_t(1) << kShift, kMask = kChunk - 1;
+  ZeroedU32() = default;
+  ZeroedU32(const ZeroedU32&) = delete;
+  ZeroedU32& operator=(const ZeroedU32&) = delete;
+  ~ZeroedU32() { for (uint32_t* c : chunks_) std::free(c); }
+  size_t size() const { return size_; }
+  uint32_t& operator[](size_t i) { return chunks_[i >> kShift][i & kMask]; }
+  const uint32_t& operator[](size_t i) const { return chunks_[i >> kShift][i & kMask]; }
+  void resize(size_t n) {   // grows only
+    if (n <= size_) return;
+    const size_t want = (n + kChunk - 1) >> kShift;
+    while (chunks_.size() < want) {
+      uint32_t* c = static_cast<uint32_t*>(std::calloc(kChunk, sizeof(uint32_t)));
+      if (!c) throw std::bad_alloc();
+      chunks_.push_back(c);
+    }
+    size_ = n;
+  }
+ private:
+  std::vector<uint32_t*> chunks_;
+  size_t size_ = 0;
+};
+
+// Per-vertex host records, in chunks of 2^16 vertices that never move: growing the id space
+// constructs only the new chunks (in parallel — 1 GB of records for 10 M vertices is 190 ms of
+// page faults on one thread), and no growth ever relocates the records of existing vertices.
+class NodeTable {
+ public:
+  static constexpr size_t kShift = 16, kChunk = size_t(1) << kShift, kMask = kChunk - 1;
+  size_t size() const { return size_; }
+  NodeState& operator[](size_t v) { return chunks_[v >> kShift][v & kMask]; }
+  const NodeState& operator[](size_t v) const { return chunks_[v >> kShift][v & kMask]; }
+  void resize(size_t n);   // grows only (edge_store.hip)
+ private:
+  std::vector<std::unique_ptr<NodeState[]>> chunks_;
+  size_t size_ = 0;
 };
 
 class EdgeStore {
@@ -134,12 +237,12 @@ class EdgeStore {
   PinnedBuffer order_pinned_; // device-ordered batch: group table + sorted timestamps (host)
 
   // host state
-  std::vector<NodeState> nodes_;
+  NodeTable nodes_;
   std::vector<uint8_t> seen_;  // bit0: in nodes_, bit1: in src_nodes_
   size_t max_node_id_ = 0;
   bool any_node_ = false;
   size_t num_nodes_ = 0, num_src_nodes_ = 0;
-  std::vector<uint32_t> eid_dense_;
+  ZeroedU32 eid_dense_;
   std::unordered_map<int64_t, uint64_t> eid_sparse_;
   size_t num_live_eids_ = 0;
   uint64_t eids_inserted_ = 0;
