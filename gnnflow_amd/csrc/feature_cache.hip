@@ -127,7 +127,11 @@ struct Ctx {
   const int64_t* ids;
   uint32_t n;
   int vec4;                 // rows are float4-addressable
-  uint32_t dimv;            // row length in float4s (vec4) or floats
+  uint32_t dimv;            // row length in float4s (vec4 / odd4) or floats
+  // rows of dim % 4 != 0 floats (GDELT: 413 / 186) or misaligned bases: dimv 16-byte vectors
+  // at 4-byte alignment + `tail` floats per row, rows `dim` floats apart
+  int odd4;
+  uint32_t dim, tail;
   uint32_t tile_rows;       // rows per wave in the gather
   uint32_t inflight;        // 16-byte loads a lane keeps in flight while copying a tile
   float* out;
@@ -204,12 +208,17 @@ __device__ inline bool use_staged_victims(uint32_t stage_tiles, uint32_t missed_
   return stage_tiles != 0 && missed_rows > kStageMinWant;
 }
 
+// a float4 that is only 4-byte aligned: global memory takes unaligned 16-byte accesses, a
+// wave's 1 KB run then touches 9 lines instead of 8
+typedef float uf4 __attribute__((ext_vector_type(4), aligned(4)));
+
 template <typename VecT> __device__ inline VecT vec_zero();
+template <> __device__ inline uf4 vec_zero<uf4>() { return uf4{0.f, 0.f, 0.f, 0.f}; }
 template <> __device__ inline float vec_zero<float>() { return 0.0f; }
 template <> __device__ inline float4 vec_zero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ---- the gather kernel -------------------------------------------------------------
-template <typename VecT>
+template <typename VecT, bool kOdd = false>
 __device__ inline void gather_body(const Ctx& c) {
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * kThreads + threadIdx.x;
@@ -226,10 +235,14 @@ __device__ inline void gather_body(const Ctx& c) {
     uint32_t* nxt = reinterpret_cast<uint32_t*>(c.ctr_next);
     for (uint32_t i = gtid; i < kCounterWords; i += nthreads) nxt[i] = 0;
   }
-  const VecT* feats = reinterpret_cast<const VecT*>(c.feats);
-  const VecT* cache_buf = reinterpret_cast<const VecT*>(c.cache_buf);
-  VecT* out = reinterpret_cast<VecT*>(c.out);
+  // row stride in units of VecT — or, for odd rows, in floats (rowu) with VecT at any float
+  using Unit = std::conditional_t<kOdd, float, VecT>;
+  constexpr uint32_t kVF = kOdd ? 4u : 1u;   // Units per VecT
+  const Unit* feats = reinterpret_cast<const Unit*>(c.feats);
+  const Unit* cache_buf = reinterpret_cast<const Unit*>(c.cache_buf);
+  Unit* out = reinterpret_cast<Unit*>(c.out);
   const uint32_t dimv = c.dimv, tile_rows = c.tile_rows, n = c.n;
+  const uint32_t rowu = kOdd ? c.dim : c.dimv;
   const uint32_t wave = gtid >> 6;
   const uint32_t num_waves = nthreads >> 6;
   const uint32_t tiles = (n + tile_rows - 1) / tile_rows;
@@ -237,14 +250,14 @@ __device__ inline void gather_body(const Ctx& c) {
   for (uint32_t tile = wave; tile < tiles; tile += num_waves) {
     const uint32_t row0 = tile * tile_rows;
     const uint32_t rows = min(tile_rows, n - row0);
-    const VecT* src = nullptr;
+    const Unit* src = nullptr;
     int32_t slot = -2;
     if (lane < static_cast<int>(rows)) {
       const int64_t id = c.ids[row0 + lane];
       if (id >= 0 && static_cast<uint64_t>(id) < c.num_ids) {
         slot = c.map ? c.map[id] : -1;
         if (slot >= 0) {
-          src = cache_buf + static_cast<uint64_t>(slot) * dimv;
+          src = cache_buf + static_cast<uint64_t>(slot) * rowu;
           // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
           // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161).
           if (c.update && c.policy != GF_CACHE_FIFO) c.touched[slot] = c.epoch_new;
@@ -254,9 +267,9 @@ __device__ inline void gather_body(const Ctx& c) {
         } else {
           slot = -1;
           src = c.miss_rows
-                    ? reinterpret_cast<const VecT*>(c.miss_rows) +
-                          static_cast<uint64_t>(c.miss_index[row0 + lane]) * dimv
-                    : feats + static_cast<uint64_t>(id) * dimv;
+                    ? reinterpret_cast<const Unit*>(c.miss_rows) +
+                          static_cast<uint64_t>(c.miss_index[row0 + lane]) * rowu
+                    : feats + static_cast<uint64_t>(id) * rowu;
           if (c.update) atomicMax(&c.map[id], -static_cast<int32_t>(row0 + lane + 1));
         }
       }
@@ -266,16 +279,17 @@ __device__ inline void gather_body(const Ctx& c) {
     acc_miss += __popcll(__ballot(slot == -1));
     const uint64_t src_bits = reinterpret_cast<uint64_t>(src);
     const uint32_t total = rows * dimv;
-    VecT* o = out + static_cast<uint64_t>(row0) * dimv;
+    Unit* o = out + static_cast<uint64_t>(row0) * rowu;
     // The loop trip count is wave-uniform and every lane executes the cross-lane read:
     // ds_bpermute returns 0 for a source lane that EXEC has switched off, so the
     // row-base broadcast must never sit under a per-lane condition.
-    auto load = [&](uint32_t fu, bool* valid) -> VecT {
+    auto load = [&](uint32_t fu, bool* valid, uint32_t* at) -> VecT {
       *valid = fu < total;
       const uint32_t r = *valid ? fu / dimv : 0u;
       const uint32_t cc = fu - r * dimv;
-      const VecT* s = reinterpret_cast<const VecT*>(__shfl(src_bits, r, 64));
-      return (*valid && s) ? s[cc] : vec_zero<VecT>();
+      *at = r * rowu + cc * kVF;   // where it goes, in Units from the tile's first row
+      const Unit* s = reinterpret_cast<const Unit*>(__shfl(src_bits, r, 64));
+      return (*valid && s) ? *reinterpret_cast<const VecT*>(s + cc * kVF) : vec_zero<VecT>();
     };
     // K independent 16-byte loads in flight per lane, then the stores.  (12 covers a whole
     // 16-row tile of 172-d rows in one trip; measured 14.8-14.9 us per launch against 15.5-15.7
@@ -286,16 +300,29 @@ __device__ inline void gather_body(const Ctx& c) {
       for (uint32_t base = 0; base < total; base += 64 * K) {
         VecT v[K];
         bool p[K];
+        uint32_t at[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = load(base + lane + 64 * k, &p[k]);
+        for (int k = 0; k < K; ++k) v[k] = load(base + lane + 64 * k, &p[k], &at[k]);
 #pragma unroll
         for (int k = 0; k < K; ++k)
-          if (p[k]) o[base + lane + 64 * k] = v[k];
+          if (p[k]) *reinterpret_cast<VecT*>(o + at[k]) = v[k];
       }
     };
     if (c.inflight >= 12) copy(std::integral_constant<int, 12>{});
     else if (c.inflight >= 8) copy(std::integral_constant<int, 8>{});
     else copy(std::integral_constant<int, 4>{});
+    if constexpr (kOdd) {
+      // the last dim % 4 floats of every row
+      const uint32_t tail = max(c.tail, 1u), total_t = rows * c.tail;
+      for (uint32_t base = 0; base < total_t; base += 64) {
+        const uint32_t ft = base + lane;
+        const bool valid = ft < total_t;
+        const uint32_t r = valid ? ft / tail : 0u;
+        const uint32_t t = ft - r * tail;
+        const float* sp = reinterpret_cast<const float*>(__shfl(src_bits, r, 64));
+        if (valid) o[r * rowu + dimv * 4 + t] = sp ? sp[dimv * 4 + t] : 0.0f;
+      }
+    }
   }
   if (c.ctr) {
     __shared__ uint32_t wg_hits, wg_miss;
@@ -320,6 +347,7 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
   if (c.n == 0) return;
   if (c.vec4) gather_body<float4>(c);
+  else if (c.odd4) gather_body<uf4, true>(c);
   else gather_body<float>(c);
 }
 
@@ -1216,6 +1244,24 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
           buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] = v;
           if (f2 < total) buf[static_cast<uint64_t>(pr2.x) * c.dimv + cc2] = v2;
         }
+      } else if (c.odd4) {
+        for (uint32_t f = tid; f < total; f += 2 * kWide) {
+          const uint32_t f2 = f + kWide;
+          const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
+          const uint32_t j2 = f2 < total ? f2 / c.dimv : j, cc2 = f2 < total ? f2 - j2 * c.dimv : cc;
+          const uint2 pr = inst[j], pr2 = inst[j2];
+          const uf4 v = *reinterpret_cast<const uf4*>(c.out + static_cast<uint64_t>(pr.y) * c.dim + cc * 4);
+          const uf4 v2 = *reinterpret_cast<const uf4*>(c.out + static_cast<uint64_t>(pr2.y) * c.dim + cc2 * 4);
+          *reinterpret_cast<uf4*>(c.cache_buf + static_cast<uint64_t>(pr.x) * c.dim + cc * 4) = v;
+          if (f2 < total)
+            *reinterpret_cast<uf4*>(c.cache_buf + static_cast<uint64_t>(pr2.x) * c.dim + cc2 * 4) = v2;
+        }
+        const uint32_t total_t = n_inst * c.tail, tl = max(c.tail, 1u);
+        for (uint32_t f = tid; f < total_t; f += kWide) {
+          const uint32_t j = f / tl, t = c.dimv * 4 + (f - j * tl);
+          const uint2 pr = inst[j];
+          c.cache_buf[static_cast<uint64_t>(pr.x) * c.dim + t] = c.out[static_cast<uint64_t>(pr.y) * c.dim + t];
+        }
       } else {
         for (uint32_t f = tid; f < total; f += kWide) {
           const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
@@ -1523,6 +1569,24 @@ __global__ void cache_probe_kernel(const int64_t* __restrict__ ids, uint64_t n,
   }
 }
 
+// rows that are not float4-addressable (dim % 4 != 0, or a misaligned base) still move as
+// 16-byte vectors at 4-byte alignment plus a per-row tail; `allowed`: the kernels that will see
+// this context know the mode (the LFU / FIFO install does not)
+inline void set_odd4(Ctx& c, size_t dim, bool allowed) {
+  c.dim = static_cast<uint32_t>(dim);
+  c.odd4 = 0;
+  c.tail = 0;
+  if (c.vec4 || !allowed || dim < 8) return;
+  static const bool enabled = [] {
+    const char* v = std::getenv("GNNFLOW_GATHER_ODD_VEC4");   // tuning / tests; 0 = scalar rows
+    return !(v && std::atoi(v) == 0);
+  }();
+  if (!enabled) return;
+  c.odd4 = 1;
+  c.dimv = static_cast<uint32_t>(dim / 4);
+  c.tail = static_cast<uint32_t>(dim % 4);
+}
+
 inline bool vec4_ok(size_t dim, const void* a, const void* b, const void* c) {
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   return dim % 4 == 0 && al(a) && al(b) && al(c);
@@ -1705,6 +1769,7 @@ Ctx plain_ctx(const float* feats, size_t num_rows, size_t dim, const int64_t* id
   c.n = static_cast<uint32_t>(n);
   c.vec4 = vec4_ok(dim, feats, out, out) ? 1 : 0;
   c.dimv = static_cast<uint32_t>(c.vec4 ? dim / 4 : dim);
+  set_odd4(c, dim, true);
   c.tile_rows = pick_tile_rows(n);
   c.inflight = pick_inflight();
   c.out = out;
@@ -2080,6 +2145,7 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
   c.n = static_cast<uint32_t>(n);
   c.vec4 = vec4_ok(dim_, buffer_.data(), feats_, d_out) ? 1 : 0;
   c.dimv = static_cast<uint32_t>(c.vec4 ? dim_ / 4 : dim_);
+  set_odd4(c, dim_, policy_ == GF_CACHE_LRU || !update || capacity_ == 0);
   c.tile_rows = pick_tile_rows(n);
   c.inflight = pick_inflight();
   c.out = d_out;
@@ -2176,6 +2242,7 @@ void FeatureCache::fetch_pulled(const int64_t* d_ids, size_t n, float* d_out, bo
   if (r.c[0].vec4 && (reinterpret_cast<uintptr_t>(d_miss_rows) & 15u)) {
     r.c[0].vec4 = 0;
     r.c[0].dimv = static_cast<uint32_t>(dim_);
+    set_odd4(r.c[0], dim_, policy_ == GF_CACHE_LRU || !update || capacity_ == 0);
   }
   launch_round(r, stream);
 }
