@@ -1326,6 +1326,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
         __syncthreads();
         const uint32_t pos0 = static_cast<uint32_t>((t0 + t) * kWide) << 5;
         const uint32_t bit = tid & 31u, below = (1u << bit) - 1u;
+#pragma unroll 1   // fully unrolled, the 32 loads' registers spill (128 VGPRs at 1024 threads)
         for (uint32_t j0 = 0; j0 < 32; j0 += 8) {
           uint32_t slot[8], at[8];
 #pragma unroll
