@@ -149,6 +149,7 @@ struct Ctx {
   uint32_t* queue[2];       // LRU: the slots, least recently refreshed first (double buffer)
   QueueState* qstate;       // LRU: which buffer is current, device resident
   uint32_t tiles_per_wg;    // LRU: row tiles per scan workgroup (1 unless > 1M rows)
+  uint32_t inst_rows;       // LRU: block rows per install workgroup (kInstRows or kWide)
   // LRU of a LARGE cache (queue form, see "LRU as a queue" below); qmode == 0: list form
   int qmode;                // this update appends to the queue instead of rewriting the list
   int q_rebuild;            // list-form update of a queue-capable cache: rebuild qpos afterwards
@@ -1131,6 +1132,39 @@ __global__ __launch_bounds__(kWide) void lru_queue_count_kernel(Round r) {
   }
 }
 
+// Copies the rows a workgroup installed — inst[j] = {slot, row} — from the block's output into
+// the cache, as one flat array of 16-byte vectors, kWide threads, K loads in flight per thread
+// (rows of `rowf` floats; VecT float4 for 16-byte-aligned rows, uf4 otherwise).
+template <typename VecT, int K>
+__device__ inline void copy_installed(const Ctx& c, const uint2* inst, uint32_t n_inst,
+                                      uint32_t rowf, int tid) {
+  const uint32_t total = n_inst * c.dimv;
+#pragma unroll 1
+  for (uint32_t f0 = tid; f0 < total; f0 += K * kWide) {
+    float4 v[K];   // (an array of the under-aligned uf4 would live in scratch)
+    uint32_t dj[K], dc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t f = f0 + k * kWide;
+      const bool ok = f < total;
+      const uint32_t j = ok ? f / c.dimv : 0u, cc = ok ? f - j * c.dimv : 0u;
+      const uint2 pr = inst[j];
+      dj[k] = ok ? pr.x : ~0u;
+      dc[k] = cc;
+      const VecT t = *reinterpret_cast<const VecT*>(c.out + static_cast<uint64_t>(pr.y) * rowf + cc * 4);
+      v[k] = make_float4(t.x, t.y, t.z, t.w);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (dj[k] != ~0u) {
+        VecT t;
+        t.x = v[k].x; t.y = v[k].y; t.z = v[k].z; t.w = v[k].w;
+        *reinterpret_cast<VecT*>(c.cache_buf + static_cast<uint64_t>(dj[k]) * rowf + dc[k] * 4) = t;
+      }
+    }
+  }
+}
+
 // Applies the update; two kinds of workgroups:
 //  * row workgroups [0, row_blocks), one thread per block row: the m-th distinct missed id
 //    (m < k = min(#distinct misses, capacity)) takes the m-th victim's slot — map / slot_id /
@@ -1148,21 +1182,24 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
   const uint32_t spans = (row_tiles + c.tiles_per_wg - 1) / c.tiles_per_wg;
   const uint32_t cap = c.capacity;
   if (blockIdx.x < row_blocks) {
-    // kInstRows rows per workgroup, one thread each; ALL kWide threads then copy the
-    // installed rows, so the copy of a block's ~thousands of missed rows is spread over
-    // n / kInstRows workgroups with 4 rows' worth of loads in flight per installing thread
-    __shared__ uint2 inst[kInstRows];   // {slot, row} installed by this workgroup
+    // inst_rows block rows per workgroup, one thread each (256 for the usual blocks: ALL kWide
+    // threads then copy the installed rows, so the copy of a block's ~thousands of missed rows
+    // is spread over n / 256 workgroups; 1024 from 65 536 rows on, where a workgroup's fixed
+    // ~10 us of dependent loads — one workgroup fits a CU — would otherwise come n / 256 / 256
+    // times in a row)
+    __shared__ uint2 inst[kWide];   // {slot, row} installed by this workgroup
     __shared__ uint32_t n_inst;
     __shared__ uint32_t s_keep[kMaxStageTiles], s_hitp[kMaxStageTiles], s_nonhit;
     const uint32_t span_rows = c.tiles_per_wg * kLruRows;
-    const uint32_t chunks = (c.n + kInstRows - 1) / kInstRows;
+    const uint32_t inst_rows = c.inst_rows;
+    const uint32_t chunks = (c.n + inst_rows - 1) / inst_rows;
     for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += row_blocks) {
-      const uint32_t i = chunk * kInstRows + tid;
-      const bool in = tid < static_cast<int>(kInstRows) && i < c.n;
+      const uint32_t i = chunk * inst_rows + tid;
+      const bool in = tid < static_cast<int>(inst_rows) && i < c.n;
       // every independent load first: the row's code and id, the span counts, the record
       const uint32_t code = in ? c.rep_flag[i] : 0u;
       const int64_t id = in ? c.ids[i] : 0;
-      const uint32_t w = (chunk * kInstRows) / span_rows;   // scan workgroup of these rows
+      const uint32_t w = (chunk * inst_rows) / span_rows;   // scan workgroup of these rows
       uint32_t pm = 0, tm = 0;
       for (uint32_t t = tid; t < spans; t += kWide) {
         const uint32_t m = c.row_tile_sum[t];
@@ -1232,30 +1269,11 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
       // copy the installed rows out of the block's output, as one flat array
       const uint32_t total = n_inst * c.dimv;
       if (c.vec4) {
-        const float4* out = reinterpret_cast<const float4*>(c.out);
-        float4* buf = reinterpret_cast<float4*>(c.cache_buf);
-        for (uint32_t f = tid; f < total; f += 2 * kWide) {
-          const uint32_t f2 = f + kWide;
-          const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
-          const uint32_t j2 = f2 < total ? f2 / c.dimv : j, cc2 = f2 < total ? f2 - j2 * c.dimv : cc;
-          const uint2 pr = inst[j], pr2 = inst[j2];
-          const float4 v = out[static_cast<uint64_t>(pr.y) * c.dimv + cc];
-          const float4 v2 = out[static_cast<uint64_t>(pr2.y) * c.dimv + cc2];
-          buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] = v;
-          if (f2 < total) buf[static_cast<uint64_t>(pr2.x) * c.dimv + cc2] = v2;
-        }
+        if (c.inst_rows > kInstRows) copy_installed<float4, 6>(c, inst, n_inst, c.dimv * 4, tid);
+        else copy_installed<float4, 2>(c, inst, n_inst, c.dimv * 4, tid);
       } else if (c.odd4) {
-        for (uint32_t f = tid; f < total; f += 2 * kWide) {
-          const uint32_t f2 = f + kWide;
-          const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
-          const uint32_t j2 = f2 < total ? f2 / c.dimv : j, cc2 = f2 < total ? f2 - j2 * c.dimv : cc;
-          const uint2 pr = inst[j], pr2 = inst[j2];
-          const uf4 v = *reinterpret_cast<const uf4*>(c.out + static_cast<uint64_t>(pr.y) * c.dim + cc * 4);
-          const uf4 v2 = *reinterpret_cast<const uf4*>(c.out + static_cast<uint64_t>(pr2.y) * c.dim + cc2 * 4);
-          *reinterpret_cast<uf4*>(c.cache_buf + static_cast<uint64_t>(pr.x) * c.dim + cc * 4) = v;
-          if (f2 < total)
-            *reinterpret_cast<uf4*>(c.cache_buf + static_cast<uint64_t>(pr2.x) * c.dim + cc2 * 4) = v2;
-        }
+        if (c.inst_rows > kInstRows) copy_installed<uf4, 6>(c, inst, n_inst, c.dim, tid);
+        else copy_installed<uf4, 2>(c, inst, n_inst, c.dim, tid);
         const uint32_t total_t = n_inst * c.tail, tl = max(c.tail, 1u);
         for (uint32_t f = tid; f < total_t; f += kWide) {
           const uint32_t j = f / tl, t = c.dimv * 4 + (f - j * tl);
@@ -1692,7 +1710,7 @@ void launch_round(Round& r, hipStream_t stream) {
   if (!any_update) return;
   ProfileScope ps(kProfLru, stream);
   size_t q_scan_blocks = 0, q_rows = 0, q_cap = 0, q_bit_tiles = 0, q_victim_blocks = 1;
-  size_t q_append_blocks = 0;
+  size_t q_append_blocks = 0, q_inst_blocks = 0;
   size_t h_n = 0, h_cap = 0, h_tiles = 0;
   for (int i = 0; i < r.count; ++i) {
     const Ctx& c = r.c[i];
@@ -1701,6 +1719,7 @@ void launch_round(Round& r, hipStream_t stream) {
       const size_t row_tiles = (c.n + kLruRows - 1) / kLruRows;
       q_scan_blocks = std::max(q_scan_blocks, (row_tiles + c.tiles_per_wg - 1) / c.tiles_per_wg);
       q_rows = std::max<size_t>(q_rows, c.n);
+      q_inst_blocks = std::max<size_t>(q_inst_blocks, (c.n + c.inst_rows - 1) / c.inst_rows);
       if (c.qmode) {
         // queue form: bitmap tiles of kWide words (32 queue positions per word; the tail is
         // below 1.5 * capacity + 64)
@@ -1731,8 +1750,7 @@ void launch_round(Round& r, hipStream_t stream) {
     if (q_bit_tiles)
       lru_queue_count_kernel<<<dim3(static_cast<unsigned>(std::min<size_t>(q_bit_tiles, 1024)),
                                     r.count), dim3(kWide), 0, stream>>>(r);
-    const unsigned ib = static_cast<unsigned>(
-        std::max<size_t>(1, std::min<size_t>((q_rows + kInstRows - 1) / kInstRows, 4096)));
+    const unsigned ib = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(q_inst_blocks, 4096)));
     lru_list_install_kernel<<<dim3(ib + lb, r.count), dim3(kWide), 0, stream>>>(r, ib, lb);
     GF_HIP(hipGetLastError());
     for (int i = 0; i < r.count; ++i) {
@@ -2169,6 +2187,7 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
   if (c.update && policy_ == GF_CACHE_LRU) {
     const size_t row_tiles = (n + kLruRows - 1) / kLruRows;
     c.tiles_per_wg = static_cast<uint32_t>((row_tiles + kMaxRowTiles - 1) / kMaxRowTiles);
+    c.inst_rows = n >= 65536 ? kWide : kInstRows;
     c.queue[0] = queue_.as<uint32_t>();
     c.queue[1] = queue_alt_.as<uint32_t>();
     c.qstate = qstate_.as<QueueState>();
