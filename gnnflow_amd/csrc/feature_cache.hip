@@ -1455,7 +1455,7 @@ __global__ void list_fill_kernel(uint32_t* list, uint32_t first, uint32_t prefix
 }
 
 // ---- LRU as a queue (large caches) --------------------------------------------------------
-// The list passes above cost O(capacity) per update: 343 us for a 30 k-row block on a 40 M-slot
+// The list passes above cost O(capacity) per update: 352 us for a 30 k-row block on a 40 M-slot
 // cache (GDELT scale) against 17 us for the gather itself.  From queue_min_capacity() slots on
 // (2 M), the SAME list is therefore kept as a queue with dead entries: `queue` holds entries
 // [head, tail) (capacity * 3/2 allocated), qpos[slot] is the position of the slot's one LIVE
@@ -1612,8 +1612,8 @@ inline bool vec4_ok(size_t dim, const void* a, const void* b, const void* c) {
 }
 
 // LRU caches of at least this many slots are kept as a queue (O(block rows) updates): a
-// 30 k-row fetch with update costs 38 / 47 / 75 / 150 / 343 us in the list form at 0.13 / 1 / 4
-// / 16 / 40 M slots and 48 / 50 / 54 us in the queue form at 4 / 16 / 40 M
+// 30 k-row fetch with update costs 30 / 42 / 77 / 152 / 352 us in the list form at 0.13 / 1 / 4
+// / 16 / 40 M slots and 45 / 45 / 49 us in the queue form at 4 / 16 / 40 M
 // (profiles/r02_lru_capacity_sweep.jsonl)
 inline size_t queue_min_capacity() {
   const char* v = std::getenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY");   // tuning / tests
