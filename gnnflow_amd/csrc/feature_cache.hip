@@ -128,8 +128,9 @@ struct Ctx {
   uint32_t n;
   int vec4;                 // rows are float4-addressable
   uint32_t dimv;            // row length in float4s (vec4 / odd4) or floats
-  // rows of dim % 4 != 0 floats (GDELT: 413 / 186) or misaligned bases: dimv 16-byte vectors
-  // at 4-byte alignment + `tail` floats per row, rows `dim` floats apart
+  // rows of dim % 4 != 0 floats (GDELT: 413 / 186) or misaligned bases: dimv = ceil(dim / 4)
+  // 16-byte vectors at 4-byte alignment per row, the last one ending with the row (it overlaps
+  // its neighbour); rows `dim` floats apart
   int odd4;
   uint32_t dim, tail;
   uint32_t tile_rows;       // rows per wave in the gather
@@ -288,9 +289,12 @@ __device__ inline void gather_body(const Ctx& c) {
       *valid = fu < total;
       const uint32_t r = *valid ? fu / dimv : 0u;
       const uint32_t cc = fu - r * dimv;
-      *at = r * rowu + cc * kVF;   // where it goes, in Units from the tile's first row
+      // odd rows: the last vector of a row ends with the row (it overlaps its neighbour by
+      // 4 - dim % 4 floats, which are simply written twice) — no scalar tail pass
+      const uint32_t off = kOdd ? min(cc * kVF, rowu - kVF) : cc * kVF;
+      *at = r * rowu + off;   // where it goes, in Units from the tile's first row
       const Unit* s = reinterpret_cast<const Unit*>(__shfl(src_bits, r, 64));
-      return (*valid && s) ? *reinterpret_cast<const VecT*>(s + cc * kVF) : vec_zero<VecT>();
+      return (*valid && s) ? *reinterpret_cast<const VecT*>(s + off) : vec_zero<VecT>();
     };
     // K independent 16-byte loads in flight per lane, then the stores.  (12 covers a whole
     // 16-row tile of 172-d rows in one trip; measured 14.8-14.9 us per launch against 15.5-15.7
@@ -312,18 +316,6 @@ __device__ inline void gather_body(const Ctx& c) {
     if (c.inflight >= 12) copy(std::integral_constant<int, 12>{});
     else if (c.inflight >= 8) copy(std::integral_constant<int, 8>{});
     else copy(std::integral_constant<int, 4>{});
-    if constexpr (kOdd) {
-      // the last dim % 4 floats of every row
-      const uint32_t tail = max(c.tail, 1u), total_t = rows * c.tail;
-      for (uint32_t base = 0; base < total_t; base += 64) {
-        const uint32_t ft = base + lane;
-        const bool valid = ft < total_t;
-        const uint32_t r = valid ? ft / tail : 0u;
-        const uint32_t t = ft - r * tail;
-        const float* sp = reinterpret_cast<const float*>(__shfl(src_bits, r, 64));
-        if (valid) o[r * rowu + dimv * 4 + t] = sp ? sp[dimv * 4 + t] : 0.0f;
-      }
-    }
   }
   if (c.ctr) {
     __shared__ uint32_t wg_hits, wg_miss;
@@ -1150,8 +1142,8 @@ __device__ inline void copy_installed(const Ctx& c, const uint2* inst, uint32_t 
       const uint32_t j = ok ? f / c.dimv : 0u, cc = ok ? f - j * c.dimv : 0u;
       const uint2 pr = inst[j];
       dj[k] = ok ? pr.x : ~0u;
-      dc[k] = cc;
-      const VecT t = *reinterpret_cast<const VecT*>(c.out + static_cast<uint64_t>(pr.y) * rowf + cc * 4);
+      dc[k] = min(cc * 4, rowf - 4);   // odd rows: the last vector ends with the row
+      const VecT t = *reinterpret_cast<const VecT*>(c.out + static_cast<uint64_t>(pr.y) * rowf + dc[k]);
       v[k] = make_float4(t.x, t.y, t.z, t.w);
     }
 #pragma unroll
@@ -1159,7 +1151,7 @@ __device__ inline void copy_installed(const Ctx& c, const uint2* inst, uint32_t 
       if (dj[k] != ~0u) {
         VecT t;
         t.x = v[k].x; t.y = v[k].y; t.z = v[k].z; t.w = v[k].w;
-        *reinterpret_cast<VecT*>(c.cache_buf + static_cast<uint64_t>(dj[k]) * rowf + dc[k] * 4) = t;
+        *reinterpret_cast<VecT*>(c.cache_buf + static_cast<uint64_t>(dj[k]) * rowf + dc[k]) = t;
       }
     }
   }
@@ -1274,12 +1266,6 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
       } else if (c.odd4) {
         if (c.inst_rows > kInstRows) copy_installed<uf4, 6>(c, inst, n_inst, c.dim, tid);
         else copy_installed<uf4, 2>(c, inst, n_inst, c.dim, tid);
-        const uint32_t total_t = n_inst * c.tail, tl = max(c.tail, 1u);
-        for (uint32_t f = tid; f < total_t; f += kWide) {
-          const uint32_t j = f / tl, t = c.dimv * 4 + (f - j * tl);
-          const uint2 pr = inst[j];
-          c.cache_buf[static_cast<uint64_t>(pr.x) * c.dim + t] = c.out[static_cast<uint64_t>(pr.y) * c.dim + t];
-        }
       } else {
         for (uint32_t f = tid; f < total; f += kWide) {
           const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
@@ -1589,7 +1575,7 @@ __global__ void cache_probe_kernel(const int64_t* __restrict__ ids, uint64_t n,
 }
 
 // rows that are not float4-addressable (dim % 4 != 0, or a misaligned base) still move as
-// 16-byte vectors at 4-byte alignment plus a per-row tail; `allowed`: the kernels that will see
+// 16-byte vectors at 4-byte alignment; `allowed`: the kernels that will see
 // this context know the mode (the LFU / FIFO install does not)
 inline void set_odd4(Ctx& c, size_t dim, bool allowed) {
   c.dim = static_cast<uint32_t>(dim);
@@ -1602,7 +1588,7 @@ inline void set_odd4(Ctx& c, size_t dim, bool allowed) {
   }();
   if (!enabled) return;
   c.odd4 = 1;
-  c.dimv = static_cast<uint32_t>(dim / 4);
+  c.dimv = static_cast<uint32_t>((dim + 3) / 4);   // the last vector overlaps its neighbour
   c.tail = static_cast<uint32_t>(dim % 4);
 }
 
