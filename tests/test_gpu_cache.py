@@ -388,8 +388,21 @@ def test_two_large_blocks_per_fetch_around_the_row_tile_size(policy, second):
                         seed=40 + second % 7, skew=0.9, policy=policy, reset_after=(2,))
 
 
+def test_resize_crosses_from_the_list_into_the_queue_form(monkeypatch):
+    """The edge cache has 200 slots before the resize and 340 after it; with the queue form
+    starting at 300 slots the resize also changes the form of the replacement order (and the
+    node cache, 40 -> 66 slots, stays a list)."""
+    monkeypatch.setenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", "300")
+    hip = _resize_scenario("lru")
+    assert hip._edge.lru_state()["queue_form"] == 1 and hip._node.lru_state()["queue_form"] == 0
+
+
 @pytest.mark.parametrize("policy", ["lru", "lfu", "fifo"])
 def test_resize_grows_id_space_and_capacity_keeping_the_contents(policy):
+    _resize_scenario(policy)
+
+
+def _resize_scenario(policy):
     """Cache.resize (cache.py:197-221): after the graph has grown, cached ids still hit with
     the right rows, the new ids are served from the new tables and get cached, the capacity
     follows the ratio, and the replacement order continues (new slots are empty and oldest /
@@ -440,6 +453,7 @@ def test_resize_grows_id_space_and_capacity_keeping_the_contents(policy):
         batch(N1, E1, bi)
     with pytest.raises(ValueError):        # the caller must supply tables that cover the new ids
         hip.resize(N1 + 50, E1)
+    return hip
 
 
 def _edge_only_pair(E, cap_ratio, d=4, seed=11):
