@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kTileThreads) void partition_scatter_kernel(
     const int64_t* __restrict__ nodes, const float* __restrict__ ts,
     const uint64_t* __restrict__ d_R, uint64_t R_host, OwnerDiv od,
     const uint32_t* __restrict__ tile_base, int64_t* __restrict__ requests,
-    uint32_t* __restrict__ pos) {
+    uint32_t* __restrict__ pos, uint32_t* __restrict__ root_of) {
   const uint32_t P = od.P;
   __shared__ uint32_t wave_cnt[kTileThreads / 64][kMaxParts];
   const uint64_t R = d_R ? *d_R : R_host;
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kTileThreads) void partition_scatter_kernel(
   requests[2 * static_cast<uint64_t>(p)] = v;
   requests[2 * static_cast<uint64_t>(p) + 1] = static_cast<int64_t>(__float_as_uint(ts[i]));
   pos[i] = p;
+  if (root_of) root_of[p] = static_cast<uint32_t>(i);
 }
 
 // Layers of up to 32 768 roots: the whole plan in ONE launch, no scratch, no kernel boundary.
@@ -152,7 +153,8 @@ constexpr uint32_t kFusedPlanRoots = 32768;
 __global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
     const int64_t* __restrict__ nodes, const float* __restrict__ ts,
     const uint64_t* __restrict__ d_R, uint64_t R_host, OwnerDiv od, uint32_t rank,
-    int64_t* __restrict__ requests, uint32_t* __restrict__ pos, uint64_t* __restrict__ counts) {
+    int64_t* __restrict__ requests, uint32_t* __restrict__ pos, uint64_t* __restrict__ counts,
+    uint32_t* __restrict__ root_of) {
   const uint32_t P = od.P;
   __shared__ uint32_t s_before[kFusedThreads / 64][kMaxParts];
   __shared__ uint32_t s_total[kFusedThreads / 64][kMaxParts];
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
   requests[2 * static_cast<uint64_t>(p)] = my_node;
   requests[2 * static_cast<uint64_t>(p) + 1] = static_cast<int64_t>(__float_as_uint(ts[i]));
   pos[i] = p;
+  if (root_of) root_of[p] = i;   // the inverse: which root a request / reply row belongs to
 }
 
 }  // namespace
@@ -243,7 +246,8 @@ size_t partition_scratch_bytes(size_t R, int world_size) {
 void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_t* d_R,
                         size_t R_bound, int world_size, int rank, int64_t* d_requests,
                         uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
-                        size_t scratch_bytes, int device, hipStream_t stream) {
+                        size_t scratch_bytes, int device, hipStream_t stream,
+                        uint32_t* d_root_of) {
   GF_REQUIRE(world_size >= 1 && world_size <= kMaxParts, "partition: world size must be 1..64");
   GF_REQUIRE(rank >= 0 && rank < world_size, "partition: rank out of range");
   GF_REQUIRE(d_counts != nullptr, "partition: null counts");
@@ -265,7 +269,8 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
   if (fused_plan && R_bound <= kFusedPlanRoots) {
     const unsigned grid = static_cast<unsigned>((R_bound + kFusedThreads - 1) / kFusedThreads);
     partition_plan_fused_kernel<<<dim3(grid), dim3(kFusedThreads), 0, stream>>>(
-        d_nodes, d_ts, d_R, R_bound, od, static_cast<uint32_t>(rank), d_requests, d_pos, d_counts);
+        d_nodes, d_ts, d_R, R_bound, od, static_cast<uint32_t>(rank), d_requests, d_pos, d_counts,
+        d_root_of);
     GF_HIP(hipGetLastError());
     return;
   }
@@ -279,7 +284,7 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
                                                             static_cast<uint32_t>(rank), tile_base,
                                                             d_counts);
   partition_scatter_kernel<<<dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream>>>(
-      d_nodes, d_ts, d_R, R_bound, od, tile_base, d_requests, d_pos);
+      d_nodes, d_ts, d_R, R_bound, od, tile_base, d_requests, d_pos, d_root_of);
   GF_HIP(hipGetLastError());
 }
 
@@ -287,7 +292,7 @@ void partition_plan(const int64_t* d_nodes, const float* d_ts, size_t R, int wor
                     int64_t* d_requests, uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
                     size_t scratch_bytes, int device, hipStream_t stream) {
   partition_plan_dev(d_nodes, d_ts, nullptr, R, world_size, rank, d_requests, d_pos, d_counts,
-                     d_scratch, scratch_bytes, device, stream);
+                     d_scratch, scratch_bytes, device, stream, nullptr);
 }
 
 }  // namespace gf

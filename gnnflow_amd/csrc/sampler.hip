@@ -591,14 +591,17 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
     uint32_t num_snapshots, float window, uint32_t fanout, int uniform, int prop_time,
     uint64_t seed, uint64_t call, int64_t* __restrict__ out,
     const uint64_t* __restrict__ d_own, const uint64_t* __restrict__ d_total,
-    uint64_t total_host) {
+    uint64_t total_host, const uint32_t* __restrict__ root_of, uint32_t* __restrict__ rec_cnt) {
   // d_own != null: "this rank's own share" of a chained partitioned layer — the last *d_own
-  // of the layer's R request rows (R = *d_total, or total_host), counts still on the device
+  // of the layer's R request rows (R = *d_total, or total_host), counts still on the device.
+  // root_of / rec_cnt (own share only): the number of valid slots of every row goes straight
+  // to its root's counter, so the merge does not have to read the rows back to count them.
   if (d_own) {
     n = *d_own;
     const uint64_t skip = (d_total ? *d_total : total_host) - n;
     req += 2 * skip;
     out += skip * fanout * 3;
+    if (root_of) root_of += skip;
   }
   constexpr int kGroupsPerBlock = kSearchThreads / GROUP;
   const int lane = threadIdx.x % GROUP;
@@ -625,6 +628,7 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
       }
     }
     const uint32_t valid = valid_slots(n_cand, fanout, uniform);
+    if (rec_cnt && lane == 0) rec_cnt[root_of[r]] = valid;
     for (uint32_t j = lane; j < fanout; j += GROUP) {
       const uint64_t slot = r * fanout + j;
       int64_t* o = out + slot * 3;
@@ -715,6 +719,25 @@ __global__ __launch_bounds__(kEmitThreads) void merge_count_sums_kernel(
   }
 }
 
+// Chained form: the own share's counts came from the sampling kernel itself; only the rows
+// that arrived from other ranks — the first R - counts[rank] of the reply buffer — are read back
+__global__ void merge_count_remote_kernel(const int64_t* __restrict__ rep,
+                                          const uint32_t* __restrict__ root_of,
+                                          const uint64_t* __restrict__ d_R, uint64_t R_host,
+                                          const uint64_t* __restrict__ d_own, uint32_t fanout,
+                                          uint32_t* __restrict__ rec_cnt) {
+  const uint64_t R = d_R ? *d_R : R_host;
+  const uint64_t n_net = R - min(R, *d_own);
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t row = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n_net;
+       row += stride) {
+    const int64_t* s = rep + row * fanout * 3;
+    uint32_t c = 0;
+    for (uint32_t j = 0; j < fanout; ++j) c += s[3 * j] >= 0 ? 1u : 0u;
+    rec_cnt[root_of[row]] = c;
+  }
+}
+
 __global__ __launch_bounds__(kEmitThreads) void merge_emit_prefix_kernel(
     const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
     const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t fanout,
@@ -745,8 +768,14 @@ __global__ __launch_bounds__(kEmitThreads) void merge_emit_prefix_kernel(
   const uint32_t nroots = r_last - r_first + 1;   // <= kEmitThreads
   const uint32_t b_first = r_first / kEmitThreads;   // count workgroups of kEmitThreads roots
   uint32_t part = 0;
-  for (uint32_t b = tid; b < b_first; b += kEmitThreads) part += wg_sum[b];
-  for (uint32_t r = b_first * kEmitThreads + tid; r < r_first; r += kEmitThreads) part += rec_cnt[r];
+  if (wg_sum) {
+    for (uint32_t b = tid; b < b_first; b += kEmitThreads) part += wg_sum[b];
+    for (uint32_t r = b_first * kEmitThreads + tid; r < r_first; r += kEmitThreads) part += rec_cnt[r];
+  } else {
+    // no per-workgroup sums: add up the counts of all the roots before this workgroup's
+    // (coalesced, <= 128 KB out of L2: cheaper than the launch that would have summed them)
+    for (uint32_t r = tid; r < r_first; r += kEmitThreads) part += rec_cnt[r];
+  }
   for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
   if (lane == 0) red[wave] = part;
   const uint32_t mine = tid < static_cast<int>(nroots) ? rec_cnt[r_first + tid] : 0u;
@@ -1217,7 +1246,8 @@ void Sampler::sample_layer_padded(const int64_t* d_requests, size_t n, uint32_t 
   launch_padded(width, grid, stream, gv, d_requests, static_cast<uint64_t>(n), snapshot,
                 num_snapshots_, window_, F, uniform, prop_time_ ? 1 : 0, seed_, call, d_out,
                 static_cast<const uint64_t*>(nullptr), static_cast<const uint64_t*>(nullptr),
-                static_cast<uint64_t>(0));
+                static_cast<uint64_t>(0), static_cast<const uint32_t*>(nullptr),
+                static_cast<uint32_t*>(nullptr));
   GF_HIP(hipGetLastError());
 }
 
@@ -1291,7 +1321,8 @@ void Sampler::merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, 
 void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_t* d_R,
                         size_t R_bound, int world_size, int rank, int64_t* d_requests,
                         uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
-                        size_t scratch_bytes, int device, hipStream_t stream);
+                        size_t scratch_bytes, int device, hipStream_t stream,
+                        uint32_t* d_root_of);
 size_t partition_scratch_bytes(size_t R, int world_size);
 
 void Sampler::part_layout(size_t R0, uint32_t layer, int world_size, gf_part_layout* out) const {
@@ -1349,6 +1380,21 @@ void Sampler::part_begin(const int64_t* d_roots, const float* d_ts, size_t R, vo
   part_.stream = stream;
 }
 
+// Scratch of the chained merge in the sampler's workspace (ordered by the stream like the rest
+// of it): rec_cnt[i] = valid slots of root i, root_of[row] = root of a request / reply row
+// (the workspace's `base` array, which the fused merge does not need).
+uint32_t* Sampler::part_rec_cnt() const {
+  return reinterpret_cast<uint32_t*>(ws_.as<char>() + align_up(ws_roots_ * 8, 16));
+}
+uint32_t* Sampler::part_root_of() const {
+  return reinterpret_cast<uint32_t*>(ws_.as<char>() + align_up(ws_roots_ * 8, 16) +
+                                     align_up(ws_roots_ * 4, 16));
+}
+// Layers that take the fused merge get their own share's counts from the sampling kernel.
+bool Sampler::part_own_counts(size_t root_bound) const {
+  return fused_scan_ && root_bound <= kSmallRoots && root_bound > 0;
+}
+
 uint64_t* Sampler::part_counts() const {
   return reinterpret_cast<uint64_t*>(ws_.as<char>() + align_up(ws_roots_ * 8, 16) +
                                      3 * align_up(ws_roots_ * 4, 16));
@@ -1394,7 +1440,8 @@ void Sampler::part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_
     partition_plan_dev(roots, ts, d_R, layer == 0 ? part_.R : Rb, part_.world, part_.rank,
                        reinterpret_cast<int64_t*>(w + lay.requests),
                        reinterpret_cast<uint32_t*>(w + lay.pos), d_counts, w + lay.scratch,
-                       lay.scratch_bytes, graph_->device(), stream);
+                       lay.scratch_bytes, graph_->device(), stream,
+                       part_own_counts(layer == 0 ? part_.R : Rb) ? part_root_of() : nullptr);
   }
   if (!(phases & 2)) return;
   // this rank's own share: the last counts[rank] request rows; the kernel takes the count
@@ -1412,7 +1459,8 @@ void Sampler::part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_
                   snapshot, num_snapshots_, window_, F, policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0,
                   prop_time_ ? 1 : 0, seed_, call, reinterpret_cast<int64_t*>(w + lay.replies),
                   static_cast<const uint64_t*>(d_counts + part_.rank), d_R,
-                  static_cast<uint64_t>(R_host));
+                  static_cast<uint64_t>(R_host), static_cast<const uint32_t*>(part_root_of()),
+                  part_own_counts(n_bound) ? part_rec_cnt() : static_cast<uint32_t*>(nullptr));
     GF_HIP(hipGetLastError());
   }
 }
@@ -1448,17 +1496,21 @@ void Sampler::part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
     return;
   }
   ProfileScope ps(kProfEmit, stream);
-  if (fused_scan_ && Rb <= kSmallRoots) {
-    // rec_cnt / wg_sum live in the sampler workspace (base is not needed: no scan launch)
-    uint32_t* wg_sum = tile_scratch;
-    const unsigned cgrid = static_cast<unsigned>((Rb + kEmitThreads - 1) / kEmitThreads);
-    merge_count_sums_kernel<<<dim3(cgrid), dim3(kEmitThreads), 0, stream>>>(
-        rep, pos, d_R, R_host, F, rec_cnt, wg_sum);
+  if (part_own_counts(Rb)) {
+    // rec_cnt lives in the sampler workspace; the own share's counts are already there
+    // (part_plan_own phase 2), the rows received from other ranks are counted here; the emit
+    // derives its own prefix from the counts (no scan launch, no per-workgroup sums)
+    (void)base; (void)tile_scratch;
+    if (part_.world > 1) {
+      uint64_t* d_counts = reinterpret_cast<uint64_t*>(w + lay.counts);
+      merge_count_remote_kernel<<<dim3(capped_grid(Rb, 256, 1024)), dim3(256), 0, stream>>>(
+          rep, part_root_of(), d_R, R_host, d_counts + part_.rank, F, rec_cnt);
+    }
     const unsigned egrid = static_cast<unsigned>(
         (static_cast<uint64_t>(Rb) * F + kEmitThreads - 1) / kEmitThreads);
     merge_emit_prefix_kernel<<<dim3(egrid), dim3(kEmitThreads), 0, stream>>>(
-        roots, ts, d_R, R_host, F, rep, pos, rec_cnt, wg_sum, out.all_nodes, out.all_ts, out.dt,
-        out.eids, out.row, out.col, slot, slot + 1, next_R);
+        roots, ts, d_R, R_host, F, rep, pos, rec_cnt, static_cast<const uint32_t*>(nullptr),
+        out.all_nodes, out.all_ts, out.dt, out.eids, out.row, out.col, slot, slot + 1, next_R);
     GF_HIP(hipGetLastError());
     return;
   }

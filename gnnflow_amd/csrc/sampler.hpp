@@ -111,6 +111,9 @@ class Sampler {
     hipStream_t stream = nullptr;
   };
   uint64_t* part_counts() const;
+  uint32_t* part_rec_cnt() const;
+  uint32_t* part_root_of() const;
+  bool part_own_counts(size_t root_bound) const;
   void part_roots(uint32_t layer, uint32_t snapshot, const int64_t** roots, const float** ts,
                   const uint64_t** d_R, uint64_t* R_host) const;
   InFlight ring_[kMaxInFlight];
