@@ -406,6 +406,20 @@ void EdgeStore::upload_entries(const std::vector<int64_t>& ids) {
   GF_HIP(hipStreamSynchronize(stream_));
 }
 
+// entries prepared by the caller in pinned memory: int64 ids[k] followed by NodeEntry[k]
+void EdgeStore::publish_entries(const PinnedBuffer& prepared, size_t k) {
+  if (k == 0) return;
+  const size_t bytes = k * (sizeof(int64_t) + sizeof(NodeEntry));
+  staging_.reserve(bytes, 0, stream_);
+  GF_HIP(hipMemcpyAsync(staging_.data(), prepared.data(), bytes, hipMemcpyHostToDevice, stream_));
+  int64_t* d_ids = staging_.as<int64_t>();
+  NodeEntry* d_ent = reinterpret_cast<NodeEntry*>(d_ids + k);
+  update_nodes_kernel<<<dim3((k + 255) / 256), dim3(256), 0, stream_>>>(
+      d_ids, d_ent, k, table_.as<NodeEntry>());
+  GF_HIP(hipGetLastError());
+  GF_HIP(hipStreamSynchronize(stream_));
+}
+
 // ---- ingest: DynamicGraph::AddEdges, dynamic_graph.cu:77-138 -------------------
 namespace {
 // GNNFLOW_INGEST_PROFILE=1: per-phase host time of add_edges on stderr
@@ -471,7 +485,19 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   //    600-edge ingests, where a sort launch chain would cost more than the whole call — by
   //    the host counting sort.
   struct Group { int64_t v; size_t begin, end; };
-  std::vector<Group> groups;
+  // the runs of equal source: a host vector (host ordering), or a view of the device
+  // ordering's group table in pinned memory (no 6.5 M-element vector to build per chunk)
+  struct GroupList {
+    std::vector<Group> host;
+    const uint32_t* src = nullptr;
+    const uint32_t* start = nullptr;
+    size_t n = 0;
+    size_t size() const { return src ? n : host.size(); }
+    Group operator[](size_t g) const {
+      return src ? Group{static_cast<int64_t>(src[g]), start[g], start[g + 1]} : host[g];
+    }
+    void push_back(const Group& g) { host.push_back(g); }
+  } groups;
   std::vector<uint32_t> perm;        // host path only
   std::vector<float> s_ts_vec;
   const float* s_ts = nullptr;
@@ -498,10 +524,9 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     sorter->download(g_src, g_start, h_sts, stream_);
     g_start[G] = static_cast<uint32_t>(n);
     s_ts = h_sts;
-    groups.resize(G);
-    parallel_for(G, 1 << 16, [&](size_t g0, size_t g1) {
-      for (size_t g = g0; g < g1; ++g) groups[g] = {static_cast<int64_t>(g_src[g]), g_start[g], g_start[g + 1]};
-    });
+    groups.src = g_src;
+    groups.start = g_start;
+    groups.n = G;
     pt.mark("groups");
   } else {
     perm.resize(n);
@@ -684,7 +709,6 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   std::vector<uint64_t> newcap(G, 0);
   std::vector<Move> moves;
   std::vector<std::pair<uint64_t, uint64_t>> deferred_free;
-  std::vector<int64_t> touched(G);
   size_t planA_nodes = 0, planA_srcs = 0;   // added to the counters once the helper has joined
   {
     std::mutex mu;
@@ -790,6 +814,11 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   pt.mark("planB");
   std::vector<uint64_t> dest;          // host path: per-edge destinations for the staging copy
   if (!on_device) dest.resize(n);
+  // the node-table entries to publish are written here, while the vertex record is in cache
+  // (a separate pass over the records just to read them back cost 5 ms per 10^7 edges)
+  publish_pinned_.reserve(G * (sizeof(int64_t) + sizeof(NodeEntry)));
+  int64_t* pub_ids = publish_pinned_.as<int64_t>();
+  NodeEntry* pub_ent = reinterpret_cast<NodeEntry*>(pub_ids + G);
   parallel_for(G, 1 << 13, [&](size_t g0, size_t g1) {
     for (size_t g = g0; g < g1; ++g) {
       if (g + 16 < g1) __builtin_prefetch(&nodes_[groups[g + 16].v], 1, 1);
@@ -802,7 +831,10 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
         for (size_t k = 0; k < cnt; ++k) dest[gr.begin + k] = base + k;
       st.live_size += cnt;
       st.last_ts = s_ts[gr.end - 1];
-      touched[g] = gr.v;
+      pub_ids[g] = gr.v;
+      pub_ent[g].start = st.seg_start + st.live_off;
+      pub_ent[g].size = static_cast<uint32_t>(st.live_size);
+      pub_ent[g].reserved = 0;
     }
   });
   GF_REQUIRE(bump_ <= pool_elems_, "add_edges: internal error: pool smaller than planned");
@@ -857,7 +889,7 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   }
   pt.mark("device");
   for (auto& f : deferred_free) seg_free(f.first, f.second);
-  upload_entries(touched);  // ends with the stream sync of dynamic_graph.cu:135-137
+  publish_entries(publish_pinned_, G);  // ends with the stream sync of dynamic_graph.cu:135-137
   pt.mark("publish");
   // the bookkeeping helper shares nothing with the device phase either: joined last
   if (sets_thread.t.joinable()) sets_thread.t.join();

@@ -216,6 +216,7 @@ class EdgeStore {
   void simulate_blocks(NodeState& st, const float* ts, size_t n, BlockDelta* delta);
   LogicalBlock new_block(size_t size, BlockDelta* delta);
   void upload_entries(const std::vector<int64_t>& ids);
+  void publish_entries(const PinnedBuffer& prepared, size_t k);
 
   // config
   size_t initial_pool_size_, maximum_pool_size_, minimum_block_size_;
@@ -235,6 +236,7 @@ class EdgeStore {
   DeviceBuffer staging_;      // ingest staging (device)
   PinnedBuffer pinned_;       // ingest staging (host)
   PinnedBuffer order_pinned_; // device-ordered batch: group table + sorted timestamps (host)
+  PinnedBuffer publish_pinned_;  // node-table entries of the batch, written by the planning pass
 
   // host state
   NodeTable nodes_;

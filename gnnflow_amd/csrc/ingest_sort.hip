@@ -19,6 +19,8 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
+#include <thread>
+#include <vector>
 
 namespace gf {
 namespace {
@@ -99,6 +101,37 @@ inline unsigned grid_for(size_t n) {
 
 }  // namespace
 
+IngestSorter::~IngestSorter() {
+  for (hipEvent_t e : stage_done_)
+    if (e) (void)hipEventDestroy(e);
+}
+
+void IngestSorter::upload(void* d_dst, const void* h_src, size_t bytes, hipStream_t stream) {
+  constexpr size_t kSlot = size_t(32) << 20;   // bytes per pinned slot
+  constexpr unsigned kThreads = 8;
+  const char* src = static_cast<const char*>(h_src);
+  char* dst = static_cast<char*>(d_dst);
+  for (size_t off = 0; off < bytes; off += kSlot) {
+    const size_t m = std::min(kSlot, bytes - off);
+    const int s = stage_next_;
+    stage_next_ ^= 1;
+    stage_[s].reserve(kSlot);
+    if (!stage_done_[s]) GF_HIP(hipEventCreateWithFlags(&stage_done_[s], hipEventDisableTiming));
+    else GF_HIP(hipEventSynchronize(stage_done_[s]));   // the slot's previous copy has left it
+    char* slot = stage_[s].as<char>();
+    const size_t per = (m + kThreads - 1) / kThreads;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < kThreads; ++t) {
+      const size_t a = t * per, b = std::min(m, a + per);
+      if (a < b) th.emplace_back([=] { std::memcpy(slot + a, src + off + a, b - a); });
+    }
+    std::memcpy(slot, src + off, std::min(per, m));
+    for (auto& t : th) t.join();
+    GF_HIP(hipMemcpyAsync(dst + off, slot, m, hipMemcpyHostToDevice, stream));
+    GF_HIP(hipEventRecord(stage_done_[s], stream));
+  }
+}
+
 void IngestSorter::reserve(size_t n, hipStream_t stream) {
   if (n <= cap_) return;
   size_t cap = std::max<size_t>(cap_ ? cap_ : (1 << 16), 1);
@@ -131,11 +164,10 @@ size_t IngestSorter::order(const int64_t* h_src, const int64_t* h_dst, const flo
   GF_REQUIRE(n > 0 && n < 0x7FFFFFFFull, "ingest sort: batch size out of range");
   reserve(n, stream);
   char* b = buf_.as<char>();
-  // upload (the runtime stages pageable memory itself)
-  GF_HIP(hipMemcpyAsync(b + o_src_, h_src, n * 8, hipMemcpyHostToDevice, stream));
-  GF_HIP(hipMemcpyAsync(b + o_ts_, h_ts, n * 4, hipMemcpyHostToDevice, stream));
-  GF_HIP(hipMemcpyAsync(b + o_dst_, h_dst, n * 8, hipMemcpyHostToDevice, stream));
-  GF_HIP(hipMemcpyAsync(b + o_eid_, h_eid, n * 8, hipMemcpyHostToDevice, stream));
+  upload(b + o_src_, h_src, n * 8, stream);
+  upload(b + o_ts_, h_ts, n * 4, stream);
+  upload(b + o_dst_, h_dst, n * 8, stream);
+  upload(b + o_eid_, h_eid, n * 8, stream);
   const uint32_t n32 = static_cast<uint32_t>(n);
   uint64_t* keys0 = reinterpret_cast<uint64_t*>(b + o_keys0_);
   uint64_t* keys1 = reinterpret_cast<uint64_t*>(b + o_keys1_);

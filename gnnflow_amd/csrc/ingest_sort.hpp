@@ -11,6 +11,7 @@ namespace gf {
 
 class IngestSorter {
  public:
+  ~IngestSorter();
   // Uploads the batch, orders it and builds the group table on the device; returns the number
   // of groups (distinct sources).  node_bits = bits needed for the largest source id (<= 32).
   size_t order(const int64_t* h_src, const int64_t* h_dst, const float* h_ts,
@@ -25,6 +26,12 @@ class IngestSorter {
 
  private:
   void reserve(size_t n, hipStream_t stream);
+  // host -> device through two pinned slots filled by several threads: the runtime's own
+  // staging of a pageable source ran anywhere between 11 and 47 GB/s on the same box
+  void upload(void* d_dst, const void* h_src, size_t bytes, hipStream_t stream);
+  PinnedBuffer stage_[2];
+  hipEvent_t stage_done_[2] = {nullptr, nullptr};
+  int stage_next_ = 0;
   DeviceBuffer buf_;
   size_t cap_ = 0, n_ = 0, groups_ = 0, tmp_bytes_ = 0;
   size_t o_src_ = 0, o_dst_ = 0, o_eid_ = 0, o_ts_ = 0, o_keys0_ = 0, o_keys1_ = 0, o_vals0_ = 0,

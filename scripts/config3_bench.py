@@ -28,6 +28,8 @@ ap.add_argument("--sort-roots", action="store_true")
 args = ap.parse_args()
 
 dev = torch.device("cuda", 0)
+from gnnflow_amd.utils import bind_to_device_cpus
+bind_to_device_cpus(0)   # host arrays and ingest threads on the GPU's NUMA node
 lib = _capi.load()
 N, E = args.nodes, args.edges
 t0 = time.time()

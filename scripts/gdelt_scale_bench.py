@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--policy", default="uniform")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
+    from gnnflow_amd.utils import bind_to_device_cpus
+    bind_to_device_cpus(0)   # host arrays and ingest threads on the GPU's NUMA node
     N, E = args.nodes, args.edges
     t0 = time.time()
     g = synthetic.powerlaw_device(N, E, dev, seed=42, alpha=1.0, t_max=1e6)

@@ -4,6 +4,8 @@ import torch, numpy as np
 import gnnflow_amd
 from gnnflow_amd import synthetic
 dev = torch.device("cuda", 0)
+from gnnflow_amd.utils import bind_to_device_cpus
+bind_to_device_cpus(0)   # host arrays and ingest threads on the GPU's NUMA node
 N, E = 10_000_000, 60_000_000
 g = synthetic.powerlaw_device(N, E, dev, seed=42)
 graph = gnnflow_amd.DynamicGraph(1 << 30, 64 << 30, "cuda", 16, 1024, "insert")
