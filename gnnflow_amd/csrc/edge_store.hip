@@ -4,6 +4,8 @@
 #include "edge_store.hpp"
 #include "ingest_sort.hpp"
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -181,14 +183,49 @@ GraphView EdgeStore::view() const {
 
 // ---- bookkeeping ----------------------------------------------------------------
 // dynamic_graph.cu:140-147 AddNodes
+namespace {
+constexpr size_t kHugePage = size_t(2) << 20;
+inline size_t huge_rounded(size_t bytes) { return (bytes + kHugePage - 1) / kHugePage * kHugePage; }
+}  // namespace
+
+void* huge_zeroed_alloc(size_t bytes) {
+  const size_t rounded = huge_rounded(bytes);
+  char* raw = static_cast<char*>(mmap(nullptr, rounded + kHugePage, PROT_READ | PROT_WRITE,
+                                      MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+  if (raw == MAP_FAILED) throw std::bad_alloc();
+  char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(raw) + kHugePage - 1) /
+                                    kHugePage * kHugePage);
+  if (p > raw) (void)munmap(raw, static_cast<size_t>(p - raw));
+  const size_t tail = static_cast<size_t>(raw + rounded + kHugePage - (p + rounded));
+  if (tail) (void)munmap(p + rounded, tail);
+  (void)madvise(p, rounded, MADV_HUGEPAGE);
+  return p;
+}
+
+void huge_free(void* p, size_t bytes) {
+  if (p) (void)munmap(p, huge_rounded(bytes));
+}
+
 void NodeTable::resize(size_t n) {
   if (n <= size_) return;
   const size_t have = chunks_.size(), want = (n + kChunk - 1) >> kShift;
-  chunks_.resize(want);
+  chunks_.resize(want, nullptr);
   parallel_for(want - have, 1, [&](size_t c0, size_t c1) {
-    for (size_t c = c0; c < c1; ++c) chunks_[have + c].reset(new NodeState[kChunk]);
+    for (size_t c = c0; c < c1; ++c) {
+      NodeState* chunk = static_cast<NodeState*>(huge_zeroed_alloc(kChunk * sizeof(NodeState)));
+      for (size_t i = 0; i < kChunk; ++i) new (chunk + i) NodeState();
+      chunks_[have + c] = chunk;
+    }
   });
   size_ = n;
+}
+
+NodeTable::~NodeTable() {
+  for (NodeState* chunk : chunks_) {
+    if (!chunk) continue;
+    for (size_t i = 0; i < kChunk; ++i) chunk[i].~NodeState();
+    huge_free(chunk, kChunk * sizeof(NodeState));
+  }
 }
 
 void EdgeStore::add_nodes(int64_t max_node) {
@@ -705,8 +742,11 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
   //    Pass A (parallel over groups — every group is another vertex): replay the block policy
   //    and decide whether the vertex needs a larger segment.  Pass B (only the groups that do):
   //    the segment allocator.  Pass C (parallel): bases, live ranges.
-  std::vector<uint64_t> gbase(G);
-  std::vector<uint64_t> newcap(G, 0);
+  // per-group scratch kept across calls: a fresh 52 MB std::vector per 10^7-edge chunk is an
+  // mmap + 13 k page faults + munmap every time
+  if (gbase_.size() < G) { gbase_.resize(G); newcap_.resize(G); }
+  uint64_t* gbase = gbase_.data();
+  uint64_t* newcap = newcap_.data();   // every entry is written by pass A
   std::vector<Move> moves;
   std::vector<std::pair<uint64_t, uint64_t>> deferred_free;
   size_t planA_nodes = 0, planA_srcs = 0;   // added to the counters once the helper has joined
@@ -723,8 +763,8 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
         NodeState& st = nodes_[gr.v];
         simulate_blocks(st, s_ts + gr.begin, cnt, &delta);
         const uint64_t need = st.live_size + cnt;
-        if (st.seg_cap == 0 || st.live_off + need > st.seg_cap)
-          newcap[g] = pow2_ceil(std::max<uint64_t>(need, min_phys));
+        newcap[g] = (st.seg_cap == 0 || st.live_off + need > st.seg_cap)
+                        ? pow2_ceil(std::max<uint64_t>(need, min_phys)) : 0;
         // bookkeeping sets, source side (dynamic_graph.cu:89-103): once per distinct source
         uint8_t cur = __atomic_load_n(&seen_[gr.v], __ATOMIC_RELAXED);
         if ((cur & 3) != 3) {
@@ -853,7 +893,7 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     GF_HIP(hipStreamSynchronize(stream_));  // staging is reused below
   }
   if (on_device) {
-    sorter->scatter(gbase.data(), ts_pool_.as<float>(), nbr_pool_.as<EdgePair>(), stream_);
+    sorter->scatter(gbase, ts_pool_.as<float>(), nbr_pool_.as<EdgePair>(), stream_);
     GF_HIP(hipStreamSynchronize(stream_));   // gbase is a host vector
   } else {
     for (size_t off = 0; off < n; off += kIngestChunk) {

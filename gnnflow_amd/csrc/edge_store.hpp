@@ -132,6 +132,13 @@ struct NodeState {
   size_t num_blocks() const { return blocks.size() - first_block; }
 };
 
+// Zeroed host memory for the big random-access tables of the ingest (vertex records, edge-id
+// counters): 2 MB-aligned and advised MADV_HUGEPAGE — 512 times fewer first-touch faults and
+// TLB entries that cover the planning passes' random accesses (THP is `madvise` on the target
+// boxes, so nothing gets huge pages unasked).  Anonymous mmap: the pages are zero.
+void* huge_zeroed_alloc(size_t bytes);
+void huge_free(void* p, size_t bytes);
+
 // Zero-initialised uint32 counters in chunks of 2^22 that never move: calloc hands out
 // untouched zero pages, so a batch that extends the edge-id counters by 10^7 entries pays
 // neither a serial 40 MB memset nor a copy of the old ones — only for the pages it actually
@@ -142,7 +149,7 @@ class ZeroedU32 {
   ZeroedU32() = default;
   ZeroedU32(const ZeroedU32&) = delete;
   ZeroedU32& operator=(const ZeroedU32&) = delete;
-  ~ZeroedU32() { for (uint32_t* c : chunks_) std::free(c); }
+  ~ZeroedU32() { for (uint32_t* c : chunks_) huge_free(c, kChunk * sizeof(uint32_t)); }
   size_t size() const { return size_; }
   uint32_t& operator[](size_t i) { return chunks_[i >> kShift][i & kMask]; }
   const uint32_t& operator[](size_t i) const { return chunks_[i >> kShift][i & kMask]; }
@@ -150,8 +157,7 @@ class ZeroedU32 {
     if (n <= size_) return;
     const size_t want = (n + kChunk - 1) >> kShift;
     while (chunks_.size() < want) {
-      uint32_t* c = static_cast<uint32_t*>(std::calloc(kChunk, sizeof(uint32_t)));
-      if (!c) throw std::bad_alloc();
+      uint32_t* c = static_cast<uint32_t*>(huge_zeroed_alloc(kChunk * sizeof(uint32_t)));
       chunks_.push_back(c);
     }
     size_ = n;
@@ -171,8 +177,12 @@ class NodeTable {
   NodeState& operator[](size_t v) { return chunks_[v >> kShift][v & kMask]; }
   const NodeState& operator[](size_t v) const { return chunks_[v >> kShift][v & kMask]; }
   void resize(size_t n);   // grows only (edge_store.hip)
+  NodeTable() = default;
+  NodeTable(const NodeTable&) = delete;
+  NodeTable& operator=(const NodeTable&) = delete;
+  ~NodeTable();
  private:
-  std::vector<std::unique_ptr<NodeState[]>> chunks_;
+  std::vector<NodeState*> chunks_;   // 2 MB-aligned, MADV_HUGEPAGE (edge_store.hip)
   size_t size_ = 0;
 };
 
@@ -236,6 +246,7 @@ class EdgeStore {
   DeviceBuffer staging_;      // ingest staging (device)
   PinnedBuffer pinned_;       // ingest staging (host)
   PinnedBuffer order_pinned_; // device-ordered batch: group table + sorted timestamps (host)
+  std::vector<uint64_t> gbase_, newcap_;   // per-group planning scratch, kept across calls
   PinnedBuffer publish_pinned_;  // node-table entries of the batch, written by the planning pass
 
   // host state
