@@ -282,6 +282,15 @@ void EdgeStore::ensure_pool(uint64_t elems) {
   while (cap < elems) cap *= 2;
   // the whole used prefix [0, old bump) is preserved across the reallocation
   uint64_t keep = std::min<uint64_t>(pool_elems_, bump_);
+  if (!pools_ready_) {
+    // address ranges for the most the pools may ever hold: power-of-two segments can take up
+    // to ~4x the live edges; capped at 64 G elements
+    const uint64_t max_elems = std::min<uint64_t>(
+        std::max<uint64_t>(16 * (maximum_pool_size_ / kBlockSpace + 1), cap), uint64_t(1) << 36);
+    ts_pool_.init(max_elems * sizeof(float), device_);
+    nbr_pool_.init(max_elems * sizeof(EdgePair), device_);
+    pools_ready_ = true;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   ts_pool_.reserve(cap * sizeof(float), keep * sizeof(float), stream_);
   const auto t1 = std::chrono::steady_clock::now();

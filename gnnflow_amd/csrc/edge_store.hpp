@@ -238,7 +238,9 @@ class EdgeStore {
   hipStream_t stream_ = nullptr;
 
   // device state
-  DeviceBuffer ts_pool_, nbr_pool_, table_;
+  GrowBuffer ts_pool_, nbr_pool_;   // grow in place (HIP virtual memory), never move
+  bool pools_ready_ = false;
+  DeviceBuffer table_;
   uint64_t pool_elems_ = 0;   // capacity of the pools, in elements
   uint64_t bump_ = 0;         // high-water mark of the segment allocator
   uint64_t table_cap_ = 0;    // entries allocated in table_
