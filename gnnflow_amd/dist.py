@@ -313,9 +313,13 @@ class DevicePartitionedSampler:
     sampler: a gnnflow_amd.TemporalSampler over THIS rank's shard (edges whose source it
     owns, see PartitionedGraph)."""
 
-    def __init__(self, sampler, group=None):
+    def __init__(self, sampler, group=None, always_exchange=False):
+        """always_exchange: take the multi-rank path — count exchange, request / reply
+        all-to-all-v, served requests, merge — even with one rank (where every message is
+        empty).  For tests: it is the only way to run the RCCL branch on a one-GPU box."""
         import ctypes as C
         from . import _capi
+        self._always_exchange = bool(always_exchange)
         self._C, self._capi = C, _capi
         self._lib = _capi.load()
         self._sampler = sampler
@@ -387,7 +391,7 @@ class DevicePartitionedSampler:
         out_ptr = slab[5] + off
         ws = self._workspace(ws_bytes, stream)
         sptr = slab[6]
-        if P == 1:
+        if P == 1 and not self._always_exchange:
             call = lib.gf_sampler_sample_partitioned_async if worker_enqueue \
                 else lib.gf_sampler_sample_partitioned
             check(call(smp._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
@@ -482,6 +486,9 @@ class FeatureShards:
                                                   device=self.device)
         self.bytes_sent = 0       # ids out + rows back, for the traffic figures in DESIGN.md
         self.rows_pulled = 0
+        # tests: run the collective protocol even with one rank (every row then travels
+        # through the all-to-all-v to this rank itself)
+        self.always_exchange = False
 
     @classmethod
     def from_full(cls, feats, keys, rank: int, world_size: int, device, group=None):
@@ -498,7 +505,7 @@ class FeatureShards:
         dev, P = self.device, self.P
         ids = ids.to(dev, torch.int64)
         n = int(ids.shape[0])
-        if P == 1:
+        if P == 1 and not self.always_exchange:
             local = self.index[ids].long()
             if n and bool((local < 0).any()):
                 raise KeyError("FeatureShards.pull: id without a row on its owner")

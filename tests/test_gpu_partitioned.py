@@ -153,6 +153,85 @@ def test_ranks_sharing_one_gpu_match_the_oracle(world):
     assert dict(ret) == {r: True for r in range(world)}
 
 
+def _rccl_worker(rank, world, port, ret):
+    """One rank, backend "nccl" (= RCCL): the multi-rank path of DevicePartitionedSampler —
+    count exchange, asynchronous request all-to-all-v overlapped with the own share, served
+    requests, reply all-to-all-v, merge — with every message empty, and FeatureShards' pull
+    protocol; both straight on HBM tensors through RCCL, on the sampling stream."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from gnnflow_amd import DynamicGraph, TemporalSampler
+        from gnnflow_amd.dist import DevicePartitionedSampler, _backend_is_host_only, _exchange
+        from tests import synth
+        assert not _backend_is_host_only(None)
+        # the collective itself, on HBM tensors, also asynchronously
+        a = torch.arange(12, dtype=torch.int64, device=dev).view(6, 2)
+        b = torch.empty_like(a)
+        w = _exchange(b, a, [6], [6], None, async_op=True)
+        w.wait()
+        ok = bool(torch.equal(a, b))
+        src, dst, ts, eid = _graph()
+        g = DynamicGraph(1 << 20, 64 << 20, "cuda", 8, 64, "insert")
+        g.add_edges(src, dst, ts, eid, add_reverse=True)
+        kw = dict(fanouts=[7, 5], sample_strategy="recent")
+        plain = TemporalSampler(g, **kw)
+        part = DevicePartitionedSampler(TemporalSampler(g, **kw), always_exchange=True)
+        side = torch.cuda.Stream()
+        for it, R in enumerate([0, 1, 97, 600, 3000]):
+            nodes, t = synth.random_roots(400, R, 1000.0, seed=it, extra_ids=[403])
+            if it % 2:
+                got = part.sample_async(torch.from_numpy(nodes).to(dev), torch.from_numpy(t).to(dev),
+                                        stream=side).wait()
+            else:
+                got = part.sample(nodes, t)
+            want = plain.sample(nodes, t)
+            for gl, wl in zip(got, want):
+                for gb, wb in zip(gl, wl):
+                    ok &= gb.num_dst_nodes() == wb.num_dst_nodes()
+                    for x, y in ((gb.srcdata["ID"], wb.srcdata["ID"]), (gb.srcdata["ts"], wb.srcdata["ts"]),
+                                 (gb.edata["ID"], wb.edata["ID"]), (gb.edata["dt"], wb.edata["dt"]),
+                                 (gb.edges()[0], wb.edges()[0]), (gb.edges()[1], wb.edges()[1])):
+                        ok &= bool(torch.equal(x, y))
+        # owner-sharded feature rows: ids out and rows back through RCCL (to this rank itself)
+        from gnnflow_amd.dist import FeatureShards
+        rng = np.random.RandomState(3)
+        table = rng.rand(5000, 172).astype(np.float32)
+        shards = FeatureShards.from_full(torch.from_numpy(table), np.arange(5000), 0, 1, dev)
+        shards.always_exchange = True
+        for n in (0, 1, 777, 4096):
+            ids = rng.randint(0, 5000, n).astype(np.int64)
+            rows = shards.pull(torch.from_numpy(ids).to(dev), torch.from_numpy(ids).to(dev))
+            ok &= bool(np.array_equal(rows.cpu().numpy(), table[ids]))
+        torch.cuda.synchronize()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multi_rank_path_over_rccl_with_one_rank():
+    """No box with more than one GPU has been available, so RCCL never carried a message
+    between two ranks; this at least runs the RCCL branch of the exchange — process-group
+    initialisation with a device id, all_to_all_single on HBM tensors (synchronous and
+    async_op + wait), stream ordering against the sampler's kernels on a side stream — with
+    one rank, where the partitioned sampler normally short-circuits to the native chain."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
+    assert dict(ret) == {0: True}
+
+
 def test_uniform_policy_through_the_padded_kernel_is_uniform():
     """Partitioned uniform sampling is distribution-matched (each owner draws from its own
     Philox stream): every in-window edge equally likely, all `fanout` slots filled (sampling
