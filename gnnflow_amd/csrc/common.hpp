@@ -128,54 +128,31 @@ class DeviceBuffer {
   size_t bytes_ = 0;
 };
 
-// A device buffer that grows IN PLACE: a range of virtual addresses is reserved once
-// (hipMemAddressReserve) and physical memory is mapped behind what is already there as the
-// buffer grows (hipMemCreate / hipMemMap, chunks that double) — no reallocation, no copy of the
-// old contents, the address never changes, and kernels that are running on the old part are
-// not disturbed.  (Growing a multi-GB hipMalloc'd pool by reallocation was measured anywhere
-// between 2 and 260 ms per step on the same machine.)  Opt-in (see init()); otherwise, or if
-// the virtual-memory API is not available, the buffer grows by reallocation.
+// A device buffer that grows by reallocation while it is small and IN PLACE once it is large:
+// from kInPlaceBytes on, a range of virtual addresses is reserved (hipMemAddressReserve) and
+// physical memory is mapped behind what is already there as the buffer grows (hipMemCreate /
+// hipMemMap, 1 GiB pieces) — no reallocation, no copy of the old contents, no second copy of
+// the buffer alive while it grows, and the address no longer changes.  Growing a multi-GB
+// hipMalloc'd pool by reallocation was measured at 120-530 ms per step on the MAG-shaped build
+// (8.6 -> 17 GB) and needs old + new at once.  Small buffers stay on hipMalloc: with the pools
+// of the 21 MB REDDIT-shaped graph mapped this way the hash-partitioned replay ran at 76 us
+// per step instead of 52 (unexplained; sampling on the multi-GB graphs is unaffected).
+// GNNFLOW_VMM_POOLS=0: always reallocate.
 class GrowBuffer {
  public:
+  static constexpr size_t kInPlaceBytes = size_t(1) << 30;
+  static constexpr size_t kPiece = size_t(1) << 30;
+
   GrowBuffer() = default;
   GrowBuffer(const GrowBuffer&) = delete;
   GrowBuffer& operator=(const GrowBuffer&) = delete;
   ~GrowBuffer() { release(); }
 
-  // max_bytes: the most it may ever be asked to hold (the reservation; costs nothing)
+  // max_bytes: the most it may ever be asked to hold (the reservation costs nothing)
   void init(size_t max_bytes, int device) {
     release();
-    // OFF unless GNNFLOW_VMM_POOLS=1.  Measured on ROCm 7.2 / MI355X: growth steps cost 0.1-0.2
-    // ms instead of 1-260 ms, but the 200 M-edge build is no faster over all (249 vs 247 M
-    // edges/s, the steps are few) and the hash-partitioned replay ran at 76 us per step instead
-    // of 52 with the pools mapped this way (plain path: unchanged) — unexplained, so the
-    // reallocating pools stay the default.
-    static const bool enabled = [] {
-      const char* v = std::getenv("GNNFLOW_VMM_POOLS");
-      return v && std::atoi(v) == 1;
-    }();
-    if (!enabled) return;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = device;
-    size_t gran = 0;
-    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) !=
-            hipSuccess || gran == 0) {
-      (void)hipGetLastError();
-      return;
-    }
-    gran_ = std::max<size_t>(gran, size_t(2) << 20);
-    va_ = align_up(std::max<size_t>(max_bytes, gran_), gran_);
-    void* base = nullptr;
-    if (hipMemAddressReserve(&base, va_, gran_, nullptr, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      va_ = 0;
-      return;
-    }
-    base_ = static_cast<char*>(base);
+    max_bytes_ = max_bytes;
     device_ = device;
-    vmm_ = true;
   }
 
   void* data() const { return vmm_ ? static_cast<void*>(base_) : fallback_.data(); }
@@ -186,12 +163,62 @@ class GrowBuffer {
   // makes [0, n) usable; the first `keep` bytes keep their contents
   void reserve(size_t n, size_t keep, hipStream_t stream) {
     if (!vmm_) {
-      fallback_.reserve(n, keep, stream);
+      if (n <= fallback_.bytes()) return;
+      if (n < kInPlaceBytes || !start_in_place()) {
+        fallback_.reserve(n, keep, stream);
+        return;
+      }
+      // the move into the reserved range: the one copy this buffer will ever see again
+      map_up_to(n);
+      if (keep && fallback_.data()) {
+        GF_HIP(hipMemcpyAsync(base_, fallback_.data(), keep, hipMemcpyDeviceToDevice, stream));
+        GF_HIP(hipStreamSynchronize(stream));
+      }
+      fallback_.release();
       return;
     }
-    if (n <= mapped_) return;
-    if (n > va_ / std::max<size_t>(piece_, 1) * std::max<size_t>(piece_, 1) && piece_)
-      throw Error(GF_ERR_OUT_OF_MEMORY, "device pool: more than the reserved address range");
+    if (n > mapped_) map_up_to(n);
+  }
+
+  void release() {
+    if (vmm_) {
+      size_t off = 0;
+      for (auto& h : chunks_) {
+        (void)hipMemUnmap(base_ + off, kPiece);
+        (void)hipMemRelease(h);
+        off += kPiece;
+      }
+      chunks_.clear();
+      if (base_) (void)hipMemAddressFree(base_, va_);
+    }
+    fallback_.release();
+    vmm_ = false;
+    base_ = nullptr;
+    va_ = mapped_ = 0;
+  }
+
+ private:
+  bool start_in_place() {
+    static const bool enabled = [] {
+      const char* v = std::getenv("GNNFLOW_VMM_POOLS");
+      return !(v && std::atoi(v) == 0);
+    }();
+    if (!enabled || max_bytes_ < kInPlaceBytes) return false;
+    va_ = align_up(max_bytes_, kPiece);
+    void* base = nullptr;
+    if (hipMemAddressReserve(&base, va_, kPiece, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      va_ = 0;
+      return false;
+    }
+    base_ = static_cast<char*>(base);
+    vmm_ = true;
+    return true;
+  }
+
+  // Pieces of ONE size: with pieces of different sizes in one reservation hipMemSetAccess
+  // fails with "invalid argument" on ROCm 7.2 (scripts/micro/vmm_probe2.hip).
+  void map_up_to(size_t n) {
     if (n > va_)
       throw Error(GF_ERR_OUT_OF_MEMORY, "device pool: more than the reserved address range");
     hipMemAllocationProp prop = {};
@@ -201,54 +228,22 @@ class GrowBuffer {
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    // Pieces of ONE size per buffer, fixed by the first request (2 MB ... 256 MB): with pieces
-    // of different sizes in one reservation hipMemSetAccess fails with "invalid argument" on
-    // ROCm 7.2 (scripts/micro/vmm_probe2.hip); uniform pieces never did.
-    if (piece_ == 0) {
-      piece_ = gran_;
-      while (piece_ < n && piece_ < (size_t(256) << 20)) piece_ *= 2;
-    }
-    // at least as much again as is mapped (doubling), at least what is asked for
-    const size_t goal = std::min(align_up(std::max(n, 2 * mapped_), piece_), va_ / piece_ * piece_);
+    const size_t goal = align_up(n, kPiece);
     while (mapped_ < goal) {
-      const size_t chunk = piece_;
       hipMemGenericAllocationHandle_t h;
-      hipError_t e = hipMemCreate(&h, chunk, &prop, 0);
-      if (e != hipSuccess && mapped_ >= n) {   // the headroom beyond `n` is optional
-        (void)hipGetLastError();
-        break;
-      }
-      GF_HIP(e);
-      GF_HIP(hipMemMap(base_ + mapped_, chunk, 0, h, 0));
-      GF_HIP(hipMemSetAccess(base_ + mapped_, chunk, &acc, 1));
-      chunks_.push_back({h, chunk});
-      mapped_ += chunk;
+      GF_HIP(hipMemCreate(&h, kPiece, &prop, 0));
+      GF_HIP(hipMemMap(base_ + mapped_, kPiece, 0, h, 0));
+      GF_HIP(hipMemSetAccess(base_ + mapped_, kPiece, &acc, 1));
+      chunks_.push_back(h);
+      mapped_ += kPiece;
     }
   }
 
-  void release() {
-    if (vmm_) {
-      size_t off = 0;
-      for (auto& c : chunks_) {
-        (void)hipMemUnmap(base_ + off, c.second);
-        (void)hipMemRelease(c.first);
-        off += c.second;
-      }
-      chunks_.clear();
-      if (base_) (void)hipMemAddressFree(base_, va_);
-    }
-    fallback_.release();
-    vmm_ = false;
-    base_ = nullptr;
-    va_ = mapped_ = piece_ = 0;
-  }
-
- private:
   bool vmm_ = false;
   char* base_ = nullptr;
-  size_t va_ = 0, mapped_ = 0, gran_ = 0, piece_ = 0;
+  size_t va_ = 0, mapped_ = 0, max_bytes_ = 0;
   int device_ = 0;
-  std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks_;
+  std::vector<hipMemGenericAllocationHandle_t> chunks_;
   DeviceBuffer fallback_;
 };
 

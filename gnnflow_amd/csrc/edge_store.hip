@@ -279,7 +279,13 @@ void EdgeStore::seg_free(uint64_t start, uint64_t cap) {
 void EdgeStore::ensure_pool(uint64_t elems) {
   if (elems <= pool_elems_) return;
   uint64_t cap = pool_elems_ ? pool_elems_ : std::max<uint64_t>(initial_pool_size_ / kBlockSpace, 1024);
-  while (cap < elems) cap *= 2;
+  if (nbr_pool_.in_place() && ts_pool_.in_place()) {
+    // growing in place costs nothing but the mapping: a quarter of headroom instead of doubling
+    // (at 1.3 G edges doubling left 160 GB of HBM in use for 47 GB of edges)
+    cap = std::max(cap, elems + elems / 4);
+  } else {
+    while (cap < elems) cap *= 2;
+  }
   // the whole used prefix [0, old bump) is preserved across the reallocation
   uint64_t keep = std::min<uint64_t>(pool_elems_, bump_);
   if (!pools_ready_) {
