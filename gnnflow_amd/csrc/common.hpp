@@ -164,7 +164,7 @@ class GrowBuffer {
   void reserve(size_t n, size_t keep, hipStream_t stream) {
     if (!vmm_) {
       if (n <= fallback_.bytes()) return;
-      if (n < kInPlaceBytes || !start_in_place()) {
+      if (n < in_place_bytes() || !start_in_place()) {
         fallback_.reserve(n, keep, stream);
         return;
       }
@@ -198,12 +198,20 @@ class GrowBuffer {
   }
 
  private:
+  static size_t in_place_bytes() {
+    static const size_t v = [] {
+      const char* e = std::getenv("GNNFLOW_VMM_MIN_BYTES");   // experiments / tests
+      return e ? static_cast<size_t>(std::atoll(e)) : kInPlaceBytes;
+    }();
+    return v;
+  }
+
   bool start_in_place() {
     static const bool enabled = [] {
       const char* v = std::getenv("GNNFLOW_VMM_POOLS");
       return !(v && std::atoi(v) == 0);
     }();
-    if (!enabled || max_bytes_ < kInPlaceBytes) return false;
+    if (!enabled || max_bytes_ < in_place_bytes()) return false;
     va_ = align_up(max_bytes_, kPiece);
     void* base = nullptr;
     if (hipMemAddressReserve(&base, va_, kPiece, nullptr, 0) != hipSuccess) {
