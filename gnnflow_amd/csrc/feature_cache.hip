@@ -133,6 +133,9 @@ struct Ctx {
   // its neighbour); rows `dim` floats apart
   int odd4;
   uint32_t dim, tail;
+  // the feature table is in HBM: the install kernel copies a missed row into the cache from
+  // the table (read by the gather a moment ago: in L2) rather than from the streamed output
+  int inst_from_table;
   uint32_t tile_rows;       // rows per wave in the gather
   uint32_t inflight;        // 16-byte loads a lane keeps in flight while copying a tile
   float* out;
@@ -1140,9 +1143,10 @@ __global__ __launch_bounds__(kWide) void lru_queue_count_kernel(Round r) {
 // the cache, as one flat array of 16-byte vectors, kWide threads, K loads in flight per thread
 // (rows of `rowf` floats; VecT float4 for 16-byte-aligned rows, uf4 otherwise).
 template <typename VecT, int K>
-__device__ inline void copy_installed(const Ctx& c, const uint2* inst, uint32_t n_inst,
-                                      uint32_t rowf, int tid) {
+__device__ inline void copy_installed(const Ctx& c, const uint2* inst, const int64_t* inst_id,
+                                      uint32_t n_inst, uint32_t rowf, int tid) {
   const uint32_t total = n_inst * c.dimv;
+  const bool table = c.inst_from_table != 0;
 #pragma unroll 1
   for (uint32_t f0 = tid; f0 < total; f0 += K * kWide) {
     float4 v[K];   // (an array of the under-aligned uf4 would live in scratch)
@@ -1155,7 +1159,9 @@ __device__ inline void copy_installed(const Ctx& c, const uint2* inst, uint32_t 
       const uint2 pr = inst[j];
       dj[k] = ok ? pr.x : ~0u;
       dc[k] = min(cc * 4, rowf - 4);   // odd rows: the last vector ends with the row
-      const VecT t = *reinterpret_cast<const VecT*>(c.out + static_cast<uint64_t>(pr.y) * rowf + dc[k]);
+      const float* srow = table ? c.feats + static_cast<uint64_t>(inst_id[j]) * rowf
+                                : c.out + static_cast<uint64_t>(pr.y) * rowf;
+      const VecT t = *reinterpret_cast<const VecT*>(srow + dc[k]);
       v[k] = make_float4(t.x, t.y, t.z, t.w);
     }
 #pragma unroll
@@ -1192,6 +1198,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
     // ~10 us of dependent loads — one workgroup fits a CU — would otherwise come n / 256 / 256
     // times in a row)
     __shared__ uint2 inst[kWide];   // {slot, row} installed by this workgroup
+    __shared__ int64_t inst_id[kWide];   // ... and the id (the row's place in the table)
     __shared__ uint32_t n_inst;
     __shared__ uint32_t s_keep[kMaxStageTiles], s_hitp[kMaxStageTiles], s_nonhit;
     const uint32_t span_rows = c.tiles_per_wg * kLruRows;
@@ -1264,7 +1271,9 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
           if (old >= 0) c.map[old] = kAbsent;
           c.slot_id[slot] = id;
           c.map[id] = static_cast<int32_t>(slot);
-          inst[atomicAdd(&n_inst, 1u)] = make_uint2(slot, i);
+          const uint32_t at = atomicAdd(&n_inst, 1u);
+          inst[at] = make_uint2(slot, i);
+          inst_id[at] = id;
         } else {
           c.map[id] = kAbsent;   // "we only cache the first self.capacity", lru_cache.py:127-133
         }
@@ -1273,16 +1282,18 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
       // copy the installed rows out of the block's output, as one flat array
       const uint32_t total = n_inst * c.dimv;
       if (c.vec4) {
-        if (c.inst_rows > kInstRows) copy_installed<float4, 6>(c, inst, n_inst, c.dimv * 4, tid);
-        else copy_installed<float4, 2>(c, inst, n_inst, c.dimv * 4, tid);
+        if (c.inst_rows > kInstRows) copy_installed<float4, 6>(c, inst, inst_id, n_inst, c.dimv * 4, tid);
+        else copy_installed<float4, 2>(c, inst, inst_id, n_inst, c.dimv * 4, tid);
       } else if (c.odd4) {
-        if (c.inst_rows > kInstRows) copy_installed<uf4, 6>(c, inst, n_inst, c.dim, tid);
-        else copy_installed<uf4, 2>(c, inst, n_inst, c.dim, tid);
+        if (c.inst_rows > kInstRows) copy_installed<uf4, 6>(c, inst, inst_id, n_inst, c.dim, tid);
+        else copy_installed<uf4, 2>(c, inst, inst_id, n_inst, c.dim, tid);
       } else {
         for (uint32_t f = tid; f < total; f += kWide) {
           const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
           const uint2 pr = inst[j];
-          c.cache_buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] = c.out[static_cast<uint64_t>(pr.y) * c.dimv + cc];
+          c.cache_buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] =
+              c.inst_from_table ? c.feats[static_cast<uint64_t>(inst_id[j]) * c.dimv + cc]
+                                : c.out[static_cast<uint64_t>(pr.y) * c.dimv + cc];
         }
       }
       __syncthreads();
@@ -1586,6 +1597,16 @@ __global__ void cache_probe_kernel(const int64_t* __restrict__ ids, uint64_t n,
   }
 }
 
+inline bool pointer_on_device(const void* p) {
+  hipPointerAttribute_t attr;
+  std::memset(&attr, 0, sizeof(attr));
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice;
+}
+
 // rows that are not float4-addressable (dim % 4 != 0, or a misaligned base) still move as
 // 16-byte vectors at 4-byte alignment; `allowed`: the kernels that will see
 // this context know the mode (the LFU / FIFO install does not)
@@ -1834,6 +1855,7 @@ FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const fl
   GF_REQUIRE(capacity <= num_ids, "cache: capacity larger than the id space");
   GF_REQUIRE(capacity < 0x7FFFFFFFull, "cache: capacity must be < 2^31");
   DeviceGuard dg(device_);
+  table_on_device_ = pointer_on_device(d_feats);
   buffer_.reserve(std::max<size_t>(capacity * dim * sizeof(float), 16), 0, nullptr, true);
   map_.reserve(std::max<size_t>(num_ids * sizeof(int32_t), 16));
   slot_id_.reserve(std::max<size_t>(capacity * sizeof(int64_t), 16));
@@ -2034,7 +2056,10 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
   GF_REQUIRE(new_capacity <= new_num_ids && new_capacity < 0x7FFFFFFFull,
              "cache: invalid capacity");
   DeviceGuard dg(device_);
-  if (d_feats) feats_ = d_feats;
+  if (d_feats) {
+    feats_ = d_feats;
+    table_on_device_ = pointer_on_device(d_feats);
+  }
   if (policy_ == GF_CACHE_LRU && new_capacity > capacity_) compact_queue(stream);   // dense list
   if (new_num_ids > num_ids_) {
     DeviceBuffer nmap;
@@ -2162,6 +2187,7 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
   c.n = static_cast<uint32_t>(n);
   c.vec4 = vec4_ok(dim_, buffer_.data(), feats_, d_out) ? 1 : 0;
   c.dimv = static_cast<uint32_t>(c.vec4 ? dim_ / 4 : dim_);
+  c.inst_from_table = table_on_device_ ? 1 : 0;
   set_odd4(c, dim_, policy_ == GF_CACHE_LRU || !update || capacity_ == 0);
   c.tile_rows = pick_tile_rows(n);
   c.inflight = pick_inflight();
@@ -2257,6 +2283,7 @@ void FeatureCache::fetch_pulled(const int64_t* d_ids, size_t n, float* d_out, bo
   prepare(d_ids, n, d_out, update, d_stats, &r.c[0], stream);
   r.c[0].miss_rows = d_miss_rows;
   r.c[0].miss_index = d_miss_index;
+  r.c[0].inst_from_table = 0;   // the missed rows are the pulled ones, not the local table's
   if (r.c[0].vec4 && (reinterpret_cast<uintptr_t>(d_miss_rows) & 15u)) {
     r.c[0].vec4 = 0;
     r.c[0].dimv = static_cast<uint32_t>(dim_);

@@ -66,6 +66,7 @@ class FeatureCache {
   size_t num_ids_, capacity_, dim_;
   const float* feats_;
   int device_;
+  bool table_on_device_ = false;   // the feature table is HBM-resident (not pinned host memory)
 
   DeviceBuffer buffer_;    // float[capacity * dim]        cache rows
   DeviceBuffer map_;       // int32[num_ids]               id -> slot (kAbsent if none)
