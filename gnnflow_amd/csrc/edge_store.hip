@@ -739,7 +739,11 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     // of threads here: the planning passes run at the same time)
     parallel_for(n, 1 << 16, 4, [&](size_t i0, size_t i1) {
       size_t nn = 0, ns = 0;
-      for (size_t i = i0; i < i1; ++i) mark(dst[i], 1, &nn, &ns);
+      for (size_t i = i0; i < i1; ++i) {
+        // random bytes of a table that is 120 MB at MAG scale: fetch ahead
+        if (i + 32 < i1) __builtin_prefetch(&seen_[dst[i + 32]], 0, 1);
+        mark(dst[i], 1, &nn, &ns);
+      }
       std::lock_guard<std::mutex> lk(mu);
       num_nodes_ += nn;
     });
