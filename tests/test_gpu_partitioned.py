@@ -141,7 +141,7 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_ranks_sharing_one_gpu_match_the_oracle(world):
     import torch.multiprocessing as mp
     s = socket.socket()
