@@ -75,3 +75,31 @@ def test_feature_shards_single_process():
     ids = torch.tensor([3, 3, 49, 0])
     assert np.array_equal(sh.pull(ids, ids).numpy(), feats[[3, 3, 49, 0]])
     assert sh.pull(ids[:0], ids[:0]).shape == (0, 4)
+
+
+def _worker_one(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnnflow_amd.dist import FeatureShards
+        rng = np.random.RandomState(2)
+        feats = rng.rand(300, 5).astype(np.float32)
+        sh = FeatureShards.from_full(feats, np.arange(300), 0, 1, "cpu")
+        sh.always_exchange = True     # the collective protocol with one rank: rows travel to itself
+        ok = True
+        for n in (0, 1, 64, 1000):
+            ids = rng.randint(0, 300, n).astype(np.int64)
+            ok &= np.array_equal(sh.pull(torch.from_numpy(ids), torch.from_numpy(ids)).numpy(),
+                                 feats[ids])
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_feature_shards_forced_exchange_with_one_rank():
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_one, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert dict(ret) == {0: True}
