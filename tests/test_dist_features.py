@@ -60,7 +60,7 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_feature_shards_pull_over_gloo(world):
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)

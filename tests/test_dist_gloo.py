@@ -107,6 +107,17 @@ def test_partitioned_sampler_three_ranks_own_share_in_the_middle():
     assert dict(ret) == {0: True, 1: True, 2: True}
 
 
+def test_partitioned_sampler_eight_ranks():
+    """world_size 8 — the whole target node (8 GPUs): every rank both requests from and serves
+    7 peers, one of them with an empty batch in every round.  Runs on CPU processes, where
+    the GPU box's limit of 6 processes per card does not apply."""
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), CFGS[0], ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
 def _single_rank_worker(rank, world, port, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -141,7 +141,9 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
+# At most 4 ranks: the GPU box allows 6 processes on the card, and the pytest parent holds it
+# too (world 8 lives on the CPU: tests/test_dist_gloo.py).
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_ranks_sharing_one_gpu_match_the_oracle(world):
     import torch.multiprocessing as mp
     s = socket.socket()
