@@ -57,7 +57,8 @@ class GfPartLayout(C.Structure):
     """struct gf_part_layout (include/gnnflow_hip.h): byte offsets inside the workspace of
     one (layer, snapshot) of a chained partitioned sample."""
     _fields_ = [(n, C.c_size_t) for n in ("root_bound", "requests", "replies", "counts", "pos",
-                                          "scratch", "scratch_bytes", "total")]
+                                          "scratch", "scratch_bytes", "total", "slot_stride",
+                                          "inbox", "served")]
 
 
 # every symbol include/gnnflow_hip.h declares: name -> (restype, argtypes)
@@ -134,6 +135,12 @@ PROTOTYPES = {
     "gf_sampler_part_begin": (C.c_int, [_p, _p, _p, _sz, _p, _sz, C.c_int, C.c_int, _p]),
     "gf_sampler_part_plan_own": (C.c_int, [_p, C.c_uint32, C.c_uint32, _p, _sz, C.c_int]),
     "gf_sampler_part_merge": (C.c_int, [_p, C.c_uint32, C.c_uint32, _p, _sz]),
+    "gf_sampler_part_layout_slotted": (C.c_int, [_p, _sz, C.c_uint32, C.c_int, C.c_double, _sz,
+                                                 C.POINTER(GfPartLayout)]),
+    "gf_sampler_part_begin_slotted": (C.c_int, [_p, _p, _p, _sz, _p, _sz, C.c_int, C.c_int,
+                                                C.c_double, _sz, _p]),
+    "gf_sampler_part_serve": (C.c_int, [_p, C.c_uint32, C.c_uint32, _p, _sz]),
+    "gf_sampler_part_overflowed": (C.c_int, [_p, C.POINTER(C.c_int)]),
     "gf_sampler_part_commit": (C.c_int, [_p]),
     "gf_sampler_part_abort": (C.c_int, [_p]),
     "gf_sampler_sample_partitioned": (C.c_int, [_p, _p, _p, _sz, _p, _sz, _p, _sz, _p]),

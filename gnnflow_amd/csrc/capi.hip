@@ -636,7 +636,17 @@ int gf_sampler_part_layout(const gf_sampler* s, size_t num_roots, uint32_t layer
   return guarded([&] {
     GF_REQUIRE(s != nullptr, "null sampler handle");
     GF_REQUIRE(world_size >= 1 && world_size <= 64, "partition: world size must be 1..64");
-    s->impl.part_layout(std::max<size_t>(num_roots, 1), layer, world_size, out);
+    s->impl.part_layout(std::max<size_t>(num_roots, 1), layer, world_size, 0.0, 0, out);
+  });
+}
+int gf_sampler_part_layout_slotted(const gf_sampler* s, size_t num_roots, uint32_t layer,
+                                   int world_size, double slack, size_t slot_roots,
+                                   gf_part_layout* out) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    GF_REQUIRE(world_size >= 1 && world_size <= 64, "partition: world size must be 1..64");
+    GF_REQUIRE(slack > 0.0, "part_layout_slotted: slack must be positive");
+    s->impl.part_layout(std::max<size_t>(num_roots, 1), layer, world_size, slack, slot_roots, out);
   });
 }
 int gf_sampler_part_begin(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
@@ -646,8 +656,33 @@ int gf_sampler_part_begin(gf_sampler* s, const int64_t* d_roots, const float* d_
     GF_REQUIRE(s != nullptr, "null sampler handle");
     GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
                "part_begin: earlier samples were begun through the enqueue thread");
-    s->impl.part_begin(d_roots, d_root_ts, num_roots, d_out, out_bytes, world_size, rank,
+    s->impl.part_begin(d_roots, d_root_ts, num_roots, d_out, out_bytes, world_size, rank, 0.0, 0,
                        static_cast<hipStream_t>(stream));
+  });
+}
+int gf_sampler_part_begin_slotted(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,
+                                  size_t num_roots, void* d_out, size_t out_bytes, int world_size,
+                                  int rank, double slack, size_t slot_roots, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    GF_REQUIRE(slack > 0.0, "part_begin_slotted: slack must be positive");
+    GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
+               "part_begin: earlier samples were begun through the enqueue thread");
+    s->impl.part_begin(d_roots, d_root_ts, num_roots, d_out, out_bytes, world_size, rank, slack,
+                       slot_roots, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_sampler_part_serve(gf_sampler* s, uint32_t layer, uint32_t snapshot, void* d_ws,
+                          size_t ws_bytes) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    s->impl.part_serve(layer, snapshot, d_ws, ws_bytes);
+  });
+}
+int gf_sampler_part_overflowed(const gf_sampler* s, int* out) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr && out != nullptr, "part_overflowed: null argument");
+    *out = s->impl.last_overflow() ? 1 : 0;
   });
 }
 int gf_sampler_part_plan_own(gf_sampler* s, uint32_t layer, uint32_t snapshot, void* d_ws,

@@ -11,6 +11,15 @@
 // Layers of up to 32 768 roots: one launch (partition_plan_fused_kernel).  Larger ones: three
 // short launches — per-tile owner histograms (wave ballots), one-workgroup scan of the tile
 // table, stable scatter.  Integer / byte work, no atomics.
+//
+// Slotted form (stride != 0; the exchange without a host synchronisation): owner q's run
+// starts at the FIXED row q * stride — row q * stride itself is the slot's header
+// {rows in the slot, bit 0 = "a slot of the sending rank overflowed"} and up to
+// cap = stride - 1 requests follow — and the rank's own share starts at row P * stride, so the
+// send buffer is P equal slots whatever the counts are (an equal-split all-to-all needs no
+// sizes on the host).  Roots beyond a slot's capacity are not written (their pos is the
+// slot's header row, which no reply ever fills): the sample is flagged and sampled again
+// through the variable-size exchange.
 #include "common.hpp"
 
 #include <cstdint>
@@ -67,7 +76,8 @@ __global__ __launch_bounds__(kTileThreads) void partition_count_kernel(
 // tile's roots of owner o.
 __global__ __launch_bounds__(1024) void partition_scan_kernel(
     const uint32_t* __restrict__ tile_counts, uint64_t tiles, uint32_t P, uint32_t rank,
-    uint32_t* __restrict__ tile_base, uint64_t* __restrict__ counts) {
+    uint32_t* __restrict__ tile_base, uint64_t* __restrict__ counts, uint32_t stride,
+    int64_t* __restrict__ requests, uint32_t* __restrict__ d_overflow, int overflow_store) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry_s;
   __shared__ uint32_t total_s[kMaxParts];
@@ -100,10 +110,26 @@ __global__ __launch_bounds__(1024) void partition_scan_kernel(
   }
   // pass 2: where each owner's run starts
   if (tid == 0) {
-    uint32_t at = 0;
-    for (uint32_t o = 0; o < P; ++o)
-      if (o != rank) { start_s[o] = at; at += total_s[o]; }
-    start_s[rank] = at;
+    if (stride) {
+      const uint32_t cap = stride - 1;
+      uint32_t ovf = 0;
+      for (uint32_t o = 0; o < P; ++o) {
+        start_s[o] = o == rank ? P * stride : o * stride + 1;
+        if (o != rank && total_s[o] > cap) ovf = 1;
+      }
+      for (uint32_t o = 0; o < P; ++o) {
+        requests[2 * static_cast<uint64_t>(o) * stride] =
+            o == rank ? 0 : static_cast<int64_t>(min(total_s[o], cap));
+        requests[2 * static_cast<uint64_t>(o) * stride + 1] = ovf;
+      }
+      if (overflow_store) *d_overflow = ovf;
+      else if (ovf) *d_overflow = 1;
+    } else {
+      uint32_t at = 0;
+      for (uint32_t o = 0; o < P; ++o)
+        if (o != rank) { start_s[o] = at; at += total_s[o]; }
+      start_s[rank] = at;
+    }
     for (uint32_t o = 0; o < P; ++o) counts[o] = total_s[o];
   }
   __syncthreads();
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(kTileThreads) void partition_scatter_kernel(
     const int64_t* __restrict__ nodes, const float* __restrict__ ts,
     const uint64_t* __restrict__ d_R, uint64_t R_host, OwnerDiv od,
     const uint32_t* __restrict__ tile_base, int64_t* __restrict__ requests,
-    uint32_t* __restrict__ pos, uint32_t* __restrict__ root_of) {
+    uint32_t* __restrict__ pos, uint32_t* __restrict__ root_of, uint32_t stride, uint32_t rank) {
   const uint32_t P = od.P;
   __shared__ uint32_t wave_cnt[kTileThreads / 64][kMaxParts];
   const uint64_t R = d_R ? *d_R : R_host;
@@ -132,6 +158,10 @@ __global__ __launch_bounds__(kTileThreads) void partition_scatter_kernel(
   if (i >= R) return;
   uint32_t p = tile_base[static_cast<uint64_t>(blockIdx.x) * P + o] + before_in_wave;
   for (int w = 0; w < wave; ++w) p += wave_cnt[w][o];
+  if (stride && o != rank && p - (o * stride + 1) >= stride - 1) {   // beyond the slot
+    pos[i] = o * stride;
+    return;
+  }
   requests[2 * static_cast<uint64_t>(p)] = v;
   requests[2 * static_cast<uint64_t>(p) + 1] = static_cast<int64_t>(__float_as_uint(ts[i]));
   pos[i] = p;
@@ -154,7 +184,8 @@ __global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
     const int64_t* __restrict__ nodes, const float* __restrict__ ts,
     const uint64_t* __restrict__ d_R, uint64_t R_host, OwnerDiv od, uint32_t rank,
     int64_t* __restrict__ requests, uint32_t* __restrict__ pos, uint64_t* __restrict__ counts,
-    uint32_t* __restrict__ root_of) {
+    uint32_t* __restrict__ root_of, uint32_t stride, uint32_t* __restrict__ d_overflow,
+    int overflow_store) {
   const uint32_t P = od.P;
   __shared__ uint32_t s_before[kFusedThreads / 64][kMaxParts];
   __shared__ uint32_t s_total[kFusedThreads / 64][kMaxParts];
@@ -218,16 +249,38 @@ __global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
   }
   __syncthreads();
   if (tid == 0) {
-    uint32_t at = 0;
-    for (uint32_t o = 0; o < P; ++o)
-      if (o != rank) { s_start[o] = at; at += s_total[0][o]; }
-    s_start[rank] = at;
+    if (stride) {
+      const uint32_t cap = stride - 1;
+      uint32_t ovf = 0;
+      for (uint32_t o = 0; o < P; ++o) {
+        s_start[o] = o == rank ? P * stride : o * stride + 1;
+        if (o != rank && s_total[0][o] > cap) ovf = 1;
+      }
+      if (tile == 0) {   // the slots' headers; the sample-wide flag
+        for (uint32_t o = 0; o < P; ++o) {
+          requests[2 * static_cast<uint64_t>(o) * stride] =
+              o == rank ? 0 : static_cast<int64_t>(min(s_total[0][o], cap));
+          requests[2 * static_cast<uint64_t>(o) * stride + 1] = ovf;
+        }
+        if (overflow_store) *d_overflow = ovf;
+        else if (ovf) *d_overflow = 1;
+      }
+    } else {
+      uint32_t at = 0;
+      for (uint32_t o = 0; o < P; ++o)
+        if (o != rank) { s_start[o] = at; at += s_total[0][o]; }
+      s_start[rank] = at;
+    }
   }
   __syncthreads();
   const uint32_t i = tile * kFusedThreads + tid;
   if (i >= R) return;
   uint32_t p = s_start[my_owner] + s_before[0][my_owner] + before_in_wave;
   for (int w = 0; w < wave; ++w) p += s_tile[w][my_owner];
+  if (stride && my_owner != rank && p - s_start[my_owner] >= stride - 1) {   // beyond the slot
+    pos[i] = my_owner * stride;
+    return;
+  }
   requests[2 * static_cast<uint64_t>(p)] = my_node;
   requests[2 * static_cast<uint64_t>(p) + 1] = static_cast<int64_t>(__float_as_uint(ts[i]));
   pos[i] = p;
@@ -247,17 +300,27 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
                         size_t R_bound, int world_size, int rank, int64_t* d_requests,
                         uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
                         size_t scratch_bytes, int device, hipStream_t stream,
-                        uint32_t* d_root_of) {
+                        uint32_t* d_root_of, uint32_t stride, uint32_t* d_overflow,
+                        int overflow_store) {
   GF_REQUIRE(world_size >= 1 && world_size <= kMaxParts, "partition: world size must be 1..64");
+  GF_REQUIRE(stride == 0 || (stride >= 2 && d_overflow != nullptr),
+             "partition: the slotted form needs a stride >= 2 and an overflow word");
+  GF_REQUIRE(static_cast<uint64_t>(stride) * world_size + R_bound < 0xFFFFFFFFull,
+             "partition: more than 2^32-1 request rows");
   GF_REQUIRE(rank >= 0 && rank < world_size, "partition: rank out of range");
   GF_REQUIRE(d_counts != nullptr, "partition: null counts");
   GF_REQUIRE(R_bound < 0xFFFFFFFFull, "partition: more than 2^32-1 roots");
   DeviceGuard dg(device);
-  if (R_bound == 0) {
+  const bool no_roots = R_bound == 0;
+  if (no_roots && !stride) {
     GF_HIP(hipMemsetAsync(d_counts, 0, world_size * sizeof(uint64_t), stream));
     return;
   }
-  GF_REQUIRE(d_nodes && d_ts && d_requests && d_pos && d_scratch, "partition: null pointer");
+  // slotted: a rank without roots still writes its (empty) slot headers and the flag — one
+  // workgroup of the fused kernel with R = 0
+  if (no_roots) { R_bound = 1; d_R = nullptr; }
+  GF_REQUIRE(no_roots || (d_nodes && d_ts), "partition: null pointer");
+  GF_REQUIRE(d_requests && d_pos && d_scratch, "partition: null pointer");
   GF_REQUIRE(scratch_bytes >= partition_scratch_bytes(R_bound, world_size),
              "partition: scratch buffer too small");
   const uint32_t P = static_cast<uint32_t>(world_size);
@@ -266,11 +329,11 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
     const char* v = std::getenv("GNNFLOW_PARTITION_SMALL_PLAN");   // tests: 0 = tiled form only
     return !(v && std::atoi(v) == 0);
   }();
-  if (fused_plan && R_bound <= kFusedPlanRoots) {
+  if ((fused_plan || no_roots) && R_bound <= kFusedPlanRoots) {
     const unsigned grid = static_cast<unsigned>((R_bound + kFusedThreads - 1) / kFusedThreads);
     partition_plan_fused_kernel<<<dim3(grid), dim3(kFusedThreads), 0, stream>>>(
-        d_nodes, d_ts, d_R, R_bound, od, static_cast<uint32_t>(rank), d_requests, d_pos, d_counts,
-        d_root_of);
+        d_nodes, d_ts, d_R, no_roots ? 0 : R_bound, od, static_cast<uint32_t>(rank), d_requests,
+        d_pos, d_counts, d_root_of, stride, d_overflow, overflow_store);
     GF_HIP(hipGetLastError());
     return;
   }
@@ -280,11 +343,12 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
       static_cast<char*>(d_scratch) + align_up(tiles * world_size * sizeof(uint32_t), 16));
   partition_count_kernel<<<dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream>>>(
       d_nodes, d_R, R_bound, od, tile_counts);
-  partition_scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(tile_counts, tiles, P,
-                                                            static_cast<uint32_t>(rank), tile_base,
-                                                            d_counts);
+  partition_scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(
+      tile_counts, tiles, P, static_cast<uint32_t>(rank), tile_base, d_counts, stride, d_requests,
+      d_overflow, overflow_store);
   partition_scatter_kernel<<<dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream>>>(
-      d_nodes, d_ts, d_R, R_bound, od, tile_base, d_requests, d_pos, d_root_of);
+      d_nodes, d_ts, d_R, R_bound, od, tile_base, d_requests, d_pos, d_root_of, stride,
+      static_cast<uint32_t>(rank));
   GF_HIP(hipGetLastError());
 }
 
@@ -292,7 +356,7 @@ void partition_plan(const int64_t* d_nodes, const float* d_ts, size_t R, int wor
                     int64_t* d_requests, uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
                     size_t scratch_bytes, int device, hipStream_t stream) {
   partition_plan_dev(d_nodes, d_ts, nullptr, R, world_size, rank, d_requests, d_pos, d_counts,
-                     d_scratch, scratch_bytes, device, stream, nullptr);
+                     d_scratch, scratch_bytes, device, stream, nullptr, 0, nullptr, 0);
 }
 
 }  // namespace gf

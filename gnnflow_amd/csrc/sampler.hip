@@ -115,6 +115,7 @@ struct Publish {
   uint64_t* h_flag;           // pinned host sequence word
   uint64_t seq;
   uint32_t num_words;         // 0 = nothing to publish
+  const uint32_t* d_extra = nullptr;   // one more word behind the counts (slot overflow), or null
 };
 
 // Stream-ordered after the last emit kernel, so every output of the sample is complete
@@ -122,6 +123,7 @@ struct Publish {
 __global__ void sample_publish_kernel(Publish p) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (uint32_t i = 0; i < p.num_words; ++i) p.h_counts[i] = p.d_counts[i];
+  p.h_counts[p.num_words] = p.d_extra ? *p.d_extra : 0;
   __threadfence_system();
   *reinterpret_cast<volatile uint64_t*>(p.h_flag) = p.seq;
 }
@@ -591,14 +593,21 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
     uint32_t num_snapshots, float window, uint32_t fanout, int uniform, int prop_time,
     uint64_t seed, uint64_t call, int64_t* __restrict__ out,
     const uint64_t* __restrict__ d_own, const uint64_t* __restrict__ d_total,
-    uint64_t total_host, const uint32_t* __restrict__ root_of, uint32_t* __restrict__ rec_cnt) {
+    uint64_t total_host, const uint32_t* __restrict__ root_of, uint32_t* __restrict__ rec_cnt,
+    uint32_t stride, uint32_t world, uint32_t* __restrict__ d_overflow) {
   // d_own != null: "this rank's own share" of a chained partitioned layer — the last *d_own
   // of the layer's R request rows (R = *d_total, or total_host), counts still on the device.
   // root_of / rec_cnt (own share only): the number of valid slots of every row goes straight
   // to its root's counter, so the merge does not have to read the rows back to count them.
+  // stride != 0: the slotted layout (partition.hip).  Own share: it starts at row
+  // world * stride.  Otherwise `req` is the INBOX of an equal-split exchange — `world` slots of
+  // `stride` rows, row 0 of a slot its header {rows that follow, flags} — and only the rows
+  // a header announces are served (reply row = request row); a sender's overflow flag is
+  // folded into this rank's word, so every rank learns of it in the same exchange.
   if (d_own) {
     n = *d_own;
-    const uint64_t skip = (d_total ? *d_total : total_host) - n;
+    const uint64_t skip = stride ? static_cast<uint64_t>(world) * stride
+                                 : (d_total ? *d_total : total_host) - n;
     req += 2 * skip;
     out += skip * fanout * 3;
     if (root_of) root_of += skip;
@@ -608,7 +617,17 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
   const int group_in_wave = (threadIdx.x % 64) / GROUP;
   const uint64_t group = static_cast<uint64_t>(blockIdx.x) * kGroupsPerBlock + threadIdx.x / GROUP;
   const uint64_t num_groups = static_cast<uint64_t>(gridDim.x) * kGroupsPerBlock;
+  const bool inbox = stride && !d_own;
   for (uint64_t r = group; r < n; r += num_groups) {
+    if (inbox) {
+      const uint64_t q = r / stride, j = r - q * stride;
+      if (j == 0) {
+        if (lane == 0 && (req[2 * r + 1] & 1)) *d_overflow = 1;
+        continue;
+      }
+      const uint64_t rows = static_cast<uint64_t>(req[2 * q * stride]);
+      if (j - 1 >= min(rows, static_cast<uint64_t>(stride - 1))) continue;
+    }
     const int64_t nid = req[2 * r];
     const float t = __uint_as_float(static_cast<uint32_t>(static_cast<uint64_t>(req[2 * r + 1])));
     float start, end;
@@ -652,13 +671,18 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
 // valid slots of root i's reply row (a prefix of the row for both policies)
 __global__ void merge_count_kernel(const int64_t* __restrict__ rep, const uint32_t* __restrict__ pos,
                                    const uint64_t* __restrict__ d_R, uint64_t R_host,
-                                   uint32_t fanout, uint32_t* __restrict__ rec_cnt) {
+                                   uint32_t fanout, uint32_t* __restrict__ rec_cnt,
+                                   uint32_t stride, uint32_t world) {
   const uint64_t R = d_R ? *d_R : R_host;
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= R) return;
-  const int64_t* s = rep + static_cast<uint64_t>(pos[i]) * fanout * 3;
+  const uint32_t p = pos[i];
   uint32_t c = 0;
-  for (uint32_t j = 0; j < fanout; ++j) c += s[3 * j] >= 0 ? 1u : 0u;
+  // slotted layout: a header row stands for a root that did not fit its owner's slot
+  if (!(stride && p < world * stride && p % stride == 0)) {
+    const int64_t* s = rep + static_cast<uint64_t>(p) * fanout * 3;
+    for (uint32_t j = 0; j < fanout; ++j) c += s[3 * j] >= 0 ? 1u : 0u;
+  }
   rec_cnt[i] = c;
 }
 
@@ -735,6 +759,36 @@ __global__ void merge_count_remote_kernel(const int64_t* __restrict__ rep,
     uint32_t c = 0;
     for (uint32_t j = 0; j < fanout; ++j) c += s[3 * j] >= 0 ? 1u : 0u;
     rec_cnt[root_of[row]] = c;
+  }
+}
+
+// Slotted layout: the rows that arrived from other ranks sit in `world` slots of `stride`
+// rows (row 0 of a slot: the header row, never a reply); slot q holds min(counts[q], cap) rows.
+// A root that did not fit its owner's slot (pos = the slot's header row) has no reply: its
+// count is set to 0 here, so that the block's sizes stay within the layer's bounds while the
+// overflowed sample runs to its end (it is then sampled again, dist.py).
+__global__ void merge_count_slots_kernel(const int64_t* __restrict__ rep,
+                                         const uint32_t* __restrict__ root_of,
+                                         const uint32_t* __restrict__ pos,
+                                         const uint64_t* __restrict__ d_R, uint64_t R_host,
+                                         const uint64_t* __restrict__ counts, uint32_t stride,
+                                         uint32_t world, uint32_t rank, uint32_t fanout,
+                                         uint32_t* __restrict__ rec_cnt) {
+  const uint64_t rows = static_cast<uint64_t>(world) * stride;
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  const uint64_t first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (uint64_t row = first; row < rows; row += step) {
+    const uint64_t q = row / stride, j = row - q * stride;
+    if (j == 0 || q == rank || j - 1 >= min(counts[q], static_cast<uint64_t>(stride - 1))) continue;
+    const int64_t* s = rep + row * fanout * 3;
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < fanout; ++k) c += s[3 * k] >= 0 ? 1u : 0u;
+    rec_cnt[root_of[row]] = c;
+  }
+  const uint64_t R = d_R ? *d_R : R_host;
+  for (uint64_t i = first; i < R; i += step) {
+    const uint32_t p = pos[i];
+    if (p < rows && p % stride == 0) rec_cnt[i] = 0;
   }
 }
 
@@ -888,7 +942,7 @@ Sampler::Sampler(EdgeStore* graph, const uint32_t* fanouts, size_t num_layers, i
   }
   DeviceGuard dg(graph_->device());
   for (InFlight& f : ring_) GF_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
-  rec_words_ = 1 + 2 * num_layers * num_snapshots;
+  rec_words_ = 2 + 2 * num_layers * num_snapshots;   // flag, {R, S} per block, overflow
   h_counts_.reserve(kMaxInFlight * rec_words_ * sizeof(uint64_t));
   std::memset(h_counts_.data(), 0, kMaxInFlight * rec_words_ * sizeof(uint64_t));
   h_layer_counts_.reserve(2 * sizeof(uint64_t));
@@ -1147,6 +1201,7 @@ void Sampler::sample_end(gf_block* blocks) {
   };
   if (slot->roots == 0) {
     for (size_t b = 0; b < L * NS; ++b) std::memset(&blocks[b], 0, sizeof(gf_block));
+    last_overflow_ = false;
     pop();
     return;
   }
@@ -1181,6 +1236,7 @@ void Sampler::sample_end(gf_block* blocks) {
     o.num_edges = hc[2 * b + 1];
     o.num_src_nodes = o.num_dst_nodes + o.num_edges;
   }
+  last_overflow_ = hc[2 * L * NS] != 0;
   pop();
 }
 
@@ -1247,7 +1303,7 @@ void Sampler::sample_layer_padded(const int64_t* d_requests, size_t n, uint32_t 
                 num_snapshots_, window_, F, uniform, prop_time_ ? 1 : 0, seed_, call, d_out,
                 static_cast<const uint64_t*>(nullptr), static_cast<const uint64_t*>(nullptr),
                 static_cast<uint64_t>(0), static_cast<const uint32_t*>(nullptr),
-                static_cast<uint32_t*>(nullptr));
+                static_cast<uint32_t*>(nullptr), 0u, 0u, static_cast<uint32_t*>(nullptr));
   GF_HIP(hipGetLastError());
 }
 
@@ -1275,7 +1331,7 @@ void Sampler::merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, 
   uint64_t* d_counts = reinterpret_cast<uint64_t*>(w);
   BlockPtrs out = carve(static_cast<char*>(d_out), R, F);
   merge_count_kernel<<<dim3(static_cast<unsigned>((R + 255) / 256)), dim3(256), 0, stream>>>(
-      d_replies, d_pos, nullptr, R, F, rec_cnt);
+      d_replies, d_pos, nullptr, R, F, rec_cnt, 0u, 0u);
   if (R <= 65536) {
     sample_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
         rec_cnt, base, nullptr, R, F, 0, d_counts, d_counts + 1, nullptr);
@@ -1322,25 +1378,51 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
                         size_t R_bound, int world_size, int rank, int64_t* d_requests,
                         uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
                         size_t scratch_bytes, int device, hipStream_t stream,
-                        uint32_t* d_root_of);
+                        uint32_t* d_root_of, uint32_t stride, uint32_t* d_overflow,
+                        int overflow_store);
 size_t partition_scratch_bytes(size_t R, int world_size);
 
-void Sampler::part_layout(size_t R0, uint32_t layer, int world_size, gf_part_layout* out) const {
+void Sampler::part_layout(size_t R0, uint32_t layer, int world_size, double slack,
+                          size_t slot_roots, gf_part_layout* out) const {
   GF_REQUIRE(layer < fanouts_.size(), "part_layout: layer out of range");
   GF_REQUIRE(out != nullptr, "part_layout: null output");
+  GF_REQUIRE(slack >= 0.0, "part_layout: negative slack");
   const size_t Rb = root_bound(R0, layer), F = fanouts_[layer];
+  // slotted form (slack > 0): per-peer capacity = the even share of the worst-case root count
+  // times `slack`, never more than the layer can have; rows = P slots of (header + cap) + the
+  // own share's region.  The capacity follows from `slot_roots` — the batch size every rank
+  // agreed on — not from this rank's own R0: the slots must have the same size on all ranks.
+  size_t stride = 0, rows = Rb;
+  if (slack > 0.0) {
+    const size_t Sb = root_bound(std::max<size_t>(slot_roots, 1), layer);
+    const double share = std::ceil(static_cast<double>(Sb) * slack / world_size);
+    const size_t cap = std::max<size_t>(1, std::min<size_t>(Sb, static_cast<size_t>(share)));
+    stride = cap + 1;
+    rows = static_cast<size_t>(world_size) * stride + Rb;
+    GF_REQUIRE(rows < 0xFFFFFFFFull, "part_layout: more than 2^32-1 request rows");
+  }
   out->root_bound = Rb;
   out->requests = 0;
-  out->replies = Rb * 16;
-  out->counts = out->replies + Rb * F * 24;
+  out->replies = rows * 16;
+  out->counts = out->replies + rows * F * 24;
   out->pos = out->counts + align_up(static_cast<size_t>(world_size) * 8, 16);
   out->scratch = align_up(out->pos + Rb * 4, 16);
   out->scratch_bytes = partition_scratch_bytes(Rb, world_size);
-  out->total = align_up(out->scratch + out->scratch_bytes, 256);
+  size_t end = align_up(out->scratch + out->scratch_bytes, 256);
+  out->slot_stride = stride;
+  out->inbox = out->served = 0;
+  if (stride) {
+    const size_t slots = static_cast<size_t>(world_size) * stride;
+    out->inbox = end;
+    out->served = align_up(out->inbox + slots * 16, 256);
+    end = align_up(out->served + slots * F * 24, 256);
+  }
+  out->total = end;
 }
 
 void Sampler::part_begin(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
-                         size_t out_bytes, int world_size, int rank, hipStream_t stream) {
+                         size_t out_bytes, int world_size, int rank, double slack,
+                         size_t slot_roots, hipStream_t stream) {
   const size_t L = fanouts_.size(), NS = num_snapshots_;
   GF_REQUIRE(!part_.active, "part_begin: a partitioned sample is already being built");
   GF_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "part_begin: bad rank / world");
@@ -1356,7 +1438,10 @@ void Sampler::part_begin(const int64_t* d_roots, const float* d_ts, size_t R, vo
     slot = &ring_[(ring_head_ + ring_count_) % kMaxInFlight];
   }
   DeviceGuard dg(graph_->device());
-  reserve_workspace(root_bound(Rs, L - 1), L * NS, stream);
+  // root_of[] is indexed by request ROW: the slotted form has more rows than roots
+  gf_part_layout last;
+  part_layout(Rs, static_cast<uint32_t>(L - 1), world_size, slack, slot_roots, &last);
+  reserve_workspace(std::max(root_bound(Rs, L - 1), last.replies / 16), L * NS, stream);
   slot->ptrs.assign(L * NS, BlockPtrs{});
   slot->roots = Rs;          // never the "R = 0 short-circuit" record: sizes come from the device
   slot->stream = stream;
@@ -1377,7 +1462,14 @@ void Sampler::part_begin(const int64_t* d_roots, const float* d_ts, size_t R, vo
   part_.Rs = Rs;
   part_.world = world_size;
   part_.rank = rank;
+  part_.slack = slack;
+  part_.slot_roots = slot_roots;
   part_.stream = stream;
+}
+
+// the sample-wide "a slot overflowed somewhere" word: behind the block counters
+uint32_t* Sampler::part_overflow() const {
+  return reinterpret_cast<uint32_t*>(part_counts() + 2 * ws_blocks_);
 }
 
 // Scratch of the chained merge in the sampler's workspace (ordered by the stream like the rest
@@ -1423,7 +1515,7 @@ void Sampler::part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_
   GF_REQUIRE(part_.active, "part_plan_own: no partitioned sample is being built");
   GF_REQUIRE(layer < fanouts_.size() && snapshot < num_snapshots_, "part_plan_own: out of range");
   gf_part_layout lay;
-  part_layout(part_.Rs, layer, part_.world, &lay);
+  part_layout(part_.Rs, layer, part_.world, part_.slack, part_.slot_roots, &lay);
   GF_REQUIRE(d_ws && ws_bytes >= lay.total, "part_plan_own: workspace too small");
   DeviceGuard dg(graph_->device());
   char* w = static_cast<char*>(d_ws);
@@ -1431,22 +1523,28 @@ void Sampler::part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_
   part_roots(layer, snapshot, &roots, &ts, &d_R, &R_host);
   hipStream_t stream = part_.stream;
   const size_t Rb = lay.root_bound;
+  const uint32_t stride = static_cast<uint32_t>(lay.slot_stride);
   uint64_t* d_counts = reinterpret_cast<uint64_t*>(w + lay.counts);
   if (!(phases & 1)) {
     // planned by an earlier call
-  } else if (layer == 0 && part_.R == 0) {
+  } else if (layer == 0 && part_.R == 0 && !stride) {
     GF_HIP(hipMemsetAsync(d_counts, 0, part_.world * sizeof(uint64_t), stream));
   } else {
+    // slotted: the sample's first plan STORES the overflow word (the workspace is shared by
+    // the samples in flight on this stream), the later ones only raise it
     partition_plan_dev(roots, ts, d_R, layer == 0 ? part_.R : Rb, part_.world, part_.rank,
                        reinterpret_cast<int64_t*>(w + lay.requests),
                        reinterpret_cast<uint32_t*>(w + lay.pos), d_counts, w + lay.scratch,
                        lay.scratch_bytes, graph_->device(), stream,
-                       part_own_counts(layer == 0 ? part_.R : Rb) ? part_root_of() : nullptr);
+                       part_own_counts(layer == 0 ? part_.R : Rb) ? part_root_of() : nullptr,
+                       stride, stride ? part_overflow() : nullptr,
+                       layer == 0 && snapshot == 0 ? 1 : 0);
   }
   if (!(phases & 2)) return;
-  // this rank's own share: the last counts[rank] request rows; the kernel takes the count
-  // from the device, so with one rank nothing is read back, and with several the caller
-  // issues it right after starting the request all-to-all-v, which it then overlaps
+  // this rank's own share: the last counts[rank] request rows (slotted: the rows from
+  // world * stride on); the kernel takes the count from the device, so with one rank nothing
+  // is read back, and with several the caller issues it right after starting the request
+  // exchange, which it then overlaps
   const uint64_t call = calls_++;
   const uint32_t F = fanouts_[layer];
   const size_t n_bound = layer == 0 ? part_.R : Rb;
@@ -1460,16 +1558,49 @@ void Sampler::part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_
                   prop_time_ ? 1 : 0, seed_, call, reinterpret_cast<int64_t*>(w + lay.replies),
                   static_cast<const uint64_t*>(d_counts + part_.rank), d_R,
                   static_cast<uint64_t>(R_host), static_cast<const uint32_t*>(part_root_of()),
-                  part_own_counts(n_bound) ? part_rec_cnt() : static_cast<uint32_t*>(nullptr));
+                  part_own_counts(n_bound) ? part_rec_cnt() : static_cast<uint32_t*>(nullptr),
+                  stride, static_cast<uint32_t>(part_.world), static_cast<uint32_t*>(nullptr));
     GF_HIP(hipGetLastError());
   }
+}
+
+// Slotted form: serves the request inbox (what the equal-split exchange delivered: one slot per
+// rank) from this rank's shard into `served`, reply row = request row; the caller sends
+// `served` back slot for slot into the prefix of the reply buffer.
+void Sampler::part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes) {
+  GF_REQUIRE(part_.active, "part_serve: no partitioned sample is being built");
+  GF_REQUIRE(layer < fanouts_.size() && snapshot < num_snapshots_, "part_serve: out of range");
+  gf_part_layout lay;
+  part_layout(part_.Rs, layer, part_.world, part_.slack, part_.slot_roots, &lay);
+  GF_REQUIRE(lay.slot_stride, "part_serve: the sample was not begun in the slotted form");
+  GF_REQUIRE(d_ws && ws_bytes >= lay.total, "part_serve: workspace too small");
+  DeviceGuard dg(graph_->device());
+  char* w = static_cast<char*>(d_ws);
+  hipStream_t stream = part_.stream;
+  const uint64_t call = calls_++;
+  const uint32_t F = fanouts_[layer];
+  const uint32_t stride = static_cast<uint32_t>(lay.slot_stride);
+  const uint64_t n = static_cast<uint64_t>(part_.world) * stride;
+  GF_REQUIRE(n * F < 0xFFFFFFFFull, "sampler: more than 2^32-1 slots in one layer");
+  const int width = n > kSmallRoots ? large_group_ : search_group_;
+  const unsigned grid = capped_grid(n, kSearchThreads / width, 256 * 8);
+  ProfileScope ps(kProfSearch, stream);
+  launch_padded(width, grid, stream, graph_->view(),
+                reinterpret_cast<const int64_t*>(w + lay.inbox), n, snapshot, num_snapshots_,
+                window_, F, policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0, prop_time_ ? 1 : 0,
+                seed_, call, reinterpret_cast<int64_t*>(w + lay.served),
+                static_cast<const uint64_t*>(nullptr), static_cast<const uint64_t*>(nullptr),
+                static_cast<uint64_t>(0), static_cast<const uint32_t*>(nullptr),
+                static_cast<uint32_t*>(nullptr), stride, static_cast<uint32_t>(part_.world),
+                part_overflow());
+  GF_HIP(hipGetLastError());
 }
 
 void Sampler::part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes) {
   GF_REQUIRE(part_.active, "part_merge: no partitioned sample is being built");
   GF_REQUIRE(layer < fanouts_.size() && snapshot < num_snapshots_, "part_merge: out of range");
   gf_part_layout lay;
-  part_layout(part_.Rs, layer, part_.world, &lay);
+  part_layout(part_.Rs, layer, part_.world, part_.slack, part_.slot_roots, &lay);
   GF_REQUIRE(d_ws && ws_bytes >= lay.total, "part_merge: workspace too small");
   DeviceGuard dg(graph_->device());
   const size_t L = fanouts_.size(), NS = num_snapshots_;
@@ -1501,7 +1632,13 @@ void Sampler::part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
     // (part_plan_own phase 2), the rows received from other ranks are counted here; the emit
     // derives its own prefix from the counts (no scan launch, no per-workgroup sums)
     (void)base; (void)tile_scratch;
-    if (part_.world > 1) {
+    if (lay.slot_stride) {
+      const uint64_t* d_counts = reinterpret_cast<const uint64_t*>(w + lay.counts);
+      merge_count_slots_kernel<<<dim3(capped_grid(part_.world * lay.slot_stride + Rb, 256, 1024)),
+                                 dim3(256), 0, stream>>>(
+          rep, part_root_of(), pos, d_R, R_host, d_counts, static_cast<uint32_t>(lay.slot_stride),
+          static_cast<uint32_t>(part_.world), static_cast<uint32_t>(part_.rank), F, rec_cnt);
+    } else if (part_.world > 1) {
       uint64_t* d_counts = reinterpret_cast<uint64_t*>(w + lay.counts);
       merge_count_remote_kernel<<<dim3(capped_grid(Rb, 256, 1024)), dim3(256), 0, stream>>>(
           rep, part_root_of(), d_R, R_host, d_counts + part_.rank, F, rec_cnt);
@@ -1515,7 +1652,8 @@ void Sampler::part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
     return;
   }
   merge_count_kernel<<<dim3(static_cast<unsigned>((Rb + 255) / 256)), dim3(256), 0, stream>>>(
-      rep, pos, d_R, R_host, F, rec_cnt);
+      rep, pos, d_R, R_host, F, rec_cnt, static_cast<uint32_t>(lay.slot_stride),
+      static_cast<uint32_t>(part_.world));
   if (Rb <= 65536) {
     sample_scan_kernel<<<dim3(1), dim3(kScanThreads), 0, stream>>>(
         rec_cnt, base, d_R, R_host, F, 0, slot, slot + 1, next_R);
@@ -1554,6 +1692,7 @@ void Sampler::part_commit() {
   pub.h_flag = rec;
   pub.seq = slot->seq;
   pub.num_words = static_cast<uint32_t>(L * NS * 2);
+  pub.d_extra = part_.slack > 0.0 ? part_overflow() : nullptr;
   sample_publish_kernel<<<dim3(1), dim3(64), 0, stream>>>(pub);
   GF_HIP(hipGetLastError());
   GF_HIP(hipEventRecord(slot->done, stream));
@@ -1568,13 +1707,13 @@ void Sampler::sample_partitioned(const int64_t* d_roots, const float* d_ts, size
                                  size_t out_bytes, void* d_ws, size_t ws_bytes,
                                  hipStream_t stream) {
   const size_t L = fanouts_.size(), NS = num_snapshots_;
-  part_begin(d_roots, d_ts, R, d_out, out_bytes, 1, 0, stream);
+  part_begin(d_roots, d_ts, R, d_out, out_bytes, 1, 0, 0.0, 0, stream);
   try {
     char* w = static_cast<char*>(d_ws);
     size_t off = 0;
     for (size_t l = 0; l < L; ++l) {
       gf_part_layout lay;
-      part_layout(part_.Rs, static_cast<uint32_t>(l), 1, &lay);
+      part_layout(part_.Rs, static_cast<uint32_t>(l), 1, 0.0, 0, &lay);
       for (size_t s = 0; s < NS; ++s) {
         GF_REQUIRE(off + lay.total <= ws_bytes, "sample_partitioned: workspace too small");
         part_plan_own(static_cast<uint32_t>(l), static_cast<uint32_t>(s), w + off, lay.total, 3);

@@ -52,9 +52,17 @@ class Sampler {
                     const int64_t* d_replies, const uint32_t* d_pos, void* d_out,
                     size_t out_bytes, gf_block* block, hipStream_t stream);
   // ---- the same, chained on the device (no read-back between layers; sampler.hip) --------
-  void part_layout(size_t R0, uint32_t layer, int world_size, gf_part_layout* out) const;
+  // slack > 0: the slotted form (fixed-capacity slots per peer, equal-split exchange, no count
+  // read-back; partition.hip), capacity = slack x the even share of the layer's worst case
+  // of a sample that starts from `slot_roots` roots — the same number on every rank
+  void part_layout(size_t R0, uint32_t layer, int world_size, double slack, size_t slot_roots,
+                   gf_part_layout* out) const;
   void part_begin(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
-                  size_t out_bytes, int world_size, int rank, hipStream_t stream);
+                  size_t out_bytes, int world_size, int rank, double slack, size_t slot_roots,
+                  hipStream_t stream);
+  void part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes);
+  // slotted form: did a slot overflow anywhere in the sample sample_end() returned last
+  bool last_overflow() const { return last_overflow_; }
   // phases: 1 = bucket the roots, 2 = sample this rank's own share, 3 = both
   void part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes, int phases);
   void part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes);
@@ -108,9 +116,13 @@ class Sampler {
     const float* d_ts = nullptr;
     size_t R = 0, Rs = 1;
     int world = 1, rank = 0;
+    double slack = 0.0;
+    size_t slot_roots = 0;
     hipStream_t stream = nullptr;
   };
   uint64_t* part_counts() const;
+  uint32_t* part_overflow() const;
+  bool last_overflow_ = false;
   uint32_t* part_rec_cnt() const;
   uint32_t* part_root_of() const;
   bool part_own_counts(size_t root_bound) const;

@@ -294,30 +294,77 @@ def _exchange(out: torch.Tensor, send: torch.Tensor, out_splits, in_splits, grou
                                   input_split_sizes=in_splits, group=group, async_op=async_op)
 
 
+class _PartitionedPending:
+    """PendingSample of a slotted partitioned sample: `wait()` also reads the sample's overflow
+    flag and, if a slot overflowed on ANY rank (the flag travels in the slot headers, so every
+    rank reads the same value for the same sample), samples the batch again through the
+    variable-size exchange — on every rank, at the same point of its call sequence."""
+
+    def __init__(self, owner, pending, nodes, ts, stream):
+        self._owner, self._pending = owner, pending
+        self._nodes, self._ts, self._stream = nodes, ts, stream
+        self._result = None
+        self._overflowed = False
+        # samples end in the order they were begun, possibly inside a younger sample's wait():
+        # the flag is read when THIS sample's native sample_end has just returned
+        pending._after_end = self._read_flag
+
+    def _read_flag(self):
+        own = self._owner
+        flag = own._C.c_int(0)
+        own._capi.check(own._lib.gf_sampler_part_overflowed(own._sampler._h, own._C.byref(flag)))
+        self._overflowed = bool(flag.value)
+
+    def wait(self):
+        if self._result is None:
+            own = self._owner
+            mfgs = self._pending.wait()
+            if self._overflowed:
+                own.overflows += 1
+                mfgs = own._sample_variable(self._nodes, self._ts, self._stream).wait()
+            self._result = mfgs
+            self._nodes = self._ts = None
+        return self._result
+
+
 class DevicePartitionedSampler:
     """PartitionedSampler whose per-rank work is native and chained on the device
-    (include/gnnflow_hip.h "Chained form"): per layer `gf_sampler_part_plan_own` buckets the
-    roots — their count is the previous layer's R + S and never leaves HBM — and samples this
-    rank's own share while the request all-to-all-v is in flight, the received requests are
-    served by `gf_sampler_sample_layer_padded`, `gf_sampler_part_merge` builds the block.
+    (include/gnnflow_hip.h "Chained form" / "Slotted form"): per layer `gf_sampler_part_plan_own`
+    buckets the roots — their count is the previous layer's R + S and never leaves HBM — and
+    samples this rank's own share while the request exchange is in flight, the received
+    requests are served from this rank's shard, `gf_sampler_part_merge` builds the block.
     Returns `gnnflow_amd.MFGBlock`s in HBM exactly like `TemporalSampler.sample()` — for
     most-recent sampling bit-identical to one GPU holding the whole graph — so
     `Cache.fetch_feature` takes them unchanged.
 
-    Host synchronisation: with P ranks ONE per layer (the owner counts are the split sizes of
-    the all-to-all-v) plus the final size read-back; with one rank only the read-back — the
-    whole chain is a single native call that `sample_async` can hand to the enqueue thread
-    like the plain sampler's.  A rank whose batch is empty still takes part in every
-    collective (its peers would otherwise block in them).
+    Host synchronisation with P ranks: NONE inside a sample (slotted form, the default): every
+    peer has a slot of fixed capacity `slack` x the even share of the layer's worst-case root
+    count in the request and reply buffers, so both exchanges of a layer are equal-split
+    all-to-alls whose sizes are known in advance; plan -> exchange -> own share + serve ->
+    exchange -> merge is enqueued without reading anything back, and the only wait is the
+    final size read-back in `PendingSample.wait()`.  A slot that would overflow raises a flag
+    that reaches every rank in the same exchange; that sample is then redone through the
+    variable-size exchange (`slack=0` always takes it: all-to-all-v, one host synchronisation
+    per layer for the split sizes).  With one rank the whole chain is a single native call
+    that `sample_async` can hand to the enqueue thread like the plain sampler's.  A rank whose
+    batch is empty still takes part in every collective (its peers would otherwise block).
 
     sampler: a gnnflow_amd.TemporalSampler over THIS rank's shard (edges whose source it
     owns, see PartitionedGraph)."""
 
-    def __init__(self, sampler, group=None, always_exchange=False):
-        """always_exchange: take the multi-rank path — count exchange, request / reply
-        all-to-all-v, served requests, merge — even with one rank (where every message is
-        empty).  For tests: it is the only way to run the RCCL branch on a one-GPU box."""
+    def __init__(self, sampler, group=None, always_exchange=False, slack=None, slot_roots=None):
+        """always_exchange: take the multi-rank path — request / reply exchange, served
+        requests, merge — even with one rank (where every message is empty).  For tests: it
+        is the only way to run the RCCL branch on a one-GPU box.
+        slack: capacity factor of the slotted exchange (default GNNFLOW_PART_SLACK or 2.0);
+        0 = the variable-size exchange.
+        slot_roots: the batch size (roots per sample() call) the slot capacities are derived
+        from — the SAME number on every rank, because the slots of an equal-split exchange
+        must have the same size everywhere.  None: agreed on by an all-reduce (max) of the
+        ranks' first batches — one host synchronisation, once.  Larger batches later are still
+        sampled correctly (they overflow into the variable-size exchange)."""
         import ctypes as C
+        import os
         from . import _capi
         self._always_exchange = bool(always_exchange)
         self._C, self._capi = C, _capi
@@ -329,35 +376,47 @@ class DevicePartitionedSampler:
         self._device = sampler._device
         self._fanouts = list(sampler._fanouts)
         self._L, self._S = sampler._num_layers, sampler._num_snapshots
-        self._layouts = {}     # R0 -> ([layouts per layer], [workspace offsets], total bytes)
+        if slack is None:
+            slack = float(os.environ.get("GNNFLOW_PART_SLACK", "2.0"))
+        self._slack = max(float(slack), 0.0)
+        self._slot_roots = int(slot_roots) if slot_roots else 0
+        self._layouts = {}     # (R0, slack) -> ([layouts per layer], [workspace offsets], total)
         self._ws_ring = [None, None, None, None]   # one workspace per in-flight sample
+        self._ws_views = [None, None, None, None]  # tensor views into it, per (R0, slack)
         self._ws_next = 0
+        self.overflows = 0     # slotted samples that had to be redone
 
     # the plain sampler's attributes the pipeline / cache helpers look at
     @property
     def _inflight(self):
         return self._sampler._inflight
 
-    def _plan(self, R0: int):
-        hit = self._layouts.get(R0)
+    def _plan(self, R0: int, slack: float = 0.0):
+        hit = self._layouts.get((R0, slack))
         if hit is None:
             C = self._C
             lays, offs, total = [], [], 0
             for layer in range(self._L):
                 lay = self._capi.GfPartLayout()
-                self._capi.check(self._lib.gf_sampler_part_layout(
-                    self._sampler._h, R0, layer, self._P, C.byref(lay)))
+                if slack > 0:
+                    self._capi.check(self._lib.gf_sampler_part_layout_slotted(
+                        self._sampler._h, R0, layer, self._P, slack, self._slot_roots,
+                        C.byref(lay)))
+                else:
+                    self._capi.check(self._lib.gf_sampler_part_layout(
+                        self._sampler._h, R0, layer, self._P, C.byref(lay)))
                 lays.append(lay)
                 row = []
                 for _ in range(self._S):
                     row.append(total)
                     total += lay.total
                 offs.append(row)
-            hit = self._layouts[R0] = (lays, offs, total)
+            hit = self._layouts[(R0, slack)] = (lays, offs, total)
         return hit
 
-    def _workspace(self, nbytes: int, stream) -> torch.Tensor:
-        """grow-only scratch, one per sample that can be in flight at a time"""
+    def _workspace(self, nbytes: int, stream):
+        """grow-only scratch, one per sample that can be in flight at a time: (tensor, ring
+        index)"""
         i = self._ws_next
         self._ws_next = (i + 1) % len(self._ws_ring)
         ws = self._ws_ring[i]
@@ -365,54 +424,144 @@ class DevicePartitionedSampler:
             with torch.cuda.stream(stream):
                 ws = self._ws_ring[i] = torch.empty(max(nbytes, 1), dtype=torch.uint8,
                                                     device=self._device)
-        return ws
+            self._ws_views[i] = None
+        return ws, i
+
+    def _slot_views(self, ws, i, R0, lays, offs):
+        """(requests out, inbox, served, replies in) int64 views of every (layer, snapshot) —
+        the four buffers of the two equal-split exchanges — cut once per workspace and R0."""
+        hit = self._ws_views[i]
+        if hit is None or hit[0] != R0:
+            P, views = self._P, {}
+            for layer in range(self._L):
+                lay, F = lays[layer], self._fanouts[layer]
+                n = P * lay.slot_stride
+                for s in range(self._S):
+                    off = offs[layer][s]
+
+                    def cut(at, nbytes):
+                        return ws[off + at: off + at + nbytes].view(torch.int64)
+                    views[(layer, s)] = (cut(lay.requests, 16 * n), cut(lay.inbox, 16 * n),
+                                         cut(lay.served, 24 * F * n), cut(lay.replies, 24 * F * n))
+            hit = self._ws_views[i] = (R0, views)
+        return hit[1]
 
     def sample_async(self, nodes, ts, stream=None, worker_enqueue=False):
-        """TemporalSampler.sample_async for the partitioned graph: returns a PendingSample;
-        `.wait()` gives the MFGs.  With more than one rank the collectives run inside this
-        call (one host synchronisation per layer); the final kernels and the size read-back
-        are asynchronous either way."""
-        from .temporal_sampler import PendingSample
-        C, lib, check = self._C, self._lib, self._capi.check
-        smp, dev, P, me = self._sampler, self._device, self._P, self._rank
+        """TemporalSampler.sample_async for the partitioned graph: returns a pending sample;
+        `.wait()` gives the MFGs.  With more than one rank the launches and the collectives
+        are enqueued by this call without any host synchronisation (slotted form)."""
+        smp, dev = self._sampler, self._device
         if len(smp._inflight) >= smp._max_inflight:
             smp._inflight[0].wait()
         if stream is None:
             stream = torch.cuda.current_stream(dev)
         nodes, ts = smp._to_device(nodes, ts, stream)
-        R = int(nodes.shape[0])
-        lays, offs, ws_bytes = self._plan(max(R, 1))
+        if self._P == 1 and not self._always_exchange:
+            return self._sample_one_rank(nodes, ts, stream, worker_enqueue)
+        if self._slack > 0:
+            return _PartitionedPending(self, self._sample_slotted(nodes, ts, stream), nodes, ts,
+                                       stream)
+        return self._sample_variable(nodes, ts, stream)
+
+    def _output(self, R, stream):
+        C, smp = self._C, self._sampler
         nbytes = smp._bytes_cache.get(max(R, 1))
         if nbytes is None:
             n = C.c_size_t(0)
-            check(lib.gf_sampler_output_bytes(smp._h, max(R, 1), C.byref(n)))
+            self._capi.check(self._lib.gf_sampler_output_bytes(smp._h, max(R, 1), C.byref(n)))
             nbytes = smp._bytes_cache[max(R, 1)] = n.value
         slab, off = smp._output_buffer(nbytes, stream)
-        out_ptr = slab[5] + off
-        ws = self._workspace(ws_bytes, stream)
-        sptr = slab[6]
-        if P == 1 and not self._always_exchange:
-            call = lib.gf_sampler_sample_partitioned_async if worker_enqueue \
-                else lib.gf_sampler_sample_partitioned
-            check(call(smp._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
-                       out_ptr, nbytes, ws.data_ptr(), ws_bytes, sptr))
-        else:
-            with torch.cuda.stream(stream):
-                check(lib.gf_sampler_part_begin(
-                    smp._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
-                    out_ptr, nbytes, P, me, sptr))
-                try:
-                    for layer in range(self._L):
-                        for s in range(self._S):
-                            self._exchange_layer(layer, s, lays[layer], ws, offs[layer][s], sptr)
-                    check(lib.gf_sampler_part_commit(smp._h))
-                except Exception:
-                    lib.gf_sampler_part_abort(smp._h)
-                    raise
+        return slab, slab[5] + off, nbytes
+
+    def _pend(self, slab, keep, R):
+        from .temporal_sampler import PendingSample
         # R = 0 still yields real (empty) blocks whose sizes come from the device
-        pending = PendingSample(smp, slab, (nodes, ts, ws), max(R, 1), None)
-        smp._inflight.append(pending)
+        pending = PendingSample(self._sampler, slab, keep, max(R, 1), None)
+        self._sampler._inflight.append(pending)
         return pending
+
+    def _sample_one_rank(self, nodes, ts, stream, worker_enqueue):
+        lib, smp = self._lib, self._sampler
+        R = int(nodes.shape[0])
+        _, _, ws_bytes = self._plan(max(R, 1))
+        slab, out_ptr, nbytes = self._output(R, stream)
+        ws, _ = self._workspace(ws_bytes, stream)
+        call = lib.gf_sampler_sample_partitioned_async if worker_enqueue \
+            else lib.gf_sampler_sample_partitioned
+        self._capi.check(call(smp._h, nodes.data_ptr() if R else None,
+                              ts.data_ptr() if R else None, R, out_ptr, nbytes, ws.data_ptr(),
+                              ws_bytes, slab[6]))
+        return self._pend(slab, (nodes, ts, ws), R)
+
+    def _sample_slotted(self, nodes, ts, stream):
+        """The whole sample enqueued on `stream` without reading anything back: per layer
+        plan -> equal-split exchange of the request slots (asynchronous, overlapped with the
+        own share) -> serve -> equal-split exchange of the reply slots -> merge."""
+        lib, check, smp = self._lib, self._capi.check, self._sampler
+        P, me, group = self._P, self._rank, self._group
+        R = int(nodes.shape[0])
+        R0 = max(R, 1)
+        if not self._slot_roots:
+            self._slot_roots = self._agree_on_slot_roots(R0)
+        lays, offs, ws_bytes = self._plan(R0, self._slack)
+        slab, out_ptr, nbytes = self._output(R, stream)
+        ws, wi = self._workspace(ws_bytes, stream)
+        views = self._slot_views(ws, wi, R0, lays, offs)
+        base = ws.data_ptr()
+        with torch.cuda.stream(stream):
+            check(lib.gf_sampler_part_begin_slotted(
+                smp._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
+                out_ptr, nbytes, P, me, self._slack, self._slot_roots, slab[6]))
+            try:
+                for layer in range(self._L):
+                    total = lays[layer].total
+                    for s in range(self._S):
+                        req, inbox, served, rep = views[(layer, s)]
+                        at = base + offs[layer][s]
+                        check(lib.gf_sampler_part_plan_own(smp._h, layer, s, at, total, 1))
+                        work = _exchange(inbox, req, None, None, group, async_op=True)
+                        check(lib.gf_sampler_part_plan_own(smp._h, layer, s, at, total, 2))
+                        if work is not None:
+                            work.wait()          # orders the stream, not the host
+                        check(lib.gf_sampler_part_serve(smp._h, layer, s, at, total))
+                        _exchange(rep, served, None, None, group)
+                        check(lib.gf_sampler_part_merge(smp._h, layer, s, at, total))
+                check(lib.gf_sampler_part_commit(smp._h))
+            except Exception:
+                lib.gf_sampler_part_abort(smp._h)
+                raise
+        return self._pend(slab, (nodes, ts, ws), R)
+
+    def _agree_on_slot_roots(self, R0: int) -> int:
+        if self._P == 1:
+            return R0
+        host = _backend_is_host_only(self._group)
+        t = torch.tensor([R0], dtype=torch.int64, device="cpu" if host else self._device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._group)
+        return int(t.item())
+
+    def _sample_variable(self, nodes, ts, stream):
+        """Variable-size exchange: all-to-all-v of exactly the rows there are; the per-owner
+        counts are read back once per layer (they are the split sizes)."""
+        lib, check, smp = self._lib, self._capi.check, self._sampler
+        R = int(nodes.shape[0])
+        lays, offs, ws_bytes = self._plan(max(R, 1))
+        slab, out_ptr, nbytes = self._output(R, stream)
+        ws, _ = self._workspace(ws_bytes, stream)
+        sptr = slab[6]
+        with torch.cuda.stream(stream):
+            check(lib.gf_sampler_part_begin(
+                smp._h, nodes.data_ptr() if R else None, ts.data_ptr() if R else None, R,
+                out_ptr, nbytes, self._P, self._rank, sptr))
+            try:
+                for layer in range(self._L):
+                    for s in range(self._S):
+                        self._exchange_layer(layer, s, lays[layer], ws, offs[layer][s], sptr)
+                check(lib.gf_sampler_part_commit(smp._h))
+            except Exception:
+                lib.gf_sampler_part_abort(smp._h)
+                raise
+        return self._pend(slab, (nodes, ts, ws), R)
 
     def _exchange_layer(self, layer, snapshot, lay, ws, off, sptr):
         """One (layer, snapshot) with P > 1 ranks, on the current stream."""
@@ -452,9 +601,65 @@ class DevicePartitionedSampler:
         return self.sample_async(nodes, ts).wait()
 
     def sample_layer(self, nodes, ts, layer: int, snapshot: int):
-        raise NotImplementedError(
-            "DevicePartitionedSampler samples whole MFGs (sample / sample_async): the layers "
-            "of a partitioned sample are chained on the device")
+        """One (layer, snapshot) over the partitioned graph — the reference's per-layer call
+        (gnnflow/distributed/dist_sampler.py:159-242 `sample_layer_global`: bucket by
+        partition, sample remotely, merge).  A collective: every rank calls it for the same
+        (layer, snapshot), with no roots if it has none.  Returns the block
+        `TemporalSampler.sample_layer` would return on one GPU holding the whole graph (roots
+        in the caller's order).  Synchronous: the per-owner counts and the block sizes are read
+        back, as the reference's RPC round trip is."""
+        C, lib, check = self._C, self._lib, self._capi.check
+        smp, dev, P, me = self._sampler, self._device, self._P, self._rank
+        layer, snapshot = int(layer), int(snapshot)
+        if not 0 <= layer < self._L or not 0 <= snapshot < self._S:
+            raise ValueError("sample_layer: layer / snapshot out of range")
+        F = self._fanouts[layer]
+        nodes, ts = smp._to_device(nodes, ts)
+        R = int(nodes.shape[0])
+        if P == 1 and not self._always_exchange:
+            return smp.sample_layer(nodes, ts, layer, snapshot)
+        with torch.cuda.device(dev):
+            st = smp._stream()
+            n = C.c_size_t(0)
+            check(lib.gf_partition_scratch_bytes(max(R, 1), P, C.byref(n)))
+            scratch = torch.empty(max(n.value, 16), dtype=torch.uint8, device=dev)
+            req = torch.empty((max(R, 1), 2), dtype=torch.int64, device=dev)
+            pos = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
+            counts = torch.zeros(P, dtype=torch.int64, device=dev)
+            if R:
+                check(lib.gf_partition_plan(nodes.data_ptr(), ts.data_ptr(), R, P, me,
+                                            req.data_ptr(), pos.data_ptr(), counts.data_ptr(),
+                                            scratch.data_ptr(), scratch.numel(), dev.index, st))
+            recv_counts = torch.empty_like(counts)
+            _exchange(recv_counts, counts, None, None, self._group)
+            sc, rc = counts.tolist(), recv_counts.tolist()
+            n_net = R - sc[me]
+            sc[me] = rc[me] = 0
+            n_got = sum(rc)
+            got = torch.empty((n_got, 2), dtype=torch.int64, device=dev)
+            work = _exchange(got, req[:n_net], rc, sc, self._group, async_op=True)
+            rep = torch.empty((max(R, 1), F * 3), dtype=torch.int64, device=dev)
+            if R - n_net:       # own share: the suffix of the request rows
+                check(lib.gf_sampler_sample_layer_padded(
+                    smp._h, req[n_net:].data_ptr(), R - n_net, layer, snapshot,
+                    rep[n_net:].data_ptr(), st))
+            if work is not None:
+                work.wait()
+            served = torch.empty((n_got, F * 3), dtype=torch.int64, device=dev)
+            if n_got:
+                check(lib.gf_sampler_sample_layer_padded(smp._h, got.data_ptr(), n_got, layer,
+                                                         snapshot, served.data_ptr(), st))
+            _exchange(rep[:n_net], served, sc, rc, self._group)
+            if R == 0:
+                return smp._empty_block()
+            nb = C.c_size_t(0)
+            check(lib.gf_sampler_layer_output_bytes(smp._h, R, layer, C.byref(nb)))
+            buf = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+            gb = self._capi.GfBlock()
+            check(lib.gf_sampler_merge_padded(smp._h, nodes.data_ptr(), ts.data_ptr(), R, layer,
+                                              rep.data_ptr(), pos.data_ptr(), buf.data_ptr(),
+                                              nb.value, C.byref(gb), st))
+            return smp._block(buf, gb)
 
 
 # ---- feature tables sharded by owner (SURVEY.md 8(e) "Features") --------------------------

@@ -46,6 +46,7 @@ class PendingSample:
         self._marks = marks
         self._result = None
         self._error = None
+        self._after_end = None   # called right after the native sample_end of THIS sample
 
     def wait(self) -> List[List[MFGBlock]]:
         if self._error is not None:
@@ -59,6 +60,8 @@ class PendingSample:
             q.popleft()          # whatever happens, the native side has popped it too
             try:
                 self._result = self._sampler._finish(self._buf, self._R, self._marks)
+                if self._after_end is not None:
+                    self._after_end()
             except Exception as e:   # the failed sample must not wedge the sampler
                 self._error = e
                 raise

@@ -355,6 +355,10 @@ typedef struct gf_part_layout {
   size_t scratch;
   size_t scratch_bytes;
   size_t total;          /* bytes of this workspace */
+  /* slotted form only (0 otherwise): */
+  size_t slot_stride;    /* request / reply rows per peer slot = 1 header row + capacity */
+  size_t inbox;          /* [world_size][slot_stride][2] int64: the requests this rank received */
+  size_t served;         /* [world_size][slot_stride][fanout][3] int64: its replies to them */
 } gf_part_layout;
 GF_API int gf_sampler_part_layout(const gf_sampler* s, size_t num_roots, uint32_t layer,
                                   int world_size, gf_part_layout* out);
@@ -369,6 +373,41 @@ GF_API int gf_sampler_part_merge(gf_sampler* s, uint32_t layer, uint32_t snapsho
                                  size_t ws_bytes);
 GF_API int gf_sampler_part_commit(gf_sampler* s);
 GF_API int gf_sampler_part_abort(gf_sampler* s);
+
+/* Slotted form of the chained exchange: NO host synchronisation inside a sample.  The
+ * variable-size exchange above needs each layer's per-owner counts on the host (they are the
+ * split sizes of the all-to-all-v).  Here every peer has a slot of FIXED capacity — slack x
+ * the even share of the layer's worst-case root count for a batch of `slot_roots` roots, a
+ * number all ranks agree on once (their own batches may be smaller or larger: a larger one
+ * merely overflows sooner) — in the request and reply buffers:
+ *   requests  [world_size slots][slot_stride rows][2] int64, row 0 of a slot = its header
+ *             {rows that follow, bit 0: a slot of the sender overflowed}, then this rank's own
+ *             share from row world_size * slot_stride on; replies: the same rows x fanout x 3
+ * so the exchanges are equal-split all-to-alls whose sizes the host knows in advance:
+ *   gf_sampler_part_begin_slotted
+ *   per (layer, snapshot):
+ *     gf_sampler_part_plan_own(phase 1)   bucket into the slots, write the headers
+ *     — all-to-all, equal split: request rows [0, world_size * slot_stride) -> `inbox` —
+ *     gf_sampler_part_plan_own(phase 2)   own share, overlapping the exchange
+ *     gf_sampler_part_serve               inbox -> `served` (reply row = request row)
+ *     — all-to-all, equal split: `served` -> reply rows [0, world_size * slot_stride) —
+ *     gf_sampler_part_merge
+ *   gf_sampler_part_commit; gf_sampler_sample_end; gf_sampler_part_overflowed
+ * A slot that would overflow drops the excess roots and raises a flag that travels in the
+ * headers, so EVERY rank sees it in the same exchange; gf_sampler_part_overflowed reports it
+ * for the sample gf_sampler_sample_end returned last, and all ranks then sample that batch
+ * again through the variable-size exchange (no reference counterpart: the reference's RPC
+ * futures are variable-size by construction, gnnflow/distributed/dist_sampler.py:188-242). */
+GF_API int gf_sampler_part_layout_slotted(const gf_sampler* s, size_t num_roots, uint32_t layer,
+                                          int world_size, double slack, size_t slot_roots,
+                                          gf_part_layout* out);
+GF_API int gf_sampler_part_begin_slotted(gf_sampler* s, const int64_t* d_roots,
+                                         const float* d_root_ts, size_t num_roots, void* d_out,
+                                         size_t out_bytes, int world_size, int rank, double slack,
+                                         size_t slot_roots, void* stream);
+GF_API int gf_sampler_part_serve(gf_sampler* s, uint32_t layer, uint32_t snapshot, void* d_ws,
+                                 size_t ws_bytes);
+GF_API int gf_sampler_part_overflowed(const gf_sampler* s, int* out);
 GF_API int gf_sampler_sample_partitioned(gf_sampler* s, const int64_t* d_roots,
                                          const float* d_root_ts, size_t num_roots, void* d_out,
                                          size_t out_bytes, void* d_ws, size_t ws_bytes,

@@ -96,8 +96,21 @@ def test_single_rank_chain_equals_plain_sampler(strategy, snapshots, window, pro
                 assert torch.equal(gb.srcdata["ID"], wb.srcdata["ID"])
 
 
-def _worker(rank, world, port, ret):
+def _same(gb, wb):
+    ok = np.array_equal(gb.srcdata["ID"].cpu().numpy(), wb.srcdata["ID"])
+    ok &= np.array_equal(gb.srcdata["ts"].cpu().numpy(), wb.srcdata["ts"])
+    ok &= np.array_equal(gb.edata["ID"].cpu().numpy(), wb.edata["ID"])
+    ok &= np.array_equal(gb.edata["dt"].cpu().numpy().view(np.uint8),
+                         np.asarray(wb.edata["dt"]).view(np.uint8))
+    ok &= np.array_equal(gb.edges()[0].cpu().numpy(), wb.edges()[0])
+    ok &= np.array_equal(gb.edges()[1].cpu().numpy(), wb.edges()[1])
+    return bool(ok)
+
+
+def _worker(rank, world, port, ret, tiled):
     sys.path.insert(0, ROOT)
+    if tiled:   # read once per process: the count / scan / scatter form of the plan for every layer
+        os.environ["GNNFLOW_PARTITION_SMALL_PLAN"] = "0"
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -117,24 +130,53 @@ def _worker(rank, world, port, ret):
             full.add_edges(src[sl], dst[sl], ts[sl], eid[sl], add_reverse=True)
             pg.add_edges(src[sl], dst[sl], ts[sl], eid[sl], add_reverse=True)
         ref = O.OracleSampler(full, [6, 4], "recent")
-        part = DevicePartitionedSampler(TemporalSampler(shard, [6, 4], "recent"))
         ok = True
-        sizes = [0, 1, 97, 600, 2000]
-        for it in range(len(sizes)):
-            # rotated per rank: in every round a different rank has an EMPTY batch and must
-            # still take part in the layer's collectives (its peers would block otherwise)
-            R = sizes[(it + rank) % len(sizes)]
-            nodes, t = synth.random_roots(400, R, 1000.0, seed=1000 * rank + it, extra_ids=[403])
-            got, want = part.sample(nodes, t), ref.sample(nodes, t)
-            for gl, wl in zip(got, want):
-                for gb, wb in zip(gl, wl):
-                    ok &= np.array_equal(gb.srcdata["ID"].cpu().numpy(), wb.srcdata["ID"])
-                    ok &= np.array_equal(gb.srcdata["ts"].cpu().numpy(), wb.srcdata["ts"])
-                    ok &= np.array_equal(gb.edata["ID"].cpu().numpy(), wb.edata["ID"])
-                    ok &= np.array_equal(gb.edata["dt"].cpu().numpy().view(np.uint8),
-                                         np.asarray(wb.edata["dt"]).view(np.uint8))
-                    ok &= np.array_equal(gb.edges()[0].cpu().numpy(), wb.edges()[0])
-                    ok &= np.array_equal(gb.edges()[1].cpu().numpy(), wb.edges()[1])
+        # slack 2: the slotted exchange (no host synchronisation inside a sample); 0.02: slots so
+        # small that they overflow -> the flag reaches every rank and the sample is redone through
+        # the variable-size exchange; 0: the variable-size exchange itself
+        for slack in (2.0, 0.02, 0.0):
+            # 6000 roots: layer 1 is bounded by 42 000 > 32 768 roots -> the tiled plan and the
+            # count / scan / emit merge
+            sizes = [0, 1, 97, 600, 2000] + ([6000] if slack == 2.0 else [])
+            # slot_roots: the ranks' batches differ in size, the slots must not.  With slack 0.02
+            # it is left to the first sample's all-reduce (max of 0 and 1 roots): tiny slots
+            part = DevicePartitionedSampler(TemporalSampler(shard, [6, 4], "recent"), slack=slack,
+                                            slot_roots=max(sizes) if slack == 2.0 else None)
+            for it in range(len(sizes)):
+                # rotated per rank: in every round a different rank has an EMPTY batch and must
+                # still take part in the layer's collectives (its peers would block otherwise)
+                R = sizes[(it + rank) % len(sizes)]
+                nodes, t = synth.random_roots(400, R, 1000.0, seed=1000 * rank + it, extra_ids=[403])
+                got, want = part.sample(nodes, t), ref.sample(nodes, t)
+                for gl, wl in zip(got, want):
+                    for gb, wb in zip(gl, wl):
+                        ok &= _same(gb, wb)
+            if slack == 2.0:
+                ok &= part.overflows == 0
+            if slack == 0.02:
+                # every rank counts the same overflowed samples (a flag raised on one rank is
+                # seen by all of them)
+                n_over = torch.tensor([part.overflows])
+                both = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+                dist.all_gather(both, n_over)
+                ok &= part.overflows > 0 and all(int(x) == part.overflows for x in both)
+                # three samples in flight on a side stream, overflowing ones among them: the
+                # redo happens inside wait(), in the same order on every rank
+                side = torch.cuda.Stream()
+                reqs = [synth.random_roots(400, R, 1000.0, seed=77 * rank + R)
+                        for R in (300, 3 + rank, 1500)]
+                pend = [part.sample_async(torch.from_numpy(n).cuda(), torch.from_numpy(t).cuda(),
+                                          stream=side) for n, t in reqs]
+                for (n, t), p in zip(reqs, pend):
+                    for gl, wl in zip(p.wait(), ref.sample(n, t)):
+                        for gb, wb in zip(gl, wl):
+                            ok &= _same(gb, wb)
+            # the per-layer call (reference: sample_layer_global), roots in the caller's order
+            nodes, t = synth.random_roots(400, 50 * rank, 1000.0, seed=9 + rank)
+            for layer, snap in ((0, 0), (1, 0)):
+                gb = part.sample_layer(nodes, t, layer, snap)
+                wb = ref.sample_layer(nodes, t, layer, snap)
+                ok &= gb.num_dst_nodes() == wb.num_dst_nodes() and _same(gb, wb)
         torch.cuda.synchronize()
         ret[rank] = bool(ok)
     finally:
@@ -143,15 +185,15 @@ def _worker(rank, world, port, ret):
 
 # At most 4 ranks: the GPU box allows 6 processes on the card, and the pytest parent holds it
 # too (world 8 lives on the CPU: tests/test_dist_gloo.py).
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_ranks_sharing_one_gpu_match_the_oracle(world):
+@pytest.mark.parametrize("world,tiled", [(2, False), (2, True), (3, False), (4, False)])
+def test_ranks_sharing_one_gpu_match_the_oracle(world, tiled):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, tiled), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
 
 
@@ -185,23 +227,31 @@ def _rccl_worker(rank, world, port, ret):
         g.add_edges(src, dst, ts, eid, add_reverse=True)
         kw = dict(fanouts=[7, 5], sample_strategy="recent")
         plain = TemporalSampler(g, **kw)
-        part = DevicePartitionedSampler(TemporalSampler(g, **kw), always_exchange=True)
         side = torch.cuda.Stream()
-        for it, R in enumerate([0, 1, 97, 600, 3000]):
-            nodes, t = synth.random_roots(400, R, 1000.0, seed=it, extra_ids=[403])
-            if it % 2:
-                got = part.sample_async(torch.from_numpy(nodes).to(dev), torch.from_numpy(t).to(dev),
-                                        stream=side).wait()
-            else:
-                got = part.sample(nodes, t)
-            want = plain.sample(nodes, t)
-            for gl, wl in zip(got, want):
-                for gb, wb in zip(gl, wl):
-                    ok &= gb.num_dst_nodes() == wb.num_dst_nodes()
-                    for x, y in ((gb.srcdata["ID"], wb.srcdata["ID"]), (gb.srcdata["ts"], wb.srcdata["ts"]),
-                                 (gb.edata["ID"], wb.edata["ID"]), (gb.edata["dt"], wb.edata["dt"]),
-                                 (gb.edges()[0], wb.edges()[0]), (gb.edges()[1], wb.edges()[1])):
-                        ok &= bool(torch.equal(x, y))
+        # the slotted exchange (equal-split all_to_all_single, nothing read back) and the
+        # variable-size one (all-to-all-v), both with every message empty
+        for slack in (2.0, 0.0):
+            part = DevicePartitionedSampler(TemporalSampler(g, **kw), always_exchange=True,
+                                            slack=slack)
+            for it, R in enumerate([0, 1, 97, 600, 3000]):
+                nodes, t = synth.random_roots(400, R, 1000.0, seed=it, extra_ids=[403])
+                if it % 2:
+                    got = part.sample_async(torch.from_numpy(nodes).to(dev),
+                                            torch.from_numpy(t).to(dev), stream=side).wait()
+                else:
+                    got = part.sample(nodes, t)
+                want = plain.sample(nodes, t)
+                for gl, wl in zip(got, want):
+                    for gb, wb in zip(gl, wl):
+                        ok &= gb.num_dst_nodes() == wb.num_dst_nodes()
+                        for x, y in ((gb.srcdata["ID"], wb.srcdata["ID"]), (gb.srcdata["ts"], wb.srcdata["ts"]),
+                                     (gb.edata["ID"], wb.edata["ID"]), (gb.edata["dt"], wb.edata["dt"]),
+                                     (gb.edges()[0], wb.edges()[0]), (gb.edges()[1], wb.edges()[1])):
+                            ok &= bool(torch.equal(x, y))
+            ok &= part.overflows == 0
+            gb, wb = part.sample_layer(nodes, t, 1, 0), plain.sample_layer(nodes, t, 1, 0)
+            ok &= bool(torch.equal(gb.edata["ID"], wb.edata["ID"]) and
+                       torch.equal(gb.srcdata["ID"], wb.srcdata["ID"]))
         # owner-sharded feature rows: ids out and rows back through RCCL (to this rank itself)
         from gnnflow_amd.dist import FeatureShards
         rng = np.random.RandomState(3)
