@@ -26,10 +26,16 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline":     feature-gather kernel, algorithmic bytes / HIP-event time vs 8 TB/s
   "cpu_baseline": the CPU oracle (C port of the reference algorithm) timed on this
                   host on a bounded sample of the same batches (rank 0, N=1 only).
-Multi-GPU: every rank holds a replica of the (13 MB) graph and feature tables and
-replays its own interleaved share of the batches — data parallel, no data-path
-collective, "scaling": "weak" (DESIGN.md "Multi-GPU"; the hash-partitioned
-all-to-all path for graphs that do not fit one GPU is gnnflow_amd.dist).
+Multi-GPU (N > 1): north_star's split is the headline — the graph is HASH-PARTITIONED by
+source vertex over the N ranks (owner(v) = splitmix64(v) mod N), every rank replays its own
+interleaved share of the batches (fixed work per GPU: "scaling": "weak"), and per layer
+the roots travel to their owners and the sampled neighbours back as RCCL all-to-alls
+(gnnflow_amd.dist.DevicePartitionedSampler, slotted exchange: no host synchronisation
+inside a sample).  Feature tables (REDDIT-shaped: 463 MB) are replicated, the LRU cache is
+per GPU.  The per-GPU-replica figure (no data-path collective; what the reference does
+inside one machine) rides along as the extra key "replica"; `--partition replica` makes
+it the main loop.  At N = 1 the main loop is the plain single-GPU path and the hash path
+(every root is the rank's own) is the extra key "hash_partition".
 """
 import argparse
 import json
@@ -75,12 +81,19 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--sample-only", action="store_true",
                     help="time sample() alone (no feature gather)")
-    ap.add_argument("--partition", default="replica", choices=["replica", "hash"],
-                    help="multi-GPU mode: per-GPU replicas of the graph (default; what the "
-                         "reference does inside one machine) or hash-partitioned shards with "
-                         "an all-to-all exchange per layer (gnnflow_amd/dist.py)")
-    ap.add_argument("--no-hash-leg", action="store_true",
-                    help="skip the second timed run over the hash-partitioned graph")
+    ap.add_argument("--partition", default=None, choices=["replica", "hash"],
+                    help="the main loop's graph: hash-partitioned shards with an all-to-all "
+                         "exchange per layer (gnnflow_amd/dist.py; the default with --gpus > 1) "
+                         "or a full replica per GPU (the default with one GPU; what the "
+                         "reference does inside one machine)")
+    ap.add_argument("--no-hash-leg", "--no-second-leg", dest="no_second_leg", action="store_true",
+                    help="skip the second timed run over the other kind of graph")
+    ap.add_argument("--part-slack", type=float, default=None,
+                    help="slot capacity factor of the partitioned exchange (0 = variable-size "
+                         "all-to-all-v with one host sync per layer; default 2.0)")
+    ap.add_argument("--always-exchange", action="store_true",
+                    help="with one rank: still run the exchange (every message empty) — "
+                         "prices the RCCL calls on a one-GPU box")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap batch i+1's sample() with batch i's fetch_feature()")
     ap.add_argument("--pipeline-depth", type=int, default=2,
@@ -107,7 +120,7 @@ def main():
     backend = os.environ.get("GNNFLOW_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.partition == "hash":
+    if world > 1 or args.partition == "hash" or args.always_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
@@ -115,6 +128,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "--gpus must match the launched world size"
+    if args.partition is None:
+        args.partition = "hash" if world > 1 else "replica"
 
     # Host threads per rank in the pipelined loop: Python + two polling enqueue lanes.  When the
     # ranks of this node have fewer than 4 usable cores each (a CPU-quota'd container), fall
@@ -152,8 +167,10 @@ def main():
     sampler = gnnflow_amd.TemporalSampler(graph, fanouts, args.strategy, seed=1234)
     if args.partition == "hash":
         # every rank owns a shard; per layer the roots are bucketed by owner, requests and
-        # replies travel as all-to-all-v, and the rank's own share is sampled meanwhile
-        sampler = DevicePartitionedSampler(sampler)
+        # replies travel as equal-split all-to-alls, and the rank's own share is sampled meanwhile
+        sampler = DevicePartitionedSampler(sampler, slack=args.part_slack,
+                                           slot_roots=3 * args.batch_size,
+                                           always_exchange=args.always_exchange)
 
     gen = torch.Generator(device=dev).manual_seed(42)
     edge_feats = torch.rand((g["num_edges"], d_e), generator=gen, device=dev)
@@ -314,15 +331,19 @@ def main():
         out["cache_edge_ratio"] = float(cache.cache_edge_ratio)
         out["cache_node_ratio"] = float(cache.cache_node_ratio)
 
-    if cache is not None and args.partition == "replica" and not args.no_hash_leg:
-        # north_star's split, in the same line: the graph hash-partitioned over the ranks
-        # (owner(v) = splitmix64(v) mod P, gnnflow_amd/dist.py), remote neighbours pulled by
-        # all-to-all-v per layer, the same batches, cache and pipeline.  One chronological
-        # replay.  (At P = 1 every root is the rank's own: the figure then prices the
-        # bucketing / fixed-slot / merge kernels against the plain sampler above.)
-        hash_leg.pending_line = out
-        out["hash_partition"] = hash_leg(args, rank, world, local_rank, backend, g, fanouts, cache,
-                                         dev_batches, dev, nb, barrier)
+    if args.partition == "hash":
+        out["config"]["exchange"] = exchange_note(sampler, world, backend)
+    if cache is not None and not args.no_second_leg:
+        # The other kind of graph in the same line, over the same batches, cache and pipeline,
+        # one chronological replay: the hash-partitioned one when the main loop ran on replicas
+        # (at P = 1 every root is the rank's own: the figure then prices the bucketing /
+        # fixed-slot / merge kernels against the plain sampler above), the replicas when the
+        # main loop ran on the partitioned graph (N > 1).
+        other = "hash" if args.partition == "replica" else "replica"
+        second_leg.pending_line = out
+        out["hash_partition" if other == "hash" else "replica"] = second_leg(
+            other, args, rank, world, local_rank, backend, g, fanouts, cache, dev_batches, dev,
+            nb, barrier)
 
     if args.breakdown and rank == 0:
         lib.gf_profile_reset()
@@ -347,8 +368,27 @@ def main():
         dist.destroy_process_group()
 
 
-def hash_leg(args, rank, world, local_rank, backend, g, fanouts, cache, dev_batches, dev, nb,
-             barrier):
+def exchange_note(sampler, world, backend):
+    if world == 1 and not getattr(sampler, "_always_exchange", False):
+        return "none (one rank: every root is its own)"
+    via = "RCCL" if backend == "nccl" else backend
+    if getattr(sampler, "_slack", 0) > 0 and getattr(sampler, "_comm", None) is not None:
+        return ("2 equal-split all-to-alls per layer over the library's own RCCL communicator "
+                "(one native call per sample, issued by the enqueue thread; slot capacity {} x "
+                "the even share; exchanges {}; no host sync inside a sample; {} overflowed "
+                "samples redone)".format(
+                    sampler._slack, "on the communicator's stream, requests overlapped with "
+                    "the own share" if sampler._overlap else "in the sampling stream",
+                    sampler.overflows))
+    if getattr(sampler, "_slack", 0) > 0:
+        return ("2 equal-split all-to-alls per layer over {} (slot capacity {} x the even share, "
+                "no host sync inside a sample; {} overflowed samples redone)".format(
+                    via, sampler._slack, sampler.overflows))
+    return "2 all-to-all-v per layer over {} (one host sync per layer)".format(via)
+
+
+def second_leg(kind, args, rank, world, local_rank, backend, g, fanouts, cache, dev_batches, dev,
+               nb, barrier):
     import threading
     import torch
     import torch.distributed as dist
@@ -356,30 +396,33 @@ def hash_leg(args, rank, world, local_rank, backend, g, fanouts, cache, dev_batc
     from gnnflow_amd.dist import DevicePartitionedSampler, PartitionedGraph
     from gnnflow_amd.pipeline import ReplayPipeline
     # RCCL with more than one rank has never run on this code path before the first scaling
-    # run: a watchdog ends every rank cleanly if a collective hangs, and rank 0 still prints
-    # the line it has (the caller prints `pending_line` with an error note).
+    # run: a watchdog ends every rank if a collective hangs — rank 0 first prints the line it
+    # has, with an error note, then every rank exits NON-ZERO.
     limit = float(os.environ.get("GNNFLOW_HASH_LEG_TIMEOUT", "180"))
     done = threading.Event()
 
     def watchdog():
         if not done.wait(limit):
-            if rank == 0 and hash_leg.pending_line is not None:
-                hash_leg.pending_line["hash_partition"] = {
+            if rank == 0 and second_leg.pending_line is not None:
+                second_leg.pending_line["hash_partition" if kind == "hash" else "replica"] = {
                     "error": "timed out after {} s".format(limit)}
-                print(json.dumps(hash_leg.pending_line), flush=True)
-            os._exit(0)
+                print(json.dumps(second_leg.pending_line), flush=True)
+            os._exit(3)
     threading.Thread(target=watchdog, daemon=True).start()
     try:
         MiB = 1 << 20
-        shard = gnnflow_amd.DynamicGraph(20 * MiB, 1000 * MiB, "cuda", 62, 1024, "insert",
+        graph = gnnflow_amd.DynamicGraph(20 * MiB, 1000 * MiB, "cuda", 62, 1024, "insert",
                                          device=local_rank)
-        pg = PartitionedGraph(shard, rank, world)
+        ingest = PartitionedGraph(graph, rank, world) if kind == "hash" else graph
         for lo in range(0, g["num_edges"], 100000):
             hi = lo + 100000
-            pg.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
-                         add_reverse=args.undirected)
-        sampler = DevicePartitionedSampler(
-            gnnflow_amd.TemporalSampler(shard, fanouts, args.strategy, seed=1234))
+            ingest.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
+                             add_reverse=args.undirected)
+        sampler = gnnflow_amd.TemporalSampler(graph, fanouts, args.strategy, seed=1234)
+        if kind == "hash":
+            sampler = DevicePartitionedSampler(sampler, slack=args.part_slack,
+                                               slot_roots=3 * args.batch_size,
+                                               always_exchange=args.always_exchange)
         pipe = ReplayPipeline(sampler, cache, dev_batches, dev,
                               pipelined=not args.no_pipeline, depth=args.pipeline_depth)
         steps = nb
@@ -409,15 +452,15 @@ def hash_leg(args, rank, world, local_rank, backend, g, fanouts, cache, dev_batc
             edges_all = float(acc["edges"])
         return {"value": edges_all / elapsed, "unit": "edges/s", "ms_per_step": 1e3 * elapsed / steps,
                 "steps": steps, "world_size": world, "pipelined": bool(pipe.pipelined),
-                "exchange": "none (one rank: every root is its own)" if world == 1 else
-                "2 all-to-all-v per layer over {}".format("RCCL" if backend == "nccl" else backend)}
-    except Exception as e:   # the replica figure above must survive a failing exchange
+                "exchange": exchange_note(sampler, world, backend) if kind == "hash" else
+                "none (a full replica of the graph per GPU, no data-path collective)"}
+    except Exception as e:   # the main figure above must survive a failing second leg
         return {"error": "{}: {}".format(type(e).__name__, e)}
     finally:
         done.set()
 
 
-hash_leg.pending_line = None
+second_leg.pending_line = None
 
 
 def usable_cores(cap=32):

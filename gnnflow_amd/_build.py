@@ -11,8 +11,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libgnnflow_hip.so")
-SOURCES = ["capi.hip", "edge_store.hip", "sampler.hip", "feature_cache.hip", "memory_ops.hip", "block_ops.hip", "partition.hip", "ingest_sort.hip"]
+SOURCES = ["capi.hip", "edge_store.hip", "sampler.hip", "feature_cache.hip", "memory_ops.hip", "block_ops.hip", "partition.hip", "ingest_sort.hip", "comm.hip"]
 HEADERS = ["common.hpp", "edge_store.hpp", "sampler.hpp", "feature_cache.hpp", "ingest_sort.hpp",
+           "comm.hpp",
            os.path.join("..", "..", "include", "gnnflow_hip.h"),
            os.path.join("..", "..", "include", "gnnflow_rng.h")]
 ARCH = "gfx950"

@@ -145,6 +145,15 @@ PROTOTYPES = {
     "gf_sampler_part_abort": (C.c_int, [_p]),
     "gf_sampler_sample_partitioned": (C.c_int, [_p, _p, _p, _sz, _p, _sz, _p, _sz, _p]),
     "gf_sampler_sample_partitioned_async": (C.c_int, [_p, _p, _p, _sz, _p, _sz, _p, _sz, _p]),
+    "gf_comm_unique_id": (C.c_int, [_p]),
+    "gf_comm_create": (C.c_int, [C.POINTER(_p), _p, C.c_int, C.c_int, C.c_int]),
+    "gf_comm_destroy": (C.c_int, [_p]),
+    "gf_comm_all_to_all": (C.c_int, [_p, _p, _p, _sz, _p]),
+    "gf_comm_all_to_all_v": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p]),
+    "gf_sampler_sample_partitioned_comm": (C.c_int, [_p, _p, _p, _p, _sz, _p, _sz, _p, _sz,
+                                                     C.c_double, _sz, C.c_int, _p]),
+    "gf_sampler_sample_partitioned_comm_async": (C.c_int, [_p, _p, _p, _p, _sz, _p, _sz, _p, _sz,
+                                                           C.c_double, _sz, C.c_int, _p]),
     "gf_block_segment_offsets": (C.c_int, [_p, _sz, _sz, _p, C.c_int, _p]),
     "gf_block_edge_softmax": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, C.c_int, _p]),
     "gf_block_edge_softmax_backward": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, _p, C.c_int, _p]),

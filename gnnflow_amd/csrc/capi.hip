@@ -742,6 +742,77 @@ int gf_sampler_sample_partitioned_async(gf_sampler* s, const int64_t* d_roots,
         }));
   });
 }
+// ---- RCCL communicator (comm.hip) --------------------------------------------------------
+struct gf_comm {
+  gf::RcclComm impl;
+  gf_comm(const uint8_t* id, int world, int rank, int device) : impl(id, world, rank, device) {}
+};
+int gf_comm_unique_id(uint8_t* out) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_comm_unique_id: null output");
+    gf::RcclComm::unique_id(out);
+  });
+}
+int gf_comm_create(gf_comm** out, const uint8_t* id, int world_size, int rank, int device) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr && id != nullptr, "gf_comm_create: null argument");
+    *out = new gf_comm(id, world_size, rank, device);
+  });
+}
+int gf_comm_destroy(gf_comm* c) {
+  return guarded([&] { delete c; });
+}
+int gf_comm_all_to_all(gf_comm* c, const void* d_send, void* d_recv, size_t bytes_per_peer,
+                       void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(c != nullptr, "null communicator");
+    c->impl.all_to_all(d_send, d_recv, bytes_per_peer, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_comm_all_to_all_v(gf_comm* c, const void* d_send, const size_t* send_bytes,
+                         const size_t* send_offsets, void* d_recv, const size_t* recv_bytes,
+                         const size_t* recv_offsets, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(c != nullptr, "null communicator");
+    c->impl.all_to_all_v(d_send, send_bytes, send_offsets, d_recv, recv_bytes, recv_offsets,
+                         static_cast<hipStream_t>(stream));
+  });
+}
+int gf_sampler_sample_partitioned_comm(gf_sampler* s, gf_comm* c, const int64_t* d_roots,
+                                       const float* d_root_ts, size_t num_roots, void* d_out,
+                                       size_t out_bytes, void* d_ws, size_t ws_bytes, double slack,
+                                       size_t slot_roots, int overlap, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr && c != nullptr, "null sampler / communicator handle");
+    GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
+               "sample_partitioned_comm: earlier samples were begun through the enqueue thread");
+    s->impl.sample_partitioned_slotted(d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws,
+                                       ws_bytes, slack, slot_roots, c->impl, overlap != 0,
+                                       static_cast<hipStream_t>(stream));
+    s->begin_tickets.push_back(0);
+  });
+}
+int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c, const int64_t* d_roots,
+                                             const float* d_root_ts, size_t num_roots, void* d_out,
+                                             size_t out_bytes, void* d_ws, size_t ws_bytes,
+                                             double slack, size_t slot_roots, int overlap,
+                                             void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr && c != nullptr, "null sampler / communicator handle");
+    GF_REQUIRE(s->begin_tickets.size() < gf::Sampler::kMaxInFlight,
+               "sample_partitioned_comm_async: too many samples in flight on this sampler");
+    gf::Sampler* impl = &s->impl;
+    gf::RcclComm* comm = &c->impl;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool ov = overlap != 0;
+    s->begin_tickets.push_back(gf::EnqueueWorker::get(1).submit(
+        [impl, comm, d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws, ws_bytes, slack,
+         slot_roots, ov, st]() {
+          impl->sample_partitioned_slotted(d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws,
+                                           ws_bytes, slack, slot_roots, *comm, ov, st);
+        }));
+  });
+}
 int gf_block_segment_offsets(const int64_t* d_row, size_t num_edges, size_t num_dst,
                              int64_t* d_offsets, int device, void* stream) {
   return guarded([&] {

@@ -1728,6 +1728,55 @@ void Sampler::sample_partitioned(const int64_t* d_roots, const float* d_ts, size
   }
 }
 
+// several ranks: plan -> request slots out (equal split) -> own share + serve -> reply slots back
+// -> merge, per (layer, snapshot), all enqueued by this one call (dist.py issues the same chain
+// step by step when the exchange has to go through torch.distributed)
+void Sampler::sample_partitioned_slotted(const int64_t* d_roots, const float* d_ts, size_t R,
+                                         void* d_out, size_t out_bytes, void* d_ws,
+                                         size_t ws_bytes, double slack, size_t slot_roots,
+                                         Exchange& ex, bool overlap, hipStream_t stream) {
+  const size_t L = fanouts_.size(), NS = num_snapshots_;
+  GF_REQUIRE(slack > 0.0, "sample_partitioned_slotted: slack must be positive");
+  part_begin(d_roots, d_ts, R, d_out, out_bytes, ex.world(), ex.rank(), slack, slot_roots, stream);
+  try {
+    char* w = static_cast<char*>(d_ws);
+    size_t off = 0;
+    for (size_t l = 0; l < L; ++l) {
+      gf_part_layout lay;
+      part_layout(part_.Rs, static_cast<uint32_t>(l), part_.world, slack, slot_roots, &lay);
+      const size_t slot_rows = lay.slot_stride;
+      const size_t F = fanouts_[l];
+      for (size_t s = 0; s < NS; ++s) {
+        GF_REQUIRE(off + lay.total <= ws_bytes, "sample_partitioned_slotted: workspace too small");
+        char* b = w + off;
+        const uint32_t li = static_cast<uint32_t>(l), si = static_cast<uint32_t>(s);
+        part_plan_own(li, si, b, lay.total, 1);
+        if (overlap) {
+          ex.all_to_all_forked(b + lay.requests, b + lay.inbox, slot_rows * 16, stream);
+          part_plan_own(li, si, b, lay.total, 2);
+          ex.join(stream);
+        } else {
+          ex.all_to_all(b + lay.requests, b + lay.inbox, slot_rows * 16, stream);
+          part_plan_own(li, si, b, lay.total, 2);
+        }
+        part_serve(li, si, b, lay.total);
+        if (overlap) {   // one communicator, one stream: the reply exchange goes there too
+          ex.all_to_all_forked(b + lay.served, b + lay.replies, slot_rows * F * 24, stream);
+          ex.join(stream);
+        } else {
+          ex.all_to_all(b + lay.served, b + lay.replies, slot_rows * F * 24, stream);
+        }
+        part_merge(li, si, b, lay.total);
+        off += lay.total;
+      }
+    }
+    part_commit();
+  } catch (...) {
+    part_abort();
+    throw;
+  }
+}
+
 // Copies device-resident blocks into freshly malloc'ed host arrays
 // (api.cc:17-24 vec2npy copies likewise).
 void Sampler::to_host_blocks(const gf_block* dev, gf_block* host, size_t n, hipStream_t stream) {

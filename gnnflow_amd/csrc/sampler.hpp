@@ -6,6 +6,7 @@
 #include <mutex>
 #include <vector>
 
+#include "comm.hpp"
 #include "common.hpp"
 #include "edge_store.hpp"
 
@@ -70,6 +71,13 @@ class Sampler {
   void part_abort();
   void sample_partitioned(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                           size_t out_bytes, void* d_ws, size_t ws_bytes, hipStream_t stream);
+  // several ranks, slotted form, the exchanges issued through `ex` (RCCL): the whole chain in
+  // one call, nothing read back.  overlap: the request exchange runs on the communicator's
+  // stream while this rank's own share is sampled on `stream`.
+  void sample_partitioned_slotted(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
+                                  size_t out_bytes, void* d_ws, size_t ws_bytes, double slack,
+                                  size_t slot_roots, Exchange& ex, bool overlap,
+                                  hipStream_t stream);
   // host-vector forms (reference calling convention)
   void sample_host(const int64_t* nodes, const float* ts, size_t R, gf_block* blocks);
   void sample_layer_host(const int64_t* nodes, const float* ts, size_t R, uint32_t layer,

@@ -294,6 +294,55 @@ def _exchange(out: torch.Tensor, send: torch.Tensor, out_splits, in_splits, grou
                                   input_split_sizes=in_splits, group=group, async_op=async_op)
 
 
+class NativeComm:
+    """The library's own RCCL communicator over the ranks of a torch process group
+    (include/gnnflow_hip.h gf_comm_*): rank 0 draws the unique id, torch.distributed carries
+    its 128 bytes to the other ranks — control plane only — and every rank joins.  The data
+    path then never goes through torch.distributed: an all-to-all costs a native call."""
+
+    def __init__(self, device, group=None):
+        import ctypes as C
+        from . import _capi
+        self._lib = _capi.load()
+        self.P = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        device = torch.device(device)
+        idb = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            _capi.check(self._lib.gf_comm_unique_id(idb))
+        if self.P > 1:
+            t = torch.tensor(list(idb), dtype=torch.uint8)
+            on_device = not _backend_is_host_only(group)
+            if on_device:
+                t = t.to(device)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast(t, src=src, group=group)
+            idb = (C.c_uint8 * 128)(*t.cpu().tolist())
+        self.h = C.c_void_p()
+        _capi.check(self._lib.gf_comm_create(C.byref(self.h), idb, self.P, self.rank,
+                                             device.index or 0))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self._lib.gf_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    @staticmethod
+    def usable(group=None) -> bool:
+        """RCCL needs one GPU per rank: over a host-only backend (gloo: CPU tests, several
+        ranks sharing one card) the exchange is staged through torch.distributed instead."""
+        import os
+        mode = os.environ.get("GNNFLOW_PART_TRANSPORT", "auto").lower()
+        if mode == "torch":
+            return False
+        if mode == "native":
+            return True
+        return not dist.is_initialized() or not _backend_is_host_only(group)
+
+
 class _PartitionedPending:
     """PendingSample of a slotted partitioned sample: `wait()` also reads the sample's overflow
     flag and, if a slot overflowed on ANY rank (the flag travels in the slot headers, so every
@@ -321,6 +370,11 @@ class _PartitionedPending:
             mfgs = self._pending.wait()
             if self._overflowed:
                 own.overflows += 1
+                # the samples begun after this one end first (their launches may still be with
+                # the enqueue thread; their results are kept), then the batch is sampled again
+                q = own._sampler._inflight
+                while q:
+                    q[0].wait()
                 mfgs = own._sample_variable(self._nodes, self._ts, self._stream).wait()
             self._result = mfgs
             self._nodes = self._ts = None
@@ -352,7 +406,8 @@ class DevicePartitionedSampler:
     sampler: a gnnflow_amd.TemporalSampler over THIS rank's shard (edges whose source it
     owns, see PartitionedGraph)."""
 
-    def __init__(self, sampler, group=None, always_exchange=False, slack=None, slot_roots=None):
+    def __init__(self, sampler, group=None, always_exchange=False, slack=None, slot_roots=None,
+                 comm=None, overlap=None):
         """always_exchange: take the multi-rank path — request / reply exchange, served
         requests, merge — even with one rank (where every message is empty).  For tests: it
         is the only way to run the RCCL branch on a one-GPU box.
@@ -362,7 +417,17 @@ class DevicePartitionedSampler:
         from — the SAME number on every rank, because the slots of an equal-split exchange
         must have the same size everywhere.  None: agreed on by an all-reduce (max) of the
         ranks' first batches — one host synchronisation, once.  Larger batches later are still
-        sampled correctly (they overflow into the variable-size exchange)."""
+        sampled correctly (they overflow into the variable-size exchange).
+        comm: a NativeComm (the library's RCCL communicator) — the slotted chain is then ONE
+        native call that the enqueue thread can issue (`worker_enqueue=True`).  None: created
+        on first use when the process group runs over RCCL; the exchange goes through
+        torch.distributed (staged through host memory over gloo) otherwise.
+        overlap: run the exchanges on the communicator's own stream, the request exchange while
+        the rank's own share is sampled (north_star's side-stream overlap).  Default
+        GNNFLOW_PART_OVERLAP or OFF: on this runtime the two event hand-overs per exchange
+        cost far more than the ~6 us own-share kernel they hide (one rank over RCCL, every
+        message empty: 268 us per step with them, 116 us with everything in the sampling
+        stream; profiles/r03_part_bench_one_gpu.jsonl)."""
         import ctypes as C
         import os
         from . import _capi
@@ -380,6 +445,11 @@ class DevicePartitionedSampler:
             slack = float(os.environ.get("GNNFLOW_PART_SLACK", "2.0"))
         self._slack = max(float(slack), 0.0)
         self._slot_roots = int(slot_roots) if slot_roots else 0
+        self._comm = comm
+        self._comm_tried = comm is not None
+        if overlap is None:
+            overlap = os.environ.get("GNNFLOW_PART_OVERLAP", "0") != "0"
+        self._overlap = bool(overlap)
         self._layouts = {}     # (R0, slack) -> ([layouts per layer], [workspace offsets], total)
         self._ws_ring = [None, None, None, None]   # one workspace per in-flight sample
         self._ws_views = [None, None, None, None]  # tensor views into it, per (R0, slack)
@@ -459,8 +529,8 @@ class DevicePartitionedSampler:
         if self._P == 1 and not self._always_exchange:
             return self._sample_one_rank(nodes, ts, stream, worker_enqueue)
         if self._slack > 0:
-            return _PartitionedPending(self, self._sample_slotted(nodes, ts, stream), nodes, ts,
-                                       stream)
+            return _PartitionedPending(
+                self, self._sample_slotted(nodes, ts, stream, worker_enqueue), nodes, ts, stream)
         return self._sample_variable(nodes, ts, stream)
 
     def _output(self, R, stream):
@@ -493,7 +563,7 @@ class DevicePartitionedSampler:
                               ws_bytes, slab[6]))
         return self._pend(slab, (nodes, ts, ws), R)
 
-    def _sample_slotted(self, nodes, ts, stream):
+    def _sample_slotted(self, nodes, ts, stream, worker_enqueue=False):
         """The whole sample enqueued on `stream` without reading anything back: per layer
         plan -> equal-split exchange of the request slots (asynchronous, overlapped with the
         own share) -> serve -> equal-split exchange of the reply slots -> merge."""
@@ -503,9 +573,21 @@ class DevicePartitionedSampler:
         R0 = max(R, 1)
         if not self._slot_roots:
             self._slot_roots = self._agree_on_slot_roots(R0)
+        if not self._comm_tried:
+            self._comm_tried = True
+            if NativeComm.usable(group):
+                self._comm = NativeComm(self._device, group)
         lays, offs, ws_bytes = self._plan(R0, self._slack)
         slab, out_ptr, nbytes = self._output(R, stream)
         ws, wi = self._workspace(ws_bytes, stream)
+        if self._comm is not None:
+            # the library's own communicator: the chain is one native call
+            call = lib.gf_sampler_sample_partitioned_comm_async if worker_enqueue \
+                else lib.gf_sampler_sample_partitioned_comm
+            check(call(smp._h, self._comm.h, nodes.data_ptr() if R else None,
+                       ts.data_ptr() if R else None, R, out_ptr, nbytes, ws.data_ptr(), ws_bytes,
+                       self._slack, self._slot_roots, 1 if self._overlap else 0, slab[6]))
+            return self._pend(slab, (nodes, ts, ws), R)
         views = self._slot_views(ws, wi, R0, lays, offs)
         base = ws.data_ptr()
         with torch.cuda.stream(stream):

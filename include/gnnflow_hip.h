@@ -418,6 +418,43 @@ GF_API int gf_sampler_sample_partitioned_async(gf_sampler* s, const int64_t* d_r
                                                void* d_out, size_t out_bytes, void* d_ws,
                                                size_t ws_bytes, void* stream);
 
+/* ---- RCCL communicator of the partitioned path ------------------------------------------- */
+/* The exchanges above issued by the library itself over RCCL / xGMI (the reference's transport
+ * is torch RPC between machines, gnnflow/distributed/dist_sampler.py:188-242).  RCCL is resolved
+ * at run time (the librccl.so.1 already in the process, else ROCm's), so a single-GPU user never
+ * loads it.  Bootstrap: rank 0 calls gf_comm_unique_id and hands the 128 bytes to every rank by
+ * whatever channel it has (torch.distributed broadcast, a file, MPI); then EVERY rank calls
+ * gf_comm_create (collective).  gf_comm_all_to_all: bytes_per_peer bytes to / from every rank
+ * (equal split, this rank included), ordered on `stream`; gf_comm_all_to_all_v: host arrays of
+ * world_size byte counts / byte offsets. */
+typedef struct gf_comm gf_comm;
+GF_API int gf_comm_unique_id(uint8_t out[128]);
+GF_API int gf_comm_create(gf_comm** out, const uint8_t id[128], int world_size, int rank,
+                          int device);
+GF_API int gf_comm_destroy(gf_comm* c);
+GF_API int gf_comm_all_to_all(gf_comm* c, const void* d_send, void* d_recv, size_t bytes_per_peer,
+                              void* stream);
+GF_API int gf_comm_all_to_all_v(gf_comm* c, const void* d_send, const size_t* send_bytes,
+                                const size_t* send_offsets, void* d_recv, const size_t* recv_bytes,
+                                const size_t* recv_offsets, void* stream);
+/* The slotted chain of one sample() over `c` in ONE call (and through the enqueue thread):
+ * gf_sampler_part_begin_slotted, then per (layer, snapshot) plan -> request slots out -> own
+ * share + serve -> reply slots back -> merge, then commit; nothing is read back.
+ * d_ws: the slotted layouts' totals, layer after layer, snapshot after snapshot.
+ * overlap != 0: the exchanges run on the communicator's own stream, the request exchange while
+ * this rank's own share is sampled on `stream`.  gf_sampler_sample_end + gf_sampler_part_overflowed
+ * complete it. */
+GF_API int gf_sampler_sample_partitioned_comm(gf_sampler* s, gf_comm* c, const int64_t* d_roots,
+                                              const float* d_root_ts, size_t num_roots,
+                                              void* d_out, size_t out_bytes, void* d_ws,
+                                              size_t ws_bytes, double slack, size_t slot_roots,
+                                              int overlap, void* stream);
+GF_API int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c,
+                                                    const int64_t* d_roots, const float* d_root_ts,
+                                                    size_t num_roots, void* d_out, size_t out_bytes,
+                                                    void* d_ws, size_t ws_bytes, double slack,
+                                                    size_t slot_roots, int overlap, void* stream);
+
 /* ---- message passing on a sampled block ---------------------- */
 /* The DGL calls of the reference's layers on an MFG (gnnflow/models/modules/layers.py:153-159,
  * models/graphsage.py:27-31, models/gat.py:28-46), as segment operations: a block's edges are

@@ -76,10 +76,13 @@ def test_driver_command_line_is_representative():
 def test_two_ranks_through_torchrun():
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
               "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2",
-              "--steps", "40", "--warmup", "5"],
+              "--steps", "40", "--warmup", "5", "--min-replays", "1"],
              env={"GNNFLOW_BENCH_DEVICE": "0", "GNNFLOW_BENCH_BACKEND": "gloo"})
     _check_common(d, 2, 40, 5)
-    assert d["config"]["parallelism"] == "replica-dp2"
+    # N > 1: the headline is north_star's split — the graph hash-partitioned over the ranks,
+    # both ranks exchanging roots / replies per layer (staged through gloo on this one-GPU box)
+    assert d["config"]["parallelism"] == "hash-dp2"
+    assert "equal-split" in d["config"]["exchange"] and "no host sync" in d["config"]["exchange"]
     assert "cpu_baseline" not in d       # rank 0 at N = 1 only
-    h = d["hash_partition"]              # both ranks exchange roots / replies (gloo here)
-    assert "error" not in h and h["world_size"] == 2 and h["value"] > 0
+    r = d["replica"]                     # the per-GPU-replica figure rides along
+    assert "error" not in r and r["world_size"] == 2 and r["value"] > 0

@@ -228,16 +228,21 @@ def _rccl_worker(rank, world, port, ret):
         kw = dict(fanouts=[7, 5], sample_strategy="recent")
         plain = TemporalSampler(g, **kw)
         side = torch.cuda.Stream()
-        # the slotted exchange (equal-split all_to_all_single, nothing read back) and the
-        # variable-size one (all-to-all-v), both with every message empty
-        for slack in (2.0, 0.0):
+        # the slotted exchange — through the library's own RCCL communicator (one native call
+        # per sample, also via the enqueue thread; with and without the communicator's side
+        # stream) and through torch.distributed's equal-split all_to_all_single — and the
+        # variable-size one (all-to-all-v); every message is empty
+        for slack, transport, overlap in ((2.0, "native", True), (2.0, "native", False),
+                                          (2.0, "torch", True), (0.0, "auto", True)):
+            os.environ["GNNFLOW_PART_TRANSPORT"] = transport
             part = DevicePartitionedSampler(TemporalSampler(g, **kw), always_exchange=True,
-                                            slack=slack)
+                                            slack=slack, overlap=overlap)
             for it, R in enumerate([0, 1, 97, 600, 3000]):
                 nodes, t = synth.random_roots(400, R, 1000.0, seed=it, extra_ids=[403])
                 if it % 2:
                     got = part.sample_async(torch.from_numpy(nodes).to(dev),
-                                            torch.from_numpy(t).to(dev), stream=side).wait()
+                                            torch.from_numpy(t).to(dev), stream=side,
+                                            worker_enqueue=transport == "native").wait()
                 else:
                     got = part.sample(nodes, t)
                 want = plain.sample(nodes, t)
@@ -249,9 +254,32 @@ def _rccl_worker(rank, world, port, ret):
                                      (gb.edges()[0], wb.edges()[0]), (gb.edges()[1], wb.edges()[1])):
                             ok &= bool(torch.equal(x, y))
             ok &= part.overflows == 0
+            ok &= (part._comm is not None) == (slack > 0 and transport == "native")
+            if transport == "native" and slack > 0:   # three samples in flight, enqueue thread
+                reqs = [synth.random_roots(400, R, 1000.0, seed=50 + R) for R in (300, 2, 1500)]
+                pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t_).to(dev),
+                                          stream=side, worker_enqueue=True) for n, t_ in reqs]
+                for (n, t_), p in zip(reqs, pend):
+                    for gl, wl in zip(p.wait(), plain.sample(n, t_)):
+                        for gb, wb in zip(gl, wl):
+                            ok &= bool(torch.equal(gb.edata["ID"], wb.edata["ID"]) and
+                                       torch.equal(gb.srcdata["ID"], wb.srcdata["ID"]))
             gb, wb = part.sample_layer(nodes, t, 1, 0), plain.sample_layer(nodes, t, 1, 0)
             ok &= bool(torch.equal(gb.edata["ID"], wb.edata["ID"]) and
                        torch.equal(gb.srcdata["ID"], wb.srcdata["ID"]))
+        os.environ["GNNFLOW_PART_TRANSPORT"] = "auto"
+        # the communicator's variable-size form: 3 + 5 bytes out of / into the middle of buffers
+        from gnnflow_amd.dist import NativeComm
+        from gnnflow_amd import _capi
+        comm = NativeComm(dev)
+        a8 = torch.arange(32, dtype=torch.uint8, device=dev)
+        b8 = torch.zeros(32, dtype=torch.uint8, device=dev)
+        one = C.c_size_t * 1
+        _capi.check(_capi.load().gf_comm_all_to_all_v(
+            comm.h, a8.data_ptr(), one(5), one(3), b8.data_ptr(), one(5), one(7), None))
+        torch.cuda.synchronize()
+        ok &= b8.tolist() == [0] * 7 + [3, 4, 5, 6, 7] + [0] * 20
+        comm.close()
         # owner-sharded feature rows: ids out and rows back through RCCL (to this rank itself)
         from gnnflow_amd.dist import FeatureShards
         rng = np.random.RandomState(3)
