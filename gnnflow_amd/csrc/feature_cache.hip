@@ -149,14 +149,16 @@ struct Ctx {
   float* cache_buf;
   int64_t* slot_id;
   uint32_t* stamp;          // LFU: use count (FIFO: install epoch; LRU: unused)
-  uint32_t* touched;        // epoch of the slot's last hit (pending until the block misses)
+  uint32_t* touched;        // epoch of the last hit (pending until the block misses) — LRU list
+                            // form: indexed by the entry's LIST POSITION (qpos[slot]), so the
+                            // two list passes read it densely, next to the list itself;
+                            // otherwise (queue form, LFU) by slot
   uint32_t* queue[2];       // LRU: the slots, least recently refreshed first (double buffer)
   QueueState* qstate;       // LRU: which buffer is current, device resident
   uint32_t tiles_per_wg;    // LRU: row tiles per scan workgroup (1 unless > 1M rows)
   uint32_t inst_rows;       // LRU: block rows per install workgroup (kInstRows or kWide)
   // LRU of a LARGE cache (queue form, see "LRU as a queue" below); qmode == 0: list form
   int qmode;                // this update appends to the queue instead of rewriting the list
-  int q_rebuild;            // list-form update of a queue-capable cache: rebuild qpos afterwards
   uint32_t* qpos;           // [capacity] position of the slot's live queue entry
   uint32_t* hit_rep;        // [capacity] one of the rows that hit the slot in this block
   uint32_t* qbits;          // one bit per queue position: entry of a slot hit by this block
@@ -273,7 +275,8 @@ __device__ inline void gather_body(const Ctx& c) {
           src = cache_buf + static_cast<uint64_t>(slot) * rowu;
           // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
           // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161).
-          if (c.update && c.policy != GF_CACHE_FIFO) c.touched[slot] = c.epoch_new;
+          if (c.update && c.policy != GF_CACHE_FIFO)
+            c.touched[(c.policy == GF_CACHE_LRU && !c.qmode) ? c.qpos[slot] : slot] = c.epoch_new;
           // queue form: any ONE of the rows that hit the slot stands for it (plain stores of
           // different values to one word: exactly one of them remains)
           if (c.qmode) c.hit_rep[slot] = row0 + lane;
@@ -954,7 +957,10 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
     bool first = true, staged = false;
     for (uint32_t t = blockIdx.x - row_blocks; t < list_tiles; t += list_blocks) {
       const uint32_t p0 = t * kRowTile + tid * kItems;
-      uint32_t sl[kItems], hit[kItems], local = 0;
+      uint32_t sl[kItems], hit[kItems], tc[kItems], local = 0;
+      // the hit marks are indexed by list position: their loads do not wait for the list's
+#pragma unroll
+      for (uint32_t j = 0; j < kItems; ++j) tc[j] = p0 + j < cap ? c.touched[p0 + j] : 0u;
       if (first) {
         // the first tile is read from BOTH buffers while the parity word is still on its
         // way (one dependent hop less on the kernel's critical chain)
@@ -976,7 +982,7 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
       }
 #pragma unroll
       for (uint32_t j = 0; j < kItems; ++j) {
-        hit[j] = (p0 + j < cap && c.touched[sl[j]] == c.epoch_new) ? 1u : 0u;
+        hit[j] = (p0 + j < cap && tc[j] == c.epoch_new) ? 1u : 0u;
         local += hit[j];
       }
       uint32_t total;
@@ -1048,7 +1054,7 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
 #pragma unroll
     for (uint32_t j = 0; j < kItems; ++j) {
       const bool in = p0 + j < cap;
-      hit[j] = in ? (c.touched[sl[j]] == c.epoch_new ? 1u : 0u) : 2u;
+      hit[j] = in ? (c.touched[p0 + j] == c.epoch_new ? 1u : 0u) : 2u;
       lk += hit[j] == 0u;
       lh += hit[j] == 1u;
     }
@@ -1387,68 +1393,64 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
   }
   const uint32_t* list = c.queue[parity & 1u];
   uint32_t* next = c.queue[(parity & 1u) ^ 1u];
-  constexpr uint32_t kItems = kRowTile / kWide;
+  // A workgroup rewrites SUB-tiles of kWide entries, one per thread (the scan kernel counted
+  // the hits per tile of kRowTile = 4 sub-tiles): the rewrite's 2 x capacity scattered stores
+  // — next[] nearly dense, qpos[] anywhere — are bound by the address rate of the CUs that
+  // issue them, so they are spread over 4 x as many (install 11.7 -> see profiles/ with 33
+  // workgroups of 4096 entries on the 134 k-slot cache).
+  constexpr uint32_t kSubs = kRowTile / kWide;
   const uint32_t list_tiles = (cap + kRowTile - 1) / kRowTile;
+  const uint32_t sub_tiles = (cap + kWide - 1) / kWide;
   const uint32_t groups = (list_tiles + kQGroup - 1) / kQGroup;
-  // The first tile's entries are read from BOTH buffers right away, together with the parity
-  // word and the counts, and its touch marks before the sums: two dependent hops less on the
-  // kernel's critical chain.
-  const uint32_t t_first = blockIdx.x - row_blocks;
-  uint32_t sl0[kItems], tc0[kItems];
+  // The first sub-tile's entries are read from BOTH buffers right away, together with the
+  // parity word and the counts, and its hit marks (indexed by position: no need to wait for
+  // the entries): two dependent hops less on the kernel's critical chain.
+  const uint32_t st_first = blockIdx.x - row_blocks;
+  uint32_t sl0, tc0;
   {
-    uint32_t alt[kItems];
-    const uint32_t p0 = t_first * kRowTile + tid * kItems;
-#pragma unroll
-    for (uint32_t j = 0; j < kItems; ++j) {
-      sl0[j] = p0 + j < cap ? c.queue[0][p0 + j] : 0u;
-      alt[j] = p0 + j < cap ? c.queue[1][p0 + j] : 0u;
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < kItems; ++j) sl0[j] = (parity & 1u) ? alt[j] : sl0[j];
+    const uint32_t p = st_first * kWide + tid;
+    const uint32_t a0 = p < cap ? c.queue[0][p] : 0u;
+    const uint32_t a1 = p < cap ? c.queue[1][p] : 0u;
+    tc0 = p < cap ? c.touched[p] : 0u;
+    sl0 = (parity & 1u) ? a1 : a0;
   }
   // #distinct misses and #hit slots of the whole block
   uint32_t tm = 0, th = 0;
   for (uint32_t t = tid; t < spans; t += kWide) tm += c.row_tile_sum[t];
   for (uint32_t g = tid; g < groups; g += kWide) th += c.tile_old[g];
   if (total_miss(c.ctr) == 0) return;   // block without a miss: the list stays as it is
-#pragma unroll
-  for (uint32_t j = 0; j < kItems; ++j) tc0[j] = c.touched[sl0[j]];
   tm = wide_sum(tm, ws);
   th = wide_sum(th, ws);
   const uint32_t k = min(tm, cap), n_kept = cap - th;
-  for (uint32_t t = t_first; t < list_tiles; t += list_blocks) {
-    const uint32_t p0 = t * kRowTile + tid * kItems;
-    uint32_t sl[kItems], tc[kItems], hit[kItems], local = 0;
-    if (t == t_first) {
-#pragma unroll
-      for (uint32_t j = 0; j < kItems; ++j) { sl[j] = sl0[j]; tc[j] = tc0[j]; }
+  for (uint32_t st = st_first; st < sub_tiles; st += list_blocks) {
+    const uint32_t t = st / kSubs, q = st - t * kSubs;
+    const uint32_t p = st * kWide + tid;
+    uint32_t sl, tc;
+    if (st == st_first) {
+      sl = sl0; tc = tc0;
     } else {
-#pragma unroll
-      for (uint32_t j = 0; j < kItems; ++j) sl[j] = p0 + j < cap ? list[p0 + j] : 0u;
-#pragma unroll
-      for (uint32_t j = 0; j < kItems; ++j) tc[j] = c.touched[sl[j]];
+      sl = p < cap ? list[p] : 0u;
+      tc = p < cap ? c.touched[p] : 0u;
     }
-    // hit entries before this tile: whole groups, then the tiles of this tile's group
+    // hit entries before this sub-tile: whole groups, the tiles of this tile's group, and
+    // the sub-tiles of this tile before it (their marks, read densely)
     uint32_t before = 0;
     const uint32_t g0 = t / kQGroup;
     for (uint32_t g = tid; g < g0; g += kWide) before += c.tile_old[g];
     for (uint32_t u = g0 * kQGroup + tid; u < t; u += kWide) before += c.tile_tie[u];
-#pragma unroll
-    for (uint32_t j = 0; j < kItems; ++j) {
-      hit[j] = (p0 + j < cap && tc[j] == c.epoch_new) ? 1u : 0u;
-      local += hit[j];
+    for (uint32_t j = 0; j < q; ++j) {
+      const uint32_t pj = t * kRowTile + j * kWide + tid;   // < p <= cap
+      before += (pj < cap && c.touched[pj] == c.epoch_new) ? 1u : 0u;
     }
+    const uint32_t hit = (p < cap && tc == c.epoch_new) ? 1u : 0u;
     before = wide_sum(before, ws);
     uint32_t total;
-    uint32_t hb = before + wide_excl_scan(local, ws, &total);   // hit entries before p
-#pragma unroll
-    for (uint32_t j = 0; j < kItems; ++j) {
-      const uint32_t p = p0 + j;
-      if (p < cap) {
-        const uint32_t l = hit[j] ? n_kept + hb : p - hb;   // index in L
-        next[l < k ? cap - k + l : l - k] = sl[j];
-      }
-      hb += hit[j];
+    const uint32_t hb = before + wide_excl_scan(hit, ws, &total);   // hit entries before p
+    if (p < cap) {
+      const uint32_t l = hit ? n_kept + hb : p - hb;   // index in L
+      const uint32_t at = l < k ? cap - k + l : l - k;
+      next[at] = sl;
+      c.qpos[sl] = at;   // where the next block's hits of this slot leave their mark
     }
   }
   if (blockIdx.x == row_blocks && tid == 0) c.qstate->parity = parity ^ 1u;
@@ -1762,7 +1764,9 @@ void launch_round(Round& r, hipStream_t stream) {
     // only); the install kernel's also append for the queue-form contexts
     const unsigned lb_list = static_cast<unsigned>(
         std::min<size_t>((q_cap + kRowTile - 1) / kRowTile, 1024));
-    const unsigned lb = std::max<unsigned>(1, std::max(lb_list, static_cast<unsigned>(q_append_blocks)));
+    // install: sub-tiles of kWide list entries per workgroup for the list-form contexts
+    const unsigned lb_sub = static_cast<unsigned>(std::min<size_t>((q_cap + kWide - 1) / kWide, 1024));
+    const unsigned lb = std::max<unsigned>(1, std::max(lb_sub, static_cast<unsigned>(q_append_blocks)));
     const unsigned vb = static_cast<unsigned>(q_victim_blocks);
     lru_list_scan_kernel<<<dim3(rb + lb_list + vb, r.count), dim3(kWide), 0, stream>>>(
         r, rb, lb_list, vb);
@@ -1772,14 +1776,6 @@ void launch_round(Round& r, hipStream_t stream) {
     const unsigned ib = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(q_inst_blocks, 4096)));
     lru_list_install_kernel<<<dim3(ib + lb, r.count), dim3(kWide), 0, stream>>>(r, ib, lb);
     GF_HIP(hipGetLastError());
-    for (int i = 0; i < r.count; ++i) {
-      const Ctx& c = r.c[i];
-      if (c.update && c.q_rebuild) {
-        lru_queue_index_kernel<<<dim3(2048), dim3(256), 0, stream>>>(
-            c.queue[0], c.queue[1], c.qstate, c.qpos, c.capacity);
-        GF_HIP(hipGetLastError());
-      }
-    }
   }
   if (!h_cap) return;
   max_n = h_n; max_cap = h_cap; max_tiles = h_tiles;
@@ -1911,8 +1907,8 @@ void FeatureCache::init_queue(hipStream_t stream) {
   GF_HIP(hipMemcpyAsync(qstate_.data(), &qs, sizeof(qs), hipMemcpyHostToDevice, stream));
   GF_HIP(hipStreamSynchronize(stream));   // qs is a stack variable
   tail_bound_ = capacity_;
+  qpos_.reserve(std::max<size_t>(capacity_, 4) * sizeof(uint32_t), 0, stream);
   if (queue_form_) {
-    qpos_.reserve(capacity_ * sizeof(uint32_t), 0, stream);
     hit_rep_.reserve(capacity_ * sizeof(uint32_t), 0, stream);
     qbits_.reserve(qbits_bytes(queue_cap_), 0, stream);
     GF_HIP(hipMemsetAsync(qbits_.data(), 0, qbits_bytes(queue_cap_), stream));
@@ -1920,18 +1916,17 @@ void FeatureCache::init_queue(hipStream_t stream) {
     const size_t groups = (tiles + kQGroup - 1) / kQGroup + 1;
     compact_.reserve(align_up(tiles * (kRowTile / 64) * 8, 256) + align_up(tiles * 4, 256) +
                      align_up(groups * 4, 256) + 256, 0, stream);
-    index_queue(stream);
   } else {
-    qpos_.release();
     hit_rep_.release();
     qbits_.release();
     compact_.release();
   }
+  index_queue(stream);
 }
 
 // qpos[] of a dense list
 void FeatureCache::index_queue(hipStream_t stream) {
-  if (!queue_form_ || !capacity_) return;
+  if (!capacity_) return;
   lru_queue_index_kernel<<<dim3(2048), dim3(256), 0, stream>>>(
       queue_.as<uint32_t>(), queue_alt_.as<uint32_t>(), qstate_.as<QueueState>(),
       qpos_.as<uint32_t>(), static_cast<uint32_t>(capacity_));
@@ -2122,9 +2117,13 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
     std::swap(queue_, na);
     std::swap(queue_alt_, nb);
     tail_bound_ = new_capacity;
-    if (queue_form_) {
-      DeviceBuffer np, nh, nc, nbits;
+    {
+      DeviceBuffer np;
       np.reserve(new_capacity * sizeof(uint32_t));
+      std::swap(qpos_, np);
+    }
+    if (queue_form_) {
+      DeviceBuffer nh, nc, nbits;
       nh.reserve(new_capacity * sizeof(uint32_t));
       nbits.reserve(qbits_bytes(queue_cap_));
       GF_HIP(hipMemsetAsync(nbits.data(), 0, qbits_bytes(queue_cap_), stream));
@@ -2133,12 +2132,11 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
       const size_t groups = (tiles + kQGroup - 1) / kQGroup + 1;
       nc.reserve(align_up(tiles * (kRowTile / 64) * 8, 256) + align_up(tiles * 4, 256) +
                  align_up(groups * 4, 256) + 256);
-      std::swap(qpos_, np);
       std::swap(hit_rep_, nh);
       std::swap(compact_, nc);
-      index_queue(stream);
-      GF_HIP(hipStreamSynchronize(stream));
     }
+    index_queue(stream);
+    GF_HIP(hipStreamSynchronize(stream));
   }
 }
 
@@ -2226,8 +2224,8 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
       c.stage_tiles = st <= max_stage_tiles() ? static_cast<uint32_t>(st) : 0u;
       c.stage_hits = st == list_tiles ? 1 : 0;
     }
+    c.qpos = qpos_.as<uint32_t>();
     if (queue_form_) {
-      c.qpos = qpos_.as<uint32_t>();
       c.hit_rep = hit_rep_.as<uint32_t>();
       if (n <= capacity_ / 4) {
         // appends at most n entries (#distinct hit slots + #victims <= rows)
@@ -2238,10 +2236,9 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
         c.v_chunks = static_cast<uint32_t>(victim_chunks(n));
         c.stage_tiles = 0;
       } else {
-        // a block this large is cheaper in the list form: on the dense list, and qpos[] is
-        // rebuilt behind it
+        // a block this large is cheaper in the list form, on the dense list (whose install
+        // leaves qpos[] = the new list positions, which is what the queue form expects)
         compact_queue(stream);
-        c.q_rebuild = 1;
         ++list_form_updates_;
       }
     }

@@ -72,14 +72,15 @@ class FeatureCache {
   DeviceBuffer map_;       // int32[num_ids]               id -> slot (kAbsent if none)
   DeviceBuffer slot_id_;   // int64[capacity]              slot -> id (-1 empty)
   DeviceBuffer stamp_;     // uint32[capacity]  LFU: use count; FIFO: install epoch
-  DeviceBuffer touched_;   // uint32[capacity]  epoch of the last hit (pending)
+  DeviceBuffer touched_;   // uint32[capacity]  epoch of the last hit (pending); LRU list form:
+                           // indexed by list position, else by slot
   DeviceBuffer queue_, queue_alt_;   // uint32[capacity]  LRU: slots, least recently refreshed
                                      // first; two buffers, the device knows which is current
   DeviceBuffer qstate_;    // LRU: parity of the current list buffer (+ head / tail of the
                            // queue form), device resident
   // LRU of a large cache is kept as a queue with dead entries (feature_cache.hip, "LRU as a
   // queue"): updates cost O(block rows), not O(capacity)
-  DeviceBuffer qpos_;      // uint32[capacity]  position of the slot's live queue entry
+  DeviceBuffer qpos_;      // uint32[capacity]  position of the slot's (live) list / queue entry
   DeviceBuffer hit_rep_;   // uint32[capacity]  a row of the current block that hit the slot
   DeviceBuffer qbits_;     // one bit per queue position: entries hit by the current block
   DeviceBuffer compact_;   // scratch of the (rare) queue compaction
