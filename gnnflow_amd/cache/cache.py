@@ -188,6 +188,7 @@ class Cache:
         # rows x (8 B id + 2 x 4 x dim B) over every row the gather launches moved so far
         # (SURVEY.md 8(d) algorithmic bytes; read by bench.py's roofline)
         self.algorithmic_bytes = 0
+        self.rows_moved = 0            # rows those launches gathered (aliased blocks move none)
 
     def __del__(self):
         for k in (getattr(self, "_node", None), getattr(self, "_edge", None)):
@@ -509,6 +510,7 @@ class Cache:
         stats_ptr = self._stats_ring.data_ptr() + 64 * stats_pos
         nj = len(jobs)
         self.algorithmic_bytes += sum(job[2] * (8 + 8 * job[4]) for job in jobs)
+        self.rows_moved += sum(job[2] for job in jobs)
         descs = self._desc_buf(nj)
         pack = _DESC.pack_into
         for i, (kind, ids_ptr, n, _keep, dim, b, which, key) in enumerate(jobs):

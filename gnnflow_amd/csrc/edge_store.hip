@@ -80,12 +80,13 @@ __global__ void scatter_edges_kernel(const uint64_t* __restrict__ dest,
                                      const int64_t* __restrict__ eid,
                                      const float* __restrict__ ts, size_t n,
                                      float* __restrict__ ts_pool,
-                                     EdgePair* __restrict__ nbr_pool) {
+                                     EdgePair* __restrict__ nbr_pool, FenceView fence) {
   size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
        i += stride) {
     uint64_t d = dest[i];
     ts_pool[d] = ts[i];
+    fence_store(fence, d, ts[i]);
     EdgePair p;
     p.dst = dst[i];
     p.eid = eid[i];
@@ -101,13 +102,29 @@ struct MoveDesc { uint64_t src, dst, count; };
 // is a fresh segment and frees are deferred to the end of the ingest call).
 __global__ void move_segments_kernel(const MoveDesc* __restrict__ moves, size_t nmoves,
                                      float* __restrict__ ts_pool,
-                                     EdgePair* __restrict__ nbr_pool) {
+                                     EdgePair* __restrict__ nbr_pool, FenceView fence) {
   for (size_t m = blockIdx.x; m < nmoves; m += gridDim.x) {
     MoveDesc mv = moves[m];
     for (uint64_t i = threadIdx.x; i < mv.count; i += blockDim.x) {
-      ts_pool[mv.dst + i] = ts_pool[mv.src + i];
+      const float t = ts_pool[mv.src + i];
+      ts_pool[mv.dst + i] = t;
+      fence_store(fence, mv.dst + i, t);
       nbr_pool[mv.dst + i] = nbr_pool[mv.src + i];
     }
+  }
+}
+
+// fence_l[g] = ts_pool[(g + 1) * 16^l - 1] for every block that ends below `live` (after the
+// pools were reallocated: the fence buffer is new)
+__global__ void rebuild_fences_kernel(const float* __restrict__ ts_pool, uint64_t live,
+                                      FenceView fence) {
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  const uint64_t first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (uint32_t l = 0; l < fence.levels; ++l) {
+    const uint32_t shift = 4 * (l + 1);
+    const uint64_t blocks = live >> shift;
+    for (uint64_t g = first; g < blocks; g += stride)
+      fence.base[fence.off[l] + g] = ts_pool[((g + 1) << shift) - 1];
   }
 }
 
@@ -178,7 +195,43 @@ GraphView EdgeStore::view() const {
   v.table_len = any_node_ ? max_node_id_ + 1 : 0;
   v.ts_pool = ts_pool_.as<float>();
   v.nbr_pool = nbr_pool_.as<EdgePair>();
+  v.fence = fence_view_;
   return v;
+}
+
+// (Re)allocates the fence levels for a pool of `cap` elements and fills them from the first
+// `live` elements of ts_pool_.  Called when the pools grow: rare, and one strided pass.
+void EdgeStore::rebuild_fences(uint64_t cap, uint64_t live) {
+  static const bool enabled = [] {
+    const char* v = std::getenv("GNNFLOW_SEARCH_FENCES");   // tests / A-B runs: 0 = plain search
+    return !(v && std::atoi(v) == 0);
+  }();
+  fences_enabled_ = enabled;
+  FenceView f{nullptr, {0}, 0};
+  if (!enabled) { fence_view_ = f; return; }
+  uint64_t total = 0;
+  for (uint32_t l = 0; l < kFenceMaxLevels; ++l) {
+    const uint64_t n = cap >> (4 * (l + 1));
+    if (n == 0) break;
+    f.off[l] = total;
+    total += align_up(n, 64);   // every level starts on a 256-byte boundary
+    f.levels = l + 1;
+  }
+  if (f.levels == 0) { fence_view_ = f; return; }
+  total += 64;   // a whole aligned window of 16 fences is readable behind the last level
+  // ingest kernels queued earlier hold the old view: they are on stream_, and so is this
+  DeviceBuffer fresh;
+  fresh.reserve(total * sizeof(float), 0, stream_);
+  GF_HIP(hipStreamSynchronize(stream_));
+  std::swap(fence_, fresh);
+  f.base = fence_.as<float>();
+  fence_view_ = f;
+  if (live >= 16) {
+    const unsigned grid = static_cast<unsigned>(std::min<uint64_t>(((live >> 4) + 255) / 256, 4096));
+    rebuild_fences_kernel<<<dim3(std::max(grid, 1u)), dim3(256), 0, stream_>>>(
+        ts_pool_.as<float>(), live, f);
+    GF_HIP(hipGetLastError());
+  }
 }
 
 // ---- bookkeeping ----------------------------------------------------------------
@@ -308,6 +361,7 @@ void EdgeStore::ensure_pool(uint64_t elems) {
                  std::chrono::duration<double, std::milli>(t1 - t0).count(),
                  std::chrono::duration<double, std::milli>(t2 - t1).count());
   pool_elems_ = cap;
+  rebuild_fences(cap, keep);
 }
 
 // temporal_block_allocator.cu:83-88,134-149 (AlignUp + AllocateInternal header init)
@@ -907,12 +961,13 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
     GF_HIP(hipMemcpyAsync(staging_.data(), pinned_.data(), bytes, hipMemcpyHostToDevice, stream_));
     unsigned grid = static_cast<unsigned>(std::min<size_t>(moves.size(), 4096));
     move_segments_kernel<<<dim3(grid), dim3(256), 0, stream_>>>(
-        staging_.as<MoveDesc>(), moves.size(), ts_pool_.as<float>(), nbr_pool_.as<EdgePair>());
+        staging_.as<MoveDesc>(), moves.size(), ts_pool_.as<float>(), nbr_pool_.as<EdgePair>(),
+        fence_view_);
     GF_HIP(hipGetLastError());
     GF_HIP(hipStreamSynchronize(stream_));  // staging is reused below
   }
   if (on_device) {
-    sorter->scatter(gbase, ts_pool_.as<float>(), nbr_pool_.as<EdgePair>(), stream_);
+    sorter->scatter(gbase, ts_pool_.as<float>(), nbr_pool_.as<EdgePair>(), fence_view_, stream_);
     GF_HIP(hipStreamSynchronize(stream_));   // gbase is a host vector
   } else {
     for (size_t off = 0; off < n; off += kIngestChunk) {
@@ -941,7 +996,7 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
       scatter_edges_kernel<<<dim3(grid), dim3(256), 0, stream_>>>(
           reinterpret_cast<uint64_t*>(d), reinterpret_cast<int64_t*>(d + o_dst),
           reinterpret_cast<int64_t*>(d + o_eid), reinterpret_cast<float*>(d + o_ts), m,
-          ts_pool_.as<float>(), nbr_pool_.as<EdgePair>());
+          ts_pool_.as<float>(), nbr_pool_.as<EdgePair>(), fence_view_);
       GF_HIP(hipGetLastError());
       GF_HIP(hipStreamSynchronize(stream_));  // the pinned chunk is refilled next
     }

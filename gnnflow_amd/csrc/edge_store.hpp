@@ -50,12 +50,35 @@ struct alignas(32) EdgePair {
   uint32_t pad[3];
 };
 
+// Fences over the timestamp pool: level l (1 ..) holds every 16^l-th timestamp,
+//   fence_l[g] = ts_pool[(g + 1) * 16^l - 1],
+// a pure function of the POOL (global element index, not of any segment), so whoever writes
+// ts_pool[d] also writes the fences d is the last element of (fence_store below).  Any fence
+// whose position lies inside a node's live segment is a valid pivot of that (sorted) segment,
+// and 16 consecutive pivots of a level are one 64-byte line: the window search reads ONE line
+// per round instead of 16 strided 4-byte probes = 16 sectors (sampler.hip).  1/15 float per
+// edge (0.27 B).  Levels sit in one buffer, level l at element offset off[l - 1].
+constexpr uint32_t kFenceMaxLevels = 8;   // 16^8 = 4.3 G elements per top-level block
+struct FenceView {
+  float* base;
+  uint64_t off[kFenceMaxLevels];
+  uint32_t levels;   // levels that exist for the pool's capacity (16^levels <= capacity)
+};
+__host__ __device__ inline void fence_store(const FenceView& f, uint64_t d, float v) {
+  uint64_t g = d;
+  for (uint32_t l = 0; l < f.levels && (g & 15u) == 15u; ++l) {
+    g >>= 4;
+    f.base[f.off[l] + g] = v;
+  }
+}
+
 // What a sampling kernel needs from the graph (all device pointers).
 struct GraphView {
   const NodeEntry* table;
   uint64_t table_len;
   const float* ts_pool;
   const EdgePair* nbr_pool;
+  FenceView fence;   // fence.levels == 0: no fences (GNNFLOW_SEARCH_FENCES=0)
 };
 
 // Host-only restatement of one reference TemporalBlock header
@@ -239,6 +262,10 @@ class EdgeStore {
 
   // device state
   GrowBuffer ts_pool_, nbr_pool_;   // grow in place (HIP virtual memory), never move
+  DeviceBuffer fence_;              // every 16^l-th timestamp of ts_pool_ (FenceView)
+  FenceView fence_view_{nullptr, {0}, 0};
+  bool fences_enabled_ = true;
+  void rebuild_fences(uint64_t cap, uint64_t live);
   bool pools_ready_ = false;
   DeviceBuffer table_;
   uint64_t pool_elems_ = 0;   // capacity of the pools, in elements

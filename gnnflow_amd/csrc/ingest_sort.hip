@@ -78,7 +78,7 @@ __global__ void scatter_sorted_kernel(const uint32_t* __restrict__ perm,
                                       const int64_t* __restrict__ dst,
                                       const int64_t* __restrict__ eid, uint32_t n,
                                       float* __restrict__ ts_pool,
-                                      EdgePair* __restrict__ nbr_pool) {
+                                      EdgePair* __restrict__ nbr_pool, FenceView fence) {
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint32_t g = gid_incl[i] - 1;
@@ -86,6 +86,7 @@ __global__ void scatter_sorted_kernel(const uint32_t* __restrict__ perm,
     const uint32_t p = perm[i];
     const float t = sorted_ts[i];
     ts_pool[d] = t;
+    fence_store(fence, d, t);
     EdgePair rec;
     rec.dst = dst[p];
     rec.eid = eid[p];
@@ -208,7 +209,7 @@ void IngestSorter::download(uint32_t* h_group_src, uint32_t* h_group_start, floa
 }
 
 void IngestSorter::scatter(const uint64_t* h_group_base, float* ts_pool, EdgePair* nbr_pool,
-                           hipStream_t stream) {
+                           const FenceView& fence, hipStream_t stream) {
   char* b = buf_.as<char>();
   GF_HIP(hipMemcpyAsync(b + o_gbase_, h_group_base, groups_ * 8, hipMemcpyHostToDevice, stream));
   scatter_sorted_kernel<<<dim3(grid_for(n_)), dim3(256), 0, stream>>>(
@@ -217,7 +218,7 @@ void IngestSorter::scatter(const uint64_t* h_group_base, float* ts_pool, EdgePai
       reinterpret_cast<const uint64_t*>(b + o_gbase_),
       reinterpret_cast<const float*>(b + o_sorted_ts_),
       reinterpret_cast<const int64_t*>(b + o_dst_), reinterpret_cast<const int64_t*>(b + o_eid_),
-      static_cast<uint32_t>(n_), ts_pool, nbr_pool);
+      static_cast<uint32_t>(n_), ts_pool, nbr_pool, fence);
   GF_HIP(hipGetLastError());
 }
 

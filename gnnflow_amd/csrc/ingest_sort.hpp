@@ -22,7 +22,7 @@ class IngestSorter {
                 hipStream_t stream);
   // writes sorted edge i of group g to pool element h_group_base[g] + (i - start[g])
   void scatter(const uint64_t* h_group_base, float* ts_pool, EdgePair* nbr_pool,
-               hipStream_t stream);
+               const FenceView& fence, hipStream_t stream);
 
  private:
   void reserve(size_t n, hipStream_t stream);

@@ -75,27 +75,64 @@ def load_feat(dataset: str, data_dir: Optional[str] = None, shared_memory: bool 
               local_rank: int = 0, local_world_size: int = 1, memmap: bool = False,
               load_node: bool = True, load_edge: bool = True):
     """`node_features.npy` / `edge_features.npy` of a dataset -> (node_feats, edge_feats),
-    either may be None but not both missing (gnnflow/utils.py:249-340).  `shared_memory`
-    across several local ranks is the reference's DGL shared-memory path and is not part
-    of this build: every MI355X rank keeps its own copy in HBM."""
+    either may be None but not both missing (gnnflow/utils.py:249-340).
+
+    shared_memory=True is the reference's protocol for several ranks on one machine
+    (:289-338): local rank 0 reads the files, converts to float32 and copies the tables into
+    POSIX shared memory ('node_feats' / 'edge_feats', dgl.utils.shared_mem's role:
+    gnnflow_amd.dgl_compat), broadcasts the shapes (torch.distributed object broadcast from
+    rank 0 — a collective, as in the reference), the other local ranks map the same pages, and
+    everybody meets at a barrier.  One host copy per machine instead of one per rank; what
+    each MI355X rank then puts into HBM is its own business (Cache(feature_placement=...),
+    or dist.FeatureShards.from_full for an owner shard)."""
     root = os.path.join(_data_dir(data_dir), dataset)
     node_path = os.path.join(root, 'node_features.npy')
     edge_path = os.path.join(root, 'edge_features.npy')
     if not os.path.exists(node_path) and not os.path.exists(edge_path):
         raise ValueError("Both {} and {} do not exist".format(node_path, edge_path))
-    if shared_memory and local_world_size > 1:
-        raise NotImplementedError("load_feat(shared_memory=True) across local ranks")
     mode = "r+" if memmap else None
 
     def load(path, wanted):
         if not (wanted and os.path.exists(path)):
             return None
         arr = np.load(path, mmap_mode=mode, allow_pickle=False)
-        if memmap:
-            return arr
-        t = torch.from_numpy(arr)
-        return t.to(torch.float32) if shared_memory else t
-    return load(node_path, load_node), load(edge_path, load_edge)
+        return arr if memmap else torch.from_numpy(arr)
+
+    node_feats = edge_feats = None
+    if not shared_memory or local_rank == 0:
+        node_feats, edge_feats = load(node_path, load_node), load(edge_path, load_edge)
+    if not shared_memory:
+        return node_feats, edge_feats
+
+    def f32(x):
+        return torch.as_tensor(np.asarray(x) if memmap else x).to(torch.float32)
+    if local_world_size <= 1 and not torch.distributed.is_initialized():
+        # one rank: nothing to share
+        return (f32(node_feats) if node_feats is not None else None,
+                f32(edge_feats) if edge_feats is not None else None)
+    from .dgl_compat import create_shared_mem_array, get_shared_mem_array
+    node_shm = edge_shm = None
+    if local_rank == 0:
+        if node_feats is not None:
+            node_feats = f32(node_feats)
+            node_shm = create_shared_mem_array('node_feats', node_feats.shape, node_feats.dtype)
+            node_shm[:] = node_feats[:]
+        if edge_feats is not None:
+            edge_feats = f32(edge_feats)
+            edge_shm = create_shared_mem_array('edge_feats', edge_feats.shape, edge_feats.dtype)
+            edge_shm[:] = edge_feats[:]
+        shapes = [tuple(node_feats.shape) if node_feats is not None else None,
+                  tuple(edge_feats.shape) if edge_feats is not None else None]
+        torch.distributed.broadcast_object_list(shapes, src=0)
+    else:
+        shapes = [None, None]
+        torch.distributed.broadcast_object_list(shapes, src=0)
+        if shapes[0] is not None:
+            node_shm = get_shared_mem_array('node_feats', shapes[0], torch.float32)
+        if shapes[1] is not None:
+            edge_shm = get_shared_mem_array('edge_feats', shapes[1], torch.float32)
+    torch.distributed.barrier()
+    return node_shm, edge_shm
 
 
 # ---- negative samplers (gnnflow/utils.py:343-366, 504-530) ----------------------------

@@ -2,6 +2,8 @@
 outputs of the reference's own gnnflow/utils.py + gnnflow/data.py recorded in
 tests/golden/batch_reference.npz (tests/golden/make_batch_fixtures.py)."""
 import os
+import socket
+import sys
 
 import numpy as np
 import pytest
@@ -136,6 +138,50 @@ def test_load_feat(tmp_path):
     assert node is None and edge is None
     _, mm = U.load_feat("TOY", data_dir=str(tmp_path), memmap=True)
     assert isinstance(mm, np.memmap) and np.array_equal(mm, ef)
+
+
+def _shared_feat_worker(rank, world, port, root, ret):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnnflow_amd import utils as U
+        node, edge = U.load_feat("SHM", data_dir=root, shared_memory=True, local_rank=rank,
+                                 local_world_size=world)
+        want = np.load(os.path.join(root, "SHM", "edge_features.npy"))
+        ok = node is None and edge.dtype == torch.float32 and \
+            np.array_equal(edge.numpy(), want.astype(np.float32))
+        dist.barrier()
+        if rank == 1:                 # the ranks map the SAME pages
+            edge[0, 0] = 1234.5
+        dist.barrier()
+        ok &= float(edge[0, 0]) == 1234.5
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_load_feat_shared_memory_across_local_ranks(tmp_path):
+    """gnnflow/utils.py:289-338: rank 0 reads and publishes, the others map the same pages."""
+    import torch.multiprocessing as mp
+    d = tmp_path / "SHM"
+    d.mkdir()
+    np.save(d / "edge_features.npy", np.random.RandomState(3).rand(50, 6))   # float64 on disk
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    try:
+        mp.spawn(_shared_feat_worker, args=(2, port, str(tmp_path), ret), nprocs=2, join=True)
+    finally:
+        for name in ("node_feats", "edge_feats"):
+            p = "/dev/shm/gnnflow_amd_" + name
+            if os.path.exists(p):
+                os.remove(p)
+    assert dict(ret) == {0: True, 1: True}
 
 
 # ---- world_size 2 (gloo): the samplers that talk to the process group ---------------------

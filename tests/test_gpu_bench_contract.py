@@ -56,6 +56,10 @@ def test_single_gpu_line_with_roofline_and_cpu_baseline():
     assert d["value"] > c["value"]
     # ... and the CPU baseline ran the same batches: same sampled edges per step
     assert c["edges_per_step"] == pytest.approx(d["config"]["edges_per_step"], rel=0.02)
+    # ... and moved the same feature rows (both legs serve the roots' layer's edge block from
+    # the outer block's rows)
+    assert c["rows_per_step"] == pytest.approx(d["config"]["rows_per_step"], rel=0.02)
+    assert c["host_logical_cpus"] >= c["cores"]
     # north_star's hash-partitioned split rides in the same line (one rank: no exchange)
     h = d["hash_partition"]
     assert "error" not in h and h["world_size"] == 1 and h["value"] > 0 and h["steps"] == 1121
