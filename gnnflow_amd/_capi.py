@@ -53,6 +53,34 @@ class GfFetchDesc(C.Structure):
     ]
 
 
+class GfPullDesc(C.Structure):
+    """struct gf_pull_desc (include/gnnflow_hip.h)."""
+    _fields_ = [
+        ("cache", C.c_void_p),
+        ("d_ids", C.c_void_p),
+        ("n", C.c_size_t),
+        ("d_key_base", C.c_void_p),
+        ("d_key_index", C.c_void_p),
+        ("num_ids", C.c_size_t),
+        ("d_send_ids", C.c_void_p),
+        ("d_req_pos", C.c_void_p),
+    ]
+
+
+class GfFetchPulledDesc(C.Structure):
+    """struct gf_fetch_pulled_desc (include/gnnflow_hip.h)."""
+    _fields_ = [
+        ("kind", C.c_int),
+        ("update", C.c_int),
+        ("d_ids", C.c_void_p),
+        ("n", C.c_size_t),
+        ("d_out", C.c_void_p),
+        ("d_stats", C.c_void_p),
+        ("d_pulled_rows", C.c_void_p),
+        ("d_req_pos", C.c_void_p),
+    ]
+
+
 class GfPartLayout(C.Structure):
     """struct gf_part_layout (include/gnnflow_hip.h): byte offsets inside the workspace of
     one (layer, snapshot) of a chained partitioned sample."""
@@ -111,6 +139,10 @@ PROTOTYPES = {
     "gf_cache_fetch": (C.c_int, [_p, _p, _sz, _p, C.c_int, _p, _p]),
     "gf_cache_probe": (C.c_int, [_p, _p, _sz, _p, _p]),
     "gf_cache_fetch_pulled": (C.c_int, [_p, _p, _sz, _p, C.c_int, _p, _p, _p, _p]),
+    "gf_pull_count": (C.c_int, [C.POINTER(GfPullDesc), _sz, C.c_int, _p, C.c_int, _p]),
+    "gf_pull_scatter": (C.c_int, [C.POINTER(GfPullDesc), _sz, C.c_int, _p, _p, C.c_int, _p]),
+    "gf_gather_rows_indexed": (C.c_int, [_p, _sz, _sz, _p, _sz, _p, _sz, _p, _p, C.c_int, _p]),
+    "gf_cache_fetch_blocks_pulled": (C.c_int, [_p, _p, C.POINTER(GfFetchPulledDesc), _sz, _p]),
     "gf_cache_init_rows": (C.c_int, [_p, _p, _sz, _p, _p]),
     "gf_cache_fetch_blocks": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p]),
     "gf_cache_fetch_blocks_async": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p,

@@ -445,9 +445,208 @@ class Cache:
         return out
 
     def _fetch_distributed(self, mfgs, eid, update_cache, target_edge_features):
-        """fetch_feature over sharded tables (cache.py:288-313,351-388,403-411): same rows,
-        same per-block cache semantics; every (layer, snapshot) block issues exactly one pull
-        per kind so that the ranks stay in lock step whatever their block sizes."""
+        """fetch_feature over sharded tables (cache.py:288-313,351-388,403-411): same rows, same
+        per-block cache semantics.  Planned natively (include/gnnflow_hip.h gf_pull_*): per
+        fetch ROUND — the i-th node block, the i-th edge block and, in the first round, the
+        target rows — claims + per-owner counts, ONE count exchange + read-back (the round's
+        only host synchronisation), ids out, rows served by their owners and back, then the
+        usual gather + replacement with the pulled rows standing in for the local table.  No
+        torch `nonzero / unique / argsort / bincount`.  Every rank runs the same rounds: a
+        block that is a prefix of the one fetched before it (LRU, most-recent, equal fanouts)
+        is served from that block's rows unless ANY rank cannot do so — the ranks tell each
+        other in the count exchange."""
+        if not update_cache:
+            return self._fetch_distributed_torch(mfgs, eid, update_cache, target_edge_features)
+        dev, sh = self.device, self._shards
+        with torch.cuda.device(dev):
+            node_blocks = list(mfgs[0]) if self._node is not None else []
+            edge_blocks = [b for mfg in mfgs for b in mfg] if self._edge is not None else []
+            n_node, n_edge = len(node_blocks), len(edge_blocks)
+            pos = self._stats_rows(n_node + n_edge)
+            ring = self._stats_ring
+            target = None
+            if self._edge is not None and target_edge_features and eid is not None:
+                t = self._ids(eid)
+                # cache.py:403-409: the batch's source nodes are the first roots
+                num = mfgs[-1][0].num_dst_nodes() // (self.neg_sample_ratio + 2)
+                nid = self._ids(mfgs[-1][0].srcdata['ID'])[:num]
+                if nid.shape[0] != t.shape[0]:
+                    raise ValueError("target edge ids and the batch's source roots differ "
+                                     "in length")
+                target = (t, nid)
+
+            def node_ctx(i):
+                b = node_blocks[i]
+                return dict(kind=0, cache=self._node, shard=sh.node, ids=self._ids(b.srcdata['ID']),
+                            keys=None, key_index=None, block=b,
+                            stats=ring.data_ptr() + 64 * (pos + i))
+
+            def edge_ctx(j):
+                b = edge_blocks[j]
+                ids = self._ids(b.edata['ID'])
+                n = int(ids.shape[0])
+                # owner of an edge's features: its source node = the block's root of that edge
+                return dict(kind=1, cache=self._edge, shard=sh.edge, ids=ids,
+                            keys=self._ids(b.srcdata['ID']) if n else None,
+                            key_index=b.edges()[1] if n else None, block=b,
+                            stats=ring.data_ptr() + 64 * (pos + n_node + j))
+
+            # Edge blocks after the first may be served from the first one's rows (DESIGN 3.4c)
+            # if they form a prefix chain and the LRU argument holds — on EVERY rank: this
+            # rank's verdict travels in the first round's count exchange.
+            structural = (self._policy == "lru" and self.prefix_alias and n_edge > 1
+                          and all(len(mfg) == 1 for mfg in mfgs))
+            chain = structural and all(
+                getattr(edge_blocks[j], "_edge_prefix_of", None) is edge_blocks[j - 1]
+                and edge_blocks[j].num_edges() <= edge_blocks[j - 1].num_edges() <= self.edge_capacity
+                for j in range(1, n_edge))
+            n_alias, ei, rnd = 0, 0, 0
+            while rnd < n_node or ei < n_edge or (rnd == 0 and target is not None):
+                ctxs = []
+                if rnd < n_node:
+                    ctxs.append(node_ctx(rnd))
+                if ei < n_edge:
+                    ctxs.append(edge_ctx(ei))
+                if rnd == 0 and target is not None:
+                    ctxs.append(dict(kind=2, cache=None, shard=sh.edge, ids=target[0],
+                                     keys=target[1], key_index=None, block=None, stats=0))
+                first_edge = ei == 0 and ei < n_edge
+                outs, all_fit = self._pull_round(
+                    ctxs, 1, flag=0 if (chain or not (first_edge and structural)) else 1)
+                for c, out in zip(ctxs, outs):
+                    if c["kind"] == 0:
+                        c["block"].srcdata['h'] = out
+                    elif c["kind"] == 1:
+                        if c["n"]:
+                            c["block"].edata['f'] = out
+                        ei += 1
+                        if first_edge and structural and all_fit:
+                            for b in edge_blocks[1:]:       # the whole chain, on every rank
+                                n = b.num_edges()
+                                if n:
+                                    b.edata['f'] = out[:n]
+                                n_alias += 1
+                            ei = n_edge
+                    else:
+                        self._target_edge_thunk = None
+                        self._target_edge_features = out
+                rnd += 1
+            self._stats_span = (pos, n_node, n_node + n_edge, ring, n_alias)
+        return mfgs
+
+    def _pull_round(self, ctxs, upd, flag=0):
+        """One fetch round over sharded tables; returns (rows per context, True iff no rank
+        raised `flag`).  A collective: every rank calls it with the same kinds of contexts."""
+        lib, dev, sh = self._lib, self.device, self._shards
+        P, nctx = sh.P, len(ctxs)
+        st = self._stream()
+        i32, i64 = torch.int32, torch.int64
+        descs = (_capi.GfPullDesc * nctx)()
+        keep = []
+        for k, c in enumerate(ctxs):
+            n = int(c["ids"].shape[0])
+            c["n"] = n
+            c["send_ids"] = torch.empty(max(n, 1), dtype=i64, device=dev)
+            c["req_pos"] = torch.empty(max(n, 1), dtype=i32, device=dev)
+            d = descs[k]
+            d.cache = c["cache"].h if c["cache"] is not None else None
+            d.d_ids = c["ids"].data_ptr() if n else None
+            d.n = n
+            d.d_key_base = c["keys"].data_ptr() if (c["keys"] is not None and n) else None
+            d.d_key_index = c["key_index"].data_ptr() if (c["key_index"] is not None and n) else None
+            d.num_ids = c["shard"].num_ids
+            d.d_send_ids = c["send_ids"].data_ptr()
+            d.d_req_pos = c["req_pos"].data_ptr()
+            keep.append((c["ids"], c["keys"], c["key_index"]))
+        # 1. claims + per-owner counts; row nctx of the table carries this rank's flag
+        counts = torch.empty((nctx + 1, P), dtype=i32, device=dev)
+        _capi.check(lib.gf_pull_count(descs, nctx, P, counts.data_ptr(), dev.index, st))
+        counts[nctx].fill_(int(flag))
+        recv_counts = sh.exchange_counts(counts)
+        # 2. the round's one host synchronisation: own and received counts
+        host = torch.stack([counts, recv_counts]).cpu()
+        sh.host_syncs += 1
+        sc = host[0, :nctx].tolist()
+        rc = host[1, :nctx].tolist()
+        all_fit = not bool(host[1, nctx].any()) and not flag
+        # 3. ids into the compact owner-major send buffers
+        offsets = (torch.cumsum(counts[:nctx], dim=1, dtype=i32) - counts[:nctx]).contiguous()
+        cursor = torch.empty((nctx, P), dtype=i32, device=dev)
+        _capi.check(lib.gf_pull_scatter(descs, nctx, P, offsets.data_ptr(), cursor.data_ptr(),
+                                        dev.index, st))
+        n_send = [sum(x) for x in sc]
+        n_recv = [sum(x) for x in rc]
+        send = [c["send_ids"][:n_send[k]] for k, c in enumerate(ctxs)]
+        got = [torch.empty(n_recv[k], dtype=i64, device=dev) for k in range(nctx)]
+        sh.exchange_segments(send, sc, got, rc)
+        # 4. this rank serves what it was asked for ...
+        served = []
+        for k, c in enumerate(ctxs):
+            shard = c["shard"]
+            rows = torch.empty((n_recv[k], shard.dim), dtype=torch.float32, device=dev)
+            if n_recv[k]:
+                _capi.check(lib.gf_gather_rows_indexed(
+                    shard.rows.data_ptr(), int(shard.rows.shape[0]), shard.dim,
+                    shard.index.data_ptr(), shard.num_ids, got[k].data_ptr(), n_recv[k],
+                    rows.data_ptr(), self._pull_flag().data_ptr(), dev.index, st))
+            served.append(rows)
+        # 5. ... and the rows come back in the order of the ids
+        pulled = [torch.empty((max(n_send[k], 1), c["shard"].dim), dtype=torch.float32, device=dev)
+                  for k, c in enumerate(ctxs)]
+        sh.exchange_segments(served, rc, [p[:n_send[k]] for k, p in enumerate(pulled)], sc)
+        me = sh.rank
+        for k, c in enumerate(ctxs):      # traffic figures (DESIGN.md), per shard and in all
+            rows = n_send[k] - sc[k][me]
+            nbytes = 8 * rows + 4 * c["shard"].dim * (n_recv[k] - rc[k][me])
+            c["shard"].rows_pulled += rows
+            c["shard"].bytes_sent += nbytes
+            sh.rows_pulled += rows
+            sh.bytes_sent += nbytes
+        # 6. gather + replacement, the pulled rows standing in for the local table
+        fdescs = (_capi.GfFetchPulledDesc * nctx)()
+        outs, nf = [], 0
+        for k, c in enumerate(ctxs):
+            n, dim = c["n"], c["shard"].dim
+            if c["kind"] == 2:       # cache-free: every row travelled, req_pos is its place
+                outs.append(pulled[k][c["req_pos"][:n].long()] if n else
+                            torch.empty((0, dim), dtype=torch.float32, device=dev))
+                continue
+            out = torch.empty((n, dim), dtype=torch.float32, device=dev)
+            outs.append(out)
+            if n == 0:
+                continue
+            f = fdescs[nf]
+            nf += 1
+            f.kind, f.update = c["kind"], upd
+            f.d_ids, f.n, f.d_out = c["ids"].data_ptr(), n, out.data_ptr()
+            f.d_stats = c["stats"]
+            f.d_pulled_rows = pulled[k].data_ptr()
+            f.d_req_pos = c["req_pos"].data_ptr()
+        if nf:
+            _capi.check(lib.gf_cache_fetch_blocks_pulled(
+                self._node.h if self._node is not None else None,
+                self._edge.h if self._edge is not None else None, fdescs, nf, st))
+        # everything above is queued on this stream; the allocator hands the temporaries'
+        # memory out again only behind it on the same stream
+        return outs, all_fit
+
+    def _pull_flag(self):
+        f = getattr(self, "_pull_flag_t", None)
+        if f is None:
+            f = self._pull_flag_t = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return f
+
+    def check_pulls(self):
+        """Raises KeyError if any rank asked this one for a row it does not own since the last
+        check (a device flag: reading it synchronises)."""
+        f = getattr(self, "_pull_flag_t", None)
+        if f is not None and int(f.item()):
+            f.zero_()
+            raise KeyError("sharded feature pull: asked for an id this rank does not own")
+
+    def _fetch_distributed_torch(self, mfgs, eid, update_cache, target_edge_features):
+        """The pull expressed with torch ops (probe -> unique -> FeatureShards.pull), one pull
+        per block and kind: used for fetches that do not update the cache."""
         dev = self.device
         upd = 1 if update_cache else 0
         with torch.cuda.device(dev):

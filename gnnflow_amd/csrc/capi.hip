@@ -498,6 +498,41 @@ int gf_cache_probe(gf_cache* c, const int64_t* d_ids, size_t n, int32_t* d_slot,
     c->impl.probe(d_ids, n, d_slot, static_cast<hipStream_t>(stream));
   });
 }
+int gf_pull_count(const gf_pull_desc* descs, size_t n, int world_size, uint32_t* d_counts,
+                  int device, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(descs != nullptr && n >= 1 && n <= 4, "gf_pull_count: 1..4 contexts");
+    gf::FeatureCache* caches[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (size_t i = 0; i < n; ++i) caches[i] = descs[i].cache ? &descs[i].cache->impl : nullptr;
+    gf::pull_count(descs, n, world_size, caches, d_counts, device, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_pull_scatter(const gf_pull_desc* descs, size_t n, int world_size, const uint32_t* d_offsets,
+                    uint32_t* d_cursor, int device, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(descs != nullptr && n >= 1 && n <= 4, "gf_pull_scatter: 1..4 contexts");
+    gf::FeatureCache* caches[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (size_t i = 0; i < n; ++i) caches[i] = descs[i].cache ? &descs[i].cache->impl : nullptr;
+    gf::pull_scatter(descs, n, world_size, caches, d_offsets, d_cursor, device,
+                     static_cast<hipStream_t>(stream));
+  });
+}
+int gf_gather_rows_indexed(const float* d_rows, size_t num_local_rows, size_t dim,
+                           const int32_t* d_index, size_t num_ids, const int64_t* d_ids, size_t n,
+                           float* d_out, uint32_t* d_flag, int device, void* stream) {
+  return guarded([&] {
+    gf::gather_rows_indexed(d_rows, num_local_rows, dim, d_index, num_ids, d_ids, n, d_out, d_flag,
+                            device, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_cache_fetch_blocks_pulled(gf_cache* node_cache, gf_cache* edge_cache,
+                                 const gf_fetch_pulled_desc* descs, size_t n, void* stream) {
+  return guarded([&] {
+    gf::fetch_blocks_pulled(node_cache ? &node_cache->impl : nullptr,
+                            edge_cache ? &edge_cache->impl : nullptr, descs, n,
+                            static_cast<hipStream_t>(stream));
+  });
+}
 int gf_cache_fetch_pulled(gf_cache* c, const int64_t* d_ids, size_t n, float* d_out, int update,
                           uint32_t* d_stats, const float* d_miss_rows,
                           const uint32_t* d_miss_index, void* stream) {

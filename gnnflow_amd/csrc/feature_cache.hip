@@ -62,6 +62,7 @@
 // reference skips update_*_cache then too, cache.py:318); a hit only changes replacement
 // state if the block also had a miss, exactly as in the reference.
 #include "feature_cache.hpp"
+#include "owner_hash.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -144,6 +145,13 @@ struct Ctx {
   // miss_index[i] of miss_rows — the rows the caller pulled from their owners — not from feats
   const float* miss_rows;
   const uint32_t* miss_index;
+  // ... or, when the pull was planned natively (gf_pull_*): from row req_pos[rep] of miss_rows,
+  // rep = the row whose claim on map[id] the plan settled (cache-free context: the row itself)
+  const uint32_t* req_pos;
+  // serving a shard: the table row of id is remap[id] (global id -> local row, < 0: not owned
+  // -> *flag is raised and row 0 is served)
+  const int32_t* remap;
+  uint32_t* flag;
   uint64_t num_ids;
   int32_t* map;             // null: no cache (plain gather)
   float* cache_buf;
@@ -271,6 +279,7 @@ __device__ inline void gather_body(const Ctx& c) {
       const int64_t id = c.ids[row0 + lane];
       if (id >= 0 && static_cast<uint64_t>(id) < c.num_ids) {
         slot = c.map ? c.map[id] : -1;
+        const int32_t claim = slot;   // a missed id of a planned pull: -(representative row + 1)
         if (slot >= 0) {
           src = cache_buf + static_cast<uint64_t>(slot) * rowu;
           // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
@@ -282,10 +291,18 @@ __device__ inline void gather_body(const Ctx& c) {
           if (c.qmode) c.hit_rep[slot] = row0 + lane;
         } else {
           slot = -1;
-          src = c.miss_rows
-                    ? reinterpret_cast<const Unit*>(c.miss_rows) +
-                          static_cast<uint64_t>(c.miss_index[row0 + lane]) * rowu
-                    : feats + static_cast<uint64_t>(id) * rowu;
+          if (c.miss_rows) {
+            const uint32_t at = c.req_pos
+                ? c.req_pos[c.map ? static_cast<uint32_t>(-(claim + 1)) : row0 + lane]
+                : c.miss_index[row0 + lane];
+            src = reinterpret_cast<const Unit*>(c.miss_rows) + static_cast<uint64_t>(at) * rowu;
+          } else if (c.remap) {
+            int32_t local = c.remap[id];
+            if (local < 0) { *c.flag = 1u; local = 0; }
+            src = feats + static_cast<uint64_t>(local) * rowu;
+          } else {
+            src = feats + static_cast<uint64_t>(id) * rowu;
+          }
           if (c.update) atomicMax(&c.map[id], -static_cast<int32_t>(row0 + lane + 1));
         }
       }
@@ -360,6 +377,95 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
   if (c.vec4) gather_body<float4>(c);
   else if (c.odd4) gather_body<uf4, true>(c);
   else gather_body<float>(c);
+}
+
+// ---- planning a pull from sharded feature tables -------------------------------------------
+// Cache(distributed=True) (reference: cache.py:288-313,351-388 probe the cache, `unique` the
+// missed ids and pull their rows from the owning machine's KVStore, kvstore.py:285-339).  Here
+// the owners are the GPUs of the node.  Per fetch round, for up to kMaxCtx contexts (a node
+// block, an edge block, cache-free target rows) in the same launches:
+//   claim    every missed row claims its id (atomicMax(map[id], -(row + 1)): the lowest row
+//            wins — the same claim the gather makes, which it will find settled);
+//   count    the rows that TRAVEL — the winners, and every row of a cache-free context — per
+//            owner(key) = splitmix64(key) mod P (key: the node id; for edge rows the edge's
+//            source node);
+//   (the caller exchanges the counts, reads them back — the round's one host synchronisation —
+//    and derives the owner-major offsets)
+//   scatter  the travelling ids into the compact owner-major send buffer; req_pos[row] = the
+//            position of the row's id = the index of its row in the pulled rows, which arrive
+//            in the same order.
+struct PullCtx {
+  const int64_t* ids;
+  uint32_t n;
+  const int64_t* key_base;    // owner key of row i: key_base[key_index[i]] | key_base[i] | ids[i]
+  const int64_t* key_index;
+  int32_t* map;               // null: cache-free (every row travels)
+  uint64_t num_ids;
+  uint32_t* counts;           // [world]
+  const uint32_t* offsets;    // [world] first position per owner (scatter)
+  uint32_t* cursor;           // [world] zeroed
+  int64_t* send_ids;
+  uint32_t* req_pos;          // [n]
+};
+struct PullRound {
+  PullCtx c[kMaxCtx];
+  int count;
+  OwnerDiv od;
+};
+
+__device__ inline int64_t pull_key(const PullCtx& c, uint32_t i) {
+  if (!c.key_base) return c.ids[i];
+  return c.key_base[c.key_index ? c.key_index[i] : static_cast<int64_t>(i)];
+}
+
+__global__ __launch_bounds__(256) void pull_claim_kernel(PullRound r) {
+  const PullCtx& c = r.c[blockIdx.y];
+  if (!c.map) return;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += stride) {
+    const int64_t id = c.ids[i];
+    if (id < 0 || static_cast<uint64_t>(id) >= c.num_ids) continue;
+    if (c.map[id] < 0) atomicMax(&c.map[id], -static_cast<int32_t>(i + 1));
+  }
+}
+
+// does row i travel, and to whom (P = it does not)
+__device__ inline uint32_t pull_owner(const PullCtx& c, uint32_t i, OwnerDiv od) {
+  if (i >= c.n) return od.P;
+  const int64_t id = c.ids[i];
+  if (id < 0 || static_cast<uint64_t>(id) >= c.num_ids) return od.P;
+  if (c.map && c.map[id] != -static_cast<int32_t>(i + 1)) return od.P;   // hit, or not the winner
+  return owner_of(pull_key(c, i), od);
+}
+
+template <bool kScatter>
+__global__ __launch_bounds__(256) void pull_bucket_kernel(PullRound r) {
+  const PullCtx& c = r.c[blockIdx.y];
+  const uint32_t P = r.od.P;
+  const int lane = threadIdx.x & 63;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t rounds = (c.n + stride - 1) / stride;   // uniform trip count (ballots inside)
+  for (uint32_t k = 0; k < rounds; ++k) {
+    const uint32_t i = k * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t o = pull_owner(c, i, r.od);
+    for (uint32_t q = 0; q < P; ++q) {
+      const unsigned long long m = __ballot(o == q);
+      if (!m) continue;                                   // wave-uniform
+      if (!kScatter) {
+        if (lane == 0) atomicAdd(&c.counts[q], static_cast<uint32_t>(__popcll(m)));
+      } else {
+        uint32_t base = 0;
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        if (lane == leader) base = atomicAdd(&c.cursor[q], static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(base, leader, 64);
+        if (o == q) {
+          const uint32_t at = c.offsets[q] + base + __popcll(m & ((1ull << lane) - 1ull));
+          c.send_ids[at] = c.ids[i];
+          c.req_pos[i] = at;
+        }
+      }
+    }
+  }
 }
 
 // ---- LRU bookkeeping ---------------------------------------------------------------
@@ -2350,6 +2456,134 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
       const gf_fetch_desc& d = *plain[pi++];
       r.c[r.count++] = plain_ctx(edge->feats_, edge->num_ids_, edge->dim_, d.d_ids, d.n, d.d_out);
     }
+    launch_round(r, stream);
+  }
+}
+
+// ---- sharded feature tables: plan, serve, fetch (kernels above: "planning a pull") ---------
+namespace {
+PullRound make_pull_round(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
+                          uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_cursor,
+                          size_t* max_rows) {
+  GF_REQUIRE(descs != nullptr && n >= 1 && n <= static_cast<size_t>(kMaxCtx),
+             "pull: 1..4 contexts per round");
+  GF_REQUIRE(world >= 1 && world <= 64, "pull: world size must be 1..64");
+  PullRound r;
+  std::memset(&r, 0, sizeof(r));
+  r.count = static_cast<int>(n);
+  r.od = owner_div(static_cast<uint32_t>(world));
+  *max_rows = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const gf_pull_desc& d = descs[i];
+    GF_REQUIRE(d.n == 0 || d.d_ids != nullptr, "pull: null ids");
+    GF_REQUIRE(d.n < 0x7FFFFFFFull, "pull: more than 2^31-1 rows in one block");
+    PullCtx& c = r.c[i];
+    c.ids = d.d_ids;
+    c.n = static_cast<uint32_t>(d.n);
+    c.key_base = d.d_key_base;
+    c.key_index = d.d_key_index;
+    c.map = caches[i] ? caches[i]->pull_map() : nullptr;
+    c.num_ids = caches[i] ? caches[i]->num_ids() : d.num_ids;
+    c.counts = d_counts ? d_counts + i * world : nullptr;
+    c.offsets = d_offsets ? d_offsets + i * world : nullptr;
+    c.cursor = d_cursor ? d_cursor + i * world : nullptr;
+    c.send_ids = d.d_send_ids;
+    c.req_pos = d.d_req_pos;
+    *max_rows = std::max(*max_rows, d.n);
+  }
+  return r;
+}
+inline unsigned pull_grid(size_t rows) {
+  return static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>((rows + 255) / 256, 2048)));
+}
+}  // namespace
+
+void pull_count(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
+                uint32_t* d_counts, int device, hipStream_t stream) {
+  GF_REQUIRE(d_counts != nullptr, "pull_count: null counts");
+  DeviceGuard dg(device);
+  size_t rows;
+  PullRound r = make_pull_round(descs, n, world, caches, d_counts, nullptr, nullptr, &rows);
+  GF_HIP(hipMemsetAsync(d_counts, 0, n * world * sizeof(uint32_t), stream));
+  if (rows == 0) return;
+  const dim3 grid(pull_grid(rows), static_cast<unsigned>(n));
+  pull_claim_kernel<<<grid, dim3(256), 0, stream>>>(r);
+  pull_bucket_kernel<false><<<grid, dim3(256), 0, stream>>>(r);
+  GF_HIP(hipGetLastError());
+}
+
+void pull_scatter(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
+                  const uint32_t* d_offsets, uint32_t* d_cursor, int device, hipStream_t stream) {
+  GF_REQUIRE(d_offsets && d_cursor, "pull_scatter: null offsets / cursor");
+  DeviceGuard dg(device);
+  size_t rows;
+  PullRound r = make_pull_round(descs, n, world, caches, nullptr, d_offsets, d_cursor, &rows);
+  for (size_t i = 0; i < n; ++i)
+    GF_REQUIRE(descs[i].n == 0 || (descs[i].d_send_ids && descs[i].d_req_pos),
+               "pull_scatter: null send / position buffer");
+  GF_HIP(hipMemsetAsync(d_cursor, 0, n * world * sizeof(uint32_t), stream));
+  if (rows == 0) return;
+  const dim3 grid(pull_grid(rows), static_cast<unsigned>(n));
+  pull_bucket_kernel<true><<<grid, dim3(256), 0, stream>>>(r);
+  GF_HIP(hipGetLastError());
+}
+
+// the owner's side: out[i,:] = rows[index[ids[i]],:]
+void gather_rows_indexed(const float* d_rows, size_t num_local_rows, size_t dim,
+                         const int32_t* d_index, size_t num_ids, const int64_t* d_ids, size_t n,
+                         float* d_out, uint32_t* d_flag, int device, hipStream_t stream) {
+  if (n == 0) return;
+  GF_REQUIRE(d_rows && d_index && d_ids && d_out && d_flag, "gather_rows_indexed: null pointer");
+  GF_REQUIRE(dim > 0 && num_local_rows > 0, "gather_rows_indexed: empty shard");
+  DeviceGuard dg(device);
+  Round r;
+  r.count = 1;
+  r.c[0] = plain_ctx(d_rows, num_ids, dim, d_ids, n, d_out);
+  r.c[0].remap = d_index;
+  r.c[0].flag = d_flag;
+  launch_round(r, stream);
+}
+
+// All fetches of one fetch_feature() call over sharded tables, rounds as in fetch_blocks: the
+// pulled rows stand in for the local table, a missed row finds its own through the claim the
+// plan settled (Ctx::req_pos).
+void fetch_blocks_pulled(FeatureCache* node, FeatureCache* edge, const gf_fetch_pulled_desc* descs,
+                         size_t n, hipStream_t stream) {
+  GF_REQUIRE(descs != nullptr || n == 0, "fetch_blocks_pulled: null descriptors");
+  std::vector<const gf_fetch_pulled_desc*> nodes, edges;
+  for (size_t i = 0; i < n; ++i) {
+    const gf_fetch_pulled_desc& d = descs[i];
+    GF_REQUIRE(d.kind == 0 || d.kind == 1, "fetch_blocks_pulled: kind must be 0 (node) or 1 (edge)");
+    if (d.n == 0) continue;
+    GF_REQUIRE(d.d_pulled_rows && d.d_req_pos, "fetch_blocks_pulled: null pulled rows");
+    GF_REQUIRE((d.kind == 0 ? node : edge) != nullptr, "fetch_blocks_pulled: block without its cache");
+    (d.kind == 0 ? nodes : edges).push_back(&d);
+  }
+  const int device = node ? node->device() : (edge ? edge->device() : 0);
+  DeviceGuard dg(device);
+  size_t max_node_rows = 0, max_edge_rows = 0;
+  for (const auto* d : nodes) max_node_rows = std::max(max_node_rows, d->n);
+  for (const auto* d : edges) max_edge_rows = std::max(max_edge_rows, d->n);
+  if (node && max_node_rows) node->reserve_workspace(max_node_rows, stream);
+  if (edge && max_edge_rows) edge->reserve_workspace(max_edge_rows, stream);
+  const size_t rounds = std::max(nodes.size(), edges.size());
+  for (size_t i = 0; i < rounds; ++i) {
+    Round r;
+    r.count = 0;
+    auto add = [&](FeatureCache* fc, const gf_fetch_pulled_desc& d) {
+      Ctx& c = r.c[r.count++];
+      fc->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &c, stream);
+      c.miss_rows = d.d_pulled_rows;
+      c.req_pos = d.d_req_pos;
+      c.inst_from_table = 0;   // the missed rows are the pulled ones, not a local table's
+      if (c.vec4 && (reinterpret_cast<uintptr_t>(d.d_pulled_rows) & 15u)) {
+        c.vec4 = 0;
+        c.dimv = static_cast<uint32_t>(fc->dim_);
+        set_odd4(c, fc->dim_, fc->policy_ == GF_CACHE_LRU || !d.update || fc->capacity_ == 0);
+      }
+    };
+    if (i < nodes.size()) add(node, *nodes[i]);
+    if (i < edges.size()) add(edge, *edges[i]);
     launch_round(r, stream);
   }
 }

@@ -27,6 +27,17 @@ void memory_update(float* node_memory, float* node_memory_ts, float* mailbox, fl
 class FeatureCache;
 void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
                   hipStream_t stream);
+// sharded feature tables (Cache(distributed=True)): plan the pull of a round's contexts,
+// serve received ids from a shard, fetch with the pulled rows (feature_cache.hip)
+void pull_count(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
+                uint32_t* d_counts, int device, hipStream_t stream);
+void pull_scatter(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
+                  const uint32_t* d_offsets, uint32_t* d_cursor, int device, hipStream_t stream);
+void gather_rows_indexed(const float* d_rows, size_t num_local_rows, size_t dim,
+                         const int32_t* d_index, size_t num_ids, const int64_t* d_ids, size_t n,
+                         float* d_out, uint32_t* d_flag, int device, hipStream_t stream);
+void fetch_blocks_pulled(FeatureCache* node, FeatureCache* edge, const gf_fetch_pulled_desc* descs,
+                         size_t n, hipStream_t stream);
 
 class FeatureCache {
  public:
@@ -52,10 +63,14 @@ class FeatureCache {
   void lru_state(uint64_t out[7]) const;   // gf_cache_lru_state
   size_t mem_bytes() const;
   int device() const { return device_; }
+  size_t num_ids() const { return num_ids_; }
+  int32_t* pull_map() { return capacity_ ? map_.as<int32_t>() : nullptr; }
 
  private:
   friend void fetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
                            hipStream_t);
+  friend void fetch_blocks_pulled(FeatureCache*, FeatureCache*, const gf_fetch_pulled_desc*, size_t,
+                                  hipStream_t);
   void reserve_workspace(size_t n, hipStream_t stream);
   // fills a device context (feature_cache.hip: struct Ctx) for one block fetch and advances
   // the host-side epoch / counter ring (LRU: schedules a queue compaction when due)

@@ -821,7 +821,80 @@ class FeatureShards:
 
 class ShardedFeatures:
     """What `Cache(distributed=True, kvstore_client=...)` takes: the node and / or edge
-    feature shards of this rank."""
+    feature shards of this rank, and the transport of their pulls."""
 
-    def __init__(self, node: Optional[FeatureShards] = None, edge: Optional[FeatureShards] = None):
+    def __init__(self, node: Optional[FeatureShards] = None, edge: Optional[FeatureShards] = None,
+                 group=None, comm: Optional["NativeComm"] = None):
         self.node, self.edge = node, edge
+        self.group = group
+        any_shard = node if node is not None else edge
+        self.P = any_shard.P if any_shard is not None else 1
+        self.rank = any_shard.rank if any_shard is not None else 0
+        self.device = any_shard.device if any_shard is not None else torch.device("cpu")
+        self._comm = comm
+        self._comm_tried = comm is not None
+        self.always_exchange = False     # tests: run the exchanges with one rank too
+        self.rows_pulled = 0             # rows that came from other ranks
+        self.bytes_sent = 0              # ids out + rows back
+        self.host_syncs = 0              # count read-backs (one per fetch round)
+
+    # ---- the exchanges of a native pull (gnnflow_amd/cache/cache.py _fetch_distributed) -----
+    def comm(self):
+        """The library's own RCCL communicator (None: go through torch.distributed — gloo in
+        the CPU tests and when several ranks share one card)."""
+        if not self._comm_tried:
+            self._comm_tried = True
+            if self.device.type == "cuda" and dist.is_initialized() and \
+                    NativeComm.usable(self.group):
+                self._comm = NativeComm(self.device, self.group)
+        return self._comm
+
+    def exchange_counts(self, counts: torch.Tensor) -> torch.Tensor:
+        """counts [nctx, P] (int32, device): rows this rank sends to each owner per context ->
+        [nctx, P]: rows each rank asks THIS rank for.  Equal split, sizes known: no sync."""
+        nctx, P = counts.shape
+        if P == 1 and not self.always_exchange:
+            return counts.clone()
+        send = counts.t().contiguous()              # owner-major: what goes to rank p
+        recv = torch.empty_like(send)
+        comm = self.comm()
+        if comm is not None:
+            from . import _capi
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _capi.check(comm._lib.gf_comm_all_to_all(comm.h, send.data_ptr(), recv.data_ptr(),
+                                                     4 * nctx, st))
+        else:
+            _exchange(recv, send, None, None, self.group)
+        return recv.t().contiguous()
+
+    def exchange_segments(self, send: List[torch.Tensor], sc: List[List[int]],
+                          recv: List[torch.Tensor], rc: List[List[int]]):
+        """One variable-size exchange per context, all in ONE RCCL group when the library's
+        communicator carries them: context k sends sc[k][p] rows of send[k] (owner-major) to
+        rank p and receives rc[k][p] rows into recv[k] (rank-major)."""
+        if self.P == 1 and not self.always_exchange:
+            for a, b in zip(send, recv):
+                b.copy_(a)
+            return
+        comm = self.comm()
+        if comm is not None:
+            import ctypes as C
+            from . import _capi
+            P = self.P
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            for k in range(len(send)):
+                row = send[k].element_size() * (send[k].shape[1] if send[k].dim() > 1 else 1)
+                arr = C.c_size_t * P
+                sb, so, rb, ro = [], [], [], []
+                a = b = 0
+                for p in range(P):
+                    sb.append(sc[k][p] * row); so.append(a); a += sc[k][p] * row
+                    rb.append(rc[k][p] * row); ro.append(b); b += rc[k][p] * row
+                if a == 0 and b == 0:
+                    continue
+                _capi.check(comm._lib.gf_comm_all_to_all_v(
+                    comm.h, send[k].data_ptr() if a else recv[k].data_ptr(), arr(*sb), arr(*so),
+                    recv[k].data_ptr() if b else send[k].data_ptr(), arr(*rb), arr(*ro), st))
+            return
+        for k in range(len(send)):
+            _exchange(recv[k], send[k], rc[k], sc[k], self.group)

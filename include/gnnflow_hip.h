@@ -232,6 +232,60 @@ GF_API int gf_cache_fetch_pulled(gf_cache* c, const int64_t* d_ids, size_t n, fl
 GF_API int gf_cache_init_rows(gf_cache* c, const int64_t* d_ids, size_t n, const float* d_rows,
                               void* stream);
 
+/* The same pull planned natively, for all contexts of a fetch round at once (a node block, an
+ * edge block, cache-free target rows — up to 4), without torch ops and with ONE host
+ * synchronisation per round (reference: cache.py:288-313,351-388 probe / unique / pull;
+ * kvstore.py:285-339).  owner(key) = splitmix64(key) mod world_size; the key of row i is
+ * d_key_base[d_key_index[i]] (edge rows: the edge's source node = the block's root of that
+ * edge), d_key_base[i], or the id itself when d_key_base is NULL.
+ *   gf_pull_count    settles the claims of the missed ids (lowest row wins, the claim the
+ *                    fetch's own gather makes) and counts the rows that travel — the winners,
+ *                    and every row of a cache-free context — per owner:
+ *                    d_counts[ctx * world_size + owner] (uint32, zeroed by the call);
+ *   — the caller exchanges the counts, reads own and received counts back (the round's one
+ *     host synchronisation) and uploads the owner-major offsets —
+ *   gf_pull_scatter  writes the travelling ids compact and owner-major into d_send_ids and
+ *                    d_req_pos[row] = the position of the row's id = the index of its row among
+ *                    the pulled rows, which arrive in the same order (d_cursor: [n * world_size]
+ *                    scratch);
+ *   — ids out (all-to-all-v), gf_gather_rows_indexed on the owner, rows back —
+ *   gf_cache_fetch_blocks_pulled   the fetch round with the pulled rows standing in for the
+ *                    local table; a missed row finds its row through the settled claim. */
+typedef struct gf_pull_desc {
+  gf_cache* cache;             /* NULL: cache-free rows (every row travels) */
+  const int64_t* d_ids;
+  size_t n;
+  const int64_t* d_key_base;   /* NULL: the id is the key */
+  const int64_t* d_key_index;  /* NULL: key = d_key_base[i] */
+  size_t num_ids;              /* id space of a cache-free context (a cache knows its own) */
+  int64_t* d_send_ids;         /* [n] gf_pull_scatter */
+  uint32_t* d_req_pos;         /* [n] gf_pull_scatter */
+} gf_pull_desc;
+GF_API int gf_pull_count(const gf_pull_desc* descs, size_t n, int world_size, uint32_t* d_counts,
+                         int device, void* stream);
+GF_API int gf_pull_scatter(const gf_pull_desc* descs, size_t n, int world_size,
+                           const uint32_t* d_offsets, uint32_t* d_cursor, int device,
+                           void* stream);
+/* the owner's side of a pull: d_out[i,:] = d_rows[d_index[d_ids[i]],:] (d_index: global id ->
+ * local row of this shard, int32, -1 = not owned: *d_flag is set to 1 and row 0 is served) */
+GF_API int gf_gather_rows_indexed(const float* d_rows, size_t num_local_rows, size_t dim,
+                                  const int32_t* d_index, size_t num_ids, const int64_t* d_ids,
+                                  size_t n, float* d_out, uint32_t* d_flag, int device,
+                                  void* stream);
+typedef struct gf_fetch_pulled_desc {
+  int kind;                    /* 0: node block, 1: edge block (executed in array order) */
+  int update;
+  const int64_t* d_ids;
+  size_t n;
+  float* d_out;
+  uint32_t* d_stats;
+  const float* d_pulled_rows;  /* the rows that came back for this context */
+  const uint32_t* d_req_pos;   /* gf_pull_scatter's */
+} gf_fetch_pulled_desc;
+GF_API int gf_cache_fetch_blocks_pulled(gf_cache* node_cache, gf_cache* edge_cache,
+                                        const gf_fetch_pulled_desc* descs, size_t n,
+                                        void* stream);
+
 /* All fetches of one Cache.fetch_feature() call (cache.py:255-413) in one call.
  * kind 0: block of node ids through node_cache (srcdata['h'], cache.py:269-323);
  * kind 1: block of edge ids through edge_cache (edata['f'], cache.py:326-400), executed

@@ -19,7 +19,28 @@ def _tables(N, E, d):
     return (rng.rand(N, d).astype(np.float32), rng.rand(E, d).astype(np.float32))
 
 
-def _run(rank, world, ratio):
+def _reference_cache(cache, shards, ratio, N, E, d, nfeat, efeat, dev):
+    """A LOCAL cache over the full tables started from the distributed cache's initial state
+    (cache.py:161-173: node cache empty, edge cache = the first rows of this rank's shard):
+    the two must then make the same replacement decisions — only where a missed row comes from
+    differs."""
+    import ctypes as C
+    import torch
+    from gnnflow_amd import _capi
+    from gnnflow_amd.cache import LRUCache
+    ref = LRUCache(ratio, ratio, N, E, dev, torch.from_numpy(nfeat), torch.from_numpy(efeat), d, d)
+    lib, st = _capi.load(), None
+    _capi.check(lib.gf_cache_init_rows(ref._node.h, None, 0, None, st))
+    n = min(ref.edge_capacity, int(shards.edge.local_ids.shape[0]))
+    ids = shards.edge.local_ids[:n].contiguous()
+    rows = shards.edge.rows[:n].contiguous()
+    _capi.check(lib.gf_cache_init_rows(ref._edge.h, ids.data_ptr() if n else None, n,
+                                       rows.data_ptr() if n else None, st))
+    torch.cuda.synchronize()
+    return ref
+
+
+def _run(rank, world, ratio, always_exchange=False):
     import torch
     from gnnflow_amd import DynamicGraph, TemporalSampler
     from gnnflow_amd.cache import LRUCache
@@ -35,9 +56,12 @@ def _run(rank, world, ratio):
     sampler = TemporalSampler(g, [6, 6], "recent")
     shards = ShardedFeatures(node=FeatureShards.from_full(nfeat, np.arange(N), rank, world, dev),
                              edge=FeatureShards.from_full(efeat, src, rank, world, dev))
+    shards.always_exchange = always_exchange
     cache = LRUCache(ratio, ratio, N, E, dev, None, None, d, d, kvstore_client=shards,
                      distributed=True)
     cache.init_cache()
+    ref = _reference_cache(cache, shards, ratio, N, E, d, nfeat, efeat, dev)
+    ref_sampler = TemporalSampler(g, [6, 6], "recent")
     ok = True
     sizes = [0, 60, 300, 900]
     for it in range(len(sizes)):
@@ -57,12 +81,25 @@ def _run(rank, world, ratio):
                     assert np.array_equal(b.edata["f"].cpu().numpy(),
                                           efeat[b.edata["ID"].cpu().numpy()]), ("f", it, B)
         assert np.array_equal(cache.target_edge_features.cpu().numpy(), efeat[eid[pick]]), "target"
+        # the same fetch on the local reference cache: identical hit counts and cached ids
+        ref.fetch_feature(ref_sampler.sample(roots, rts), eid[pick])
+        if B:
+            assert float(cache.cache_node_ratio) == float(ref.cache_node_ratio), ("node ratio", it)
+            assert float(cache.cache_edge_ratio) == float(ref.cache_edge_ratio), ("edge ratio", it)
+        for kind in ("node", "edge"):
+            assert np.array_equal(cache.slot_ids(kind), ref.slot_ids(kind)), (kind, "slots", it)
         cache.fetch_feature(mfgs, eid[pick])   # same blocks again (all ranks: lock step)
+        ref.fetch_feature(ref_sampler.sample(roots, rts), eid[pick])
         if B and ratio == 1.0:                 # a cache as large as the id space kept them all
             assert float(cache.cache_edge_ratio) == 1.0, "edge ratio"
             assert float(cache.cache_node_ratio) == 1.0, "node ratio"
         elif B:
             assert 0.0 <= float(cache.cache_edge_ratio) <= 1.0
+    cache.check_pulls()
+    # ONE count read-back per fetch round; a fetch is one round (node block + outer edge block +
+    # target rows, the inner edge block riding on the outer one's rows) or two (outer block
+    # larger than the cache: no alias) — never a sync per torch op as before
+    assert 2 * len(sizes) <= shards.host_syncs <= 4 * len(sizes), shards.host_syncs
     torch.cuda.synchronize()
     return bool(ok)
 

@@ -290,6 +290,10 @@ def _rccl_worker(rank, world, port, ret):
             ids = rng.randint(0, 5000, n).astype(np.int64)
             rows = shards.pull(torch.from_numpy(ids).to(dev), torch.from_numpy(ids).to(dev))
             ok &= bool(np.array_equal(rows.cpu().numpy(), table[ids]))
+        # Cache(distributed=True): the natively planned pull — count exchange, ids out, rows
+        # back — through the library's communicator (every message to this rank itself)
+        from tests.test_gpu_dist_features import _run as run_sharded_cache
+        ok &= run_sharded_cache(0, 1, 0.1, always_exchange=True)
         torch.cuda.synchronize()
         ret[rank] = bool(ok)
     finally:
