@@ -91,6 +91,10 @@ def parse():
     ap.add_argument("--part-slack", type=float, default=None,
                     help="slot capacity factor of the partitioned exchange (0 = variable-size "
                          "all-to-all-v with one host sync per layer; default 2.0)")
+    ap.add_argument("--shard-features", action="store_true",
+                    help="hash-partitioned run: shard the feature tables by owner too "
+                         "(Cache(distributed=True): missed rows are pulled from their owners); "
+                         "default: replicated tables")
     ap.add_argument("--always-exchange", action="store_true",
                     help="with one rank: still run the exchange (every message empty) — "
                          "prices the RCCL calls on a one-GPU box")
@@ -107,6 +111,15 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: everything else that libraries print
+    # there (RCCL's version banner on communicator creation, for one) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(record):
+        os.write(json_fd, (json.dumps(record) + "\n").encode())
+    main.emit = emit
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +141,21 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "--gpus must match the launched world size"
+    if world > 1:
+        # a collective that never completes (RCCL between ranks has not run on this code before
+        # the first scaling run) must not hang the job: after GNNFLOW_BENCH_TIMEOUT seconds rank
+        # 0 prints an error record and every rank exits non-zero
+        import threading
+        limit = float(os.environ.get("GNNFLOW_BENCH_TIMEOUT", "900"))
+        main.done = threading.Event()
+
+        def bench_watchdog():
+            if not main.done.wait(limit):
+                if rank == 0:
+                    emit({"metric": "sampled_edges_per_s", "value": 0.0, "unit": "edges/s",
+                          "n_gpus": world, "error": "timed out after {} s".format(limit)})
+                os._exit(3)
+        threading.Thread(target=bench_watchdog, daemon=True).start()
     if args.partition is None:
         args.partition = "hash" if world > 1 else "replica"
 
@@ -176,7 +204,17 @@ def main():
     edge_feats = torch.rand((g["num_edges"], d_e), generator=gen, device=dev)
     node_feats = torch.rand((g["num_nodes"], d_n), generator=gen, device=dev)
     cache = None
-    if not args.sample_only:
+    if not args.sample_only and args.shard_features and args.partition == "hash":
+        from gnnflow_amd.dist import FeatureShards, ShardedFeatures
+        import numpy as np
+        shards = ShardedFeatures(
+            node=FeatureShards.from_full(node_feats, np.arange(g["num_nodes"]), rank, world, dev),
+            edge=FeatureShards.from_full(edge_feats, g["src"], rank, world, dev))
+        shards.always_exchange = args.always_exchange
+        cache = LRUCache(args.cache_ratio, args.cache_ratio, g["num_nodes"], g["num_edges"], dev,
+                         None, None, d_n, d_e, kvstore_client=shards, distributed=True)
+        cache.init_cache()
+    elif not args.sample_only:
         cache = LRUCache(args.cache_ratio, args.cache_ratio, g["num_nodes"], g["num_edges"],
                          dev, node_feats, edge_feats, d_n, d_e,
                          feature_placement=args.feature_placement)
@@ -339,6 +377,10 @@ def main():
 
     if args.partition == "hash":
         out["config"]["exchange"] = exchange_note(sampler, world, backend)
+        out["config"]["features"] = (
+            "sharded by owner: {} rows pulled, {} count read-backs in {} steps".format(
+                cache._shards.rows_pulled, cache._shards.host_syncs, timed_steps + args.warmup)
+            if cache is not None and cache.distributed else "replicated on every GPU")
     if cache is not None and not args.no_second_leg:
         # The other kind of graph in the same line, over the same batches, cache and pipeline,
         # one chronological replay: the hash-partitioned one when the main loop ran on replicas
@@ -369,7 +411,9 @@ def main():
                                            edge_feats.cpu().numpy(), node_feats.cpu().numpy(),
                                            cache is not None)
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
+    if getattr(main, "done", None) is not None:
+        main.done.set()
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -412,7 +456,7 @@ def second_leg(kind, args, rank, world, local_rank, backend, g, fanouts, cache, 
             if rank == 0 and second_leg.pending_line is not None:
                 second_leg.pending_line["hash_partition" if kind == "hash" else "replica"] = {
                     "error": "timed out after {} s".format(limit)}
-                print(json.dumps(second_leg.pending_line), flush=True)
+                main.emit(second_leg.pending_line)
             os._exit(3)
     threading.Thread(target=watchdog, daemon=True).start()
     try:

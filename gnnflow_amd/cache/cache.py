@@ -534,20 +534,28 @@ class Cache:
             self._stats_span = (pos, n_node, n_node + n_edge, ring, n_alias)
         return mfgs
 
+    def _arena(self, name, numel, dtype):
+        """Grow-only device scratch of the pull rounds, by name (a torch.empty per buffer per
+        round costs more host time than the round's kernels run)."""
+        pool = self.__dict__.setdefault("_arena_pool", {})
+        t = pool.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = pool[name] = torch.empty(max(int(numel * 1.25), 64), dtype=dtype, device=self.device)
+        return t
+
     def _pull_round(self, ctxs, upd, flag=0):
         """One fetch round over sharded tables; returns (rows per context, True iff no rank
         raised `flag`).  A collective: every rank calls it with the same kinds of contexts."""
         lib, dev, sh = self._lib, self.device, self._shards
         P, nctx = sh.P, len(ctxs)
         st = self._stream()
-        i32, i64 = torch.int32, torch.int64
+        i32, i64, f32 = torch.int32, torch.int64, torch.float32
         descs = (_capi.GfPullDesc * nctx)()
-        keep = []
         for k, c in enumerate(ctxs):
             n = int(c["ids"].shape[0])
             c["n"] = n
-            c["send_ids"] = torch.empty(max(n, 1), dtype=i64, device=dev)
-            c["req_pos"] = torch.empty(max(n, 1), dtype=i32, device=dev)
+            c["send_ids"] = self._arena("send%d" % k, max(n, 1), i64)
+            c["req_pos"] = self._arena("pos%d" % k, max(n, 1), i32)
             d = descs[k]
             d.cache = c["cache"].h if c["cache"] is not None else None
             d.d_ids = c["ids"].data_ptr() if n else None
@@ -557,33 +565,40 @@ class Cache:
             d.num_ids = c["shard"].num_ids
             d.d_send_ids = c["send_ids"].data_ptr()
             d.d_req_pos = c["req_pos"].data_ptr()
-            keep.append((c["ids"], c["keys"], c["key_index"]))
         # 1. claims + per-owner counts; row nctx of the table carries this rank's flag
-        counts = torch.empty((nctx + 1, P), dtype=i32, device=dev)
+        words = (nctx + 1) * P
+        both = self._arena("counts", 2 * words + nctx * P, i32)
+        counts = both[:words].view(nctx + 1, P)
         _capi.check(lib.gf_pull_count(descs, nctx, P, counts.data_ptr(), dev.index, st))
         counts[nctx].fill_(int(flag))
         recv_counts = sh.exchange_counts(counts)
-        # 2. the round's one host synchronisation: own and received counts
-        host = torch.stack([counts, recv_counts]).cpu()
+        both[words:2 * words].view(nctx + 1, P).copy_(recv_counts)
+        # 2. the round's one host synchronisation: own and received counts, through pinned memory
+        pin = self.__dict__.get("_pin_counts")
+        if pin is None or pin.numel() < 2 * words:
+            pin = self._pin_counts = torch.empty(max(2 * words, 256), dtype=i32).pin_memory()
+        pin[:2 * words].copy_(both[:2 * words], non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
         sh.host_syncs += 1
+        host = pin[:2 * words].view(2, nctx + 1, P)
         sc = host[0, :nctx].tolist()
         rc = host[1, :nctx].tolist()
         all_fit = not bool(host[1, nctx].any()) and not flag
-        # 3. ids into the compact owner-major send buffers
-        offsets = (torch.cumsum(counts[:nctx], dim=1, dtype=i32) - counts[:nctx]).contiguous()
-        cursor = torch.empty((nctx, P), dtype=i32, device=dev)
-        _capi.check(lib.gf_pull_scatter(descs, nctx, P, offsets.data_ptr(), cursor.data_ptr(),
+        # 3. ids into the compact owner-major send buffers (offsets: prefix of the counts)
+        cursor = both[2 * words:2 * words + nctx * P]
+        _capi.check(lib.gf_pull_scatter(descs, nctx, P, counts.data_ptr(), cursor.data_ptr(),
                                         dev.index, st))
         n_send = [sum(x) for x in sc]
         n_recv = [sum(x) for x in rc]
         send = [c["send_ids"][:n_send[k]] for k, c in enumerate(ctxs)]
-        got = [torch.empty(n_recv[k], dtype=i64, device=dev) for k in range(nctx)]
+        got = [self._arena("got%d" % k, max(n_recv[k], 1), i64)[:n_recv[k]] for k in range(nctx)]
         sh.exchange_segments(send, sc, got, rc)
         # 4. this rank serves what it was asked for ...
         served = []
         for k, c in enumerate(ctxs):
             shard = c["shard"]
-            rows = torch.empty((n_recv[k], shard.dim), dtype=torch.float32, device=dev)
+            rows = self._arena("served%d" % k, max(n_recv[k], 1) * shard.dim, f32)
+            rows = rows[:n_recv[k] * shard.dim].view(n_recv[k], shard.dim)
             if n_recv[k]:
                 _capi.check(lib.gf_gather_rows_indexed(
                     shard.rows.data_ptr(), int(shard.rows.shape[0]), shard.dim,
@@ -591,8 +606,11 @@ class Cache:
                     rows.data_ptr(), self._pull_flag().data_ptr(), dev.index, st))
             served.append(rows)
         # 5. ... and the rows come back in the order of the ids
-        pulled = [torch.empty((max(n_send[k], 1), c["shard"].dim), dtype=torch.float32, device=dev)
-                  for k, c in enumerate(ctxs)]
+        pulled = []
+        for k, c in enumerate(ctxs):
+            dim = c["shard"].dim
+            t = self._arena("pulled%d" % k, max(n_send[k], 1) * dim, f32)
+            pulled.append(t[:max(n_send[k], 1) * dim].view(max(n_send[k], 1), dim))
         sh.exchange_segments(served, rc, [p[:n_send[k]] for k, p in enumerate(pulled)], sc)
         me = sh.rank
         for k, c in enumerate(ctxs):      # traffic figures, per shard and in all
@@ -609,9 +627,9 @@ class Cache:
             n, dim = c["n"], c["shard"].dim
             if c["kind"] == 2:       # cache-free: every row travelled, req_pos is its place
                 outs.append(pulled[k][c["req_pos"][:n].long()] if n else
-                            torch.empty((0, dim), dtype=torch.float32, device=dev))
+                            torch.empty((0, dim), dtype=f32, device=dev))
                 continue
-            out = torch.empty((n, dim), dtype=torch.float32, device=dev)
+            out = torch.empty((n, dim), dtype=f32, device=dev)
             outs.append(out)
             if n == 0:
                 continue
@@ -626,8 +644,8 @@ class Cache:
             _capi.check(lib.gf_cache_fetch_blocks_pulled(
                 self._node.h if self._node is not None else None,
                 self._edge.h if self._edge is not None else None, fdescs, nf, st))
-        # everything above is queued on this stream; the allocator hands the temporaries'
-        # memory out again only behind it on the same stream
+        # every buffer above is used on this stream only: the next round's kernels, which reuse
+        # the arena, are ordered behind this round's
         return outs, all_fit
 
     def _pull_flag(self):

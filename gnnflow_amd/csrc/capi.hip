@@ -507,13 +507,13 @@ int gf_pull_count(const gf_pull_desc* descs, size_t n, int world_size, uint32_t*
     gf::pull_count(descs, n, world_size, caches, d_counts, device, static_cast<hipStream_t>(stream));
   });
 }
-int gf_pull_scatter(const gf_pull_desc* descs, size_t n, int world_size, const uint32_t* d_offsets,
+int gf_pull_scatter(const gf_pull_desc* descs, size_t n, int world_size, uint32_t* d_counts,
                     uint32_t* d_cursor, int device, void* stream) {
   return guarded([&] {
     GF_REQUIRE(descs != nullptr && n >= 1 && n <= 4, "gf_pull_scatter: 1..4 contexts");
     gf::FeatureCache* caches[4] = {nullptr, nullptr, nullptr, nullptr};
     for (size_t i = 0; i < n; ++i) caches[i] = descs[i].cache ? &descs[i].cache->impl : nullptr;
-    gf::pull_scatter(descs, n, world_size, caches, d_offsets, d_cursor, device,
+    gf::pull_scatter(descs, n, world_size, caches, d_counts, d_cursor, device,
                      static_cast<hipStream_t>(stream));
   });
 }

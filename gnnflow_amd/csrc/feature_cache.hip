@@ -401,8 +401,8 @@ struct PullCtx {
   const int64_t* key_index;
   int32_t* map;               // null: cache-free (every row travels)
   uint64_t num_ids;
-  uint32_t* counts;           // [world]
-  const uint32_t* offsets;    // [world] first position per owner (scatter)
+  uint32_t* counts;           // [world] rows per owner (count: written; scatter: read — the
+                              // owner-major offsets are their exclusive prefix)
   uint32_t* cursor;           // [world] zeroed
   int64_t* send_ids;
   uint32_t* req_pos;          // [n]
@@ -443,6 +443,14 @@ __global__ __launch_bounds__(256) void pull_bucket_kernel(PullRound r) {
   const PullCtx& c = r.c[blockIdx.y];
   const uint32_t P = r.od.P;
   const int lane = threadIdx.x & 63;
+  __shared__ uint32_t s_off[64];
+  if (kScatter) {   // first send position per owner: the exclusive prefix of the counts
+    if (threadIdx.x == 0) {
+      uint32_t at = 0;
+      for (uint32_t q = 0; q < P; ++q) { s_off[q] = at; at += c.counts[q]; }
+    }
+    __syncthreads();
+  }
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t rounds = (c.n + stride - 1) / stride;   // uniform trip count (ballots inside)
   for (uint32_t k = 0; k < rounds; ++k) {
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(256) void pull_bucket_kernel(PullRound r) {
         if (lane == leader) base = atomicAdd(&c.cursor[q], static_cast<uint32_t>(__popcll(m)));
         base = __shfl(base, leader, 64);
         if (o == q) {
-          const uint32_t at = c.offsets[q] + base + __popcll(m & ((1ull << lane) - 1ull));
+          const uint32_t at = s_off[q] + base + __popcll(m & ((1ull << lane) - 1ull));
           c.send_ids[at] = c.ids[i];
           c.req_pos[i] = at;
         }
@@ -2463,8 +2471,7 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
 // ---- sharded feature tables: plan, serve, fetch (kernels above: "planning a pull") ---------
 namespace {
 PullRound make_pull_round(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
-                          uint32_t* d_counts, const uint32_t* d_offsets, uint32_t* d_cursor,
-                          size_t* max_rows) {
+                          uint32_t* d_counts, uint32_t* d_cursor, size_t* max_rows) {
   GF_REQUIRE(descs != nullptr && n >= 1 && n <= static_cast<size_t>(kMaxCtx),
              "pull: 1..4 contexts per round");
   GF_REQUIRE(world >= 1 && world <= 64, "pull: world size must be 1..64");
@@ -2484,8 +2491,7 @@ PullRound make_pull_round(const gf_pull_desc* descs, size_t n, int world, Featur
     c.key_index = d.d_key_index;
     c.map = caches[i] ? caches[i]->pull_map() : nullptr;
     c.num_ids = caches[i] ? caches[i]->num_ids() : d.num_ids;
-    c.counts = d_counts ? d_counts + i * world : nullptr;
-    c.offsets = d_offsets ? d_offsets + i * world : nullptr;
+    c.counts = d_counts + i * world;
     c.cursor = d_cursor ? d_cursor + i * world : nullptr;
     c.send_ids = d.d_send_ids;
     c.req_pos = d.d_req_pos;
@@ -2503,7 +2509,7 @@ void pull_count(const gf_pull_desc* descs, size_t n, int world, FeatureCache* co
   GF_REQUIRE(d_counts != nullptr, "pull_count: null counts");
   DeviceGuard dg(device);
   size_t rows;
-  PullRound r = make_pull_round(descs, n, world, caches, d_counts, nullptr, nullptr, &rows);
+  PullRound r = make_pull_round(descs, n, world, caches, d_counts, nullptr, &rows);
   GF_HIP(hipMemsetAsync(d_counts, 0, n * world * sizeof(uint32_t), stream));
   if (rows == 0) return;
   const dim3 grid(pull_grid(rows), static_cast<unsigned>(n));
@@ -2513,11 +2519,11 @@ void pull_count(const gf_pull_desc* descs, size_t n, int world, FeatureCache* co
 }
 
 void pull_scatter(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
-                  const uint32_t* d_offsets, uint32_t* d_cursor, int device, hipStream_t stream) {
-  GF_REQUIRE(d_offsets && d_cursor, "pull_scatter: null offsets / cursor");
+                  uint32_t* d_counts, uint32_t* d_cursor, int device, hipStream_t stream) {
+  GF_REQUIRE(d_counts && d_cursor, "pull_scatter: null counts / cursor");
   DeviceGuard dg(device);
   size_t rows;
-  PullRound r = make_pull_round(descs, n, world, caches, nullptr, d_offsets, d_cursor, &rows);
+  PullRound r = make_pull_round(descs, n, world, caches, d_counts, d_cursor, &rows);
   for (size_t i = 0; i < n; ++i)
     GF_REQUIRE(descs[i].n == 0 || (descs[i].d_send_ids && descs[i].d_req_pos),
                "pull_scatter: null send / position buffer");

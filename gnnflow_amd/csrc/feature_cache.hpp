@@ -32,7 +32,7 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
 void pull_count(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
                 uint32_t* d_counts, int device, hipStream_t stream);
 void pull_scatter(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
-                  const uint32_t* d_offsets, uint32_t* d_cursor, int device, hipStream_t stream);
+                  uint32_t* d_counts, uint32_t* d_cursor, int device, hipStream_t stream);
 void gather_rows_indexed(const float* d_rows, size_t num_local_rows, size_t dim,
                          const int32_t* d_index, size_t num_ids, const int64_t* d_ids, size_t n,
                          float* d_out, uint32_t* d_flag, int device, hipStream_t stream);

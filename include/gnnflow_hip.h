@@ -242,12 +242,12 @@ GF_API int gf_cache_init_rows(gf_cache* c, const int64_t* d_ids, size_t n, const
  *                    fetch's own gather makes) and counts the rows that travel — the winners,
  *                    and every row of a cache-free context — per owner:
  *                    d_counts[ctx * world_size + owner] (uint32, zeroed by the call);
- *   — the caller exchanges the counts, reads own and received counts back (the round's one
- *     host synchronisation) and uploads the owner-major offsets —
- *   gf_pull_scatter  writes the travelling ids compact and owner-major into d_send_ids and
- *                    d_req_pos[row] = the position of the row's id = the index of its row among
- *                    the pulled rows, which arrive in the same order (d_cursor: [n * world_size]
- *                    scratch);
+ *   — the caller exchanges the counts and reads own and received counts back: the round's one
+ *     host synchronisation (they are the split sizes of the two exchanges below) —
+ *   gf_pull_scatter  writes the travelling ids compact and owner-major (offsets = the exclusive
+ *                    prefix of gf_pull_count's d_counts) into d_send_ids and d_req_pos[row] =
+ *                    the position of the row's id = the index of its row among the pulled rows,
+ *                    which arrive in the same order (d_cursor: [n * world_size] scratch);
  *   — ids out (all-to-all-v), gf_gather_rows_indexed on the owner, rows back —
  *   gf_cache_fetch_blocks_pulled   the fetch round with the pulled rows standing in for the
  *                    local table; a missed row finds its row through the settled claim. */
@@ -264,8 +264,7 @@ typedef struct gf_pull_desc {
 GF_API int gf_pull_count(const gf_pull_desc* descs, size_t n, int world_size, uint32_t* d_counts,
                          int device, void* stream);
 GF_API int gf_pull_scatter(const gf_pull_desc* descs, size_t n, int world_size,
-                           const uint32_t* d_offsets, uint32_t* d_cursor, int device,
-                           void* stream);
+                           uint32_t* d_counts, uint32_t* d_cursor, int device, void* stream);
 /* the owner's side of a pull: d_out[i,:] = d_rows[d_index[d_ids[i]],:] (d_index: global id ->
  * local row of this shard, int32, -1 = not owned: *d_flag is set to 1 and row 0 is served) */
 GF_API int gf_gather_rows_indexed(const float* d_rows, size_t num_local_rows, size_t dim,

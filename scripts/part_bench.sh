@@ -15,6 +15,8 @@ run python bench.py $C --partition hash --always-exchange
 GNNFLOW_PART_OVERLAP=0 run python bench.py $C --partition hash --always-exchange
 GNNFLOW_PART_TRANSPORT=torch run python bench.py $C --partition hash --always-exchange
 run python bench.py $C --partition hash --always-exchange --part-slack 0
+run python bench.py $C --partition hash --shard-features
+run python bench.py $C --partition hash --shard-features --always-exchange
 if [ "$1" = "multi" ]; then
 for n in 2 4; do
   GNNFLOW_BENCH_DEVICE=0 GNNFLOW_BENCH_BACKEND=gloo run python -m torch.distributed.run --nnodes=1 \
@@ -29,5 +31,5 @@ for l in open("gpurun_out/r03_part_bench.jsonl"):
     d = json.loads(l)
     if "error" in d: print(d); continue
     c = d["config"]
-    print("{:12s} n={} {:8.1f} M edges/s {:7.1f} us/step  {}".format(c["parallelism"], d["n_gpus"], d["value"]/1e6, 1e3*d["ms_per_step"], c.get("exchange", "")))
+    print("{:12s} n={} {:8.1f} M edges/s {:7.1f} us/step  {} | features: {}".format(c["parallelism"], d["n_gpus"], d["value"]/1e6, 1e3*d["ms_per_step"], c.get("exchange", ""), c.get("features", "replica")))
 PY
