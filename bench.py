@@ -48,7 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
-PMC_TRAFFIC_FILE = "r02_pmc_gather_traffic.json"
+PMC_TRAFFIC_FILE = "r03_pmc_gather_traffic.json"
 
 
 def workload_key(args, repeats):

@@ -116,7 +116,7 @@ __device__ inline uint32_t lower_bound_fenced(const GraphView& g, uint64_t s, ui
                                               int lane, int group_in_wave) {
   constexpr int V = 16 / GROUP;   // consecutive values per lane: the group covers 16 per round
   uint64_t lo = s, hi = s + n;    // the answer lies in [lo, hi]
-  if (n > 16 && g.fence.levels == 0)
+  if (g.fence.levels == 0)   // small layers (view_for), or fences switched off
     return lower_bound_group<GROUP>(g.ts_pool + s, n, x, lane, group_in_wave);
   if (n > 16) {
     int top = (31 - __clz(n - 1)) >> 2;   // coarsest level with 16^top < n
@@ -999,6 +999,17 @@ void launch_padded(int width, unsigned grid, hipStream_t stream, Args... args) {
 
 }  // namespace
 
+// The fences pay where a layer is bound by memory traffic (large layers: one line per round
+// instead of GROUP sectors; config 3, batch 300 k: search 538 -> 516 us).  A small layer is a
+// pure latency chain with the same number of rounds either way, and the fenced search's extra
+// address arithmetic made it slower (REDDIT-shaped batch 600: 6.0 -> 7.7 us per launch): small
+// layers search the timestamps directly.
+inline GraphView view_for(const EdgeStore* g, size_t roots) {
+  GraphView v = g->view();
+  if (roots <= kSmallRoots) v.fence.levels = 0;
+  return v;
+}
+
 // ---- host driver -------------------------------------------------------------------
 Sampler::Sampler(EdgeStore* graph, const uint32_t* fanouts, size_t num_layers, int policy,
                  uint32_t num_snapshots, float window, bool prop_time, uint64_t seed)
@@ -1105,7 +1116,7 @@ void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb
   uint32_t* rec_cnt = reinterpret_cast<uint32_t*>(w); w += align_up(ws_roots_ * 4, 16);
   uint32_t* base = reinterpret_cast<uint32_t*>(w);    w += align_up(ws_roots_ * 4, 16);
   uint32_t* wg_sum = reinterpret_cast<uint32_t*>(w);
-  const GraphView gv = graph_->view();
+  const GraphView gv = view_for(graph_, Rb);
   const uint64_t call = calls_++;
   // small layers: search publishes per-workgroup sums and emit does its own prefix
   const bool small = fused_scan_ && Rb <= kSmallRoots;
@@ -1377,7 +1388,7 @@ void Sampler::sample_layer_padded(const int64_t* d_requests, size_t n, uint32_t 
   GF_REQUIRE(static_cast<uint64_t>(n) * F < 0xFFFFFFFFull,
              "sampler: more than 2^32-1 slots in one layer");
   DeviceGuard dg(graph_->device());
-  const GraphView gv = graph_->view();
+  const GraphView gv = view_for(graph_, n);
   const int uniform = policy_ == GF_SAMPLING_POLICY_UNIFORM;
   const int width = n > kSmallRoots ? large_group_ : search_group_;
   const unsigned grid = capped_grid(n, kSearchThreads / width, 256 * 8);
@@ -1635,7 +1646,7 @@ void Sampler::part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_
     const int width = n_bound > kSmallRoots ? large_group_ : search_group_;
     const unsigned grid = capped_grid(n_bound, kSearchThreads / width, 256 * 8);
     ProfileScope ps(kProfSearch, stream);
-    launch_padded(width, grid, stream, graph_->view(),
+    launch_padded(width, grid, stream, view_for(graph_, n_bound),
                   reinterpret_cast<const int64_t*>(w + lay.requests), static_cast<uint64_t>(0),
                   snapshot, num_snapshots_, window_, F, policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0,
                   prop_time_ ? 1 : 0, seed_, call, reinterpret_cast<int64_t*>(w + lay.replies),
@@ -1668,7 +1679,7 @@ void Sampler::part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
   const int width = n > kSmallRoots ? large_group_ : search_group_;
   const unsigned grid = capped_grid(n, kSearchThreads / width, 256 * 8);
   ProfileScope ps(kProfSearch, stream);
-  launch_padded(width, grid, stream, graph_->view(),
+  launch_padded(width, grid, stream, view_for(graph_, n),
                 reinterpret_cast<const int64_t*>(w + lay.inbox), n, snapshot, num_snapshots_,
                 window_, F, policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0, prop_time_ ? 1 : 0,
                 seed_, call, reinterpret_cast<int64_t*>(w + lay.served),
