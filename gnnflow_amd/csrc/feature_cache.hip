@@ -176,6 +176,7 @@ struct Ctx {
   // in v_pos (the next victims when a block needs more slots than its hits leave over);
   // 0: one workgroup walks the list instead (more than kMaxStageTiles tiles needed)
   uint32_t stage_tiles;
+  uint32_t stage_min;       // ... for blocks that missed more rows than this
   int stage_hits;
   uint32_t v_chunks;        // victim walk: chunks of kRowTile queue entries behind the head
   uint32_t* v_slot;         // [(v_chunks * kRowTile) + n] candidates per chunk (+ the lone walk's)
@@ -219,8 +220,9 @@ __device__ inline uint32_t total_miss(const Counters* c) {
 // 40.4-41.0 staged; 30 k-row blocks with 15-30 k misses: 37.7 us per fetch with the walk, 29.4
 // staged).  The same counter is read by both kernels, so they agree.
 constexpr uint32_t kStageMinWant = 8192;
-__device__ inline bool use_staged_victims(uint32_t stage_tiles, uint32_t missed_rows) {
-  return stage_tiles != 0 && missed_rows > kStageMinWant;
+__device__ inline bool use_staged_victims(uint32_t stage_tiles, uint32_t missed_rows,
+                                          uint32_t min_want) {
+  return stage_tiles != 0 && missed_rows > min_want;
 }
 
 // a float4 that is only 4-byte aligned: global memory takes unaligned 16-byte accesses, a
@@ -1089,7 +1091,7 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
         first = false;
         const uint32_t missed = total_miss(c.ctr);
         if (missed == 0) return;   // uniform across the launch
-        staged = use_staged_victims(c.stage_tiles, missed);
+        staged = use_staged_victims(c.stage_tiles, missed, c.stage_min);
       } else {
 #pragma unroll
         for (uint32_t j = 0; j < kItems; ++j) sl[j] = p0 + j < cap ? list[p0 + j] : 0u;
@@ -1155,7 +1157,7 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
     return;
   }
   if (blockIdx.x != row_blocks + list_blocks ||
-      use_staged_victims(c.stage_tiles, total_miss(c.ctr))) return;
+      use_staged_victims(c.stage_tiles, total_miss(c.ctr), c.stage_min)) return;
   if (want == 0) return;
   uint32_t* kept = c.rep_row;     // victims: not-hit entries from the front of the list
   uint32_t* moved = c.rep_rank;   // hit entries passed on the way
@@ -1338,7 +1340,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
         if (t < w) pm += m;
       }
       const uint32_t q_found = c.ctr->q_found;
-      const bool staged = !c.qmode && use_staged_victims(c.stage_tiles, total_miss(c.ctr));
+      const bool staged = !c.qmode && use_staged_victims(c.stage_tiles, total_miss(c.ctr), c.stage_min);
       uint32_t stage_hit = 0, stage_len = 0, th_part = 0;
       if (staged && chunk == blockIdx.x) {
         // list form: hit counts of the tiles that staged their entries, and of the whole list
@@ -2336,6 +2338,11 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
       const size_t list_tiles = (capacity_ + kRowTile - 1) / kRowTile;
       const size_t st = std::min(list_tiles, (2 * n + kRowTile - 1) / kRowTile + 2);
       c.stage_tiles = st <= max_stage_tiles() ? static_cast<uint32_t>(st) : 0u;
+      static const uint32_t stage_min = [] {
+        const char* e = std::getenv("GNNFLOW_LRU_STAGE_MIN_WANT");   // tuning / tests
+        return e ? static_cast<uint32_t>(std::atoll(e)) : kStageMinWant;
+      }();
+      c.stage_min = stage_min;
       c.stage_hits = st == list_tiles ? 1 : 0;
     }
     c.qpos = qpos_.as<uint32_t>();
