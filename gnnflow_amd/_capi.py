@@ -67,6 +67,21 @@ class GfPullDesc(C.Structure):
     ]
 
 
+class GfPullCtx(C.Structure):
+    """struct gf_pull_ctx (include/gnnflow_hip.h)."""
+    _fields_ = [
+        ("pull", GfPullDesc),
+        ("d_shard_rows", C.c_void_p),
+        ("shard_rows", C.c_size_t),
+        ("d_shard_index", C.c_void_p),
+        ("dim", C.c_size_t),
+        ("kind", C.c_int),
+        ("update", C.c_int),
+        ("d_out", C.c_void_p),
+        ("d_stats", C.c_void_p),
+    ]
+
+
 class GfFetchPulledDesc(C.Structure):
     """struct gf_fetch_pulled_desc (include/gnnflow_hip.h)."""
     _fields_ = [
@@ -143,6 +158,10 @@ PROTOTYPES = {
     "gf_pull_scatter": (C.c_int, [C.POINTER(GfPullDesc), _sz, C.c_int, _p, _p, C.c_int, _p]),
     "gf_gather_rows_indexed": (C.c_int, [_p, _sz, _sz, _p, _sz, _p, _sz, _p, _p, C.c_int, _p]),
     "gf_cache_fetch_blocks_pulled": (C.c_int, [_p, _p, C.POINTER(GfFetchPulledDesc), _sz, _p]),
+    "gf_pull_session_create": (C.c_int, [C.POINTER(_p), _p, C.c_int]),
+    "gf_pull_session_destroy": (C.c_int, [_p]),
+    "gf_pull_round": (C.c_int, [_p, _p, _p, C.POINTER(GfPullCtx), _sz, C.c_int, C.POINTER(C.c_int),
+                                _p, _p, _p, _p]),
     "gf_cache_init_rows": (C.c_int, [_p, _p, _sz, _p, _p]),
     "gf_cache_fetch_blocks": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p]),
     "gf_cache_fetch_blocks_async": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p,

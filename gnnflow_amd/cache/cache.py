@@ -543,11 +543,63 @@ class Cache:
             t = pool[name] = torch.empty(max(int(numel * 1.25), 64), dtype=dtype, device=self.device)
         return t
 
+    def _pull_round_native(self, ctxs, upd, flag, comm):
+        """The round as ONE native call (gf_pull_round): the library's communicator carries the
+        exchanges (`comm` None: one rank, nothing travels)."""
+        lib, dev, sh = self._lib, self.device, self._shards
+        nctx = len(ctxs)
+        sess = self.__dict__.get("_pull_session")
+        if sess is None or sess[1] is not comm:
+            h = C.c_void_p()
+            _capi.check(lib.gf_pull_session_create(C.byref(h), comm.h if comm is not None else None,
+                                                   dev.index))
+            sess = self._pull_session = (h, comm)
+        arr = (_capi.GfPullCtx * nctx)()
+        outs = []
+        for k, c in enumerate(ctxs):
+            n = int(c["ids"].shape[0])
+            c["n"] = n
+            shard = c["shard"]
+            out = torch.empty((n, shard.dim), dtype=torch.float32, device=dev)
+            outs.append(out)
+            a = arr[k]
+            a.pull.d_ids = c["ids"].data_ptr() if n else None
+            a.pull.n = n
+            a.pull.d_key_base = c["keys"].data_ptr() if (c["keys"] is not None and n) else None
+            a.pull.d_key_index = c["key_index"].data_ptr() if (c["key_index"] is not None and n) else None
+            a.pull.num_ids = shard.num_ids
+            a.d_shard_rows = shard.rows.data_ptr()
+            a.shard_rows = int(shard.rows.shape[0])
+            a.d_shard_index = shard.index.data_ptr()
+            a.dim = shard.dim
+            a.kind, a.update = c["kind"], upd
+            a.d_out = out.data_ptr() if n else None
+            a.d_stats = c["stats"] if c["kind"] != 2 else None
+        any_flag = C.c_int(0)
+        rows = (C.c_uint64 * nctx)()
+        nbytes = (C.c_uint64 * nctx)()
+        _capi.check(lib.gf_pull_round(
+            sess[0], self._node.h if self._node is not None else None,
+            self._edge.h if self._edge is not None else None, arr, nctx, int(flag),
+            C.byref(any_flag), rows, nbytes, self._pull_flag().data_ptr(), self._stream()))
+        sh.host_syncs += 1
+        for k, c in enumerate(ctxs):
+            c["shard"].rows_pulled += rows[k]
+            c["shard"].bytes_sent += nbytes[k]
+            sh.rows_pulled += rows[k]
+            sh.bytes_sent += nbytes[k]
+        return outs, not any_flag.value
+
     def _pull_round(self, ctxs, upd, flag=0):
         """One fetch round over sharded tables; returns (rows per context, True iff no rank
         raised `flag`).  A collective: every rank calls it with the same kinds of contexts."""
         lib, dev, sh = self._lib, self.device, self._shards
         P, nctx = sh.P, len(ctxs)
+        if P == 1 and not sh.always_exchange:
+            return self._pull_round_native(ctxs, upd, flag, None)
+        comm = sh.comm()
+        if comm is not None:
+            return self._pull_round_native(ctxs, upd, flag, comm)
         st = self._stream()
         i32, i64, f32 = torch.int32, torch.int64, torch.float32
         descs = (_capi.GfPullDesc * nctx)()

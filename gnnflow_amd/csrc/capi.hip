@@ -19,6 +19,14 @@
 struct gf_graph { gf::EdgeStore impl; template <typename... A> explicit gf_graph(A&&... a) : impl(std::forward<A>(a)...) {} };
 struct gf_sampler { gf::Sampler impl; std::deque<uint64_t> begin_tickets; /* 0 = begun synchronously */ template <typename... A> explicit gf_sampler(A&&... a) : impl(std::forward<A>(a)...) {} };
 struct gf_cache { gf::FeatureCache impl; template <typename... A> explicit gf_cache(A&&... a) : impl(std::forward<A>(a)...) {} };
+struct gf_comm {
+  gf::RcclComm impl;
+  gf_comm(const uint8_t* id, int world, int rank, int device) : impl(id, world, rank, device) {}
+};
+struct gf_pull_session {
+  gf::PullSession impl;
+  gf_pull_session(gf::Exchange* ex, int device) : impl(ex, device) {}
+};
 
 namespace gf {
 
@@ -533,6 +541,25 @@ int gf_cache_fetch_blocks_pulled(gf_cache* node_cache, gf_cache* edge_cache,
                             static_cast<hipStream_t>(stream));
   });
 }
+int gf_pull_session_create(gf_pull_session** out, gf_comm* comm, int device) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_pull_session_create: null output");
+    *out = new gf_pull_session(comm ? &comm->impl : nullptr, device);
+  });
+}
+int gf_pull_session_destroy(gf_pull_session* s) {
+  return guarded([&] { delete s; });
+}
+int gf_pull_round(gf_pull_session* s, gf_cache* node_cache, gf_cache* edge_cache,
+                  const gf_pull_ctx* ctxs, size_t n, int flag, int* any_flag, uint64_t* rows_pulled,
+                  uint64_t* bytes_sent, uint32_t* d_error_flag, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null pull session");
+    s->impl.round(node_cache ? &node_cache->impl : nullptr, edge_cache ? &edge_cache->impl : nullptr,
+                  ctxs, n, flag, any_flag, rows_pulled, bytes_sent, d_error_flag,
+                  static_cast<hipStream_t>(stream));
+  });
+}
 int gf_cache_fetch_pulled(gf_cache* c, const int64_t* d_ids, size_t n, float* d_out, int update,
                           uint32_t* d_stats, const float* d_miss_rows,
                           const uint32_t* d_miss_index, void* stream) {
@@ -778,10 +805,6 @@ int gf_sampler_sample_partitioned_async(gf_sampler* s, const int64_t* d_roots,
   });
 }
 // ---- RCCL communicator (comm.hip) --------------------------------------------------------
-struct gf_comm {
-  gf::RcclComm impl;
-  gf_comm(const uint8_t* id, int world, int rank, int device) : impl(id, world, rank, device) {}
-};
 int gf_comm_unique_id(uint8_t* out) {
   return guarded([&] {
     GF_REQUIRE(out != nullptr, "gf_comm_unique_id: null output");

@@ -403,8 +403,8 @@ struct PullCtx {
   const int64_t* key_index;
   int32_t* map;               // null: cache-free (every row travels)
   uint64_t num_ids;
-  uint32_t* counts;           // [world] rows per owner (count: written; scatter: read — the
-                              // owner-major offsets are their exclusive prefix)
+  uint32_t* counts;           // rows per owner q at counts[q * cstride] (count: written;
+  uint32_t cstride;           // scatter: read — the owner-major offsets are their prefix)
   uint32_t* cursor;           // [world] zeroed
   int64_t* send_ids;
   uint32_t* req_pos;          // [n]
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void pull_bucket_kernel(PullRound r) {
   if (kScatter) {   // first send position per owner: the exclusive prefix of the counts
     if (threadIdx.x == 0) {
       uint32_t at = 0;
-      for (uint32_t q = 0; q < P; ++q) { s_off[q] = at; at += c.counts[q]; }
+      for (uint32_t q = 0; q < P; ++q) { s_off[q] = at; at += c.counts[q * c.cstride]; }
     }
     __syncthreads();
   }
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void pull_bucket_kernel(PullRound r) {
       const unsigned long long m = __ballot(o == q);
       if (!m) continue;                                   // wave-uniform
       if (!kScatter) {
-        if (lane == 0) atomicAdd(&c.counts[q], static_cast<uint32_t>(__popcll(m)));
+        if (lane == 0) atomicAdd(&c.counts[q * c.cstride], static_cast<uint32_t>(__popcll(m)));
       } else {
         uint32_t base = 0;
         const int leader = __ffsll(static_cast<long long>(m)) - 1;
@@ -2478,7 +2478,8 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
 // ---- sharded feature tables: plan, serve, fetch (kernels above: "planning a pull") ---------
 namespace {
 PullRound make_pull_round(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
-                          uint32_t* d_counts, uint32_t* d_cursor, size_t* max_rows) {
+                          uint32_t* d_counts, uint32_t* d_cursor, size_t* max_rows,
+                          uint32_t cstride = 1) {
   GF_REQUIRE(descs != nullptr && n >= 1 && n <= static_cast<size_t>(kMaxCtx),
              "pull: 1..4 contexts per round");
   GF_REQUIRE(world >= 1 && world <= 64, "pull: world size must be 1..64");
@@ -2498,7 +2499,8 @@ PullRound make_pull_round(const gf_pull_desc* descs, size_t n, int world, Featur
     c.key_index = d.d_key_index;
     c.map = caches[i] ? caches[i]->pull_map() : nullptr;
     c.num_ids = caches[i] ? caches[i]->num_ids() : d.num_ids;
-    c.counts = d_counts + i * world;
+    c.counts = cstride == 1 ? d_counts + i * world : d_counts + i;   // [ctx][owner] | [owner][ctx]
+    c.cstride = cstride;
     c.cursor = d_cursor ? d_cursor + i * world : nullptr;
     c.send_ids = d.d_send_ids;
     c.req_pos = d.d_req_pos;
@@ -2599,6 +2601,145 @@ void fetch_blocks_pulled(FeatureCache* node, FeatureCache* edge, const gf_fetch_
     if (i < edges.size()) add(edge, *edges[i]);
     launch_round(r, stream);
   }
+}
+
+// out[i,:] = rows[pos[i],:] — the cache-free context of a pull round (every row travelled;
+// req_pos is its place among the pulled rows)
+namespace {
+__global__ void rows_by_pos_kernel(const float* __restrict__ rows, const uint32_t* __restrict__ pos,
+                                   uint32_t n, uint32_t dim, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t i = wave; i < n; i += nwaves) {
+    const float* s = rows + static_cast<uint64_t>(pos[i]) * dim;
+    float* o = out + static_cast<uint64_t>(i) * dim;
+    for (uint32_t c = lane; c < dim; c += 64) o[c] = s[c];
+  }
+}
+}  // namespace
+
+// One fetch round over sharded tables as ONE native call: plan -> count exchange -> the round's
+// host synchronisation -> scatter -> ids out -> serve -> rows back -> fetch (the stages
+// Cache._pull_round issues one by one when the exchange has to go through torch.distributed).
+PullSession::PullSession(Exchange* ex, int device) : ex_(ex), device_(device) {}
+
+void PullSession::round(FeatureCache* node, FeatureCache* edge, const gf_pull_ctx* ctxs, size_t n,
+                        int flag, int* any_flag, uint64_t* rows_pulled, uint64_t* bytes_sent,
+                        uint32_t* d_error_flag, hipStream_t st) {
+  GF_REQUIRE(ctxs != nullptr && n >= 1 && n <= static_cast<size_t>(kMaxCtx),
+             "pull round: 1..4 contexts");
+  GF_REQUIRE(d_error_flag != nullptr, "pull round: null error flag");
+  DeviceGuard dg(device_);
+  const int P = ex_ ? ex_->world() : 1, me = ex_ ? ex_->rank() : 0;
+  const size_t W = n + 1;   // words per owner: the contexts' counts + this rank's flag
+  // buffers
+  gf_pull_desc descs[kMaxCtx];
+  FeatureCache* caches[kMaxCtx] = {nullptr, nullptr, nullptr, nullptr};
+  for (size_t k = 0; k < n; ++k) {
+    const gf_pull_ctx& c = ctxs[k];
+    GF_REQUIRE(c.kind >= 0 && c.kind <= 2, "pull round: bad kind");
+    GF_REQUIRE(c.dim > 0 && c.d_shard_rows && c.d_shard_index, "pull round: bad shard");
+    caches[k] = c.kind == 0 ? node : (c.kind == 1 ? edge : nullptr);
+    GF_REQUIRE(c.kind == 2 || caches[k] != nullptr, "pull round: block without its cache");
+    send_ids_[k].reserve(std::max<size_t>(c.pull.n, 1) * 8, 0, st);
+    req_pos_[k].reserve(std::max<size_t>(c.pull.n, 1) * 4, 0, st);
+    descs[k] = c.pull;
+    descs[k].cache = nullptr;   // caches[] carries it
+    descs[k].d_send_ids = send_ids_[k].as<int64_t>();
+    descs[k].d_req_pos = req_pos_[k].as<uint32_t>();
+  }
+  counts_.reserve((2 * P * W + n * P) * 4, 0, st);
+  h_counts_.reserve(2 * P * W * 4);
+  uint32_t* d_counts = counts_.as<uint32_t>();        // [P][W] own, then [P][W] received
+  uint32_t* d_recv = d_counts + P * W;
+  uint32_t* d_cursor = d_recv + P * W;
+  // 1. claims + per-owner counts, owner-major so that row q goes to rank q as it is
+  size_t rows;
+  PullRound r = make_pull_round(descs, n, P, caches, d_counts, nullptr, &rows,
+                                static_cast<uint32_t>(W));
+  GF_HIP(hipMemsetAsync(d_counts, 0, P * W * 4, st));
+  if (rows) {
+    const dim3 grid(pull_grid(rows), static_cast<unsigned>(n));
+    pull_claim_kernel<<<grid, dim3(256), 0, st>>>(r);
+    pull_bucket_kernel<false><<<grid, dim3(256), 0, st>>>(r);
+    GF_HIP(hipGetLastError());
+  }
+  if (flag)   // this rank's flag rides in word n of every owner's row (any non-zero value)
+    GF_HIP(hipMemset2DAsync(d_counts + n, W * 4, 1, 4, P, st));
+  if (ex_) ex_->all_to_all(d_counts, d_recv, W * 4, st);
+  else GF_HIP(hipMemcpyAsync(d_recv, d_counts, P * W * 4, hipMemcpyDeviceToDevice, st));
+  // 2. the round's one host synchronisation
+  uint32_t* h = h_counts_.as<uint32_t>();
+  GF_HIP(hipMemcpyAsync(h, d_counts, 2 * P * W * 4, hipMemcpyDeviceToHost, st));
+  GF_HIP(hipStreamSynchronize(st));
+  const uint32_t* hs = h;             // hs[q * W + k]: rows of context k this rank sends to q
+  const uint32_t* hr = h + P * W;     // hr[q * W + k]: rows rank q asks this rank for
+  int any = flag ? 1 : 0;
+  for (int q = 0; q < P; ++q) any |= hr[q * W + n] ? 1 : 0;
+  if (any_flag) *any_flag = any;
+  // 3. ids into the compact owner-major send buffers
+  r = make_pull_round(descs, n, P, caches, d_counts, d_cursor, &rows, static_cast<uint32_t>(W));
+  GF_HIP(hipMemsetAsync(d_cursor, 0, n * P * 4, st));
+  if (rows) {
+    pull_bucket_kernel<true><<<dim3(pull_grid(rows), static_cast<unsigned>(n)), dim3(256), 0, st>>>(r);
+    GF_HIP(hipGetLastError());
+  }
+  std::vector<size_t> sb(P), so(P), rb(P), ro(P);
+  gf_fetch_pulled_desc fd[kMaxCtx];
+  size_t nf = 0;
+  for (size_t k = 0; k < n; ++k) {
+    const gf_pull_ctx& c = ctxs[k];
+    size_t n_send = 0, n_recv = 0;
+    for (int q = 0; q < P; ++q) { n_send += hs[q * W + k]; n_recv += hr[q * W + k]; }
+    got_[k].reserve(std::max<size_t>(n_recv, 1) * 8, 0, st);
+    served_[k].reserve(std::max<size_t>(n_recv, 1) * c.dim * 4, 0, st);
+    pulled_[k].reserve(std::max<size_t>(n_send, 1) * c.dim * 4, 0, st);
+    auto exchange = [&](const void* send, void* recv, size_t row_bytes, bool back) {
+      // forward: this rank's ids to their owners; back: the owners' rows to the requesters
+      size_t a = 0, b = 0;
+      for (int q = 0; q < P; ++q) {
+        const size_t s_rows = back ? hr[q * W + k] : hs[q * W + k];
+        const size_t r_rows = back ? hs[q * W + k] : hr[q * W + k];
+        sb[q] = s_rows * row_bytes; so[q] = a; a += sb[q];
+        rb[q] = r_rows * row_bytes; ro[q] = b; b += rb[q];
+      }
+      if (a == 0 && b == 0) return;
+      if (ex_) ex_->all_to_all_v(send, sb.data(), so.data(), recv, rb.data(), ro.data(), st);
+      else GF_HIP(hipMemcpyAsync(recv, send, a, hipMemcpyDeviceToDevice, st));
+    };
+    // 4. ids out, served by their owners, rows back
+    exchange(send_ids_[k].data(), got_[k].data(), 8, false);
+    if (n_recv)
+      gather_rows_indexed(c.d_shard_rows, c.shard_rows, c.dim, c.d_shard_index, c.pull.num_ids,
+                          got_[k].as<int64_t>(), n_recv, served_[k].as<float>(), d_error_flag,
+                          device_, st);
+    exchange(served_[k].data(), pulled_[k].data(), c.dim * 4, true);
+    if (rows_pulled) rows_pulled[k] = n_send - hs[me * W + k];
+    if (bytes_sent)
+      bytes_sent[k] = 8 * (n_send - hs[me * W + k]) + 4 * c.dim * (n_recv - hr[me * W + k]);
+    // 5. the fetch itself
+    if (c.pull.n == 0) continue;
+    GF_REQUIRE(c.d_out != nullptr, "pull round: null output");
+    if (c.kind == 2) {
+      const unsigned grid = static_cast<unsigned>(std::min<size_t>((c.pull.n + 3) / 4, 2048));
+      rows_by_pos_kernel<<<dim3(grid), dim3(256), 0, st>>>(
+          pulled_[k].as<float>(), req_pos_[k].as<uint32_t>(), static_cast<uint32_t>(c.pull.n),
+          static_cast<uint32_t>(c.dim), c.d_out);
+      GF_HIP(hipGetLastError());
+      continue;
+    }
+    gf_fetch_pulled_desc& f = fd[nf++];
+    f.kind = c.kind;
+    f.update = c.update;
+    f.d_ids = c.pull.d_ids;
+    f.n = c.pull.n;
+    f.d_out = c.d_out;
+    f.d_stats = c.d_stats;
+    f.d_pulled_rows = pulled_[k].as<float>();
+    f.d_req_pos = req_pos_[k].as<uint32_t>();
+  }
+  if (nf) fetch_blocks_pulled(node, edge, fd, nf, st);
 }
 
 void FeatureCache::slot_ids(int64_t* out, size_t capacity) const {

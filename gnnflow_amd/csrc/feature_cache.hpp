@@ -4,6 +4,7 @@
 
 #include <cstdint>
 
+#include "comm.hpp"
 #include "common.hpp"
 
 namespace gf {
@@ -38,6 +39,22 @@ void gather_rows_indexed(const float* d_rows, size_t num_local_rows, size_t dim,
                          float* d_out, uint32_t* d_flag, int device, hipStream_t stream);
 void fetch_blocks_pulled(FeatureCache* node, FeatureCache* edge, const gf_fetch_pulled_desc* descs,
                          size_t n, hipStream_t stream);
+
+// One fetch round over sharded feature tables as one native call (gf_pull_round): the buffers
+// of the round (grow-only) and the transport (null: one rank, nothing travels).
+class PullSession {
+ public:
+  PullSession(Exchange* ex, int device);
+  void round(FeatureCache* node, FeatureCache* edge, const gf_pull_ctx* ctxs, size_t n, int flag,
+             int* any_flag, uint64_t* rows_pulled, uint64_t* bytes_sent, uint32_t* d_error_flag,
+             hipStream_t stream);
+
+ private:
+  Exchange* ex_;
+  int device_;
+  DeviceBuffer send_ids_[4], req_pos_[4], got_[4], served_[4], pulled_[4], counts_;
+  PinnedBuffer h_counts_;
+};
 
 class FeatureCache {
  public:

@@ -178,6 +178,7 @@ GF_API void gf_host_blocks_free(gf_block* blocks, size_t n);
 
 /* ---- feature gather + LRU cache: gnnflow/cache/cache.py, lru_cache.py -------- */
 typedef struct gf_cache gf_cache;
+typedef struct gf_comm gf_comm;   /* RCCL communicator of the partitioned path, below */
 
 /* One cache "kind" (node or edge) of Cache.__init__ (cache.py:82-134) +
  * LRUCache.__init__ (lru_cache.py:56-61): `capacity` rows of `dim` float32 in
@@ -284,6 +285,32 @@ typedef struct gf_fetch_pulled_desc {
 GF_API int gf_cache_fetch_blocks_pulled(gf_cache* node_cache, gf_cache* edge_cache,
                                         const gf_fetch_pulled_desc* descs, size_t n,
                                         void* stream);
+
+/* The whole round in ONE call (the stages above + the exchanges through `comm`, which may be
+ * NULL with one rank): per context the pull description, this rank's shard of the context's
+ * table (rows + global id -> local row index) and where the fetched rows go.  kind 2 = cache-free
+ * (target edge features): d_out[i,:] = the pulled row of d_ids[i].  `flag` travels to every rank
+ * in the count exchange and *any_flag = OR over all ranks (Cache uses it to agree on the prefix
+ * alias).  rows_pulled / bytes_sent [n]: per context, rows fetched from OTHER ranks and bytes
+ * this rank put on the wire (ids out + rows served).  One host synchronisation. */
+typedef struct gf_pull_ctx {
+  gf_pull_desc pull;           /* cache, d_send_ids, d_req_pos are ignored (the session's own) */
+  const float* d_shard_rows;   /* [shard_rows, dim] */
+  size_t shard_rows;
+  const int32_t* d_shard_index;/* [pull.num_ids] */
+  size_t dim;
+  int kind;                    /* 0 node block, 1 edge block, 2 cache-free rows */
+  int update;
+  float* d_out;                /* [pull.n, dim] */
+  uint32_t* d_stats;
+} gf_pull_ctx;
+typedef struct gf_pull_session gf_pull_session;
+GF_API int gf_pull_session_create(gf_pull_session** out, gf_comm* comm, int device);
+GF_API int gf_pull_session_destroy(gf_pull_session* s);
+GF_API int gf_pull_round(gf_pull_session* s, gf_cache* node_cache, gf_cache* edge_cache,
+                         const gf_pull_ctx* ctxs, size_t n, int flag, int* any_flag,
+                         uint64_t* rows_pulled, uint64_t* bytes_sent, uint32_t* d_error_flag,
+                         void* stream);
 
 /* All fetches of one Cache.fetch_feature() call (cache.py:255-413) in one call.
  * kind 0: block of node ids through node_cache (srcdata['h'], cache.py:269-323);
@@ -480,7 +507,6 @@ GF_API int gf_sampler_sample_partitioned_async(gf_sampler* s, const int64_t* d_r
  * gf_comm_create (collective).  gf_comm_all_to_all: bytes_per_peer bytes to / from every rank
  * (equal split, this rank included), ordered on `stream`; gf_comm_all_to_all_v: host arrays of
  * world_size byte counts / byte offsets. */
-typedef struct gf_comm gf_comm;
 GF_API int gf_comm_unique_id(uint8_t out[128]);
 GF_API int gf_comm_create(gf_comm** out, const uint8_t id[128], int world_size, int rank,
                           int device);
