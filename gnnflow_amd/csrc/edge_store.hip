@@ -196,6 +196,12 @@ GraphView EdgeStore::view() const {
   v.ts_pool = ts_pool_.as<float>();
   v.nbr_pool = nbr_pool_.as<EdgePair>();
   v.fence = fence_view_;
+  static const bool shortcut = [] {
+    const char* e = std::getenv("GNNFLOW_SEARCH_LAST_TS");   // tests / A-B runs: 0 = always search
+    return !(e && std::atoi(e) == 0);
+  }();
+  // -1: the newest-edge shortcut is off altogether
+  v.nonneg_ts = !shortcut ? -1 : (negative_ts_.load(std::memory_order_relaxed) ? 0 : 1);
   return v;
 }
 
@@ -500,7 +506,7 @@ void EdgeStore::upload_entries(const std::vector<int64_t>& ids) {
       h_ids[i] = ids[i];
       h_ent[i].start = st.seg_start + st.live_off;
       h_ent[i].size = static_cast<uint32_t>(st.live_size);
-      h_ent[i].reserved = 0;
+      std::memcpy(&h_ent[i].last_ts_bits, &st.last_ts, 4);
     }
   });
   GF_HIP(hipMemcpyAsync(staging_.data(), pinned_.data(), bytes, hipMemcpyHostToDevice, stream_));
@@ -944,10 +950,11 @@ void EdgeStore::add_edges(const int64_t* src, const int64_t* dst, const float* t
         for (size_t k = 0; k < cnt; ++k) dest[gr.begin + k] = base + k;
       st.live_size += cnt;
       st.last_ts = s_ts[gr.end - 1];
+      if (s_ts[gr.begin] < 0.0f) negative_ts_.store(true, std::memory_order_relaxed);
       pub_ids[g] = gr.v;
       pub_ent[g].start = st.seg_start + st.live_off;
       pub_ent[g].size = static_cast<uint32_t>(st.live_size);
-      pub_ent[g].reserved = 0;
+      std::memcpy(&pub_ent[g].last_ts_bits, &st.last_ts, 4);
     }
   });
   GF_REQUIRE(bump_ <= pool_elems_, "add_edges: internal error: pool smaller than planned");

@@ -16,6 +16,7 @@
 // block-granular behaviour.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <algorithm>
 #include <new>
@@ -35,7 +36,10 @@ class IngestSorter;   // ingest_sort.hpp
 struct NodeEntry {   // device node table entry, 16 B
   uint64_t start;    // first live element in the pools
   uint32_t size;     // live edges (chronological, oldest first)
-  uint32_t reserved;
+  // bits of the timestamp of the node's NEWEST edge: a root that looks at the node from later
+  // than that (the common case: queries are about "now") has its window's upper end at `size`
+  // without touching the timestamps — one random access per root instead of two
+  uint32_t last_ts_bits;
 };
 
 // One neighbour record, 32 B and 32-byte aligned: everything the emit kernels need about a
@@ -79,6 +83,8 @@ struct GraphView {
   const float* ts_pool;
   const EdgePair* nbr_pool;
   FenceView fence;   // fence.levels == 0: no fences (GNNFLOW_SEARCH_FENCES=0)
+  int nonneg_ts;     // no negative timestamp was ever ingested: a window that starts at 0 starts
+                     // at the node's first edge (no search for the lower end either)
 };
 
 // Host-only restatement of one reference TemporalBlock header
@@ -265,6 +271,7 @@ class EdgeStore {
   DeviceBuffer fence_;              // every 16^l-th timestamp of ts_pool_ (FenceView)
   FenceView fence_view_{nullptr, {0}, 0};
   bool fences_enabled_ = true;
+  std::atomic<bool> negative_ts_{false};   // an edge with a negative timestamp was ingested
   void rebuild_fences(uint64_t cap, uint64_t live);
   bool pools_ready_ = false;
   DeviceBuffer table_;

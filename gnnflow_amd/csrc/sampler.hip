@@ -182,6 +182,25 @@ __device__ inline uint32_t lower_bound_fenced(const GraphView& g, uint64_t s, ui
   }
 }
 
+// The window [start, end) of one root on its node's segment, with the two shortcuts the node
+// entry allows (edge_store.hpp): `end` later than the node's newest edge -> hi = size; a window
+// that starts at 0 on a graph without negative timestamps -> lo = 0.  Otherwise the searches.
+template <int GROUP>
+__device__ inline void window_bounds(const GraphView& g, const NodeEntry& e, float start, float end,
+                                     int lane, int group_in_wave, uint32_t* lo_out,
+                                     uint32_t* hi_out) {
+  uint32_t hi;
+  if (g.nonneg_ts >= 0 && end > __uint_as_float(e.last_ts_bits)) hi = e.size;
+  else hi = lower_bound_fenced<GROUP>(g, e.start, e.size, end, lane, group_in_wave);
+  uint32_t lo = 0;
+  if (!(g.nonneg_ts > 0 && start <= 0.0f) && hi > 0) {
+    const float first = g.ts_pool[e.start];
+    if (start > first) lo = lower_bound_fenced<GROUP>(g, e.start, hi, start, lane, group_in_wave);
+  }
+  *lo_out = lo;
+  *hi_out = hi;
+}
+
 __device__ inline uint32_t valid_slots(uint32_t n_cand, uint32_t fanout, int uniform) {
   // recent: slot j valid iff j < #candidates (sampling_kernels.cu:88-104);
   // uniform: every slot valid iff there is a candidate (:202, with replacement)
@@ -281,11 +300,8 @@ __global__ __launch_bounds__(kSearchThreads) void sample_search_kernel(
     if (nid >= 0 && static_cast<uint64_t>(nid) < g.table_len) {
       const NodeEntry e = g.table[nid];
       if (e.size > 0) {
-        const float* ts = g.ts_pool + e.start;
-        const float first = ts[0];
-        const uint32_t hi = lower_bound_fenced<GROUP>(g, e.start, e.size, end, lane, group_in_wave);
-        uint32_t lo = 0;
-        if (start > first) lo = lower_bound_fenced<GROUP>(g, e.start, hi, start, lane, group_in_wave);
+        uint32_t lo, hi;
+        window_bounds<GROUP>(g, e, start, end, lane, group_in_wave, &lo, &hi);
         n_cand = hi > lo ? hi - lo : 0;
         end_off = e.start + hi;
       }
@@ -347,8 +363,14 @@ __global__ __launch_bounds__(kSearchThreads) void sample_search_lanes_kernel(
     e.start = 0;
     e.size = 0;
     if (in && nid >= 0 && static_cast<uint64_t>(nid) < g.table_len) e = g.table[nid];
-    const bool big = e.size > kLaneDeg;
-    if (in && !big) {
+    // newest edge older than the window's end and the window open at 0: nothing to read
+    const bool whole = g.nonneg_ts > 0 && start <= 0.0f && e.size > 0 &&
+                       end > __uint_as_float(e.last_ts_bits);
+    const bool big = e.size > kLaneDeg && !whole;
+    if (in && whole) {
+      rec_end[r] = e.start + e.size;
+      rec_cnt[r] = e.size;
+    } else if (in && !big) {
       uint32_t hi = 0, lo = 0;
       if (e.size > 0) {
         const float* ts = g.ts_pool + e.start;
@@ -720,11 +742,8 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
     if (nid >= 0 && static_cast<uint64_t>(nid) < g.table_len) {
       const NodeEntry e = g.table[nid];
       if (e.size > 0) {
-        const float* ts = g.ts_pool + e.start;
-        const float first = ts[0];
-        const uint32_t hi = lower_bound_fenced<GROUP>(g, e.start, e.size, end, lane, group_in_wave);
-        uint32_t lo = 0;
-        if (start > first) lo = lower_bound_fenced<GROUP>(g, e.start, hi, start, lane, group_in_wave);
+        uint32_t lo, hi;
+        window_bounds<GROUP>(g, e, start, end, lane, group_in_wave, &lo, &hi);
         n_cand = hi > lo ? hi - lo : 0;
         end_off = e.start + hi;
       }

@@ -176,6 +176,49 @@ def test_sample_layer_result_object_and_debug_sample():
         assert r.num_dst_nodes() == q.num_dst_nodes()
 
 
+@pytest.mark.parametrize("R", [3000, 70000, (1 << 20) + 77])
+def test_negative_timestamps_and_roots_around_the_newest_edge(R):
+    """The node entry carries its newest edge's timestamp: a root later than that takes the whole
+    segment without a search, and a window open at 0 starts at the first edge — but only on a
+    graph without negative timestamps.  Here half of the timestamps ARE negative, roots sit
+    before, at and after every node's newest edge, with and without a window — small layers,
+    large ones (fences) and the lane-per-root pass — bit-exact against the oracle."""
+    import gnnflow_amd
+    from oracle import oracle as O
+    N, E = 3000, 60000
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=31, tie_levels=700)
+    ts = (ts - np.float32(500.0)).astype(np.float32)        # [-500, 500)
+    # the reference's fresh block starts with end_timestamp = 0 and CHECKs it against a batch's
+    # newest edge (temporal_block init; utils.cu:42-43), so every vertex's FIRST batch must end
+    # at t >= 0: one batch, and one closing edge per vertex at t = 499.5
+    src = np.concatenate([src, np.arange(N, dtype=np.int64)])
+    dst = np.concatenate([dst, (np.arange(N, dtype=np.int64) + 1) % N])
+    ts = np.concatenate([ts, np.full(N, 499.5, np.float32)])
+    eid = np.arange(E + N, dtype=np.int64)
+    E = E + N
+    g, o = _graphs(min_block=8)
+    g.add_edges(src, dst, ts, eid)
+    o.add_edges(src, dst, ts, eid)
+    rng = np.random.RandomState(R % 1000)
+    nodes = rng.randint(0, N, R).astype(np.int64)
+    # a third of the roots exactly at an edge time of their node (ties with the newest edge
+    # included), a third later than everything, the rest anywhere, some before the first edge
+    t = rng.uniform(-600.0, 600.0, R).astype(np.float32)
+    pick = rng.randint(0, E, R)
+    at_edge = rng.rand(R) < 0.33
+    nodes[at_edge] = src[pick[at_edge]]
+    t[at_edge] = ts[pick[at_edge]]
+    t[rng.rand(R) < 0.33] = np.float32(1e6)
+    for cfg in (dict(fanouts=[5, 2], sample_strategy="recent"),
+                dict(fanouts=[4], sample_strategy="recent", snapshot_time_window=90.0),
+                dict(fanouts=[3], sample_strategy="uniform", num_snapshots=2,
+                     snapshot_time_window=250.0, seed=8)):
+        hs = gnnflow_amd.TemporalSampler(g, **cfg)
+        os_ = O.OracleSampler(o, **cfg)
+        os_.threads = 8
+        _cmp_blocks(hs.sample(nodes, t), os_.sample(nodes, t), "neg ts R={} {}".format(R, cfg))
+
+
 @pytest.mark.parametrize("strategy", ["recent", "uniform"])
 def test_large_batch_parallel_scan_path(strategy):
     """Layers with more than 65 536 roots take the tiled 3-phase scan instead of the
