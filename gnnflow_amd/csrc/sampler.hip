@@ -692,27 +692,47 @@ __device__ inline int64_t pack_f32_pair(float lo, float hi) {
 // Search + select in ONE launch: with `fanout` fixed slots per root there is no compaction,
 // hence no prefix sum between the two.  Same window / candidate / selection rules as
 // sample_search_kernel + sample_emit_kernel; the Philox counter is the slot index.
+struct PaddedCommon {
+  uint32_t snapshot_idx, num_snapshots;
+  float window;
+  uint32_t fanout;
+  int uniform, prop_time;
+  uint64_t seed;
+};
+struct PaddedJob {
+  const int64_t* req;
+  uint64_t n;
+  uint64_t call;             // Philox call counter of this job
+  int64_t* out;
+  const uint64_t* d_own;
+  const uint64_t* d_total;
+  uint64_t total_host;
+  const uint32_t* root_of;
+  uint32_t* rec_cnt;
+  uint32_t stride, world;
+  uint32_t* d_overflow;
+};
+
+// d_own != null: "this rank's own share" of a chained partitioned layer — the last *d_own
+// of the layer's R request rows (R = *d_total, or total_host), counts still on the device.
+// root_of / rec_cnt (own share only): the number of valid slots of every row goes straight
+// to its root's counter, so the merge does not have to read the rows back to count them.
+// stride != 0: the slotted layout (partition.hip).  Own share: it starts at row
+// world * stride.  Otherwise `req` is the INBOX of an equal-split exchange — `world` slots of
+// `stride` rows, row 0 of a slot its header {rows that follow, flags} — and only the rows
+// a header announces are served (reply row = request row); a sender's overflow flag is
+// folded into this rank's word, so every rank learns of it in the same exchange.
 template <int GROUP>
-__global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
-    GraphView g, const int64_t* __restrict__ req, uint64_t n, uint32_t snapshot_idx,
-    uint32_t num_snapshots, float window, uint32_t fanout, int uniform, int prop_time,
-    uint64_t seed, uint64_t call, int64_t* __restrict__ out,
-    const uint64_t* __restrict__ d_own, const uint64_t* __restrict__ d_total,
-    uint64_t total_host, const uint32_t* __restrict__ root_of, uint32_t* __restrict__ rec_cnt,
-    uint32_t stride, uint32_t world, uint32_t* __restrict__ d_overflow) {
-  // d_own != null: "this rank's own share" of a chained partitioned layer — the last *d_own
-  // of the layer's R request rows (R = *d_total, or total_host), counts still on the device.
-  // root_of / rec_cnt (own share only): the number of valid slots of every row goes straight
-  // to its root's counter, so the merge does not have to read the rows back to count them.
-  // stride != 0: the slotted layout (partition.hip).  Own share: it starts at row
-  // world * stride.  Otherwise `req` is the INBOX of an equal-split exchange — `world` slots of
-  // `stride` rows, row 0 of a slot its header {rows that follow, flags} — and only the rows
-  // a header announces are served (reply row = request row); a sender's overflow flag is
-  // folded into this rank's word, so every rank learns of it in the same exchange.
-  if (d_own) {
-    n = *d_own;
-    const uint64_t skip = stride ? static_cast<uint64_t>(world) * stride
-                                 : (d_total ? *d_total : total_host) - n;
+__device__ inline void padded_job(const GraphView& g, const PaddedCommon& c, PaddedJob j) {
+  const int64_t* __restrict__ req = j.req;
+  int64_t* __restrict__ out = j.out;
+  const uint32_t* __restrict__ root_of = j.root_of;
+  uint64_t n = j.n;
+  const uint32_t fanout = c.fanout, stride = j.stride;
+  if (j.d_own) {
+    n = *j.d_own;
+    const uint64_t skip = stride ? static_cast<uint64_t>(j.world) * stride
+                                 : (j.d_total ? *j.d_total : j.total_host) - n;
     req += 2 * skip;
     out += skip * fanout * 3;
     if (root_of) root_of += skip;
@@ -722,21 +742,21 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
   const int group_in_wave = (threadIdx.x % 64) / GROUP;
   const uint64_t group = static_cast<uint64_t>(blockIdx.x) * kGroupsPerBlock + threadIdx.x / GROUP;
   const uint64_t num_groups = static_cast<uint64_t>(gridDim.x) * kGroupsPerBlock;
-  const bool inbox = stride && !d_own;
+  const bool inbox = stride && !j.d_own;
   for (uint64_t r = group; r < n; r += num_groups) {
     if (inbox) {
-      const uint64_t q = r / stride, j = r - q * stride;
-      if (j == 0) {
-        if (lane == 0 && (req[2 * r + 1] & 1)) *d_overflow = 1;
+      const uint64_t q = r / stride, jj = r - q * stride;
+      if (jj == 0) {
+        if (lane == 0 && (req[2 * r + 1] & 1)) *j.d_overflow = 1;
         continue;
       }
       const uint64_t rows = static_cast<uint64_t>(req[2 * q * stride]);
-      if (j - 1 >= min(rows, static_cast<uint64_t>(stride - 1))) continue;
+      if (jj - 1 >= min(rows, static_cast<uint64_t>(stride - 1))) continue;
     }
     const int64_t nid = req[2 * r];
     const float t = __uint_as_float(static_cast<uint32_t>(static_cast<uint64_t>(req[2 * r + 1])));
     float start, end;
-    time_window(t, snapshot_idx, num_snapshots, window, &start, &end);
+    time_window(t, c.snapshot_idx, c.num_snapshots, c.window, &start, &end);
     uint64_t end_off = 0;
     uint32_t n_cand = 0;
     if (nid >= 0 && static_cast<uint64_t>(nid) < g.table_len) {
@@ -748,19 +768,19 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
         end_off = e.start + hi;
       }
     }
-    const uint32_t valid = valid_slots(n_cand, fanout, uniform);
-    if (rec_cnt && lane == 0) rec_cnt[root_of[r]] = valid;
-    for (uint32_t j = lane; j < fanout; j += GROUP) {
-      const uint64_t slot = r * fanout + j;
+    const uint32_t valid = valid_slots(n_cand, fanout, c.uniform);
+    if (j.rec_cnt && lane == 0) j.rec_cnt[root_of[r]] = valid;
+    for (uint32_t k = lane; k < fanout; k += GROUP) {
+      const uint64_t slot = r * fanout + k;
       int64_t* o = out + slot * 3;
-      if (j < valid) {
-        const uint32_t pick = uniform ? gf_philox4x32_10_first(seed, slot, call) % n_cand : j;
+      if (k < valid) {
+        const uint32_t pick = c.uniform ? gf_philox4x32_10_first(c.seed, slot, j.call) % n_cand : k;
         const uint64_t e = end_off - 1 - pick;
         const EdgePair nb = g.nbr_pool[e];
         const float ets = nb.ts;
         o[0] = nb.dst;
         o[1] = nb.eid;
-        o[2] = pack_f32_pair(prop_time ? t : ets, t - ets);
+        o[2] = pack_f32_pair(c.prop_time ? t : ets, t - ets);
       } else {
         o[0] = -1;
         o[1] = -1;
@@ -768,6 +788,28 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
       }
     }
   }
+}
+
+template <int GROUP>
+__global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
+    GraphView g, const int64_t* __restrict__ req, uint64_t n, uint32_t snapshot_idx,
+    uint32_t num_snapshots, float window, uint32_t fanout, int uniform, int prop_time,
+    uint64_t seed, uint64_t call, int64_t* __restrict__ out,
+    const uint64_t* __restrict__ d_own, const uint64_t* __restrict__ d_total,
+    uint64_t total_host, const uint32_t* __restrict__ root_of, uint32_t* __restrict__ rec_cnt,
+    uint32_t stride, uint32_t world, uint32_t* __restrict__ d_overflow) {
+  const PaddedCommon c{snapshot_idx, num_snapshots, window, fanout, uniform, prop_time, seed};
+  padded_job<GROUP>(g, c, PaddedJob{req, n, call, out, d_own, d_total, total_host, root_of, rec_cnt,
+                                    stride, world, d_overflow});
+}
+
+// Two jobs in one launch (blockIdx.y): the requests this rank received AND its own share —
+// one launch and one kernel boundary less per layer when the exchange runs in the sampling
+// stream (nothing to overlap the own share with).
+template <int GROUP>
+__global__ __launch_bounds__(kSearchThreads) void sample_padded_pair_kernel(
+    GraphView g, PaddedCommon c, PaddedJob a, PaddedJob b) {
+  padded_job<GROUP>(g, c, blockIdx.y == 0 ? a : b);
 }
 
 // valid slots of root i's reply row (a prefix of the row for both policies)
@@ -1013,6 +1055,17 @@ void launch_padded(int width, unsigned grid, hipStream_t stream, Args... args) {
     case 4: sample_padded_kernel<4><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
     case 8: sample_padded_kernel<8><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
     default: sample_padded_kernel<16><<<dim3(grid), dim3(kSearchThreads), 0, stream>>>(args...); break;
+  }
+}
+
+void launch_padded_pair(int width, unsigned grid, hipStream_t stream, const GraphView& g,
+                        const PaddedCommon& c, const PaddedJob& a, const PaddedJob& b) {
+  const dim3 gr(grid, 2), bl(kSearchThreads);
+  switch (width) {
+    case 2: sample_padded_pair_kernel<2><<<gr, bl, 0, stream>>>(g, c, a, b); break;
+    case 4: sample_padded_pair_kernel<4><<<gr, bl, 0, stream>>>(g, c, a, b); break;
+    case 8: sample_padded_pair_kernel<8><<<gr, bl, 0, stream>>>(g, c, a, b); break;
+    default: sample_padded_pair_kernel<16><<<gr, bl, 0, stream>>>(g, c, a, b); break;
   }
 }
 
@@ -1680,7 +1733,8 @@ void Sampler::part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_
 // Slotted form: serves the request inbox (what the equal-split exchange delivered: one slot per
 // rank) from this rank's shard into `served`, reply row = request row; the caller sends
 // `served` back slot for slot into the prefix of the reply buffer.
-void Sampler::part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes) {
+void Sampler::part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes,
+                         bool with_own) {
   GF_REQUIRE(part_.active, "part_serve: no partitioned sample is being built");
   GF_REQUIRE(layer < fanouts_.size() && snapshot < num_snapshots_, "part_serve: out of range");
   gf_part_layout lay;
@@ -1695,6 +1749,32 @@ void Sampler::part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
   const uint32_t stride = static_cast<uint32_t>(lay.slot_stride);
   const uint64_t n = static_cast<uint64_t>(part_.world) * stride;
   GF_REQUIRE(n * F < 0xFFFFFFFFull, "sampler: more than 2^32-1 slots in one layer");
+  if (with_own) {
+    // the received requests and this rank's own share in ONE launch (part_plan_own phase 2 is
+    // then not called for this layer)
+    const int64_t* roots; const float* ts; const uint64_t* d_R; uint64_t R_host;
+    part_roots(layer, snapshot, &roots, &ts, &d_R, &R_host);
+    const size_t n_bound = layer == 0 ? part_.R : lay.root_bound;
+    const uint64_t call_own = calls_++;
+    const size_t n_max = std::max<size_t>(n, n_bound);
+    const int width = n_max > kSmallRoots ? large_group_ : search_group_;
+    const unsigned grid = capped_grid(n_max, kSearchThreads / width, 256 * 8);
+    uint64_t* d_counts = reinterpret_cast<uint64_t*>(w + lay.counts);
+    const PaddedCommon pc{snapshot, num_snapshots_, window_, F,
+                          policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0, prop_time_ ? 1 : 0, seed_};
+    const PaddedJob serve{reinterpret_cast<const int64_t*>(w + lay.inbox), n, call,
+                          reinterpret_cast<int64_t*>(w + lay.served), nullptr, nullptr, 0, nullptr,
+                          nullptr, stride, static_cast<uint32_t>(part_.world), part_overflow()};
+    const PaddedJob own{reinterpret_cast<const int64_t*>(w + lay.requests), 0, call_own,
+                        reinterpret_cast<int64_t*>(w + lay.replies), d_counts + part_.rank, d_R,
+                        R_host, part_root_of(),
+                        part_own_counts(n_bound) ? part_rec_cnt() : nullptr, stride,
+                        static_cast<uint32_t>(part_.world), nullptr};
+    ProfileScope ps(kProfSearch, stream);
+    launch_padded_pair(width, grid, stream, view_for(graph_, n_max), pc, serve, own);
+    GF_HIP(hipGetLastError());
+    return;
+  }
   const int width = n > kSmallRoots ? large_group_ : search_group_;
   const unsigned grid = capped_grid(n, kSearchThreads / width, 256 * 8);
   ProfileScope ps(kProfSearch, stream);
@@ -1870,9 +1950,8 @@ void Sampler::sample_partitioned_slotted(const int64_t* d_roots, const float* d_
           ex.join(stream);
         } else {
           ex.all_to_all(b + lay.requests, b + lay.inbox, slot_rows * 16, stream);
-          part_plan_own(li, si, b, lay.total, 2);
         }
-        part_serve(li, si, b, lay.total);
+        part_serve(li, si, b, lay.total, /*with_own=*/!overlap);
         if (overlap) {   // one communicator, one stream: the reply exchange goes there too
           ex.all_to_all_forked(b + lay.served, b + lay.replies, slot_rows * F * 24, stream);
           ex.join(stream);

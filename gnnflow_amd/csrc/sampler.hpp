@@ -61,7 +61,10 @@ class Sampler {
   void part_begin(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                   size_t out_bytes, int world_size, int rank, double slack, size_t slot_roots,
                   hipStream_t stream);
-  void part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes);
+  // with_own: also sample this rank's own share in the same launch (instead of part_plan_own
+  // phase 2)
+  void part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes,
+                  bool with_own = false);
   // slotted form: did a slot overflow anywhere in the sample sample_end() returned last
   bool last_overflow() const { return last_overflow_; }
   // phases: 1 = bucket the roots, 2 = sample this rank's own share, 3 = both
