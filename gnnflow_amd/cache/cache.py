@@ -497,8 +497,10 @@ class Cache:
             structural = (self._policy == "lru" and self.prefix_alias and n_edge > 1
                           and all(len(mfg) == 1 for mfg in mfgs))
             chain = structural and all(
-                getattr(edge_blocks[j], "_edge_prefix_of", None) is edge_blocks[j - 1]
-                and edge_blocks[j].num_edges() <= edge_blocks[j - 1].num_edges() <= self.edge_capacity
+                edge_blocks[j].num_edges() == 0      # (a rank without roots: nothing to serve)
+                or (getattr(edge_blocks[j], "_edge_prefix_of", None) is edge_blocks[j - 1]
+                    and edge_blocks[j].num_edges() <= edge_blocks[j - 1].num_edges()
+                    <= self.edge_capacity)
                 for j in range(1, n_edge))
             n_alias, ei, rnd = 0, 0, 0
             while rnd < n_node or ei < n_edge or (rnd == 0 and target is not None):
