@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -20,8 +21,12 @@ struct gf_graph { gf::EdgeStore impl; template <typename... A> explicit gf_graph
 struct gf_sampler { gf::Sampler impl; std::deque<uint64_t> begin_tickets; /* 0 = begun synchronously */ template <typename... A> explicit gf_sampler(A&&... a) : impl(std::forward<A>(a)...) {} };
 struct gf_cache { gf::FeatureCache impl; template <typename... A> explicit gf_cache(A&&... a) : impl(std::forward<A>(a)...) {} };
 struct gf_comm {
-  gf::RcclComm impl;
-  gf_comm(const uint8_t* id, int world, int rank, int device) : impl(id, world, rank, device) {}
+  std::unique_ptr<gf::Exchange> owned;
+  gf::Exchange& impl;
+  gf::IpcExchange* ipc = nullptr;
+  gf_comm(const uint8_t* id, int world, int rank, int device)
+      : owned(new gf::RcclComm(id, world, rank, device)), impl(*owned) {}
+  gf_comm(gf::IpcExchange* x) : owned(x), impl(*owned), ipc(x) {}
 };
 struct gf_pull_session {
   gf::PullSession impl;
@@ -820,6 +825,25 @@ int gf_comm_create(gf_comm** out, const uint8_t* id, int world_size, int rank, i
 int gf_comm_destroy(gf_comm* c) {
   return guarded([&] { delete c; });
 }
+int gf_ipc_comm_create(gf_comm** out, int world_size, int rank, int device, size_t mailbox_bytes,
+                       const char* shm_name) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_ipc_comm_create: null output");
+    *out = new gf_comm(new gf::IpcExchange(world_size, rank, device, mailbox_bytes, shm_name));
+  });
+}
+int gf_ipc_comm_handle(gf_comm* c, uint8_t* out) {
+  return guarded([&] {
+    GF_REQUIRE(c != nullptr && c->ipc != nullptr && out != nullptr, "not an IPC communicator");
+    c->ipc->handle(out);
+  });
+}
+int gf_ipc_comm_open(gf_comm* c, const uint8_t* handles) {
+  return guarded([&] {
+    GF_REQUIRE(c != nullptr && c->ipc != nullptr, "not an IPC communicator");
+    c->ipc->open_peers(handles);
+  });
+}
 int gf_comm_all_to_all(gf_comm* c, const void* d_send, void* d_recv, size_t bytes_per_peer,
                        void* stream) {
   return guarded([&] {
@@ -860,7 +884,7 @@ int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c, const in
     GF_REQUIRE(s->begin_tickets.size() < gf::Sampler::kMaxInFlight,
                "sample_partitioned_comm_async: too many samples in flight on this sampler");
     gf::Sampler* impl = &s->impl;
-    gf::RcclComm* comm = &c->impl;
+    gf::Exchange* comm = &c->impl;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool ov = overlap != 0;
     s->begin_tickets.push_back(gf::EnqueueWorker::get(1).submit(

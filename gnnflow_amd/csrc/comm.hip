@@ -7,6 +7,13 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -151,6 +158,123 @@ void RcclComm::all_to_all_v(const void* send, const size_t* send_bytes, const si
     throw;
   }
   GF_RCCL(a.GroupEnd());
+}
+
+// ---- IpcExchange ---------------------------------------------------------------------------
+struct IpcExchange::Shared {
+  std::atomic<uint32_t> arrived;
+  std::atomic<uint32_t> sense;
+  uint32_t pad[14];
+  // per (sender, receiver): where the receiver's chunk sits in the sender's mailbox
+  struct Slot { uint64_t off, bytes; } slot[64][64];
+};
+
+static_assert(sizeof(hipIpcMemHandle_t) == IpcExchange::kHandleBytes, "hipIpcMemHandle_t is 64 bytes");
+
+IpcExchange::IpcExchange(int world, int rank, int device, size_t box_bytes, const char* shm_name)
+    : world_(world), rank_(rank), device_(device), box_bytes_(box_bytes), shm_name_(shm_name) {
+  GF_REQUIRE(world >= 1 && world <= 64 && rank >= 0 && rank < world, "ipc comm: bad rank / world");
+  GF_REQUIRE(box_bytes >= 4096 && shm_name && shm_name[0] == '/', "ipc comm: bad mailbox / name");
+  DeviceGuard dg(device);
+  shm_bytes_ = sizeof(Shared);
+  const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+  GF_REQUIRE(fd >= 0, "ipc comm: shm_open failed");
+  if (ftruncate(fd, static_cast<off_t>(shm_bytes_)) != 0) {
+    close(fd);
+    throw Error(GF_ERR_IO, "ipc comm: ftruncate failed");
+  }
+  void* p = mmap(nullptr, shm_bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  GF_REQUIRE(p != MAP_FAILED, "ipc comm: mmap failed");
+  shm_ = static_cast<Shared*>(p);   // a fresh object is zero-filled: counters start at 0
+  GF_HIP(hipMalloc(reinterpret_cast<void**>(&box_), box_bytes_));
+  peer_box_.assign(world, nullptr);
+  peer_box_[rank] = box_;
+}
+
+IpcExchange::~IpcExchange() {
+  for (int q = 0; q < world_; ++q)
+    if (q != rank_ && peer_box_[q]) (void)hipIpcCloseMemHandle(peer_box_[q]);
+  if (box_) (void)hipFree(box_);
+  if (shm_) munmap(shm_, shm_bytes_);
+  if (rank_ == 0) shm_unlink(shm_name_.c_str());
+}
+
+void IpcExchange::handle(uint8_t out[kHandleBytes]) const {
+  hipIpcMemHandle_t h;
+  GF_HIP(hipIpcGetMemHandle(&h, box_));
+  std::memcpy(out, &h, kHandleBytes);
+}
+
+void IpcExchange::open_peers(const uint8_t* handles) {
+  GF_REQUIRE(handles != nullptr, "ipc comm: null handles");
+  DeviceGuard dg(device_);
+  for (int q = 0; q < world_; ++q) {
+    if (q == rank_) continue;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles + static_cast<size_t>(q) * kHandleBytes, kHandleBytes);
+    void* p = nullptr;
+    GF_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    peer_box_[q] = static_cast<char*>(p);
+  }
+  barrier();
+}
+
+// sense-reversing barrier over the shared counters; a peer that never arrives (it died) ends
+// the wait after 30 s with an error instead of a hang
+void IpcExchange::barrier() {
+  if (world_ == 1) return;
+  const uint32_t my = sense_ ^= 1u;
+  if (shm_->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == static_cast<uint32_t>(world_)) {
+    shm_->arrived.store(0, std::memory_order_relaxed);
+    shm_->sense.store(my, std::memory_order_release);
+    return;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spin = 0; shm_->sense.load(std::memory_order_acquire) != my; ++spin) {
+    if ((spin & 255) == 255) {
+      sched_yield();
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+        throw Error(GF_ERR_HIP, "ipc comm: a rank did not reach the barrier within 30 s");
+    }
+  }
+}
+
+void IpcExchange::all_to_all(const void* send, void* recv, size_t bytes_per_peer,
+                             hipStream_t stream) {
+  std::vector<size_t> b(world_, bytes_per_peer), o(world_);
+  for (int q = 0; q < world_; ++q) o[q] = static_cast<size_t>(q) * bytes_per_peer;
+  all_to_all_v(send, b.data(), o.data(), recv, b.data(), o.data(), stream);
+}
+
+void IpcExchange::all_to_all_v(const void* send, const size_t* send_bytes, const size_t* send_off,
+                               void* recv, const size_t* recv_bytes, const size_t* recv_off,
+                               hipStream_t stream) {
+  GF_REQUIRE(send_bytes && send_off && recv_bytes && recv_off, "all_to_all_v: null split arrays");
+  DeviceGuard dg(device_);
+  // 1. pack this rank's chunks into its mailbox and say where each peer's chunk is
+  size_t at = 0;
+  for (int q = 0; q < world_; ++q) {
+    GF_REQUIRE(at + send_bytes[q] <= box_bytes_, "ipc comm: message larger than the mailbox");
+    shm_->slot[rank_][q].off = at;
+    shm_->slot[rank_][q].bytes = send_bytes[q];
+    if (send_bytes[q])
+      GF_HIP(hipMemcpyAsync(box_ + at, static_cast<const char*>(send) + send_off[q], send_bytes[q],
+                            hipMemcpyDeviceToDevice, stream));
+    at += (send_bytes[q] + 255) & ~size_t{255};
+  }
+  GF_HIP(hipStreamSynchronize(stream));
+  barrier();   // every mailbox is complete
+  // 2. fetch this rank's chunk from every peer's mailbox
+  for (int q = 0; q < world_; ++q) {
+    const Shared::Slot s = shm_->slot[q][rank_];
+    GF_REQUIRE(s.bytes == recv_bytes[q], "ipc comm: send / receive sizes disagree");
+    if (s.bytes)
+      GF_HIP(hipMemcpyAsync(static_cast<char*>(recv) + recv_off[q], peer_box_[q] + s.off, s.bytes,
+                            hipMemcpyDeviceToDevice, stream));
+  }
+  GF_HIP(hipStreamSynchronize(stream));
+  barrier();   // the mailboxes may be overwritten again
 }
 
 }  // namespace gf

@@ -8,6 +8,8 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <string>
+#include <vector>
 
 #include "common.hpp"
 
@@ -55,6 +57,43 @@ class RcclComm : public Exchange {
   int world_, rank_, device_;
   hipStream_t side_ = nullptr;
   hipEvent_t fork_ = nullptr, done_ = nullptr;
+};
+
+// The same exchanges between processes that can map each other's device memory (hipIpc*): the
+// ranks of one node — including several ranks SHARING one GPU, where RCCL refuses to run — so
+// that the native multi-rank chains run for real on a one-GPU box.  Host-synchronising: every
+// exchange is copy-out, process barrier (POSIX shared memory), copy-in from the peers'
+// mailboxes, barrier.  A test / single-box transport, not a fast path.
+class IpcExchange : public Exchange {
+ public:
+  static constexpr size_t kHandleBytes = 64;   // sizeof(hipIpcMemHandle_t)
+  // shm_name: the name of a POSIX shared-memory object all ranks use (created by whoever comes
+  // first); box_bytes: capacity of this rank's mailbox = the largest message it sends
+  IpcExchange(int world, int rank, int device, size_t box_bytes, const char* shm_name);
+  ~IpcExchange() override;
+  void handle(uint8_t out[kHandleBytes]) const;          // this rank's mailbox, to publish
+  void open_peers(const uint8_t* handles);               // [world][kHandleBytes], then a barrier
+  int world() const override { return world_; }
+  int rank() const override { return rank_; }
+  void all_to_all(const void* send, void* recv, size_t bytes_per_peer,
+                  hipStream_t stream) override;
+  void all_to_all_forked(const void* send, void* recv, size_t bytes_per_peer,
+                         hipStream_t after) override { all_to_all(send, recv, bytes_per_peer, after); }
+  void join(hipStream_t) override {}
+  void all_to_all_v(const void* send, const size_t* send_bytes, const size_t* send_off, void* recv,
+                    const size_t* recv_bytes, const size_t* recv_off, hipStream_t stream) override;
+
+ private:
+  struct Shared;
+  void barrier();
+  int world_, rank_, device_;
+  size_t box_bytes_;
+  char* box_ = nullptr;               // this rank's mailbox (device)
+  std::vector<char*> peer_box_;       // the peers' mailboxes as mapped here
+  Shared* shm_ = nullptr;
+  size_t shm_bytes_ = 0;
+  std::string shm_name_;
+  uint32_t sense_ = 0;
 };
 
 }  // namespace gf

@@ -2704,9 +2704,10 @@ void PullSession::round(FeatureCache* node, FeatureCache* edge, const gf_pull_ct
         sb[q] = s_rows * row_bytes; so[q] = a; a += sb[q];
         rb[q] = r_rows * row_bytes; ro[q] = b; b += rb[q];
       }
-      if (a == 0 && b == 0) return;
+      // every rank makes every call, whatever its own sizes are: a transport may synchronise
+      // the ranks inside it
       if (ex_) ex_->all_to_all_v(send, sb.data(), so.data(), recv, rb.data(), ro.data(), st);
-      else GF_HIP(hipMemcpyAsync(recv, send, a, hipMemcpyDeviceToDevice, st));
+      else if (a) GF_HIP(hipMemcpyAsync(recv, send, a, hipMemcpyDeviceToDevice, st));
     };
     // 4. ids out, served by their owners, rows back
     exchange(send_ids_[k].data(), got_[k].data(), 8, false);

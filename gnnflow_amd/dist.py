@@ -295,18 +295,46 @@ def _exchange(out: torch.Tensor, send: torch.Tensor, out_splits, in_splits, grou
 
 
 class NativeComm:
-    """The library's own RCCL communicator over the ranks of a torch process group
-    (include/gnnflow_hip.h gf_comm_*): rank 0 draws the unique id, torch.distributed carries
-    its 128 bytes to the other ranks — control plane only — and every rank joins.  The data
-    path then never goes through torch.distributed: an all-to-all costs a native call."""
+    """The library's own communicator over the ranks of a torch process group
+    (include/gnnflow_hip.h gf_comm_* / gf_ipc_comm_*); torch.distributed only carries the
+    bootstrap (control plane), never the data path.
+      transport "rccl": RCCL — rank 0 draws the unique id, its 128 bytes are broadcast, every
+                        rank joins; an all-to-all then costs a native call;
+      transport "ipc":  hipIpc mailboxes + a process barrier in POSIX shared memory, for ranks
+                        of one node that RCCL cannot serve — several ranks SHARING one GPU (the
+                        one-GPU test box): host-synchronising, a test / single-box transport."""
 
-    def __init__(self, device, group=None):
+    _counter = 0
+
+    def __init__(self, device, group=None, transport="rccl", mailbox_bytes=64 << 20):
         import ctypes as C
+        import os
         from . import _capi
         self._lib = _capi.load()
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.transport = transport
         device = torch.device(device)
+        self.h = C.c_void_p()
+        if transport == "ipc":
+            NativeComm._counter += 1
+            name = ["/gnnflow_ipc_{}_{}".format(os.getpid(), NativeComm._counter)]
+            if self.P > 1:
+                src = dist.get_global_rank(group, 0) if group is not None else 0
+                dist.broadcast_object_list(name, src=src, group=group)
+            _capi.check(self._lib.gf_ipc_comm_create(C.byref(self.h), self.P, self.rank,
+                                                     device.index or 0, int(mailbox_bytes),
+                                                     name[0].encode()))
+            mine = (C.c_uint8 * 64)()
+            _capi.check(self._lib.gf_ipc_comm_handle(self.h, mine))
+            handles = [None] * self.P
+            if self.P > 1:
+                dist.all_gather_object(handles, bytes(mine), group=group)
+            else:
+                handles = [bytes(mine)]
+            blob = (C.c_uint8 * (64 * self.P))(*b"".join(handles))
+            _capi.check(self._lib.gf_ipc_comm_open(self.h, blob))
+            return
         idb = (C.c_uint8 * 128)()
         if self.rank == 0:
             _capi.check(self._lib.gf_comm_unique_id(idb))
@@ -318,7 +346,6 @@ class NativeComm:
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast(t, src=src, group=group)
             idb = (C.c_uint8 * 128)(*t.cpu().tolist())
-        self.h = C.c_void_p()
         _capi.check(self._lib.gf_comm_create(C.byref(self.h), idb, self.P, self.rank,
                                              device.index or 0))
 
@@ -331,16 +358,26 @@ class NativeComm:
         self.close()
 
     @staticmethod
-    def usable(group=None) -> bool:
-        """RCCL needs one GPU per rank: over a host-only backend (gloo: CPU tests, several
-        ranks sharing one card) the exchange is staged through torch.distributed instead."""
+    def choose(group=None):
+        """Which transport carries the exchanges: "rccl" when the process group runs over RCCL
+        (one GPU per rank), else None = staged through torch.distributed (gloo: CPU tests,
+        several ranks sharing one card) unless GNNFLOW_PART_TRANSPORT says "ipc" (the library's
+        hipIpc transport: the native chains with several ranks on one GPU) or "torch"."""
         import os
         mode = os.environ.get("GNNFLOW_PART_TRANSPORT", "auto").lower()
         if mode == "torch":
-            return False
+            return None
+        if mode in ("ipc", "rccl"):
+            return mode
         if mode == "native":
-            return True
-        return not dist.is_initialized() or not _backend_is_host_only(group)
+            return "rccl"
+        if not dist.is_initialized() or not _backend_is_host_only(group):
+            return "rccl"
+        return None
+
+    @staticmethod
+    def usable(group=None) -> bool:
+        return NativeComm.choose(group) is not None
 
 
 class _PartitionedPending:
@@ -573,11 +610,17 @@ class DevicePartitionedSampler:
         R0 = max(R, 1)
         if not self._slot_roots:
             self._slot_roots = self._agree_on_slot_roots(R0)
+        lays, offs, ws_bytes = self._plan(R0, self._slack)
         if not self._comm_tried:
             self._comm_tried = True
-            if NativeComm.usable(group):
-                self._comm = NativeComm(self._device, group)
-        lays, offs, ws_bytes = self._plan(R0, self._slack)
+            kind = NativeComm.choose(group)
+            if kind is not None:
+                # ipc: the mailbox holds the largest message — a layer's reply slots for a batch
+                # of slot_roots roots (same on every rank)
+                ref = self._plan(max(self._slot_roots, 1), self._slack)[0]
+                box = max([1 << 16] + [P * lay.slot_stride * (24 * f + 16) + 512 * P
+                                       for lay, f in zip(ref, self._fanouts)])
+                self._comm = NativeComm(self._device, group, kind, mailbox_bytes=box)
         slab, out_ptr, nbytes = self._output(R, stream)
         ws, wi = self._workspace(ws_bytes, stream)
         if self._comm is not None:
@@ -844,9 +887,11 @@ class ShardedFeatures:
         the CPU tests and when several ranks share one card)."""
         if not self._comm_tried:
             self._comm_tried = True
-            if self.device.type == "cuda" and dist.is_initialized() and \
-                    NativeComm.usable(self.group):
-                self._comm = NativeComm(self.device, self.group)
+            kind = NativeComm.choose(self.group)
+            if self.device.type == "cuda" and dist.is_initialized() and kind is not None:
+                import os
+                mb = int(os.environ.get("GNNFLOW_IPC_MAILBOX_MB", "256"))
+                self._comm = NativeComm(self.device, self.group, kind, mailbox_bytes=mb << 20)
         return self._comm
 
     def exchange_counts(self, counts: torch.Tensor) -> torch.Tensor:
@@ -890,8 +935,7 @@ class ShardedFeatures:
                 for p in range(P):
                     sb.append(sc[k][p] * row); so.append(a); a += sc[k][p] * row
                     rb.append(rc[k][p] * row); ro.append(b); b += rc[k][p] * row
-                if a == 0 and b == 0:
-                    continue
+                # every rank makes every call (the ipc transport synchronises the ranks inside)
                 _capi.check(comm._lib.gf_comm_all_to_all_v(
                     comm.h, send[k].data_ptr() if a else recv[k].data_ptr(), arr(*sb), arr(*so),
                     recv[k].data_ptr() if b else send[k].data_ptr(), arr(*rb), arr(*ro), st))

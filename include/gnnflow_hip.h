@@ -516,6 +516,18 @@ GF_API int gf_comm_all_to_all(gf_comm* c, const void* d_send, void* d_recv, size
 GF_API int gf_comm_all_to_all_v(gf_comm* c, const void* d_send, const size_t* send_bytes,
                                 const size_t* send_offsets, void* d_recv, const size_t* recv_bytes,
                                 const size_t* recv_offsets, void* stream);
+/* The same exchanges between processes that map each other's device memory (hipIpc*) — the ranks
+ * of one node, several ranks SHARING one GPU included (where RCCL refuses to run): a
+ * host-synchronising test / single-box transport (copy-out, process barrier over POSIX shared
+ * memory, copy-in from the peers' mailboxes, barrier).  Every rank: gf_ipc_comm_create (same
+ * `shm_name`, "/..."; `mailbox_bytes` = its largest message), gf_ipc_comm_handle -> 64 bytes to
+ * publish to all ranks, gf_ipc_comm_open(all handles, rank-major).  The handle then works with
+ * every gf_comm_* / *_comm entry point. */
+GF_API int gf_ipc_comm_create(gf_comm** out, int world_size, int rank, int device,
+                              size_t mailbox_bytes, const char* shm_name);
+GF_API int gf_ipc_comm_handle(gf_comm* c, uint8_t out[64]);
+GF_API int gf_ipc_comm_open(gf_comm* c, const uint8_t* handles);
+
 /* The slotted chain of one sample() over `c` in ONE call (and through the enqueue thread):
  * gf_sampler_part_begin_slotted, then per (layer, snapshot) plan -> request slots out -> own
  * share + serve -> reply slots back -> merge, then commit; nothing is read back.

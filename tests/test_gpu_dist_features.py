@@ -104,8 +104,9 @@ def _run(rank, world, ratio, always_exchange=False):
     return bool(ok)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, transport="torch"):
     sys.path.insert(0, ROOT)
+    os.environ["GNNFLOW_PART_TRANSPORT"] = transport   # ipc: the native round, several ranks
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -121,15 +122,15 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_features_ranks_sharing_one_gpu(world):
+@pytest.mark.parametrize("world,transport", [(2, "torch"), (3, "torch"), (2, "ipc"), (4, "ipc")])
+def test_sharded_features_ranks_sharing_one_gpu(world, transport):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, transport), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
 
 

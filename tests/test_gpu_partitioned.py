@@ -107,8 +107,11 @@ def _same(gb, wb):
     return bool(ok)
 
 
-def _worker(rank, world, port, ret, tiled):
+def _worker(rank, world, port, ret, tiled, transport="torch"):
     sys.path.insert(0, ROOT)
+    # torch: the stages issued from Python, exchanges staged through gloo + host memory;
+    # ipc: the library's hipIpc transport — the NATIVE one-call chain with several ranks for real
+    os.environ["GNNFLOW_PART_TRANSPORT"] = transport
     if tiled:   # read once per process: the count / scan / scatter form of the plan for every layer
         os.environ["GNNFLOW_PARTITION_SMALL_PLAN"] = "0"
     import torch
@@ -153,6 +156,8 @@ def _worker(rank, world, port, ret, tiled):
                         ok &= _same(gb, wb)
             if slack == 2.0:
                 ok &= part.overflows == 0
+            if slack > 0:
+                ok &= (part._comm is not None) == (transport == "ipc")
             if slack == 0.02:
                 # every rank counts the same overflowed samples (a flag raised on one rank is
                 # seen by all of them)
@@ -166,7 +171,8 @@ def _worker(rank, world, port, ret, tiled):
                 reqs = [synth.random_roots(400, R, 1000.0, seed=77 * rank + R)
                         for R in (300, 3 + rank, 1500)]
                 pend = [part.sample_async(torch.from_numpy(n).cuda(), torch.from_numpy(t).cuda(),
-                                          stream=side) for n, t in reqs]
+                                          stream=side, worker_enqueue=transport == "ipc")
+                        for n, t in reqs]
                 for (n, t), p in zip(reqs, pend):
                     for gl, wl in zip(p.wait(), ref.sample(n, t)):
                         for gb, wb in zip(gl, wl):
@@ -185,15 +191,17 @@ def _worker(rank, world, port, ret, tiled):
 
 # At most 4 ranks: the GPU box allows 6 processes on the card, and the pytest parent holds it
 # too (world 8 lives on the CPU: tests/test_dist_gloo.py).
-@pytest.mark.parametrize("world,tiled", [(2, False), (2, True), (3, False), (4, False)])
-def test_ranks_sharing_one_gpu_match_the_oracle(world, tiled):
+@pytest.mark.parametrize("world,tiled,transport", [
+    (2, False, "torch"), (2, True, "torch"), (3, False, "torch"), (4, False, "torch"),
+    (2, False, "ipc"), (2, True, "ipc"), (4, False, "ipc")])
+def test_ranks_sharing_one_gpu_match_the_oracle(world, tiled, transport):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, port, ret, tiled), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, tiled, transport), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
 
 
