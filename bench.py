@@ -422,6 +422,12 @@ def exchange_note(sampler, world, backend):
     if world == 1 and not getattr(sampler, "_always_exchange", False):
         return "none (one rank: every root is its own)"
     via = "RCCL" if backend == "nccl" else backend
+    if getattr(sampler, "_slack", 0) > 0 and getattr(sampler, "_comm", None) is not None \
+            and sampler._comm.transport == "ipc":
+        return ("2 equal-split exchanges per layer over the library's hipIpc transport (ranks "
+                "sharing a GPU; host-synchronising: a test transport) — one native call per "
+                "sample, slot capacity {} x the even share; {} overflowed samples redone".format(
+                    sampler._slack, sampler.overflows))
     if getattr(sampler, "_slack", 0) > 0 and getattr(sampler, "_comm", None) is not None:
         return ("2 equal-split all-to-alls per layer over the library's own RCCL communicator "
                 "(one native call per sample, issued by the enqueue thread; slot capacity {} x "

@@ -165,8 +165,8 @@ struct IpcExchange::Shared {
   std::atomic<uint32_t> arrived;
   std::atomic<uint32_t> sense;
   uint32_t pad[14];
-  // per (sender, receiver): where the receiver's chunk sits in the sender's mailbox
-  struct Slot { uint64_t off, bytes; } slot[64][64];
+  // per (parity, sender, receiver): where the receiver's chunk sits in the sender's mailbox
+  struct Slot { uint64_t off, bytes; } slot[2][64][64];
 };
 
 static_assert(sizeof(hipIpcMemHandle_t) == IpcExchange::kHandleBytes, "hipIpcMemHandle_t is 64 bytes");
@@ -252,12 +252,18 @@ void IpcExchange::all_to_all_v(const void* send, const size_t* send_bytes, const
                                hipStream_t stream) {
   GF_REQUIRE(send_bytes && send_off && recv_bytes && recv_off, "all_to_all_v: null split arrays");
   DeviceGuard dg(device_);
+  // The mailbox has two halves used alternately, so ONE barrier per exchange is enough: a peer
+  // can only overwrite the half this rank is still reading two exchanges later, i.e. after this
+  // rank has reached the next exchange's barrier.
+  const uint32_t par = parity_;
+  parity_ ^= 1u;
+  const size_t half = box_bytes_ / 2;
   // 1. pack this rank's chunks into its mailbox and say where each peer's chunk is
-  size_t at = 0;
+  size_t at = par * half;
   for (int q = 0; q < world_; ++q) {
-    GF_REQUIRE(at + send_bytes[q] <= box_bytes_, "ipc comm: message larger than the mailbox");
-    shm_->slot[rank_][q].off = at;
-    shm_->slot[rank_][q].bytes = send_bytes[q];
+    GF_REQUIRE(at + send_bytes[q] <= (par + 1) * half, "ipc comm: message larger than the mailbox");
+    shm_->slot[par][rank_][q].off = at;
+    shm_->slot[par][rank_][q].bytes = send_bytes[q];
     if (send_bytes[q])
       GF_HIP(hipMemcpyAsync(box_ + at, static_cast<const char*>(send) + send_off[q], send_bytes[q],
                             hipMemcpyDeviceToDevice, stream));
@@ -267,14 +273,13 @@ void IpcExchange::all_to_all_v(const void* send, const size_t* send_bytes, const
   barrier();   // every mailbox is complete
   // 2. fetch this rank's chunk from every peer's mailbox
   for (int q = 0; q < world_; ++q) {
-    const Shared::Slot s = shm_->slot[q][rank_];
+    const Shared::Slot s = shm_->slot[par][q][rank_];
     GF_REQUIRE(s.bytes == recv_bytes[q], "ipc comm: send / receive sizes disagree");
     if (s.bytes)
       GF_HIP(hipMemcpyAsync(static_cast<char*>(recv) + recv_off[q], peer_box_[q] + s.off, s.bytes,
                             hipMemcpyDeviceToDevice, stream));
   }
-  GF_HIP(hipStreamSynchronize(stream));
-  barrier();   // the mailboxes may be overwritten again
+  // (the copies are ordered on `stream`; nobody touches this half again before the next barrier)
 }
 
 }  // namespace gf

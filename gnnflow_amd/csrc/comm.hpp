@@ -68,7 +68,8 @@ class IpcExchange : public Exchange {
  public:
   static constexpr size_t kHandleBytes = 64;   // sizeof(hipIpcMemHandle_t)
   // shm_name: the name of a POSIX shared-memory object all ranks use (created by whoever comes
-  // first); box_bytes: capacity of this rank's mailbox = the largest message it sends
+  // first); box_bytes: capacity of this rank's mailbox = TWICE the largest message it sends
+  // (two halves, used alternately)
   IpcExchange(int world, int rank, int device, size_t box_bytes, const char* shm_name);
   ~IpcExchange() override;
   void handle(uint8_t out[kHandleBytes]) const;          // this rank's mailbox, to publish
@@ -93,7 +94,7 @@ class IpcExchange : public Exchange {
   Shared* shm_ = nullptr;
   size_t shm_bytes_ = 0;
   std::string shm_name_;
-  uint32_t sense_ = 0;
+  uint32_t sense_ = 0, parity_ = 0;
 };
 
 }  // namespace gf

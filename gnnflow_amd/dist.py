@@ -620,7 +620,7 @@ class DevicePartitionedSampler:
                 ref = self._plan(max(self._slot_roots, 1), self._slack)[0]
                 box = max([1 << 16] + [P * lay.slot_stride * (24 * f + 16) + 512 * P
                                        for lay, f in zip(ref, self._fanouts)])
-                self._comm = NativeComm(self._device, group, kind, mailbox_bytes=box)
+                self._comm = NativeComm(self._device, group, kind, mailbox_bytes=2 * box)
         slab, out_ptr, nbytes = self._output(R, stream)
         ws, wi = self._workspace(ws_bytes, stream)
         if self._comm is not None:
