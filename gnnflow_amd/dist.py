@@ -620,7 +620,13 @@ class DevicePartitionedSampler:
                 ref = self._plan(max(self._slot_roots, 1), self._slack)[0]
                 box = max([1 << 16] + [P * lay.slot_stride * (24 * f + 16) + 512 * P
                                        for lay, f in zip(ref, self._fanouts)])
-                self._comm = NativeComm(self._device, group, kind, mailbox_bytes=2 * box)
+                try:
+                    self._comm = NativeComm(self._device, group, kind, mailbox_bytes=2 * box)
+                except Exception as e:     # no RCCL to load, ...: the same on every rank
+                    import sys
+                    print("gnnflow_amd: no native communicator ({}: {}); the exchanges go "
+                          "through torch.distributed".format(type(e).__name__, e), file=sys.stderr)
+                    self._comm = None
         slab, out_ptr, nbytes = self._output(R, stream)
         ws, wi = self._workspace(ws_bytes, stream)
         if self._comm is not None:
