@@ -569,9 +569,14 @@ __global__ __launch_bounds__(kEmitThreads) void sample_emit_kernel(
     int prop_time, uint64_t seed, uint64_t call, const uint64_t* __restrict__ rec_end,
     const uint32_t* __restrict__ rec_cnt, const uint32_t* __restrict__ base,
     int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
-    int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col) {
+    int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col,
+    Publish pub) {
   const uint64_t R = d_R ? *d_R : R_host;
   const uint64_t total = R * fanout;
+  if (pub.num_words && blockIdx.x == 0 && threadIdx.x == 0) {   // sizes: final before this launch
+    for (uint32_t i = 0; i < pub.num_words; ++i) pub.h_counts[i] = pub.d_counts[i];
+    pub.h_counts[pub.num_words] = 0;
+  }
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
   for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
        t += stride) {
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(kEmitThreads) void sample_emit_prefix_kernel(
     const uint32_t* __restrict__ rec_cnt, const uint32_t* __restrict__ wg_sum,
     uint32_t roots_per_search_wg, int64_t* __restrict__ all_nodes, float* __restrict__ all_ts,
     float* __restrict__ dt, int64_t* __restrict__ eids, int64_t* __restrict__ row,
-    int64_t* __restrict__ col, uint64_t* out_R, uint64_t* out_S, uint64_t* next_R) {
+    int64_t* __restrict__ col, uint64_t* out_R, uint64_t* out_S, uint64_t* next_R, Publish pub) {
   __shared__ uint32_t red[kEmitThreads / 64];
   __shared__ uint32_t lbase[kEmitThreads];
   __shared__ uint32_t wave_tot[kEmitThreads / 64];
@@ -680,6 +685,11 @@ __global__ __launch_bounds__(kEmitThreads) void sample_emit_prefix_kernel(
     *out_R = R;
     *out_S = S;
     if (next_R) *next_R = R + S;
+    // the LAST kernel of a sample also copies every block's sizes into pinned host memory (the
+    // earlier blocks' are final: their kernels are complete; this block's were just written by
+    // this thread); the host learns of the sample's completion from the stream's event
+    for (uint32_t i = 0; i < pub.num_words; ++i) pub.h_counts[i] = pub.d_counts[i];
+    if (pub.num_words) pub.h_counts[pub.num_words] = 0;
   }
 }
 
@@ -1178,7 +1188,9 @@ void Sampler::reserve_workspace(size_t Rb, size_t num_blocks, hipStream_t stream
 void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb,
                             const uint64_t* d_R, uint64_t R_host, uint32_t layer,
                             uint32_t snapshot, const BlockPtrs& out, uint64_t* d_counts_slot,
-                            uint64_t* next_R, hipStream_t stream) {
+                            uint64_t* next_R, hipStream_t stream, const void* publish) {
+  Publish pub{};
+  if (publish) pub = *static_cast<const Publish*>(publish);
   const uint32_t F = fanouts_[layer];
   const int uniform = policy_ == GF_SAMPLING_POLICY_UNIFORM;
   GF_REQUIRE(static_cast<uint64_t>(Rb) * F < 0xFFFFFFFFull,
@@ -1236,7 +1248,7 @@ void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb
     sample_emit_prefix_kernel<<<dim3(grid), dim3(kEmitThreads), 0, stream>>>(
         gv, d_roots, d_ts, d_R, R_host, F, uniform, prop_time_ ? 1 : 0, seed_, call, rec_end,
         rec_cnt, wg_sum, roots_per_wg, out.all_nodes, out.all_ts, out.dt, out.eids, out.row,
-        out.col, d_counts_slot, d_counts_slot + 1, next_R);
+        out.col, d_counts_slot, d_counts_slot + 1, next_R, pub);
     GF_HIP(hipGetLastError());
     return;
   }
@@ -1265,7 +1277,7 @@ void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb
     unsigned grid = capped_grid(static_cast<uint64_t>(Rb) * F, kEmitThreads, 256 * 16);
     sample_emit_kernel<<<dim3(grid), dim3(kEmitThreads), 0, stream>>>(
         gv, d_roots, d_ts, d_R, R_host, F, uniform, prop_time_ ? 1 : 0, seed_, call, rec_end,
-        rec_cnt, base, out.all_nodes, out.all_ts, out.dt, out.eids, out.row, out.col);
+        rec_cnt, base, out.all_nodes, out.all_ts, out.dt, out.eids, out.row, out.col, pub);
     GF_HIP(hipGetLastError());
   }
 }
@@ -1291,6 +1303,7 @@ void Sampler::sample_begin(const int64_t* d_roots, const float* d_ts, size_t R, 
   // (only this thread begins samples: the slot stays free until ring_count_ is bumped below)
   slot->ptrs.assign(L * NS, BlockPtrs{});
   slot->roots = R;
+  slot->by_event = false;
   slot->stream = stream;
   if (R == 0) {  // temporal_sampler.cu:107-114
     calls_ += L * NS;
@@ -1314,22 +1327,6 @@ void Sampler::sample_begin(const int64_t* d_roots, const float* d_ts, size_t R, 
       p += layer_output_bytes(Rb, l);
     }
   }
-  for (size_t l = 0; l < L; ++l) {
-    const size_t Rb = root_bound(R, l);
-    for (size_t s = 0; s < NS; ++s) {
-      const size_t b = l * NS + s;
-      uint64_t* cslot = d_counts + 2 * b;
-      // the next layer of the same snapshot reads its root count R + S from next_R
-      uint64_t* next_R = (l + 1 < L) ? cslot + 2 * NS : nullptr;
-      if (l == 0) {
-        enqueue_layer(d_roots, d_ts, Rb, nullptr, R, l, s, ptrs[b], cslot, next_R, stream);
-      } else {
-        const BlockPtrs& prev = ptrs[(l - 1) * NS + s];
-        enqueue_layer(prev.all_nodes, prev.all_ts, Rb, cslot, 0, l, s, ptrs[b], cslot, next_R,
-                      stream);
-      }
-    }
-  }
   slot->seq = ++publish_seq_;
   uint64_t* rec = h_counts_.as<uint64_t>() + (slot->seq % kMaxInFlight) * rec_words_;
   *reinterpret_cast<volatile uint64_t*>(rec) = 0;   // this record's publish is pending
@@ -1339,8 +1336,34 @@ void Sampler::sample_begin(const int64_t* d_roots, const float* d_ts, size_t R, 
   pub.h_flag = rec;
   pub.seq = slot->seq;
   pub.num_words = static_cast<uint32_t>(L * NS * 2);
-  sample_publish_kernel<<<dim3(1), dim3(64), 0, stream>>>(pub);
-  GF_HIP(hipGetLastError());
+  // GNNFLOW_PUBLISH_EVENT=1: no publish kernel — the sample's LAST kernel copies the sizes to
+  // pinned memory and the host polls the stream's event for completion
+  static const bool by_event = [] {
+    const char* v = std::getenv("GNNFLOW_PUBLISH_EVENT");
+    return v && std::atoi(v) != 0;
+  }();
+  slot->by_event = by_event;
+  for (size_t l = 0; l < L; ++l) {
+    const size_t Rb = root_bound(R, l);
+    for (size_t s = 0; s < NS; ++s) {
+      const size_t b = l * NS + s;
+      uint64_t* cslot = d_counts + 2 * b;
+      // the next layer of the same snapshot reads its root count R + S from next_R
+      uint64_t* next_R = (l + 1 < L) ? cslot + 2 * NS : nullptr;
+      const void* last = (by_event && b + 1 == L * NS) ? &pub : nullptr;
+      if (l == 0) {
+        enqueue_layer(d_roots, d_ts, Rb, nullptr, R, l, s, ptrs[b], cslot, next_R, stream, last);
+      } else {
+        const BlockPtrs& prev = ptrs[(l - 1) * NS + s];
+        enqueue_layer(prev.all_nodes, prev.all_ts, Rb, cslot, 0, l, s, ptrs[b], cslot, next_R,
+                      stream, last);
+      }
+    }
+  }
+  if (!by_event) {
+    sample_publish_kernel<<<dim3(1), dim3(64), 0, stream>>>(pub);
+    GF_HIP(hipGetLastError());
+  }
   GF_HIP(hipEventRecord(slot->done, stream));
   std::lock_guard<std::mutex> lk(ring_mu_);
   ++ring_count_;
@@ -1377,7 +1400,16 @@ void Sampler::sample_end(gf_block* blocks) {
   const uint64_t* rec = h_counts_.as<uint64_t>() + (slot->seq % kMaxInFlight) * rec_words_;
   volatile const uint64_t* flag = rec;
   bool seen = false;
-  for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
+  if (slot->by_event) {   // completion = the event behind the sample's last kernel
+    for (uint64_t spin = 0;; ++spin) {
+      const hipError_t q = hipEventQuery(slot->done);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) { pop(); GF_HIP(q); }
+      if (spin > 4096 && (spin & 63) == 0) sched_yield();
+    }
+    seen = true;
+  }
+  for (uint64_t spin = 0; !seen && spin < (1ull << 26); ++spin) {
     if (*flag == slot->seq) { seen = true; break; }
     __builtin_ia32_pause();
     // a short pure spin covers the usual few microseconds; beyond that give the core away
@@ -1432,7 +1464,8 @@ void Sampler::sample_layer(const int64_t* d_roots, const float* d_ts, size_t R, 
   uint64_t* d_counts = reinterpret_cast<uint64_t*>(
       ws_.as<char>() + align_up(ws_roots_ * 8, 16) + 3 * align_up(ws_roots_ * 4, 16));
   BlockPtrs ptrs = carve(static_cast<char*>(d_out), R, fanouts_[layer]);
-  enqueue_layer(d_roots, d_ts, R, nullptr, R, layer, snapshot, ptrs, d_counts, nullptr, stream);
+  enqueue_layer(d_roots, d_ts, R, nullptr, R, layer, snapshot, ptrs, d_counts, nullptr, stream,
+                nullptr);
   GF_HIP(hipMemcpyAsync(h_layer_counts_.data(), d_counts, 2 * sizeof(uint64_t),
                         hipMemcpyDeviceToHost, stream));
   GF_HIP(hipStreamSynchronize(stream));
@@ -1610,6 +1643,7 @@ void Sampler::part_begin(const int64_t* d_roots, const float* d_ts, size_t R, vo
   reserve_workspace(std::max(root_bound(Rs, L - 1), last.replies / 16), L * NS, stream);
   slot->ptrs.assign(L * NS, BlockPtrs{});
   slot->roots = Rs;          // never the "R = 0 short-circuit" record: sizes come from the device
+  slot->by_event = false;    // a partitioned sample publishes through its publish kernel
   slot->stream = stream;
   char* p = static_cast<char*>(d_out);
   for (size_t l = 0; l < L; ++l) {

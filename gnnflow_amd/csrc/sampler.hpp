@@ -95,7 +95,7 @@ class Sampler {
   void enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t R_bound,
                      const uint64_t* d_R, uint64_t R_host, uint32_t layer, uint32_t snapshot,
                      const BlockPtrs& out, uint64_t* d_counts_slot, uint64_t* next_R,
-                     hipStream_t stream);
+                     hipStream_t stream, const void* publish);
   void reserve_workspace(size_t R_bound_max, size_t num_blocks, hipStream_t stream);
   void to_host_blocks(const gf_block* dev, gf_block* host, size_t n, hipStream_t stream);
 
@@ -118,6 +118,7 @@ class Sampler {
     uint64_t seq = 0;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    bool by_event = false;   // sizes published by the sample's last kernel, completion by `done`
     std::vector<BlockPtrs> ptrs;
   };
   struct PartState {
