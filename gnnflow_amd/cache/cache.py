@@ -191,6 +191,10 @@ class Cache:
         self.rows_moved = 0            # rows those launches gathered (aliased blocks move none)
 
     def __del__(self):
+        sess = self.__dict__.get("_pull_session")
+        if sess is not None and sess[0].value:       # before the caches it fetches into
+            self._lib.gf_pull_session_destroy(sess[0])
+            self._pull_session = None
         for k in (getattr(self, "_node", None), getattr(self, "_edge", None)):
             if k is not None:
                 k.close()
