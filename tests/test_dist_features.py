@@ -67,6 +67,50 @@ def test_feature_shards_pull_over_gloo(world):
     assert dict(ret) == {r: True for r in range(world)}
 
 
+def _transport_worker(rank, world, port, ret):
+    """ShardedFeatures' exchanges of a natively planned pull round, on CPU tensors over gloo:
+    counts [nctx, P] -> what every rank asks THIS rank for; one variable-size exchange per
+    context, rank-major on the receiving side."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnnflow_amd.dist import FeatureShards, ShardedFeatures
+        feats = np.arange(40, dtype=np.float32).reshape(10, 4)
+        sh = ShardedFeatures(node=FeatureShards.from_full(feats, np.arange(10), rank, world, "cpu"))
+        nctx = 3
+        # rank r sends (r + 2 q + k) % 5 rows of context k to rank q
+        sc = [[(rank + 2 * q + k) % 5 for q in range(world)] for k in range(nctx)]
+        counts = torch.tensor(sc, dtype=torch.int32)
+        got = sh.exchange_counts(counts)
+        rc = [[(q + 2 * rank + k) % 5 for q in range(world)] for k in range(nctx)]
+        ok = got.tolist() == rc
+        # rows: context k's row for (sender s, receiver q, index i) carries 1000 s + 100 q + 10 k + i
+        send, recv = [], []
+        for k in range(nctx):
+            rows = [[1000 * rank + 100 * q + 10 * k + i] * (k + 1)
+                    for q in range(world) for i in range(sc[k][q])]
+            send.append(torch.tensor(rows, dtype=torch.int64).reshape(-1, k + 1))
+            recv.append(torch.empty((sum(rc[k]), k + 1), dtype=torch.int64))
+        sh.exchange_segments(send, sc, recv, rc)
+        for k in range(nctx):
+            want = [[1000 * s + 100 * rank + 10 * k + i] * (k + 1)
+                    for s in range(world) for i in range(rc[k][s])]
+            ok &= recv[k].tolist() == want
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_pull_round_exchanges_over_gloo(world):
+    ret = mp.Manager().dict()
+    mp.spawn(_transport_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
 def test_feature_shards_single_process():
     from gnnflow_amd.dist import FeatureShards
     rng = np.random.RandomState(1)
