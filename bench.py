@@ -11,21 +11,31 @@ stream: TemporalSampler.sample() (2 layers, fanout [10,10], most-recent, 1800 ro
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N
+ranks: the parent — before importing torch or touching HIP — starts N fresh children of this
+file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's one JSON line and
+exits non-zero if any child does (launch_ranks below).
+
 The workload is the CHRONOLOGICAL REPLAY of the whole stream (1121 batches): early
 batches sample almost nothing and late ones ~25k edges, and the LRU cache only behaves
 like the real thing when consecutive batches follow each other.  So the timed region is
 `repeats` back-to-back windows of K consecutive batches, starting at batch 0 on a freshly
-initialised cache and wrapping around at the end of the stream, with
-repeats = ceil(4 * 1121 / K) unless --repeats says otherwise: whatever K is, the region
-covers >= 4 whole replays (>= 0.2 s) and edges_per_step is the full-replay mean.
-ms_per_step = elapsed / (K * repeats).  The loop itself is
+initialised cache and wrapping around at the end of the stream.  Unless --repeats says
+otherwise, `repeats` covers >= --min-replays (4) whole replays AND >= --min-seconds (2 s) of
+wall time — the step time comes from an untimed calibration replay, the maximum over the ranks —
+so whatever K is, edges_per_step is the full-replay mean and a clock outside the process sees
+the region.  ms_per_step = elapsed / (K * repeats); `timed_steps` = K * repeats and
+`timed_seconds` sit next to `steps` in the line.  The loop itself is
 gnnflow_amd.pipeline.ReplayPipeline.run — the function tests/test_gpu_pipeline_parity.py
 checks against the oracle.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline":     feature-gather kernel, algorithmic bytes / HIP-event time vs 8 TB/s
   "cpu_baseline": the CPU oracle (C port of the reference algorithm) timed on this
-                  host on a bounded sample of the same batches (rank 0, N=1 only).
+                  host on a bounded sample of the same batches (rank 0, N=1 only)
+  "config3":      (N=1) BASELINE configs[2] — uniform sampling on the synthetic power-law graph
+                  (10 M nodes / 200 M edges) at batch 600 / 6 000 / 60 000 / 600 000: edges/s,
+                  search / emit GB/s from dispatch-attached events, algorithmic fractions.
 Multi-GPU (N > 1): north_star's split is the headline — the graph is HASH-PARTITIONED by
 source vertex over the N ranks (owner(v) = splitmix64(v) mod N), every rank replays its own
 interleaved share of the batches (fixed work per GPU: "scaling": "weak"), and per layer
@@ -34,8 +44,11 @@ the roots travel to their owners and the sampled neighbours back as RCCL all-to-
 inside a sample).  Feature tables (REDDIT-shaped: 463 MB) are replicated, the LRU cache is
 per GPU.  The per-GPU-replica figure (no data-path collective; what the reference does
 inside one machine) rides along as the extra key "replica"; `--partition replica` makes
-it the main loop.  At N = 1 the main loop is the plain single-GPU path and the hash path
-(every root is the rank's own) is the extra key "hash_partition".
+it the main loop.  Should the hash-partitioned loop FAIL (RCCL between ranks ran for the first
+time in the driver's scaling run), every rank falls back to the replica loop: the line then
+says "parallelism": "replica-dpN" and carries the failure under "hash_partition": {"error"}.
+At N = 1 the main loop is the plain single-GPU path and the hash path (every root is the
+rank's own) is the extra key "hash_partition".
 """
 import argparse
 import json
@@ -48,12 +61,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
-PMC_TRAFFIC_FILE = "r03_pmc_gather_traffic.json"
+PMC_TRAFFIC_FILE = "r04_pmc_gather_traffic.json"
 
 
-def workload_key(args, repeats):
-    """What a committed PMC traffic measurement must have been taken with to be quoted."""
-    return {"steps": args.steps, "repeats": repeats, "warmup": args.warmup,
+def workload_key(args):
+    """What a committed PMC traffic measurement must have been taken with to be quoted (the
+    per-launch traffic of the gather does not depend on how often the replay is repeated)."""
+    return {"steps": args.steps, "warmup": args.warmup,
             "batch_size": args.batch_size, "fanouts": args.fanouts, "strategy": args.strategy,
             "cache_ratio": args.cache_ratio, "undirected": bool(args.undirected),
             "feature_placement": args.feature_placement, "partition": args.partition,
@@ -61,15 +75,18 @@ def workload_key(args, repeats):
             "sample_only": bool(args.sample_only)}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1121)   # one full chronological replay
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=0,
                     help="windows of --steps consecutive batches in the timed region "
-                         "(0 = enough for --min-replays whole replays of the stream)")
+                         "(0 = enough for --min-replays whole replays and --min-seconds)")
     ap.add_argument("--min-replays", type=float, default=4.0)
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="lower bound of the timed region's wall time (an outside clock and "
+                         "rocm-smi's busy sampling must be able to see it)")
     ap.add_argument("--batch-size", type=int, default=600)
     ap.add_argument("--fanouts", type=str, default="10,10")
     ap.add_argument("--strategy", type=str, default="recent")
@@ -91,6 +108,10 @@ def parse():
     ap.add_argument("--part-slack", type=float, default=None,
                     help="slot capacity factor of the partitioned exchange (0 = variable-size "
                          "all-to-all-v with one host sync per layer; default 2.0)")
+    ap.add_argument("--part-lanes", type=int, default=None,
+                    help="sampling lanes of the partitioned sampler: consecutive batches go "
+                         "round-robin to lanes with their own stream, workspace and communicator, "
+                         "so their exchange chains overlap (default GNNFLOW_PART_LANES or 3)")
     ap.add_argument("--shard-features", action="store_true",
                     help="hash-partitioned run: shard the feature tables by owner too "
                          "(Cache(distributed=True): missed rows are pulled from their owners); "
@@ -100,17 +121,226 @@ def parse():
                          "prices the RCCL calls on a one-GPU box")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap batch i+1's sample() with batch i's fetch_feature()")
-    ap.add_argument("--pipeline-depth", type=int, default=2,
-                    help="batches whose sample() is in flight ahead of the fetch (1..3)")
+    ap.add_argument("--pipeline-depth", type=int, default=None,
+                    help="batches whose sample() is in flight ahead of the fetch (default 2; "
+                         "the partitioned sampler's lanes + 1)")
     ap.add_argument("--event-stride", type=int, default=17,
                     help="time every n-th gather launch with HIP events (1 = all)")
     ap.add_argument("--breakdown", action="store_true",
                     help="extra untimed pass with per-kernel-family HIP-event times")
-    return ap.parse_args()
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the config-3 sweep (10 M nodes / 200 M edges, uniform) at N = 1")
+    ap.add_argument("--config3-batches", default="600,6000,60000,600000")
+    ap.add_argument("--config3-nodes", type=int, default=10_000_000)
+    ap.add_argument("--config3-edges", type=int, default=200_000_000)
+    return ap.parse_args(argv)
+
+
+# ---- N > 1 without a launcher: this file starts its own ranks -------------------------------
+def launch_ranks(args, argv):
+    """The parent of `python bench.py --gpus N` (N > 1, no WORLD_SIZE): N fresh children of this
+    file, one per GPU, rendezvous on 127.0.0.1.  Nothing here imports torch or touches HIP (a
+    process that has initialised the GPU must not start workers by fork/exec).  Rank 0's stdout
+    is relayed — it carries the one JSON line —, the other ranks' goes to stderr.  Exit status:
+    0 only if every child exited 0; a child that dies takes the others with it after a grace
+    period (their watchdogs fire first, so rank 0 still gets its error record out)."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n),
+               LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    kids = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        kids.append(subprocess.Popen(cmd, env=e, stdin=subprocess.DEVNULL,
+                                     stdout=subprocess.PIPE if r == 0 else sys.stderr))
+
+    def stop(sig):
+        for k in kids:
+            if k.poll() is None:
+                try:
+                    k.send_signal(sig)
+                except OSError:
+                    pass
+
+    def on_signal(signum, _frame):
+        stop(signal.SIGTERM)
+        time.sleep(2.0)
+        stop(signal.SIGKILL)
+        os._exit(128 + signum)
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+
+    lines = []
+
+    def relay():
+        for raw in kids[0].stdout:
+            line = raw.decode(errors="replace")
+            if line.startswith("{"):
+                lines.append(line)
+            else:
+                sys.stderr.write(line)
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    limit = float(os.environ.get("GNNFLOW_BENCH_TIMEOUT", "900")) + 120.0
+    t0 = time.time()
+    bad_at = None
+    while any(k.poll() is None for k in kids):
+        time.sleep(0.1)
+        if bad_at is None and any(k.poll() not in (None, 0) for k in kids):
+            bad_at = time.time()
+        if bad_at is not None and time.time() - bad_at > 30.0:
+            stop(signal.SIGTERM)
+            time.sleep(2.0)
+            stop(signal.SIGKILL)
+        if time.time() - t0 > limit:
+            stop(signal.SIGKILL)
+    t.join(timeout=10.0)
+    rcs = [k.returncode for k in kids]
+    rc = next((c for c in rcs if c), 0)
+    if lines:
+        sys.stdout.write(lines[-1])       # exactly one line
+    else:
+        sys.stdout.write(json.dumps({
+            "metric": "sampled_edges_per_s", "value": 0.0, "unit": "edges/s", "n_gpus": n,
+            "error": "no rank printed a record; exit codes {}".format(rcs)}) + "\n")
+        rc = rc or 1
+    sys.stdout.flush()
+    return rc if rc >= 0 else 128 - rc
+
+
+# ---- one rank -------------------------------------------------------------------------------
+class Ctx:
+    pass
+
+
+def build_leg(ctx, kind):
+    """Graph + sampler of one kind over this rank's GPU: "replica" = the whole graph, "hash" =
+    this rank's shard + the partitioned sampler."""
+    import gnnflow_amd
+    args, g = ctx.args, ctx.g
+    MiB = 1 << 20
+    # gnnflow/config.py:121-131 _reddit_default_config
+    graph = gnnflow_amd.DynamicGraph(20 * MiB, 1000 * MiB, "cuda", 62, 1024, "insert",
+                                     device=ctx.local_rank)
+    ingest = graph
+    if kind == "hash":
+        from gnnflow_amd.dist import DevicePartitionedSampler, PartitionedGraph
+        ingest = PartitionedGraph(graph, ctx.rank, ctx.world)
+    t0 = time.time()
+    for lo in range(0, g["num_edges"], 100000):   # benchmark_sampler.py:56-63
+        hi = lo + 100000
+        ingest.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
+                         add_reverse=args.undirected)
+    build_s = time.time() - t0
+    sampler = gnnflow_amd.TemporalSampler(graph, ctx.fanouts, args.strategy, seed=1234)
+    if kind == "hash":
+        # every rank owns a shard; per layer the roots are bucketed by owner, requests and
+        # replies travel as equal-split all-to-alls, and the rank's own share is sampled meanwhile
+        sampler = DevicePartitionedSampler(sampler, slack=args.part_slack,
+                                           slot_roots=3 * args.batch_size,
+                                           always_exchange=args.always_exchange,
+                                           lanes=args.part_lanes)
+    return graph, sampler, build_s
+
+
+def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
+    """Warm-up, calibration, then the timed region over this rank's share of the replay.
+    Returns a dict with elapsed (max over ranks), edges (sum over ranks), this rank's edges,
+    timed_steps, repeats and the pipeline."""
+    import torch
+    import torch.distributed as dist
+    from gnnflow_amd.pipeline import ReplayPipeline
+    args, world, nb = ctx.args, ctx.world, ctx.nb
+    depth = args.pipeline_depth
+    if depth is None:
+        depth = max(2, getattr(sampler, "lanes", 1) + 1)
+    pipe = ReplayPipeline(sampler, cache, ctx.dev_batches, ctx.dev,
+                          pipelined=cache is not None and not args.no_pipeline, depth=depth)
+
+    def reduce(value, op):
+        if world == 1:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64,
+                         device=ctx.dev if ctx.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=op)
+        return float(t)
+
+    pipe.run(0, args.warmup if main_leg else min(args.warmup, nb))
+    steps = args.steps if main_leg else nb
+    repeats = args.repeats if (main_leg and args.repeats > 0) else 0
+    if repeats == 0:
+        # calibration: the step time over the late (heaviest) batches of one replay
+        cal = min(nb, 400)
+        ctx.barrier()
+        t0 = time.perf_counter()
+        pipe.run(max(nb - cal, 0), cal)
+        ctx.barrier()
+        t_step = reduce((time.perf_counter() - t0) / cal, dist.ReduceOp.MAX)
+        need = max(min_replays * nb, min_seconds / max(t_step, 1e-7))
+        repeats = max(1, -(-int(need) // max(steps, 1)))
+    timed_steps = steps * repeats
+    # the timed region replays from the first batch on a freshly initialised cache
+    if cache is not None:
+        cache.init_cache()
+        cache.algorithmic_bytes = 0
+        cache.rows_moved = 0
+    if main_leg:
+        ctx.lib.gf_profile_reset()
+        # HIP events on the gather launches of the timed region, on their stream.  Every 17th
+        # launch is timed: an event pair costs stream time, which at ~40 us per step would
+        # distort the throughput measured in the same pass.
+        ctx.lib.gf_profile_set_stride(args.event_stride)
+        ctx.lib.gf_profile_enable(1 << ctx.capi.PROFILE_SLOTS["gather"])
+    acc = {"edges": 0}
+
+    def account(_i, mfgs):
+        for mfg in mfgs:
+            for b in mfg:
+                acc["edges"] += b.num_edges()
+
+    ctx.barrier()
+    t0 = time.perf_counter()
+    pipe.run(0, timed_steps, account)
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    if main_leg:
+        ctx.lib.gf_profile_enable(0)
+        ctx.lib.gf_profile_set_stride(1)
+    if world > 1:
+        elapsed_max = reduce(elapsed, dist.ReduceOp.MAX)
+        edges_all = reduce(acc["edges"], dist.ReduceOp.SUM)
+    else:
+        elapsed_max, edges_all = elapsed, float(acc["edges"])
+    return dict(elapsed=elapsed_max, edges_all=edges_all, edges=acc["edges"], steps=steps,
+                repeats=repeats, timed_steps=timed_steps, pipe=pipe)
+
+
+def agree(ctx, ok):
+    """min over the ranks of a success flag (the ranks must take the same branch)."""
+    if ctx.world == 1:
+        return bool(ok)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                     device=ctx.dev if ctx.backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t))
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
     # stdout carries exactly ONE line, the JSON record: everything else that libraries print
     # there (RCCL's version banner on communicator creation, for one) goes to stderr
     sys.stdout.flush()
@@ -120,9 +350,11 @@ def main():
     def emit(record):
         os.write(json_fd, (json.dumps(record) + "\n").encode())
     main.emit = emit
-    rank = int(os.environ.get("RANK", "0"))
+    ctx = Ctx()
+    ctx.args = args
+    rank = ctx.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
@@ -130,9 +362,10 @@ def main():
     # collectives.  The driver's multi-GPU runs use neither.
     if "GNNFLOW_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["GNNFLOW_BENCH_DEVICE"])
-    backend = os.environ.get("GNNFLOW_BENCH_BACKEND", "nccl")
+    ctx.local_rank = local_rank
+    backend = ctx.backend = os.environ.get("GNNFLOW_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = ctx.dev = torch.device("cuda", local_rank)
     if world > 1 or args.partition == "hash" or args.always_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -166,7 +399,7 @@ def main():
     if per_rank < 4:
         os.environ.setdefault("GNNFLOW_ENQUEUE_LANES", "1")
         os.environ.setdefault("GNNFLOW_ENQUEUE_SPIN_US", "0")
-    import gnnflow_amd
+    import gnnflow_amd  # noqa: F401
     from gnnflow_amd import _capi, synthetic
     from gnnflow_amd.cache import LRUCache
     from gnnflow_amd.utils import bind_to_device_cpus
@@ -174,37 +407,24 @@ def main():
     # there; gnnflow_amd/utils.py).  The CPU baseline below runs inside the same mask.
     bound = bind_to_device_cpus(local_rank)
 
-    lib = _capi.load()
-    fanouts = [int(x) for x in args.fanouts.split(",")]
-    g = synthetic.reddit_like(seed=42)
+    lib = ctx.lib = _capi.load()
+    ctx.capi = _capi
+    fanouts = ctx.fanouts = [int(x) for x in args.fanouts.split(",")]
+    g = ctx.g = synthetic.reddit_like(seed=42)
     d_e, d_n = synthetic.REDDIT["dim_edge"], synthetic.REDDIT["dim_node"]
-    MiB = 1 << 20
-    # gnnflow/config.py:121-131 _reddit_default_config
-    graph = gnnflow_amd.DynamicGraph(20 * MiB, 1000 * MiB, "cuda", 62, 1024, "insert",
-                                     device=local_rank)
-    t0 = time.time()
-    ingest = graph
-    if args.partition == "hash":
-        from gnnflow_amd.dist import DevicePartitionedSampler, PartitionedGraph
-        ingest = PartitionedGraph(graph, rank, world)
-    for lo in range(0, g["num_edges"], 100000):   # benchmark_sampler.py:56-63
-        hi = lo + 100000
-        ingest.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
-                         add_reverse=args.undirected)
-    build_s = time.time() - t0
-    sampler = gnnflow_amd.TemporalSampler(graph, fanouts, args.strategy, seed=1234)
-    if args.partition == "hash":
-        # every rank owns a shard; per layer the roots are bucketed by owner, requests and
-        # replies travel as equal-split all-to-alls, and the rank's own share is sampled meanwhile
-        sampler = DevicePartitionedSampler(sampler, slack=args.part_slack,
-                                           slot_roots=3 * args.batch_size,
-                                           always_exchange=args.always_exchange)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    ctx.barrier = barrier
 
     gen = torch.Generator(device=dev).manual_seed(42)
     edge_feats = torch.rand((g["num_edges"], d_e), generator=gen, device=dev)
     node_feats = torch.rand((g["num_nodes"], d_n), generator=gen, device=dev)
     cache = None
-    if not args.sample_only and args.shard_features and args.partition == "hash":
+    sharded = (not args.sample_only) and args.shard_features and args.partition == "hash"
+    if sharded:
         from gnnflow_amd.dist import FeatureShards, ShardedFeatures
         import numpy as np
         shards = ShardedFeatures(
@@ -222,77 +442,71 @@ def main():
 
     # this rank's share of the chronological replay, resident in HBM
     batches = list(synthetic.replay_batches(g, args.batch_size, seed=42))
-    nb = len(batches) // world            # same on every rank (a longer share loses its tail)
+    nb = ctx.nb = len(batches) // world   # same on every rank (a longer share loses its tail)
     mine = (batches[rank::world] if world > 1 else batches)[:nb]
-    dev_batches = [(torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev),
-                    torch.from_numpy(e).to(dev)) for r, t, e in mine]
-    repeats = args.repeats if args.repeats > 0 else \
-        max(1, -(-int(args.min_replays * nb) // max(args.steps, 1)))
-    timed_steps = args.steps * repeats
+    ctx.dev_batches = [(torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev),
+                        torch.from_numpy(e).to(dev)) for r, t, e in mine]
 
     # Software pipeline (the reference's training loop prefetches the next batch's
     # sample() on a Python thread, scripts/offline_edge_prediction.py:343-346,397-399):
     # batch i+1's sample() is enqueued on a side HIP stream before batch i's
     # fetch_feature() is issued on the main stream.  Every batch goes through the same
     # calls; nothing is skipped or cached.  gnnflow_amd/pipeline.py, parity-tested.
-    from gnnflow_amd.pipeline import ReplayPipeline
-    pipe = ReplayPipeline(sampler, cache, dev_batches, dev,
-                          pipelined=cache is not None and not args.no_pipeline,
-                          depth=args.pipeline_depth)
+    #
+    # The main loop.  A failing hash-partitioned loop (it runs over RCCL between ranks for the
+    # first time in the driver's scaling run) must not cost the line: every rank then times
+    # the replica loop instead and the record says so.
+    def run_main(kind):
+        graph, sampler, build_s = build_leg(ctx, kind)
+        res = time_leg(ctx, sampler, cache, True, args.min_seconds, args.min_replays)
+        res.update(graph=graph, sampler=sampler, build_s=build_s, kind=kind)
+        return res
+
+    main_kind, hash_error, res = args.partition, None, None
+    try:
+        if os.environ.get("GNNFLOW_BENCH_FAIL_HASH") and main_kind == "hash":   # test hook
+            raise RuntimeError("GNNFLOW_BENCH_FAIL_HASH is set")
+        res = run_main(main_kind)
+        failure = None
+    except Exception as e:                      # noqa: BLE001 — reported in the record
+        import traceback
+        traceback.print_exc()
+        failure = "{}: {}".format(type(e).__name__, e)
+    if not agree(ctx, failure is None):
+        failure = failure or "the loop failed on another rank"
+        if main_kind == "hash" and not sharded:
+            hash_error, main_kind = failure, "replica"
+            try:
+                res = run_main("replica")
+                failure = None
+            except Exception as e:              # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                failure = "hash: {}; replica: {}: {}".format(hash_error, type(e).__name__, e)
+            if not agree(ctx, failure is None):
+                failure = failure or "the replica loop failed on another rank"
+        if failure is not None:
+            if rank == 0:
+                emit({"metric": "sampled_edges_per_s", "value": 0.0, "unit": "edges/s",
+                      "n_gpus": world, "error": failure})
+            if getattr(main, "done", None) is not None:
+                main.done.set()
+            os._exit(1)
+    sampler, pipe = res["sampler"], res["pipe"]
+    elapsed_max, edges_all, edges = res["elapsed"], res["edges_all"], res["edges"]
+    repeats, timed_steps = res["repeats"], res["timed_steps"]
     pipelined = pipe.pipelined
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    pipe.run(0, args.warmup)
-    # the timed region replays from the first batch on a freshly initialised cache
-    if cache is not None:
-        cache.init_cache()
-        cache.algorithmic_bytes = 0
-        cache.rows_moved = 0
-    lib.gf_profile_reset()
-    # HIP events on the gather launches of the timed region, on their stream.  Every 17th
-    # launch is timed: an event pair costs stream time, which at ~50 us per step would
-    # distort the throughput measured in the same pass.
-    lib.gf_profile_set_stride(args.event_stride)
-    lib.gf_profile_enable(1 << _capi.PROFILE_SLOTS["gather"])
-    barrier()
-    t0 = time.perf_counter()
-    acc = {"edges": 0}
-
-    def account(_i, mfgs):
-        for mfg in mfgs:
-            for b in mfg:
-                acc["edges"] += b.num_edges()
-
-    pipe.run(0, timed_steps, account)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    edges = acc["edges"]
+    args.partition = main_kind
     # rows x (8 B id + 2 x 4 x d B row read + write), summed by the cache
     # over the rows its gather launches really moved (a block served as a prefix of
     # another block's rows moves nothing and counts nothing)
     gather_bytes = cache.algorithmic_bytes if cache is not None else 0
-    lib.gf_profile_enable(0)
-    lib.gf_profile_set_stride(1)
+    rows_moved = cache.rows_moved if cache is not None else 0
 
     import ctypes as C
     g_ms, g_n, g_all = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
     lib.gf_profile_get(_capi.PROFILE_SLOTS["gather"], C.byref(g_ms), C.byref(g_n))
     lib.gf_profile_launches(_capi.PROFILE_SLOTS["gather"], C.byref(g_all))
-
-    stats = torch.tensor([elapsed, float(edges)], dtype=torch.float64,
-                         device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        tmax = stats[0:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        esum = stats[1:2].clone()
-        dist.all_reduce(esum, op=dist.ReduceOp.SUM)
-        elapsed_max, edges_all = float(tmax), float(esum)
-    else:
-        elapsed_max, edges_all = elapsed, float(edges)
 
     share = "" if world == 1 else " of this rank's share (every {}th batch)".format(world)
     window = "batches 0..{}{} in chronological order, {:.2f} times over".format(
@@ -305,6 +519,8 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "repeats": repeats,
+        "timed_steps": timed_steps,
+        "timed_seconds": elapsed_max,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed_max / timed_steps,
         "higher_is_better": True,
@@ -333,13 +549,13 @@ def main():
             # feature rows gathered per step (node block + outer edge block + target rows; the
             # inner edge block is a prefix of the outer one's rows and moves nothing) — the CPU
             # baseline below moves the same rows
-            "rows_per_step": (cache.rows_moved / max(timed_steps, 1)) if cache is not None else 0,
+            "rows_per_step": (rows_moved / max(timed_steps, 1)) if cache is not None else 0,
             "feature_placement": args.feature_placement,
-            "graph_build_s": round(build_s, 3),
-            "parallelism": "{}-dp{}".format(args.partition, world),
+            "graph_build_s": round(res["build_s"], 3),
+            "parallelism": "{}-dp{}".format(main_kind, world),
             "pipelined": bool(pipelined),
             "pipeline_depth": pipe.depth if pipelined else 0,
-            "workload_key": workload_key(args, repeats),
+            "workload_key": workload_key(args),
             "cpus_bound_to_gpu_node": len(bound) if bound else None,
             "usable_cores_per_rank": per_rank,
             "host_logical_cpus": os.cpu_count(),
@@ -356,42 +572,43 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": "gather_rows_kernel",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS,
+            # PMC counters cannot be read inside this process: `traffic` stays null in the run,
+            # and the committed rocprofv3 --pmc passes over THIS command line ride along as
+            # `traffic_from_profile` when the arguments match (scripts/rocprof_pmc.sh; FETCH_SIZE /
+            # WRITE_SIZE in separate passes, gfx950 FETCH x2 correction)
+            "traffic": None,
             "launches": int(n_launches), "launches_timed": int(g_n.value),
             "avg_launch_us": avg_us,
             "algorithmic_bytes_per_launch": bytes_per_launch,
         }
-        # HBM traffic of the same kernel from PMC counters (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate passes over THIS command line, gfx950 FETCH x2 correction;
-        # scripts/rocprof_pmc.sh).  Attached only when the committed measurement was taken
-        # with the arguments of this run.
         pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
         if os.path.exists(pmc):
             with open(pmc) as f:
                 rec = json.load(f)
-            if rec.get("bench_args") == workload_key(args, repeats):
-                out["roofline"]["traffic"] = rec["hbm_traffic_bytes_per_dispatch"]
+            if rec.get("bench_args") == workload_key(args):
+                out["roofline"]["traffic_from_profile"] = rec["hbm_traffic_bytes_per_dispatch"]
                 out["roofline"]["traffic_source"] = "profiles/" + PMC_TRAFFIC_FILE
         out["cache_edge_ratio"] = float(cache.cache_edge_ratio)
         out["cache_node_ratio"] = float(cache.cache_node_ratio)
 
-    if args.partition == "hash":
+    if main_kind == "hash":
         out["config"]["exchange"] = exchange_note(sampler, world, backend)
         out["config"]["features"] = (
             "sharded by owner: {} rows pulled, {} count read-backs in {} steps".format(
                 cache._shards.rows_pulled, cache._shards.host_syncs, timed_steps + args.warmup)
             if cache is not None and cache.distributed else "replicated on every GPU")
-    if cache is not None and not args.no_second_leg:
-        # The other kind of graph in the same line, over the same batches, cache and pipeline,
-        # one chronological replay: the hash-partitioned one when the main loop ran on replicas
-        # (at P = 1 every root is the rank's own: the figure then prices the bucketing /
-        # fixed-slot / merge kernels against the plain sampler above), the replicas when the
-        # main loop ran on the partitioned graph (N > 1).
-        other = "hash" if args.partition == "replica" else "replica"
+    if hash_error is not None:
+        out["hash_partition"] = {"error": hash_error, "fallback": "replica loop timed instead"}
+    elif cache is not None and not args.no_second_leg:
+        # The other kind of graph in the same line, over the same batches, cache and pipeline:
+        # the hash-partitioned one when the main loop ran on replicas (at P = 1 every root is
+        # the rank's own: the figure then prices the bucketing / fixed-slot / merge kernels
+        # against the plain sampler above), the replicas when the main loop ran on the
+        # partitioned graph (N > 1).
+        other = "hash" if main_kind == "replica" else "replica"
         second_leg.pending_line = out
-        out["hash_partition" if other == "hash" else "replica"] = second_leg(
-            other, args, rank, world, local_rank, backend, g, fanouts, cache, dev_batches, dev,
-            nb, barrier)
+        out["hash_partition" if other == "hash" else "replica"] = second_leg(ctx, other, cache)
 
     if args.breakdown and rank == 0:
         lib.gf_profile_reset()
@@ -406,6 +623,8 @@ def main():
             bd[name] = {"total_ms": ms.value, "intervals": int(n.value)}
         out["kernel_breakdown_200_steps"] = bd
 
+    if rank == 0 and world == 1 and not args.no_config3:
+        out["config3"] = config3_leg(args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, batches[:min(timed_steps, nb)], fanouts, args,
                                            edge_feats.cpu().numpy(), node_feats.cpu().numpy(),
@@ -418,24 +637,46 @@ def main():
         dist.destroy_process_group()
 
 
+def config3_leg(args, dev):
+    """BASELINE configs[2] in the same line: uniform sampling on the synthetic power-law graph
+    (10 M nodes / 200 M edges; 7.2 GB of edge store, far beyond the Infinity Cache) at batch
+    600 ... 600 000.  scripts/config3_bench.py does the work; skipped on a GPU with < 64 GB."""
+    import torch
+    try:
+        _free, total = torch.cuda.mem_get_info(dev)
+        if total < (64 << 30):
+            return {"skipped": "GPU has {:.0f} GB of memory (< 64 GB)".format(total / 2**30)}
+        from scripts import config3_bench
+        return config3_bench.sweep(
+            args.config3_nodes, args.config3_edges,
+            [int(b) for b in args.config3_batches.split(",")], ["uniform"], dev, reps=5)
+    except Exception as e:       # noqa: BLE001 — the headline must survive this leg
+        import traceback
+        traceback.print_exc()
+        return {"error": "{}: {}".format(type(e).__name__, e)}
+
+
 def exchange_note(sampler, world, backend):
     if world == 1 and not getattr(sampler, "_always_exchange", False):
         return "none (one rank: every root is its own)"
     via = "RCCL" if backend == "nccl" else backend
-    if getattr(sampler, "_slack", 0) > 0 and getattr(sampler, "_comm", None) is not None \
-            and sampler._comm.transport == "ipc":
+    lanes = getattr(sampler, "lanes", 1)
+    lane_note = "; {} sampling lanes (stream + workspace + communicator each), consecutive " \
+                "batches round-robin".format(lanes) if lanes > 1 else ""
+    comm = getattr(sampler, "_comm", None)
+    if getattr(sampler, "_slack", 0) > 0 and comm is not None and comm.transport == "ipc":
         return ("2 equal-split exchanges per layer over the library's hipIpc transport (ranks "
                 "sharing a GPU; host-synchronising: a test transport) — one native call per "
-                "sample, slot capacity {} x the even share; {} overflowed samples redone".format(
-                    sampler._slack, sampler.overflows))
-    if getattr(sampler, "_slack", 0) > 0 and getattr(sampler, "_comm", None) is not None:
+                "sample, slot capacity {} x the even share; {} overflowed samples redone{}".format(
+                    sampler._slack, sampler.overflows, lane_note))
+    if getattr(sampler, "_slack", 0) > 0 and comm is not None:
         return ("2 equal-split all-to-alls per layer over the library's own RCCL communicator "
                 "(one native call per sample, issued by the enqueue thread; slot capacity {} x "
                 "the even share; exchanges {}; no host sync inside a sample; {} overflowed "
-                "samples redone)".format(
+                "samples redone{})".format(
                     sampler._slack, "on the communicator's stream, requests overlapped with "
                     "the own share" if sampler._overlap else "in the sampling stream",
-                    sampler.overflows))
+                    sampler.overflows, lane_note))
     if getattr(sampler, "_slack", 0) > 0:
         return ("2 equal-split all-to-alls per layer over {} (slot capacity {} x the even share, "
                 "no host sync inside a sample; {} overflowed samples redone)".format(
@@ -443,74 +684,35 @@ def exchange_note(sampler, world, backend):
     return "2 all-to-all-v per layer over {} (one host sync per layer)".format(via)
 
 
-def second_leg(kind, args, rank, world, local_rank, backend, g, fanouts, cache, dev_batches, dev,
-               nb, barrier):
+def second_leg(ctx, kind, cache):
     import threading
-    import torch
-    import torch.distributed as dist
-    import gnnflow_amd
-    from gnnflow_amd.dist import DevicePartitionedSampler, PartitionedGraph
-    from gnnflow_amd.pipeline import ReplayPipeline
     # RCCL with more than one rank has never run on this code path before the first scaling
     # run: a watchdog ends every rank if a collective hangs — rank 0 first prints the line it
     # has, with an error note, then every rank exits NON-ZERO.
     limit = float(os.environ.get("GNNFLOW_HASH_LEG_TIMEOUT", "180"))
     done = threading.Event()
+    key = "hash_partition" if kind == "hash" else "replica"
 
     def watchdog():
         if not done.wait(limit):
-            if rank == 0 and second_leg.pending_line is not None:
-                second_leg.pending_line["hash_partition" if kind == "hash" else "replica"] = {
-                    "error": "timed out after {} s".format(limit)}
+            if ctx.rank == 0 and second_leg.pending_line is not None:
+                second_leg.pending_line[key] = {"error": "timed out after {} s".format(limit)}
                 main.emit(second_leg.pending_line)
             os._exit(3)
     threading.Thread(target=watchdog, daemon=True).start()
     try:
-        MiB = 1 << 20
-        graph = gnnflow_amd.DynamicGraph(20 * MiB, 1000 * MiB, "cuda", 62, 1024, "insert",
-                                         device=local_rank)
-        ingest = PartitionedGraph(graph, rank, world) if kind == "hash" else graph
-        for lo in range(0, g["num_edges"], 100000):
-            hi = lo + 100000
-            ingest.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi],
-                             add_reverse=args.undirected)
-        sampler = gnnflow_amd.TemporalSampler(graph, fanouts, args.strategy, seed=1234)
-        if kind == "hash":
-            sampler = DevicePartitionedSampler(sampler, slack=args.part_slack,
-                                               slot_roots=3 * args.batch_size,
-                                               always_exchange=args.always_exchange)
-        pipe = ReplayPipeline(sampler, cache, dev_batches, dev,
-                              pipelined=not args.no_pipeline, depth=args.pipeline_depth)
-        steps = nb
-        pipe.run(0, min(args.warmup, steps))
-        cache.init_cache()
-        barrier()
-        t0 = time.perf_counter()
-        acc = {"edges": 0}
-
-        def account(_i, mfgs):
-            for mfg in mfgs:
-                for b in mfg:
-                    acc["edges"] += b.num_edges()
-
-        pipe.run(0, steps, account)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        stats = torch.tensor([elapsed, float(acc["edges"])], dtype=torch.float64,
-                             device=dev if backend == "nccl" else "cpu")
-        if world > 1:
-            tmax = stats[0:1].clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            esum = stats[1:2].clone()
-            dist.all_reduce(esum, op=dist.ReduceOp.SUM)
-            elapsed, edges_all = float(tmax), float(esum)
-        else:
-            edges_all = float(acc["edges"])
-        return {"value": edges_all / elapsed, "unit": "edges/s", "ms_per_step": 1e3 * elapsed / steps,
-                "steps": steps, "world_size": world, "pipelined": bool(pipe.pipelined),
-                "exchange": exchange_note(sampler, world, backend) if kind == "hash" else
+        _graph, sampler, _ = build_leg(ctx, kind)
+        res = time_leg(ctx, sampler, cache, False, min(ctx.args.min_seconds, 1.0), 1.0)
+        return {"value": res["edges_all"] / res["elapsed"], "unit": "edges/s",
+                "ms_per_step": 1e3 * res["elapsed"] / res["timed_steps"],
+                "steps": res["steps"], "repeats": res["repeats"],
+                "timed_seconds": res["elapsed"], "world_size": ctx.world,
+                "pipelined": bool(res["pipe"].pipelined),
+                "exchange": exchange_note(sampler, ctx.world, ctx.backend) if kind == "hash" else
                 "none (a full replica of the graph per GPU, no data-path collective)"}
     except Exception as e:   # the main figure above must survive a failing second leg
+        import traceback
+        traceback.print_exc()
         return {"error": "{}: {}".format(type(e).__name__, e)}
     finally:
         done.set()

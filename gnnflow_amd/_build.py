@@ -12,10 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libgnnflow_hip.so")
 SOURCES = ["capi.hip", "edge_store.hip", "sampler.hip", "feature_cache.hip", "memory_ops.hip", "block_ops.hip", "partition.hip", "ingest_sort.hip", "comm.hip"]
-HEADERS = ["common.hpp", "edge_store.hpp", "sampler.hpp", "feature_cache.hpp", "ingest_sort.hpp",
-           "comm.hpp",
-           os.path.join("..", "..", "include", "gnnflow_hip.h"),
-           os.path.join("..", "..", "include", "gnnflow_rng.h")]
+# every header under csrc/ (a new one is picked up without touching this file) + the public ones
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))) + [
+    os.path.join("..", "..", "include", "gnnflow_hip.h"),
+    os.path.join("..", "..", "include", "gnnflow_rng.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-result", "-ffp-contract=off"]

@@ -444,7 +444,7 @@ class DevicePartitionedSampler:
     owns, see PartitionedGraph)."""
 
     def __init__(self, sampler, group=None, always_exchange=False, slack=None, slot_roots=None,
-                 comm=None, overlap=None):
+                 comm=None, overlap=None, lanes=None):
         """always_exchange: take the multi-rank path — request / reply exchange, served
         requests, merge — even with one rank (where every message is empty).  For tests: it
         is the only way to run the RCCL branch on a one-GPU box.
@@ -492,6 +492,7 @@ class DevicePartitionedSampler:
         self._ws_views = [None, None, None, None]  # tensor views into it, per (R0, slack)
         self._ws_next = 0
         self.overflows = 0     # slotted samples that had to be redone
+        self.lanes = 1
 
     # the plain sampler's attributes the pipeline / cache helpers look at
     @property
