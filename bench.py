@@ -278,14 +278,14 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
     steps = args.steps if main_leg else nb
     repeats = args.repeats if (main_leg and args.repeats > 0) else 0
     if repeats == 0:
-        # calibration: the step time over the late (heaviest) batches of one replay
-        cal = min(nb, 400)
+        # calibration: the mean step time of one whole replay (15 % on top: the timed region
+        # must not end up just short of --min-seconds)
         ctx.barrier()
         t0 = time.perf_counter()
-        pipe.run(max(nb - cal, 0), cal)
+        pipe.run(0, nb)
         ctx.barrier()
-        t_step = reduce((time.perf_counter() - t0) / cal, dist.ReduceOp.MAX)
-        need = max(min_replays * nb, min_seconds / max(t_step, 1e-7))
+        t_step = reduce((time.perf_counter() - t0) / nb, dist.ReduceOp.MAX)
+        need = max(min_replays * nb, 1.15 * min_seconds / max(t_step, 1e-7))
         repeats = max(1, -(-int(need) // max(steps, 1)))
     timed_steps = steps * repeats
     # the timed region replays from the first batch on a freshly initialised cache

@@ -202,6 +202,7 @@ PROTOTYPES = {
     "gf_ipc_comm_create": (C.c_int, [C.POINTER(_p), C.c_int, C.c_int, C.c_int, _sz, C.c_char_p]),
     "gf_ipc_comm_handle": (C.c_int, [_p, _p]),
     "gf_ipc_comm_open": (C.c_int, [_p, _p]),
+    "gf_loopback_comm_create": (C.c_int, [C.POINTER(_p), C.c_int, C.c_int]),
     "gf_comm_all_to_all": (C.c_int, [_p, _p, _p, _sz, _p]),
     "gf_comm_all_to_all_v": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "gf_sampler_sample_partitioned_comm": (C.c_int, [_p, _p, _p, _p, _sz, _p, _sz, _p, _sz,

@@ -12,6 +12,7 @@
 #include <string>
 #include <thread>
 
+#include "comm.hpp"
 #include "common.hpp"
 #include "edge_store.hpp"
 #include "feature_cache.hpp"
@@ -27,6 +28,8 @@ struct gf_comm {
   gf_comm(const uint8_t* id, int world, int rank, int device)
       : owned(new gf::RcclComm(id, world, rank, device)), impl(*owned) {}
   gf_comm(gf::IpcExchange* x) : owned(x), impl(*owned), ipc(x) {}
+  gf_comm(gf::LoopbackExchange* x) : owned(x), impl(*owned), loopback(true) {}
+  bool loopback = false;   // ranks are threads of this process: no shared enqueue thread
 };
 struct gf_pull_session {
   gf::PullSession impl;
@@ -844,6 +847,13 @@ int gf_ipc_comm_open(gf_comm* c, const uint8_t* handles) {
     c->ipc->open_peers(handles);
   });
 }
+int gf_loopback_comm_create(gf_comm** out, int world_size, int device) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_loopback_comm_create: null output");
+    auto ranks = gf::LoopbackExchange::create(world_size, device);
+    for (int r = 0; r < world_size; ++r) out[r] = new gf_comm(ranks[r].release());
+  });
+}
 int gf_comm_all_to_all(gf_comm* c, const void* d_send, void* d_recv, size_t bytes_per_peer,
                        void* stream) {
   return guarded([&] {
@@ -881,6 +891,8 @@ int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c, const in
                                              void* stream) {
   return guarded([&] {
     GF_REQUIRE(s != nullptr && c != nullptr, "null sampler / communicator handle");
+    GF_REQUIRE(!c->loopback, "sample_partitioned_comm_async: a loopback communicator's ranks are "
+                             "threads; one enqueue thread cannot serve them (use the synchronous call)");
     GF_REQUIRE(s->begin_tickets.size() < gf::Sampler::kMaxInFlight,
                "sample_partitioned_comm_async: too many samples in flight on this sampler");
     gf::Sampler* impl = &s->impl;

@@ -10,10 +10,12 @@
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -177,11 +179,31 @@ IpcExchange::IpcExchange(int world, int rank, int device, size_t box_bytes, cons
   GF_REQUIRE(box_bytes >= 4096 && shm_name && shm_name[0] == '/', "ipc comm: bad mailbox / name");
   DeviceGuard dg(device);
   shm_bytes_ = sizeof(Shared);
-  const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
-  GF_REQUIRE(fd >= 0, "ipc comm: shm_open failed");
-  if (ftruncate(fd, static_cast<off_t>(shm_bytes_)) != 0) {
-    close(fd);
-    throw Error(GF_ERR_IO, "ipc comm: ftruncate failed");
+  // Rank 0 creates the object afresh (never a leftover of a crashed run: O_EXCL after an
+  // unlink; a fresh object is zero-filled, so the barrier counters start at 0); the other ranks
+  // only ever open what rank 0 made, and wait for it to have its full size.
+  int fd = -1;
+  if (rank == 0) {
+    shm_unlink(shm_name);
+    fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    GF_REQUIRE(fd >= 0, "ipc comm: shm_open failed");
+    if (ftruncate(fd, static_cast<off_t>(shm_bytes_)) != 0) {
+      close(fd);
+      shm_unlink(shm_name);
+      throw Error(GF_ERR_IO, "ipc comm: ftruncate failed");
+    }
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      if (fd < 0) fd = shm_open(shm_name, O_RDWR, 0600);
+      struct stat sb;
+      if (fd >= 0 && fstat(fd, &sb) == 0 && static_cast<size_t>(sb.st_size) >= shm_bytes_) break;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+        if (fd >= 0) close(fd);
+        throw Error(GF_ERR_IO, "ipc comm: rank 0's shared-memory object did not appear");
+      }
+      usleep(1000);
+    }
   }
   void* p = mmap(nullptr, shm_bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   close(fd);
@@ -254,7 +276,13 @@ void IpcExchange::all_to_all_v(const void* send, const size_t* send_bytes, const
   DeviceGuard dg(device_);
   // The mailbox has two halves used alternately, so ONE barrier per exchange is enough: a peer
   // can only overwrite the half this rank is still reading two exchanges later, i.e. after this
-  // rank has reached the next exchange's barrier.
+  // rank has reached the next exchange's barrier.  That argument needs this rank's copy-ins of
+  // the PREVIOUS exchange to be complete when it reaches this barrier: they are ordered before
+  // the hipStreamSynchronize below when both exchanges use one stream — a change of stream
+  // synchronises the old one first.
+  if (last_stream_set_ && last_stream_ != stream) GF_HIP(hipStreamSynchronize(last_stream_));
+  last_stream_ = stream;
+  last_stream_set_ = true;
   const uint32_t par = parity_;
   parity_ ^= 1u;
   const size_t half = box_bytes_ / 2;
@@ -280,6 +308,85 @@ void IpcExchange::all_to_all_v(const void* send, const size_t* send_bytes, const
                             hipMemcpyDeviceToDevice, stream));
   }
   // (the copies are ordered on `stream`; nobody touches this half again before the next barrier)
+}
+
+// ---- LoopbackExchange ----------------------------------------------------------------------
+class LoopbackGroup {
+ public:
+  explicit LoopbackGroup(int world) : world_(world), post_(world) {}
+  struct Post {
+    const char* send = nullptr;
+    std::vector<size_t> bytes, off;
+  };
+  Post& post(int rank) { return post_[rank]; }
+  // a rank whose thread never arrives (it raised) ends the others' wait after 60 s with an
+  // error instead of a hang
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu_);
+    const uint64_t gen = generation_;
+    if (++arrived_ == world_) {
+      arrived_ = 0;
+      ++generation_;
+      cv_.notify_all();
+      return;
+    }
+    if (!cv_.wait_for(lk, std::chrono::seconds(60), [&] { return generation_ != gen; })) {
+      --arrived_;
+      throw Error(GF_ERR_HIP, "loopback comm: a rank did not reach the exchange within 60 s");
+    }
+  }
+
+ private:
+  const int world_;
+  std::vector<Post> post_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  int arrived_ = 0;
+  uint64_t generation_ = 0;
+};
+
+std::vector<std::unique_ptr<LoopbackExchange>> LoopbackExchange::create(int world, int device) {
+  GF_REQUIRE(world >= 1 && world <= 64, "loopback comm: world size must be 1..64");
+  auto group = std::make_shared<LoopbackGroup>(world);
+  std::vector<std::unique_ptr<LoopbackExchange>> out;
+  for (int r = 0; r < world; ++r)
+    out.emplace_back(new LoopbackExchange(group, world, r, device));
+  return out;
+}
+
+LoopbackExchange::LoopbackExchange(std::shared_ptr<LoopbackGroup> g, int world, int rank,
+                                   int device)
+    : group_(std::move(g)), world_(world), rank_(rank), device_(device) {}
+
+LoopbackExchange::~LoopbackExchange() = default;
+
+void LoopbackExchange::all_to_all(const void* send, void* recv, size_t bytes_per_peer,
+                                  hipStream_t stream) {
+  std::vector<size_t> b(world_, bytes_per_peer), o(world_);
+  for (int q = 0; q < world_; ++q) o[q] = static_cast<size_t>(q) * bytes_per_peer;
+  all_to_all_v(send, b.data(), o.data(), recv, b.data(), o.data(), stream);
+}
+
+void LoopbackExchange::all_to_all_v(const void* send, const size_t* send_bytes,
+                                    const size_t* send_off, void* recv, const size_t* recv_bytes,
+                                    const size_t* recv_off, hipStream_t stream) {
+  GF_REQUIRE(send_bytes && send_off && recv_bytes && recv_off, "all_to_all_v: null split arrays");
+  DeviceGuard dg(device_);
+  LoopbackGroup::Post& mine = group_->post(rank_);
+  mine.send = static_cast<const char*>(send);
+  mine.bytes.assign(send_bytes, send_bytes + world_);
+  mine.off.assign(send_off, send_off + world_);
+  GF_HIP(hipStreamSynchronize(stream));   // this rank's send buffer is complete
+  group_->barrier();                      // ... and so is everybody's
+  for (int q = 0; q < world_; ++q) {
+    const LoopbackGroup::Post& p = group_->post(q);
+    GF_REQUIRE(p.bytes[rank_] == recv_bytes[q], "loopback comm: send / receive sizes disagree");
+    if (recv_bytes[q])
+      GF_HIP(hipMemcpyAsync(static_cast<char*>(recv) + recv_off[q], p.send + p.off[rank_],
+                            recv_bytes[q], hipMemcpyDeviceToDevice, stream));
+  }
+  GF_HIP(hipStreamSynchronize(stream));   // this rank has read the peers' buffers
+  group_->barrier();                      // ... and so has everybody: they may be reused
 }
 
 }  // namespace gf

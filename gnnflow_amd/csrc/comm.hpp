@@ -8,6 +8,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -95,6 +96,38 @@ class IpcExchange : public Exchange {
   size_t shm_bytes_ = 0;
   std::string shm_name_;
   uint32_t sense_ = 0, parity_ = 0;
+  hipStream_t last_stream_ = nullptr;   // the stream of the previous exchange
+  bool last_stream_set_ = false;
+};
+
+// The same exchanges between "ranks" that are objects of ONE process: every virtual rank has its
+// own sampler / cache / pull session and its own host thread, and they meet in a LoopbackGroup.
+// An exchange = publish the send buffer, synchronise the own stream, thread barrier, copy this
+// rank's chunks straight out of the peers' send buffers on the own stream, synchronise, barrier
+// (after which the peers may overwrite their send buffers).  Host-synchronising test transport:
+// it runs the native multi-rank chains (gf_sampler_sample_partitioned_comm, gf_pull_round) at
+// world sizes the one-GPU test box cannot give as processes (8 ranks = 8 GPU processes > the
+// box's limit).  Each rank's calls must come from its own thread; the *_async entry points (one
+// enqueue thread for all ranks) would deadlock and are refused.
+class LoopbackGroup;
+class LoopbackExchange : public Exchange {
+ public:
+  static std::vector<std::unique_ptr<LoopbackExchange>> create(int world, int device);
+  ~LoopbackExchange() override;
+  int world() const override { return world_; }
+  int rank() const override { return rank_; }
+  void all_to_all(const void* send, void* recv, size_t bytes_per_peer,
+                  hipStream_t stream) override;
+  void all_to_all_forked(const void* send, void* recv, size_t bytes_per_peer,
+                         hipStream_t after) override { all_to_all(send, recv, bytes_per_peer, after); }
+  void join(hipStream_t) override {}
+  void all_to_all_v(const void* send, const size_t* send_bytes, const size_t* send_off, void* recv,
+                    const size_t* recv_bytes, const size_t* recv_off, hipStream_t stream) override;
+
+ private:
+  LoopbackExchange(std::shared_ptr<LoopbackGroup> g, int world, int rank, int device);
+  std::shared_ptr<LoopbackGroup> group_;
+  int world_, rank_, device_;
 };
 
 }  // namespace gf

@@ -302,9 +302,29 @@ class NativeComm:
                         rank joins; an all-to-all then costs a native call;
       transport "ipc":  hipIpc mailboxes + a process barrier in POSIX shared memory, for ranks
                         of one node that RCCL cannot serve — several ranks SHARING one GPU (the
-                        one-GPU test box): host-synchronising, a test / single-box transport."""
+                        one-GPU test box): host-synchronising, a test / single-box transport;
+      transport "loopback": `NativeComm.loopback(P, device)` — P virtual ranks inside THIS
+                        process, each driven by its own thread (world 8 on a one-GPU box)."""
 
     _counter = 0
+
+    @classmethod
+    def loopback(cls, world_size, device):
+        """P communicators of one in-process group (include/gnnflow_hip.h
+        gf_loopback_comm_create): rank r's calls must come from rank r's own thread."""
+        import ctypes as C
+        from . import _capi
+        lib = _capi.load()
+        device = torch.device(device)
+        arr = (C.c_void_p * world_size)()
+        _capi.check(lib.gf_loopback_comm_create(arr, world_size, device.index or 0))
+        out = []
+        for r in range(world_size):
+            c = cls.__new__(cls)
+            c._lib, c.P, c.rank, c.transport = lib, world_size, r, "loopback"
+            c.h = C.c_void_p(arr[r])
+            out.append(c)
+        return out
 
     def __init__(self, device, group=None, transport="rccl", mailbox_bytes=64 << 20):
         import ctypes as C
@@ -318,7 +338,10 @@ class NativeComm:
         self.h = C.c_void_p()
         if transport == "ipc":
             NativeComm._counter += 1
-            name = ["/gnnflow_ipc_{}_{}".format(os.getpid(), NativeComm._counter)]
+            # pid + counter + random token: an object left behind by a crashed run with a reused
+            # pid is never picked up again
+            name = ["/gnnflow_ipc_{}_{}_{}".format(os.getpid(), NativeComm._counter,
+                                                   os.urandom(6).hex())]
             if self.P > 1:
                 src = dist.get_global_rank(group, 0) if group is not None else 0
                 dist.broadcast_object_list(name, src=src, group=group)
@@ -379,6 +402,36 @@ class NativeComm:
     def usable(group=None) -> bool:
         return NativeComm.choose(group) is not None
 
+    @staticmethod
+    def create_agreed(device, group, kind, mailbox_bytes=64 << 20):
+        """NativeComm(...) or None — the SAME answer on every rank: a rank whose creation
+        failed (no RCCL to load, ncclCommInitRank error) tells the others through one
+        all-reduce(min) over the bootstrap group, and then every rank drops its communicator
+        and the exchanges go through torch.distributed everywhere.  (A group split between the
+        two transports would hang in its first all-to-all.)"""
+        import sys
+        comm, err = None, None
+        try:
+            comm = NativeComm(device, group, kind, mailbox_bytes=mailbox_bytes)
+        except Exception as e:     # noqa: BLE001
+            err = e
+        ok = comm is not None
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            host = _backend_is_host_only(group)
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                             device="cpu" if host else torch.device(device))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            ok = bool(int(t))
+        if not ok:
+            if comm is not None:
+                comm.close()
+            print("gnnflow_amd: no native communicator on every rank ({}); the exchanges go "
+                  "through torch.distributed".format(
+                      "{}: {}".format(type(err).__name__, err) if err else "another rank failed"),
+                  file=sys.stderr)
+            return None
+        return comm
+
 
 class _PartitionedPending:
     """PendingSample of a slotted partitioned sample: `wait()` also reads the sample's overflow
@@ -386,8 +439,8 @@ class _PartitionedPending:
     rank reads the same value for the same sample), samples the batch again through the
     variable-size exchange — on every rank, at the same point of its call sequence."""
 
-    def __init__(self, owner, pending, nodes, ts, stream):
-        self._owner, self._pending = owner, pending
+    def __init__(self, owner, lane, pending, nodes, ts, stream):
+        self._owner, self._lane, self._pending = owner, lane, pending
         self._nodes, self._ts, self._stream = nodes, ts, stream
         self._result = None
         self._overflowed = False
@@ -398,7 +451,8 @@ class _PartitionedPending:
     def _read_flag(self):
         own = self._owner
         flag = own._C.c_int(0)
-        own._capi.check(own._lib.gf_sampler_part_overflowed(own._sampler._h, own._C.byref(flag)))
+        own._capi.check(own._lib.gf_sampler_part_overflowed(self._lane.sampler._h,
+                                                            own._C.byref(flag)))
         self._overflowed = bool(flag.value)
 
     def wait(self):
@@ -407,15 +461,34 @@ class _PartitionedPending:
             mfgs = self._pending.wait()
             if self._overflowed:
                 own.overflows += 1
-                # the samples begun after this one end first (their launches may still be with
-                # the enqueue thread; their results are kept), then the batch is sampled again
-                q = own._sampler._inflight
+                # the samples begun on this lane after this one end first (their launches may
+                # still be with the enqueue thread; their results are kept), then the batch is
+                # sampled again.  Every rank does this at the same point of its call sequence
+                # and — the pipeline being the same on every rank — with the same number of
+                # samples in flight on the lane, so the lane's communicator sees the same order
+                # of collectives everywhere.
+                q = self._lane.sampler._inflight
                 while q:
                     q[0].wait()
-                mfgs = own._sample_variable(self._nodes, self._ts, self._stream).wait()
+                mfgs = own._sample_variable(self._lane, self._nodes, self._ts, self._stream).wait()
             self._result = mfgs
             self._nodes = self._ts = None
         return self._result
+
+
+class _Lane:
+    """One sampling lane of a DevicePartitionedSampler: a sampler over the rank's shard with its
+    own native workspace and publish ring, the stream its chains run on, its communicator, and
+    a ring of exchange workspaces (one per sample that can be in flight on the lane)."""
+
+    def __init__(self, sampler, comm=None):
+        self.sampler = sampler
+        self.stream = None          # lanes >= 1: their own stream, created on first use
+        self.comm = comm
+        self.comm_tried = comm is not None
+        self.ws_ring = [None, None, None, None]
+        self.ws_views = [None, None, None, None]
+        self.ws_next = 0
 
 
 class DevicePartitionedSampler:
@@ -440,6 +513,14 @@ class DevicePartitionedSampler:
     that `sample_async` can hand to the enqueue thread like the plain sampler's.  A rank whose
     batch is empty still takes part in every collective (its peers would otherwise block).
 
+    Throughput, not latency: a sample is a chain of ~13 dependent stream operations (two
+    all-to-alls per layer among them), so consecutive batches are spread round-robin over
+    `lanes` sampling lanes — each with its own stream, native workspace and communicator — and
+    batch i+1's plan / exchange / serve overlaps batch i's (reference: the asynchronous
+    per-partition requests of gnnflow/distributed/dist_sampler.py:188-220).  Every rank sends
+    batch i to lane i mod lanes, one thread issues all chains in batch order, so every
+    communicator sees the same order of collectives on every rank.
+
     sampler: a gnnflow_amd.TemporalSampler over THIS rank's shard (edges whose source it
     owns, see PartitionedGraph)."""
 
@@ -455,16 +536,21 @@ class DevicePartitionedSampler:
         must have the same size everywhere.  None: agreed on by an all-reduce (max) of the
         ranks' first batches — one host synchronisation, once.  Larger batches later are still
         sampled correctly (they overflow into the variable-size exchange).
-        comm: a NativeComm (the library's RCCL communicator) — the slotted chain is then ONE
-        native call that the enqueue thread can issue (`worker_enqueue=True`).  None: created
-        on first use when the process group runs over RCCL; the exchange goes through
+        comm: a NativeComm (the library's communicator; a list of them: one per lane) — the
+        slotted chain is then ONE native call that the enqueue thread can issue
+        (`worker_enqueue=True`), and world size / rank are the communicator's (a loopback
+        communicator's ranks live in one process without torch.distributed).  None: created on
+        first use when the process group runs over RCCL; the exchange goes through
         torch.distributed (staged through host memory over gloo) otherwise.
         overlap: run the exchanges on the communicator's own stream, the request exchange while
         the rank's own share is sampled (north_star's side-stream overlap).  Default
         GNNFLOW_PART_OVERLAP or OFF: on this runtime the two event hand-overs per exchange
         cost far more than the ~6 us own-share kernel they hide (one rank over RCCL, every
         message empty: 268 us per step with them, 116 us with everything in the sampling
-        stream; profiles/r03_part_bench_one_gpu.jsonl)."""
+        stream; profiles/r03_part_bench_one_gpu.jsonl).
+        lanes: sampling lanes (default GNNFLOW_PART_LANES or 3 with more than one rank /
+        always_exchange, else 1).  A lane is used only by `sample_async(..., stream=...)` calls
+        that name a stream (the pipelined loop); `sample()` always runs on lane 0."""
         import ctypes as C
         import os
         from . import _capi
@@ -473,8 +559,12 @@ class DevicePartitionedSampler:
         self._lib = _capi.load()
         self._sampler = sampler
         self._group = group
-        self._P = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._rank = dist.get_rank(group) if dist.is_initialized() else 0
+        comms = list(comm) if isinstance(comm, (list, tuple)) else ([comm] if comm is not None else [])
+        if comms:
+            self._P, self._rank = comms[0].P, comms[0].rank
+        else:
+            self._P = dist.get_world_size(group) if dist.is_initialized() else 1
+            self._rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._device = sampler._device
         self._fanouts = list(sampler._fanouts)
         self._L, self._S = sampler._num_layers, sampler._num_snapshots
@@ -482,22 +572,32 @@ class DevicePartitionedSampler:
             slack = float(os.environ.get("GNNFLOW_PART_SLACK", "2.0"))
         self._slack = max(float(slack), 0.0)
         self._slot_roots = int(slot_roots) if slot_roots else 0
-        self._comm = comm
-        self._comm_tried = comm is not None
         if overlap is None:
             overlap = os.environ.get("GNNFLOW_PART_OVERLAP", "0") != "0"
         self._overlap = bool(overlap)
+        if lanes is None:
+            lanes = int(os.environ.get("GNNFLOW_PART_LANES", "3"))
+        if (self._P == 1 and not self._always_exchange) or self._slack <= 0:
+            lanes = 1        # no exchange chain to overlap / host-synchronising exchange
+        if comms and comms[0].transport in ("ipc", "loopback"):
+            lanes = min(lanes, len(comms))    # host-synchronising transports: as many as given
+        lanes = max(1, min(int(lanes), 4))
+        self._lanes = [_Lane(sampler, comms[0] if comms else None)]
+        for k in range(1, lanes):
+            self._lanes.append(_Lane(sampler.clone(), comms[k] if k < len(comms) else None))
+        self.lanes = lanes
+        self._rr = 0               # round-robin cursor over the lanes
         self._layouts = {}     # (R0, slack) -> ([layouts per layer], [workspace offsets], total)
-        self._ws_ring = [None, None, None, None]   # one workspace per in-flight sample
-        self._ws_views = [None, None, None, None]  # tensor views into it, per (R0, slack)
-        self._ws_next = 0
         self.overflows = 0     # slotted samples that had to be redone
-        self.lanes = 1
 
     # the plain sampler's attributes the pipeline / cache helpers look at
     @property
     def _inflight(self):
         return self._sampler._inflight
+
+    @property
+    def _comm(self):
+        return self._lanes[0].comm
 
     def _plan(self, R0: int, slack: float = 0.0):
         hit = self._layouts.get((R0, slack))
@@ -522,23 +622,23 @@ class DevicePartitionedSampler:
             hit = self._layouts[(R0, slack)] = (lays, offs, total)
         return hit
 
-    def _workspace(self, nbytes: int, stream):
-        """grow-only scratch, one per sample that can be in flight at a time: (tensor, ring
-        index)"""
-        i = self._ws_next
-        self._ws_next = (i + 1) % len(self._ws_ring)
-        ws = self._ws_ring[i]
+    def _workspace(self, lane, nbytes: int, stream):
+        """grow-only scratch, one per sample that can be in flight on the lane at a time:
+        (tensor, ring index)"""
+        i = lane.ws_next
+        lane.ws_next = (i + 1) % len(lane.ws_ring)
+        ws = lane.ws_ring[i]
         if ws is None or ws.numel() < nbytes:
             with torch.cuda.stream(stream):
-                ws = self._ws_ring[i] = torch.empty(max(nbytes, 1), dtype=torch.uint8,
-                                                    device=self._device)
-            self._ws_views[i] = None
+                ws = lane.ws_ring[i] = torch.empty(max(nbytes, 1), dtype=torch.uint8,
+                                                   device=self._device)
+            lane.ws_views[i] = None
         return ws, i
 
-    def _slot_views(self, ws, i, R0, lays, offs):
+    def _slot_views(self, lane, ws, i, R0, lays, offs):
         """(requests out, inbox, served, replies in) int64 views of every (layer, snapshot) —
         the four buffers of the two equal-split exchanges — cut once per workspace and R0."""
-        hit = self._ws_views[i]
+        hit = lane.ws_views[i]
         if hit is None or hit[0] != R0:
             P, views = self._P, {}
             for layer in range(self._L):
@@ -551,28 +651,45 @@ class DevicePartitionedSampler:
                         return ws[off + at: off + at + nbytes].view(torch.int64)
                     views[(layer, s)] = (cut(lay.requests, 16 * n), cut(lay.inbox, 16 * n),
                                          cut(lay.served, 24 * F * n), cut(lay.replies, 24 * F * n))
-            hit = self._ws_views[i] = (R0, views)
+            hit = lane.ws_views[i] = (R0, views)
         return hit[1]
+
+    def _pick_lane(self, stream):
+        """(lane, stream) of the next sample: lane 0 on the caller's stream unless the caller
+        named a stream and there are several lanes — then round-robin, lanes >= 1 on their own
+        streams (the caller consumes the blocks after wait(), which has seen them complete)."""
+        if stream is None:
+            return self._lanes[0], torch.cuda.current_stream(self._device)
+        if self.lanes == 1:
+            return self._lanes[0], stream
+        k = self._rr % self.lanes
+        self._rr += 1
+        lane = self._lanes[k]
+        if k == 0:
+            return lane, stream
+        if lane.stream is None:
+            lane.stream = torch.cuda.Stream(device=self._device)
+        return lane, lane.stream
 
     def sample_async(self, nodes, ts, stream=None, worker_enqueue=False):
         """TemporalSampler.sample_async for the partitioned graph: returns a pending sample;
         `.wait()` gives the MFGs.  With more than one rank the launches and the collectives
         are enqueued by this call without any host synchronisation (slotted form)."""
-        smp, dev = self._sampler, self._device
+        lane, stream = self._pick_lane(stream)
+        smp = lane.sampler
         if len(smp._inflight) >= smp._max_inflight:
             smp._inflight[0].wait()
-        if stream is None:
-            stream = torch.cuda.current_stream(dev)
         nodes, ts = smp._to_device(nodes, ts, stream)
         if self._P == 1 and not self._always_exchange:
-            return self._sample_one_rank(nodes, ts, stream, worker_enqueue)
+            return self._sample_one_rank(lane, nodes, ts, stream, worker_enqueue)
         if self._slack > 0:
             return _PartitionedPending(
-                self, self._sample_slotted(nodes, ts, stream, worker_enqueue), nodes, ts, stream)
-        return self._sample_variable(nodes, ts, stream)
+                self, lane, self._sample_slotted(lane, nodes, ts, stream, worker_enqueue),
+                nodes, ts, stream)
+        return self._sample_variable(lane, nodes, ts, stream)
 
-    def _output(self, R, stream):
-        C, smp = self._C, self._sampler
+    def _output(self, lane, R, stream):
+        C, smp = self._C, lane.sampler
         nbytes = smp._bytes_cache.get(max(R, 1))
         if nbytes is None:
             n = C.c_size_t(0)
@@ -581,64 +698,70 @@ class DevicePartitionedSampler:
         slab, off = smp._output_buffer(nbytes, stream)
         return slab, slab[5] + off, nbytes
 
-    def _pend(self, slab, keep, R):
+    def _pend(self, lane, slab, keep, R):
         from .temporal_sampler import PendingSample
         # R = 0 still yields real (empty) blocks whose sizes come from the device
-        pending = PendingSample(self._sampler, slab, keep, max(R, 1), None)
-        self._sampler._inflight.append(pending)
+        pending = PendingSample(lane.sampler, slab, keep, max(R, 1), None)
+        lane.sampler._inflight.append(pending)
         return pending
 
-    def _sample_one_rank(self, nodes, ts, stream, worker_enqueue):
-        lib, smp = self._lib, self._sampler
+    def _sample_one_rank(self, lane, nodes, ts, stream, worker_enqueue):
+        lib, smp = self._lib, lane.sampler
         R = int(nodes.shape[0])
         _, _, ws_bytes = self._plan(max(R, 1))
-        slab, out_ptr, nbytes = self._output(R, stream)
-        ws, _ = self._workspace(ws_bytes, stream)
+        slab, out_ptr, nbytes = self._output(lane, R, stream)
+        ws, _ = self._workspace(lane, ws_bytes, stream)
         call = lib.gf_sampler_sample_partitioned_async if worker_enqueue \
             else lib.gf_sampler_sample_partitioned
         self._capi.check(call(smp._h, nodes.data_ptr() if R else None,
                               ts.data_ptr() if R else None, R, out_ptr, nbytes, ws.data_ptr(),
                               ws_bytes, slab[6]))
-        return self._pend(slab, (nodes, ts, ws), R)
+        return self._pend(lane, slab, (nodes, ts, ws), R)
 
-    def _sample_slotted(self, nodes, ts, stream, worker_enqueue=False):
+    def _ensure_comm(self, lane):
+        """The lane's communicator, created on first use (collective: every rank creates its
+        lanes' communicators in the same order) — or None: exchanges through torch.distributed."""
+        if not lane.comm_tried:
+            lane.comm_tried = True
+            kind = NativeComm.choose(self._group)
+            if kind is not None:
+                # ipc: the mailbox holds the largest message — a layer's reply slots for a batch
+                # of slot_roots roots (same on every rank)
+                P = self._P
+                ref = self._plan(max(self._slot_roots, 1), self._slack)[0]
+                # (and, for an overflowed sample's redo through the variable-size exchange,
+                # never less than 16 MiB)
+                box = max([16 << 20] + [P * lay.slot_stride * (24 * f + 16) + 512 * P
+                                        for lay, f in zip(ref, self._fanouts)])
+                lane.comm = NativeComm.create_agreed(self._device, self._group, kind,
+                                                     mailbox_bytes=2 * box)
+        return lane.comm
+
+    def _sample_slotted(self, lane, nodes, ts, stream, worker_enqueue=False):
         """The whole sample enqueued on `stream` without reading anything back: per layer
         plan -> equal-split exchange of the request slots (asynchronous, overlapped with the
         own share) -> serve -> equal-split exchange of the reply slots -> merge."""
-        lib, check, smp = self._lib, self._capi.check, self._sampler
+        lib, check, smp = self._lib, self._capi.check, lane.sampler
         P, me, group = self._P, self._rank, self._group
         R = int(nodes.shape[0])
         R0 = max(R, 1)
         if not self._slot_roots:
             self._slot_roots = self._agree_on_slot_roots(R0)
         lays, offs, ws_bytes = self._plan(R0, self._slack)
-        if not self._comm_tried:
-            self._comm_tried = True
-            kind = NativeComm.choose(group)
-            if kind is not None:
-                # ipc: the mailbox holds the largest message — a layer's reply slots for a batch
-                # of slot_roots roots (same on every rank)
-                ref = self._plan(max(self._slot_roots, 1), self._slack)[0]
-                box = max([1 << 16] + [P * lay.slot_stride * (24 * f + 16) + 512 * P
-                                       for lay, f in zip(ref, self._fanouts)])
-                try:
-                    self._comm = NativeComm(self._device, group, kind, mailbox_bytes=2 * box)
-                except Exception as e:     # no RCCL to load, ...: the same on every rank
-                    import sys
-                    print("gnnflow_amd: no native communicator ({}: {}); the exchanges go "
-                          "through torch.distributed".format(type(e).__name__, e), file=sys.stderr)
-                    self._comm = None
-        slab, out_ptr, nbytes = self._output(R, stream)
-        ws, wi = self._workspace(ws_bytes, stream)
-        if self._comm is not None:
-            # the library's own communicator: the chain is one native call
-            call = lib.gf_sampler_sample_partitioned_comm_async if worker_enqueue \
+        comm = self._ensure_comm(lane)
+        slab, out_ptr, nbytes = self._output(lane, R, stream)
+        ws, wi = self._workspace(lane, ws_bytes, stream)
+        if comm is not None:
+            # the library's own communicator: the chain is one native call (a loopback
+            # communicator's ranks are threads: they cannot share the one enqueue thread)
+            call = lib.gf_sampler_sample_partitioned_comm_async \
+                if (worker_enqueue and comm.transport != "loopback") \
                 else lib.gf_sampler_sample_partitioned_comm
-            check(call(smp._h, self._comm.h, nodes.data_ptr() if R else None,
+            check(call(smp._h, comm.h, nodes.data_ptr() if R else None,
                        ts.data_ptr() if R else None, R, out_ptr, nbytes, ws.data_ptr(), ws_bytes,
                        self._slack, self._slot_roots, 1 if self._overlap else 0, slab[6]))
-            return self._pend(slab, (nodes, ts, ws), R)
-        views = self._slot_views(ws, wi, R0, lays, offs)
+            return self._pend(lane, slab, (nodes, ts, ws), R)
+        views = self._slot_views(lane, ws, wi, R0, lays, offs)
         base = ws.data_ptr()
         with torch.cuda.stream(stream):
             check(lib.gf_sampler_part_begin_slotted(
@@ -662,24 +785,60 @@ class DevicePartitionedSampler:
             except Exception:
                 lib.gf_sampler_part_abort(smp._h)
                 raise
-        return self._pend(slab, (nodes, ts, ws), R)
+        return self._pend(lane, slab, (nodes, ts, ws), R)
 
     def _agree_on_slot_roots(self, R0: int) -> int:
         if self._P == 1:
             return R0
+        if not dist.is_initialized() or (self._comm is not None
+                                         and self._comm.transport == "loopback"):
+            raise ValueError("DevicePartitionedSampler: pass slot_roots (the batch size every rank "
+                             "agrees on) when the ranks do not share a torch process group")
         host = _backend_is_host_only(self._group)
         t = torch.tensor([R0], dtype=torch.int64, device="cpu" if host else self._device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._group)
         return int(t.item())
 
-    def _sample_variable(self, nodes, ts, stream):
+    # ---- exchanges of the variable-size form: the lane's communicator when it has one, else
+    # torch.distributed ---------------------------------------------------------------------
+    def _xchg_equal(self, comm, out, send):
+        """equal split: send[p] -> rank p's out[me] (rows of equal size)"""
+        if comm is None:
+            return _exchange(out, send, None, None, self._group)
+        st = torch.cuda.current_stream(self._device).cuda_stream
+        per_peer = send.numel() * send.element_size() // self._P
+        self._capi.check(self._lib.gf_comm_all_to_all(comm.h, send.data_ptr(), out.data_ptr(),
+                                                      per_peer, st))
+        return None
+
+    def _xchg_rows(self, comm, out, send, out_rows, in_rows, async_op=False):
+        """variable split: in_rows[p] rows of `send` to rank p, out_rows[p] rows from it"""
+        if comm is None:
+            return _exchange(out, send, out_rows, in_rows, self._group, async_op=async_op)
+        C, P = self._C, self._P
+        row = send.element_size() * (send.shape[1] if send.dim() > 1 else 1)
+        arr = C.c_size_t * P
+        sb, so, rb, ro = [], [], [], []
+        a = b = 0
+        for p in range(P):
+            sb.append(in_rows[p] * row); so.append(a); a += in_rows[p] * row
+            rb.append(out_rows[p] * row); ro.append(b); b += out_rows[p] * row
+        st = torch.cuda.current_stream(self._device).cuda_stream
+        # every rank makes every call, whatever its own sizes are (a transport may synchronise
+        # the ranks inside it); an empty side still needs a valid pointer
+        self._capi.check(self._lib.gf_comm_all_to_all_v(
+            comm.h, send.data_ptr() if a else out.data_ptr(), arr(*sb), arr(*so),
+            out.data_ptr() if b else send.data_ptr(), arr(*rb), arr(*ro), st))
+        return None
+
+    def _sample_variable(self, lane, nodes, ts, stream):
         """Variable-size exchange: all-to-all-v of exactly the rows there are; the per-owner
         counts are read back once per layer (they are the split sizes)."""
-        lib, check, smp = self._lib, self._capi.check, self._sampler
+        lib, check, smp = self._lib, self._capi.check, lane.sampler
         R = int(nodes.shape[0])
         lays, offs, ws_bytes = self._plan(max(R, 1))
-        slab, out_ptr, nbytes = self._output(R, stream)
-        ws, _ = self._workspace(ws_bytes, stream)
+        slab, out_ptr, nbytes = self._output(lane, R, stream)
+        ws, _ = self._workspace(lane, ws_bytes, stream)
         sptr = slab[6]
         with torch.cuda.stream(stream):
             check(lib.gf_sampler_part_begin(
@@ -688,23 +847,24 @@ class DevicePartitionedSampler:
             try:
                 for layer in range(self._L):
                     for s in range(self._S):
-                        self._exchange_layer(layer, s, lays[layer], ws, offs[layer][s], sptr)
+                        self._exchange_layer(lane, layer, s, lays[layer], ws, offs[layer][s], sptr)
                 check(lib.gf_sampler_part_commit(smp._h))
             except Exception:
                 lib.gf_sampler_part_abort(smp._h)
                 raise
-        return self._pend(slab, (nodes, ts, ws), R)
+        return self._pend(lane, slab, (nodes, ts, ws), R)
 
-    def _exchange_layer(self, layer, snapshot, lay, ws, off, sptr):
+    def _exchange_layer(self, lane, layer, snapshot, lay, ws, off, sptr):
         """One (layer, snapshot) with P > 1 ranks, on the current stream."""
-        C, lib, check = self._C, self._lib, self._capi.check
-        smp, dev, P, me, F = self._sampler, self._device, self._P, self._rank, self._fanouts[layer]
+        lib, check = self._lib, self._capi.check
+        smp, dev, P, me, F = lane.sampler, self._device, self._P, self._rank, self._fanouts[layer]
+        comm = lane.comm
         base = ws.data_ptr() + off
         # 1. bucket by owner (the layer's root count is still on the device)
         check(lib.gf_sampler_part_plan_own(smp._h, layer, snapshot, base, lay.total, 1))
         counts = ws[off + lay.counts: off + lay.counts + 8 * P].view(torch.int64)
         recv_counts = torch.empty_like(counts)
-        _exchange(recv_counts, counts, None, None, self._group)
+        self._xchg_equal(comm, recv_counts, counts)
         sc, rc = counts.tolist(), recv_counts.tolist()      # the layer's one host sync
         R = sum(sc)
         n_net = R - sc[me]
@@ -713,19 +873,19 @@ class DevicePartitionedSampler:
         rep = ws[off + lay.replies: off + lay.replies + 24 * F * R].view(torch.int64).view(R, F * 3)
         # 2. requests to the other ranks ...
         n_got = sum(rc)
-        got = torch.empty((n_got, 2), dtype=torch.int64, device=dev)
-        work = _exchange(got, req[:n_net], rc, sc, self._group, async_op=True)
+        got = torch.empty((max(n_got, 1), 2), dtype=torch.int64, device=dev)[:n_got]
+        work = self._xchg_rows(comm, got, req[:n_net], rc, sc, async_op=True)
         # ... overlapped with this rank's own share on its shard
         check(lib.gf_sampler_part_plan_own(smp._h, layer, snapshot, base, lay.total, 2))
         if work is not None:
             work.wait()
         # 3. the received requests, served from this rank's shard; replies land in the prefix
         #    of `rep`
-        served = torch.empty((n_got, F * 3), dtype=torch.int64, device=dev)
+        served = torch.empty((max(n_got, 1), F * 3), dtype=torch.int64, device=dev)[:n_got]
         check(lib.gf_sampler_sample_layer_padded(
             smp._h, got.data_ptr() if n_got else None, n_got, layer, snapshot,
             served.data_ptr() if n_got else None, sptr))
-        _exchange(rep[:n_net], served, sc, rc, self._group)
+        self._xchg_rows(comm, rep[:n_net], served, sc, rc)
         # 4. replies -> block in the original root order; sizes stay on the device
         check(lib.gf_sampler_part_merge(smp._h, layer, snapshot, base, lay.total))
 
@@ -742,6 +902,7 @@ class DevicePartitionedSampler:
         back, as the reference's RPC round trip is."""
         C, lib, check = self._C, self._lib, self._capi.check
         smp, dev, P, me = self._sampler, self._device, self._P, self._rank
+        comm = self._lanes[0].comm
         layer, snapshot = int(layer), int(snapshot)
         if not 0 <= layer < self._L or not 0 <= snapshot < self._S:
             raise ValueError("sample_layer: layer / snapshot out of range")
@@ -763,13 +924,13 @@ class DevicePartitionedSampler:
                                             req.data_ptr(), pos.data_ptr(), counts.data_ptr(),
                                             scratch.data_ptr(), scratch.numel(), dev.index, st))
             recv_counts = torch.empty_like(counts)
-            _exchange(recv_counts, counts, None, None, self._group)
+            self._xchg_equal(comm, recv_counts, counts)
             sc, rc = counts.tolist(), recv_counts.tolist()
             n_net = R - sc[me]
             sc[me] = rc[me] = 0
             n_got = sum(rc)
-            got = torch.empty((n_got, 2), dtype=torch.int64, device=dev)
-            work = _exchange(got, req[:n_net], rc, sc, self._group, async_op=True)
+            got = torch.empty((max(n_got, 1), 2), dtype=torch.int64, device=dev)[:n_got]
+            work = self._xchg_rows(comm, got, req[:n_net], rc, sc, async_op=True)
             rep = torch.empty((max(R, 1), F * 3), dtype=torch.int64, device=dev)
             if R - n_net:       # own share: the suffix of the request rows
                 check(lib.gf_sampler_sample_layer_padded(
@@ -777,11 +938,11 @@ class DevicePartitionedSampler:
                     rep[n_net:].data_ptr(), st))
             if work is not None:
                 work.wait()
-            served = torch.empty((n_got, F * 3), dtype=torch.int64, device=dev)
+            served = torch.empty((max(n_got, 1), F * 3), dtype=torch.int64, device=dev)[:n_got]
             if n_got:
                 check(lib.gf_sampler_sample_layer_padded(smp._h, got.data_ptr(), n_got, layer,
                                                          snapshot, served.data_ptr(), st))
-            _exchange(rep[:n_net], served, sc, rc, self._group)
+            self._xchg_rows(comm, rep[:n_net], served, sc, rc)
             if R == 0:
                 return smp._empty_block()
             nb = C.c_size_t(0)
@@ -808,13 +969,18 @@ class FeatureShards:
     """
 
     def __init__(self, num_ids: int, local_ids: torch.Tensor, local_rows: torch.Tensor,
-                 group=None):
+                 group=None, rank=None, world_size=None):
+        """rank / world_size: only for ranks that do not share a torch process group (the
+        virtual ranks of a loopback communicator); else the group's."""
         self.num_ids = int(num_ids)
         self.device = local_rows.device
         self.dim = int(local_rows.shape[1])
         self.group = group
-        self.P = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if world_size is not None:
+            self.P, self.rank = int(world_size), int(rank)
+        else:
+            self.P = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local_ids = local_ids.to(self.device, torch.int64)
         self.rows = local_rows.to(torch.float32).contiguous()
         # global id -> local row (dense: 4 B per id of the GLOBAL id space on every rank)
@@ -836,7 +1002,9 @@ class FeatureShards:
         keys_np = np.asarray(keys, dtype=np.int64)
         own = np.nonzero(owner_of_np(keys_np, world_size) == rank)[0]
         ids = torch.from_numpy(own)
-        return cls(feats.shape[0], ids.to(device), feats[ids].to(device, torch.float32), group)
+        explicit = not dist.is_initialized() or dist.get_world_size(group) != world_size
+        return cls(feats.shape[0], ids.to(device), feats[ids].to(device, torch.float32), group,
+                   rank=rank if explicit else None, world_size=world_size if explicit else None)
 
     def pull(self, ids: torch.Tensor, keys: torch.Tensor) -> torch.Tensor:
         dev, P = self.device, self.P

@@ -38,7 +38,8 @@ class ReplayPipeline:
         self.pipelined = bool(pipelined) and cache is not None and \
             hasattr(sampler, "sample_async")
         self.side = torch.cuda.Stream(device=self.device) if self.pipelined else None
-        self.depth = max(1, min(int(depth), 3))   # the sampler holds 4 begun samples at most
+        # a sampler (a lane of the partitioned sampler) holds 4 begun samples at most
+        self.depth = max(1, min(int(depth), 3 * max(1, getattr(sampler, "lanes", 1))))
 
     def step(self, i: int):
         r, t, e = self.batches[i % len(self.batches)]

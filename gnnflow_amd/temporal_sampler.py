@@ -98,6 +98,10 @@ class TemporalSampler:
             _capi.SAMPLING_POLICY[sample_strategy], self._num_snapshots,
             float(snapshot_time_window), 1 if prop_time else 0, int(seed)))
         self._is_static = bool(kwargs.get('is_static', False))
+        self._ctor = dict(fanouts=list(self._fanouts), sample_strategy=sample_strategy,
+                          num_snapshots=self._num_snapshots,
+                          snapshot_time_window=float(snapshot_time_window),
+                          prop_time=bool(prop_time), seed=int(seed), is_static=self._is_static)
         self._bytes_cache = {}
         self._inflight = deque()       # PendingSamples, oldest first
         self._max_inflight = 4         # gf::Sampler::kMaxInFlight
@@ -109,6 +113,12 @@ class TemporalSampler:
         if h is not None and h.value:
             self._lib.gf_sampler_destroy(h)
             self._h = None
+
+    def clone(self) -> "TemporalSampler":
+        """A second sampler over the same graph with the same arguments: its own native
+        workspace, publish ring and draw counter, so the two can have samples in flight on
+        different streams at once (the lanes of gnnflow_amd.dist.DevicePartitionedSampler)."""
+        return TemporalSampler(self._graph, **self._ctor)
 
     # ---- helpers ------------------------------------------------------------------
     def _to_device(self, target_vertices, timestamps, stream=None):

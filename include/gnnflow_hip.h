@@ -528,6 +528,15 @@ GF_API int gf_ipc_comm_create(gf_comm** out, int world_size, int rank, int devic
 GF_API int gf_ipc_comm_handle(gf_comm* c, uint8_t out[64]);
 GF_API int gf_ipc_comm_open(gf_comm* c, const uint8_t* handles);
 
+/* The same exchanges between "ranks" that live in ONE process (world_size handles, rank r =
+ * out[r], all on `device`): each rank is driven by its own host thread, an exchange is a thread
+ * barrier + device copies straight out of the peers' send buffers.  Host-synchronising test
+ * transport: it runs the native multi-rank chains at world sizes a one-GPU box cannot give as
+ * processes (8 ranks).  Works with every gf_comm_* / *_comm entry point except the *_async
+ * ones (one enqueue thread cannot serve ranks that wait for each other).  No reference
+ * counterpart (the reference has no distributed test). */
+GF_API int gf_loopback_comm_create(gf_comm** out, int world_size, int device);
+
 /* The slotted chain of one sample() over `c` in ONE call (and through the enqueue thread):
  * gf_sampler_part_begin_slotted, then per (layer, snapshot) plan -> request slots out -> own
  * share + serve -> reply slots back -> merge, then commit; nothing is read back.
