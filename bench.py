@@ -111,7 +111,7 @@ def parse(argv=None):
     ap.add_argument("--part-lanes", type=int, default=None,
                     help="sampling lanes of the partitioned sampler: consecutive batches go "
                          "round-robin to lanes with their own stream, workspace and communicator, "
-                         "so their exchange chains overlap (default GNNFLOW_PART_LANES or 3)")
+                         "so their exchange chains overlap (default GNNFLOW_PART_LANES or 4)")
     ap.add_argument("--shard-features", action="store_true",
                     help="hash-partitioned run: shard the feature tables by owner too "
                          "(Cache(distributed=True): missed rows are pulled from their owners); "
@@ -123,7 +123,7 @@ def parse(argv=None):
                     help="do not overlap batch i+1's sample() with batch i's fetch_feature()")
     ap.add_argument("--pipeline-depth", type=int, default=None,
                     help="batches whose sample() is in flight ahead of the fetch (default 2; "
-                         "the partitioned sampler's lanes + 1)")
+                         "twice the partitioned sampler's lanes)")
     ap.add_argument("--event-stride", type=int, default=17,
                     help="time every n-th gather launch with HIP events (1 = all)")
     ap.add_argument("--breakdown", action="store_true",
@@ -262,7 +262,8 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
     args, world, nb = ctx.args, ctx.world, ctx.nb
     depth = args.pipeline_depth
     if depth is None:
-        depth = max(2, getattr(sampler, "lanes", 1) + 1)
+        lanes = getattr(sampler, "lanes", 1)
+        depth = 2 if lanes == 1 else 2 * lanes     # two samples in flight per sampling lane
     pipe = ReplayPipeline(sampler, cache, ctx.dev_batches, ctx.dev,
                           pipelined=cache is not None and not args.no_pipeline, depth=depth)
 

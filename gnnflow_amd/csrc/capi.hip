@@ -248,6 +248,8 @@ class EnqueueWorker {
 using gf::guarded;
 
 namespace gf {
+// sampler.hip
+void part_host_us(double out[8], bool reset);
 // partition.hip
 size_t partition_scratch_bytes(size_t R, int world_size);
 void partition_plan(const int64_t* d_nodes, const float* d_ts, size_t R, int world_size, int rank,
@@ -421,7 +423,8 @@ int gf_sampler_sample_end(gf_sampler* s, gf_block* blocks) {
     s->begin_tickets.pop_front();
     if (t) {   // begun through the enqueue thread: wait for the enqueue of THIS sample
       std::string err;
-      const int rc = gf::EnqueueWorker::get(1).wait(t, &err);
+      // bit 63: the job went to the fetch lane's thread (the chains of a communicator)
+      const int rc = gf::EnqueueWorker::get((t >> 63) ? 0 : 1).wait(t & ~(1ull << 63), &err);
       if (rc != GF_OK) { gf::set_last_error(err); return rc; }
     }
   }
@@ -899,7 +902,19 @@ int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c, const in
     gf::Exchange* comm = &c->impl;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool ov = overlap != 0;
-    s->begin_tickets.push_back(gf::EnqueueWorker::get(1).submit(
+    // The chain of a sample over a communicator is ~11 stream operations, collectives among
+    // them, and the pipelined loop is bound by the host time of issuing them.  Two issuing
+    // threads slow each other down here (measured, one rank over RCCL, 3 lanes: the chain's
+    // issue time 40 us with one thread for chains AND fetches, 63-83 us with a thread each;
+    // step 53 vs 72-84 us), so the chains share the fetch lane's thread.  It also keeps ONE
+    // global order of everything that is enqueued, on every rank.  GNNFLOW_PART_OWN_THREAD=1:
+    // the sampling lane's own thread.
+    static const int lane = [] {
+      const char* v = std::getenv("GNNFLOW_PART_OWN_THREAD");
+      return (v && std::atoi(v) != 0) ? 1 : 0;
+    }();
+    const uint64_t mark = lane == 0 ? (1ull << 63) : 0;
+    s->begin_tickets.push_back(mark | gf::EnqueueWorker::get(lane).submit(
         [impl, comm, d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws, ws_bytes, slack,
          slot_roots, ov, st]() {
           impl->sample_partitioned_slotted(d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws,
@@ -967,6 +982,12 @@ int gf_block_reduce_max_backward(size_t num_dst, const int64_t* d_col, size_t di
   });
 }
 
+int gf_debug_part_host_us(double* out, int reset) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_debug_part_host_us: null output");
+    gf::part_host_us(out, reset != 0);
+  });
+}
 int gf_profile_enable(int mask) {
   std::lock_guard<std::mutex> lk(gf::g_prof_mu);
   gf::g_prof_mask = static_cast<unsigned>(mask);

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(1024) void partition_scan_kernel(
         requests[2 * static_cast<uint64_t>(o) * stride + 1] = ovf;
       }
       if (overflow_store) *d_overflow = ovf;
-      else if (ovf) *d_overflow = 1;
+      else if (ovf) atomicOr(d_overflow, 1u);
     } else {
       uint32_t at = 0;
       for (uint32_t o = 0; o < P; ++o)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
           requests[2 * static_cast<uint64_t>(o) * stride + 1] = ovf;
         }
         if (overflow_store) *d_overflow = ovf;
-        else if (ovf) *d_overflow = 1;
+        else if (ovf) atomicOr(d_overflow, 1u);
       }
     } else {
       uint32_t at = 0;

@@ -34,6 +34,8 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -757,7 +759,7 @@ __device__ inline void padded_job(const GraphView& g, const PaddedCommon& c, Pad
     if (inbox) {
       const uint64_t q = r / stride, jj = r - q * stride;
       if (jj == 0) {
-        if (lane == 0 && (req[2 * r + 1] & 1)) *j.d_overflow = 1;
+        if (lane == 0 && (req[2 * r + 1] & 1)) atomicOr(j.d_overflow, 1u);
         continue;
       }
       const uint64_t rows = static_cast<uint64_t>(req[2 * q * stride]);
@@ -1024,6 +1026,123 @@ __global__ __launch_bounds__(kEmitThreads) void merge_emit_prefix_kernel(
   }
   if (t_last == total - 1 && tid == static_cast<int>(nroots) - 1) {
     const uint64_t S = static_cast<uint64_t>(lbase[tid]) + mine;
+    *out_R = R;
+    *out_S = S;
+    if (next_R) *next_R = R + S;
+  }
+}
+
+// Slotted layout, small layers: the whole merge in ONE launch.  The slots of the layer, in
+// (root, slot) order, are compacted: thread t owns slot (r, j) = (t / fanout, t % fanout), which
+// is valid iff root r has a reply row (pos[r] is not a slot's header row = the root fitted its
+// owner's slot) and that row's slot j holds an edge; its place in the output is the number of
+// valid slots before it.  The prefix over the workgroups' tiles travels through 8-byte granules
+// {launch tag, tile count}: every workgroup publishes its tile's count with ONE relaxed
+// agent-scope store before it looks at anybody else's, then adds up the granules of the tiles
+// before its own (decoupled look-back; a granule is one naturally aligned sc1 store / sc1 load,
+// so no fence is needed: /opt/skills/guides MI355X_MICROARCH "granule").  Tiles are dispatched in
+// index order per XCD, so the lowest unfinished tile never waits for an undispatched one.  A
+// poll that does not see its granule within kGranuleSpins tries gives up and flags the sample as
+// overflowed — it is then sampled again through the variable-size exchange (never a hang).
+// Replaces merge_count_slots_kernel + merge_emit_prefix_kernel: the chain of a sample is bound
+// by the host thread that issues its launches, so one launch less per layer is ~3 us per sample.
+constexpr uint64_t kGranuleCountMask = 0x3FF;      // a tile has kEmitThreads = 256 slots
+constexpr uint32_t kGranuleSpins = 1u << 24;
+__global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_kernel(
+    const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t fanout,
+    const int64_t* __restrict__ rep, const uint32_t* __restrict__ pos, uint32_t stride,
+    uint32_t world, uint64_t* granules, uint64_t tag, uint32_t* d_overflow,
+    int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
+    int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col,
+    uint64_t* out_R, uint64_t* out_S, uint64_t* next_R) {
+  __shared__ uint32_t wave_cnt[kEmitThreads / 64];
+  __shared__ uint32_t red[kEmitThreads / 64];
+  const uint64_t R = d_R ? *d_R : R_host;
+  const uint64_t total = R * fanout;
+  if (total == 0) {   // nobody owns "the last slot": workgroup 0 reports the empty block
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *out_R = 0;
+      *out_S = 0;
+      if (next_R) *next_R = 0;
+    }
+    return;
+  }
+  const uint64_t t0 = static_cast<uint64_t>(blockIdx.x) * kEmitThreads;
+  if (t0 >= total) return;   // uniform for the workgroup; no tile behind it exists either
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t t = t0 + tid;
+  bool valid = false;
+  uint32_t r = 0;
+  int64_t s0 = 0, s1 = 0;
+  uint64_t packed = 0;
+  if (t < total) {
+    r = static_cast<uint32_t>(t / fanout);
+    const uint32_t j = static_cast<uint32_t>(t - static_cast<uint64_t>(r) * fanout);
+    const uint32_t p = pos[r];
+    if (!(p < world * stride && p % stride == 0)) {
+      const int64_t* s = rep + (static_cast<uint64_t>(p) * fanout + j) * 3;
+      s0 = s[0];
+      valid = s0 >= 0;
+      if (valid) {
+        s1 = s[1];
+        packed = static_cast<uint64_t>(s[2]);
+      }
+    }
+  }
+  const uint64_t ballot = __ballot(valid);
+  const uint32_t before = static_cast<uint32_t>(__popcll(ballot & ((1ull << lane) - 1ull)));
+  if (lane == 0) wave_cnt[wave] = static_cast<uint32_t>(__popcll(ballot));
+  __syncthreads();
+  uint32_t tile_cnt = 0, wbase = 0;
+#pragma unroll
+  for (int w = 0; w < kEmitThreads / 64; ++w) {
+    if (w < wave) wbase += wave_cnt[w];
+    tile_cnt += wave_cnt[w];
+  }
+  if (tid == 0)
+    __hip_atomic_store(&granules[blockIdx.x], tag | tile_cnt, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // look-back: the tiles before this one
+  uint32_t part = 0;
+  for (uint32_t b = tid; b < blockIdx.x; b += kEmitThreads) {
+    uint64_t g = 0;
+    uint32_t spins = 0;
+    for (;;) {
+      g = __hip_atomic_load(&granules[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((g & ~kGranuleCountMask) == tag) break;
+      if (++spins == kGranuleSpins) {   // never a hang: the sample is redone
+        atomicOr(d_overflow, 4u);
+        g = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    part += static_cast<uint32_t>(g & kGranuleCountMask);
+  }
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  uint32_t base = 0;
+#pragma unroll
+  for (int w = 0; w < kEmitThreads / 64; ++w) base += red[w];
+  if (t < total) {
+    if (t < R) {
+      all_nodes[t] = roots[t];
+      all_ts[t] = root_ts[t];
+    }
+    if (valid) {
+      const uint64_t o = static_cast<uint64_t>(base) + wbase + before;
+      all_nodes[R + o] = s0;
+      all_ts[R + o] = __uint_as_float(static_cast<uint32_t>(packed));
+      dt[o] = __uint_as_float(static_cast<uint32_t>(packed >> 32));
+      eids[o] = s1;
+      row[o] = static_cast<int64_t>(r);
+      col[o] = static_cast<int64_t>(R + o);
+    }
+  }
+  if (t0 + kEmitThreads >= total && tid == 0) {   // the tile with the last slot
+    const uint64_t S = static_cast<uint64_t>(base) + tile_cnt;
     *out_R = R;
     *out_S = S;
     if (next_R) *next_R = R + S;
@@ -1435,7 +1554,13 @@ void Sampler::sample_end(gf_block* blocks) {
     o.num_src_nodes = o.num_dst_nodes + o.num_edges;
   }
   last_overflow_ = hc[2 * L * NS] != 0;
+  const bool granule_timeout = (hc[2 * L * NS] & 4) != 0;
   pop();
+  // merge_slots_fused_kernel gave up waiting for another workgroup's granule: the blocks are
+  // garbage.  Not expected to happen; reported instead of handed on (GNNFLOW_PART_FUSED_MERGE=0
+  // takes the two-launch merge)
+  if (granule_timeout)
+    throw Error(GF_ERR_HIP, "partitioned merge: a look-back granule did not arrive (fused merge)");
 }
 
 void Sampler::sample(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
@@ -1566,6 +1691,8 @@ void Sampler::merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, 
   block->num_src_nodes = hc[0] + hc[1];
 }
 
+std::atomic<uint64_t> g_part_host_ns[8];
+
 // ---- partitioned sampling, chained on the device ------------------------------------------
 // part_begin -> for every (layer, snapshot): part_plan_own, [the caller's exchange: request
 // all-to-all-v, sample_layer_padded for what it received, reply all-to-all-v], part_merge ->
@@ -1687,6 +1814,18 @@ bool Sampler::part_own_counts(size_t root_bound) const {
   return fused_scan_ && root_bound <= kSmallRoots && root_bound > 0;
 }
 
+// Slotted form, layers of <= kSmallRoots roots: the merge is ONE launch (merge_slots_fused_kernel);
+// neither the per-root counts nor root_of[] are needed then.  GNNFLOW_PART_FUSED_MERGE=0: the
+// count + emit pair.
+bool Sampler::part_fused_merge(size_t root_bound, uint32_t fanout) const {
+  static const bool on = [] {
+    const char* v = std::getenv("GNNFLOW_PART_FUSED_MERGE");
+    return !(v && std::atoi(v) == 0);
+  }();
+  return on && part_.slack > 0.0 && part_own_counts(root_bound) && fanout <= kEmitThreads &&
+         (root_bound * fanout + kEmitThreads - 1) / kEmitThreads <= ws_roots_;
+}
+
 uint64_t* Sampler::part_counts() const {
   return reinterpret_cast<uint64_t*>(ws_.as<char>() + align_up(ws_roots_ * 8, 16) +
                                      3 * align_up(ws_roots_ * 4, 16));
@@ -1736,7 +1875,9 @@ void Sampler::part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_
                        reinterpret_cast<int64_t*>(w + lay.requests),
                        reinterpret_cast<uint32_t*>(w + lay.pos), d_counts, w + lay.scratch,
                        lay.scratch_bytes, graph_->device(), stream,
-                       part_own_counts(layer == 0 ? part_.R : Rb) ? part_root_of() : nullptr,
+                       (part_own_counts(layer == 0 ? part_.R : Rb) &&
+                        !part_fused_merge(layer == 0 ? part_.R : Rb, fanouts_[layer]))
+                           ? part_root_of() : nullptr,
                        stride, stride ? part_overflow() : nullptr,
                        layer == 0 && snapshot == 0 ? 1 : 0);
   }
@@ -1758,7 +1899,8 @@ void Sampler::part_plan_own(uint32_t layer, uint32_t snapshot, void* d_ws, size_
                   prop_time_ ? 1 : 0, seed_, call, reinterpret_cast<int64_t*>(w + lay.replies),
                   static_cast<const uint64_t*>(d_counts + part_.rank), d_R,
                   static_cast<uint64_t>(R_host), static_cast<const uint32_t*>(part_root_of()),
-                  part_own_counts(n_bound) ? part_rec_cnt() : static_cast<uint32_t*>(nullptr),
+                  (part_own_counts(n_bound) && !part_fused_merge(n_bound, F))
+                      ? part_rec_cnt() : static_cast<uint32_t*>(nullptr),
                   stride, static_cast<uint32_t>(part_.world), static_cast<uint32_t*>(nullptr));
     GF_HIP(hipGetLastError());
   }
@@ -1802,7 +1944,8 @@ void Sampler::part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
     const PaddedJob own{reinterpret_cast<const int64_t*>(w + lay.requests), 0, call_own,
                         reinterpret_cast<int64_t*>(w + lay.replies), d_counts + part_.rank, d_R,
                         R_host, part_root_of(),
-                        part_own_counts(n_bound) ? part_rec_cnt() : nullptr, stride,
+                        (part_own_counts(n_bound) && !part_fused_merge(n_bound, F))
+                            ? part_rec_cnt() : nullptr, stride,
                         static_cast<uint32_t>(part_.world), nullptr};
     ProfileScope ps(kProfSearch, stream);
     launch_padded_pair(width, grid, stream, view_for(graph_, n_max), pc, serve, own);
@@ -1854,6 +1997,19 @@ void Sampler::part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
     return;
   }
   ProfileScope ps(kProfEmit, stream);
+  if (lay.slot_stride && part_fused_merge(Rb, F)) {
+    // granules: the workspace's rec_end array (8 B per root, unused by the partitioned path)
+    const unsigned egrid = static_cast<unsigned>(
+        (static_cast<uint64_t>(Rb) * F + kEmitThreads - 1) / kEmitThreads);
+    const uint64_t tag = (++merge_epoch_) << 10;
+    merge_slots_fused_kernel<<<dim3(egrid), dim3(kEmitThreads), 0, stream>>>(
+        roots, ts, d_R, R_host, F, rep, pos, static_cast<uint32_t>(lay.slot_stride),
+        static_cast<uint32_t>(part_.world), reinterpret_cast<uint64_t*>(ws_.as<char>()), tag,
+        part_overflow(), out.all_nodes, out.all_ts, out.dt, out.eids, out.row, out.col, slot,
+        slot + 1, next_R);
+    GF_HIP(hipGetLastError());
+    return;
+  }
   if (part_own_counts(Rb)) {
     // rec_cnt lives in the sampler workspace; the own share's counts are already there
     // (part_plan_own phase 2), the rows received from other ranks are counted here; the emit
@@ -1964,7 +2120,19 @@ void Sampler::sample_partitioned_slotted(const int64_t* d_roots, const float* d_
                                          Exchange& ex, bool overlap, hipStream_t stream) {
   const size_t L = fanouts_.size(), NS = num_snapshots_;
   GF_REQUIRE(slack > 0.0, "sample_partitioned_slotted: slack must be positive");
+  // host time of the issuing thread per stage (gf_debug_part_host_us): the chain is ~13 stream
+  // operations issued by ONE thread, which is what bounds its throughput at batch 600
+  using clk = std::chrono::steady_clock;
+  auto t_prev = clk::now();
+  auto lap = [&](int stage) {
+    const auto t = clk::now();
+    g_part_host_ns[stage].fetch_add(
+        std::chrono::duration_cast<std::chrono::nanoseconds>(t - t_prev).count(),
+        std::memory_order_relaxed);
+    t_prev = t;
+  };
   part_begin(d_roots, d_ts, R, d_out, out_bytes, ex.world(), ex.rank(), slack, slot_roots, stream);
+  lap(0);
   try {
     char* w = static_cast<char*>(d_ws);
     size_t off = 0;
@@ -1978,6 +2146,7 @@ void Sampler::sample_partitioned_slotted(const int64_t* d_roots, const float* d_
         char* b = w + off;
         const uint32_t li = static_cast<uint32_t>(l), si = static_cast<uint32_t>(s);
         part_plan_own(li, si, b, lay.total, 1);
+        lap(1);
         if (overlap) {
           ex.all_to_all_forked(b + lay.requests, b + lay.inbox, slot_rows * 16, stream);
           part_plan_own(li, si, b, lay.total, 2);
@@ -1985,21 +2154,37 @@ void Sampler::sample_partitioned_slotted(const int64_t* d_roots, const float* d_
         } else {
           ex.all_to_all(b + lay.requests, b + lay.inbox, slot_rows * 16, stream);
         }
+        lap(2);
         part_serve(li, si, b, lay.total, /*with_own=*/!overlap);
+        lap(3);
         if (overlap) {   // one communicator, one stream: the reply exchange goes there too
           ex.all_to_all_forked(b + lay.served, b + lay.replies, slot_rows * F * 24, stream);
           ex.join(stream);
         } else {
           ex.all_to_all(b + lay.served, b + lay.replies, slot_rows * F * 24, stream);
         }
+        lap(4);
         part_merge(li, si, b, lay.total);
+        lap(5);
         off += lay.total;
       }
     }
     part_commit();
+    lap(6);
+    g_part_host_ns[7].fetch_add(1, std::memory_order_relaxed);   // samples
   } catch (...) {
     part_abort();
     throw;
+  }
+}
+
+// Host time the issuing thread spent per stage of the slotted chain since the last reset:
+// out[0..6] = begin, plan, request exchange, serve, reply exchange, merge, commit (us, summed
+// over all samples), out[7] = samples.
+void part_host_us(double out[8], bool reset) {
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t v = reset ? g_part_host_ns[i].exchange(0) : g_part_host_ns[i].load();
+    out[i] = i < 7 ? v / 1e3 : static_cast<double>(v);
   }
 }
 

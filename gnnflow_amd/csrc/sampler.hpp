@@ -138,6 +138,9 @@ class Sampler {
   uint32_t* part_rec_cnt() const;
   uint32_t* part_root_of() const;
   bool part_own_counts(size_t root_bound) const;
+  // slotted form, small layers: count + prefix + emit of the merge in ONE launch (granules)
+  bool part_fused_merge(size_t root_bound, uint32_t fanout) const;
+  uint64_t merge_epoch_ = 0;   // tag of the look-back granules of the fused merge
   void part_roots(uint32_t layer, uint32_t snapshot, const int64_t** roots, const float** ts,
                   const uint64_t** d_R, uint64_t* R_host) const;
   InFlight ring_[kMaxInFlight];

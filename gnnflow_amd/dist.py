@@ -548,7 +548,7 @@ class DevicePartitionedSampler:
         cost far more than the ~6 us own-share kernel they hide (one rank over RCCL, every
         message empty: 268 us per step with them, 116 us with everything in the sampling
         stream; profiles/r03_part_bench_one_gpu.jsonl).
-        lanes: sampling lanes (default GNNFLOW_PART_LANES or 3 with more than one rank /
+        lanes: sampling lanes (default GNNFLOW_PART_LANES or 4 with more than one rank /
         always_exchange, else 1).  A lane is used only by `sample_async(..., stream=...)` calls
         that name a stream (the pipelined loop); `sample()` always runs on lane 0."""
         import ctypes as C
@@ -576,7 +576,7 @@ class DevicePartitionedSampler:
             overlap = os.environ.get("GNNFLOW_PART_OVERLAP", "0") != "0"
         self._overlap = bool(overlap)
         if lanes is None:
-            lanes = int(os.environ.get("GNNFLOW_PART_LANES", "3"))
+            lanes = int(os.environ.get("GNNFLOW_PART_LANES", "4"))
         if (self._P == 1 and not self._always_exchange) or self._slack <= 0:
             lanes = 1        # no exchange chain to overlap / host-synchronising exchange
         if comms and comms[0].transport in ("ipc", "loopback"):
@@ -668,7 +668,9 @@ class DevicePartitionedSampler:
         if k == 0:
             return lane, stream
         if lane.stream is None:
-            lane.stream = torch.cuda.Stream(device=self._device)
+            import os
+            prio = int(os.environ.get("GNNFLOW_PART_LANE_PRIORITY", "0"))
+            lane.stream = torch.cuda.Stream(device=self._device, priority=prio)
         return lane, lane.stream
 
     def sample_async(self, nodes, ts, stream=None, worker_enqueue=False):

@@ -12,6 +12,7 @@ the GPU.  Every batch goes through the same calls as the plain loop; nothing is 
 bench.py times this loop and tests/test_gpu_pipeline_parity.py checks THIS loop — the same
 function — against the CPU oracle, so the path that is measured is the path that is tested.
 """
+import os
 from collections import deque
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -39,7 +40,12 @@ class ReplayPipeline:
             hasattr(sampler, "sample_async")
         self.side = torch.cuda.Stream(device=self.device) if self.pipelined else None
         # a sampler (a lane of the partitioned sampler) holds 4 begun samples at most
-        self.depth = max(1, min(int(depth), 3 * max(1, getattr(sampler, "lanes", 1))))
+        self.depth = max(1, min(int(depth), 3 * max(1, getattr(self.sampler, "lanes", 1))))
+        # GNNFLOW_PIPELINE_FETCH_FIRST=1: submit batch i's fetch before the sample of batch
+        # i + depth (the chains of a partitioned sampler over a communicator share the fetches'
+        # issuing thread; measured: no consistent difference, profiles/README.md round 4)
+        ff = os.environ.get("GNNFLOW_PIPELINE_FETCH_FIRST")
+        self.fetch_first = ff is not None and ff != "0"
 
     def step(self, i: int):
         r, t, e = self.batches[i % len(self.batches)]
@@ -71,9 +77,10 @@ class ReplayPipeline:
             r, t, _ = batches[nxt % nb]
             pending.append(sampler.sample_async(r, t, stream=side, worker_enqueue=True))
             nxt += 1
+        fetch_first = self.fetch_first
         for i in range(first, last):
             mfgs = pending.popleft().wait()
-            if nxt < last:
+            if nxt < last and not fetch_first:
                 r, t, _ = batches[nxt % nb]
                 pending.append(sampler.sample_async(r, t, stream=side, worker_enqueue=True))
                 nxt += 1
@@ -81,6 +88,10 @@ class ReplayPipeline:
                 for b in mfg:
                     b.record_stream(main)
             cache.fetch_feature(mfgs, batches[i % nb][2], async_enqueue=True)
+            if nxt < last and fetch_first:
+                r, t, _ = batches[nxt % nb]
+                pending.append(sampler.sample_async(r, t, stream=side, worker_enqueue=True))
+                nxt += 1
             if on_step:
                 on_step(i % nb, mfgs)
         cache.wait_enqueued()

@@ -611,6 +611,11 @@ GF_API int gf_profile_get(int which, double* total_ms, uint64_t* launches);
  * host time and a few microseconds of stream time per launch, which a latency-bound
  * workload feels; gf_profile_get then reports the sampled intervals. */
 GF_API int gf_profile_set_stride(unsigned stride);
+/* Host time the issuing thread spent per stage of the slotted partitioned chain since the last
+ * reset: out[0..6] = begin, plan, request exchange, serve, reply exchange, merge, commit
+ * (microseconds, summed over the samples), out[7] = samples.  Diagnostics: the chain is ~13
+ * stream operations issued by one thread, which bounds its throughput at small batches. */
+GF_API int gf_debug_part_host_us(double out[8], int reset);
 /* All launches of a family seen since the last reset while it was enabled, timed or not. */
 GF_API int gf_profile_launches(int which, uint64_t* launches);
 
