@@ -279,13 +279,15 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
     steps = args.steps if main_leg else nb
     repeats = args.repeats if (main_leg and args.repeats > 0) else 0
     if repeats == 0:
-        # calibration: the mean step time of one whole replay (15 % on top: the timed region
+        # calibration: the mean step time of a whole replay (15 % on top: the timed region
         # must not end up just short of --min-seconds)
-        ctx.barrier()
-        t0 = time.perf_counter()
-        pipe.run(0, nb)
-        ctx.barrier()
-        t_step = reduce((time.perf_counter() - t0) / nb, dist.ReduceOp.MAX)
+        t_step = None
+        for _ in range(2):      # the first replay still grows buffers: the second one counts
+            ctx.barrier()
+            t0 = time.perf_counter()
+            pipe.run(0, nb)
+            ctx.barrier()
+            t_step = reduce((time.perf_counter() - t0) / nb, dist.ReduceOp.MAX)
         need = max(min_replays * nb, 1.15 * min_seconds / max(t_step, 1e-7))
         repeats = max(1, -(-int(need) // max(steps, 1)))
     timed_steps = steps * repeats

@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=${1:-r02}
 shift
-ARGS="${*:---batches 60000,300000 --policies uniform --reps 3}"
+ARGS="${*:---batches 60000,600000 --policies uniform --reps 2}"
 mkdir -p gpurun_out/pmc
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc -o ${TAG}_c3_$C -- python3 scripts/config3_bench.py $ARGS > gpurun_out/pmc/${TAG}_c3_$C.log 2>&1
