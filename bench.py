@@ -111,7 +111,7 @@ def parse(argv=None):
     ap.add_argument("--part-lanes", type=int, default=None,
                     help="sampling lanes of the partitioned sampler: consecutive batches go "
                          "round-robin to lanes with their own stream, workspace and communicator, "
-                         "so their exchange chains overlap (default GNNFLOW_PART_LANES or 4)")
+                         "so their exchange chains overlap (default GNNFLOW_PART_LANES or 2)")
     ap.add_argument("--shard-features", action="store_true",
                     help="hash-partitioned run: shard the feature tables by owner too "
                          "(Cache(distributed=True): missed rows are pulled from their owners); "
@@ -123,7 +123,7 @@ def parse(argv=None):
                     help="do not overlap batch i+1's sample() with batch i's fetch_feature()")
     ap.add_argument("--pipeline-depth", type=int, default=None,
                     help="batches whose sample() is in flight ahead of the fetch (default 2; "
-                         "twice the partitioned sampler's lanes)")
+                         "three per lane of the partitioned sampler)")
     ap.add_argument("--event-stride", type=int, default=17,
                     help="time every n-th gather launch with HIP events (1 = all)")
     ap.add_argument("--breakdown", action="store_true",
@@ -263,7 +263,9 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
     depth = args.pipeline_depth
     if depth is None:
         lanes = getattr(sampler, "lanes", 1)
-        depth = 2 if lanes == 1 else 2 * lanes     # two samples in flight per sampling lane
+        # partitioned sampler: three samples per lane (a chain carries two, one more is held
+        # for its partner or already in flight)
+        depth = 2 if lanes == 1 else 3 * lanes
     pipe = ReplayPipeline(sampler, cache, ctx.dev_batches, ctx.dev,
                           pipelined=cache is not None and not args.no_pipeline, depth=depth)
 
@@ -666,6 +668,9 @@ def exchange_note(sampler, world, backend):
     lanes = getattr(sampler, "lanes", 1)
     lane_note = "; {} sampling lanes (stream + workspace + communicator each), consecutive " \
                 "batches round-robin".format(lanes) if lanes > 1 else ""
+    if getattr(sampler, "pairs", 0):
+        lane_note += "; {} chains carried two samples each (shared launches and " \
+                     "exchanges)".format(sampler.pairs)
     comm = getattr(sampler, "_comm", None)
     if getattr(sampler, "_slack", 0) > 0 and comm is not None and comm.transport == "ipc":
         return ("2 equal-split exchanges per layer over the library's hipIpc transport (ranks "

@@ -922,6 +922,72 @@ int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c, const in
         }));
   });
 }
+int gf_sampler_part_pair_ws_bytes(const gf_sampler* s, size_t roots_a, size_t roots_b,
+                                  int world_size, double slack, size_t slot_roots, size_t* bytes) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr && bytes != nullptr, "part_pair_ws_bytes: null argument");
+    GF_REQUIRE(world_size >= 1 && world_size <= 32, "pair: world size must be 1..32");
+    *bytes = (slack > 0.0 && s->impl.pair_ok(roots_a, roots_b))
+                 ? gf::Sampler::pair_ws_bytes(s->impl, roots_a, roots_b, world_size, slack,
+                                              slot_roots)
+                 : 0;
+  });
+}
+int gf_sampler_sample_partitioned_comm_pair(gf_sampler* sa, gf_sampler* sb, gf_comm* c,
+                                            const int64_t* d_roots_a, const float* d_ts_a,
+                                            size_t roots_a, void* d_out_a, size_t out_bytes_a,
+                                            const int64_t* d_roots_b, const float* d_ts_b,
+                                            size_t roots_b, void* d_out_b, size_t out_bytes_b,
+                                            void* d_ws, size_t ws_bytes, double slack,
+                                            size_t slot_roots, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(sa != nullptr && sb != nullptr && c != nullptr, "null sampler / communicator handle");
+    for (gf_sampler* s : {sa, sb})
+      GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
+                 "sample_partitioned_comm_pair: earlier samples were begun through the enqueue thread");
+    gf::Sampler::sample_partitioned_pair(sa->impl, d_roots_a, d_ts_a, roots_a, d_out_a, out_bytes_a,
+                                         sb->impl, d_roots_b, d_ts_b, roots_b, d_out_b, out_bytes_b,
+                                         d_ws, ws_bytes, slack, slot_roots, c->impl,
+                                         static_cast<hipStream_t>(stream));
+    sa->begin_tickets.push_back(0);
+    sb->begin_tickets.push_back(0);
+  });
+}
+int gf_sampler_sample_partitioned_comm_pair_async(gf_sampler* sa, gf_sampler* sb, gf_comm* c,
+                                                  const int64_t* d_roots_a, const float* d_ts_a,
+                                                  size_t roots_a, void* d_out_a, size_t out_bytes_a,
+                                                  const int64_t* d_roots_b, const float* d_ts_b,
+                                                  size_t roots_b, void* d_out_b, size_t out_bytes_b,
+                                                  void* d_ws, size_t ws_bytes, double slack,
+                                                  size_t slot_roots, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(sa != nullptr && sb != nullptr && c != nullptr, "null sampler / communicator handle");
+    GF_REQUIRE(!c->loopback, "sample_partitioned_comm_pair_async: a loopback communicator's ranks "
+                             "are threads (use the synchronous call)");
+    for (gf_sampler* s : {sa, sb})
+      GF_REQUIRE(s->begin_tickets.size() < gf::Sampler::kMaxInFlight,
+                 "sample_partitioned_comm_pair_async: too many samples in flight on a sampler");
+    gf::Sampler* ia = &sa->impl;
+    gf::Sampler* ib = &sb->impl;
+    gf::Exchange* comm = &c->impl;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static const int lane = [] {
+      const char* v = std::getenv("GNNFLOW_PART_OWN_THREAD");
+      return (v && std::atoi(v) != 0) ? 1 : 0;
+    }();
+    const uint64_t mark = lane == 0 ? (1ull << 63) : 0;
+    // ONE job for both samples: both tickets are this job's
+    const uint64_t t = mark | gf::EnqueueWorker::get(lane).submit(
+        [=]() {
+          gf::Sampler::sample_partitioned_pair(*ia, d_roots_a, d_ts_a, roots_a, d_out_a,
+                                               out_bytes_a, *ib, d_roots_b, d_ts_b, roots_b,
+                                               d_out_b, out_bytes_b, d_ws, ws_bytes, slack,
+                                               slot_roots, *comm, st);
+        });
+    sa->begin_tickets.push_back(t);
+    sb->begin_tickets.push_back(t);
+  });
+}
 int gf_block_segment_offsets(const int64_t* d_row, size_t num_edges, size_t num_dst,
                              int64_t* d_offsets, int device, void* stream) {
   return guarded([&] {

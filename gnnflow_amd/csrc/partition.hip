@@ -22,6 +22,7 @@
 // through the variable-size exchange.
 #include "common.hpp"
 #include "owner_hash.hpp"
+#include "partition.hpp"
 
 #include <cstdint>
 #include <cstdlib>
@@ -163,12 +164,14 @@ __global__ __launch_bounds__(kTileThreads) void partition_scatter_kernel(
 constexpr int kFusedThreads = 1024;
 constexpr uint32_t kFusedPlanRoots = 32768;
 
-__global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
+// slot_mul / slot_add / own_base: several samples sharing one request buffer (PlanJob); a single
+// sample: 1, 0, P * stride.
+__device__ inline void plan_fused_body(
     const int64_t* __restrict__ nodes, const float* __restrict__ ts,
     const uint64_t* __restrict__ d_R, uint64_t R_host, OwnerDiv od, uint32_t rank,
     int64_t* __restrict__ requests, uint32_t* __restrict__ pos, uint64_t* __restrict__ counts,
     uint32_t* __restrict__ root_of, uint32_t stride, uint32_t* __restrict__ d_overflow,
-    int overflow_store) {
+    int overflow_store, uint32_t slot_mul, uint32_t slot_add, uint32_t own_base) {
   const uint32_t P = od.P;
   __shared__ uint32_t s_before[kFusedThreads / 64][kMaxParts];
   __shared__ uint32_t s_total[kFusedThreads / 64][kMaxParts];
@@ -236,14 +239,14 @@ __global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
       const uint32_t cap = stride - 1;
       uint32_t ovf = 0;
       for (uint32_t o = 0; o < P; ++o) {
-        s_start[o] = o == rank ? P * stride : o * stride + 1;
+        s_start[o] = o == rank ? own_base : (o * slot_mul + slot_add) * stride + 1;
         if (o != rank && s_total[0][o] > cap) ovf = 1;
       }
       if (tile == 0) {   // the slots' headers; the sample-wide flag
         for (uint32_t o = 0; o < P; ++o) {
-          requests[2 * static_cast<uint64_t>(o) * stride] =
-              o == rank ? 0 : static_cast<int64_t>(min(s_total[0][o], cap));
-          requests[2 * static_cast<uint64_t>(o) * stride + 1] = ovf;
+          const uint64_t h = static_cast<uint64_t>(o * slot_mul + slot_add) * stride;
+          requests[2 * h] = o == rank ? 0 : static_cast<int64_t>(min(s_total[0][o], cap));
+          requests[2 * h + 1] = ovf;
         }
         if (overflow_store) *d_overflow = ovf;
         else if (ovf) atomicOr(d_overflow, 1u);
@@ -261,13 +264,33 @@ __global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
   uint32_t p = s_start[my_owner] + s_before[0][my_owner] + before_in_wave;
   for (int w = 0; w < wave; ++w) p += s_tile[w][my_owner];
   if (stride && my_owner != rank && p - s_start[my_owner] >= stride - 1) {   // beyond the slot
-    pos[i] = my_owner * stride;
+    pos[i] = (my_owner * slot_mul + slot_add) * stride;
     return;
   }
   requests[2 * static_cast<uint64_t>(p)] = my_node;
   requests[2 * static_cast<uint64_t>(p) + 1] = static_cast<int64_t>(__float_as_uint(ts[i]));
   pos[i] = p;
   if (root_of) root_of[p] = i;   // the inverse: which root a request / reply row belongs to
+}
+
+__global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
+    const int64_t* __restrict__ nodes, const float* __restrict__ ts,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, OwnerDiv od, uint32_t rank,
+    int64_t* __restrict__ requests, uint32_t* __restrict__ pos, uint64_t* __restrict__ counts,
+    uint32_t* __restrict__ root_of, uint32_t stride, uint32_t* __restrict__ d_overflow,
+    int overflow_store) {
+  plan_fused_body(nodes, ts, d_R, R_host, od, rank, requests, pos, counts, root_of, stride,
+                  d_overflow, overflow_store, 1u, 0u, od.P * stride);
+}
+
+// Up to two samples' plans in ONE launch (blockIdx.y picks the job): the chain of a
+// partitioned sample is bound by the host thread that issues its launches, so two samples that
+// share their launches and exchanges halve that cost (sampler.hip sample_partitioned_pair).
+__global__ __launch_bounds__(kFusedThreads) void partition_plan_jobs_kernel(
+    PlanJob a, PlanJob b, OwnerDiv od, uint32_t rank, uint32_t stride) {
+  const PlanJob& j = blockIdx.y == 0 ? a : b;
+  plan_fused_body(j.nodes, j.ts, j.d_R, j.R_host, od, rank, j.requests, j.pos, j.counts, nullptr,
+                  stride, j.d_overflow, j.overflow_store, j.slot_mul, j.slot_add, j.own_base);
 }
 
 }  // namespace
@@ -332,6 +355,27 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
   partition_scatter_kernel<<<dim3(static_cast<unsigned>(tiles)), dim3(kTileThreads), 0, stream>>>(
       d_nodes, d_ts, d_R, R_bound, od, tile_base, d_requests, d_pos, d_root_of, stride,
       static_cast<uint32_t>(rank));
+  GF_HIP(hipGetLastError());
+}
+
+void partition_plan_jobs(const PlanJob* jobs, int n, size_t R_bound, int world_size, int rank,
+                         uint32_t stride, int device, hipStream_t stream) {
+  GF_REQUIRE(jobs != nullptr && (n == 1 || n == 2), "partition: 1 or 2 plan jobs");
+  GF_REQUIRE(world_size >= 1 && world_size <= kMaxParts, "partition: world size must be 1..64");
+  GF_REQUIRE(stride >= 2, "partition: plan jobs need the slotted form");
+  GF_REQUIRE(rank >= 0 && rank < world_size, "partition: rank out of range");
+  GF_REQUIRE(R_bound <= kFusedPlanRoots, "partition: plan jobs are for layers of <= 32 768 roots");
+  static_assert(kPlanJobsMaxRoots == kFusedPlanRoots, "one limit");
+  for (int k = 0; k < n; ++k)
+    GF_REQUIRE(jobs[k].requests && jobs[k].pos && jobs[k].counts && jobs[k].d_overflow,
+               "partition: null pointer in a plan job");
+  DeviceGuard dg(device);
+  const OwnerDiv od = owner_div(static_cast<uint32_t>(world_size));
+  const unsigned grid = static_cast<unsigned>(
+      (std::max<size_t>(R_bound, 1) + kFusedThreads - 1) / kFusedThreads);
+  partition_plan_jobs_kernel<<<dim3(grid, static_cast<unsigned>(n)), dim3(kFusedThreads), 0,
+                               stream>>>(jobs[0], jobs[n - 1], od, static_cast<uint32_t>(rank),
+                                         stride);
   GF_HIP(hipGetLastError());
 }
 

@@ -30,6 +30,7 @@
 // "j-th most recent, spilling to the previous block" (:88-92) is index
 // end-1-j on that sequence.  tests/ proves it against the block-walking oracle.
 #include "sampler.hpp"
+#include "partition.hpp"
 
 #include <sched.h>
 
@@ -226,6 +227,15 @@ struct Publish {
 // (and released by the kernel boundary) before the host can observe the sequence word.
 __global__ void sample_publish_kernel(Publish p) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (uint32_t i = 0; i < p.num_words; ++i) p.h_counts[i] = p.d_counts[i];
+  p.h_counts[p.num_words] = p.d_extra ? *p.d_extra : 0;
+  __threadfence_system();
+  *reinterpret_cast<volatile uint64_t*>(p.h_flag) = p.seq;
+}
+
+__global__ void sample_publish_pair_kernel(Publish a, Publish b) {
+  if (threadIdx.x != 0) return;
+  const Publish& p = blockIdx.x == 0 ? a : b;
   for (uint32_t i = 0; i < p.num_words; ++i) p.h_counts[i] = p.d_counts[i];
   p.h_counts[p.num_words] = p.d_extra ? *p.d_extra : 0;
   __threadfence_system();
@@ -723,6 +733,11 @@ struct PaddedJob {
   uint32_t* rec_cnt;
   uint32_t stride, world;
   uint32_t* d_overflow;
+  // several samples sharing one exchange (sample_partitioned_pair): an own share starts at row
+  // own_skip (0: world * stride); the inbox holds `world` = P x m slots, slot v belongs to
+  // sample v % m: odd slots of a pair raise d_overflow2
+  uint64_t own_skip = 0;
+  uint32_t* d_overflow2 = nullptr;
 };
 
 // d_own != null: "this rank's own share" of a chained partitioned layer — the last *d_own
@@ -743,7 +758,7 @@ __device__ inline void padded_job(const GraphView& g, const PaddedCommon& c, Pad
   const uint32_t fanout = c.fanout, stride = j.stride;
   if (j.d_own) {
     n = *j.d_own;
-    const uint64_t skip = stride ? static_cast<uint64_t>(j.world) * stride
+    const uint64_t skip = stride ? (j.own_skip ? j.own_skip : static_cast<uint64_t>(j.world) * stride)
                                  : (j.d_total ? *j.d_total : j.total_host) - n;
     req += 2 * skip;
     out += skip * fanout * 3;
@@ -759,7 +774,8 @@ __device__ inline void padded_job(const GraphView& g, const PaddedCommon& c, Pad
     if (inbox) {
       const uint64_t q = r / stride, jj = r - q * stride;
       if (jj == 0) {
-        if (lane == 0 && (req[2 * r + 1] & 1)) atomicOr(j.d_overflow, 1u);
+        if (lane == 0 && (req[2 * r + 1] & 1))
+          atomicOr((j.d_overflow2 && (q & 1)) ? j.d_overflow2 : j.d_overflow, 1u);
         continue;
       }
       const uint64_t rows = static_cast<uint64_t>(req[2 * q * stride]);
@@ -822,6 +838,12 @@ template <int GROUP>
 __global__ __launch_bounds__(kSearchThreads) void sample_padded_pair_kernel(
     GraphView g, PaddedCommon c, PaddedJob a, PaddedJob b) {
   padded_job<GROUP>(g, c, blockIdx.y == 0 ? a : b);
+}
+// ... and three: the shared inbox of two samples and both own shares
+template <int GROUP>
+__global__ __launch_bounds__(kSearchThreads) void sample_padded_trio_kernel(
+    GraphView g, PaddedCommon c, PaddedJob a, PaddedJob b, PaddedJob d) {
+  padded_job<GROUP>(g, c, blockIdx.y == 0 ? a : (blockIdx.y == 1 ? b : d));
 }
 
 // valid slots of root i's reply row (a prefix of the row for both policies)
@@ -1048,11 +1070,26 @@ __global__ __launch_bounds__(kEmitThreads) void merge_emit_prefix_kernel(
 // by the host thread that issues its launches, so one launch less per layer is ~3 us per sample.
 constexpr uint64_t kGranuleCountMask = 0x3FF;      // a tile has kEmitThreads = 256 slots
 constexpr uint32_t kGranuleSpins = 1u << 24;
-__global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_kernel(
+struct MergeJob {
+  const int64_t* roots;
+  const float* root_ts;
+  const uint64_t* d_R;
+  uint64_t R_host;
+  const int64_t* rep;        // the (shared) reply buffer
+  const uint32_t* pos;
+  uint32_t slot_rows;        // rows of the buffer that belong to slots (P x m x stride)
+  uint64_t* granules;
+  uint64_t tag;
+  uint32_t* d_overflow;
+  int64_t* all_nodes; float* all_ts; float* dt; int64_t* eids; int64_t* row; int64_t* col;
+  uint64_t* out_R; uint64_t* out_S; uint64_t* next_R;
+};
+
+__device__ inline void merge_slots_fused_body(
     const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
     const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t fanout,
     const int64_t* __restrict__ rep, const uint32_t* __restrict__ pos, uint32_t stride,
-    uint32_t world, uint64_t* granules, uint64_t tag, uint32_t* d_overflow,
+    uint32_t slot_rows, uint64_t* granules, uint64_t tag, uint32_t* d_overflow,
     int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
     int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col,
     uint64_t* out_R, uint64_t* out_S, uint64_t* next_R) {
@@ -1080,7 +1117,7 @@ __global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_kernel(
     r = static_cast<uint32_t>(t / fanout);
     const uint32_t j = static_cast<uint32_t>(t - static_cast<uint64_t>(r) * fanout);
     const uint32_t p = pos[r];
-    if (!(p < world * stride && p % stride == 0)) {
+    if (!(p < slot_rows && p % stride == 0)) {
       const int64_t* s = rep + (static_cast<uint64_t>(p) * fanout + j) * 3;
       s0 = s[0];
       valid = s0 >= 0;
@@ -1149,6 +1186,28 @@ __global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_kernel(
   }
 }
 
+__global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_kernel(
+    const int64_t* __restrict__ roots, const float* __restrict__ root_ts,
+    const uint64_t* __restrict__ d_R, uint64_t R_host, uint32_t fanout,
+    const int64_t* __restrict__ rep, const uint32_t* __restrict__ pos, uint32_t stride,
+    uint32_t world, uint64_t* granules, uint64_t tag, uint32_t* d_overflow,
+    int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
+    int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col,
+    uint64_t* out_R, uint64_t* out_S, uint64_t* next_R) {
+  merge_slots_fused_body(roots, root_ts, d_R, R_host, fanout, rep, pos, stride, world * stride,
+                         granules, tag, d_overflow, all_nodes, all_ts, dt, eids, row, col, out_R,
+                         out_S, next_R);
+}
+
+// two samples that shared their exchange (blockIdx.y picks the job; each has its own granules)
+__global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_pair_kernel(
+    MergeJob a, MergeJob b, uint32_t fanout, uint32_t stride) {
+  const MergeJob& j = blockIdx.y == 0 ? a : b;
+  merge_slots_fused_body(j.roots, j.root_ts, j.d_R, j.R_host, fanout, j.rep, j.pos, stride,
+                         j.slot_rows, j.granules, j.tag, j.d_overflow, j.all_nodes, j.all_ts, j.dt,
+                         j.eids, j.row, j.col, j.out_R, j.out_S, j.next_R);
+}
+
 inline unsigned capped_grid(uint64_t work_items, unsigned per_block, unsigned cap) {
   uint64_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -1195,6 +1254,18 @@ void launch_padded_pair(int width, unsigned grid, hipStream_t stream, const Grap
     case 4: sample_padded_pair_kernel<4><<<gr, bl, 0, stream>>>(g, c, a, b); break;
     case 8: sample_padded_pair_kernel<8><<<gr, bl, 0, stream>>>(g, c, a, b); break;
     default: sample_padded_pair_kernel<16><<<gr, bl, 0, stream>>>(g, c, a, b); break;
+  }
+}
+
+void launch_padded_trio(int width, unsigned grid, hipStream_t stream, const GraphView& g,
+                        const PaddedCommon& c, const PaddedJob& a, const PaddedJob& b,
+                        const PaddedJob& d) {
+  const dim3 gr(grid, 3), bl(kSearchThreads);
+  switch (width) {
+    case 2: sample_padded_trio_kernel<2><<<gr, bl, 0, stream>>>(g, c, a, b, d); break;
+    case 4: sample_padded_trio_kernel<4><<<gr, bl, 0, stream>>>(g, c, a, b, d); break;
+    case 8: sample_padded_trio_kernel<8><<<gr, bl, 0, stream>>>(g, c, a, b, d); break;
+    default: sample_padded_trio_kernel<16><<<gr, bl, 0, stream>>>(g, c, a, b, d); break;
   }
 }
 
@@ -1700,14 +1771,6 @@ std::atomic<uint64_t> g_part_host_ns[8];
 // previous layer's R + S), so nothing is read back between the layers; part_commit publishes
 // the block sizes like sample_begin does and sample_end() returns them.  With one rank there
 // is no exchange and sample_partitioned() issues the whole chain in one call.
-void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_t* d_R,
-                        size_t R_bound, int world_size, int rank, int64_t* d_requests,
-                        uint32_t* d_pos, uint64_t* d_counts, void* d_scratch,
-                        size_t scratch_bytes, int device, hipStream_t stream,
-                        uint32_t* d_root_of, uint32_t stride, uint32_t* d_overflow,
-                        int overflow_store);
-size_t partition_scratch_bytes(size_t R, int world_size);
-
 void Sampler::part_layout(size_t R0, uint32_t layer, int world_size, double slack,
                           size_t slot_roots, gf_part_layout* out) const {
   GF_REQUIRE(layer < fanouts_.size(), "part_layout: layer out of range");
@@ -2059,28 +2122,37 @@ void Sampler::part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
   GF_HIP(hipGetLastError());
 }
 
-void Sampler::part_commit() {
+// the publish record of the sample being built (its pinned words are reset here)
+void Sampler::part_commit_prepare(void* publish_out) {
   GF_REQUIRE(part_.active, "part_commit: no partitioned sample is being built");
   const size_t L = fanouts_.size(), NS = num_snapshots_;
-  DeviceGuard dg(graph_->device());
   InFlight* slot = part_.slot;
-  hipStream_t stream = part_.stream;
   part_.active = false;
   slot->seq = ++publish_seq_;
   uint64_t* rec = h_counts_.as<uint64_t>() + (slot->seq % kMaxInFlight) * rec_words_;
   *reinterpret_cast<volatile uint64_t*>(rec) = 0;
-  Publish pub;
+  Publish& pub = *static_cast<Publish*>(publish_out);
   pub.d_counts = part_counts();
   pub.h_counts = rec + 1;
   pub.h_flag = rec;
   pub.seq = slot->seq;
   pub.num_words = static_cast<uint32_t>(L * NS * 2);
   pub.d_extra = part_.slack > 0.0 ? part_overflow() : nullptr;
-  sample_publish_kernel<<<dim3(1), dim3(64), 0, stream>>>(pub);
-  GF_HIP(hipGetLastError());
-  GF_HIP(hipEventRecord(slot->done, stream));
+}
+
+void Sampler::part_commit_finish() {
+  GF_HIP(hipEventRecord(part_.slot->done, part_.stream));
   std::lock_guard<std::mutex> lk(ring_mu_);
   ++ring_count_;
+}
+
+void Sampler::part_commit() {
+  DeviceGuard dg(graph_->device());
+  Publish pub;
+  part_commit_prepare(&pub);
+  sample_publish_kernel<<<dim3(1), dim3(64), 0, part_.stream>>>(pub);
+  GF_HIP(hipGetLastError());
+  part_commit_finish();
 }
 
 void Sampler::part_abort() { part_.active = false; }
@@ -2185,6 +2257,207 @@ void part_host_us(double out[8], bool reset) {
   for (int i = 0; i < 8; ++i) {
     const uint64_t v = reset ? g_part_host_ns[i].exchange(0) : g_part_host_ns[i].load();
     out[i] = i < 7 ? v / 1e3 : static_cast<double>(v);
+  }
+}
+
+// ---- two samples in ONE chain ---------------------------------------------------------------
+// The slotted chain of a sample is ~11 stream operations, and at batch 600 its throughput is
+// bound by the host thread that issues them (measured: 3-6 us each), not by the GPU.  Two
+// consecutive batches therefore SHARE their launches and exchanges: sample a (sampler `a`) and
+// sample b (sampler `b`, a clone on the same graph: its own output, counters, publish record)
+// write their requests into one buffer — owner q's rows of sample j into slot 2 q + j, so the
+// buffer is P runs of two slots and ONE equal-split all-to-all moves both —, the received
+// slots (2 P of them, served alike) and both own shares are sampled by one launch, one
+// exchange brings the replies back, one launch merges both, one publishes both: 11 operations
+// per TWO samples.  Conditions (else the caller issues two single chains): one snapshot, every
+// layer of both samples within the fused plan / fused merge limits (<= 32 768 roots,
+// fanout <= 256).  Layout of the shared workspace of layer l, rows of 16 B (requests) and
+// fanout x 24 B (replies):  [2 P slots of `stride` rows | own share a | own share b].
+size_t Sampler::pair_ws_bytes(const Sampler& a, size_t Ra, size_t Rb, int world, double slack,
+                              size_t slot_roots) {
+  size_t total = 0;
+  for (size_t l = 0; l < a.fanouts_.size(); ++l) {
+    PairLayout lay;
+    a.pair_layout(std::max<size_t>(Ra, 1), std::max<size_t>(Rb, 1), static_cast<uint32_t>(l),
+                  world, slack, slot_roots, &lay);
+    total += lay.total;
+  }
+  return total;
+}
+
+bool Sampler::pair_ok(size_t Ra, size_t Rb) const {
+  if (num_snapshots_ != 1) return false;
+  for (size_t l = 0; l < fanouts_.size(); ++l) {
+    const size_t bound = std::max(root_bound(std::max<size_t>(Ra, 1), l),
+                                  root_bound(std::max<size_t>(Rb, 1), l));
+    if (bound > kSmallRoots || bound > kPlanJobsMaxRoots || fanouts_[l] > kEmitThreads ||
+        !fused_scan_)
+      return false;
+  }
+  return true;
+}
+
+void Sampler::pair_layout(size_t Ra, size_t Rb, uint32_t layer, int world, double slack,
+                          size_t slot_roots, PairLayout* out) const {
+  gf_part_layout one;
+  part_layout(Ra, layer, world, slack, slot_roots, &one);   // for the slot stride
+  const size_t F = fanouts_[layer];
+  const size_t ba = root_bound(Ra, layer), bb = root_bound(Rb, layer);
+  const size_t slot_rows = 2 * static_cast<size_t>(world) * one.slot_stride;
+  const size_t rows = slot_rows + ba + bb;
+  GF_REQUIRE(rows < 0xFFFFFFFFull, "pair layout: more than 2^32-1 request rows");
+  out->stride = one.slot_stride;
+  out->slot_rows = slot_rows;
+  out->own_a = slot_rows;
+  out->own_b = slot_rows + ba;
+  size_t at = 0;
+  out->requests = at; at = align_up(at + rows * 16, 256);
+  out->replies = at;  at = align_up(at + rows * F * 24, 256);
+  out->inbox = at;    at = align_up(at + slot_rows * 16, 256);
+  out->served = at;   at = align_up(at + slot_rows * F * 24, 256);
+  out->counts_a = at; at = align_up(at + static_cast<size_t>(world) * 8, 256);
+  out->counts_b = at; at = align_up(at + static_cast<size_t>(world) * 8, 256);
+  out->pos_a = at;    at = align_up(at + ba * 4, 256);
+  out->pos_b = at;    at = align_up(at + bb * 4, 256);
+  out->total = at;
+}
+
+void Sampler::sample_partitioned_pair(Sampler& a, const int64_t* d_roots_a, const float* d_ts_a,
+                                      size_t Ra, void* d_out_a, size_t out_bytes_a, Sampler& b,
+                                      const int64_t* d_roots_b, const float* d_ts_b, size_t Rb,
+                                      void* d_out_b, size_t out_bytes_b, void* d_ws,
+                                      size_t ws_bytes, double slack, size_t slot_roots,
+                                      Exchange& ex, hipStream_t stream) {
+  GF_REQUIRE(&a != &b, "sample_partitioned_pair: the two samples need a sampler each");
+  GF_REQUIRE(a.graph_ == b.graph_ && a.fanouts_ == b.fanouts_ && a.policy_ == b.policy_ &&
+                 a.num_snapshots_ == b.num_snapshots_ && a.window_ == b.window_ &&
+                 a.prop_time_ == b.prop_time_ && a.seed_ == b.seed_,
+             "sample_partitioned_pair: the samplers differ");
+  GF_REQUIRE(slack > 0.0, "sample_partitioned_pair: slack must be positive");
+  GF_REQUIRE(a.pair_ok(Ra, Rb), "sample_partitioned_pair: these samples cannot share a chain");
+  const size_t L = a.fanouts_.size();
+  const int P = ex.world(), me = ex.rank();
+  using clk = std::chrono::steady_clock;
+  auto t_prev = clk::now();
+  auto lap = [&](int stage) {
+    const auto t = clk::now();
+    g_part_host_ns[stage].fetch_add(
+        std::chrono::duration_cast<std::chrono::nanoseconds>(t - t_prev).count(),
+        std::memory_order_relaxed);
+    t_prev = t;
+  };
+  a.part_begin(d_roots_a, d_ts_a, Ra, d_out_a, out_bytes_a, P, me, slack, slot_roots, stream);
+  try {
+    b.part_begin(d_roots_b, d_ts_b, Rb, d_out_b, out_bytes_b, P, me, slack, slot_roots, stream);
+  } catch (...) {
+    a.part_abort();
+    throw;
+  }
+  lap(0);
+  try {
+    DeviceGuard dg(a.graph_->device());
+    Sampler* sm[2] = {&a, &b};
+    char* w = static_cast<char*>(d_ws);
+    size_t off = 0;
+    for (size_t l = 0; l < L; ++l) {
+      PairLayout lay;
+      a.pair_layout(a.part_.Rs, b.part_.Rs, static_cast<uint32_t>(l), P, slack, slot_roots, &lay);
+      GF_REQUIRE(off + lay.total <= ws_bytes, "sample_partitioned_pair: workspace too small");
+      char* base = w + off;
+      const uint32_t F = a.fanouts_[l], stride = static_cast<uint32_t>(lay.stride);
+      int64_t* requests = reinterpret_cast<int64_t*>(base + lay.requests);
+      int64_t* replies = reinterpret_cast<int64_t*>(base + lay.replies);
+      const size_t counts_off[2] = {lay.counts_a, lay.counts_b};
+      const size_t pos_off[2] = {lay.pos_a, lay.pos_b};
+      const size_t own_row[2] = {lay.own_a, lay.own_b};
+      const int64_t* roots[2]; const float* ts[2]; const uint64_t* d_R[2]; uint64_t R_host[2];
+      size_t n_bound[2];
+      for (int j = 0; j < 2; ++j) {
+        sm[j]->part_roots(static_cast<uint32_t>(l), 0, &roots[j], &ts[j], &d_R[j], &R_host[j]);
+        n_bound[j] = l == 0 ? sm[j]->part_.R : sm[j]->root_bound(sm[j]->part_.Rs, l);
+      }
+      const size_t bound = std::max(n_bound[0], n_bound[1]);
+      // 1. both plans
+      PlanJob pj[2];
+      for (int j = 0; j < 2; ++j) {
+        pj[j] = PlanJob{roots[j], ts[j], d_R[j], R_host[j], requests,
+                        reinterpret_cast<uint32_t*>(base + pos_off[j]),
+                        reinterpret_cast<uint64_t*>(base + counts_off[j]),
+                        sm[j]->part_overflow(), l == 0 ? 1 : 0, 2u, static_cast<uint32_t>(j),
+                        static_cast<uint32_t>(own_row[j])};
+      }
+      partition_plan_jobs(pj, 2, bound, P, me, stride, a.graph_->device(), stream);
+      lap(1);
+      // 2. both samples' request slots out
+      ex.all_to_all(requests, base + lay.inbox, 2 * static_cast<size_t>(stride) * 16, stream);
+      lap(2);
+      // 3. the received slots (of both samples, served alike) and both own shares
+      const uint64_t n_inbox = lay.slot_rows;
+      const size_t n_max = std::max<size_t>(n_inbox, bound);
+      const int width = n_max > kSmallRoots ? a.large_group_ : a.search_group_;
+      const unsigned grid = capped_grid(n_max, kSearchThreads / width, 256 * 8);
+      const PaddedCommon pc{0, 1, a.window_, F, a.policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0,
+                            a.prop_time_ ? 1 : 0, a.seed_};
+      PaddedJob serve{reinterpret_cast<const int64_t*>(base + lay.inbox), n_inbox, a.calls_++,
+                      reinterpret_cast<int64_t*>(base + lay.served), nullptr, nullptr, 0, nullptr,
+                      nullptr, stride, static_cast<uint32_t>(2 * P), a.part_overflow()};
+      serve.d_overflow2 = b.part_overflow();
+      PaddedJob own[2];
+      for (int j = 0; j < 2; ++j) {
+        own[j] = PaddedJob{requests, 0, sm[j]->calls_++, replies,
+                           reinterpret_cast<const uint64_t*>(base + counts_off[j]) + me, d_R[j],
+                           R_host[j], nullptr, nullptr, stride, static_cast<uint32_t>(2 * P),
+                           nullptr};
+        own[j].own_skip = own_row[j];
+      }
+      {
+        ProfileScope ps(kProfSearch, stream);
+        launch_padded_trio(width, grid, stream, view_for(a.graph_, n_max), pc, serve, own[0],
+                           own[1]);
+        GF_HIP(hipGetLastError());
+      }
+      lap(3);
+      // 4. the replies back
+      ex.all_to_all(base + lay.served, replies, 2 * static_cast<size_t>(stride) * F * 24, stream);
+      lap(4);
+      // 5. both merges
+      MergeJob mj[2];
+      for (int j = 0; j < 2; ++j) {
+        Sampler& s = *sm[j];
+        uint64_t* cslot = s.part_counts() + 2 * l;
+        const BlockPtrs& out = s.part_.slot->ptrs[l];
+        mj[j] = MergeJob{roots[j], ts[j], d_R[j], R_host[j], replies,
+                         reinterpret_cast<const uint32_t*>(base + pos_off[j]),
+                         static_cast<uint32_t>(lay.slot_rows),
+                         reinterpret_cast<uint64_t*>(s.ws_.as<char>()), (++s.merge_epoch_) << 10,
+                         s.part_overflow(), out.all_nodes, out.all_ts, out.dt, out.eids, out.row,
+                         out.col, cslot, cslot + 1, (l + 1 < L) ? cslot + 2 : nullptr};
+      }
+      {
+        ProfileScope ps(kProfEmit, stream);
+        const unsigned egrid = static_cast<unsigned>(
+            (static_cast<uint64_t>(std::max<size_t>(bound, 1)) * F + kEmitThreads - 1) /
+            kEmitThreads);
+        merge_slots_fused_pair_kernel<<<dim3(egrid, 2), dim3(kEmitThreads), 0, stream>>>(
+            mj[0], mj[1], F, stride);
+        GF_HIP(hipGetLastError());
+      }
+      lap(5);
+      off += lay.total;
+    }
+    Publish pa, pb;
+    a.part_commit_prepare(&pa);
+    b.part_commit_prepare(&pb);
+    sample_publish_pair_kernel<<<dim3(2), dim3(64), 0, stream>>>(pa, pb);
+    GF_HIP(hipGetLastError());
+    a.part_commit_finish();
+    b.part_commit_finish();
+    lap(6);
+    g_part_host_ns[7].fetch_add(2, std::memory_order_relaxed);   // samples
+  } catch (...) {
+    a.part_abort();
+    b.part_abort();
+    throw;
   }
 }
 

@@ -437,13 +437,22 @@ class _PartitionedPending:
     """PendingSample of a slotted partitioned sample: `wait()` also reads the sample's overflow
     flag and, if a slot overflowed on ANY rank (the flag travels in the slot headers, so every
     rank reads the same value for the same sample), samples the batch again through the
-    variable-size exchange — on every rank, at the same point of its call sequence."""
+    variable-size exchange — on every rank, at the same point of its call sequence.
+    A sample may be HELD (not issued yet) while it waits for the next batch to share its chain
+    with (DevicePartitionedSampler pairs); `wait()` on a held sample issues it alone."""
 
-    def __init__(self, owner, lane, pending, nodes, ts, stream):
-        self._owner, self._lane, self._pending = owner, lane, pending
+    def __init__(self, owner, lane, smp, pending, nodes, ts, stream, worker_enqueue=False):
+        self._owner, self._lane, self._smp = owner, lane, smp
         self._nodes, self._ts, self._stream = nodes, ts, stream
+        self._worker_enqueue = worker_enqueue
         self._result = None
         self._overflowed = False
+        self._pending = None
+        if pending is not None:
+            self._attach(pending)
+
+    def _attach(self, pending):
+        self._pending = pending
         # samples end in the order they were begun, possibly inside a younger sample's wait():
         # the flag is read when THIS sample's native sample_end has just returned
         pending._after_end = self._read_flag
@@ -451,26 +460,29 @@ class _PartitionedPending:
     def _read_flag(self):
         own = self._owner
         flag = own._C.c_int(0)
-        own._capi.check(own._lib.gf_sampler_part_overflowed(self._lane.sampler._h,
-                                                            own._C.byref(flag)))
+        own._capi.check(own._lib.gf_sampler_part_overflowed(self._smp._h, own._C.byref(flag)))
         self._overflowed = bool(flag.value)
 
     def wait(self):
         if self._result is None:
             own = self._owner
+            if self._pending is None:
+                own._issue_held_alone(self)
             mfgs = self._pending.wait()
             if self._overflowed:
                 own.overflows += 1
-                # the samples begun on this lane after this one end first (their launches may
-                # still be with the enqueue thread; their results are kept), then the batch is
-                # sampled again.  Every rank does this at the same point of its call sequence
-                # and — the pipeline being the same on every rank — with the same number of
-                # samples in flight on the lane, so the lane's communicator sees the same order
-                # of collectives everywhere.
-                q = self._lane.sampler._inflight
-                while q:
-                    q[0].wait()
-                mfgs = own._sample_variable(self._lane, self._nodes, self._ts, self._stream).wait()
+                # the samples begun on this LANE after this one end first (their launches may
+                # still be with the enqueue thread, and they use the lane's communicator; their
+                # results are kept), then the batch is sampled again.  Every rank does this at the same point of its call sequence
+                # and — the pipeline being the same on every rank — with the same samples in
+                # flight on the lane, so the lane's communicator sees the same order of
+                # collectives everywhere.
+                for smp in (self._lane.sampler, self._lane.sampler_b):
+                    q = smp._inflight if smp is not None else ()
+                    while q:
+                        q[0].wait()
+                mfgs = own._sample_variable(self._lane, self._smp, self._nodes, self._ts,
+                                            self._stream).wait()
             self._result = mfgs
             self._nodes = self._ts = None
         return self._result
@@ -481,8 +493,9 @@ class _Lane:
     own native workspace and publish ring, the stream its chains run on, its communicator, and
     a ring of exchange workspaces (one per sample that can be in flight on the lane)."""
 
-    def __init__(self, sampler, comm=None):
+    def __init__(self, sampler, comm=None, sampler_b=None):
         self.sampler = sampler
+        self.sampler_b = sampler_b  # pairs: the second sample of a shared chain runs through it
         self.stream = None          # lanes >= 1: their own stream, created on first use
         self.comm = comm
         self.comm_tried = comm is not None
@@ -525,7 +538,7 @@ class DevicePartitionedSampler:
     owns, see PartitionedGraph)."""
 
     def __init__(self, sampler, group=None, always_exchange=False, slack=None, slot_roots=None,
-                 comm=None, overlap=None, lanes=None):
+                 comm=None, overlap=None, lanes=None, pair=None):
         """always_exchange: take the multi-rank path — request / reply exchange, served
         requests, merge — even with one rank (where every message is empty).  For tests: it
         is the only way to run the RCCL branch on a one-GPU box.
@@ -548,9 +561,15 @@ class DevicePartitionedSampler:
         cost far more than the ~6 us own-share kernel they hide (one rank over RCCL, every
         message empty: 268 us per step with them, 116 us with everything in the sampling
         stream; profiles/r03_part_bench_one_gpu.jsonl).
-        lanes: sampling lanes (default GNNFLOW_PART_LANES or 4 with more than one rank /
+        lanes: sampling lanes (default GNNFLOW_PART_LANES or 2 with more than one rank /
         always_exchange, else 1).  A lane is used only by `sample_async(..., stream=...)` calls
-        that name a stream (the pipelined loop); `sample()` always runs on lane 0."""
+        that name a stream (the pipelined loop); `sample()` always runs on lane 0.
+        pair: let two consecutive `sample_async(..., stream=...)` calls share ONE chain — its
+        launches and its exchanges (include/gnnflow_hip.h gf_sampler_sample_partitioned_comm_pair:
+        11 stream operations per two samples instead of per sample; the chain is bound by the
+        host thread that issues it).  The first of the two is held until the second arrives
+        or it is waited for.  Default GNNFLOW_PART_PAIR or on; needs the library's
+        communicator, one snapshot and layers of <= 32 768 roots (else single chains)."""
         import ctypes as C
         import os
         from . import _capi
@@ -576,16 +595,24 @@ class DevicePartitionedSampler:
             overlap = os.environ.get("GNNFLOW_PART_OVERLAP", "0") != "0"
         self._overlap = bool(overlap)
         if lanes is None:
-            lanes = int(os.environ.get("GNNFLOW_PART_LANES", "4"))
+            lanes = int(os.environ.get("GNNFLOW_PART_LANES", "2"))
         if (self._P == 1 and not self._always_exchange) or self._slack <= 0:
             lanes = 1        # no exchange chain to overlap / host-synchronising exchange
         if comms and comms[0].transport in ("ipc", "loopback"):
             lanes = min(lanes, len(comms))    # host-synchronising transports: as many as given
         lanes = max(1, min(int(lanes), 4))
-        self._lanes = [_Lane(sampler, comms[0] if comms else None)]
+        if pair is None:
+            pair = os.environ.get("GNNFLOW_PART_PAIR", "1") != "0"
+        self._pair = bool(pair) and self._slack > 0 and self._S == 1 and \
+            not (self._P == 1 and not self._always_exchange)
+        self._lanes = [_Lane(sampler, comms[0] if comms else None,
+                             sampler.clone() if self._pair else None)]
         for k in range(1, lanes):
-            self._lanes.append(_Lane(sampler.clone(), comms[k] if k < len(comms) else None))
+            self._lanes.append(_Lane(sampler.clone(), comms[k] if k < len(comms) else None,
+                                     sampler.clone() if self._pair else None))
         self.lanes = lanes
+        self._held = None          # a sample waiting for its partner (pairs)
+        self.pairs = 0             # chains that carried two samples
         self._rr = 0               # round-robin cursor over the lanes
         self._layouts = {}     # (R0, slack) -> ([layouts per layer], [workspace offsets], total)
         self.overflows = 0     # slotted samples that had to be redone
@@ -677,6 +704,8 @@ class DevicePartitionedSampler:
         """TemporalSampler.sample_async for the partitioned graph: returns a pending sample;
         `.wait()` gives the MFGs.  With more than one rank the launches and the collectives
         are enqueued by this call without any host synchronisation (slotted form)."""
+        if self._pair and stream is not None:
+            return self._sample_paired(nodes, ts, stream, worker_enqueue)
         lane, stream = self._pick_lane(stream)
         smp = lane.sampler
         if len(smp._inflight) >= smp._max_inflight:
@@ -686,12 +715,77 @@ class DevicePartitionedSampler:
             return self._sample_one_rank(lane, nodes, ts, stream, worker_enqueue)
         if self._slack > 0:
             return _PartitionedPending(
-                self, lane, self._sample_slotted(lane, nodes, ts, stream, worker_enqueue),
+                self, lane, smp, self._sample_slotted(lane, smp, nodes, ts, stream, worker_enqueue),
                 nodes, ts, stream)
-        return self._sample_variable(lane, nodes, ts, stream)
+        return self._sample_variable(lane, smp, nodes, ts, stream)
 
-    def _output(self, lane, R, stream):
-        C, smp = self._C, lane.sampler
+    # ---- pairs: two consecutive samples in one chain ------------------------------------------
+    def _sample_paired(self, nodes, ts, stream, worker_enqueue):
+        held = self._held
+        if held is None:
+            lane, st = self._pick_lane(stream)
+            nodes, ts = lane.sampler._to_device(nodes, ts, st)
+            self._held = h = _PartitionedPending(self, lane, lane.sampler, None, nodes, ts, st,
+                                                 worker_enqueue)
+            return h
+        self._held = None
+        lane, st = held._lane, held._stream
+        nodes, ts = lane.sampler_b._to_device(nodes, ts, st)
+        second = _PartitionedPending(self, lane, lane.sampler_b, None, nodes, ts, st, worker_enqueue)
+        self._issue_pair(lane, held, second, st, worker_enqueue)
+        return second
+
+    def _issue_held_alone(self, p):
+        """`p` is waited for before its partner arrived: its chain is issued for it alone."""
+        if self._held is p:
+            self._held = None
+        smp = p._smp
+        if len(smp._inflight) >= smp._max_inflight:
+            smp._inflight[0].wait()
+        p._attach(self._sample_slotted(p._lane, smp, p._nodes, p._ts, p._stream, p._worker_enqueue))
+
+    def _issue_pair(self, lane, first, second, stream, worker_enqueue):
+        C, lib, check = self._C, self._lib, self._capi.check
+        sa, sb = lane.sampler, lane.sampler_b
+        for smp in (sa, sb):
+            if len(smp._inflight) >= smp._max_inflight:
+                smp._inflight[0].wait()
+        Ra, Rb = int(first._nodes.shape[0]), int(second._nodes.shape[0])
+        if not self._slot_roots:
+            self._slot_roots = self._agree_on_slot_roots(max(Ra, Rb, 1))
+        comm = self._ensure_comm(lane)
+        ws_bytes = 0
+        if comm is not None:
+            key = ("pair", max(Ra, 1), max(Rb, 1))
+            ws_bytes = self._layouts.get(key)
+            if ws_bytes is None:
+                n = C.c_size_t(0)
+                check(lib.gf_sampler_part_pair_ws_bytes(sa._h, max(Ra, 1), max(Rb, 1), self._P,
+                                                        self._slack, self._slot_roots, C.byref(n)))
+                ws_bytes = self._layouts[key] = n.value
+        if not ws_bytes:      # no communicator / not pairable: two single chains
+            first._attach(self._sample_slotted(lane, sa, first._nodes, first._ts, stream,
+                                               worker_enqueue))
+            second._attach(self._sample_slotted(lane, sb, second._nodes, second._ts, stream,
+                                                worker_enqueue))
+            return
+        slab_a, out_a, nb_a = self._output(sa, Ra, stream)
+        slab_b, out_b, nb_b = self._output(sb, Rb, stream)
+        ws, _ = self._workspace(lane, ws_bytes, stream)
+        call = lib.gf_sampler_sample_partitioned_comm_pair_async \
+            if (worker_enqueue and comm.transport != "loopback") \
+            else lib.gf_sampler_sample_partitioned_comm_pair
+        na, ta, nb_, tb = first._nodes, first._ts, second._nodes, second._ts
+        check(call(sa._h, sb._h, comm.h,
+                   na.data_ptr() if Ra else None, ta.data_ptr() if Ra else None, Ra, out_a, nb_a,
+                   nb_.data_ptr() if Rb else None, tb.data_ptr() if Rb else None, Rb, out_b, nb_b,
+                   ws.data_ptr(), ws_bytes, self._slack, self._slot_roots, slab_a[6]))
+        first._attach(self._pend(sa, slab_a, (na, ta, ws), Ra))
+        second._attach(self._pend(sb, slab_b, (nb_, tb, ws), Rb))
+        self.pairs += 1
+
+    def _output(self, smp, R, stream):
+        C = self._C
         nbytes = smp._bytes_cache.get(max(R, 1))
         if nbytes is None:
             n = C.c_size_t(0)
@@ -700,25 +794,25 @@ class DevicePartitionedSampler:
         slab, off = smp._output_buffer(nbytes, stream)
         return slab, slab[5] + off, nbytes
 
-    def _pend(self, lane, slab, keep, R):
+    def _pend(self, smp, slab, keep, R):
         from .temporal_sampler import PendingSample
         # R = 0 still yields real (empty) blocks whose sizes come from the device
-        pending = PendingSample(lane.sampler, slab, keep, max(R, 1), None)
-        lane.sampler._inflight.append(pending)
+        pending = PendingSample(smp, slab, keep, max(R, 1), None)
+        smp._inflight.append(pending)
         return pending
 
     def _sample_one_rank(self, lane, nodes, ts, stream, worker_enqueue):
         lib, smp = self._lib, lane.sampler
         R = int(nodes.shape[0])
         _, _, ws_bytes = self._plan(max(R, 1))
-        slab, out_ptr, nbytes = self._output(lane, R, stream)
+        slab, out_ptr, nbytes = self._output(smp, R, stream)
         ws, _ = self._workspace(lane, ws_bytes, stream)
         call = lib.gf_sampler_sample_partitioned_async if worker_enqueue \
             else lib.gf_sampler_sample_partitioned
         self._capi.check(call(smp._h, nodes.data_ptr() if R else None,
                               ts.data_ptr() if R else None, R, out_ptr, nbytes, ws.data_ptr(),
                               ws_bytes, slab[6]))
-        return self._pend(lane, slab, (nodes, ts, ws), R)
+        return self._pend(smp, slab, (nodes, ts, ws), R)
 
     def _ensure_comm(self, lane):
         """The lane's communicator, created on first use (collective: every rank creates its
@@ -739,11 +833,11 @@ class DevicePartitionedSampler:
                                                      mailbox_bytes=2 * box)
         return lane.comm
 
-    def _sample_slotted(self, lane, nodes, ts, stream, worker_enqueue=False):
+    def _sample_slotted(self, lane, smp, nodes, ts, stream, worker_enqueue=False):
         """The whole sample enqueued on `stream` without reading anything back: per layer
         plan -> equal-split exchange of the request slots (asynchronous, overlapped with the
         own share) -> serve -> equal-split exchange of the reply slots -> merge."""
-        lib, check, smp = self._lib, self._capi.check, lane.sampler
+        lib, check = self._lib, self._capi.check
         P, me, group = self._P, self._rank, self._group
         R = int(nodes.shape[0])
         R0 = max(R, 1)
@@ -751,7 +845,7 @@ class DevicePartitionedSampler:
             self._slot_roots = self._agree_on_slot_roots(R0)
         lays, offs, ws_bytes = self._plan(R0, self._slack)
         comm = self._ensure_comm(lane)
-        slab, out_ptr, nbytes = self._output(lane, R, stream)
+        slab, out_ptr, nbytes = self._output(smp, R, stream)
         ws, wi = self._workspace(lane, ws_bytes, stream)
         if comm is not None:
             # the library's own communicator: the chain is one native call (a loopback
@@ -762,7 +856,7 @@ class DevicePartitionedSampler:
             check(call(smp._h, comm.h, nodes.data_ptr() if R else None,
                        ts.data_ptr() if R else None, R, out_ptr, nbytes, ws.data_ptr(), ws_bytes,
                        self._slack, self._slot_roots, 1 if self._overlap else 0, slab[6]))
-            return self._pend(lane, slab, (nodes, ts, ws), R)
+            return self._pend(smp, slab, (nodes, ts, ws), R)
         views = self._slot_views(lane, ws, wi, R0, lays, offs)
         base = ws.data_ptr()
         with torch.cuda.stream(stream):
@@ -787,7 +881,7 @@ class DevicePartitionedSampler:
             except Exception:
                 lib.gf_sampler_part_abort(smp._h)
                 raise
-        return self._pend(lane, slab, (nodes, ts, ws), R)
+        return self._pend(smp, slab, (nodes, ts, ws), R)
 
     def _agree_on_slot_roots(self, R0: int) -> int:
         if self._P == 1:
@@ -833,13 +927,13 @@ class DevicePartitionedSampler:
             out.data_ptr() if b else send.data_ptr(), arr(*rb), arr(*ro), st))
         return None
 
-    def _sample_variable(self, lane, nodes, ts, stream):
+    def _sample_variable(self, lane, smp, nodes, ts, stream):
         """Variable-size exchange: all-to-all-v of exactly the rows there are; the per-owner
         counts are read back once per layer (they are the split sizes)."""
-        lib, check, smp = self._lib, self._capi.check, lane.sampler
+        lib, check = self._lib, self._capi.check
         R = int(nodes.shape[0])
         lays, offs, ws_bytes = self._plan(max(R, 1))
-        slab, out_ptr, nbytes = self._output(lane, R, stream)
+        slab, out_ptr, nbytes = self._output(smp, R, stream)
         ws, _ = self._workspace(lane, ws_bytes, stream)
         sptr = slab[6]
         with torch.cuda.stream(stream):
@@ -849,17 +943,18 @@ class DevicePartitionedSampler:
             try:
                 for layer in range(self._L):
                     for s in range(self._S):
-                        self._exchange_layer(lane, layer, s, lays[layer], ws, offs[layer][s], sptr)
+                        self._exchange_layer(lane, smp, layer, s, lays[layer], ws, offs[layer][s],
+                                             sptr)
                 check(lib.gf_sampler_part_commit(smp._h))
             except Exception:
                 lib.gf_sampler_part_abort(smp._h)
                 raise
-        return self._pend(lane, slab, (nodes, ts, ws), R)
+        return self._pend(smp, slab, (nodes, ts, ws), R)
 
-    def _exchange_layer(self, lane, layer, snapshot, lay, ws, off, sptr):
+    def _exchange_layer(self, lane, smp, layer, snapshot, lay, ws, off, sptr):
         """One (layer, snapshot) with P > 1 ranks, on the current stream."""
         lib, check = self._lib, self._capi.check
-        smp, dev, P, me, F = lane.sampler, self._device, self._P, self._rank, self._fanouts[layer]
+        dev, P, me, F = self._device, self._P, self._rank, self._fanouts[layer]
         comm = lane.comm
         base = ws.data_ptr() + off
         # 1. bucket by owner (the layer's root count is still on the device)

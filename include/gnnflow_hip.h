@@ -555,6 +555,31 @@ GF_API int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c,
                                                     void* d_ws, size_t ws_bytes, double slack,
                                                     size_t slot_roots, int overlap, void* stream);
 
+/* TWO samples in one chain: at batch 600 the chain's throughput is bound by the host thread that
+ * issues its ~11 stream operations, so two consecutive batches share their launches and their
+ * exchanges — sample a through sampler `sa`, sample b through `sb` (a second sampler over the
+ * same graph with the same arguments: each keeps its own output, block counters and publish
+ * record; gf_sampler_sample_end / gf_sampler_part_overflowed per sampler as usual).  Owner q's
+ * requests of sample j travel in slot 2 q + j of ONE buffer, so one equal-split all-to-all moves
+ * both samples' slots; 11 operations per two samples.  gf_sampler_part_pair_ws_bytes: size of
+ * the shared exchange workspace, 0 if these two samples cannot share a chain (several
+ * snapshots, a layer beyond 32 768 roots, fanout > 256): the caller then issues two single
+ * chains.  No reference counterpart (its RPC futures are per partition and per call,
+ * gnnflow/distributed/dist_sampler.py:188-220). */
+GF_API int gf_sampler_part_pair_ws_bytes(const gf_sampler* s, size_t roots_a, size_t roots_b,
+                                         int world_size, double slack, size_t slot_roots,
+                                         size_t* bytes);
+GF_API int gf_sampler_sample_partitioned_comm_pair(
+    gf_sampler* sa, gf_sampler* sb, gf_comm* c, const int64_t* d_roots_a, const float* d_ts_a,
+    size_t roots_a, void* d_out_a, size_t out_bytes_a, const int64_t* d_roots_b,
+    const float* d_ts_b, size_t roots_b, void* d_out_b, size_t out_bytes_b, void* d_ws,
+    size_t ws_bytes, double slack, size_t slot_roots, void* stream);
+GF_API int gf_sampler_sample_partitioned_comm_pair_async(
+    gf_sampler* sa, gf_sampler* sb, gf_comm* c, const int64_t* d_roots_a, const float* d_ts_a,
+    size_t roots_a, void* d_out_a, size_t out_bytes_a, const int64_t* d_roots_b,
+    const float* d_ts_b, size_t roots_b, void* d_out_b, size_t out_bytes_b, void* d_ws,
+    size_t ws_bytes, double slack, size_t slot_roots, void* stream);
+
 /* ---- message passing on a sampled block ---------------------- */
 /* The DGL calls of the reference's layers on an MFG (gnnflow/models/modules/layers.py:153-159,
  * models/graphsage.py:27-31, models/gat.py:28-46), as segment operations: a block's edges are
