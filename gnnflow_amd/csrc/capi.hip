@@ -12,6 +12,8 @@
 #include <string>
 #include <thread>
 
+#include <unistd.h>
+
 #include "comm.hpp"
 #include "common.hpp"
 #include "edge_store.hpp"
@@ -40,6 +42,14 @@ namespace gf {
 
 namespace {
 thread_local std::string g_last_error;
+
+// A process forked from one that holds handles (multiprocessing's fork start method: a Manager
+// server, a DataLoader worker) inherits the Python objects and may finalise them — its garbage
+// collector runs their __del__.  The GPU state behind a handle belongs to the process that
+// loaded the library: in any other process a destroy call is a no-op (the child's copy of the
+// host memory goes with the process), it must never free the parent's device memory.
+const pid_t g_load_pid = getpid();
+inline bool foreign_process() { return getpid() != g_load_pid; }
 
 struct ProfileRecord { int slot; hipEvent_t start, stop; };
 std::mutex g_prof_mu;
@@ -294,6 +304,7 @@ int gf_graph_create(gf_graph** out, size_t initial_pool_size, size_t maximum_poo
   });
 }
 int gf_graph_destroy(gf_graph* g) {
+  if (gf::foreign_process()) return GF_OK;
   return guarded([&] { delete g; });
 }
 #define GF_G(g) GF_REQUIRE((g) != nullptr, "null graph handle")
@@ -368,6 +379,7 @@ int gf_sampler_create(gf_sampler** out, gf_graph* g, const uint32_t* fanouts, si
   });
 }
 int gf_sampler_destroy(gf_sampler* s) {
+  if (gf::foreign_process()) return GF_OK;
   return guarded([&] { delete s; });
 }
 int gf_sampler_output_bytes(const gf_sampler* s, size_t num_roots, size_t* bytes) {
@@ -475,6 +487,7 @@ int gf_cache_create(gf_cache** out, size_t num_ids, size_t capacity, size_t dim,
   });
 }
 int gf_cache_destroy(gf_cache* c) {
+  if (gf::foreign_process()) return GF_OK;
   return guarded([&] { delete c; });
 }
 int gf_cache_set_policy(gf_cache* c, int policy) {
@@ -559,6 +572,7 @@ int gf_pull_session_create(gf_pull_session** out, gf_comm* comm, int device) {
   });
 }
 int gf_pull_session_destroy(gf_pull_session* s) {
+  if (gf::foreign_process()) return GF_OK;
   return guarded([&] { delete s; });
 }
 int gf_pull_round(gf_pull_session* s, gf_cache* node_cache, gf_cache* edge_cache,
@@ -829,6 +843,7 @@ int gf_comm_create(gf_comm** out, const uint8_t* id, int world_size, int rank, i
   });
 }
 int gf_comm_destroy(gf_comm* c) {
+  if (gf::foreign_process()) return GF_OK;
   return guarded([&] { delete c; });
 }
 int gf_ipc_comm_create(gf_comm** out, int world_size, int rank, int device, size_t mailbox_bytes,

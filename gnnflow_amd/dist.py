@@ -462,6 +462,7 @@ class _PartitionedPending:
         flag = own._C.c_int(0)
         own._capi.check(own._lib.gf_sampler_part_overflowed(self._smp._h, own._C.byref(flag)))
         self._overflowed = bool(flag.value)
+        self._pending._after_end = None      # no reference cycle left behind
 
     def wait(self):
         if self._result is None:
@@ -485,6 +486,7 @@ class _PartitionedPending:
                                             self._stream).wait()
             self._result = mfgs
             self._nodes = self._ts = None
+            self._pending = self._lane = self._smp = self._owner = None
         return self._result
 
 

@@ -165,3 +165,34 @@ def test_out_of_range_ids_fetch_zero_rows_and_never_fault():
     assert torch.equal(got[0], nf[3]) and torch.equal(got[3], nf[9])
     assert torch.count_nonzero(got[[1, 2, 4]]) == 0
     assert float(c.cache_node_ratio) == pytest.approx(1 / 5)      # only id 3 was cached
+
+
+@pytest.mark.gpu
+def test_forked_child_does_not_free_the_parents_gpu_objects():
+    """A process forked from one that holds handles (multiprocessing's fork start method: a
+    Manager server, a DataLoader worker) inherits the Python objects; when its garbage
+    collector finalises them, the destroy calls must not touch the parent's device memory
+    (include/gnnflow_hip.h: handles belong to the process that loaded the library)."""
+    import gc
+    import os
+    import numpy as np
+    import gnnflow_amd
+    from tests import synth
+    src, dst, ts, eid = synth.powerlaw_graph(200, 4000, seed=3, tie_levels=100)
+    g = gnnflow_amd.DynamicGraph(1 << 20, 1 << 28, "cuda", 8, 64, "insert")
+    g.add_edges(src, dst, ts, eid)
+    s = gnnflow_amd.TemporalSampler(g, [5, 5])
+    nodes, t = synth.random_roots(200, 300, 1000.0, seed=1)
+    before = [b.edata["ID"].cpu().numpy() for mfg in s.sample(nodes, t) for b in mfg]
+    pid = os.fork()
+    if pid == 0:            # the child: finalise its copies of the objects, then leave
+        try:
+            s.__del__()
+            g.__del__()
+            gc.collect()
+        finally:
+            os._exit(0)
+    _, status = os.waitpid(pid, 0)
+    assert status == 0
+    after = [b.edata["ID"].cpu().numpy() for mfg in s.sample(nodes, t) for b in mfg]
+    assert all(np.array_equal(a, b) for a, b in zip(before, after))
