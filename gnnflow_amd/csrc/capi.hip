@@ -35,6 +35,9 @@ struct gf_comm {
 };
 struct gf_pull_session {
   gf::PullSession impl;
+  // over RCCL the round is issued by the enqueue thread that also issues the partitioned
+  // sampler's chains: ONE global order of collectives over all communicators, on every rank
+  bool ordered = false;
   gf_pull_session(gf::Exchange* ex, int device) : impl(ex, device) {}
 };
 
@@ -569,6 +572,7 @@ int gf_pull_session_create(gf_pull_session** out, gf_comm* comm, int device) {
   return guarded([&] {
     GF_REQUIRE(out != nullptr, "gf_pull_session_create: null output");
     *out = new gf_pull_session(comm ? &comm->impl : nullptr, device);
+    (*out)->ordered = comm != nullptr && !comm->loopback && comm->ipc == nullptr;
   });
 }
 int gf_pull_session_destroy(gf_pull_session* s) {
@@ -578,6 +582,24 @@ int gf_pull_session_destroy(gf_pull_session* s) {
 int gf_pull_round(gf_pull_session* s, gf_cache* node_cache, gf_cache* edge_cache,
                   const gf_pull_ctx* ctxs, size_t n, int flag, int* any_flag, uint64_t* rows_pulled,
                   uint64_t* bytes_sent, uint32_t* d_error_flag, void* stream) {
+  if (s != nullptr && s->ordered) {
+    // The sampler's chains (collectives on the lanes' communicators) are issued by the fetch
+    // lane's enqueue thread, this round's collectives (on the session's communicator) would be
+    // issued by the caller's: two threads, no common order across ranks — RCCL kernels of
+    // different communicators that share a hardware queue could then wait for each other.  The
+    // round therefore takes its place in that thread's queue and the caller waits for it.
+    gf::PullSession* impl = &s->impl;
+    gf::FeatureCache* nc = node_cache ? &node_cache->impl : nullptr;
+    gf::FeatureCache* ec = edge_cache ? &edge_cache->impl : nullptr;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t t = gf::EnqueueWorker::get(0).submit([=]() {
+      impl->round(nc, ec, ctxs, n, flag, any_flag, rows_pulled, bytes_sent, d_error_flag, st);
+    });
+    std::string err;
+    const int rc = gf::EnqueueWorker::get(0).wait(t, &err);
+    if (rc != GF_OK) gf::set_last_error(err);
+    return rc;
+  }
   return guarded([&] {
     GF_REQUIRE(s != nullptr, "null pull session");
     s->impl.round(node_cache ? &node_cache->impl : nullptr, edge_cache ? &edge_cache->impl : nullptr,

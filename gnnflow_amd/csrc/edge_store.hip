@@ -225,11 +225,17 @@ void EdgeStore::rebuild_fences(uint64_t cap, uint64_t live) {
   }
   if (f.levels == 0) { fence_view_ = f; return; }
   total += 64;   // a whole aligned window of 16 fences is readable behind the last level
-  // ingest kernels queued earlier hold the old view: they are on stream_, and so is this
+  // ingest kernels queued earlier hold the old view: they are on stream_, and so is this.
+  // A sample() enqueued on ANOTHER stream before this add_edges may still be running with the
+  // old view (callers order add_edges against sample(), SURVEY 8(b) "Threading" — the
+  // reference: wait_for_all_updates_to_finish — but a sample that was merely ENQUEUED earlier
+  // is legitimate): the previous generation of the fences therefore stays allocated until the
+  // next growth instead of being freed here.
   DeviceBuffer fresh;
   fresh.reserve(total * sizeof(float), 0, stream_);
   GF_HIP(hipStreamSynchronize(stream_));
   std::swap(fence_, fresh);
+  std::swap(fence_prev_, fresh);   // `fresh` now holds the generation before the previous one
   f.base = fence_.as<float>();
   fence_view_ = f;
   if (live >= 16) {

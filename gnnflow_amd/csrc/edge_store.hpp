@@ -269,6 +269,7 @@ class EdgeStore {
   // device state
   GrowBuffer ts_pool_, nbr_pool_;   // grow in place (HIP virtual memory), never move
   DeviceBuffer fence_;              // every 16^l-th timestamp of ts_pool_ (FenceView)
+  DeviceBuffer fence_prev_;         // the previous generation (samples enqueued before a growth)
   FenceView fence_view_{nullptr, {0}, 0};
   bool fences_enabled_ = true;
   std::atomic<bool> negative_ts_{false};   // an edge with a negative timestamp was ingested

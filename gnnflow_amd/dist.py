@@ -820,6 +820,17 @@ class DevicePartitionedSampler:
         """The lane's communicator, created on first use (collective: every rank creates its
         lanes' communicators in the same order) — or None: exchanges through torch.distributed."""
         if not lane.comm_tried:
+            # all lanes' communicators at once, before the first chain is issued: creating one
+            # is a collective with allocations and synchronisations of its own, which must not
+            # meet another lane's exchanges in flight
+            for other in self._lanes:
+                if other is not lane and not other.comm_tried:
+                    self._create_comm(other)
+            self._create_comm(lane)
+        return lane.comm
+
+    def _create_comm(self, lane):
+        if not lane.comm_tried:
             lane.comm_tried = True
             kind = NativeComm.choose(self._group)
             if kind is not None:
@@ -829,7 +840,8 @@ class DevicePartitionedSampler:
                 ref = self._plan(max(self._slot_roots, 1), self._slack)[0]
                 # (and, for an overflowed sample's redo through the variable-size exchange,
                 # never less than 16 MiB)
-                box = max([16 << 20] + [P * lay.slot_stride * (24 * f + 16) + 512 * P
+                m = 2 if self._pair else 1      # a pair's exchange carries two slots per peer
+                box = max([16 << 20] + [m * P * lay.slot_stride * (24 * f + 16) + 512 * P
                                         for lay, f in zip(ref, self._fanouts)])
                 lane.comm = NativeComm.create_agreed(self._device, self._group, kind,
                                                      mailbox_bytes=2 * box)

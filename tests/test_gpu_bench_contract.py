@@ -138,3 +138,18 @@ def test_a_dying_rank_ends_the_launcher_non_zero_with_one_line():
     d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5"],
              env={"GNNFLOW_BENCH_DEVICE": "7", "GNNFLOW_BENCH_BACKEND": "gloo"}, rc=1)
     assert d["value"] == 0.0 and "error" in d
+
+
+def test_two_ranks_native_chains_over_the_ipc_transport():
+    """The closest a one-GPU box gets to the driver's multi-GPU run: bench.py's own launcher, two
+    rank processes, and the NATIVE partitioned chains (sampling lanes, two samples per chain,
+    issued by the enqueue thread) with every message real — carried by the library's hipIpc
+    transport instead of RCCL, which refuses ranks that share a GPU."""
+    d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5",
+              "--min-replays", "1", "--min-seconds", "0.2", "--no-second-leg"],
+             env={"GNNFLOW_BENCH_DEVICE": "0", "GNNFLOW_BENCH_BACKEND": "gloo",
+                  "GNNFLOW_PART_TRANSPORT": "ipc"})
+    _check_common(d, 2, 20, 5)
+    assert d["config"]["parallelism"] == "hash-dp2"
+    assert "hipIpc" in d["config"]["exchange"] and "two samples each" in d["config"]["exchange"]
+    assert "0 overflowed" in d["config"]["exchange"]
