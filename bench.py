@@ -283,13 +283,17 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
     if repeats == 0:
         # calibration: the mean step time of a whole replay (15 % on top: the timed region
         # must not end up just short of --min-seconds)
-        t_step = None
-        for _ in range(2):      # the first replay still grows buffers: the second one counts
+        def timed(count):
             ctx.barrier()
             t0 = time.perf_counter()
-            pipe.run(0, nb)
+            pipe.run(0, count)
             ctx.barrier()
-            t_step = reduce((time.perf_counter() - t0) / nb, dist.ReduceOp.MAX)
+            return reduce((time.perf_counter() - t0) / count, dist.ReduceOp.MAX)
+        t_step = timed(min(nb, 64))          # a first look (the same value on every rank)
+        if t_step * nb < 0.3:
+            for _ in range(2):  # the first replay still grows buffers: the second one counts
+                t_step = timed(nb)
+        # else: slow steps (ranks sharing a GPU over a staged exchange): --min-replays decides
         need = max(min_replays * nb, 1.15 * min_seconds / max(t_step, 1e-7))
         repeats = max(1, -(-int(need) // max(steps, 1)))
     timed_steps = steps * repeats

@@ -30,6 +30,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .temporal_sampler import PendingSample as _PendingSample
+
 _MASK = (1 << 64) - 1
 
 
@@ -797,9 +799,8 @@ class DevicePartitionedSampler:
         return slab, slab[5] + off, nbytes
 
     def _pend(self, smp, slab, keep, R):
-        from .temporal_sampler import PendingSample
         # R = 0 still yields real (empty) blocks whose sizes come from the device
-        pending = PendingSample(smp, slab, keep, max(R, 1), None)
+        pending = _PendingSample(smp, slab, keep, max(R, 1), None)
         smp._inflight.append(pending)
         return pending
 
