@@ -218,7 +218,7 @@ def main():
         torch.cuda.synchronize()
         total = time.perf_counter() - e0
         out.append(dict(epoch=epoch, seconds=total, batches=nb, ms_per_batch=1e3 * total / nb,
-                        sampled_edges=edges, loss=float(loss),
+                        sampled_edges=edges, loss=float(loss.detach()),
                         node_cache_hit_ratio=float(cache.cache_node_ratio),
                         host_seconds_by_stage={k: round(v, 3) for k, v in T.items()}))
     print(json.dumps({
