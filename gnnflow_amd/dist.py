@@ -601,7 +601,10 @@ class DevicePartitionedSampler:
         if lanes is None:
             lanes = int(os.environ.get("GNNFLOW_PART_LANES", "2"))
         if (self._P == 1 and not self._always_exchange) or self._slack <= 0:
-            lanes = 1        # no exchange chain to overlap / host-synchronising exchange
+            # one rank without exchange: lanes were measured and do not pay (50-53 us per step
+            # with 1 lane, 54 with 2, 48 with 3: profiles/README.md round 4); the variable-size
+            # exchange synchronises the host per layer
+            lanes = 1
         if comms and comms[0].transport in ("ipc", "loopback"):
             lanes = min(lanes, len(comms))    # host-synchronising transports: as many as given
         lanes = max(1, min(int(lanes), 4))
