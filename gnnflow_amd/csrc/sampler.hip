@@ -1371,6 +1371,8 @@ void Sampler::reserve_workspace(size_t Rb, size_t num_blocks, hipStream_t stream
   retired_.collect();
   DeviceBuffer fresh;
   fresh.reserve(bytes, 0, stream);
+  // the first array doubles as the fused merge's granules: no stale tag in fresh memory
+  GF_HIP(hipMemsetAsync(fresh.data(), 0, align_up(ws_roots_ * 8, 16), stream));
   std::swap(ws_, fresh);
   retired_.retire(std::move(fresh), stream);
 }
@@ -1764,6 +1766,12 @@ void Sampler::merge_padded(const int64_t* d_roots, const float* d_ts, size_t R, 
 
 std::atomic<uint64_t> g_part_host_ns[8];
 
+// Tag of the look-back granules of one fused-merge launch: unique in the PROCESS, not per
+// sampler — a sampler's workspace may be memory another sampler's launches wrote granules into
+// (freed and allocated again), and a stale granule must never carry a tag a later launch uses.
+std::atomic<uint64_t> g_merge_epoch{0};
+inline uint64_t next_merge_tag() { return (g_merge_epoch.fetch_add(1) + 1) << 10; }
+
 // ---- partitioned sampling, chained on the device ------------------------------------------
 // part_begin -> for every (layer, snapshot): part_plan_own, [the caller's exchange: request
 // all-to-all-v, sample_layer_padded for what it received, reply all-to-all-v], part_merge ->
@@ -2064,7 +2072,7 @@ void Sampler::part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
     // granules: the workspace's rec_end array (8 B per root, unused by the partitioned path)
     const unsigned egrid = static_cast<unsigned>(
         (static_cast<uint64_t>(Rb) * F + kEmitThreads - 1) / kEmitThreads);
-    const uint64_t tag = (++merge_epoch_) << 10;
+    const uint64_t tag = next_merge_tag();
     merge_slots_fused_kernel<<<dim3(egrid), dim3(kEmitThreads), 0, stream>>>(
         roots, ts, d_R, R_host, F, rep, pos, static_cast<uint32_t>(lay.slot_stride),
         static_cast<uint32_t>(part_.world), reinterpret_cast<uint64_t*>(ws_.as<char>()), tag,
@@ -2429,7 +2437,7 @@ void Sampler::sample_partitioned_pair(Sampler& a, const int64_t* d_roots_a, cons
         mj[j] = MergeJob{roots[j], ts[j], d_R[j], R_host[j], replies,
                          reinterpret_cast<const uint32_t*>(base + pos_off[j]),
                          static_cast<uint32_t>(lay.slot_rows),
-                         reinterpret_cast<uint64_t*>(s.ws_.as<char>()), (++s.merge_epoch_) << 10,
+                         reinterpret_cast<uint64_t*>(s.ws_.as<char>()), next_merge_tag(),
                          s.part_overflow(), out.all_nodes, out.all_ts, out.dt, out.eids, out.row,
                          out.col, cslot, cslot + 1, (l + 1 < L) ? cslot + 2 : nullptr};
       }

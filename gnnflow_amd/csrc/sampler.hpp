@@ -158,7 +158,6 @@ class Sampler {
   bool part_own_counts(size_t root_bound) const;
   // slotted form, small layers: count + prefix + emit of the merge in ONE launch (granules)
   bool part_fused_merge(size_t root_bound, uint32_t fanout) const;
-  uint64_t merge_epoch_ = 0;   // tag of the look-back granules of the fused merge
   void part_commit_prepare(void* publish_out);   // Publish record of the sample being built
   void part_commit_finish();
   void part_roots(uint32_t layer, uint32_t snapshot, const int64_t** roots, const float** ts,

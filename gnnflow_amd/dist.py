@@ -763,13 +763,30 @@ class DevicePartitionedSampler:
         comm = self._ensure_comm(lane)
         ws_bytes = 0
         if comm is not None:
-            key = ("pair", max(Ra, 1), max(Rb, 1))
-            ws_bytes = self._layouts.get(key)
-            if ws_bytes is None:
+            # Whether two samples share a chain is part of the PROTOCOL (their slots travel in
+            # one exchange): every rank must decide alike, so the decision follows from the
+            # batch size all ranks agreed on (slot_roots), not from this rank's own batches.
+            pairable = self._layouts.get("pairable")
+            if pairable is None:
                 n = C.c_size_t(0)
-                check(lib.gf_sampler_part_pair_ws_bytes(sa._h, max(Ra, 1), max(Rb, 1), self._P,
-                                                        self._slack, self._slot_roots, C.byref(n)))
-                ws_bytes = self._layouts[key] = n.value
+                sr = max(self._slot_roots, 1)
+                check(lib.gf_sampler_part_pair_ws_bytes(sa._h, sr, sr, self._P, self._slack,
+                                                        self._slot_roots, C.byref(n)))
+                pairable = self._layouts["pairable"] = n.value > 0
+            if pairable:
+                key = ("pair", max(Ra, 1), max(Rb, 1))
+                ws_bytes = self._layouts.get(key)
+                if ws_bytes is None:
+                    n = C.c_size_t(0)
+                    check(lib.gf_sampler_part_pair_ws_bytes(sa._h, max(Ra, 1), max(Rb, 1), self._P,
+                                                            self._slack, self._slot_roots,
+                                                            C.byref(n)))
+                    ws_bytes = self._layouts[key] = n.value
+                if not ws_bytes:
+                    raise ValueError(
+                        "DevicePartitionedSampler: a batch of {} / {} roots is too large to share "
+                        "a chain although batches of slot_roots = {} roots do; pass slot_roots >= "
+                        "the largest batch, or pair=False".format(Ra, Rb, self._slot_roots))
         if not ws_bytes:      # no communicator / not pairable: two single chains
             first._attach(self._sample_slotted(lane, sa, first._nodes, first._ts, stream,
                                                worker_enqueue))

@@ -60,9 +60,9 @@ def world():
     return dict(g=g, dev=dev, shards=shards, full=full, batches=batches, O=O)
 
 
-def _run_ranks(fn):
-    """fn(rank) on 8 threads; returns their results, re-raising the first failure."""
-    out, err = [None] * P, [None] * P
+def _run_ranks(fn, n=P):
+    """fn(rank) on n threads; returns their results, re-raising the first failure."""
+    out, err = [None] * n, [None] * n
 
     def body(r):
         import torch
@@ -74,7 +74,7 @@ def _run_ranks(fn):
             import traceback
             err[r] = "rank {}: {}: {}\n{}".format(r, type(e).__name__, e,
                                                   traceback.format_exc()[-1500:])
-    threads = [threading.Thread(target=body, args=(r,)) for r in range(P)]
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(n)]
     for t in threads:
         t.start()
     for t in threads:
@@ -218,3 +218,62 @@ def test_sharded_feature_pull_at_world_8(world):
     assert all(p > 0 for p in pulled)      # 7/8 of the missed rows live on other ranks
     for c in comms:
         c.close()
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+def test_pair_chains_with_ragged_and_empty_batches(ranks):
+    """Two samples per chain (gf_sampler_sample_partitioned_comm_pair) where the partners differ:
+    empty batches, single roots, different sizes on different ranks in the same exchange, two
+    snapshots (not pairable: two single chains), an odd number of samples (the last one is issued
+    alone) — every MFG against the oracle over the whole graph."""
+    import torch
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from gnnflow_amd.dist import DevicePartitionedSampler, NativeComm, PartitionedGraph
+    from oracle import oracle as O
+    from tests import synth
+    dev = torch.device("cuda", 0)
+    src, dst, ts, eid = synth.powerlaw_graph(400, 12000, seed=5, tie_levels=500)
+    full = O.OracleGraph(minimum_block_size=8)
+    shards = [DynamicGraph(1 << 20, 64 << 20, "cuda", 8, 64, "insert") for _ in range(ranks)]
+    parts = [PartitionedGraph(s, r, ranks) for r, s in enumerate(shards)]
+    for lo in range(0, len(src), 2500):
+        sl = slice(lo, lo + 2500)
+        full.add_edges(src[sl], dst[sl], ts[sl], eid[sl], add_reverse=True)
+        for pg in parts:
+            pg.add_edges(src[sl], dst[sl], ts[sl], eid[sl], add_reverse=True)
+    sizes = [0, 1, 97, 600, 2000, 3, 0, 1500, 37]          # 9 samples: the last is issued alone
+    cases = [dict(fanouts=[6, 4], num_snapshots=1, snapshot_time_window=0.0),
+             dict(fanouts=[5], num_snapshots=2, snapshot_time_window=60.0)]
+    for kw in cases:
+        comms = NativeComm.loopback(ranks, dev)
+        batches = [[synth.random_roots(400, sizes[(it + r) % len(sizes)], 1000.0,
+                                       seed=1000 * r + it, extra_ids=[403])
+                    for it in range(len(sizes))] for r in range(ranks)]
+
+        def rank_body(r):
+            part = DevicePartitionedSampler(
+                TemporalSampler(shards[r], sample_strategy="recent", **kw), comm=comms[r],
+                slack=2.0, slot_roots=max(sizes))
+            side = torch.cuda.Stream()
+            pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t).to(dev),
+                                      stream=side, worker_enqueue=True) for n, t in batches[r][:4]]
+            got = [_to_host(p.wait()) for p in pend]
+            pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t).to(dev),
+                                      stream=side) for n, t in batches[r][4:]]
+            got += [_to_host(p.wait()) for p in pend]
+            return got, part.pairs, part.overflows
+
+        res = _run_ranks(rank_body, ranks)
+        ref = O.OracleSampler(full, kw["fanouts"], "recent", num_snapshots=kw["num_snapshots"],
+                              snapshot_time_window=kw["snapshot_time_window"])
+        for r in range(ranks):
+            got, pairs, over = res[r]
+            assert over == 0
+            # 4 samples -> 2 pairs, then 5 samples -> 2 pairs + one chain for the last alone
+            assert pairs == (4 if kw["num_snapshots"] == 1 else 0)
+            for (n, t), mfgs in zip(batches[r], got):
+                for gl, wl in zip(mfgs, ref.sample(n, t)):
+                    for gb, wb in zip(gl, wl):
+                        assert _same(gb, wb), (ranks, r, kw)
+        for c in comms:
+            c.close()

@@ -349,3 +349,41 @@ def test_uniform_policy_through_the_padded_kernel_is_uniform():
     # a root without candidates gets no slot at all
     empty = part.sample(np.array([0, 5]), np.array([0.0, 12.0], np.float32))[0][0]
     assert empty.num_edges() == 0
+
+
+def test_fused_merge_granules_survive_recycled_workspaces():
+    """The fused merge's look-back granules live in the sampler's workspace.  Samplers that
+    come and go reuse each other's freed memory, so a stale granule of an EARLIER sampler must
+    never carry the tag of a later launch (tags are unique in the process, and a fresh
+    workspace is cleared): create / sample / drop many samplers and compare every block."""
+    import gc
+    import torch
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from gnnflow_amd.dist import DevicePartitionedSampler, NativeComm
+    from tests import synth
+    src, dst, ts, eid = _graph()
+    g = DynamicGraph(1 << 20, 64 << 20, "cuda", 8, 64, "insert")
+    g.add_edges(src, dst, ts, eid, add_reverse=True)
+    kw = dict(fanouts=[7, 5], sample_strategy="recent")
+    plain = TemporalSampler(g, **kw)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream()
+    for round_ in range(8):
+        comm = NativeComm.loopback(1, dev)[0]
+        part = DevicePartitionedSampler(TemporalSampler(g, **kw), comm=comm, always_exchange=True,
+                                        slot_roots=3000)
+        sizes = [3000, 600, 97, 1500][round_ % 4:] + [2000, 1]
+        reqs = [synth.random_roots(400, R, 1000.0, seed=31 * round_ + R) for R in sizes]
+        pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t).to(dev),
+                                  stream=side) for n, t in reqs]
+        for (n, t), p in zip(reqs, pend):
+            for gl, wl in zip(p.wait(), plain.sample(n, t)):
+                for gb, wb in zip(gl, wl):
+                    for a, b in ((gb.srcdata["ID"], wb.srcdata["ID"]), (gb.edata["ID"], wb.edata["ID"]),
+                                 (gb.edata["dt"], wb.edata["dt"]), (gb.edges()[1], wb.edges()[1])):
+                        assert torch.equal(a, b), round_
+        assert part.pairs >= 1
+        del part, pend
+        comm.close()
+        gc.collect()
+        torch.cuda.empty_cache()
