@@ -213,10 +213,10 @@ PROTOTYPES = {
                                                 C.POINTER(_sz)]),
     "gf_sampler_sample_partitioned_comm_pair": (C.c_int, [_p, _p, _p, _p, _p, _sz, _p, _sz, _p, _p,
                                                           _sz, _p, _sz, _p, _sz, C.c_double, _sz,
-                                                          _p]),
+                                                          C.c_int, _p]),
     "gf_sampler_sample_partitioned_comm_pair_async": (C.c_int, [_p, _p, _p, _p, _p, _sz, _p, _sz,
                                                                 _p, _p, _sz, _p, _sz, _p, _sz,
-                                                                C.c_double, _sz, _p]),
+                                                                C.c_double, _sz, C.c_int, _p]),
     "gf_block_segment_offsets": (C.c_int, [_p, _sz, _sz, _p, C.c_int, _p]),
     "gf_block_edge_softmax": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, C.c_int, _p]),
     "gf_block_edge_softmax_backward": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, _p, C.c_int, _p]),

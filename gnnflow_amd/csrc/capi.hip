@@ -976,7 +976,7 @@ int gf_sampler_sample_partitioned_comm_pair(gf_sampler* sa, gf_sampler* sb, gf_c
                                             const int64_t* d_roots_b, const float* d_ts_b,
                                             size_t roots_b, void* d_out_b, size_t out_bytes_b,
                                             void* d_ws, size_t ws_bytes, double slack,
-                                            size_t slot_roots, void* stream) {
+                                            size_t slot_roots, int force_overflow, void* stream) {
   return guarded([&] {
     GF_REQUIRE(sa != nullptr && sb != nullptr && c != nullptr, "null sampler / communicator handle");
     for (gf_sampler* s : {sa, sb})
@@ -985,7 +985,8 @@ int gf_sampler_sample_partitioned_comm_pair(gf_sampler* sa, gf_sampler* sb, gf_c
     gf::Sampler::sample_partitioned_pair(sa->impl, d_roots_a, d_ts_a, roots_a, d_out_a, out_bytes_a,
                                          sb->impl, d_roots_b, d_ts_b, roots_b, d_out_b, out_bytes_b,
                                          d_ws, ws_bytes, slack, slot_roots, c->impl,
-                                         static_cast<hipStream_t>(stream));
+                                         static_cast<hipStream_t>(stream),
+                                         static_cast<unsigned>(force_overflow));
     sa->begin_tickets.push_back(0);
     sb->begin_tickets.push_back(0);
   });
@@ -996,7 +997,8 @@ int gf_sampler_sample_partitioned_comm_pair_async(gf_sampler* sa, gf_sampler* sb
                                                   const int64_t* d_roots_b, const float* d_ts_b,
                                                   size_t roots_b, void* d_out_b, size_t out_bytes_b,
                                                   void* d_ws, size_t ws_bytes, double slack,
-                                                  size_t slot_roots, void* stream) {
+                                                  size_t slot_roots, int force_overflow,
+                                                  void* stream) {
   return guarded([&] {
     GF_REQUIRE(sa != nullptr && sb != nullptr && c != nullptr, "null sampler / communicator handle");
     GF_REQUIRE(!c->loopback, "sample_partitioned_comm_pair_async: a loopback communicator's ranks "
@@ -1019,7 +1021,8 @@ int gf_sampler_sample_partitioned_comm_pair_async(gf_sampler* sa, gf_sampler* sb
           gf::Sampler::sample_partitioned_pair(*ia, d_roots_a, d_ts_a, roots_a, d_out_a,
                                                out_bytes_a, *ib, d_roots_b, d_ts_b, roots_b,
                                                d_out_b, out_bytes_b, d_ws, ws_bytes, slack,
-                                               slot_roots, *comm, st);
+                                               slot_roots, *comm, st,
+                                               static_cast<unsigned>(force_overflow));
         });
     sa->begin_tickets.push_back(t);
     sb->begin_tickets.push_back(t);

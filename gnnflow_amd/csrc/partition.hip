@@ -171,7 +171,8 @@ __device__ inline void plan_fused_body(
     const uint64_t* __restrict__ d_R, uint64_t R_host, OwnerDiv od, uint32_t rank,
     int64_t* __restrict__ requests, uint32_t* __restrict__ pos, uint64_t* __restrict__ counts,
     uint32_t* __restrict__ root_of, uint32_t stride, uint32_t* __restrict__ d_overflow,
-    int overflow_store, uint32_t slot_mul, uint32_t slot_add, uint32_t own_base) {
+    int overflow_store, uint32_t slot_mul, uint32_t slot_add, uint32_t own_base,
+    uint32_t force_overflow = 0) {
   const uint32_t P = od.P;
   __shared__ uint32_t s_before[kFusedThreads / 64][kMaxParts];
   __shared__ uint32_t s_total[kFusedThreads / 64][kMaxParts];
@@ -237,7 +238,7 @@ __device__ inline void plan_fused_body(
   if (tid == 0) {
     if (stride) {
       const uint32_t cap = stride - 1;
-      uint32_t ovf = 0;
+      uint32_t ovf = force_overflow ? 1u : 0u;
       for (uint32_t o = 0; o < P; ++o) {
         s_start[o] = o == rank ? own_base : (o * slot_mul + slot_add) * stride + 1;
         if (o != rank && s_total[0][o] > cap) ovf = 1;
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(kFusedThreads) void partition_plan_jobs_kernel(
     PlanJob a, PlanJob b, OwnerDiv od, uint32_t rank, uint32_t stride) {
   const PlanJob& j = blockIdx.y == 0 ? a : b;
   plan_fused_body(j.nodes, j.ts, j.d_R, j.R_host, od, rank, j.requests, j.pos, j.counts, nullptr,
-                  stride, j.d_overflow, j.overflow_store, j.slot_mul, j.slot_add, j.own_base);
+                  stride, j.d_overflow, j.overflow_store, j.slot_mul, j.slot_add, j.own_base,
+                  j.force_overflow);
 }
 
 }  // namespace

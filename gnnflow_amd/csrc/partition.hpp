@@ -34,6 +34,9 @@ struct PlanJob {
   int overflow_store;       // store the word (the sample's first plan) or only raise it
   uint32_t slot_mul, slot_add;
   uint32_t own_base;        // first row of this job's own share
+  uint32_t force_overflow;  // 1: flag the sample as overflowed whatever its slots hold (the
+                            // caller submitted an empty stand-in for a batch too large for
+                            // this chain; every rank then redoes that sample)
 };
 // `n` jobs (1 or 2) in one launch; R_bound sizes the grid (the largest job's bound).
 void partition_plan_jobs(const PlanJob* jobs, int n, size_t R_bound, int world_size, int rank,

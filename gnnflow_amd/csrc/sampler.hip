@@ -2335,7 +2335,7 @@ void Sampler::sample_partitioned_pair(Sampler& a, const int64_t* d_roots_a, cons
                                       const int64_t* d_roots_b, const float* d_ts_b, size_t Rb,
                                       void* d_out_b, size_t out_bytes_b, void* d_ws,
                                       size_t ws_bytes, double slack, size_t slot_roots,
-                                      Exchange& ex, hipStream_t stream) {
+                                      Exchange& ex, hipStream_t stream, unsigned force_overflow) {
   GF_REQUIRE(&a != &b, "sample_partitioned_pair: the two samples need a sampler each");
   GF_REQUIRE(a.graph_ == b.graph_ && a.fanouts_ == b.fanouts_ && a.policy_ == b.policy_ &&
                  a.num_snapshots_ == b.num_snapshots_ && a.window_ == b.window_ &&
@@ -2392,7 +2392,7 @@ void Sampler::sample_partitioned_pair(Sampler& a, const int64_t* d_roots_a, cons
                         reinterpret_cast<uint32_t*>(base + pos_off[j]),
                         reinterpret_cast<uint64_t*>(base + counts_off[j]),
                         sm[j]->part_overflow(), l == 0 ? 1 : 0, 2u, static_cast<uint32_t>(j),
-                        static_cast<uint32_t>(own_row[j])};
+                        static_cast<uint32_t>(own_row[j]), (force_overflow >> j) & 1u};
       }
       partition_plan_jobs(pj, 2, bound, P, me, stride, a.graph_->device(), stream);
       lap(1);

@@ -89,7 +89,8 @@ class Sampler {
                                       const int64_t* d_roots_b, const float* d_ts_b, size_t Rb,
                                       void* d_out_b, size_t out_bytes_b, void* d_ws,
                                       size_t ws_bytes, double slack, size_t slot_roots,
-                                      Exchange& ex, hipStream_t stream);
+                                      Exchange& ex, hipStream_t stream,
+                                      unsigned force_overflow = 0);
   void sample_partitioned(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                           size_t out_bytes, void* d_ws, size_t ws_bytes, hipStream_t stream);
   // several ranks, slotted form, the exchanges issued through `ex` (RCCL): the whole chain in

@@ -773,7 +773,26 @@ class DevicePartitionedSampler:
                 check(lib.gf_sampler_part_pair_ws_bytes(sa._h, sr, sr, self._P, self._slack,
                                                         self._slot_roots, C.byref(n)))
                 pairable = self._layouts["pairable"] = n.value > 0
+            force = 0
             if pairable:
+                # A batch too large for the pair chain's kernels (more roots than slot_roots, so
+                # that a layer exceeds 32 768 roots) cannot change the protocol on its own: an
+                # EMPTY stand-in travels in its place with the sample's overflow flag forced,
+                # every rank sees the flag and the real batch is sampled in the redo.
+                def fits(R):
+                    ok = self._layouts.get(("fits", R))
+                    if ok is None:
+                        n = C.c_size_t(0)
+                        check(lib.gf_sampler_part_pair_ws_bytes(sa._h, R, 1, self._P, self._slack,
+                                                                self._slot_roots, C.byref(n)))
+                        ok = self._layouts[("fits", R)] = n.value > 0
+                    return ok
+                if not fits(max(Ra, 1)):
+                    force |= 1
+                    Ra = 0
+                if not fits(max(Rb, 1)):
+                    force |= 2
+                    Rb = 0
                 key = ("pair", max(Ra, 1), max(Rb, 1))
                 ws_bytes = self._layouts.get(key)
                 if ws_bytes is None:
@@ -782,11 +801,7 @@ class DevicePartitionedSampler:
                                                             self._slack, self._slot_roots,
                                                             C.byref(n)))
                     ws_bytes = self._layouts[key] = n.value
-                if not ws_bytes:
-                    raise ValueError(
-                        "DevicePartitionedSampler: a batch of {} / {} roots is too large to share "
-                        "a chain although batches of slot_roots = {} roots do; pass slot_roots >= "
-                        "the largest batch, or pair=False".format(Ra, Rb, self._slot_roots))
+                assert ws_bytes, "a pair of fitting samples has a workspace"
         if not ws_bytes:      # no communicator / not pairable: two single chains
             first._attach(self._sample_slotted(lane, sa, first._nodes, first._ts, stream,
                                                worker_enqueue))
@@ -803,7 +818,7 @@ class DevicePartitionedSampler:
         check(call(sa._h, sb._h, comm.h,
                    na.data_ptr() if Ra else None, ta.data_ptr() if Ra else None, Ra, out_a, nb_a,
                    nb_.data_ptr() if Rb else None, tb.data_ptr() if Rb else None, Rb, out_b, nb_b,
-                   ws.data_ptr(), ws_bytes, self._slack, self._slot_roots, slab_a[6]))
+                   ws.data_ptr(), ws_bytes, self._slack, self._slot_roots, force, slab_a[6]))
         first._attach(self._pend(sa, slab_a, (na, ta, ws), Ra))
         second._attach(self._pend(sb, slab_b, (nb_, tb, ws), Rb))
         self.pairs += 1

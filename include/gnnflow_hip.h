@@ -564,7 +564,11 @@ GF_API int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c,
  * both samples' slots; 11 operations per two samples.  gf_sampler_part_pair_ws_bytes: size of
  * the shared exchange workspace, 0 if these two samples cannot share a chain (several
  * snapshots, a layer beyond 32 768 roots, fanout > 256): the caller then issues two single
- * chains.  No reference counterpart (its RPC futures are per partition and per call,
+ * chains.  force_overflow (bit 0: sample a, bit 1: sample b): flag that sample as overflowed
+ * whatever its slots hold — for a batch that is too large for this chain although the batch size
+ * the ranks agreed on is not, the caller submits an EMPTY stand-in with this bit set, every rank
+ * sees the flag in the same exchange and the real batch is sampled in the redo.  No reference
+ * counterpart (its RPC futures are per partition and per call,
  * gnnflow/distributed/dist_sampler.py:188-220). */
 GF_API int gf_sampler_part_pair_ws_bytes(const gf_sampler* s, size_t roots_a, size_t roots_b,
                                          int world_size, double slack, size_t slot_roots,
@@ -573,12 +577,12 @@ GF_API int gf_sampler_sample_partitioned_comm_pair(
     gf_sampler* sa, gf_sampler* sb, gf_comm* c, const int64_t* d_roots_a, const float* d_ts_a,
     size_t roots_a, void* d_out_a, size_t out_bytes_a, const int64_t* d_roots_b,
     const float* d_ts_b, size_t roots_b, void* d_out_b, size_t out_bytes_b, void* d_ws,
-    size_t ws_bytes, double slack, size_t slot_roots, void* stream);
+    size_t ws_bytes, double slack, size_t slot_roots, int force_overflow, void* stream);
 GF_API int gf_sampler_sample_partitioned_comm_pair_async(
     gf_sampler* sa, gf_sampler* sb, gf_comm* c, const int64_t* d_roots_a, const float* d_ts_a,
     size_t roots_a, void* d_out_a, size_t out_bytes_a, const int64_t* d_roots_b,
     const float* d_ts_b, size_t roots_b, void* d_out_b, size_t out_bytes_b, void* d_ws,
-    size_t ws_bytes, double slack, size_t slot_roots, void* stream);
+    size_t ws_bytes, double slack, size_t slot_roots, int force_overflow, void* stream);
 
 /* ---- message passing on a sampled block ---------------------- */
 /* The DGL calls of the reference's layers on an MFG (gnnflow/models/modules/layers.py:153-159,
