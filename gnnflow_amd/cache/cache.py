@@ -11,6 +11,7 @@ Same constructor arguments, attributes read by callers (`cache_node_ratio`,
   * hit ratios are accumulated on the device and only synchronised when read.
 """
 import ctypes as C
+from collections import deque
 import os
 import struct
 from typing import List, Optional, Union
@@ -153,8 +154,7 @@ class Cache:
         self._shards = shards
         self.neg_sample_ratio = neg_sample_ratio
         self._target_edge_features = None
-        self._ticket = 0
-        self._pending_refs = None
+        self._tickets = deque()    # (ticket, keepalive) of asynchronous fetches not yet enqueued
         self.feature_placement = placement
         # serve an edge block that is a prefix of the previously fetched one from that
         # block's rows (LRU only; fetch_feature); GNNFLOW_PREFIX_ALIAS=0 turns it off
@@ -312,15 +312,14 @@ class Cache:
         self._stats_pos += n
         return pos
 
-    def wait_enqueued(self):
-        """Blocks until the last asynchronous fetch_feature() has been enqueued on its
-        stream (no-op otherwise).  Stream order then guarantees the results."""
-        ticket = getattr(self, "_ticket", 0)
-        if ticket:
-            self._ticket = 0
-            rc = self._lib.gf_cache_fetch_wait(ticket)
-            self._pending_refs = None
-            _capi.check(rc)
+    def wait_enqueued(self, upto=None):
+        """Blocks until the asynchronous fetch_feature() calls so far (`upto`: up to that
+        ticket) have been enqueued on their stream (no-op otherwise).  Stream order then
+        guarantees the results.  Submissions are enqueued in ticket order."""
+        q = self.__dict__.get("_tickets")
+        while q and (upto is None or q[0][0] <= upto):
+            ticket, _refs = q.popleft()
+            _capi.check(self._lib.gf_cache_fetch_wait(ticket))
 
     @property
     def target_edge_features(self):
@@ -347,7 +346,12 @@ class Cache:
         enqueue thread; `b.srcdata['h']` / `b.edata['f']` / `target_edge_features` then wait
         for the enqueue on first access (blocks built by gnnflow_amd.TemporalSampler), or
         call wait_enqueued()."""
-        self.wait_enqueued()      # at most one submission in flight
+        # at most two submissions with the enqueue thread: when that thread also issues the
+        # partitioned sampler's chains (tens of microseconds each), the previous fetch may still
+        # be queued behind one, and waiting for it here would stall the caller
+        q = self.__dict__.get("_tickets")
+        if q and (len(q) >= 2 or self.distributed):
+            self.wait_enqueued(None if self.distributed else q[0][0])
         if self.distributed:
             return self._fetch_distributed(mfgs, eid, update_cache, target_edge_features)
         upd = 1 if update_cache else 0
@@ -787,6 +791,7 @@ class Cache:
         self.algorithmic_bytes += sum(job[2] * (8 + 8 * job[4]) for job in jobs)
         self.rows_moved += sum(job[2] for job in jobs)
         descs = self._desc_buf(nj)
+        box = [0]     # this submission's ticket, for the thunks below
         pack = _DESC.pack_into
         for i, (kind, ids_ptr, n, _keep, dim, b, which, key) in enumerate(jobs):
             off = offs[i]
@@ -795,7 +800,7 @@ class Cache:
 
             def rows(off=out_base + off, n=n, dim=dim, sync=async_enqueue):
                 if sync:
-                    self.wait_enqueued()
+                    self.wait_enqueued(box[0])
                 return out_all[off:off + n * dim].view(n, dim)
             if b is None:
                 self._target_edge_thunk = rows      # cache.py:411 `edge_feats[eid]`
@@ -808,7 +813,7 @@ class Cache:
             def prefix_rows(off=out_base + offs[owner], n=n, dim=jobs[owner][4],
                             sync=async_enqueue):
                 if sync:
-                    self.wait_enqueued()
+                    self.wait_enqueued(box[0])
                 return out_all[off:off + n * dim].view(n, dim)
             b.set_lazy("e", "f", prefix_rows)
         node_h = self._node.h if self._node is not None else None
@@ -819,9 +824,9 @@ class Cache:
             ticket = C.c_uint64(0)
             _capi.check(self._lib.gf_cache_fetch_blocks_async(
                 node_h, edge_h, C.byref(cdescs), nj, self._stream(), C.byref(ticket)))
-            self._ticket = ticket.value
+            box[0] = ticket.value
             # ids / outputs / descriptors must outlive the enqueue
-            self._pending_refs = (jobs, descs, cdescs, mfgs, out_all)
+            self._tickets.append((ticket.value, (jobs, descs, cdescs, mfgs, out_all)))
         else:
             _capi.check(self._lib.gf_cache_fetch_blocks(
                 node_h, edge_h, C.byref(cdescs), nj, self._stream()))

@@ -1,0 +1,13 @@
+timeout -k 10 600 python -m pytest tests/test_gpu_cache.py tests/test_gpu_pipeline_parity.py tests/test_gpu_harness.py tests/test_gpu_example.py -x -q 2>&1 | tail -3
+C="--no-cpu-baseline --no-second-leg --no-config3 --steps 1121 --warmup 20 --min-seconds 1.0"
+show() { python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$1', round(1e3*d['ms_per_step'],1), 'us/step', round(d['value']/1e6,1), 'M edges/s depth', d['config']['pipeline_depth'])
+"; }
+for rep in 1 2 3; do
+python bench.py $C 2>/dev/null | show "replica"
+python bench.py $C --partition hash --always-exchange 2>/dev/null | show "hash pairs 2 lanes"
+done
+timeout -k 10 120 python scripts/host_overhead_hash.py --lanes 2 --depth 6 2>/dev/null | tail -2
