@@ -47,8 +47,10 @@ inside one machine) rides along as the extra key "replica"; `--partition replica
 it the main loop.  Should the hash-partitioned loop FAIL (RCCL between ranks ran for the first
 time in the driver's scaling run), every rank falls back to the replica loop: the line then
 says "parallelism": "replica-dpN" and carries the failure under "hash_partition": {"error"}.
-At N = 1 the main loop is the plain single-GPU path and the hash path (every root is the
-rank's own) is the extra key "hash_partition".
+At N = 1 the main loop is the plain single-GPU path; the hash path rides along twice: "hash_partition"
+(every root is the rank's own, no exchange) and "hash_partition_over_rccl_one_rank" (the chain an
+N > 1 run issues — slotted exchange, lanes, two samples per chain — with every message going
+through RCCL to the rank itself).
 """
 import argparse
 import json
@@ -222,11 +224,13 @@ class Ctx:
     pass
 
 
-def build_leg(ctx, kind):
+def build_leg(ctx, kind, always_exchange=None):
     """Graph + sampler of one kind over this rank's GPU: "replica" = the whole graph, "hash" =
     this rank's shard + the partitioned sampler."""
     import gnnflow_amd
     args, g = ctx.args, ctx.g
+    if always_exchange is None:
+        always_exchange = args.always_exchange
     MiB = 1 << 20
     # gnnflow/config.py:121-131 _reddit_default_config
     graph = gnnflow_amd.DynamicGraph(20 * MiB, 1000 * MiB, "cuda", 62, 1024, "insert",
@@ -247,7 +251,7 @@ def build_leg(ctx, kind):
         # replies travel as equal-split all-to-alls, and the rank's own share is sampled meanwhile
         sampler = DevicePartitionedSampler(sampler, slack=args.part_slack,
                                            slot_roots=3 * args.batch_size,
-                                           always_exchange=args.always_exchange,
+                                           always_exchange=always_exchange,
                                            lanes=args.part_lanes)
     return graph, sampler, build_s
 
@@ -618,6 +622,12 @@ def main():
         other = "hash" if main_kind == "replica" else "replica"
         second_leg.pending_line = out
         out["hash_partition" if other == "hash" else "replica"] = second_leg(ctx, other, cache)
+        if world == 1 and other == "hash" and not args.always_exchange and backend == "nccl":
+            # ... and the chain the ranks of an N > 1 run really issue — slotted exchange, lanes,
+            # two samples per chain — with every message travelling through RCCL to this rank
+            # itself: what the multi-rank path costs before any real peer exists
+            out["hash_partition_over_rccl_one_rank"] = second_leg(ctx, "hash", cache,
+                                                                  always_exchange=True)
 
     if args.breakdown and rank == 0:
         lib.gf_profile_reset()
@@ -708,14 +718,16 @@ def exchange_note(sampler, world, backend):
     return "2 all-to-all-v per layer over {} (one host sync per layer)".format(via)
 
 
-def second_leg(ctx, kind, cache):
+def second_leg(ctx, kind, cache, always_exchange=None):
     import threading
     # RCCL with more than one rank has never run on this code path before the first scaling
     # run: a watchdog ends every rank if a collective hangs — rank 0 first prints the line it
     # has, with an error note, then every rank exits NON-ZERO.
     limit = float(os.environ.get("GNNFLOW_HASH_LEG_TIMEOUT", "180"))
     done = threading.Event()
-    key = "hash_partition" if kind == "hash" else "replica"
+    key = "replica" if kind != "hash" else (
+        "hash_partition_over_rccl_one_rank" if always_exchange and ctx.world == 1
+        else "hash_partition")
 
     def watchdog():
         if not done.wait(limit):
@@ -725,13 +737,24 @@ def second_leg(ctx, kind, cache):
             os._exit(3)
     threading.Thread(target=watchdog, daemon=True).start()
     try:
-        _graph, sampler, _ = build_leg(ctx, kind)
+        if always_exchange and ctx.world == 1:
+            import socket
+            import torch.distributed as dist
+            if not dist.is_initialized():      # one rank: RCCL to this rank itself
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0))
+                    port = so.getsockname()[1]
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ["MASTER_PORT"] = str(port)
+                dist.init_process_group("nccl", device_id=ctx.dev, rank=0, world_size=1)
+        _graph, sampler, _ = build_leg(ctx, kind, always_exchange)
         res = time_leg(ctx, sampler, cache, False, min(ctx.args.min_seconds, 1.0), 1.0)
         return {"value": res["edges_all"] / res["elapsed"], "unit": "edges/s",
                 "ms_per_step": 1e3 * res["elapsed"] / res["timed_steps"],
                 "steps": res["steps"], "repeats": res["repeats"],
                 "timed_seconds": res["elapsed"], "world_size": ctx.world,
                 "pipelined": bool(res["pipe"].pipelined),
+                "pipeline_depth": res["pipe"].depth,
                 "exchange": exchange_note(sampler, ctx.world, ctx.backend) if kind == "hash" else
                 "none (a full replica of the graph per GPU, no data-path collective)"}
     except Exception as e:   # the main figure above must survive a failing second leg
