@@ -694,6 +694,16 @@ def exchange_note(sampler, world, backend):
     lanes = getattr(sampler, "lanes", 1)
     lane_note = "; {} sampling lanes (stream + workspace + communicator each), consecutive " \
                 "batches round-robin".format(lanes) if lanes > 1 else ""
+    try:
+        import ctypes as C
+        from gnnflow_amd import _capi
+        n = C.c_uint64(0)
+        _capi.load().gf_debug_merge_recounts(C.byref(n))
+        if n.value:
+            lane_note += "; {} merge tiles recounted by a look-back that stopped waiting " \
+                         "(oversubscribed GPU)".format(n.value)
+    except Exception:      # noqa: BLE001 — diagnostics only
+        pass
     if getattr(sampler, "pairs", 0):
         lane_note += "; {} chains carried two samples each (shared launches and " \
                      "exchanges)".format(sampler.pairs)

@@ -263,6 +263,7 @@ using gf::guarded;
 namespace gf {
 // sampler.hip
 void part_host_us(double out[8], bool reset);
+uint64_t merge_recounts();
 // partition.hip
 size_t partition_scratch_bytes(size_t R, int world_size);
 void partition_plan(const int64_t* d_nodes, const float* d_ts, size_t R, int world_size, int rank,
@@ -1088,6 +1089,12 @@ int gf_block_reduce_max_backward(size_t num_dst, const int64_t* d_col, size_t di
   });
 }
 
+int gf_debug_merge_recounts(uint64_t* out) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_debug_merge_recounts: null output");
+    *out = gf::merge_recounts();
+  });
+}
 int gf_debug_part_host_us(double* out, int reset) {
   return guarded([&] {
     GF_REQUIRE(out != nullptr, "gf_debug_part_host_us: null output");

@@ -1063,13 +1063,14 @@ __global__ __launch_bounds__(kEmitThreads) void merge_emit_prefix_kernel(
 // agent-scope store before it looks at anybody else's, then adds up the granules of the tiles
 // before its own (decoupled look-back; a granule is one naturally aligned sc1 store / sc1 load,
 // so no fence is needed: /opt/skills/guides MI355X_MICROARCH "granule").  Tiles are dispatched in
-// index order per XCD, so the lowest unfinished tile never waits for an undispatched one.  A
-// poll that does not see its granule within kGranuleSpins tries gives up and flags the sample as
-// overflowed — it is then sampled again through the variable-size exchange (never a hang).
+// index order, so normally the lowest unfinished tile never waits for an undispatched one; a
+// poll that does not see its granule within kGranuleSpins tries stops waiting and recounts that
+// tile itself (see the look-back loop: termination does not depend on dispatch order).
 // Replaces merge_count_slots_kernel + merge_emit_prefix_kernel: the chain of a sample is bound
 // by the host thread that issues its launches, so one launch less per layer is ~3 us per sample.
+__device__ unsigned int g_merge_recounts;          // tiles a look-back had to count itself
 constexpr uint64_t kGranuleCountMask = 0x3FF;      // a tile has kEmitThreads = 256 slots
-constexpr uint32_t kGranuleSpins = 1u << 24;
+constexpr uint32_t kGranuleSpins = 1u << 12;   // ~ a few ms of polling before a tile is recounted
 struct MergeJob {
   const int64_t* roots;
   const float* root_ts;
@@ -1140,7 +1141,13 @@ __device__ inline void merge_slots_fused_body(
   if (tid == 0)
     __hip_atomic_store(&granules[blockIdx.x], tag | tile_cnt, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
-  // look-back: the tiles before this one
+  // look-back: the tiles before this one.  A granule that has not arrived after kGranuleSpins
+  // polls is NOT waited for any longer: the thread counts that tile's valid slots itself (256
+  // slots, two loads each: slow, but it depends on nobody).  Termination therefore does not
+  // rest on the order in which workgroups are dispatched — with the GPU oversubscribed (several
+  // such kernels of different streams or processes in flight, workgroups dealt to the XCDs
+  // independently) a tile could otherwise wait for one that cannot be dispatched because its
+  // XCD is full of waiters: observed with 4 rank processes sharing one GPU.
   uint32_t part = 0;
   for (uint32_t b = tid; b < blockIdx.x; b += kEmitThreads) {
     uint64_t g = 0;
@@ -1148,9 +1155,19 @@ __device__ inline void merge_slots_fused_body(
     for (;;) {
       g = __hip_atomic_load(&granules[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((g & ~kGranuleCountMask) == tag) break;
-      if (++spins == kGranuleSpins) {   // never a hang: the sample is redone
-        atomicOr(d_overflow, 4u);
-        g = 0;
+      if (++spins == kGranuleSpins) {
+        uint32_t cnt = 0;
+        const uint64_t lo = static_cast<uint64_t>(b) * kEmitThreads;
+        const uint64_t hi = min(lo + kEmitThreads, total);
+        for (uint64_t u = lo; u < hi; ++u) {
+          const uint32_t ru = static_cast<uint32_t>(u / fanout);
+          const uint32_t ju = static_cast<uint32_t>(u - static_cast<uint64_t>(ru) * fanout);
+          const uint32_t pu = pos[ru];
+          if (!(pu < slot_rows && pu % stride == 0))
+            cnt += rep[(static_cast<uint64_t>(pu) * fanout + ju) * 3] >= 0 ? 1u : 0u;
+        }
+        g = cnt;
+        atomicAdd(&g_merge_recounts, 1u);   // diagnostics (gf_debug_merge_recounts)
         break;
       }
       __builtin_amdgcn_s_sleep(1);
@@ -1627,13 +1644,7 @@ void Sampler::sample_end(gf_block* blocks) {
     o.num_src_nodes = o.num_dst_nodes + o.num_edges;
   }
   last_overflow_ = hc[2 * L * NS] != 0;
-  const bool granule_timeout = (hc[2 * L * NS] & 4) != 0;
   pop();
-  // merge_slots_fused_kernel gave up waiting for another workgroup's granule: the blocks are
-  // garbage.  Not expected to happen; reported instead of handed on (GNNFLOW_PART_FUSED_MERGE=0
-  // takes the two-launch merge)
-  if (granule_timeout)
-    throw Error(GF_ERR_HIP, "partitioned merge: a look-back granule did not arrive (fused merge)");
 }
 
 void Sampler::sample(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
@@ -2256,6 +2267,14 @@ void Sampler::sample_partitioned_slotted(const int64_t* d_roots, const float* d_
     part_abort();
     throw;
   }
+}
+
+// Tiles whose look-back granule did not arrive in time and were recounted by the waiting thread
+// (fused merge), since the library was loaded, on the current device.
+uint64_t merge_recounts() {
+  unsigned int v = 0;
+  GF_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_merge_recounts), sizeof(v)));
+  return v;
 }
 
 // Host time the issuing thread spent per stage of the slotted chain since the last reset:

@@ -645,6 +645,11 @@ GF_API int gf_profile_set_stride(unsigned stride);
  * (microseconds, summed over the samples), out[7] = samples.  Diagnostics: the chain is ~13
  * stream operations issued by one thread, which bounds its throughput at small batches. */
 GF_API int gf_debug_part_host_us(double out[8], int reset);
+/* Tiles of the fused partitioned merge whose look-back granule did not arrive within the polling
+ * budget and were recounted by the waiting thread instead (current device, since the library
+ * was loaded).  0 in normal operation; non-zero when the GPU is heavily oversubscribed (several
+ * rank processes sharing one card).  Synchronises nothing but the copy itself. */
+GF_API int gf_debug_merge_recounts(uint64_t* out);
 /* All launches of a family seen since the last reset while it was enabled, timed or not. */
 GF_API int gf_profile_launches(int which, uint64_t* launches);
 
