@@ -144,6 +144,19 @@ def test_a_dying_rank_ends_the_launcher_non_zero_with_one_line():
     assert d["value"] == 0.0 and "error" in d
 
 
+def test_four_ranks_sharing_the_gpu_finish_the_hash_loop():
+    """Four rank processes time-slicing ONE GPU, native chains over the hipIpc transport: the
+    fused merge's look-back must not depend on the other tiles being dispatched (before the
+    recount fall-back this run ended in "a look-back granule did not arrive" and the bench fell
+    back to the replica loop)."""
+    d = _run([sys.executable, "bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5",
+              "--min-replays", "1", "--min-seconds", "0.2", "--no-second-leg"],
+             env={"GNNFLOW_BENCH_DEVICE": "0", "GNNFLOW_BENCH_BACKEND": "gloo",
+                  "GNNFLOW_PART_TRANSPORT": "ipc"})
+    _check_common(d, 4, 20, 5)
+    assert d["config"]["parallelism"] == "hash-dp4" and "hash_partition" not in d
+
+
 def test_two_ranks_native_chains_over_the_ipc_transport():
     """The closest a one-GPU box gets to the driver's multi-GPU run: bench.py's own launcher, two
     rank processes, and the NATIVE partitioned chains (sampling lanes, two samples per chain,
