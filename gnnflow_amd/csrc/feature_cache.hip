@@ -1795,9 +1795,12 @@ inline uint32_t pick_tile_rows(size_t n) {
   }();
   if (forced >= 1 && forced <= 64) return static_cast<uint32_t>(forced);
   // measured on the batch-600 blocks (10k-30k rows): 16 rows per wave beats both 4 (more,
-  // shorter waves: 17.8 us/launch) and 32 (16.7 us) at 13.8 us; aim for >= 1024 waves
+  // shorter waves: 17.8 us/launch) and 32 (16.7 us) at 13.8 us; aim for >= 1024 waves, but
+  // never below 16 rows — a 16-row tile of 172-d rows is one trip of 11 loads per lane, and
+  // the replay's mid-size blocks (5-16 k rows) ran at 8 rows per wave before: whole replay
+  // 14.1-14.3 -> 13.6 us per launch (round 4, same box; 8 rows everywhere: 20.2 us)
   uint32_t t = 64;
-  while (t > 8 && (n + t - 1) / t < 1024) t >>= 1;
+  while (t > 16 && (n + t - 1) / t < 1024) t >>= 1;
   return t;
 }
 
