@@ -2015,7 +2015,9 @@ void Sampler::part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
     const size_t n_bound = layer == 0 ? part_.R : lay.root_bound;
     const uint64_t call_own = calls_++;
     const size_t n_max = std::max<size_t>(n, n_bound);
-    const int width = n_max > kSmallRoots ? large_group_ : search_group_;
+    // width by the layer's roots, not by the (mostly empty) slot rows
+    const size_t n_real = std::max<size_t>(lay.root_bound, n_bound);
+    const int width = n_real > kSmallRoots ? large_group_ : search_group_;
     const unsigned grid = capped_grid(n_max, kSearchThreads / width, 256 * 8);
     uint64_t* d_counts = reinterpret_cast<uint64_t*>(w + lay.counts);
     const PaddedCommon pc{snapshot, num_snapshots_, window_, F,
@@ -2030,7 +2032,7 @@ void Sampler::part_serve(uint32_t layer, uint32_t snapshot, void* d_ws, size_t w
                             ? part_rec_cnt() : nullptr, stride,
                         static_cast<uint32_t>(part_.world), nullptr};
     ProfileScope ps(kProfSearch, stream);
-    launch_padded_pair(width, grid, stream, view_for(graph_, n_max), pc, serve, own);
+    launch_padded_pair(width, grid, stream, view_for(graph_, n_real), pc, serve, own);
     GF_HIP(hipGetLastError());
     return;
   }
@@ -2421,7 +2423,10 @@ void Sampler::sample_partitioned_pair(Sampler& a, const int64_t* d_roots_a, cons
       // 3. the received slots (of both samples, served alike) and both own shares
       const uint64_t n_inbox = lay.slot_rows;
       const size_t n_max = std::max<size_t>(n_inbox, bound);
-      const int width = n_max > kSmallRoots ? a.large_group_ : a.search_group_;
+      // group width by the roots there really are (<= the layer's bound per sample), not by the
+      // slot rows, most of which are empty: a latency chain wants the 16-lane search
+      // (layer 1 of the batch-600 pair: 9.3 -> see profiles/README.md round 4)
+      const int width = bound > kSmallRoots ? a.large_group_ : a.search_group_;
       const unsigned grid = capped_grid(n_max, kSearchThreads / width, 256 * 8);
       const PaddedCommon pc{0, 1, a.window_, F, a.policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0,
                             a.prop_time_ ? 1 : 0, a.seed_};
@@ -2439,7 +2444,7 @@ void Sampler::sample_partitioned_pair(Sampler& a, const int64_t* d_roots_a, cons
       }
       {
         ProfileScope ps(kProfSearch, stream);
-        launch_padded_trio(width, grid, stream, view_for(a.graph_, n_max), pc, serve, own[0],
+        launch_padded_trio(width, grid, stream, view_for(a.graph_, bound), pc, serve, own[0],
                            own[1]);
         GF_HIP(hipGetLastError());
       }
