@@ -582,36 +582,66 @@ __global__ __launch_bounds__(kEmitThreads) void sample_emit_kernel(
     const uint32_t* __restrict__ rec_cnt, const uint32_t* __restrict__ base,
     int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
     int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col,
-    Publish pub) {
+    Publish pub, int unroll) {
   const uint64_t R = d_R ? *d_R : R_host;
   const uint64_t total = R * fanout;
   if (pub.num_words && blockIdx.x == 0 && threadIdx.x == 0) {   // sizes: final before this launch
     for (uint32_t i = 0; i < pub.num_words; ++i) pub.h_counts[i] = pub.d_counts[i];
     pub.h_counts[pub.num_words] = 0;
   }
+  // Four slots per thread and trip, every load of a stage issued before the first use: a
+  // sampled edge is ONE random 32-byte record, and what bounds this kernel at large batches is
+  // how many of those reads are in flight (HBM's random-access rate), not bytes.  One slot per
+  // trip left each wave with a single record read outstanding between two dependent hops
+  // (count / end -> record -> stores); GNNFLOW_EMIT_UNROLL=1 is that form.
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-  for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
-       t += stride) {
-    if (t < R) {  // dst nodes come first in all_nodes / all_timestamps
-      all_nodes[t] = roots[t];
-      all_ts[t] = root_ts[t];
+  const uint64_t first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  constexpr int K = 4;
+  for (uint64_t t0 = first; t0 < total; t0 += (unroll ? K : 1) * stride) {
+    uint64_t t[K], r[K], end[K];
+    uint32_t j[K], n[K], bs[K];
+    float rts[K];
+    bool in[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      t[k] = t0 + static_cast<uint64_t>(k) * stride;
+      in[k] = (k == 0 || unroll) && t[k] < total;
+      r[k] = in[k] ? t[k] / fanout : 0;
+      j[k] = static_cast<uint32_t>(t[k] - r[k] * fanout);
     }
-    const uint64_t r = t / fanout;
-    const uint32_t j = static_cast<uint32_t>(t - r * fanout);
-    const uint32_t n = rec_cnt[r];
-    if (j >= valid_slots(n, fanout, uniform)) continue;
-    const uint32_t pick = uniform ? gf_philox4x32_10_first(seed, t, call) % n : j;
-    const uint64_t e = rec_end[r] - 1 - pick;
-    const EdgePair nb = g.nbr_pool[e];
-    const float ets = nb.ts;
-    const float rts = root_ts[r];
-    const uint64_t o = static_cast<uint64_t>(base[r]) + j;
-    all_nodes[R + o] = nb.dst;
-    all_ts[R + o] = prop_time ? rts : ets;
-    dt[o] = rts - ets;
-    eids[o] = nb.eid;
-    row[o] = static_cast<int64_t>(r);
-    col[o] = static_cast<int64_t>(R + o);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      n[k] = in[k] ? rec_cnt[r[k]] : 0u;
+      end[k] = in[k] ? rec_end[r[k]] : 0;
+      bs[k] = in[k] ? base[r[k]] : 0u;
+      rts[k] = in[k] ? root_ts[r[k]] : 0.f;
+      if (in[k] && t[k] < R) {  // dst nodes come first in all_nodes / all_timestamps
+        all_nodes[t[k]] = roots[t[k]];
+        all_ts[t[k]] = root_ts[t[k]];
+      }
+    }
+    EdgePair nb[K];
+    bool ok[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      ok[k] = in[k] && j[k] < valid_slots(n[k], fanout, uniform);
+      if (ok[k]) {
+        const uint32_t pick = uniform ? gf_philox4x32_10_first(seed, t[k], call) % n[k] : j[k];
+        nb[k] = g.nbr_pool[end[k] - 1 - pick];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (!ok[k]) continue;
+      const float ets = nb[k].ts;
+      const uint64_t o = static_cast<uint64_t>(bs[k]) + j[k];
+      all_nodes[R + o] = nb[k].dst;
+      all_ts[R + o] = prop_time ? rts[k] : ets;
+      dt[o] = rts[k] - ets;
+      eids[o] = nb[k].eid;
+      row[o] = static_cast<int64_t>(r[k]);
+      col[o] = static_cast<int64_t>(R + o);
+    }
   }
 }
 
@@ -1484,9 +1514,14 @@ void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb
   {
     ProfileScope ps(kProfEmit, stream);
     unsigned grid = capped_grid(static_cast<uint64_t>(Rb) * F, kEmitThreads, 256 * 16);
+    static const int unroll = [] {
+      const char* v = std::getenv("GNNFLOW_EMIT_UNROLL");   // A/B runs: 1 = one slot per trip
+      return (v && std::atoi(v) == 1) ? 0 : 1;
+    }();
     sample_emit_kernel<<<dim3(grid), dim3(kEmitThreads), 0, stream>>>(
         gv, d_roots, d_ts, d_R, R_host, F, uniform, prop_time_ ? 1 : 0, seed_, call, rec_end,
-        rec_cnt, base, out.all_nodes, out.all_ts, out.dt, out.eids, out.row, out.col, pub);
+        rec_cnt, base, out.all_nodes, out.all_ts, out.dt, out.eids, out.row, out.col, pub,
+        unroll);
     GF_HIP(hipGetLastError());
   }
 }
