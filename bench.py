@@ -113,7 +113,7 @@ def parse(argv=None):
     ap.add_argument("--part-lanes", type=int, default=None,
                     help="sampling lanes of the partitioned sampler: consecutive batches go "
                          "round-robin to lanes with their own stream, workspace and communicator, "
-                         "so their exchange chains overlap (default GNNFLOW_PART_LANES or 2)")
+                         "so their exchange chains overlap (default GNNFLOW_PART_LANES, else 2; 4 from 4 ranks on)")
     ap.add_argument("--shard-features", action="store_true",
                     help="hash-partitioned run: shard the feature tables by owner too "
                          "(Cache(distributed=True): missed rows are pulled from their owners); "

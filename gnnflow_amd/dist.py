@@ -565,8 +565,8 @@ class DevicePartitionedSampler:
         cost far more than the ~6 us own-share kernel they hide (one rank over RCCL, every
         message empty: 268 us per step with them, 116 us with everything in the sampling
         stream; profiles/r03_part_bench_one_gpu.jsonl).
-        lanes: sampling lanes (default GNNFLOW_PART_LANES or 2 with more than one rank /
-        always_exchange, else 1).  A lane is used only by `sample_async(..., stream=...)` calls
+        lanes: sampling lanes (default GNNFLOW_PART_LANES, else 2 — 4 from 4 ranks on — with
+        more than one rank / always_exchange, else 1).  A lane is used only by `sample_async(..., stream=...)` calls
         that name a stream (the pipelined loop); `sample()` always runs on lane 0.
         pair: let two consecutive `sample_async(..., stream=...)` calls share ONE chain — its
         launches and its exchanges (include/gnnflow_hip.h gf_sampler_sample_partitioned_comm_pair:
@@ -599,7 +599,10 @@ class DevicePartitionedSampler:
             overlap = os.environ.get("GNNFLOW_PART_OVERLAP", "0") != "0"
         self._overlap = bool(overlap)
         if lanes is None:
-            lanes = int(os.environ.get("GNNFLOW_PART_LANES", "2"))
+            # 2 lanes hide the chain of one rank over RCCL (measured); with 4 and more ranks the
+            # exchanges are real transfers (a pair's layer-1 replies are ~19 MB per rank at
+            # P = 8), the chain is several times longer, and more of them must be in flight
+            lanes = int(os.environ.get("GNNFLOW_PART_LANES", "4" if self._P >= 4 else "2"))
         if (self._P == 1 and not self._always_exchange) or self._slack <= 0:
             # one rank without exchange: lanes were measured and do not pay (50-53 us per step
             # with 1 lane, 54 with 2, 48 with 3: profiles/README.md round 4); the variable-size
