@@ -114,6 +114,9 @@ def parse(argv=None):
                     help="sampling lanes of the partitioned sampler: consecutive batches go "
                          "round-robin to lanes with their own stream, workspace and communicator, "
                          "so their exchange chains overlap (default GNNFLOW_PART_LANES, else 2; 4 from 4 ranks on)")
+    ap.add_argument("--part-chain", type=int, default=None,
+                    help="consecutive batches that share one chain of the partitioned sampler "
+                         "(launches and exchanges): 1..4, default GNNFLOW_PART_CHAIN, else 4")
     ap.add_argument("--shard-features", action="store_true",
                     help="hash-partitioned run: shard the feature tables by owner too "
                          "(Cache(distributed=True): missed rows are pulled from their owners); "
@@ -252,7 +255,8 @@ def build_leg(ctx, kind, always_exchange=None):
         sampler = DevicePartitionedSampler(sampler, slack=args.part_slack,
                                            slot_roots=3 * args.batch_size,
                                            always_exchange=always_exchange,
-                                           lanes=args.part_lanes)
+                                           lanes=args.part_lanes,
+                                           chain_samples=args.part_chain)
     return graph, sampler, build_s
 
 
@@ -267,9 +271,10 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
     depth = args.pipeline_depth
     if depth is None:
         lanes = getattr(sampler, "lanes", 1)
-        # partitioned sampler: three samples per lane (a chain carries two, one more is held
-        # for its partner or already in flight)
-        depth = 2 if lanes == 1 else 3 * lanes
+        # partitioned sampler: a chain carries up to `chain_samples` batches; per lane one
+        # chain in flight and half a chain being gathered
+        chain = getattr(sampler, "chain_samples", 1)
+        depth = 2 if lanes == 1 else max(3 * lanes, (3 * lanes * chain) // 2)
     pipe = ReplayPipeline(sampler, cache, ctx.dev_batches, ctx.dev,
                           pipelined=cache is not None and not args.no_pipeline, depth=depth)
 
@@ -705,8 +710,9 @@ def exchange_note(sampler, world, backend):
     except Exception:      # noqa: BLE001 — diagnostics only
         pass
     if getattr(sampler, "pairs", 0):
-        lane_note += "; {} chains carried two samples each (shared launches and " \
-                     "exchanges)".format(sampler.pairs)
+        lane_note += "; {} chains carried {:.2f} samples each on average (shared launches " \
+                     "and exchanges)".format(sampler.pairs,
+                                             getattr(sampler, "chained", 0) / sampler.pairs)
     comm = getattr(sampler, "_comm", None)
     if getattr(sampler, "_slack", 0) > 0 and comm is not None and comm.transport == "ipc":
         return ("2 equal-split exchanges per layer over the library's hipIpc transport (ranks "

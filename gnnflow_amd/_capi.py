@@ -104,6 +104,15 @@ class GfPartLayout(C.Structure):
                                           "inbox", "served")]
 
 
+class GfGroupSample(C.Structure):
+    """struct gf_group_sample (include/gnnflow_hip.h): one sample of a shared chain."""
+    _fields_ = [("sampler", C.c_void_p), ("d_roots", C.c_void_p), ("d_root_ts", C.c_void_p),
+                ("num_roots", C.c_size_t), ("d_out", C.c_void_p), ("out_bytes", C.c_size_t)]
+
+
+GF_PART_GROUP_MAX = 4
+
+
 # every symbol include/gnnflow_hip.h declares: name -> (restype, argtypes)
 _p = C.c_void_p
 _sz = C.c_size_t
@@ -209,14 +218,12 @@ PROTOTYPES = {
                                                      C.c_double, _sz, C.c_int, _p]),
     "gf_sampler_sample_partitioned_comm_async": (C.c_int, [_p, _p, _p, _p, _sz, _p, _sz, _p, _sz,
                                                            C.c_double, _sz, C.c_int, _p]),
-    "gf_sampler_part_pair_ws_bytes": (C.c_int, [_p, _sz, _sz, C.c_int, C.c_double, _sz,
-                                                C.POINTER(_sz)]),
-    "gf_sampler_sample_partitioned_comm_pair": (C.c_int, [_p, _p, _p, _p, _p, _sz, _p, _sz, _p, _p,
-                                                          _sz, _p, _sz, _p, _sz, C.c_double, _sz,
-                                                          C.c_int, _p]),
-    "gf_sampler_sample_partitioned_comm_pair_async": (C.c_int, [_p, _p, _p, _p, _p, _sz, _p, _sz,
-                                                                _p, _p, _sz, _p, _sz, _p, _sz,
-                                                                C.c_double, _sz, C.c_int, _p]),
+    "gf_sampler_part_group_ws_bytes": (C.c_int, [_p, C.POINTER(_sz), C.c_int, C.c_int, C.c_double,
+                                                 _sz, C.POINTER(_sz)]),
+    "gf_sampler_sample_partitioned_comm_group": (C.c_int, [_p, _p, C.c_int, _p, _sz, C.c_double,
+                                                           _sz, C.c_int, _p]),
+    "gf_sampler_sample_partitioned_comm_group_async": (C.c_int, [_p, _p, C.c_int, _p, _sz,
+                                                                 C.c_double, _sz, C.c_int, _p]),
     "gf_block_segment_offsets": (C.c_int, [_p, _sz, _sz, _p, C.c_int, _p]),
     "gf_block_edge_softmax": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, C.c_int, _p]),
     "gf_block_edge_softmax_backward": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, _p, C.c_int, _p]),

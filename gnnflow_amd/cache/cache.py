@@ -22,6 +22,8 @@ import torch
 from .. import _capi
 
 _DESC = struct.Struct("iiQQQQ")     # struct gf_fetch_desc: kind, update, d_ids, n, d_out, d_stats
+# asynchronous fetch_feature() submissions that may be with the enqueue thread at a time
+_MAX_QUEUED = max(1, int(os.environ.get("GNNFLOW_FETCH_QUEUED", "4")))
 assert _DESC.size == C.sizeof(_capi.GfFetchDesc)
 
 
@@ -346,11 +348,12 @@ class Cache:
         enqueue thread; `b.srcdata['h']` / `b.edata['f']` / `target_edge_features` then wait
         for the enqueue on first access (blocks built by gnnflow_amd.TemporalSampler), or
         call wait_enqueued()."""
-        # at most two submissions with the enqueue thread: when that thread also issues the
-        # partitioned sampler's chains (tens of microseconds each), the previous fetch may still
-        # be queued behind one, and waiting for it here would stall the caller
+        # at most _MAX_QUEUED submissions with the enqueue thread: when that thread also issues
+        # the partitioned sampler's chains (tens of microseconds each, up to four batches' worth
+        # in one job), the previous fetches may still be queued behind one, and waiting for them
+        # here would stall the caller
         q = self.__dict__.get("_tickets")
-        if q and (len(q) >= 2 or self.distributed):
+        if q and (len(q) >= _MAX_QUEUED or self.distributed):
             self.wait_enqueued(None if self.distributed else q[0][0])
         if self.distributed:
             return self._fetch_distributed(mfgs, eid, update_cache, target_edge_features)
@@ -826,7 +829,8 @@ class Cache:
                 node_h, edge_h, C.byref(cdescs), nj, self._stream(), C.byref(ticket)))
             box[0] = ticket.value
             # ids / outputs / descriptors must outlive the enqueue
-            self._tickets.append((ticket.value, (jobs, descs, cdescs, mfgs, out_all)))
+            self._tickets.append((ticket.value, (jobs, descs, cdescs, mfgs, out_all,
+                                                 self._stats_ring)))
         else:
             _capi.check(self._lib.gf_cache_fetch_blocks(
                 node_h, edge_h, C.byref(cdescs), nj, self._stream()))

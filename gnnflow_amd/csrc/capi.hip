@@ -960,55 +960,63 @@ int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c, const in
         }));
   });
 }
-int gf_sampler_part_pair_ws_bytes(const gf_sampler* s, size_t roots_a, size_t roots_b,
-                                  int world_size, double slack, size_t slot_roots, size_t* bytes) {
+int gf_sampler_part_group_ws_bytes(const gf_sampler* s, const size_t* roots, int m, int world_size,
+                                   double slack, size_t slot_roots, size_t* bytes) {
   return guarded([&] {
-    GF_REQUIRE(s != nullptr && bytes != nullptr, "part_pair_ws_bytes: null argument");
-    GF_REQUIRE(world_size >= 1 && world_size <= 32, "pair: world size must be 1..32");
-    *bytes = (slack > 0.0 && s->impl.pair_ok(roots_a, roots_b))
-                 ? gf::Sampler::pair_ws_bytes(s->impl, roots_a, roots_b, world_size, slack,
-                                              slot_roots)
+    GF_REQUIRE(s != nullptr && roots != nullptr && bytes != nullptr,
+               "part_group_ws_bytes: null argument");
+    GF_REQUIRE(m >= 1 && m <= GF_PART_GROUP_MAX, "group: 1..4 samples");
+    GF_REQUIRE(world_size >= 1 && world_size <= 32, "group: world size must be 1..32");
+    size_t R[GF_PART_GROUP_MAX];
+    for (int j = 0; j < m; ++j) R[j] = std::max<size_t>(roots[j], 1);
+    *bytes = (slack > 0.0 && s->impl.group_ok(R, m))
+                 ? gf::Sampler::group_ws_bytes(s->impl, R, m, world_size, slack, slot_roots)
                  : 0;
   });
 }
-int gf_sampler_sample_partitioned_comm_pair(gf_sampler* sa, gf_sampler* sb, gf_comm* c,
-                                            const int64_t* d_roots_a, const float* d_ts_a,
-                                            size_t roots_a, void* d_out_a, size_t out_bytes_a,
-                                            const int64_t* d_roots_b, const float* d_ts_b,
-                                            size_t roots_b, void* d_out_b, size_t out_bytes_b,
-                                            void* d_ws, size_t ws_bytes, double slack,
-                                            size_t slot_roots, int force_overflow, void* stream) {
+namespace {
+// the group's samples as the sampler takes them (checked)
+std::vector<gf::Sampler::GroupSample> group_samples(gf_comm* c, const gf_group_sample* samples,
+                                                    int m) {
+  GF_REQUIRE(c != nullptr && samples != nullptr, "null communicator / samples");
+  GF_REQUIRE(m >= 1 && m <= GF_PART_GROUP_MAX, "group: 1..4 samples");
+  std::vector<gf::Sampler::GroupSample> gs(m);
+  for (int j = 0; j < m; ++j) {
+    GF_REQUIRE(samples[j].sampler != nullptr, "null sampler handle");
+    gs[j] = gf::Sampler::GroupSample{&samples[j].sampler->impl, samples[j].d_roots,
+                                     samples[j].d_root_ts, samples[j].num_roots, samples[j].d_out,
+                                     samples[j].out_bytes};
+  }
+  return gs;
+}
+}  // namespace
+int gf_sampler_sample_partitioned_comm_group(gf_comm* c, const gf_group_sample* samples, int m,
+                                             void* d_ws, size_t ws_bytes, double slack,
+                                             size_t slot_roots, int force_overflow, void* stream) {
   return guarded([&] {
-    GF_REQUIRE(sa != nullptr && sb != nullptr && c != nullptr, "null sampler / communicator handle");
-    for (gf_sampler* s : {sa, sb})
+    const auto gs = group_samples(c, samples, m);
+    for (int j = 0; j < m; ++j) {
+      gf_sampler* s = samples[j].sampler;
       GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
-                 "sample_partitioned_comm_pair: earlier samples were begun through the enqueue thread");
-    gf::Sampler::sample_partitioned_pair(sa->impl, d_roots_a, d_ts_a, roots_a, d_out_a, out_bytes_a,
-                                         sb->impl, d_roots_b, d_ts_b, roots_b, d_out_b, out_bytes_b,
-                                         d_ws, ws_bytes, slack, slot_roots, c->impl,
-                                         static_cast<hipStream_t>(stream),
-                                         static_cast<unsigned>(force_overflow));
-    sa->begin_tickets.push_back(0);
-    sb->begin_tickets.push_back(0);
+                 "sample_partitioned_comm_group: earlier samples were begun through the enqueue thread");
+    }
+    gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots, c->impl,
+                                          static_cast<hipStream_t>(stream),
+                                          static_cast<unsigned>(force_overflow));
+    for (int j = 0; j < m; ++j) samples[j].sampler->begin_tickets.push_back(0);
   });
 }
-int gf_sampler_sample_partitioned_comm_pair_async(gf_sampler* sa, gf_sampler* sb, gf_comm* c,
-                                                  const int64_t* d_roots_a, const float* d_ts_a,
-                                                  size_t roots_a, void* d_out_a, size_t out_bytes_a,
-                                                  const int64_t* d_roots_b, const float* d_ts_b,
-                                                  size_t roots_b, void* d_out_b, size_t out_bytes_b,
-                                                  void* d_ws, size_t ws_bytes, double slack,
-                                                  size_t slot_roots, int force_overflow,
-                                                  void* stream) {
+int gf_sampler_sample_partitioned_comm_group_async(gf_comm* c, const gf_group_sample* samples,
+                                                   int m, void* d_ws, size_t ws_bytes,
+                                                   double slack, size_t slot_roots,
+                                                   int force_overflow, void* stream) {
   return guarded([&] {
-    GF_REQUIRE(sa != nullptr && sb != nullptr && c != nullptr, "null sampler / communicator handle");
-    GF_REQUIRE(!c->loopback, "sample_partitioned_comm_pair_async: a loopback communicator's ranks "
+    auto gs = group_samples(c, samples, m);
+    GF_REQUIRE(!c->loopback, "sample_partitioned_comm_group_async: a loopback communicator's ranks "
                              "are threads (use the synchronous call)");
-    for (gf_sampler* s : {sa, sb})
-      GF_REQUIRE(s->begin_tickets.size() < gf::Sampler::kMaxInFlight,
-                 "sample_partitioned_comm_pair_async: too many samples in flight on a sampler");
-    gf::Sampler* ia = &sa->impl;
-    gf::Sampler* ib = &sb->impl;
+    for (int j = 0; j < m; ++j)
+      GF_REQUIRE(samples[j].sampler->begin_tickets.size() < gf::Sampler::kMaxInFlight,
+                 "sample_partitioned_comm_group_async: too many samples in flight on a sampler");
     gf::Exchange* comm = &c->impl;
     hipStream_t st = static_cast<hipStream_t>(stream);
     static const int lane = [] {
@@ -1016,17 +1024,13 @@ int gf_sampler_sample_partitioned_comm_pair_async(gf_sampler* sa, gf_sampler* sb
       return (v && std::atoi(v) != 0) ? 1 : 0;
     }();
     const uint64_t mark = lane == 0 ? (1ull << 63) : 0;
-    // ONE job for both samples: both tickets are this job's
+    // ONE job for all samples of the group: every sampler's ticket is this job's
     const uint64_t t = mark | gf::EnqueueWorker::get(lane).submit(
-        [=]() {
-          gf::Sampler::sample_partitioned_pair(*ia, d_roots_a, d_ts_a, roots_a, d_out_a,
-                                               out_bytes_a, *ib, d_roots_b, d_ts_b, roots_b,
-                                               d_out_b, out_bytes_b, d_ws, ws_bytes, slack,
-                                               slot_roots, *comm, st,
-                                               static_cast<unsigned>(force_overflow));
+        [gs = std::move(gs), m, d_ws, ws_bytes, slack, slot_roots, comm, st, force_overflow]() {
+          gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots,
+                                                *comm, st, static_cast<unsigned>(force_overflow));
         });
-    sa->begin_tickets.push_back(t);
-    sb->begin_tickets.push_back(t);
+    for (int j = 0; j < m; ++j) samples[j].sampler->begin_tickets.push_back(t);
   });
 }
 int gf_block_segment_offsets(const int64_t* d_row, size_t num_edges, size_t num_dst,

@@ -101,6 +101,7 @@ RcclComm::RcclComm(const uint8_t idb[kIdBytes], int world, int rank, int device)
 }
 
 RcclComm::~RcclComm() {
+  DeviceGuard dg(device_);
   if (side_) {
     (void)hipStreamSynchronize(side_);
     (void)hipStreamDestroy(side_);

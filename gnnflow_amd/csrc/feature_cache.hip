@@ -2647,6 +2647,12 @@ void PullSession::round(FeatureCache* node, FeatureCache* edge, const gf_pull_ct
     GF_REQUIRE(c.kind == 2 || caches[k] != nullptr, "pull round: block without its cache");
     send_ids_[k].reserve(std::max<size_t>(c.pull.n, 1) * 8, 0, st);
     req_pos_[k].reserve(std::max<size_t>(c.pull.n, 1) * 4, 0, st);
+    // sized BEFORE the round's first exchange from what is known now (at most pull.n rows leave;
+    // about as many arrive when the ids spread evenly), doubling: in the steady state no
+    // hipMalloc / hipFree — a device-wide synchronisation — sits between two collectives
+    pulled_[k].reserve(std::max<size_t>(c.pull.n, 1) * c.dim * 4, 0, st);
+    got_[k].reserve(std::max<size_t>(c.pull.n, 1) * 8, 0, st);
+    served_[k].reserve(std::max<size_t>(c.pull.n, 1) * c.dim * 4, 0, st);
     descs[k] = c.pull;
     descs[k].cache = nullptr;   // caches[] carries it
     descs[k].d_send_ids = send_ids_[k].as<int64_t>();
@@ -2691,13 +2697,19 @@ void PullSession::round(FeatureCache* node, FeatureCache* edge, const gf_pull_ct
   std::vector<size_t> sb(P), so(P), rb(P), ro(P);
   gf_fetch_pulled_desc fd[kMaxCtx];
   size_t nf = 0;
+  // a skewed round (more rows asked of this rank than it asks for itself): grow for every
+  // context now, before the first of the id / row exchanges
+  for (size_t k = 0; k < n; ++k) {
+    size_t n_recv = 0;
+    for (int q = 0; q < P; ++q) n_recv += hr[q * W + k];
+    got_[k].reserve(std::max<size_t>(n_recv, 1) * 8, 0, st);
+    served_[k].reserve(std::max<size_t>(n_recv, 1) * ctxs[k].dim * 4, 0, st);
+  }
   for (size_t k = 0; k < n; ++k) {
     const gf_pull_ctx& c = ctxs[k];
     size_t n_send = 0, n_recv = 0;
     for (int q = 0; q < P; ++q) { n_send += hs[q * W + k]; n_recv += hr[q * W + k]; }
-    got_[k].reserve(std::max<size_t>(n_recv, 1) * 8, 0, st);
-    served_[k].reserve(std::max<size_t>(n_recv, 1) * c.dim * 4, 0, st);
-    pulled_[k].reserve(std::max<size_t>(n_send, 1) * c.dim * 4, 0, st);
+    GF_REQUIRE(n_send <= std::max<size_t>(c.pull.n, 1), "pull round: more rows claimed than asked");
     auto exchange = [&](const void* send, void* recv, size_t row_bytes, bool back) {
       // forward: this rank's ids to their owners; back: the owners' rows to the requesters
       size_t a = 0, b = 0;

@@ -284,12 +284,13 @@ __global__ __launch_bounds__(kFusedThreads) void partition_plan_fused_kernel(
                   d_overflow, overflow_store, 1u, 0u, od.P * stride);
 }
 
-// Up to two samples' plans in ONE launch (blockIdx.y picks the job): the chain of a
-// partitioned sample is bound by the host thread that issues its launches, so two samples that
-// share their launches and exchanges halve that cost (sampler.hip sample_partitioned_pair).
+// Up to four samples' plans in ONE launch (blockIdx.y picks the job): the chain of a
+// partitioned sample is bound by the host thread that issues its launches, so samples that
+// share their launches and exchanges divide that cost (sampler.hip sample_partitioned_group).
+struct PlanJobs { PlanJob j[4]; };
 __global__ __launch_bounds__(kFusedThreads) void partition_plan_jobs_kernel(
-    PlanJob a, PlanJob b, OwnerDiv od, uint32_t rank, uint32_t stride) {
-  const PlanJob& j = blockIdx.y == 0 ? a : b;
+    PlanJobs jobs, OwnerDiv od, uint32_t rank, uint32_t stride) {
+  const PlanJob& j = jobs.j[blockIdx.y];
   plan_fused_body(j.nodes, j.ts, j.d_R, j.R_host, od, rank, j.requests, j.pos, j.counts, nullptr,
                   stride, j.d_overflow, j.overflow_store, j.slot_mul, j.slot_add, j.own_base,
                   j.force_overflow);
@@ -362,7 +363,7 @@ void partition_plan_dev(const int64_t* d_nodes, const float* d_ts, const uint64_
 
 void partition_plan_jobs(const PlanJob* jobs, int n, size_t R_bound, int world_size, int rank,
                          uint32_t stride, int device, hipStream_t stream) {
-  GF_REQUIRE(jobs != nullptr && (n == 1 || n == 2), "partition: 1 or 2 plan jobs");
+  GF_REQUIRE(jobs != nullptr && n >= 1 && n <= 4, "partition: 1..4 plan jobs");
   GF_REQUIRE(world_size >= 1 && world_size <= kMaxParts, "partition: world size must be 1..64");
   GF_REQUIRE(stride >= 2, "partition: plan jobs need the slotted form");
   GF_REQUIRE(rank >= 0 && rank < world_size, "partition: rank out of range");
@@ -375,9 +376,10 @@ void partition_plan_jobs(const PlanJob* jobs, int n, size_t R_bound, int world_s
   const OwnerDiv od = owner_div(static_cast<uint32_t>(world_size));
   const unsigned grid = static_cast<unsigned>(
       (std::max<size_t>(R_bound, 1) + kFusedThreads - 1) / kFusedThreads);
+  PlanJobs all;
+  for (int k = 0; k < 4; ++k) all.j[k] = jobs[std::min(k, n - 1)];
   partition_plan_jobs_kernel<<<dim3(grid, static_cast<unsigned>(n)), dim3(kFusedThreads), 0,
-                               stream>>>(jobs[0], jobs[n - 1], od, static_cast<uint32_t>(rank),
-                                         stride);
+                               stream>>>(all, od, static_cast<uint32_t>(rank), stride);
   GF_HIP(hipGetLastError());
 }
 

@@ -38,7 +38,7 @@ struct PlanJob {
                             // caller submitted an empty stand-in for a batch too large for
                             // this chain; every rank then redoes that sample)
 };
-// `n` jobs (1 or 2) in one launch; R_bound sizes the grid (the largest job's bound).
+// `n` jobs (1..4) in one launch; R_bound sizes the grid (the largest job's bound).
 void partition_plan_jobs(const PlanJob* jobs, int n, size_t R_bound, int world_size, int rank,
                          uint32_t stride, int device, hipStream_t stream);
 constexpr size_t kPlanJobsMaxRoots = 32768;

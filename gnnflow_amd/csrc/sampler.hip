@@ -233,9 +233,10 @@ __global__ void sample_publish_kernel(Publish p) {
   *reinterpret_cast<volatile uint64_t*>(p.h_flag) = p.seq;
 }
 
-__global__ void sample_publish_pair_kernel(Publish a, Publish b) {
+struct PublishGroup { Publish p[4]; };
+__global__ void sample_publish_group_kernel(PublishGroup g) {
   if (threadIdx.x != 0) return;
-  const Publish& p = blockIdx.x == 0 ? a : b;
+  const Publish& p = g.p[blockIdx.x];
   for (uint32_t i = 0; i < p.num_words; ++i) p.h_counts[i] = p.d_counts[i];
   p.h_counts[p.num_words] = p.d_extra ? *p.d_extra : 0;
   __threadfence_system();
@@ -763,11 +764,12 @@ struct PaddedJob {
   uint32_t* rec_cnt;
   uint32_t stride, world;
   uint32_t* d_overflow;
-  // several samples sharing one exchange (sample_partitioned_pair): an own share starts at row
+  // several samples sharing one exchange (sample_partitioned_group): an own share starts at row
   // own_skip (0: world * stride); the inbox holds `world` = P x m slots, slot v belongs to
-  // sample v % m: odd slots of a pair raise d_overflow2
+  // sample v % m and raises THAT sample's word d_overflow_of[v % m] (m = 0: d_overflow)
   uint64_t own_skip = 0;
-  uint32_t* d_overflow2 = nullptr;
+  uint32_t m = 0;
+  uint32_t* d_overflow_of[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 // d_own != null: "this rank's own share" of a chained partitioned layer — the last *d_own
@@ -805,7 +807,7 @@ __device__ inline void padded_job(const GraphView& g, const PaddedCommon& c, Pad
       const uint64_t q = r / stride, jj = r - q * stride;
       if (jj == 0) {
         if (lane == 0 && (req[2 * r + 1] & 1))
-          atomicOr((j.d_overflow2 && (q & 1)) ? j.d_overflow2 : j.d_overflow, 1u);
+          atomicOr(j.m ? j.d_overflow_of[q % j.m] : j.d_overflow, 1u);
         continue;
       }
       const uint64_t rows = static_cast<uint64_t>(req[2 * q * stride]);
@@ -869,11 +871,12 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_pair_kernel(
     GraphView g, PaddedCommon c, PaddedJob a, PaddedJob b) {
   padded_job<GROUP>(g, c, blockIdx.y == 0 ? a : b);
 }
-// ... and three: the shared inbox of two samples and both own shares
+// ... and up to five: the shared inbox of m <= 4 samples and their own shares
+struct PaddedJobs { PaddedJob j[5]; };
 template <int GROUP>
-__global__ __launch_bounds__(kSearchThreads) void sample_padded_trio_kernel(
-    GraphView g, PaddedCommon c, PaddedJob a, PaddedJob b, PaddedJob d) {
-  padded_job<GROUP>(g, c, blockIdx.y == 0 ? a : (blockIdx.y == 1 ? b : d));
+__global__ __launch_bounds__(kSearchThreads) void sample_padded_group_kernel(
+    GraphView g, PaddedCommon c, PaddedJobs jobs) {
+  padded_job<GROUP>(g, c, jobs.j[blockIdx.y]);
 }
 
 // valid slots of root i's reply row (a prefix of the row for both policies)
@@ -1246,10 +1249,11 @@ __global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_kernel(
                          out_S, next_R);
 }
 
-// two samples that shared their exchange (blockIdx.y picks the job; each has its own granules)
-__global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_pair_kernel(
-    MergeJob a, MergeJob b, uint32_t fanout, uint32_t stride) {
-  const MergeJob& j = blockIdx.y == 0 ? a : b;
+// m <= 4 samples that shared their exchange (blockIdx.y picks the job; each has its own granules)
+struct MergeJobs { MergeJob j[4]; };
+__global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_group_kernel(
+    MergeJobs jobs, uint32_t fanout, uint32_t stride) {
+  const MergeJob& j = jobs.j[blockIdx.y];
   merge_slots_fused_body(j.roots, j.root_ts, j.d_R, j.R_host, fanout, j.rep, j.pos, stride,
                          j.slot_rows, j.granules, j.tag, j.d_overflow, j.all_nodes, j.all_ts, j.dt,
                          j.eids, j.row, j.col, j.out_R, j.out_S, j.next_R);
@@ -1304,15 +1308,14 @@ void launch_padded_pair(int width, unsigned grid, hipStream_t stream, const Grap
   }
 }
 
-void launch_padded_trio(int width, unsigned grid, hipStream_t stream, const GraphView& g,
-                        const PaddedCommon& c, const PaddedJob& a, const PaddedJob& b,
-                        const PaddedJob& d) {
-  const dim3 gr(grid, 3), bl(kSearchThreads);
+void launch_padded_group(int width, unsigned grid, int jobs_n, hipStream_t stream,
+                         const GraphView& g, const PaddedCommon& c, const PaddedJobs& jobs) {
+  const dim3 gr(grid, static_cast<unsigned>(jobs_n)), bl(kSearchThreads);
   switch (width) {
-    case 2: sample_padded_trio_kernel<2><<<gr, bl, 0, stream>>>(g, c, a, b, d); break;
-    case 4: sample_padded_trio_kernel<4><<<gr, bl, 0, stream>>>(g, c, a, b, d); break;
-    case 8: sample_padded_trio_kernel<8><<<gr, bl, 0, stream>>>(g, c, a, b, d); break;
-    default: sample_padded_trio_kernel<16><<<gr, bl, 0, stream>>>(g, c, a, b, d); break;
+    case 2: sample_padded_group_kernel<2><<<gr, bl, 0, stream>>>(g, c, jobs); break;
+    case 4: sample_padded_group_kernel<4><<<gr, bl, 0, stream>>>(g, c, jobs); break;
+    case 8: sample_padded_group_kernel<8><<<gr, bl, 0, stream>>>(g, c, jobs); break;
+    default: sample_padded_group_kernel<16><<<gr, bl, 0, stream>>>(g, c, jobs); break;
   }
 }
 
@@ -2217,6 +2220,7 @@ void Sampler::part_abort() { part_.active = false; }
 void Sampler::sample_partitioned(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                                  size_t out_bytes, void* d_ws, size_t ws_bytes,
                                  hipStream_t stream) {
+  DeviceGuard dg(graph_->device());   // once for the chain: the steps' own guards then find it set
   const size_t L = fanouts_.size(), NS = num_snapshots_;
   part_begin(d_roots, d_ts, R, d_out, out_bytes, 1, 0, 0.0, 0, stream);
   try {
@@ -2248,6 +2252,7 @@ void Sampler::sample_partitioned_slotted(const int64_t* d_roots, const float* d_
                                          Exchange& ex, bool overlap, hipStream_t stream) {
   const size_t L = fanouts_.size(), NS = num_snapshots_;
   GF_REQUIRE(slack > 0.0, "sample_partitioned_slotted: slack must be positive");
+  DeviceGuard dg(graph_->device());   // once for the chain: the steps' own guards then find it set
   // host time of the issuing thread per stage (gf_debug_part_host_us): the chain is ~13 stream
   // operations issued by ONE thread, which is what bounds its throughput at batch 600
   using clk = std::chrono::steady_clock;
@@ -2326,79 +2331,86 @@ void part_host_us(double out[8], bool reset) {
 
 // ---- two samples in ONE chain ---------------------------------------------------------------
 // The slotted chain of a sample is ~11 stream operations, and at batch 600 its throughput is
-// bound by the host thread that issues them (measured: 3-6 us each), not by the GPU.  Two
-// consecutive batches therefore SHARE their launches and exchanges: sample a (sampler `a`) and
-// sample b (sampler `b`, a clone on the same graph: its own output, counters, publish record)
-// write their requests into one buffer — owner q's rows of sample j into slot 2 q + j, so the
-// buffer is P runs of two slots and ONE equal-split all-to-all moves both —, the received
-// slots (2 P of them, served alike) and both own shares are sampled by one launch, one
-// exchange brings the replies back, one launch merges both, one publishes both: 11 operations
-// per TWO samples.  Conditions (else the caller issues two single chains): one snapshot, every
-// layer of both samples within the fused plan / fused merge limits (<= 32 768 roots,
+// bound by the host thread that issues them (measured: 3-6 us each), not by the GPU.  Up to
+// kMaxGroup = 4 consecutive batches therefore SHARE their launches and exchanges: sample j of
+// m runs through its own sampler (clones on the same graph: own output, counters, publish
+// record), all write their requests into one buffer — owner q's rows of sample j into slot
+// m q + j, so the buffer is P runs of m slots and ONE equal-split all-to-all moves them all —,
+// the received slots (m P of them, served alike) and the m own shares are sampled by one
+// launch, one exchange brings the replies back, one launch merges all, one publishes all: 11
+// operations per m samples.  Conditions (else the caller issues single chains): one snapshot,
+// every layer of every sample within the fused plan / fused merge limits (<= 32 768 roots,
 // fanout <= 256).  Layout of the shared workspace of layer l, rows of 16 B (requests) and
-// fanout x 24 B (replies):  [2 P slots of `stride` rows | own share a | own share b].
-size_t Sampler::pair_ws_bytes(const Sampler& a, size_t Ra, size_t Rb, int world, double slack,
-                              size_t slot_roots) {
+// fanout x 24 B (replies):  [m P slots of `stride` rows | own share 0 | ... | own share m-1].
+size_t Sampler::group_ws_bytes(const Sampler& a, const size_t* R, int m, int world, double slack,
+                               size_t slot_roots) {
   size_t total = 0;
   for (size_t l = 0; l < a.fanouts_.size(); ++l) {
-    PairLayout lay;
-    a.pair_layout(std::max<size_t>(Ra, 1), std::max<size_t>(Rb, 1), static_cast<uint32_t>(l),
-                  world, slack, slot_roots, &lay);
+    GroupLayout lay;
+    a.group_layout(R, m, static_cast<uint32_t>(l), world, slack, slot_roots, &lay);
     total += lay.total;
   }
   return total;
 }
 
-bool Sampler::pair_ok(size_t Ra, size_t Rb) const {
-  if (num_snapshots_ != 1) return false;
+bool Sampler::group_ok(const size_t* R, int m) const {
+  if (num_snapshots_ != 1 || m < 1 || m > kMaxGroup || !fused_scan_) return false;
   for (size_t l = 0; l < fanouts_.size(); ++l) {
-    const size_t bound = std::max(root_bound(std::max<size_t>(Ra, 1), l),
-                                  root_bound(std::max<size_t>(Rb, 1), l));
-    if (bound > kSmallRoots || bound > kPlanJobsMaxRoots || fanouts_[l] > kEmitThreads ||
-        !fused_scan_)
-      return false;
+    if (fanouts_[l] > kEmitThreads) return false;
+    for (int j = 0; j < m; ++j) {
+      const size_t bound = root_bound(std::max<size_t>(R[j], 1), l);
+      if (bound > kSmallRoots || bound > kPlanJobsMaxRoots) return false;
+    }
   }
   return true;
 }
 
-void Sampler::pair_layout(size_t Ra, size_t Rb, uint32_t layer, int world, double slack,
-                          size_t slot_roots, PairLayout* out) const {
+void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, double slack,
+                           size_t slot_roots, GroupLayout* out) const {
+  GF_REQUIRE(m >= 1 && m <= kMaxGroup, "group layout: 1..4 samples");
   gf_part_layout one;
-  part_layout(Ra, layer, world, slack, slot_roots, &one);   // for the slot stride
+  part_layout(std::max<size_t>(R[0], 1), layer, world, slack, slot_roots, &one);   // slot stride
   const size_t F = fanouts_[layer];
-  const size_t ba = root_bound(Ra, layer), bb = root_bound(Rb, layer);
-  const size_t slot_rows = 2 * static_cast<size_t>(world) * one.slot_stride;
-  const size_t rows = slot_rows + ba + bb;
-  GF_REQUIRE(rows < 0xFFFFFFFFull, "pair layout: more than 2^32-1 request rows");
+  const size_t slot_rows = static_cast<size_t>(m) * world * one.slot_stride;
+  size_t bound[kMaxGroup], rows = slot_rows;
+  for (int j = 0; j < m; ++j) {
+    bound[j] = root_bound(std::max<size_t>(R[j], 1), layer);
+    out->own[j] = rows;
+    rows += bound[j];
+  }
+  GF_REQUIRE(rows < 0xFFFFFFFFull, "group layout: more than 2^32-1 request rows");
   out->stride = one.slot_stride;
   out->slot_rows = slot_rows;
-  out->own_a = slot_rows;
-  out->own_b = slot_rows + ba;
   size_t at = 0;
   out->requests = at; at = align_up(at + rows * 16, 256);
   out->replies = at;  at = align_up(at + rows * F * 24, 256);
   out->inbox = at;    at = align_up(at + slot_rows * 16, 256);
   out->served = at;   at = align_up(at + slot_rows * F * 24, 256);
-  out->counts_a = at; at = align_up(at + static_cast<size_t>(world) * 8, 256);
-  out->counts_b = at; at = align_up(at + static_cast<size_t>(world) * 8, 256);
-  out->pos_a = at;    at = align_up(at + ba * 4, 256);
-  out->pos_b = at;    at = align_up(at + bb * 4, 256);
+  for (int j = 0; j < m; ++j) { out->counts[j] = at; at = align_up(at + static_cast<size_t>(world) * 8, 256); }
+  for (int j = 0; j < m; ++j) { out->pos[j] = at; at = align_up(at + bound[j] * 4, 256); }
   out->total = at;
 }
 
-void Sampler::sample_partitioned_pair(Sampler& a, const int64_t* d_roots_a, const float* d_ts_a,
-                                      size_t Ra, void* d_out_a, size_t out_bytes_a, Sampler& b,
-                                      const int64_t* d_roots_b, const float* d_ts_b, size_t Rb,
-                                      void* d_out_b, size_t out_bytes_b, void* d_ws,
-                                      size_t ws_bytes, double slack, size_t slot_roots,
-                                      Exchange& ex, hipStream_t stream, unsigned force_overflow) {
-  GF_REQUIRE(&a != &b, "sample_partitioned_pair: the two samples need a sampler each");
-  GF_REQUIRE(a.graph_ == b.graph_ && a.fanouts_ == b.fanouts_ && a.policy_ == b.policy_ &&
-                 a.num_snapshots_ == b.num_snapshots_ && a.window_ == b.window_ &&
-                 a.prop_time_ == b.prop_time_ && a.seed_ == b.seed_,
-             "sample_partitioned_pair: the samplers differ");
-  GF_REQUIRE(slack > 0.0, "sample_partitioned_pair: slack must be positive");
-  GF_REQUIRE(a.pair_ok(Ra, Rb), "sample_partitioned_pair: these samples cannot share a chain");
+void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
+                                       double slack, size_t slot_roots, Exchange& ex,
+                                       hipStream_t stream, unsigned force_overflow) {
+  GF_REQUIRE(gs != nullptr && m >= 1 && m <= kMaxGroup, "sample_partitioned_group: 1..4 samples");
+  Sampler& a = *gs[0].s;
+  size_t Rin[kMaxGroup];
+  for (int j = 0; j < m; ++j) {
+    GF_REQUIRE(gs[j].s != nullptr, "sample_partitioned_group: null sampler");
+    for (int k = 0; k < j; ++k)
+      GF_REQUIRE(gs[j].s != gs[k].s, "sample_partitioned_group: the samples need a sampler each");
+    const Sampler& b = *gs[j].s;
+    GF_REQUIRE(a.graph_ == b.graph_ && a.fanouts_ == b.fanouts_ && a.policy_ == b.policy_ &&
+                   a.num_snapshots_ == b.num_snapshots_ && a.window_ == b.window_ &&
+                   a.prop_time_ == b.prop_time_ && a.seed_ == b.seed_,
+               "sample_partitioned_group: the samplers differ");
+    Rin[j] = gs[j].R;
+  }
+  GF_REQUIRE(slack > 0.0, "sample_partitioned_group: slack must be positive");
+  GF_REQUIRE(a.group_ok(Rin, m), "sample_partitioned_group: these samples cannot share a chain");
+  DeviceGuard dg(a.graph_->device());
   const size_t L = a.fanouts_.size();
   const int P = ex.world(), me = ex.rank();
   using clk = std::chrono::steady_clock;
@@ -2410,52 +2422,56 @@ void Sampler::sample_partitioned_pair(Sampler& a, const int64_t* d_roots_a, cons
         std::memory_order_relaxed);
     t_prev = t;
   };
-  a.part_begin(d_roots_a, d_ts_a, Ra, d_out_a, out_bytes_a, P, me, slack, slot_roots, stream);
+  int begun = 0;
+  auto abort_all = [&]() { for (int j = 0; j < begun; ++j) gs[j].s->part_abort(); };
   try {
-    b.part_begin(d_roots_b, d_ts_b, Rb, d_out_b, out_bytes_b, P, me, slack, slot_roots, stream);
+    for (; begun < m; ++begun) {
+      const GroupSample& g = gs[begun];
+      g.s->part_begin(g.d_roots, g.d_ts, g.R, g.d_out, g.out_bytes, P, me, slack, slot_roots,
+                      stream);
+    }
   } catch (...) {
-    a.part_abort();
+    abort_all();
     throw;
   }
   lap(0);
   try {
-    DeviceGuard dg(a.graph_->device());
-    Sampler* sm[2] = {&a, &b};
     char* w = static_cast<char*>(d_ws);
     size_t off = 0;
+    size_t Rs[kMaxGroup];
+    for (int j = 0; j < m; ++j) Rs[j] = gs[j].s->part_.Rs;
     for (size_t l = 0; l < L; ++l) {
-      PairLayout lay;
-      a.pair_layout(a.part_.Rs, b.part_.Rs, static_cast<uint32_t>(l), P, slack, slot_roots, &lay);
-      GF_REQUIRE(off + lay.total <= ws_bytes, "sample_partitioned_pair: workspace too small");
+      GroupLayout lay;
+      a.group_layout(Rs, m, static_cast<uint32_t>(l), P, slack, slot_roots, &lay);
+      GF_REQUIRE(off + lay.total <= ws_bytes, "sample_partitioned_group: workspace too small");
       char* base = w + off;
       const uint32_t F = a.fanouts_[l], stride = static_cast<uint32_t>(lay.stride);
       int64_t* requests = reinterpret_cast<int64_t*>(base + lay.requests);
       int64_t* replies = reinterpret_cast<int64_t*>(base + lay.replies);
-      const size_t counts_off[2] = {lay.counts_a, lay.counts_b};
-      const size_t pos_off[2] = {lay.pos_a, lay.pos_b};
-      const size_t own_row[2] = {lay.own_a, lay.own_b};
-      const int64_t* roots[2]; const float* ts[2]; const uint64_t* d_R[2]; uint64_t R_host[2];
-      size_t n_bound[2];
-      for (int j = 0; j < 2; ++j) {
-        sm[j]->part_roots(static_cast<uint32_t>(l), 0, &roots[j], &ts[j], &d_R[j], &R_host[j]);
-        n_bound[j] = l == 0 ? sm[j]->part_.R : sm[j]->root_bound(sm[j]->part_.Rs, l);
+      const int64_t* roots[kMaxGroup]; const float* ts[kMaxGroup]; const uint64_t* d_R[kMaxGroup];
+      uint64_t R_host[kMaxGroup];
+      size_t bound = 0;
+      for (int j = 0; j < m; ++j) {
+        Sampler& s = *gs[j].s;
+        s.part_roots(static_cast<uint32_t>(l), 0, &roots[j], &ts[j], &d_R[j], &R_host[j]);
+        bound = std::max(bound, l == 0 ? s.part_.R : s.root_bound(s.part_.Rs, l));
       }
-      const size_t bound = std::max(n_bound[0], n_bound[1]);
-      // 1. both plans
-      PlanJob pj[2];
-      for (int j = 0; j < 2; ++j) {
+      // 1. all plans
+      PlanJob pj[kMaxGroup];
+      for (int j = 0; j < m; ++j) {
         pj[j] = PlanJob{roots[j], ts[j], d_R[j], R_host[j], requests,
-                        reinterpret_cast<uint32_t*>(base + pos_off[j]),
-                        reinterpret_cast<uint64_t*>(base + counts_off[j]),
-                        sm[j]->part_overflow(), l == 0 ? 1 : 0, 2u, static_cast<uint32_t>(j),
-                        static_cast<uint32_t>(own_row[j]), (force_overflow >> j) & 1u};
+                        reinterpret_cast<uint32_t*>(base + lay.pos[j]),
+                        reinterpret_cast<uint64_t*>(base + lay.counts[j]),
+                        gs[j].s->part_overflow(), l == 0 ? 1 : 0, static_cast<uint32_t>(m),
+                        static_cast<uint32_t>(j), static_cast<uint32_t>(lay.own[j]),
+                        (force_overflow >> j) & 1u};
       }
-      partition_plan_jobs(pj, 2, bound, P, me, stride, a.graph_->device(), stream);
+      partition_plan_jobs(pj, m, bound, P, me, stride, a.graph_->device(), stream);
       lap(1);
-      // 2. both samples' request slots out
-      ex.all_to_all(requests, base + lay.inbox, 2 * static_cast<size_t>(stride) * 16, stream);
+      // 2. every sample's request slots out
+      ex.all_to_all(requests, base + lay.inbox, static_cast<size_t>(m) * stride * 16, stream);
       lap(2);
-      // 3. the received slots (of both samples, served alike) and both own shares
+      // 3. the received slots (of all samples, served alike) and the own shares
       const uint64_t n_inbox = lay.slot_rows;
       const size_t n_max = std::max<size_t>(n_inbox, bound);
       // group width by the roots there really are (<= the layer's bound per sample), not by the
@@ -2465,65 +2481,63 @@ void Sampler::sample_partitioned_pair(Sampler& a, const int64_t* d_roots_a, cons
       const unsigned grid = capped_grid(n_max, kSearchThreads / width, 256 * 8);
       const PaddedCommon pc{0, 1, a.window_, F, a.policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0,
                             a.prop_time_ ? 1 : 0, a.seed_};
-      PaddedJob serve{reinterpret_cast<const int64_t*>(base + lay.inbox), n_inbox, a.calls_++,
-                      reinterpret_cast<int64_t*>(base + lay.served), nullptr, nullptr, 0, nullptr,
-                      nullptr, stride, static_cast<uint32_t>(2 * P), a.part_overflow()};
-      serve.d_overflow2 = b.part_overflow();
-      PaddedJob own[2];
-      for (int j = 0; j < 2; ++j) {
-        own[j] = PaddedJob{requests, 0, sm[j]->calls_++, replies,
-                           reinterpret_cast<const uint64_t*>(base + counts_off[j]) + me, d_R[j],
-                           R_host[j], nullptr, nullptr, stride, static_cast<uint32_t>(2 * P),
-                           nullptr};
-        own[j].own_skip = own_row[j];
+      PaddedJobs jobs;
+      jobs.j[0] = PaddedJob{reinterpret_cast<const int64_t*>(base + lay.inbox), n_inbox, a.calls_++,
+                            reinterpret_cast<int64_t*>(base + lay.served), nullptr, nullptr, 0,
+                            nullptr, nullptr, stride, static_cast<uint32_t>(m * P),
+                            a.part_overflow()};
+      jobs.j[0].m = static_cast<uint32_t>(m);
+      for (int j = 0; j < m; ++j) jobs.j[0].d_overflow_of[j] = gs[j].s->part_overflow();
+      for (int j = 0; j < m; ++j) {
+        PaddedJob& own = jobs.j[1 + j];
+        own = PaddedJob{requests, 0, gs[j].s->calls_++, replies,
+                        reinterpret_cast<const uint64_t*>(base + lay.counts[j]) + me, d_R[j],
+                        R_host[j], nullptr, nullptr, stride, static_cast<uint32_t>(m * P), nullptr};
+        own.own_skip = lay.own[j];
       }
       {
         ProfileScope ps(kProfSearch, stream);
-        launch_padded_trio(width, grid, stream, view_for(a.graph_, bound), pc, serve, own[0],
-                           own[1]);
+        launch_padded_group(width, grid, 1 + m, stream, view_for(a.graph_, bound), pc, jobs);
         GF_HIP(hipGetLastError());
       }
       lap(3);
       // 4. the replies back
-      ex.all_to_all(base + lay.served, replies, 2 * static_cast<size_t>(stride) * F * 24, stream);
+      ex.all_to_all(base + lay.served, replies, static_cast<size_t>(m) * stride * F * 24, stream);
       lap(4);
-      // 5. both merges
-      MergeJob mj[2];
-      for (int j = 0; j < 2; ++j) {
-        Sampler& s = *sm[j];
+      // 5. all merges
+      MergeJobs mj;
+      for (int j = 0; j < m; ++j) {
+        Sampler& s = *gs[j].s;
         uint64_t* cslot = s.part_counts() + 2 * l;
         const BlockPtrs& out = s.part_.slot->ptrs[l];
-        mj[j] = MergeJob{roots[j], ts[j], d_R[j], R_host[j], replies,
-                         reinterpret_cast<const uint32_t*>(base + pos_off[j]),
-                         static_cast<uint32_t>(lay.slot_rows),
-                         reinterpret_cast<uint64_t*>(s.ws_.as<char>()), next_merge_tag(),
-                         s.part_overflow(), out.all_nodes, out.all_ts, out.dt, out.eids, out.row,
-                         out.col, cslot, cslot + 1, (l + 1 < L) ? cslot + 2 : nullptr};
+        mj.j[j] = MergeJob{roots[j], ts[j], d_R[j], R_host[j], replies,
+                           reinterpret_cast<const uint32_t*>(base + lay.pos[j]),
+                           static_cast<uint32_t>(lay.slot_rows),
+                           reinterpret_cast<uint64_t*>(s.ws_.as<char>()), next_merge_tag(),
+                           s.part_overflow(), out.all_nodes, out.all_ts, out.dt, out.eids, out.row,
+                           out.col, cslot, cslot + 1, (l + 1 < L) ? cslot + 2 : nullptr};
       }
       {
         ProfileScope ps(kProfEmit, stream);
         const unsigned egrid = static_cast<unsigned>(
             (static_cast<uint64_t>(std::max<size_t>(bound, 1)) * F + kEmitThreads - 1) /
             kEmitThreads);
-        merge_slots_fused_pair_kernel<<<dim3(egrid, 2), dim3(kEmitThreads), 0, stream>>>(
-            mj[0], mj[1], F, stride);
+        merge_slots_fused_group_kernel<<<dim3(egrid, static_cast<unsigned>(m)), dim3(kEmitThreads),
+                                         0, stream>>>(mj, F, stride);
         GF_HIP(hipGetLastError());
       }
       lap(5);
       off += lay.total;
     }
-    Publish pa, pb;
-    a.part_commit_prepare(&pa);
-    b.part_commit_prepare(&pb);
-    sample_publish_pair_kernel<<<dim3(2), dim3(64), 0, stream>>>(pa, pb);
+    PublishGroup pg;
+    for (int j = 0; j < m; ++j) gs[j].s->part_commit_prepare(&pg.p[j]);
+    sample_publish_group_kernel<<<dim3(static_cast<unsigned>(m)), dim3(64), 0, stream>>>(pg);
     GF_HIP(hipGetLastError());
-    a.part_commit_finish();
-    b.part_commit_finish();
+    for (int j = 0; j < m; ++j) gs[j].s->part_commit_finish();
     lap(6);
-    g_part_host_ns[7].fetch_add(2, std::memory_order_relaxed);   // samples
+    g_part_host_ns[7].fetch_add(static_cast<uint64_t>(m), std::memory_order_relaxed);   // samples
   } catch (...) {
-    a.part_abort();
-    b.part_abort();
+    abort_all();
     throw;
   }
 }

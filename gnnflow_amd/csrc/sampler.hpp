@@ -72,25 +72,31 @@ class Sampler {
   void part_merge(uint32_t layer, uint32_t snapshot, void* d_ws, size_t ws_bytes);
   void part_commit();
   void part_abort();
-  // Two samples in ONE chain (sampler.hip "two samples in ONE chain"): `a` and `b` are two
-  // samplers over the same graph with the same arguments; shared launches, exchanges and
-  // exchange workspace, separate outputs / counters / publish records.
-  struct PairLayout {
-    size_t stride, slot_rows, own_a, own_b;          // rows
-    size_t requests, replies, inbox, served, counts_a, counts_b, pos_a, pos_b, total;  // bytes
+  // Up to kMaxGroup samples in ONE chain (sampler.hip "SHARE their launches and exchanges"):
+  // sample j runs through its own sampler — all over the same graph with the same arguments;
+  // shared launches, exchanges and exchange workspace, separate outputs / counters / publish
+  // records.
+  static constexpr int kMaxGroup = 4;
+  struct GroupSample {
+    Sampler* s;
+    const int64_t* d_roots;
+    const float* d_ts;
+    size_t R;
+    void* d_out;
+    size_t out_bytes;
   };
-  bool pair_ok(size_t Ra, size_t Rb) const;
-  void pair_layout(size_t Ra, size_t Rb, uint32_t layer, int world, double slack,
-                   size_t slot_roots, PairLayout* out) const;
-  static size_t pair_ws_bytes(const Sampler& a, size_t Ra, size_t Rb, int world, double slack,
-                              size_t slot_roots);
-  static void sample_partitioned_pair(Sampler& a, const int64_t* d_roots_a, const float* d_ts_a,
-                                      size_t Ra, void* d_out_a, size_t out_bytes_a, Sampler& b,
-                                      const int64_t* d_roots_b, const float* d_ts_b, size_t Rb,
-                                      void* d_out_b, size_t out_bytes_b, void* d_ws,
-                                      size_t ws_bytes, double slack, size_t slot_roots,
-                                      Exchange& ex, hipStream_t stream,
-                                      unsigned force_overflow = 0);
+  struct GroupLayout {
+    size_t stride, slot_rows, own[kMaxGroup];                                   // rows
+    size_t requests, replies, inbox, served, counts[kMaxGroup], pos[kMaxGroup], total;  // bytes
+  };
+  bool group_ok(const size_t* R, int m) const;
+  void group_layout(const size_t* R, int m, uint32_t layer, int world, double slack,
+                    size_t slot_roots, GroupLayout* out) const;
+  static size_t group_ws_bytes(const Sampler& a, const size_t* R, int m, int world, double slack,
+                               size_t slot_roots);
+  static void sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
+                                       double slack, size_t slot_roots, Exchange& ex,
+                                       hipStream_t stream, unsigned force_overflow = 0);
   void sample_partitioned(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                           size_t out_bytes, void* d_ws, size_t ws_bytes, hipStream_t stream);
   // several ranks, slotted form, the exchanges issued through `ex` (RCCL): the whole chain in

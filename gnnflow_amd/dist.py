@@ -296,6 +296,13 @@ def _exchange(out: torch.Tensor, send: torch.Tensor, out_splits, in_splits, grou
                                   input_split_sizes=in_splits, group=group, async_op=async_op)
 
 
+def _device_index(device):
+    """Index of a cuda device for the C ABI; a bare "cuda" means torch's current device (NOT 0:
+    rank k of a node works on device k)."""
+    device = torch.device(device)
+    return torch.cuda.current_device() if device.index is None else device.index
+
+
 class NativeComm:
     """The library's own communicator over the ranks of a torch process group
     (include/gnnflow_hip.h gf_comm_* / gf_ipc_comm_*); torch.distributed only carries the
@@ -319,7 +326,7 @@ class NativeComm:
         lib = _capi.load()
         device = torch.device(device)
         arr = (C.c_void_p * world_size)()
-        _capi.check(lib.gf_loopback_comm_create(arr, world_size, device.index or 0))
+        _capi.check(lib.gf_loopback_comm_create(arr, world_size, _device_index(device)))
         out = []
         for r in range(world_size):
             c = cls.__new__(cls)
@@ -348,7 +355,7 @@ class NativeComm:
                 src = dist.get_global_rank(group, 0) if group is not None else 0
                 dist.broadcast_object_list(name, src=src, group=group)
             _capi.check(self._lib.gf_ipc_comm_create(C.byref(self.h), self.P, self.rank,
-                                                     device.index or 0, int(mailbox_bytes),
+                                                     _device_index(device), int(mailbox_bytes),
                                                      name[0].encode()))
             mine = (C.c_uint8 * 64)()
             _capi.check(self._lib.gf_ipc_comm_handle(self.h, mine))
@@ -372,7 +379,7 @@ class NativeComm:
             dist.broadcast(t, src=src, group=group)
             idb = (C.c_uint8 * 128)(*t.cpu().tolist())
         _capi.check(self._lib.gf_comm_create(C.byref(self.h), idb, self.P, self.rank,
-                                             device.index or 0))
+                                             _device_index(device)))
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
@@ -440,8 +447,9 @@ class _PartitionedPending:
     flag and, if a slot overflowed on ANY rank (the flag travels in the slot headers, so every
     rank reads the same value for the same sample), samples the batch again through the
     variable-size exchange — on every rank, at the same point of its call sequence.
-    A sample may be HELD (not issued yet) while it waits for the next batch to share its chain
-    with (DevicePartitionedSampler pairs); `wait()` on a held sample issues it alone."""
+    A sample may be HELD (not issued yet) while it waits for the next batches to share its chain
+    with (DevicePartitionedSampler chain_samples); `wait()` on a held sample issues the chain
+    with the samples held so far."""
 
     def __init__(self, owner, lane, smp, pending, nodes, ts, stream, worker_enqueue=False):
         self._owner, self._lane, self._smp = owner, lane, smp
@@ -470,7 +478,7 @@ class _PartitionedPending:
         if self._result is None:
             own = self._owner
             if self._pending is None:
-                own._issue_held_alone(self)
+                own._issue_held()
             mfgs = self._pending.wait()
             if self._overflowed:
                 own.overflows += 1
@@ -480,8 +488,8 @@ class _PartitionedPending:
                 # and — the pipeline being the same on every rank — with the same samples in
                 # flight on the lane, so the lane's communicator sees the same order of
                 # collectives everywhere.
-                for smp in (self._lane.sampler, self._lane.sampler_b):
-                    q = smp._inflight if smp is not None else ()
+                for smp in self._lane.samplers:
+                    q = smp._inflight
                     while q:
                         q[0].wait()
                 mfgs = own._sample_variable(self._lane, self._smp, self._nodes, self._ts,
@@ -497,9 +505,10 @@ class _Lane:
     own native workspace and publish ring, the stream its chains run on, its communicator, and
     a ring of exchange workspaces (one per sample that can be in flight on the lane)."""
 
-    def __init__(self, sampler, comm=None, sampler_b=None):
+    def __init__(self, sampler, comm=None, clones=0):
         self.sampler = sampler
-        self.sampler_b = sampler_b  # pairs: the second sample of a shared chain runs through it
+        # shared chains: sample j of a chain runs through samplers[j] (clones of `sampler`)
+        self.samplers = [sampler] + [sampler.clone() for _ in range(clones)]
         self.stream = None          # lanes >= 1: their own stream, created on first use
         self.comm = comm
         self.comm_tried = comm is not None
@@ -542,7 +551,7 @@ class DevicePartitionedSampler:
     owns, see PartitionedGraph)."""
 
     def __init__(self, sampler, group=None, always_exchange=False, slack=None, slot_roots=None,
-                 comm=None, overlap=None, lanes=None, pair=None):
+                 comm=None, overlap=None, lanes=None, pair=None, chain_samples=None):
         """always_exchange: take the multi-rank path — request / reply exchange, served
         requests, merge — even with one rank (where every message is empty).  For tests: it
         is the only way to run the RCCL branch on a one-GPU box.
@@ -568,12 +577,14 @@ class DevicePartitionedSampler:
         lanes: sampling lanes (default GNNFLOW_PART_LANES, else 2 — 4 from 4 ranks on — with
         more than one rank / always_exchange, else 1).  A lane is used only by `sample_async(..., stream=...)` calls
         that name a stream (the pipelined loop); `sample()` always runs on lane 0.
-        pair: let two consecutive `sample_async(..., stream=...)` calls share ONE chain — its
-        launches and its exchanges (include/gnnflow_hip.h gf_sampler_sample_partitioned_comm_pair:
-        11 stream operations per two samples instead of per sample; the chain is bound by the
-        host thread that issues it).  The first of the two is held until the second arrives
-        or it is waited for.  Default GNNFLOW_PART_PAIR or on; needs the library's
-        communicator, one snapshot and layers of <= 32 768 roots (else single chains)."""
+        chain_samples: let up to this many (1..4) consecutive `sample_async(..., stream=...)`
+        calls share ONE chain — its launches and its exchanges (include/gnnflow_hip.h
+        gf_sampler_sample_partitioned_comm_group: 11 stream operations per m samples instead of
+        per sample; the chain is bound by the host thread that issues it).  The samples are held
+        until the chain is full or one of them is waited for (then the chain goes out with
+        those held so far).  Default GNNFLOW_PART_CHAIN or 4; needs the library's communicator,
+        one snapshot and layers of <= 32 768 roots (else single chains).
+        pair: False = chain_samples 1 (the earlier name of the switch; GNNFLOW_PART_PAIR=0)."""
         import ctypes as C
         import os
         from . import _capi
@@ -613,16 +624,20 @@ class DevicePartitionedSampler:
         lanes = max(1, min(int(lanes), 4))
         if pair is None:
             pair = os.environ.get("GNNFLOW_PART_PAIR", "1") != "0"
-        self._pair = bool(pair) and self._slack > 0 and self._S == 1 and \
-            not (self._P == 1 and not self._always_exchange)
-        self._lanes = [_Lane(sampler, comms[0] if comms else None,
-                             sampler.clone() if self._pair else None)]
+        if chain_samples is None:
+            chain_samples = int(os.environ.get("GNNFLOW_PART_CHAIN", "4"))
+        chain = max(1, min(int(chain_samples), _capi.GF_PART_GROUP_MAX)) if pair else 1
+        if not (self._slack > 0 and self._S == 1) or (self._P == 1 and not self._always_exchange):
+            chain = 1
+        self.chain_samples = chain
+        self._lanes = [_Lane(sampler, comms[0] if comms else None, chain - 1)]
         for k in range(1, lanes):
             self._lanes.append(_Lane(sampler.clone(), comms[k] if k < len(comms) else None,
-                                     sampler.clone() if self._pair else None))
+                                     chain - 1))
         self.lanes = lanes
-        self._held = None          # a sample waiting for its partner (pairs)
-        self.pairs = 0             # chains that carried two samples
+        self._held = []            # samples (of one lane) waiting for their chain to fill
+        self.pairs = 0             # chains that carried more than one sample
+        self.chained = 0           # samples that travelled in such chains
         self._rr = 0               # round-robin cursor over the lanes
         self._layouts = {}     # (R0, slack) -> ([layouts per layer], [workspace offsets], total)
         self.overflows = 0     # slotted samples that had to be redone
@@ -714,8 +729,8 @@ class DevicePartitionedSampler:
         """TemporalSampler.sample_async for the partitioned graph: returns a pending sample;
         `.wait()` gives the MFGs.  With more than one rank the launches and the collectives
         are enqueued by this call without any host synchronisation (slotted form)."""
-        if self._pair and stream is not None:
-            return self._sample_paired(nodes, ts, stream, worker_enqueue)
+        if self.chain_samples > 1 and stream is not None:
+            return self._sample_chained(nodes, ts, stream, worker_enqueue)
         lane, stream = self._pick_lane(stream)
         smp = lane.sampler
         if len(smp._inflight) >= smp._max_inflight:
@@ -729,102 +744,96 @@ class DevicePartitionedSampler:
                 nodes, ts, stream)
         return self._sample_variable(lane, smp, nodes, ts, stream)
 
-    # ---- pairs: two consecutive samples in one chain ------------------------------------------
-    def _sample_paired(self, nodes, ts, stream, worker_enqueue):
+    # ---- shared chains: up to chain_samples consecutive samples in one chain ------------------
+    def _sample_chained(self, nodes, ts, stream, worker_enqueue):
         held = self._held
-        if held is None:
+        if not held:
             lane, st = self._pick_lane(stream)
-            nodes, ts = lane.sampler._to_device(nodes, ts, st)
-            self._held = h = _PartitionedPending(self, lane, lane.sampler, None, nodes, ts, st,
-                                                 worker_enqueue)
-            return h
-        self._held = None
-        lane, st = held._lane, held._stream
-        nodes, ts = lane.sampler_b._to_device(nodes, ts, st)
-        second = _PartitionedPending(self, lane, lane.sampler_b, None, nodes, ts, st, worker_enqueue)
-        self._issue_pair(lane, held, second, st, worker_enqueue)
-        return second
+        else:
+            lane, st = held[0]._lane, held[0]._stream
+        smp = lane.samplers[len(held)]
+        nodes, ts = smp._to_device(nodes, ts, st)
+        p = _PartitionedPending(self, lane, smp, None, nodes, ts, st, worker_enqueue)
+        held.append(p)
+        if len(held) == self.chain_samples:
+            self._issue_held()
+        return p
 
-    def _issue_held_alone(self, p):
-        """`p` is waited for before its partner arrived: its chain is issued for it alone."""
-        if self._held is p:
-            self._held = None
-        smp = p._smp
-        if len(smp._inflight) >= smp._max_inflight:
-            smp._inflight[0].wait()
-        p._attach(self._sample_slotted(p._lane, smp, p._nodes, p._ts, p._stream, p._worker_enqueue))
-
-    def _issue_pair(self, lane, first, second, stream, worker_enqueue):
-        C, lib, check = self._C, self._lib, self._capi.check
-        sa, sb = lane.sampler, lane.sampler_b
-        for smp in (sa, sb):
+    def _issue_held(self):
+        """The chain of the samples held so far goes out (it is full, or one of them is waited
+        for before the next batch arrived)."""
+        held, self._held = self._held, []
+        if not held:
+            return
+        lane, stream = held[0]._lane, held[0]._stream
+        worker_enqueue = held[-1]._worker_enqueue
+        for p in held:
+            smp = p._smp
             if len(smp._inflight) >= smp._max_inflight:
                 smp._inflight[0].wait()
-        Ra, Rb = int(first._nodes.shape[0]), int(second._nodes.shape[0])
+        if len(held) == 1:
+            p = held[0]
+            p._attach(self._sample_slotted(lane, p._smp, p._nodes, p._ts, stream, worker_enqueue))
+            return
+        C, lib, check = self._C, self._lib, self._capi.check
+        m = len(held)
+        Rs = [int(p._nodes.shape[0]) for p in held]
         if not self._slot_roots:
-            self._slot_roots = self._agree_on_slot_roots(max(Ra, Rb, 1))
+            self._slot_roots = self._agree_on_slot_roots(max(Rs + [1]))
         comm = self._ensure_comm(lane)
         ws_bytes = 0
+
+        def group_bytes(roots):
+            key = ("chain",) + tuple(roots)
+            n = self._layouts.get(key)
+            if n is None:
+                arr = (C.c_size_t * len(roots))(*roots)
+                out = C.c_size_t(0)
+                check(lib.gf_sampler_part_group_ws_bytes(lane.sampler._h, arr, len(roots), self._P,
+                                                         self._slack, self._slot_roots,
+                                                         C.byref(out)))
+                n = self._layouts[key] = out.value
+            return n
+        force = 0
         if comm is not None:
-            # Whether two samples share a chain is part of the PROTOCOL (their slots travel in
-            # one exchange): every rank must decide alike, so the decision follows from the
-            # batch size all ranks agreed on (slot_roots), not from this rank's own batches.
-            pairable = self._layouts.get("pairable")
-            if pairable is None:
-                n = C.c_size_t(0)
-                sr = max(self._slot_roots, 1)
-                check(lib.gf_sampler_part_pair_ws_bytes(sa._h, sr, sr, self._P, self._slack,
-                                                        self._slot_roots, C.byref(n)))
-                pairable = self._layouts["pairable"] = n.value > 0
-            force = 0
-            if pairable:
-                # A batch too large for the pair chain's kernels (more roots than slot_roots, so
-                # that a layer exceeds 32 768 roots) cannot change the protocol on its own: an
-                # EMPTY stand-in travels in its place with the sample's overflow flag forced,
+            # Whether samples share a chain is part of the PROTOCOL (their slots travel in one
+            # exchange): every rank must decide alike, so the decision follows from the batch
+            # size all ranks agreed on (slot_roots), not from this rank's own batches.
+            sr = max(self._slot_roots, 1)
+            if group_bytes([sr]) > 0:
+                # A batch too large for the shared chain's kernels (more roots than slot_roots,
+                # so that a layer exceeds 32 768 roots) cannot change the protocol on its own:
+                # an EMPTY stand-in travels in its place with the sample's overflow flag forced,
                 # every rank sees the flag and the real batch is sampled in the redo.
-                def fits(R):
-                    ok = self._layouts.get(("fits", R))
-                    if ok is None:
-                        n = C.c_size_t(0)
-                        check(lib.gf_sampler_part_pair_ws_bytes(sa._h, R, 1, self._P, self._slack,
-                                                                self._slot_roots, C.byref(n)))
-                        ok = self._layouts[("fits", R)] = n.value > 0
-                    return ok
-                if not fits(max(Ra, 1)):
-                    force |= 1
-                    Ra = 0
-                if not fits(max(Rb, 1)):
-                    force |= 2
-                    Rb = 0
-                key = ("pair", max(Ra, 1), max(Rb, 1))
-                ws_bytes = self._layouts.get(key)
-                if ws_bytes is None:
-                    n = C.c_size_t(0)
-                    check(lib.gf_sampler_part_pair_ws_bytes(sa._h, max(Ra, 1), max(Rb, 1), self._P,
-                                                            self._slack, self._slot_roots,
-                                                            C.byref(n)))
-                    ws_bytes = self._layouts[key] = n.value
-                assert ws_bytes, "a pair of fitting samples has a workspace"
-        if not ws_bytes:      # no communicator / not pairable: two single chains
-            first._attach(self._sample_slotted(lane, sa, first._nodes, first._ts, stream,
+                for j in range(m):
+                    if group_bytes([max(Rs[j], 1)]) == 0:
+                        force |= 1 << j
+                        Rs[j] = 0
+                ws_bytes = group_bytes([max(R, 1) for R in Rs])
+                assert ws_bytes, "a chain of fitting samples has a workspace"
+        if not ws_bytes:      # no communicator / not chainable: single chains
+            for p in held:
+                p._attach(self._sample_slotted(lane, p._smp, p._nodes, p._ts, stream,
                                                worker_enqueue))
-            second._attach(self._sample_slotted(lane, sb, second._nodes, second._ts, stream,
-                                                worker_enqueue))
             return
-        slab_a, out_a, nb_a = self._output(sa, Ra, stream)
-        slab_b, out_b, nb_b = self._output(sb, Rb, stream)
+        outs = [self._output(p._smp, R, stream) for p, R in zip(held, Rs)]
         ws, _ = self._workspace(lane, ws_bytes, stream)
-        call = lib.gf_sampler_sample_partitioned_comm_pair_async \
+        call = lib.gf_sampler_sample_partitioned_comm_group_async \
             if (worker_enqueue and comm.transport != "loopback") \
-            else lib.gf_sampler_sample_partitioned_comm_pair
-        na, ta, nb_, tb = first._nodes, first._ts, second._nodes, second._ts
-        check(call(sa._h, sb._h, comm.h,
-                   na.data_ptr() if Ra else None, ta.data_ptr() if Ra else None, Ra, out_a, nb_a,
-                   nb_.data_ptr() if Rb else None, tb.data_ptr() if Rb else None, Rb, out_b, nb_b,
-                   ws.data_ptr(), ws_bytes, self._slack, self._slot_roots, force, slab_a[6]))
-        first._attach(self._pend(sa, slab_a, (na, ta, ws), Ra))
-        second._attach(self._pend(sb, slab_b, (nb_, tb, ws), Rb))
+            else lib.gf_sampler_sample_partitioned_comm_group
+        desc = (self._capi.GfGroupSample * m)()
+        for j, (p, R, (slab, out_ptr, nbytes)) in enumerate(zip(held, Rs, outs)):
+            d = desc[j]
+            d.sampler = p._smp._h.value
+            d.d_roots = p._nodes.data_ptr() if R else None
+            d.d_root_ts = p._ts.data_ptr() if R else None
+            d.num_roots, d.d_out, d.out_bytes = R, out_ptr, nbytes
+        check(call(comm.h, desc, m, ws.data_ptr(), ws_bytes, self._slack, self._slot_roots, force,
+                   outs[0][0][6]))
+        for p, R, (slab, _, _) in zip(held, Rs, outs):
+            p._attach(self._pend(p._smp, slab, (p._nodes, p._ts, ws), R))
         self.pairs += 1
+        self.chained += m
 
     def _output(self, smp, R, stream):
         C = self._C
@@ -879,7 +888,7 @@ class DevicePartitionedSampler:
                 ref = self._plan(max(self._slot_roots, 1), self._slack)[0]
                 # (and, for an overflowed sample's redo through the variable-size exchange,
                 # never less than 16 MiB)
-                m = 2 if self._pair else 1      # a pair's exchange carries two slots per peer
+                m = self.chain_samples          # a shared exchange carries m slots per peer
                 box = max([16 << 20] + [m * P * lay.slot_stride * (24 * f + 16) + 512 * P
                                         for lay, f in zip(ref, self._fanouts)])
                 lane.comm = NativeComm.create_agreed(self._device, self._group, kind,

@@ -39,8 +39,10 @@ class ReplayPipeline:
         self.pipelined = bool(pipelined) and cache is not None and \
             hasattr(sampler, "sample_async")
         self.side = torch.cuda.Stream(device=self.device) if self.pipelined else None
-        # a sampler (a lane of the partitioned sampler) holds 4 begun samples at most
-        self.depth = max(1, min(int(depth), 3 * max(1, getattr(self.sampler, "lanes", 1))))
+        # a sampler (of a lane of the partitioned sampler: one per sample of a shared chain)
+        # holds 4 begun samples at most
+        self.depth = max(1, min(int(depth), 3 * max(1, getattr(self.sampler, "lanes", 1)) *
+                                max(1, getattr(self.sampler, "chain_samples", 1))))
         # GNNFLOW_PIPELINE_FETCH_FIRST=1: submit batch i's fetch before the sample of batch
         # i + depth (the chains of a partitioned sampler over a communicator share the fetches'
         # issuing thread; measured: no consistent difference, profiles/README.md round 4)

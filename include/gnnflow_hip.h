@@ -555,34 +555,43 @@ GF_API int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c,
                                                     void* d_ws, size_t ws_bytes, double slack,
                                                     size_t slot_roots, int overlap, void* stream);
 
-/* TWO samples in one chain: at batch 600 the chain's throughput is bound by the host thread that
- * issues its ~11 stream operations, so two consecutive batches share their launches and their
- * exchanges — sample a through sampler `sa`, sample b through `sb` (a second sampler over the
- * same graph with the same arguments: each keeps its own output, block counters and publish
- * record; gf_sampler_sample_end / gf_sampler_part_overflowed per sampler as usual).  Owner q's
- * requests of sample j travel in slot 2 q + j of ONE buffer, so one equal-split all-to-all moves
- * both samples' slots; 11 operations per two samples.  gf_sampler_part_pair_ws_bytes: size of
- * the shared exchange workspace, 0 if these two samples cannot share a chain (several
- * snapshots, a layer beyond 32 768 roots, fanout > 256): the caller then issues two single
- * chains.  force_overflow (bit 0: sample a, bit 1: sample b): flag that sample as overflowed
- * whatever its slots hold — for a batch that is too large for this chain although the batch size
- * the ranks agreed on is not, the caller submits an EMPTY stand-in with this bit set, every rank
- * sees the flag in the same exchange and the real batch is sampled in the redo.  No reference
- * counterpart (its RPC futures are per partition and per call,
- * gnnflow/distributed/dist_sampler.py:188-220). */
-GF_API int gf_sampler_part_pair_ws_bytes(const gf_sampler* s, size_t roots_a, size_t roots_b,
-                                         int world_size, double slack, size_t slot_roots,
-                                         size_t* bytes);
-GF_API int gf_sampler_sample_partitioned_comm_pair(
-    gf_sampler* sa, gf_sampler* sb, gf_comm* c, const int64_t* d_roots_a, const float* d_ts_a,
-    size_t roots_a, void* d_out_a, size_t out_bytes_a, const int64_t* d_roots_b,
-    const float* d_ts_b, size_t roots_b, void* d_out_b, size_t out_bytes_b, void* d_ws,
-    size_t ws_bytes, double slack, size_t slot_roots, int force_overflow, void* stream);
-GF_API int gf_sampler_sample_partitioned_comm_pair_async(
-    gf_sampler* sa, gf_sampler* sb, gf_comm* c, const int64_t* d_roots_a, const float* d_ts_a,
-    size_t roots_a, void* d_out_a, size_t out_bytes_a, const int64_t* d_roots_b,
-    const float* d_ts_b, size_t roots_b, void* d_out_b, size_t out_bytes_b, void* d_ws,
-    size_t ws_bytes, double slack, size_t slot_roots, int force_overflow, void* stream);
+/* Up to GF_PART_GROUP_MAX samples in ONE chain: at batch 600 the chain's throughput is bound by
+ * the host thread that issues its ~11 stream operations, so m consecutive batches share their
+ * launches and their exchanges — sample j through its own sampler `samples[j].sampler` (m
+ * samplers over the same graph with the same arguments: each keeps its own output, block
+ * counters and publish record; gf_sampler_sample_end / gf_sampler_part_overflowed per sampler as
+ * usual).  Owner q's requests of sample j travel in slot m q + j of ONE buffer, so one
+ * equal-split all-to-all moves every sample's slots; 11 operations per m samples.
+ * gf_sampler_part_group_ws_bytes: size of the shared exchange workspace for samples of
+ * roots[0..m) roots, 0 if they cannot share a chain (several snapshots, a layer beyond 32 768
+ * roots, fanout > 256): the caller then issues single chains.  force_overflow (bit j: sample
+ * j): flag that sample as overflowed whatever its slots hold — for a batch that is too large for
+ * this chain although the batch size the ranks agreed on is not, the caller submits an EMPTY
+ * stand-in with this bit set, every rank sees the flag in the same exchange and the real batch
+ * is sampled in the redo.  No reference counterpart (its RPC futures are per partition and per
+ * call, gnnflow/distributed/dist_sampler.py:188-220). */
+#define GF_PART_GROUP_MAX 4
+typedef struct gf_group_sample {
+  gf_sampler* sampler;
+  const int64_t* d_roots;
+  const float* d_root_ts;
+  size_t num_roots;
+  void* d_out;          /* gf_sampler_output_bytes(num_roots) bytes, as for gf_sampler_sample */
+  size_t out_bytes;
+} gf_group_sample;
+GF_API int gf_sampler_part_group_ws_bytes(const gf_sampler* s, const size_t* roots, int m,
+                                          int world_size, double slack, size_t slot_roots,
+                                          size_t* bytes);
+GF_API int gf_sampler_sample_partitioned_comm_group(gf_comm* c, const gf_group_sample* samples,
+                                                    int m, void* d_ws, size_t ws_bytes,
+                                                    double slack, size_t slot_roots,
+                                                    int force_overflow, void* stream);
+/* ... issued by the library's enqueue thread (like gf_sampler_sample_partitioned_comm_async) */
+GF_API int gf_sampler_sample_partitioned_comm_group_async(gf_comm* c,
+                                                          const gf_group_sample* samples, int m,
+                                                          void* d_ws, size_t ws_bytes,
+                                                          double slack, size_t slot_roots,
+                                                          int force_overflow, void* stream);
 
 /* ---- message passing on a sampled block ---------------------- */
 /* The DGL calls of the reference's layers on an MFG (gnnflow/models/modules/layers.py:153-159,

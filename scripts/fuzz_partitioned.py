@@ -1,5 +1,5 @@
-"""Fuzzer for the native partitioned chains (single and paired, slotted + overflow redo) over the
-in-process loopback transport: random world sizes, graphs, fanouts, batch sizes (ragged, empty),
+"""Fuzzer for the native partitioned chains (single and shared by 2-4 samples, slotted +
+overflow redo) over the in-process loopback transport: random world sizes, graphs, fanouts, batch sizes (ragged, empty),
 slot capacities, snapshots / windows / prop_time; every most-recent MFG of every rank is compared
 bit for bit with the CPU oracle over the whole graph.  Beyond the test suite (run on the GPU box):
 
@@ -41,7 +41,7 @@ def one(seed, dev):
     window = float(rng.choice([0.0, 40.0, 200.0])) if snaps == 1 else float(rng.choice([30.0, 120.0]))
     prop = bool(rng.randint(0, 2))
     slack = float(rng.choice([2.0, 2.0, 1.0, 0.3, 0.05]))
-    pair = bool(rng.randint(0, 4) != 0)
+    chain = int(rng.choice([1, 2, 3, 4, 4]))
     minblk = int(rng.choice([4, 8, 62]))
     src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=seed, tie_levels=int(rng.choice([50, 500, 5000])))
     full = O.OracleGraph(minimum_block_size=minblk)
@@ -54,7 +54,7 @@ def one(seed, dev):
         full.add_edges(src[sl], dst[sl], ts[sl], eid[sl], add_reverse=rev)
         for pg in parts:
             pg.add_edges(src[sl], dst[sl], ts[sl], eid[sl], add_reverse=rev)
-    n_samples = int(rng.randint(3, 10))
+    n_samples = int(rng.randint(3, 14))
     pool = [0, 1, 2, 17, 97, 300, 600, 1500]
     slot_roots = int(rng.choice([600, 1500]))
     batches = [[synth.random_roots(N, int(pool[rng.randint(0, len(pool))]), 1000.0,
@@ -64,13 +64,14 @@ def one(seed, dev):
               snapshot_time_window=window, prop_time=prop)
     comms = NativeComm.loopback(P, dev)
     res, err = [None] * P, [None] * P
-    inflight = int(rng.choice([1, 2, 3, 5]))
+    inflight = int(rng.choice([1, 2, 3, 5, 8]))
 
     def body(r):
         try:
             with torch.cuda.stream(torch.cuda.Stream()):
                 part = DevicePartitionedSampler(TemporalSampler(shards[r], **kw), comm=comms[r],
-                                                slack=slack, slot_roots=slot_roots, pair=pair)
+                                                slack=slack, slot_roots=slot_roots,
+                                                chain_samples=chain)
                 side = torch.cuda.Stream()
                 got = []
                 for lo in range(0, n_samples, inflight):
@@ -90,7 +91,7 @@ def one(seed, dev):
     [t.start() for t in th]
     [t.join(timeout=300) for t in th]
     desc = dict(seed=seed, P=P, N=N, E=E, fan=fan, snaps=snaps, window=window, prop=prop, slack=slack,
-                pair=pair, inflight=inflight, slot_roots=slot_roots)
+                chain=chain, inflight=inflight, slot_roots=slot_roots)
     if any(t.is_alive() for t in th):
         return "HANG", desc
     if any(err):
@@ -129,9 +130,9 @@ def main():
             over += desc["overflows"]
             pairs += desc["pairs"]
         if (seed + 1) % 20 == 0:
-            print("... {} seeds, {} failures, {} overflowed samples redone, {} paired chains, {:.0f} s"
+            print("... {} seeds, {} failures, {} overflowed samples redone, {} shared chains, {:.0f} s"
                   .format(seed + 1 - args.first, bad, over, pairs, time.time() - t0), flush=True)
-    print("fuzz_partitioned: {} seeds, {} failures, {} overflowed samples (per rank 0), {} paired "
+    print("fuzz_partitioned: {} seeds, {} failures, {} overflowed samples (per rank 0), {} shared "
           "chains".format(args.seeds, bad, over, pairs))
     sys.exit(1 if bad else 0)
 

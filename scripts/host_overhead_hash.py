@@ -13,7 +13,10 @@ from gnnflow_amd.dist import DevicePartitionedSampler, PartitionedGraph
 ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=3)
 ap.add_argument("--depth", type=int, default=0)
+ap.add_argument("--chain", type=int, default=None)
+ap.add_argument("--profile", action="store_true", help="cProfile of the last repetition (main thread)")
 ap.add_argument("--no-exchange", action="store_true")
+ap.add_argument("--replica", action="store_true", help="the plain sampler over the whole graph (the N = 1 headline loop) for comparison")
 args = ap.parse_args()
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29578")
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
@@ -24,7 +27,10 @@ pg = PartitionedGraph(graph, 0, 1)
 for lo in range(0, g["num_edges"], 100000):
     pg.add_edges(g["src"][lo:lo+100000], g["dst"][lo:lo+100000], g["ts"][lo:lo+100000], g["eid"][lo:lo+100000])
 sampler = DevicePartitionedSampler(gnnflow_amd.TemporalSampler(graph, [10, 10]), always_exchange=not args.no_exchange,
-                                   slot_roots=1800, lanes=args.lanes)
+                                   slot_roots=1800, lanes=args.lanes, chain_samples=args.chain)
+if args.replica:
+    sampler = gnnflow_amd.TemporalSampler(graph, [10, 10])
+    sampler.lanes, sampler.chain_samples = 1, 1
 ef = torch.rand((g["num_edges"], 172), device=dev); nf = torch.rand((g["num_nodes"], 172), device=dev)
 cache = LRUCache(0.2, 0.2, g["num_nodes"], g["num_edges"], dev, nf, ef, 172, 172); cache.init_cache()
 batches = [(torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev), torch.from_numpy(e).to(dev))
@@ -33,8 +39,17 @@ side = torch.cuda.Stream(device=dev); main = torch.cuda.current_stream(dev)
 from collections import deque
 T = dict(wait=0.0, begin=0.0, rec=0.0, fetch=0.0, wq=0.0)
 orig_wait = cache.wait_enqueued
-def timed_wait():
-    t0 = time.perf_counter(); orig_wait(); T["wq"] += time.perf_counter() - t0
+T["wq_c"] = T["wq_free"] = 0.0
+def timed_wait(upto=None):      # Cache.wait_enqueued with its two halves timed apart
+    q = cache._tickets
+    while q and (upto is None or q[0][0] <= upto):
+        t0 = time.perf_counter()
+        ticket, refs = q.popleft()
+        _capi.check(cache._lib.gf_cache_fetch_wait(ticket))
+        t1 = time.perf_counter()
+        del refs                # the MFGs, ids and outputs of that fetch go here
+        t2 = time.perf_counter()
+        T["wq"] += t2 - t0; T["wq_c"] += t1 - t0; T["wq_free"] += t2 - t1
 cache.wait_enqueued = timed_wait
 DEPTH = args.depth or (sampler.lanes + 1)
 import ctypes as C
@@ -42,11 +57,14 @@ lib = _capi.load()
 def workers():
     bu, jb = C.c_double(0), C.c_uint64(0); lib.gf_worker_stats(C.byref(bu), C.byref(jb)); return bu.value, jb.value
 lib.gf_debug_part_host_us((C.c_double * 8)(), 1)
+import cProfile, pstats
 for rep in range(3):
+    prof = cProfile.Profile() if (args.profile and rep == 2) else None
     for k in T: T[k] = 0.0
     cache.init_cache()
     b0, j0 = workers()
     torch.cuda.synchronize(); t00 = time.perf_counter()
+    if prof: prof.enable()
     pending = deque(); nxt = 0
     while nxt < len(batches) and len(pending) < DEPTH:
         pending.append(sampler.sample_async(batches[nxt][0], batches[nxt][1], stream=side, worker_enqueue=True)); nxt += 1
@@ -60,13 +78,16 @@ for rep in range(3):
         T["rec"] += time.perf_counter() - t0
         t0 = time.perf_counter(); cache.fetch_feature(mfgs, batches[i][2], async_enqueue=True); T["fetch"] += time.perf_counter() - t0
     cache.wait_enqueued(); torch.cuda.synchronize(); tot = time.perf_counter() - t00
+    if prof:
+        prof.disable()
+        pstats.Stats(prof).sort_stats("tottime").print_stats(32)
     b1, j1 = workers()
     n = len(batches)
     st = (C.c_double * 8)(); lib.gf_debug_part_host_us(st, 1)
     if st[7]:
         print("  issuing thread per sample us: begin %.1f plan %.1f a2a-req %.1f serve %.1f a2a-rep %.1f merge %.1f commit %.1f = %.1f" % (
             *[st[i] / st[7] for i in range(7)], sum(st[i] for i in range(7)) / st[7]))
-    print("lanes %d depth %d per step us: total %.1f | sample.wait %.1f | sample_async %.1f | record_stream %.1f | fetch_feature %.1f (of which wait_enqueued %.1f) | enqueue threads busy %.1f us/step over %.1f jobs/step" % (
-        sampler.lanes, DEPTH, 1e6*tot/n, 1e6*T["wait"]/n, 1e6*T["begin"]/n, 1e6*T["rec"]/n, 1e6*T["fetch"]/n, 1e6*T["wq"]/n,
+    print("lanes %d chain %d depth %d per step us: total %.1f | sample.wait %.1f | sample_async %.1f | record_stream %.1f | fetch_feature %.1f (of which wait_enqueued %.1f = native wait %.1f + dropping the fetch's references %.1f) | enqueue threads busy %.1f us/step over %.1f jobs/step" % (
+        sampler.lanes, sampler.chain_samples, DEPTH, 1e6*tot/n, 1e6*T["wait"]/n, 1e6*T["begin"]/n, 1e6*T["rec"]/n, 1e6*T["fetch"]/n, 1e6*T["wq"]/n, 1e6*T["wq_c"]/n, 1e6*T["wq_free"]/n,
         (b1 - b0) / n, (j1 - j0) / n), flush=True)
 dist.destroy_process_group()

@@ -220,12 +220,13 @@ def test_sharded_feature_pull_at_world_8(world):
         c.close()
 
 
-@pytest.mark.parametrize("ranks", [2, 3, 5])
-def test_pair_chains_with_ragged_and_empty_batches(ranks):
-    """Two samples per chain (gf_sampler_sample_partitioned_comm_pair) where the partners differ:
-    empty batches, single roots, different sizes on different ranks in the same exchange, two
-    snapshots (not pairable: two single chains), an odd number of samples (the last one is issued
-    alone) — every MFG against the oracle over the whole graph."""
+@pytest.mark.parametrize("ranks,chain", [(2, 2), (2, 4), (3, 3), (3, 4), (5, 2), (5, 4)])
+def test_shared_chains_with_ragged_and_empty_batches(ranks, chain):
+    """Several samples per chain (gf_sampler_sample_partitioned_comm_group) where the partners
+    differ: empty batches, single roots, different sizes on different ranks in the same exchange,
+    two snapshots (no shared chains: single ones), a number of samples that does not fill the
+    last chain (it goes out with those held when one of them is waited for) — every MFG against
+    the oracle over the whole graph."""
     import torch
     from gnnflow_amd import DynamicGraph, TemporalSampler
     from gnnflow_amd.dist import DevicePartitionedSampler, NativeComm, PartitionedGraph
@@ -258,7 +259,7 @@ def test_pair_chains_with_ragged_and_empty_batches(ranks):
         def rank_body(r):
             part = DevicePartitionedSampler(
                 TemporalSampler(shards[r], sample_strategy="recent", **kw), comm=comms[r],
-                slack=slack, slot_roots=max(sizes))
+                slack=slack, slot_roots=max(sizes), chain_samples=chain)
             side = torch.cuda.Stream()
             pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t).to(dev),
                                       stream=side, worker_enqueue=True) for n, t in batches[r][:4]]
@@ -266,7 +267,7 @@ def test_pair_chains_with_ragged_and_empty_batches(ranks):
             pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t).to(dev),
                                       stream=side) for n, t in batches[r][4:]]
             got += [_to_host(p.wait()) for p in pend]
-            return got, part.pairs, part.overflows
+            return got, (part.pairs, part.chained), part.overflows
 
         res = _run_ranks(rank_body, ranks)
         ref = O.OracleSampler(full, kw["fanouts"], "recent", num_snapshots=kw["num_snapshots"],
@@ -277,8 +278,10 @@ def test_pair_chains_with_ragged_and_empty_batches(ranks):
                 assert over == 0
             else:
                 assert over > 0 and over == res[0][2]      # the same samples on every rank
-            # 4 samples -> 2 pairs, then 5 samples -> 2 pairs + one chain for the last alone
-            assert pairs == (4 if kw["num_snapshots"] == 1 else 0)
+            # 4 samples, all waited for, then 5: chains of 2: 2 + 2 (+ the last alone); of 3:
+            # 1 (+ one alone), then 1 + the two held ones; of 4: 1, then 1 (+ the last alone)
+            want = ({2: 4, 3: 3, 4: 2}[chain], 8) if kw["num_snapshots"] == 1 else (0, 0)
+            assert pairs == want
             for (n, t), mfgs in zip(batches[r], got):
                 for gl, wl in zip(mfgs, ref.sample(n, t)):
                     for gb, wb in zip(gl, wl):
