@@ -241,6 +241,22 @@ PROTOTYPES = {
     "gf_profile_launches": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
 }
 
+_raw_stream = None
+
+
+def current_stream(device) -> C.c_void_p:
+    """torch's current stream on `device` (a torch.device with an index) as the C ABI takes it.
+    The raw-handle query costs ~0.3 us of host time; torch.cuda.current_stream() builds a
+    Stream object (~6 us in the batch-600 loop's profile; the step itself did not change —
+    the loop is not bound by this thread, profiles/README.md round 4)."""
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or \
+            (lambda index: torch.cuda.current_stream(index).cuda_stream)
+    return C.c_void_p(_raw_stream(device.index))
+
+
 _lib = None
 
 

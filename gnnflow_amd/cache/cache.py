@@ -232,7 +232,7 @@ class Cache:
         return self._ratio(ring[pos + n_node:pos + n_cached], n_alias)
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return _capi.current_stream(self.device)
 
     def slot_ids(self, kind: str) -> np.ndarray:
         """ids cached per slot (-1: empty) of the 'node' or 'edge' cache, on the host

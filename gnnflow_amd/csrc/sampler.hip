@@ -2477,7 +2477,18 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
       // group width by the roots there really are (<= the layer's bound per sample), not by the
       // slot rows, most of which are empty: a latency chain wants the 16-lane search
       // (layer 1 of the batch-600 pair: 9.3 -> see profiles/README.md round 4)
-      const int width = bound > kSmallRoots ? a.large_group_ : a.search_group_;
+      // ... and by ALL the roots of the launch: m samples' layers together no longer fit the
+      // GPU with 16 lanes per root, and the launch shares the GPU with the other lanes' chains
+      // and the fetch kernels, so roots in flight per wave count for more than search rounds:
+      // 2 lanes per root from 4 096 roots on (batch 600, 4 samples per chain, one rank over
+      // RCCL: 56.7 us per step with 16 lanes, 50.7 with 4, 46.8 with 2, 43.8 with 2 also for
+      // the 7 200-root first layer; profiles/README.md round 4)
+      static const int chain_width = group_width_from_env("GNNFLOW_PART_CHAIN_WIDTH", 2);
+      static const size_t chain_small = [] {
+        const char* v = std::getenv("GNNFLOW_PART_CHAIN_SMALL");
+        return v ? static_cast<size_t>(std::atol(v)) : size_t{4096};
+      }();
+      const int width = static_cast<size_t>(m) * bound > chain_small ? chain_width : a.search_group_;
       const unsigned grid = capped_grid(n_max, kSearchThreads / width, 256 * 8);
       const PaddedCommon pc{0, 1, a.window_, F, a.policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0,
                             a.prop_time_ ? 1 : 0, a.seed_};

@@ -46,7 +46,7 @@ class Memory:
         self._epoch = 0
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return _capi.current_stream(self.device)
 
     def reset(self):
         """Reset the memory and the mailbox."""

@@ -193,7 +193,7 @@ class MFGBlock:
                 _capi.check(_capi.load().gf_block_segment_offsets(
                     row.data_ptr() if self._num_edges else None, self._num_edges, self._num_dst,
                     offsets.data_ptr(), self._device.index,
-                    C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)))
+                    _capi.current_stream(self._device)))
             self._segments = (offsets, None if sampler_layout else col, perm)
         return self._segments
 

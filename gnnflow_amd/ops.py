@@ -16,7 +16,7 @@ from . import _capi
 
 
 def _stream(device):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return _capi.current_stream(device)
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:

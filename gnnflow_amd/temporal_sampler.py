@@ -184,7 +184,7 @@ class TemporalSampler:
         return b
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+        return _capi.current_stream(self._device)
 
     # ---- reference API ------------------------------------------------------------
     def sample(self, target_vertices: np.ndarray, timestamps: np.ndarray) -> List[List[MFGBlock]]:

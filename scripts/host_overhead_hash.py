@@ -40,6 +40,7 @@ from collections import deque
 T = dict(wait=0.0, begin=0.0, rec=0.0, fetch=0.0, wq=0.0)
 orig_wait = cache.wait_enqueued
 T["wq_c"] = T["wq_free"] = 0.0
+DROP = [0.0] * 8
 def timed_wait(upto=None):      # Cache.wait_enqueued with its two halves timed apart
     q = cache._tickets
     while q and (upto is None or q[0][0] <= upto):
@@ -47,7 +48,11 @@ def timed_wait(upto=None):      # Cache.wait_enqueued with its two halves timed 
         ticket, refs = q.popleft()
         _capi.check(cache._lib.gf_cache_fetch_wait(ticket))
         t1 = time.perf_counter()
-        del refs                # the MFGs, ids and outputs of that fetch go here
+        refs = list(refs)       # (jobs, descs, cdescs, mfgs, out_all, stats ring)
+        while refs:
+            ta = time.perf_counter()
+            refs.pop()
+            DROP[len(refs)] += time.perf_counter() - ta
         t2 = time.perf_counter()
         T["wq"] += t2 - t0; T["wq_c"] += t1 - t0; T["wq_free"] += t2 - t1
 cache.wait_enqueued = timed_wait
@@ -83,6 +88,8 @@ for rep in range(3):
         pstats.Stats(prof).sort_stats("tottime").print_stats(32)
     b1, j1 = workers()
     n = len(batches)
+    print("  dropping (jobs, descs, cdescs, mfgs, out_all, stats ring) us/step:", [round(1e6 * d / n, 2) for d in DROP[:6]])
+    for k in range(8): DROP[k] = 0.0
     st = (C.c_double * 8)(); lib.gf_debug_part_host_us(st, 1)
     if st[7]:
         print("  issuing thread per sample us: begin %.1f plan %.1f a2a-req %.1f serve %.1f a2a-rep %.1f merge %.1f commit %.1f = %.1f" % (
