@@ -274,7 +274,8 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
         # partitioned sampler: a chain carries up to `chain_samples` batches; per lane one
         # chain in flight and half a chain being gathered
         chain = getattr(sampler, "chain_samples", 1)
-        depth = 2 if lanes == 1 else max(3 * lanes, (3 * lanes * chain) // 2)
+        depth = 2 if lanes == 1 and chain == 1 else max(3 * lanes, (3 * lanes * chain) // 2,
+                                                        2 * chain)
     pipe = ReplayPipeline(sampler, cache, ctx.dev_batches, ctx.dev,
                           pipelined=cache is not None and not args.no_pipeline, depth=depth)
 

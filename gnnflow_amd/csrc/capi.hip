@@ -256,6 +256,18 @@ class EnqueueWorker {
 };
 
 }  // namespace
+
+// The enqueue thread that issues EVERYTHING with a collective in it — the partitioned sampler's
+// chains and the pull rounds of sharded features: one thread, one order of collectives over all
+// communicators, the same on every rank.  0 = the fetch lane's thread (default: two issuing
+// threads slow each other down), 1 = the sampling lane's (GNNFLOW_PART_OWN_THREAD=1).
+int collective_lane() {
+  static const int lane = [] {
+    const char* v = std::getenv("GNNFLOW_PART_OWN_THREAD");
+    return (v && std::atoi(v) != 0) ? 1 : 0;
+  }();
+  return lane;
+}
 }  // namespace gf
 
 using gf::guarded;
@@ -593,11 +605,12 @@ int gf_pull_round(gf_pull_session* s, gf_cache* node_cache, gf_cache* edge_cache
     gf::FeatureCache* nc = node_cache ? &node_cache->impl : nullptr;
     gf::FeatureCache* ec = edge_cache ? &edge_cache->impl : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const uint64_t t = gf::EnqueueWorker::get(0).submit([=]() {
+    gf::EnqueueWorker& w = gf::EnqueueWorker::get(gf::collective_lane());
+    const uint64_t t = w.submit([=]() {
       impl->round(nc, ec, ctxs, n, flag, any_flag, rows_pulled, bytes_sent, d_error_flag, st);
     });
     std::string err;
-    const int rc = gf::EnqueueWorker::get(0).wait(t, &err);
+    const int rc = w.wait(t, &err);
     if (rc != GF_OK) gf::set_last_error(err);
     return rc;
   }
@@ -947,10 +960,7 @@ int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c, const in
     // step 53 vs 72-84 us), so the chains share the fetch lane's thread.  It also keeps ONE
     // global order of everything that is enqueued, on every rank.  GNNFLOW_PART_OWN_THREAD=1:
     // the sampling lane's own thread.
-    static const int lane = [] {
-      const char* v = std::getenv("GNNFLOW_PART_OWN_THREAD");
-      return (v && std::atoi(v) != 0) ? 1 : 0;
-    }();
+    const int lane = gf::collective_lane();
     const uint64_t mark = lane == 0 ? (1ull << 63) : 0;
     s->begin_tickets.push_back(mark | gf::EnqueueWorker::get(lane).submit(
         [impl, comm, d_roots, d_root_ts, num_roots, d_out, out_bytes, d_ws, ws_bytes, slack,
@@ -1019,10 +1029,7 @@ int gf_sampler_sample_partitioned_comm_group_async(gf_comm* c, const gf_group_sa
                  "sample_partitioned_comm_group_async: too many samples in flight on a sampler");
     gf::Exchange* comm = &c->impl;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const int lane = [] {
-      const char* v = std::getenv("GNNFLOW_PART_OWN_THREAD");
-      return (v && std::atoi(v) != 0) ? 1 : 0;
-    }();
+    const int lane = gf::collective_lane();
     const uint64_t mark = lane == 0 ? (1ull << 63) : 0;
     // ONE job for all samples of the group: every sampler's ticket is this job's
     const uint64_t t = mark | gf::EnqueueWorker::get(lane).submit(

@@ -159,7 +159,7 @@ def test_four_ranks_sharing_the_gpu_finish_the_hash_loop():
 
 def test_two_ranks_native_chains_over_the_ipc_transport():
     """The closest a one-GPU box gets to the driver's multi-GPU run: bench.py's own launcher, two
-    rank processes, and the NATIVE partitioned chains (sampling lanes, two samples per chain,
+    rank processes, and the NATIVE partitioned chains (sampling lanes, up to four samples per chain,
     issued by the enqueue thread) with every message real — carried by the library's hipIpc
     transport instead of RCCL, which refuses ranks that share a GPU."""
     d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5",
@@ -168,5 +168,6 @@ def test_two_ranks_native_chains_over_the_ipc_transport():
                   "GNNFLOW_PART_TRANSPORT": "ipc"})
     _check_common(d, 2, 20, 5)
     assert d["config"]["parallelism"] == "hash-dp2"
-    assert "hipIpc" in d["config"]["exchange"] and "two samples each" in d["config"]["exchange"]
+    assert "hipIpc" in d["config"]["exchange"] and \
+        "samples each on average" in d["config"]["exchange"]
     assert "0 overflowed" in d["config"]["exchange"]
