@@ -113,7 +113,7 @@ def parse(argv=None):
     ap.add_argument("--part-lanes", type=int, default=None,
                     help="sampling lanes of the partitioned sampler: consecutive batches go "
                          "round-robin to lanes with their own stream, workspace and communicator, "
-                         "so their exchange chains overlap (default GNNFLOW_PART_LANES, else 2; 4 from 4 ranks on)")
+                         "so their exchange chains overlap (default GNNFLOW_PART_LANES, else 2; 3 from 4 ranks on)")
     ap.add_argument("--part-chain", type=int, default=None,
                     help="consecutive batches that share one chain of the partitioned sampler "
                          "(launches and exchanges): 1..4, default GNNFLOW_PART_CHAIN, else 4")

@@ -574,7 +574,7 @@ class DevicePartitionedSampler:
         cost far more than the ~6 us own-share kernel they hide (one rank over RCCL, every
         message empty: 268 us per step with them, 116 us with everything in the sampling
         stream; profiles/r03_part_bench_one_gpu.jsonl).
-        lanes: sampling lanes (default GNNFLOW_PART_LANES, else 2 — 4 from 4 ranks on — with
+        lanes: sampling lanes (default GNNFLOW_PART_LANES, else 2 — 3 from 4 ranks on — with
         more than one rank / always_exchange, else 1).  A lane is used only by `sample_async(..., stream=...)` calls
         that name a stream (the pipelined loop); `sample()` always runs on lane 0.
         chain_samples: let up to this many (1..4) consecutive `sample_async(..., stream=...)`
@@ -611,9 +611,10 @@ class DevicePartitionedSampler:
         self._overlap = bool(overlap)
         if lanes is None:
             # 2 lanes hide the chain of one rank over RCCL (measured); with 4 and more ranks the
-            # exchanges are real transfers (a pair's layer-1 replies are ~19 MB per rank at
-            # P = 8), the chain is several times longer, and more of them must be in flight
-            lanes = int(os.environ.get("GNNFLOW_PART_LANES", "4" if self._P >= 4 else "2"))
+            # exchanges are real transfers (the layer-1 replies of a chain of four are ~38 MB
+            # per rank at P = 8), the chain is several times longer, and more of them must be
+            # in flight: a third lane (free on one GPU; a fourth stretched the fetch kernels)
+            lanes = int(os.environ.get("GNNFLOW_PART_LANES", "3" if self._P >= 4 else "2"))
         if (self._P == 1 and not self._always_exchange) or self._slack <= 0:
             # one rank without exchange: lanes were measured and do not pay (50-53 us per step
             # with 1 lane, 54 with 2, 48 with 3: profiles/README.md round 4); the variable-size
