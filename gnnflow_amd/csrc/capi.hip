@@ -988,7 +988,8 @@ namespace {
 // the group's samples as the sampler takes them (checked)
 std::vector<gf::Sampler::GroupSample> group_samples(gf_comm* c, const gf_group_sample* samples,
                                                     int m) {
-  GF_REQUIRE(c != nullptr && samples != nullptr, "null communicator / samples");
+  (void)c;   // null: one rank, nothing to exchange
+  GF_REQUIRE(samples != nullptr, "null samples");
   GF_REQUIRE(m >= 1 && m <= GF_PART_GROUP_MAX, "group: 1..4 samples");
   std::vector<gf::Sampler::GroupSample> gs(m);
   for (int j = 0; j < m; ++j) {
@@ -1010,8 +1011,8 @@ int gf_sampler_sample_partitioned_comm_group(gf_comm* c, const gf_group_sample* 
       GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
                  "sample_partitioned_comm_group: earlier samples were begun through the enqueue thread");
     }
-    gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots, c->impl,
-                                          static_cast<hipStream_t>(stream),
+    gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots,
+                                          c ? &c->impl : nullptr, static_cast<hipStream_t>(stream),
                                           static_cast<unsigned>(force_overflow));
     for (int j = 0; j < m; ++j) samples[j].sampler->begin_tickets.push_back(0);
   });
@@ -1022,20 +1023,21 @@ int gf_sampler_sample_partitioned_comm_group_async(gf_comm* c, const gf_group_sa
                                                    int force_overflow, void* stream) {
   return guarded([&] {
     auto gs = group_samples(c, samples, m);
-    GF_REQUIRE(!c->loopback, "sample_partitioned_comm_group_async: a loopback communicator's ranks "
-                             "are threads (use the synchronous call)");
+    GF_REQUIRE(!c || !c->loopback, "sample_partitioned_comm_group_async: a loopback "
+                                   "communicator's ranks are threads (use the synchronous call)");
     for (int j = 0; j < m; ++j)
       GF_REQUIRE(samples[j].sampler->begin_tickets.size() < gf::Sampler::kMaxInFlight,
                  "sample_partitioned_comm_group_async: too many samples in flight on a sampler");
-    gf::Exchange* comm = &c->impl;
+    gf::Exchange* comm = c ? &c->impl : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int lane = gf::collective_lane();
+    // no communicator, no collective: the sampling lane's thread, like the plain sampler's
+    const int lane = c ? gf::collective_lane() : 1;
     const uint64_t mark = lane == 0 ? (1ull << 63) : 0;
     // ONE job for all samples of the group: every sampler's ticket is this job's
     const uint64_t t = mark | gf::EnqueueWorker::get(lane).submit(
         [gs = std::move(gs), m, d_ws, ws_bytes, slack, slot_roots, comm, st, force_overflow]() {
           gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots,
-                                                *comm, st, static_cast<unsigned>(force_overflow));
+                                                comm, st, static_cast<unsigned>(force_overflow));
         });
     for (int j = 0; j < m; ++j) samples[j].sampler->begin_tickets.push_back(t);
   });

@@ -2392,7 +2392,7 @@ void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, do
 }
 
 void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
-                                       double slack, size_t slot_roots, Exchange& ex,
+                                       double slack, size_t slot_roots, Exchange* ex,
                                        hipStream_t stream, unsigned force_overflow) {
   GF_REQUIRE(gs != nullptr && m >= 1 && m <= kMaxGroup, "sample_partitioned_group: 1..4 samples");
   Sampler& a = *gs[0].s;
@@ -2412,7 +2412,9 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
   GF_REQUIRE(a.group_ok(Rin, m), "sample_partitioned_group: these samples cannot share a chain");
   DeviceGuard dg(a.graph_->device());
   const size_t L = a.fanouts_.size();
-  const int P = ex.world(), me = ex.rank();
+  // ex == null: ONE rank and nothing to exchange (every root is its own): the same chain
+  // without its two all-to-alls and without the inbox job
+  const int P = ex ? ex->world() : 1, me = ex ? ex->rank() : 0;
   using clk = std::chrono::steady_clock;
   auto t_prev = clk::now();
   auto lap = [&](int stage) {
@@ -2469,10 +2471,10 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
       partition_plan_jobs(pj, m, bound, P, me, stride, a.graph_->device(), stream);
       lap(1);
       // 2. every sample's request slots out
-      ex.all_to_all(requests, base + lay.inbox, static_cast<size_t>(m) * stride * 16, stream);
+      if (ex) ex->all_to_all(requests, base + lay.inbox, static_cast<size_t>(m) * stride * 16, stream);
       lap(2);
       // 3. the received slots (of all samples, served alike) and the own shares
-      const uint64_t n_inbox = lay.slot_rows;
+      const uint64_t n_inbox = ex ? lay.slot_rows : 0;
       const size_t n_max = std::max<size_t>(n_inbox, bound);
       // group width by the roots there really are (<= the layer's bound per sample), not by the
       // slot rows, most of which are empty: a latency chain wants the 16-lane search
@@ -2513,7 +2515,7 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
       }
       lap(3);
       // 4. the replies back
-      ex.all_to_all(base + lay.served, replies, static_cast<size_t>(m) * stride * F * 24, stream);
+      if (ex) ex->all_to_all(base + lay.served, replies, static_cast<size_t>(m) * stride * F * 24, stream);
       lap(4);
       // 5. all merges
       MergeJobs mj;

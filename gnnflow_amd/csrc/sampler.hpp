@@ -95,7 +95,7 @@ class Sampler {
   static size_t group_ws_bytes(const Sampler& a, const size_t* R, int m, int world, double slack,
                                size_t slot_roots);
   static void sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
-                                       double slack, size_t slot_roots, Exchange& ex,
+                                       double slack, size_t slot_roots, Exchange* ex,
                                        hipStream_t stream, unsigned force_overflow = 0);
   void sample_partitioned(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                           size_t out_bytes, void* d_ws, size_t ws_bytes, hipStream_t stream);

@@ -492,8 +492,8 @@ class _PartitionedPending:
                     q = smp._inflight
                     while q:
                         q[0].wait()
-                mfgs = own._sample_variable(self._lane, self._smp, self._nodes, self._ts,
-                                            self._stream).wait()
+                mfgs = own._redo(self._lane, self._smp, self._nodes, self._ts,
+                                 self._stream).wait()
             self._result = mfgs
             self._nodes = self._ts = None
             self._pending = self._lane = self._smp = self._owner = None
@@ -628,8 +628,11 @@ class DevicePartitionedSampler:
         if chain_samples is None:
             chain_samples = int(os.environ.get("GNNFLOW_PART_CHAIN", "4"))
         chain = max(1, min(int(chain_samples), _capi.GF_PART_GROUP_MAX)) if pair else 1
-        if not (self._slack > 0 and self._S == 1) or (self._P == 1 and not self._always_exchange):
+        if not (self._slack > 0 and self._S == 1):
             chain = 1
+        # one rank and nothing to exchange: the shared chain without its all-to-alls (the
+        # native call takes no communicator)
+        self._solo = self._P == 1 and not self._always_exchange
         self.chain_samples = chain
         self._lanes = [_Lane(sampler, comms[0] if comms else None, chain - 1)]
         for k in range(1, lanes):
@@ -772,16 +775,19 @@ class DevicePartitionedSampler:
             smp = p._smp
             if len(smp._inflight) >= smp._max_inflight:
                 smp._inflight[0].wait()
+        solo = self._solo
         if len(held) == 1:
             p = held[0]
-            p._attach(self._sample_slotted(lane, p._smp, p._nodes, p._ts, stream, worker_enqueue))
+            p._attach(self._sample_one_rank(lane, p._nodes, p._ts, stream, worker_enqueue, p._smp)
+                      if solo else
+                      self._sample_slotted(lane, p._smp, p._nodes, p._ts, stream, worker_enqueue))
             return
         C, lib, check = self._C, self._lib, self._capi.check
         m = len(held)
         Rs = [int(p._nodes.shape[0]) for p in held]
         if not self._slot_roots:
             self._slot_roots = self._agree_on_slot_roots(max(Rs + [1]))
-        comm = self._ensure_comm(lane)
+        comm = None if solo else self._ensure_comm(lane)
         ws_bytes = 0
 
         def group_bytes(roots):
@@ -796,7 +802,7 @@ class DevicePartitionedSampler:
                 n = self._layouts[key] = out.value
             return n
         force = 0
-        if comm is not None:
+        if comm is not None or solo:
             # Whether samples share a chain is part of the PROTOCOL (their slots travel in one
             # exchange): every rank must decide alike, so the decision follows from the batch
             # size all ranks agreed on (slot_roots), not from this rank's own batches.
@@ -814,13 +820,15 @@ class DevicePartitionedSampler:
                 assert ws_bytes, "a chain of fitting samples has a workspace"
         if not ws_bytes:      # no communicator / not chainable: single chains
             for p in held:
-                p._attach(self._sample_slotted(lane, p._smp, p._nodes, p._ts, stream,
+                p._attach(self._sample_one_rank(lane, p._nodes, p._ts, stream, worker_enqueue,
+                                                p._smp) if solo else
+                          self._sample_slotted(lane, p._smp, p._nodes, p._ts, stream,
                                                worker_enqueue))
             return
         outs = [self._output(p._smp, R, stream) for p, R in zip(held, Rs)]
         ws, _ = self._workspace(lane, ws_bytes, stream)
         call = lib.gf_sampler_sample_partitioned_comm_group_async \
-            if (worker_enqueue and comm.transport != "loopback") \
+            if (worker_enqueue and (solo or comm.transport != "loopback")) \
             else lib.gf_sampler_sample_partitioned_comm_group
         desc = (self._capi.GfGroupSample * m)()
         for j, (p, R, (slab, out_ptr, nbytes)) in enumerate(zip(held, Rs, outs)):
@@ -829,8 +837,8 @@ class DevicePartitionedSampler:
             d.d_roots = p._nodes.data_ptr() if R else None
             d.d_root_ts = p._ts.data_ptr() if R else None
             d.num_roots, d.d_out, d.out_bytes = R, out_ptr, nbytes
-        check(call(comm.h, desc, m, ws.data_ptr(), ws_bytes, self._slack, self._slot_roots, force,
-                   outs[0][0][6]))
+        check(call(None if solo else comm.h, desc, m, ws.data_ptr(), ws_bytes, self._slack,
+                   self._slot_roots, force, outs[0][0][6]))
         for p, R, (slab, _, _) in zip(held, Rs, outs):
             p._attach(self._pend(p._smp, slab, (p._nodes, p._ts, ws), R))
         self.pairs += 1
@@ -852,8 +860,14 @@ class DevicePartitionedSampler:
         smp._inflight.append(pending)
         return pending
 
-    def _sample_one_rank(self, lane, nodes, ts, stream, worker_enqueue):
-        lib, smp = self._lib, lane.sampler
+    def _redo(self, lane, smp, nodes, ts, stream):
+        """An overflowed sample again, through the form without slots."""
+        if self._solo:
+            return self._sample_one_rank(lane, nodes, ts, stream, False, smp)
+        return self._sample_variable(lane, smp, nodes, ts, stream)
+
+    def _sample_one_rank(self, lane, nodes, ts, stream, worker_enqueue, smp=None):
+        lib, smp = self._lib, (smp or lane.sampler)
         R = int(nodes.shape[0])
         _, _, ws_bytes = self._plan(max(R, 1))
         slab, out_ptr, nbytes = self._output(smp, R, stream)

@@ -568,8 +568,9 @@ GF_API int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c,
  * j): flag that sample as overflowed whatever its slots hold — for a batch that is too large for
  * this chain although the batch size the ranks agreed on is not, the caller submits an EMPTY
  * stand-in with this bit set, every rank sees the flag in the same exchange and the real batch
- * is sampled in the redo.  No reference counterpart (its RPC futures are per partition and per
- * call, gnnflow/distributed/dist_sampler.py:188-220). */
+ * is sampled in the redo.  c == NULL: ONE rank with nothing to exchange (world size 1, every root
+ * its own) — the same chain without the two all-to-alls.  No reference counterpart (its RPC
+ * futures are per partition and per call, gnnflow/distributed/dist_sampler.py:188-220). */
 #define GF_PART_GROUP_MAX 4
 typedef struct gf_group_sample {
   gf_sampler* sampler;

@@ -387,3 +387,39 @@ def test_fused_merge_granules_survive_recycled_workspaces():
         comm.close()
         gc.collect()
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("chain", [2, 3, 4])
+def test_one_rank_shared_chains_without_exchange(chain):
+    """World size 1, nothing to exchange: consecutive sample_async() calls still share a chain
+    (gf_sampler_sample_partitioned_comm_group with a NULL communicator: plan, own shares, merge,
+    publish — no all-to-all).  Ragged sizes, an empty batch, a batch beyond the agreed size whose
+    layers exceed the shared chain's limit (an empty stand-in with the overflow flag forced, then
+    the redo through the chain without slots), a chain that goes out before it is full."""
+    import torch
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from gnnflow_amd.dist import DevicePartitionedSampler
+    from tests import synth
+    src, dst, ts, eid = _graph()
+    g = DynamicGraph(1 << 20, 64 << 20, "cuda", 8, 64, "insert")
+    g.add_edges(src, dst, ts, eid, add_reverse=True)
+    kw = dict(fanouts=[7, 5], sample_strategy="recent")
+    plain = TemporalSampler(g, **kw)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream()
+    part = DevicePartitionedSampler(TemporalSampler(g, **kw), slot_roots=600, chain_samples=chain)
+    assert part.chain_samples == chain and part.lanes == 1
+    sizes = [600, 97, 0, 1500, 1, 600, 3, 2000, 600, 5000, 5]    # 5000 x 8 > 32 768 roots
+    reqs = [synth.random_roots(400, R, 1000.0, seed=77 + 3 * i + R) for i, R in enumerate(sizes)]
+    for wave in (reqs[:7], reqs[7:]):
+        pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t).to(dev),
+                                  stream=side, worker_enqueue=True) for n, t in wave]
+        for (n, t), p in zip(wave, pend):
+            for gl, wl in zip(p.wait(), plain.sample(n, t)):
+                for gb, wb in zip(gl, wl):
+                    for a, b in ((gb.srcdata["ID"], wb.srcdata["ID"]), (gb.srcdata["ts"], wb.srcdata["ts"]),
+                                 (gb.edata["ID"], wb.edata["ID"]), (gb.edata["dt"], wb.edata["dt"]),
+                                 (gb.edges()[0], wb.edges()[0]), (gb.edges()[1], wb.edges()[1])):
+                        assert torch.equal(a, b), (chain, len(n))
+    assert part.pairs >= 2 and part.chained >= 2 * 2
+    assert part.overflows == 1          # the 5000-root batch, redone without slots
