@@ -138,6 +138,24 @@ def test_failing_hash_loop_falls_back_to_the_replica_figure():
     assert "GNNFLOW_BENCH_FAIL_HASH" in d["hash_partition"]["error"]
 
 
+@pytest.mark.parametrize("who", ["1", "all"])
+def test_hanging_hash_loop_is_replaced_by_fresh_replica_ranks(who):
+    """A collective that some rank never joins does not raise, it HANGS: after
+    GNNFLOW_HASH_MAIN_TIMEOUT every rank starts a fresh process that times the replica loop on a
+    new rendezvous port, and the ONE line says what happened (own launcher and torchrun alike)."""
+    env = {"GNNFLOW_BENCH_DEVICE": "0", "GNNFLOW_BENCH_BACKEND": "gloo",
+           "GNNFLOW_BENCH_HANG_HASH": who, "GNNFLOW_HASH_MAIN_TIMEOUT": "15"}
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--min-replays", "1", "--min-seconds", "0.2"]
+    if who == "all":        # the driver's torchrun form: the agent's store must not be reused
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29577"] + cmd[1:]
+    d = _run(cmd, env=env)
+    _check_common(d, 2, 20, 5)
+    assert d["config"]["parallelism"] == "replica-dp2"
+    assert "did not finish within 15 s" in d["hash_partition"]["error"]
+
+
 def test_a_dying_rank_ends_the_launcher_non_zero_with_one_line():
     d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5"],
              env={"GNNFLOW_BENCH_DEVICE": "7", "GNNFLOW_BENCH_BACKEND": "gloo"}, rc=1)
