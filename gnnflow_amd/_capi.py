@@ -127,6 +127,7 @@ PROTOTYPES = {
     "gf_graph_num_vertices": (C.c_int, [_p, C.POINTER(_sz)]),
     "gf_graph_num_source_vertices": (C.c_int, [_p, C.POINTER(_sz)]),
     "gf_graph_num_edges": (C.c_int, [_p, C.POINTER(_sz)]),
+    "gf_graph_ids_fit_u32": (C.c_int, [_p, C.POINTER(C.c_int)]),
     "gf_graph_max_vertex_id": (C.c_int, [_p, C.POINTER(C.c_int64)]),
     "gf_graph_out_degree": (C.c_int, [_p, _p, _sz, _p]),
     "gf_graph_nodes": (C.c_int, [_p, _p, _sz, C.POINTER(_sz)]),
@@ -219,11 +220,12 @@ PROTOTYPES = {
     "gf_sampler_sample_partitioned_comm_async": (C.c_int, [_p, _p, _p, _p, _sz, _p, _sz, _p, _sz,
                                                            C.c_double, _sz, C.c_int, _p]),
     "gf_sampler_part_group_ws_bytes": (C.c_int, [_p, C.POINTER(_sz), C.c_int, C.c_int, C.c_double,
-                                                 _sz, C.POINTER(_sz)]),
+                                                 _sz, C.c_int, C.POINTER(_sz)]),
     "gf_sampler_sample_partitioned_comm_group": (C.c_int, [_p, _p, C.c_int, _p, _sz, C.c_double,
-                                                           _sz, C.c_int, _p]),
+                                                           _sz, C.c_int, C.c_int, _p]),
     "gf_sampler_sample_partitioned_comm_group_async": (C.c_int, [_p, _p, C.c_int, _p, _sz,
-                                                                 C.c_double, _sz, C.c_int, _p]),
+                                                                 C.c_double, _sz, C.c_int, C.c_int,
+                                                                 _p]),
     "gf_block_segment_offsets": (C.c_int, [_p, _sz, _sz, _p, C.c_int, _p]),
     "gf_block_edge_softmax": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, C.c_int, _p]),
     "gf_block_edge_softmax_backward": (C.c_int, [_p, _sz, _sz, _sz, _p, _p, _p, C.c_int, _p]),

@@ -348,6 +348,9 @@ int gf_graph_num_edges(const gf_graph* g, size_t* out) {
 int gf_graph_max_vertex_id(const gf_graph* g, int64_t* out) {
   return guarded([&] { GF_G(g); *out = g->impl.max_node_id(); });
 }
+int gf_graph_ids_fit_u32(const gf_graph* g, int* out) {
+  return guarded([&] { GF_G(g); *out = g->impl.ids_fit_u32() ? 1 : 0; });
+}
 int gf_graph_out_degree(const gf_graph* g, const int64_t* nodes, size_t n, size_t* out) {
   return guarded([&] { GF_G(g); g->impl.out_degree(nodes, n, out); });
 }
@@ -971,7 +974,8 @@ int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c, const in
   });
 }
 int gf_sampler_part_group_ws_bytes(const gf_sampler* s, const size_t* roots, int m, int world_size,
-                                   double slack, size_t slot_roots, size_t* bytes) {
+                                   double slack, size_t slot_roots, int narrow_ids,
+                                   size_t* bytes) {
   return guarded([&] {
     GF_REQUIRE(s != nullptr && roots != nullptr && bytes != nullptr,
                "part_group_ws_bytes: null argument");
@@ -980,7 +984,8 @@ int gf_sampler_part_group_ws_bytes(const gf_sampler* s, const size_t* roots, int
     size_t R[GF_PART_GROUP_MAX];
     for (int j = 0; j < m; ++j) R[j] = std::max<size_t>(roots[j], 1);
     *bytes = (slack > 0.0 && s->impl.group_ok(R, m))
-                 ? gf::Sampler::group_ws_bytes(s->impl, R, m, world_size, slack, slot_roots)
+                 ? gf::Sampler::group_ws_bytes(s->impl, R, m, world_size, slack, slot_roots,
+                                               narrow_ids != 0)
                  : 0;
   });
 }
@@ -1003,7 +1008,8 @@ std::vector<gf::Sampler::GroupSample> group_samples(gf_comm* c, const gf_group_s
 }  // namespace
 int gf_sampler_sample_partitioned_comm_group(gf_comm* c, const gf_group_sample* samples, int m,
                                              void* d_ws, size_t ws_bytes, double slack,
-                                             size_t slot_roots, int force_overflow, void* stream) {
+                                             size_t slot_roots, int force_overflow,
+                                             int narrow_ids, void* stream) {
   return guarded([&] {
     const auto gs = group_samples(c, samples, m);
     for (int j = 0; j < m; ++j) {
@@ -1013,14 +1019,15 @@ int gf_sampler_sample_partitioned_comm_group(gf_comm* c, const gf_group_sample* 
     }
     gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots,
                                           c ? &c->impl : nullptr, static_cast<hipStream_t>(stream),
-                                          static_cast<unsigned>(force_overflow));
+                                          static_cast<unsigned>(force_overflow), narrow_ids != 0);
     for (int j = 0; j < m; ++j) samples[j].sampler->begin_tickets.push_back(0);
   });
 }
 int gf_sampler_sample_partitioned_comm_group_async(gf_comm* c, const gf_group_sample* samples,
                                                    int m, void* d_ws, size_t ws_bytes,
                                                    double slack, size_t slot_roots,
-                                                   int force_overflow, void* stream) {
+                                                   int force_overflow, int narrow_ids,
+                                                   void* stream) {
   return guarded([&] {
     auto gs = group_samples(c, samples, m);
     GF_REQUIRE(!c || !c->loopback, "sample_partitioned_comm_group_async: a loopback "
@@ -1035,9 +1042,11 @@ int gf_sampler_sample_partitioned_comm_group_async(gf_comm* c, const gf_group_sa
     const uint64_t mark = lane == 0 ? (1ull << 63) : 0;
     // ONE job for all samples of the group: every sampler's ticket is this job's
     const uint64_t t = mark | gf::EnqueueWorker::get(lane).submit(
-        [gs = std::move(gs), m, d_ws, ws_bytes, slack, slot_roots, comm, st, force_overflow]() {
+        [gs = std::move(gs), m, d_ws, ws_bytes, slack, slot_roots, comm, st, force_overflow,
+         narrow_ids]() {
           gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots,
-                                                comm, st, static_cast<unsigned>(force_overflow));
+                                                comm, st, static_cast<unsigned>(force_overflow),
+                                                narrow_ids != 0);
         });
     for (int j = 0; j < m; ++j) samples[j].sampler->begin_tickets.push_back(t);
   });

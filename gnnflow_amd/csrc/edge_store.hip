@@ -395,23 +395,27 @@ LogicalBlock EdgeStore::new_block(size_t size, BlockDelta* delta) {
 // batch's largest id; ids they do not cover (negative, or far beyond what has been inserted)
 // go through a hash map.
 void EdgeStore::bump_eids(const int64_t* eids, size_t n) {
-  int64_t mx = -1;
+  int64_t mx = -1, mn = 0;
   bool consecutive = n > 0;   // eids[i] == eids[0] + i for the whole batch (a running counter)
   {
     std::mutex mu;
     parallel_for(n, 1 << 16, [&](size_t i0, size_t i1) {
-      int64_t m = -1;
+      int64_t m = -1, lo = 0;
       bool run = true;
       const int64_t base = eids[0] - 0;
       for (size_t i = i0; i < i1; ++i) {
         m = std::max(m, eids[i]);
+        lo = std::min(lo, eids[i]);
         run &= eids[i] == base + static_cast<int64_t>(i);
       }
       std::lock_guard<std::mutex> lk(mu);
       mx = std::max(mx, m);
+      mn = std::min(mn, lo);
       consecutive = consecutive && run;
     });
   }
+  eid_max_ = std::max(eid_max_, mx);
+  eid_min_ = std::min(eid_min_, mn);
   const uint64_t budget = 64 + 8 * (eids_inserted_ + n);   // dense only while reasonably full
   if (mx >= 0 && static_cast<uint64_t>(mx) >= eid_dense_.size() &&
       static_cast<uint64_t>(mx) < budget) {

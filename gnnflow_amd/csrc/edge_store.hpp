@@ -230,6 +230,11 @@ class EdgeStore {
   size_t num_src_nodes() const { return num_src_nodes_; }
   size_t num_edges() const { return num_live_eids_; }
   int64_t max_node_id() const { return static_cast<int64_t>(max_node_id_); }
+  // every node id and every edge id ever inserted fits an unsigned 32-bit word (0xFFFFFFFF is
+  // kept free): the partitioned sampler's shared chains may then use 12-byte reply slots
+  bool ids_fit_u32() const {
+    return max_node_id_ < 0xFFFFFFFFull && eid_min_ >= 0 && eid_max_ < 0xFFFFFFFFll;
+  }
   void out_degree(const int64_t* nodes, size_t n, size_t* out) const;
   size_t nodes(int64_t* out, size_t cap, bool src_only) const;
   size_t edges(int64_t* out, size_t cap) const;
@@ -295,6 +300,7 @@ class EdgeStore {
   ZeroedU32 eid_dense_;
   std::unordered_map<int64_t, uint64_t> eid_sparse_;
   size_t num_live_eids_ = 0;
+  int64_t eid_min_ = 0, eid_max_ = -1;   // over every edge id ever inserted
   uint64_t eids_inserted_ = 0;
   std::vector<std::vector<uint64_t>> free_lists_;  // by log2(capacity)
   size_t logical_bytes_ = 0;    // TemporalBlockAllocator::allocated_

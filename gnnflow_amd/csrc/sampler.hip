@@ -751,6 +751,11 @@ struct PaddedCommon {
   uint32_t fanout;
   int uniform, prop_time;
   uint64_t seed;
+  // reply slots of 12 B {dst, eid, edge time as u32 / u32 / f32 bits; dst 0xFFFFFFFF = empty}
+  // instead of 24 B {dst, eid, (out time, dt)}: the shared chains of graphs whose node and edge
+  // ids fit 32 bits (half the bytes on the wire; dt and the out time are recomputed from the
+  // root's time by the merge)
+  int narrow = 0;
 };
 struct PaddedJob {
   const int64_t* req;
@@ -788,12 +793,14 @@ __device__ inline void padded_job(const GraphView& g, const PaddedCommon& c, Pad
   const uint32_t* __restrict__ root_of = j.root_of;
   uint64_t n = j.n;
   const uint32_t fanout = c.fanout, stride = j.stride;
+  uint32_t* __restrict__ out32 = reinterpret_cast<uint32_t*>(j.out);
   if (j.d_own) {
     n = *j.d_own;
     const uint64_t skip = stride ? (j.own_skip ? j.own_skip : static_cast<uint64_t>(j.world) * stride)
                                  : (j.d_total ? *j.d_total : j.total_host) - n;
     req += 2 * skip;
-    out += skip * fanout * 3;
+    if (c.narrow) out32 += skip * fanout * 3;   // rows of fanout x 12 B
+    else out += skip * fanout * 3;              // rows of fanout x 24 B
     if (root_of) root_of += skip;
   }
   constexpr int kGroupsPerBlock = kSearchThreads / GROUP;
@@ -832,6 +839,21 @@ __device__ inline void padded_job(const GraphView& g, const PaddedCommon& c, Pad
     if (j.rec_cnt && lane == 0) j.rec_cnt[root_of[r]] = valid;
     for (uint32_t k = lane; k < fanout; k += GROUP) {
       const uint64_t slot = r * fanout + k;
+      if (c.narrow) {
+        uint32_t* o = out32 + slot * 3;
+        if (k < valid) {
+          const uint32_t pick = c.uniform ? gf_philox4x32_10_first(c.seed, slot, j.call) % n_cand : k;
+          const EdgePair nb = g.nbr_pool[end_off - 1 - pick];
+          o[0] = static_cast<uint32_t>(nb.dst);
+          o[1] = static_cast<uint32_t>(nb.eid);
+          o[2] = __float_as_uint(nb.ts);
+        } else {
+          o[0] = 0xFFFFFFFFu;
+          o[1] = 0xFFFFFFFFu;
+          o[2] = 0xFFFFFFFFu;
+        }
+        continue;
+      }
       int64_t* o = out + slot * 3;
       if (k < valid) {
         const uint32_t pick = c.uniform ? gf_philox4x32_10_first(c.seed, slot, j.call) % n_cand : k;
@@ -1126,7 +1148,10 @@ __device__ inline void merge_slots_fused_body(
     uint32_t slot_rows, uint64_t* granules, uint64_t tag, uint32_t* d_overflow,
     int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
     int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col,
-    uint64_t* out_R, uint64_t* out_S, uint64_t* next_R) {
+    uint64_t* out_R, uint64_t* out_S, uint64_t* next_R, int narrow = 0) {
+  // narrow: 0 = 24 B reply slots; 1 = 12 B slots {dst, eid, edge time}, the out time is the
+  // edge's; 2 = 12 B slots, the out time is the root's (prop_time)
+  const uint32_t* __restrict__ rep32 = reinterpret_cast<const uint32_t*>(rep);
   __shared__ uint32_t wave_cnt[kEmitThreads / 64];
   __shared__ uint32_t red[kEmitThreads / 64];
   const uint64_t R = d_R ? *d_R : R_host;
@@ -1152,12 +1177,24 @@ __device__ inline void merge_slots_fused_body(
     const uint32_t j = static_cast<uint32_t>(t - static_cast<uint64_t>(r) * fanout);
     const uint32_t p = pos[r];
     if (!(p < slot_rows && p % stride == 0)) {
-      const int64_t* s = rep + (static_cast<uint64_t>(p) * fanout + j) * 3;
-      s0 = s[0];
-      valid = s0 >= 0;
-      if (valid) {
-        s1 = s[1];
-        packed = static_cast<uint64_t>(s[2]);
+      if (narrow) {
+        const uint32_t* s = rep32 + (static_cast<uint64_t>(p) * fanout + j) * 3;
+        const uint32_t d = s[0];
+        valid = d != 0xFFFFFFFFu;
+        if (valid) {
+          s0 = static_cast<int64_t>(d);
+          s1 = static_cast<int64_t>(s[1]);
+          const float t = root_ts[r], ets = __uint_as_float(s[2]);
+          packed = static_cast<uint64_t>(pack_f32_pair(narrow == 2 ? t : ets, t - ets));
+        }
+      } else {
+        const int64_t* s = rep + (static_cast<uint64_t>(p) * fanout + j) * 3;
+        s0 = s[0];
+        valid = s0 >= 0;
+        if (valid) {
+          s1 = s[1];
+          packed = static_cast<uint64_t>(s[2]);
+        }
       }
     }
   }
@@ -1196,8 +1233,10 @@ __device__ inline void merge_slots_fused_body(
           const uint32_t ru = static_cast<uint32_t>(u / fanout);
           const uint32_t ju = static_cast<uint32_t>(u - static_cast<uint64_t>(ru) * fanout);
           const uint32_t pu = pos[ru];
-          if (!(pu < slot_rows && pu % stride == 0))
-            cnt += rep[(static_cast<uint64_t>(pu) * fanout + ju) * 3] >= 0 ? 1u : 0u;
+          if (!(pu < slot_rows && pu % stride == 0)) {
+            const uint64_t at = (static_cast<uint64_t>(pu) * fanout + ju) * 3;
+            cnt += (narrow ? rep32[at] != 0xFFFFFFFFu : rep[at] >= 0) ? 1u : 0u;
+          }
         }
         g = cnt;
         atomicAdd(&g_merge_recounts, 1u);   // diagnostics (gf_debug_merge_recounts)
@@ -1252,11 +1291,11 @@ __global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_kernel(
 // m <= 4 samples that shared their exchange (blockIdx.y picks the job; each has its own granules)
 struct MergeJobs { MergeJob j[4]; };
 __global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_group_kernel(
-    MergeJobs jobs, uint32_t fanout, uint32_t stride) {
+    MergeJobs jobs, uint32_t fanout, uint32_t stride, int narrow) {
   const MergeJob& j = jobs.j[blockIdx.y];
   merge_slots_fused_body(j.roots, j.root_ts, j.d_R, j.R_host, fanout, j.rep, j.pos, stride,
                          j.slot_rows, j.granules, j.tag, j.d_overflow, j.all_nodes, j.all_ts, j.dt,
-                         j.eids, j.row, j.col, j.out_R, j.out_S, j.next_R);
+                         j.eids, j.row, j.col, j.out_R, j.out_S, j.next_R, narrow);
 }
 
 inline unsigned capped_grid(uint64_t work_items, unsigned per_block, unsigned cap) {
@@ -2343,11 +2382,11 @@ void part_host_us(double out[8], bool reset) {
 // fanout <= 256).  Layout of the shared workspace of layer l, rows of 16 B (requests) and
 // fanout x 24 B (replies):  [m P slots of `stride` rows | own share 0 | ... | own share m-1].
 size_t Sampler::group_ws_bytes(const Sampler& a, const size_t* R, int m, int world, double slack,
-                               size_t slot_roots) {
+                               size_t slot_roots, bool narrow) {
   size_t total = 0;
   for (size_t l = 0; l < a.fanouts_.size(); ++l) {
     GroupLayout lay;
-    a.group_layout(R, m, static_cast<uint32_t>(l), world, slack, slot_roots, &lay);
+    a.group_layout(R, m, static_cast<uint32_t>(l), world, slack, slot_roots, narrow, &lay);
     total += lay.total;
   }
   return total;
@@ -2366,7 +2405,7 @@ bool Sampler::group_ok(const size_t* R, int m) const {
 }
 
 void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, double slack,
-                           size_t slot_roots, GroupLayout* out) const {
+                           size_t slot_roots, bool narrow, GroupLayout* out) const {
   GF_REQUIRE(m >= 1 && m <= kMaxGroup, "group layout: 1..4 samples");
   gf_part_layout one;
   part_layout(std::max<size_t>(R[0], 1), layer, world, slack, slot_roots, &one);   // slot stride
@@ -2382,10 +2421,11 @@ void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, do
   out->stride = one.slot_stride;
   out->slot_rows = slot_rows;
   size_t at = 0;
+  const size_t rb = narrow ? 12 : 24;   // bytes per reply slot
   out->requests = at; at = align_up(at + rows * 16, 256);
-  out->replies = at;  at = align_up(at + rows * F * 24, 256);
+  out->replies = at;  at = align_up(at + rows * F * rb, 256);
   out->inbox = at;    at = align_up(at + slot_rows * 16, 256);
-  out->served = at;   at = align_up(at + slot_rows * F * 24, 256);
+  out->served = at;   at = align_up(at + slot_rows * F * rb, 256);
   for (int j = 0; j < m; ++j) { out->counts[j] = at; at = align_up(at + static_cast<size_t>(world) * 8, 256); }
   for (int j = 0; j < m; ++j) { out->pos[j] = at; at = align_up(at + bound[j] * 4, 256); }
   out->total = at;
@@ -2393,7 +2433,7 @@ void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, do
 
 void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
                                        double slack, size_t slot_roots, Exchange* ex,
-                                       hipStream_t stream, unsigned force_overflow) {
+                                       hipStream_t stream, unsigned force_overflow, bool narrow) {
   GF_REQUIRE(gs != nullptr && m >= 1 && m <= kMaxGroup, "sample_partitioned_group: 1..4 samples");
   Sampler& a = *gs[0].s;
   size_t Rin[kMaxGroup];
@@ -2444,8 +2484,9 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
     for (int j = 0; j < m; ++j) Rs[j] = gs[j].s->part_.Rs;
     for (size_t l = 0; l < L; ++l) {
       GroupLayout lay;
-      a.group_layout(Rs, m, static_cast<uint32_t>(l), P, slack, slot_roots, &lay);
+      a.group_layout(Rs, m, static_cast<uint32_t>(l), P, slack, slot_roots, narrow, &lay);
       GF_REQUIRE(off + lay.total <= ws_bytes, "sample_partitioned_group: workspace too small");
+      const size_t rb = narrow ? 12 : 24;
       char* base = w + off;
       const uint32_t F = a.fanouts_[l], stride = static_cast<uint32_t>(lay.stride);
       int64_t* requests = reinterpret_cast<int64_t*>(base + lay.requests);
@@ -2493,7 +2534,7 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
       const int width = static_cast<size_t>(m) * bound > chain_small ? chain_width : a.search_group_;
       const unsigned grid = capped_grid(n_max, kSearchThreads / width, 256 * 8);
       const PaddedCommon pc{0, 1, a.window_, F, a.policy_ == GF_SAMPLING_POLICY_UNIFORM ? 1 : 0,
-                            a.prop_time_ ? 1 : 0, a.seed_};
+                            a.prop_time_ ? 1 : 0, a.seed_, narrow ? 1 : 0};
       PaddedJobs jobs;
       jobs.j[0] = PaddedJob{reinterpret_cast<const int64_t*>(base + lay.inbox), n_inbox, a.calls_++,
                             reinterpret_cast<int64_t*>(base + lay.served), nullptr, nullptr, 0,
@@ -2515,7 +2556,7 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
       }
       lap(3);
       // 4. the replies back
-      if (ex) ex->all_to_all(base + lay.served, replies, static_cast<size_t>(m) * stride * F * 24, stream);
+      if (ex) ex->all_to_all(base + lay.served, replies, static_cast<size_t>(m) * stride * F * rb, stream);
       lap(4);
       // 5. all merges
       MergeJobs mj;
@@ -2536,7 +2577,8 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
             (static_cast<uint64_t>(std::max<size_t>(bound, 1)) * F + kEmitThreads - 1) /
             kEmitThreads);
         merge_slots_fused_group_kernel<<<dim3(egrid, static_cast<unsigned>(m)), dim3(kEmitThreads),
-                                         0, stream>>>(mj, F, stride);
+                                         0, stream>>>(mj, F, stride,
+                                                      narrow ? (a.prop_time_ ? 2 : 1) : 0);
         GF_HIP(hipGetLastError());
       }
       lap(5);

@@ -90,13 +90,15 @@ class Sampler {
     size_t requests, replies, inbox, served, counts[kMaxGroup], pos[kMaxGroup], total;  // bytes
   };
   bool group_ok(const size_t* R, int m) const;
+  // narrow: 12-byte reply slots (ids that fit 32 bits; sampler.hip PaddedCommon)
   void group_layout(const size_t* R, int m, uint32_t layer, int world, double slack,
-                    size_t slot_roots, GroupLayout* out) const;
+                    size_t slot_roots, bool narrow, GroupLayout* out) const;
   static size_t group_ws_bytes(const Sampler& a, const size_t* R, int m, int world, double slack,
-                               size_t slot_roots);
+                               size_t slot_roots, bool narrow);
   static void sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
                                        double slack, size_t slot_roots, Exchange* ex,
-                                       hipStream_t stream, unsigned force_overflow = 0);
+                                       hipStream_t stream, unsigned force_overflow = 0,
+                                       bool narrow = false);
   void sample_partitioned(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                           size_t out_bytes, void* d_ws, size_t ws_bytes, hipStream_t stream);
   // several ranks, slotted form, the exchanges issued through `ex` (RCCL): the whole chain in

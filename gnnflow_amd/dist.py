@@ -551,7 +551,8 @@ class DevicePartitionedSampler:
     owns, see PartitionedGraph)."""
 
     def __init__(self, sampler, group=None, always_exchange=False, slack=None, slot_roots=None,
-                 comm=None, overlap=None, lanes=None, pair=None, chain_samples=None):
+                 comm=None, overlap=None, lanes=None, pair=None, chain_samples=None,
+                 narrow_ids=None):
         """always_exchange: take the multi-rank path — request / reply exchange, served
         requests, merge — even with one rank (where every message is empty).  For tests: it
         is the only way to run the RCCL branch on a one-GPU box.
@@ -584,7 +585,15 @@ class DevicePartitionedSampler:
         until the chain is full or one of them is waited for (then the chain goes out with
         those held so far).  Default GNNFLOW_PART_CHAIN or 4; needs the library's communicator,
         one snapshot and layers of <= 32 768 roots (else single chains).
-        pair: False = chain_samples 1 (the earlier name of the switch; GNNFLOW_PART_PAIR=0)."""
+        pair: False = chain_samples 1 (the earlier name of the switch; GNNFLOW_PART_PAIR=0).
+        narrow_ids: shared chains carry 12-byte reply slots {destination, edge id, edge time}
+        instead of 24-byte ones — half the bytes of the reply exchange — which needs every node
+        and edge id of every rank's shard in [0, 2^32 - 2].  It is part of the wire format: the
+        same on every rank.  None (default; GNNFLOW_PART_NARROW=0 turns it off): decided once,
+        before the first shared chain, from `graph.ids_fit_u32()` of every rank (one
+        all-reduce; ranks that do not share a torch process group — the loopback transport —
+        stay wide unless told).  Should a shard stop fitting later, its rank flags every sample
+        of its chains as overflowed and all ranks redo them through the wide form."""
         import ctypes as C
         import os
         from . import _capi
@@ -634,6 +643,9 @@ class DevicePartitionedSampler:
         # native call takes no communicator)
         self._solo = self._P == 1 and not self._always_exchange
         self.chain_samples = chain
+        if narrow_ids is None and os.environ.get("GNNFLOW_PART_NARROW", "1") == "0":
+            narrow_ids = False
+        self._narrow = None if narrow_ids is None else bool(narrow_ids)   # None: not decided yet
         self._lanes = [_Lane(sampler, comms[0] if comms else None, chain - 1)]
         for k in range(1, lanes):
             self._lanes.append(_Lane(sampler.clone(), comms[k] if k < len(comms) else None,
@@ -789,6 +801,9 @@ class DevicePartitionedSampler:
             self._slot_roots = self._agree_on_slot_roots(max(Rs + [1]))
         comm = None if solo else self._ensure_comm(lane)
         ws_bytes = 0
+        if self._narrow is None:
+            self._narrow = self._agree_on_narrow_ids(comm)
+        narrow = 1 if self._narrow else 0
 
         def group_bytes(roots):
             key = ("chain",) + tuple(roots)
@@ -797,7 +812,7 @@ class DevicePartitionedSampler:
                 arr = (C.c_size_t * len(roots))(*roots)
                 out = C.c_size_t(0)
                 check(lib.gf_sampler_part_group_ws_bytes(lane.sampler._h, arr, len(roots), self._P,
-                                                         self._slack, self._slot_roots,
+                                                         self._slack, self._slot_roots, narrow,
                                                          C.byref(out)))
                 n = self._layouts[key] = out.value
             return n
@@ -818,6 +833,10 @@ class DevicePartitionedSampler:
                         Rs[j] = 0
                 ws_bytes = group_bytes([max(R, 1) for R in Rs])
                 assert ws_bytes, "a chain of fitting samples has a workspace"
+                if narrow and not self._sampler._graph.ids_fit_u32():
+                    # this rank's shard outgrew the 12-byte slots: the wire format cannot change
+                    # on one rank's say-so, so every sample of the chain is flagged and redone
+                    force = (1 << m) - 1
         if not ws_bytes:      # no communicator / not chainable: single chains
             for p in held:
                 p._attach(self._sample_one_rank(lane, p._nodes, p._ts, stream, worker_enqueue,
@@ -838,7 +857,7 @@ class DevicePartitionedSampler:
             d.d_root_ts = p._ts.data_ptr() if R else None
             d.num_roots, d.d_out, d.out_bytes = R, out_ptr, nbytes
         check(call(None if solo else comm.h, desc, m, ws.data_ptr(), ws_bytes, self._slack,
-                   self._slot_roots, force, outs[0][0][6]))
+                   self._slot_roots, force, narrow, outs[0][0][6]))
         for p, R, (slab, _, _) in zip(held, Rs, outs):
             p._attach(self._pend(p._smp, slab, (p._nodes, p._ts, ws), R))
         self.pairs += 1
@@ -959,6 +978,19 @@ class DevicePartitionedSampler:
                 lib.gf_sampler_part_abort(smp._h)
                 raise
         return self._pend(smp, slab, (nodes, ts, ws), R)
+
+    def _agree_on_narrow_ids(self, comm) -> bool:
+        """12-byte reply slots only if EVERY rank's shard fits them (one all-reduce, once)."""
+        mine = bool(self._sampler._graph.ids_fit_u32())
+        if self._P == 1:
+            return mine
+        if not dist.is_initialized() or (comm is not None and comm.transport == "loopback"):
+            return False          # no way to ask the other ranks: stay wide unless told
+        host = _backend_is_host_only(self._group)
+        t = torch.tensor([1 if mine else 0], dtype=torch.int64,
+                         device="cpu" if host else self._device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self._group)
+        return bool(int(t.item()))
 
     def _agree_on_slot_roots(self, R0: int) -> int:
         if self._P == 1:

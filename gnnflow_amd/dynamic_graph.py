@@ -122,6 +122,13 @@ class DynamicGraph:
     def num_edges(self) -> int:
         return self._size(self._lib.gf_graph_num_edges)
 
+    def ids_fit_u32(self) -> bool:
+        """Every node id and edge id inserted so far is in [0, 2^32 - 2] (the partitioned
+        sampler's shared chains may then use 12-byte reply slots)."""
+        v = C.c_int(0)
+        _capi.check(self._lib.gf_graph_ids_fit_u32(self._h, C.byref(v)))
+        return bool(v.value)
+
     def max_vertex_id(self) -> int:
         v = C.c_int64(0)
         _capi.check(self._lib.gf_graph_max_vertex_id(self._h, C.byref(v)))

@@ -83,6 +83,10 @@ GF_API int gf_graph_num_vertices(const gf_graph* g, size_t* out);
 GF_API int gf_graph_num_source_vertices(const gf_graph* g, size_t* out);
 GF_API int gf_graph_num_edges(const gf_graph* g, size_t* out);
 GF_API int gf_graph_max_vertex_id(const gf_graph* g, int64_t* out);
+/* *out = 1 when every node id and every edge id inserted so far is in [0, 2^32 - 2]: the shared
+ * chains of the partitioned sampler may then carry 12-byte reply slots (narrow_ids below).  No
+ * reference counterpart. */
+GF_API int gf_graph_ids_fit_u32(const gf_graph* g, int* out);
 /* api.cc:56-59 out_degree(list) */
 GF_API int gf_graph_out_degree(const gf_graph* g, const int64_t* nodes, size_t n,
                                size_t* out);
@@ -569,7 +573,12 @@ GF_API int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c,
  * this chain although the batch size the ranks agreed on is not, the caller submits an EMPTY
  * stand-in with this bit set, every rank sees the flag in the same exchange and the real batch
  * is sampled in the redo.  c == NULL: ONE rank with nothing to exchange (world size 1, every root
- * its own) — the same chain without the two all-to-alls.  No reference counterpart (its RPC
+ * its own) — the same chain without the two all-to-alls.  narrow_ids != 0: reply slots of 12
+ * bytes {destination, edge id, edge time} instead of 24 — half the bytes of the reply exchange;
+ * the SAME value on every rank (it is part of the wire format), and only while every rank's
+ * shard satisfies gf_graph_ids_fit_u32 (a rank whose shard stops fitting sets every bit of
+ * force_overflow: all ranks then redo those samples through the wide variable-size form).
+ * No reference counterpart (its RPC
  * futures are per partition and per call, gnnflow/distributed/dist_sampler.py:188-220). */
 #define GF_PART_GROUP_MAX 4
 typedef struct gf_group_sample {
@@ -582,17 +591,19 @@ typedef struct gf_group_sample {
 } gf_group_sample;
 GF_API int gf_sampler_part_group_ws_bytes(const gf_sampler* s, const size_t* roots, int m,
                                           int world_size, double slack, size_t slot_roots,
-                                          size_t* bytes);
+                                          int narrow_ids, size_t* bytes);
 GF_API int gf_sampler_sample_partitioned_comm_group(gf_comm* c, const gf_group_sample* samples,
                                                     int m, void* d_ws, size_t ws_bytes,
                                                     double slack, size_t slot_roots,
-                                                    int force_overflow, void* stream);
+                                                    int force_overflow, int narrow_ids,
+                                                    void* stream);
 /* ... issued by the library's enqueue thread (like gf_sampler_sample_partitioned_comm_async) */
 GF_API int gf_sampler_sample_partitioned_comm_group_async(gf_comm* c,
                                                           const gf_group_sample* samples, int m,
                                                           void* d_ws, size_t ws_bytes,
                                                           double slack, size_t slot_roots,
-                                                          int force_overflow, void* stream);
+                                                          int force_overflow, int narrow_ids,
+                                                          void* stream);
 
 /* ---- message passing on a sampled block ---------------------- */
 /* The DGL calls of the reference's layers on an MFG (gnnflow/models/modules/layers.py:153-159,

@@ -42,6 +42,7 @@ def one(seed, dev):
     prop = bool(rng.randint(0, 2))
     slack = float(rng.choice([2.0, 2.0, 1.0, 0.3, 0.05]))
     chain = int(rng.choice([1, 2, 3, 4, 4]))
+    narrow = bool(rng.randint(0, 2))
     minblk = int(rng.choice([4, 8, 62]))
     src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=seed, tie_levels=int(rng.choice([50, 500, 5000])))
     full = O.OracleGraph(minimum_block_size=minblk)
@@ -71,7 +72,7 @@ def one(seed, dev):
             with torch.cuda.stream(torch.cuda.Stream()):
                 part = DevicePartitionedSampler(TemporalSampler(shards[r], **kw), comm=comms[r],
                                                 slack=slack, slot_roots=slot_roots,
-                                                chain_samples=chain)
+                                                chain_samples=chain, narrow_ids=narrow)
                 side = torch.cuda.Stream()
                 got = []
                 for lo in range(0, n_samples, inflight):
@@ -91,7 +92,7 @@ def one(seed, dev):
     [t.start() for t in th]
     [t.join(timeout=300) for t in th]
     desc = dict(seed=seed, P=P, N=N, E=E, fan=fan, snaps=snaps, window=window, prop=prop, slack=slack,
-                chain=chain, inflight=inflight, slot_roots=slot_roots)
+                chain=chain, narrow=narrow, inflight=inflight, slot_roots=slot_roots)
     if any(t.is_alive() for t in th):
         return "HANG", desc
     if any(err):

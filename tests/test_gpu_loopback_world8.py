@@ -115,7 +115,8 @@ def test_native_slotted_chain_at_world_8_matches_the_oracle(world, slack, first,
 
     def rank_body(r):
         part = DevicePartitionedSampler(TemporalSampler(w["shards"][r], [10, 10], "recent"),
-                                        comm=comms[r], slack=slack, slot_roots=1800)
+                                        comm=comms[r], slack=slack, slot_roots=1800,
+                                        narrow_ids=(slack == 2.0))   # 12-byte reply slots / 24
         assert part._P == P and part._rank == r and part.lanes == 1
         got = []
         # half of the batches one by one, the rest three in flight on a side stream (the redo of
@@ -248,9 +249,10 @@ def test_shared_chains_with_ragged_and_empty_batches(ranks, chain):
              # slots far too small: samples of a pair overflow (each on its own flag), every
              # rank redoes the same ones through the variable-size exchange
              dict(fanouts=[6, 4], num_snapshots=1, snapshot_time_window=0.0, slack=0.05)]
-    for kw in cases:
+    for case, kw in enumerate(cases):
         kw = dict(kw)
         slack = kw.pop("slack", 2.0)
+        kw_narrow = (case + ranks + chain) % 2 == 0     # 12-byte reply slots / 24-byte ones
         comms = NativeComm.loopback(ranks, dev)
         batches = [[synth.random_roots(400, sizes[(it + r) % len(sizes)], 1000.0,
                                        seed=1000 * r + it, extra_ids=[403])
@@ -259,7 +261,8 @@ def test_shared_chains_with_ragged_and_empty_batches(ranks, chain):
         def rank_body(r):
             part = DevicePartitionedSampler(
                 TemporalSampler(shards[r], sample_strategy="recent", **kw), comm=comms[r],
-                slack=slack, slot_roots=max(sizes), chain_samples=chain)
+                slack=slack, slot_roots=max(sizes), chain_samples=chain,
+                narrow_ids=kw_narrow)
             side = torch.cuda.Stream()
             pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t).to(dev),
                                       stream=side, worker_enqueue=True) for n, t in batches[r][:4]]

@@ -389,6 +389,50 @@ def test_fused_merge_granules_survive_recycled_workspaces():
         torch.cuda.empty_cache()
 
 
+def test_narrow_reply_slots_fall_back_when_an_id_outgrows_32_bits():
+    """12-byte reply slots need every id below 2^32 - 1.  A graph that stops fitting (here: one
+    edge id of 2^33) cannot change the wire format on its own rank's say-so: every sample of its
+    chains is flagged as overflowed and redone through the wide form — same MFGs."""
+    import torch
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from gnnflow_amd.dist import DevicePartitionedSampler, NativeComm
+    from tests import synth
+    src, dst, ts, eid = _graph()
+    g = DynamicGraph(1 << 20, 64 << 20, "cuda", 8, 64, "insert")
+    g.add_edges(src, dst, ts, eid, add_reverse=True)
+    assert g.ids_fit_u32()
+    kw = dict(fanouts=[7, 5], sample_strategy="recent")
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream()
+    comm = NativeComm.loopback(1, dev)[0]
+    part = DevicePartitionedSampler(TemporalSampler(g, **kw), comm=comm, always_exchange=True,
+                                    slot_roots=600, chain_samples=4, narrow_ids=True)
+    plain = TemporalSampler(g, **kw)
+    reqs = [synth.random_roots(400, R, 1000.0, seed=5 + R) for R in (600, 97, 300, 600)]
+
+    def run():
+        pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t).to(dev),
+                                  stream=side) for n, t in reqs]
+        for (n, t), p in zip(reqs, pend):
+            for gl, wl in zip(p.wait(), plain.sample(n, t)):
+                for gb, wb in zip(gl, wl):
+                    for a, b in ((gb.srcdata["ID"], wb.srcdata["ID"]), (gb.srcdata["ts"], wb.srcdata["ts"]),
+                                 (gb.edata["ID"], wb.edata["ID"]), (gb.edata["dt"], wb.edata["dt"]),
+                                 (gb.edges()[1], wb.edges()[1])):
+                        assert torch.equal(a, b)
+    run()
+    assert part.overflows == 0 and part.chained == 4
+    # one more edge whose id needs 34 bits, newer than everything: it is sampled
+    g.add_edges(np.array([3]), np.array([5]), np.array([float(ts.max()) + 1.0], np.float32),
+                np.array([1 << 33]))
+    assert not g.ids_fit_u32()
+    reqs[0] = (np.concatenate([reqs[0][0], [3]]),
+               np.concatenate([reqs[0][1], [float(ts.max()) + 2.0]]).astype(np.float32))
+    run()
+    assert part.overflows == 4 and part.chained == 8
+    comm.close()
+
+
 @pytest.mark.parametrize("chain", [2, 3, 4])
 def test_one_rank_shared_chains_without_exchange(chain):
     """World size 1, nothing to exchange: consecutive sample_async() calls still share a chain
@@ -407,7 +451,8 @@ def test_one_rank_shared_chains_without_exchange(chain):
     plain = TemporalSampler(g, **kw)
     dev = torch.device("cuda", 0)
     side = torch.cuda.Stream()
-    part = DevicePartitionedSampler(TemporalSampler(g, **kw), slot_roots=600, chain_samples=chain)
+    part = DevicePartitionedSampler(TemporalSampler(g, **kw), slot_roots=600, chain_samples=chain,
+                                    narrow_ids=(chain != 3))      # 12-byte reply slots / 24
     assert part.chain_samples == chain and part.lanes == 1
     sizes = [600, 97, 0, 1500, 1, 600, 3, 2000, 600, 5000, 5]    # 5000 x 8 > 32 768 roots
     reqs = [synth.random_roots(400, R, 1000.0, seed=77 + 3 * i + R) for i, R in enumerate(sizes)]
