@@ -764,8 +764,9 @@ def exchange_note(sampler, world, backend):
         pass
     if getattr(sampler, "pairs", 0):
         lane_note += "; {} chains carried {:.2f} samples each on average (shared launches " \
-                     "and exchanges)".format(sampler.pairs,
-                                             getattr(sampler, "chained", 0) / sampler.pairs)
+                     "and exchanges), {}-byte reply slots".format(
+                         sampler.pairs, getattr(sampler, "chained", 0) / sampler.pairs,
+                         12 if getattr(sampler, "_narrow", False) else 24)
     comm = getattr(sampler, "_comm", None)
     if getattr(sampler, "_slack", 0) > 0 and comm is not None and comm.transport == "ipc":
         return ("2 equal-split exchanges per layer over the library's hipIpc transport (ranks "
