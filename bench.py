@@ -111,7 +111,8 @@ def parse(argv=None):
                     help="skip the second timed run over the other kind of graph")
     ap.add_argument("--part-slack", type=float, default=None,
                     help="slot capacity factor of the partitioned exchange (0 = variable-size "
-                         "all-to-all-v with one host sync per layer; default 2.0)")
+                         "all-to-all-v with one host sync per layer; default GNNFLOW_PART_SLACK, "
+                         "else 1.2 + 0.1 x ranks: 1.4 / 1.6 / 2.0 at 2 / 4 / 8)")
     ap.add_argument("--part-lanes", type=int, default=None,
                     help="sampling lanes of the partitioned sampler: consecutive batches go "
                          "round-robin to lanes with their own stream, workspace and communicator, "
@@ -254,7 +255,10 @@ def build_leg(ctx, kind, always_exchange=None):
     if kind == "hash":
         # every rank owns a shard; per layer the roots are bucketed by owner, requests and
         # replies travel as equal-split all-to-alls, and the rank's own share is sampled meanwhile
-        sampler = DevicePartitionedSampler(sampler, slack=args.part_slack,
+        slack = args.part_slack
+        if slack is None and ctx.world == 1 and always_exchange:
+            slack = 2.0     # one rank over RCCL prices the chain of an 8-GPU run: its capacity
+        sampler = DevicePartitionedSampler(sampler, slack=slack,
                                            slot_roots=3 * args.batch_size,
                                            always_exchange=always_exchange,
                                            lanes=args.part_lanes,

@@ -556,8 +556,13 @@ class DevicePartitionedSampler:
         """always_exchange: take the multi-rank path — request / reply exchange, served
         requests, merge — even with one rank (where every message is empty).  For tests: it
         is the only way to run the RCCL branch on a one-GPU box.
-        slack: capacity factor of the slotted exchange (default GNNFLOW_PART_SLACK or 2.0);
-        0 = the variable-size exchange.
+        slack: capacity factor of the slotted exchange: a peer's slot holds `slack` x the even
+        share of the layer's worst-case root count.  Default GNNFLOW_PART_SLACK, else
+        1.2 + 0.1 x world size (1.4 at 2 ranks, 1.6 at 4, 2.0 at 8): a node that makes up a share
+        h of a batch's roots sends them all to ONE owner, whose bucket is then 1 + h (P - 1) even
+        shares — the REDDIT-shaped replay needs 1.15 / 1.31 / 1.64 at 2 / 4 / 8 ranks
+        (scripts/slack_needed.py) — and the bytes on the wire are proportional to it.  A slot
+        that overflows anyway costs a redo, never a wrong block.  0 = the variable-size exchange.
         slot_roots: the batch size (roots per sample() call) the slot capacities are derived
         from — the SAME number on every rank, because the slots of an equal-split exchange
         must have the same size everywhere.  None: agreed on by an all-reduce (max) of the
@@ -612,7 +617,8 @@ class DevicePartitionedSampler:
         self._fanouts = list(sampler._fanouts)
         self._L, self._S = sampler._num_layers, sampler._num_snapshots
         if slack is None:
-            slack = float(os.environ.get("GNNFLOW_PART_SLACK", "2.0"))
+            env = os.environ.get("GNNFLOW_PART_SLACK")
+            slack = float(env) if env not in (None, "") else 1.2 + 0.1 * min(self._P, 16)
         self._slack = max(float(slack), 0.0)
         self._slot_roots = int(slot_roots) if slot_roots else 0
         if overlap is None:
