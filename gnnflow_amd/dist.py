@@ -463,6 +463,7 @@ class _PartitionedPending:
 
     def _attach(self, pending):
         self._pending = pending
+        self._epoch = self._owner._slack_epoch     # the slot capacity this chain went out with
         # samples end in the order they were begun, possibly inside a younger sample's wait():
         # the flag is read when THIS sample's native sample_end has just returned
         pending._after_end = self._read_flag
@@ -480,8 +481,9 @@ class _PartitionedPending:
             if self._pending is None:
                 own._issue_held()
             mfgs = self._pending.wait()
+            own._waited += 1
             if self._overflowed:
-                own.overflows += 1
+                own._note_overflow(self._epoch)
                 # the samples begun on this LANE after this one end first (their launches may
                 # still be with the enqueue thread, and they use the lane's communicator; their
                 # results are kept), then the batch is sampled again.  Every rank does this at the same point of its call sequence
@@ -552,7 +554,7 @@ class DevicePartitionedSampler:
 
     def __init__(self, sampler, group=None, always_exchange=False, slack=None, slot_roots=None,
                  comm=None, overlap=None, lanes=None, pair=None, chain_samples=None,
-                 narrow_ids=None):
+                 narrow_ids=None, adapt_slack=None):
         """always_exchange: take the multi-rank path — request / reply exchange, served
         requests, merge — even with one rank (where every message is empty).  For tests: it
         is the only way to run the RCCL branch on a one-GPU box.
@@ -580,6 +582,10 @@ class DevicePartitionedSampler:
         cost far more than the ~6 us own-share kernel they hide (one rank over RCCL, every
         message empty: 268 us per step with them, 116 us with everything in the sampling
         stream; profiles/r03_part_bench_one_gpu.jsonl).
+        adapt_slack: raise the slot capacity by a quarter (up to twice the initial one) when
+        two samples overflow within 64 — every rank sees the same samples overflow, so every
+        rank takes the step at the same sample and the slots keep the same size everywhere.
+        Default: on when `slack` is the default, off when it was given.
         lanes: sampling lanes (default GNNFLOW_PART_LANES, else 2 — 3 from 4 ranks on — with
         more than one rank / always_exchange, else 1).  A lane is used only by `sample_async(..., stream=...)` calls
         that name a stream (the pipelined loop); `sample()` always runs on lane 0.
@@ -619,7 +625,14 @@ class DevicePartitionedSampler:
         if slack is None:
             env = os.environ.get("GNNFLOW_PART_SLACK")
             slack = float(env) if env not in (None, "") else 1.2 + 0.1 * min(self._P, 16)
+            if adapt_slack is None:
+                adapt_slack = env in (None, "")
         self._slack = max(float(slack), 0.0)
+        self._adapt_slack = bool(adapt_slack) and self._slack > 0
+        self._slack_cap = 2.0 * self._slack     # (the ipc test transport's mailbox is sized for it)
+        self._slack_epoch = 0                   # bumps so far
+        self._waited = 0                        # samples completed (the same count on every rank)
+        self._recent_overflows = []             # `_waited` of the overflows of this epoch
         self._slot_roots = int(slot_roots) if slot_roots else 0
         if overlap is None:
             overlap = os.environ.get("GNNFLOW_PART_OVERLAP", "0") != "0"
@@ -648,6 +661,8 @@ class DevicePartitionedSampler:
         # one rank and nothing to exchange: the shared chain without its all-to-alls (the
         # native call takes no communicator)
         self._solo = self._P == 1 and not self._always_exchange
+        if self._solo:
+            self._adapt_slack = False      # no slots in use: only a forced flag "overflows"
         self.chain_samples = chain
         if narrow_ids is None and os.environ.get("GNNFLOW_PART_NARROW", "1") == "0":
             narrow_ids = False
@@ -984,6 +999,24 @@ class DevicePartitionedSampler:
                 lib.gf_sampler_part_abort(smp._h)
                 raise
         return self._pend(smp, slab, (nodes, ts, ws), R)
+
+    def _note_overflow(self, epoch):
+        """A slotted sample has to be redone.  With adapt_slack: two of them within 64 samples
+        (chains that went out before the last step do not count) raise the capacity for the
+        chains issued from now on — deterministically, so on every rank at the same sample."""
+        self.overflows += 1
+        if not self._adapt_slack or epoch != self._slack_epoch or self._slack >= self._slack_cap:
+            return
+        recent = [w for w in self._recent_overflows if self._waited - w < 64] + [self._waited]
+        self._recent_overflows = recent
+        if len(recent) < 2:
+            return
+        self._slack = min(self._slack * 1.25, self._slack_cap)
+        self._slack_epoch += 1
+        self._recent_overflows = []
+        self._layouts = {}
+        for lane in self._lanes:
+            lane.ws_views = [None] * len(lane.ws_views)
 
     def _agree_on_narrow_ids(self, comm) -> bool:
         """12-byte reply slots only if EVERY rank's shard fits them (one all-reduce, once)."""

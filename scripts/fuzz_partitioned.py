@@ -43,6 +43,7 @@ def one(seed, dev):
     slack = float(rng.choice([2.0, 2.0, 1.0, 0.3, 0.05]))
     chain = int(rng.choice([1, 2, 3, 4, 4]))
     narrow = bool(rng.randint(0, 2))
+    adapt = bool(rng.randint(0, 2))
     minblk = int(rng.choice([4, 8, 62]))
     src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=seed, tie_levels=int(rng.choice([50, 500, 5000])))
     full = O.OracleGraph(minimum_block_size=minblk)
@@ -72,7 +73,8 @@ def one(seed, dev):
             with torch.cuda.stream(torch.cuda.Stream()):
                 part = DevicePartitionedSampler(TemporalSampler(shards[r], **kw), comm=comms[r],
                                                 slack=slack, slot_roots=slot_roots,
-                                                chain_samples=chain, narrow_ids=narrow)
+                                                chain_samples=chain, narrow_ids=narrow,
+                                                adapt_slack=adapt)
                 side = torch.cuda.Stream()
                 got = []
                 for lo in range(0, n_samples, inflight):
@@ -84,7 +86,7 @@ def one(seed, dev):
                             ("ID", b.srcdata["ID"]), ("ts", b.srcdata["ts"]), ("eid", b.edata["ID"]),
                             ("dt", b.edata["dt"]), ("row", b.edges()[1]), ("col", b.edges()[0]))}
                             for b in mfg] for mfg in m])
-                res[r] = (got, part.overflows, part.pairs)
+                res[r] = (got, (part.overflows, part._slack_epoch), part.pairs)
         except BaseException as e:   # noqa: BLE001
             import traceback
             err[r] = "{}: {}\n{}".format(type(e).__name__, e, traceback.format_exc()[-800:])
@@ -92,7 +94,7 @@ def one(seed, dev):
     [t.start() for t in th]
     [t.join(timeout=300) for t in th]
     desc = dict(seed=seed, P=P, N=N, E=E, fan=fan, snaps=snaps, window=window, prop=prop, slack=slack,
-                chain=chain, narrow=narrow, inflight=inflight, slot_roots=slot_roots)
+                chain=chain, narrow=narrow, adapt=adapt, inflight=inflight, slot_roots=slot_roots)
     if any(t.is_alive() for t in th):
         return "HANG", desc
     if any(err):
@@ -128,7 +130,7 @@ def main():
             if verdict == "HANG":
                 break
         else:
-            over += desc["overflows"]
+            over += desc["overflows"][0]
             pairs += desc["pairs"]
         if (seed + 1) % 20 == 0:
             print("... {} seeds, {} failures, {} overflowed samples redone, {} shared chains, {:.0f} s"

@@ -291,3 +291,54 @@ def test_shared_chains_with_ragged_and_empty_batches(ranks, chain):
                         assert _same(gb, wb), (ranks, r, kw)
         for c in comms:
             c.close()
+
+
+@pytest.mark.parametrize("ranks", [3, 8])
+def test_slot_capacity_adapts_on_every_rank_at_the_same_sample(ranks):
+    """adapt_slack: two overflowed samples within 64 raise the slot capacity by a quarter for
+    the chains issued from then on.  Every rank sees the same samples overflow, so all take
+    the step at the same sample (else their equal-split exchanges would disagree on the slot
+    size and the MFGs below could not come out right); chains already out with the old
+    capacity may overflow too without counting again."""
+    import torch
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from gnnflow_amd.dist import DevicePartitionedSampler, NativeComm, PartitionedGraph
+    from oracle import oracle as O
+    from tests import synth
+    dev = torch.device("cuda", 0)
+    src, dst, ts, eid = synth.powerlaw_graph(400, 12000, seed=9, tie_levels=500)
+    full = O.OracleGraph(minimum_block_size=8)
+    shards = [DynamicGraph(1 << 20, 64 << 20, "cuda", 8, 64, "insert") for _ in range(ranks)]
+    parts = [PartitionedGraph(s, r, ranks) for r, s in enumerate(shards)]
+    full.add_edges(src, dst, ts, eid, add_reverse=True)
+    for pg in parts:
+        pg.add_edges(src, dst, ts, eid, add_reverse=True)
+    n_samples = 40
+    batches = [[synth.random_roots(400, 600, 1000.0, seed=100 * r + it) for it in range(n_samples)]
+               for r in range(ranks)]
+    comms = NativeComm.loopback(ranks, dev)
+
+    def rank_body(r):
+        part = DevicePartitionedSampler(TemporalSampler(shards[r], [6, 4], "recent"), comm=comms[r],
+                                        slack=0.5, slot_roots=600, adapt_slack=True)
+        side = torch.cuda.Stream()
+        got = []
+        for lo in range(0, n_samples, 6):
+            pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t).to(dev),
+                                      stream=side) for n, t in batches[r][lo:lo + 6]]
+            got += [_to_host(p.wait()) for p in pend]
+        return got, (part.overflows, part._slack, part._slack_epoch)
+
+    res = _run_ranks(rank_body, ranks)
+    ref = O.OracleSampler(full, [6, 4], "recent")
+    state = res[0][1]
+    assert state[0] >= 2 and state[2] >= 1 and 0.5 < state[1] <= 1.0
+    for r in range(ranks):
+        got, st = res[r]
+        assert st == state                      # same overflows, same capacity, same step count
+        for (n, t), mfgs in zip(batches[r], got):
+            for gl, wl in zip(mfgs, ref.sample(n, t)):
+                for gb, wb in zip(gl, wl):
+                    assert _same(gb, wb), (ranks, r)
+    for c in comms:
+        c.close()
