@@ -22,6 +22,8 @@ import torch
 from .. import _capi
 
 _DESC = struct.Struct("iiQQQQ")     # struct gf_fetch_desc: kind, update, d_ids, n, d_out, d_stats
+_current_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
 # asynchronous fetch_feature() submissions that may be with the enqueue thread at a time
 _MAX_QUEUED = max(1, int(os.environ.get("GNNFLOW_FETCH_QUEUED", "4")))
 assert _DESC.size == C.sizeof(_capi.GfFetchDesc)
@@ -403,7 +405,7 @@ class Cache:
             jobs.append((2, t.data_ptr(), int(t.shape[0]), t, self.dim_edge_feat, None, None, None))
         if not jobs:
             return mfgs
-        if torch.cuda.current_device() != dev.index:
+        if _current_device() != dev.index:
             with torch.cuda.device(dev):
                 return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
         return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
@@ -783,17 +785,20 @@ class Cache:
 
     def _submit(self, mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases=()):
         # one output allocation for the whole call; every block's rows start 16-byte aligned
-        offs, total = [], 0
+        offs, total, alg, moved = [], 0, 0, 0
         for job in jobs:
+            n, dim = job[2], job[4]
             offs.append(total)
-            total += (job[2] * job[4] + 3) & ~3
+            total += (n * dim + 3) & ~3
+            alg += n * (8 + 8 * dim)
+            moved += n
         out_all, out_base, out_ptr = self._out_buffer(total)
         stats_pos = self._stats_rows(n_cached)
         stats_ptr = self._stats_ring.data_ptr() + 64 * stats_pos
         nj = len(jobs)
-        self.algorithmic_bytes += sum(job[2] * (8 + 8 * job[4]) for job in jobs)
-        self.rows_moved += sum(job[2] for job in jobs)
-        descs = self._desc_buf(nj)
+        self.algorithmic_bytes += alg
+        self.rows_moved += moved
+        descs, cdescs = self._desc_buf(nj)
         box = [0]     # this submission's ticket, for the thunks below
         pack = _DESC.pack_into
         for i, (kind, ids_ptr, n, _keep, dim, b, which, key) in enumerate(jobs):
@@ -821,12 +826,15 @@ class Cache:
             b.set_lazy("e", "f", prefix_rows)
         node_h = self._node.h if self._node is not None else None
         edge_h = self._edge.h if self._edge is not None else None
-        cdescs = _capi.GfFetchDesc.from_buffer(descs)
         self.num_gather_launches += max(n_node, n_cached - n_node, 1)
         if async_enqueue:
-            ticket = C.c_uint64(0)
-            _capi.check(self._lib.gf_cache_fetch_blocks_async(
-                node_h, edge_h, C.byref(cdescs), nj, self._stream(), C.byref(ticket)))
+            ticket = self.__dict__.get("_ticket_word")
+            if ticket is None:
+                ticket = self._ticket_word = C.c_uint64(0)
+            rc = self._lib.gf_cache_fetch_blocks_async(
+                node_h, edge_h, C.byref(cdescs), nj, self._stream(), C.byref(ticket))
+            if rc:
+                _capi.check(rc)
             box[0] = ticket.value
             # ids / outputs / descriptors must outlive the enqueue
             self._tickets.append((ticket.value, (jobs, descs, cdescs, mfgs, out_all,
@@ -860,13 +868,17 @@ class Cache:
         return slab[0], base, slab[4] + 4 * base
 
     def _desc_buf(self, n):
-        """A fresh descriptor array from a small ring (the previous call's array may still be
-        read by the enqueue thread)."""
-        ring = getattr(self, "_desc_ring", None)
+        """(bytearray, its ctypes view) from a small ring (the native call copies the
+        descriptors before it returns; the ring only saves building the view per call)."""
+        ring = self.__dict__.get("_desc_ring")
         if ring is None:
-            ring = self._desc_ring = [bytearray(_DESC.size * 64) for _ in range(4)]
+            ring = self._desc_ring = []
+            for _ in range(8):      # more than fetches can be queued (_MAX_QUEUED)
+                buf = bytearray(_DESC.size * 64)
+                ring.append((buf, _capi.GfFetchDesc.from_buffer(buf)))
             self._desc_next = 0
         if n > 64:
-            return bytearray(_DESC.size * n)
+            buf = bytearray(_DESC.size * n)
+            return buf, _capi.GfFetchDesc.from_buffer(buf)
         self._desc_next = (self._desc_next + 1) % len(ring)
         return ring[self._desc_next]

@@ -240,12 +240,14 @@ class TemporalSampler:
         calls (switching torch's current stream for a torch.empty costs more host time than a
         batch-600 sampling kernel runs); no per-call tensor is created — the blocks' views are
         cut out of the slab when they are first read."""
-        per_slab = min(16, (32 << 20) // max(nbytes, 1))
+        per_slab = min(16, (256 << 20) // max(nbytes, 1))
         step = (nbytes + 255) & ~255
         if per_slab < 2:
             per_slab, step = 1, nbytes
         slab = self._slab
-        if slab is None or slab[1] != stream or slab[2] != step or slab[3] >= per_slab:
+        # (identity first: torch.cuda.Stream.__ne__ is a Python-level call)
+        if slab is None or (slab[1] is not stream and slab[1] != stream) or slab[2] != step \
+                or slab[3] >= per_slab:
             with torch.cuda.stream(stream):
                 mem = torch.empty(step * per_slab, dtype=torch.uint8, device=self._device)
             # slab[4]: streams already told (record_stream) that they use this allocation
