@@ -777,9 +777,11 @@ class Cache:
     def _id_array(self, b, which):
         """(address, count, keepalive) of a block's id array: straight from the sampler's
         output when the block still has it (no torch view is created), else the tensor."""
-        raw = b.raw_ids(which) if hasattr(b, "raw_ids") else None
+        raw = getattr(b, "_raw", None)      # MFGBlock.raw_ids(), inlined (three calls per step)
         if raw is not None:
-            return raw[0], raw[1], b
+            d = b._srcdata if which == "src" else b._edata
+            if d is None or not dict.__contains__(d, 'ID'):
+                return (raw[1], b._num_src, b) if which == "src" else (raw[4], b._num_edges, b)
         t = self._ids((b.srcdata if which == "src" else b.edata)['ID'])
         return t.data_ptr(), int(t.shape[0]), t
 
@@ -798,7 +800,7 @@ class Cache:
         nj = len(jobs)
         self.algorithmic_bytes += alg
         self.rows_moved += moved
-        descs, cdescs = self._desc_buf(nj)
+        descs, cdescs, cdescs_ref = self._desc_buf(nj)
         box = [0]     # this submission's ticket, for the thunks below
         pack = _DESC.pack_into
         for i, (kind, ids_ptr, n, _keep, dim, b, which, key) in enumerate(jobs):
@@ -828,11 +830,13 @@ class Cache:
         edge_h = self._edge.h if self._edge is not None else None
         self.num_gather_launches += max(n_node, n_cached - n_node, 1)
         if async_enqueue:
-            ticket = self.__dict__.get("_ticket_word")
-            if ticket is None:
-                ticket = self._ticket_word = C.c_uint64(0)
+            word = self.__dict__.get("_ticket_word")
+            if word is None:
+                t = C.c_uint64(0)
+                word = self._ticket_word = (t, C.byref(t))
+            ticket = word[0]
             rc = self._lib.gf_cache_fetch_blocks_async(
-                node_h, edge_h, C.byref(cdescs), nj, self._stream(), C.byref(ticket))
+                node_h, edge_h, cdescs_ref, nj, self._stream(), word[1])
             if rc:
                 _capi.check(rc)
             box[0] = ticket.value
@@ -841,7 +845,7 @@ class Cache:
                                                  self._stats_ring)))
         else:
             _capi.check(self._lib.gf_cache_fetch_blocks(
-                node_h, edge_h, C.byref(cdescs), nj, self._stream()))
+                node_h, edge_h, cdescs_ref, nj, self._stream()))
         self._stats_span = (stats_pos, n_node, n_cached, self._stats_ring, len(aliases))
         return mfgs
 
@@ -868,17 +872,19 @@ class Cache:
         return slab[0], base, slab[4] + 4 * base
 
     def _desc_buf(self, n):
-        """(bytearray, its ctypes view) from a small ring (the native call copies the
+        """(bytearray, its ctypes view, a reference to pass) from a small ring (the native call copies the
         descriptors before it returns; the ring only saves building the view per call)."""
         ring = self.__dict__.get("_desc_ring")
         if ring is None:
             ring = self._desc_ring = []
             for _ in range(8):      # more than fetches can be queued (_MAX_QUEUED)
                 buf = bytearray(_DESC.size * 64)
-                ring.append((buf, _capi.GfFetchDesc.from_buffer(buf)))
+                view = _capi.GfFetchDesc.from_buffer(buf)
+                ring.append((buf, view, C.byref(view)))
             self._desc_next = 0
         if n > 64:
             buf = bytearray(_DESC.size * n)
-            return buf, _capi.GfFetchDesc.from_buffer(buf)
+            view = _capi.GfFetchDesc.from_buffer(buf)
+            return buf, view, C.byref(view)
         self._desc_next = (self._desc_next + 1) % len(ring)
         return ring[self._desc_next]
