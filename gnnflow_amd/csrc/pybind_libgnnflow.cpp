@@ -5,15 +5,21 @@
 // wrappers (gnnflow/dynamic_graph.py, gnnflow/temporal_sampler.py) import and run
 // unmodified.  Compiled with g++ (no HIP code here); links libgnnflow_hip.so.
 //
-// KVStore (api.cc:122-127) belongs to the multi-machine feature store and is out of scope.
+// KVStore (api.cc:122-127, kvstore.h:13-40) is exported as the plain host map it is in the
+// reference (key -> row tensor), so that the import chain gnnflow.cache -> gnnflow.distributed
+// .kvstore (`from libgnnflow import KVStore`, kvstore.py:12) resolves against this module.  The
+// RPC server / client around it stay out of scope; the single-node counterpart of
+// the feature store is gf_pull_round.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/gnnflow_hip.h"
@@ -78,6 +84,41 @@ struct Sampler {
   ~Sampler() { if (h) gf_sampler_destroy(h); }
   Sampler(const Sampler&) = delete;
   Sampler& operator=(const Sampler&) = delete;
+};
+
+// kvstore.h:13-40 / kvstore.cc: key -> row.  The values are torch tensors held as Python
+// objects (this module is compiled without the torch headers): `set` keeps values[i] — a view
+// of the caller's tensor, like the reference's `store_[keys[i]] = values[i]` — and `get`
+// returns the stored rows in key order; a key never set yields None (the reference returns an
+// undefined at::Tensor, which its type caster turns into None) and, like `operator[]`, enters
+// the map.
+struct KVStore {
+  using Key = unsigned int;
+  std::unordered_map<Key, py::object> store;
+  std::mutex mutex;
+
+  void set(const std::vector<Key>& keys, const py::object& values) {
+    py::tuple rows = values.attr("unbind")(0);
+    if (rows.size() < keys.size())
+      throw py::index_error("KVStore.set: fewer rows than keys");
+    std::lock_guard<std::mutex> lock(mutex);
+    for (size_t i = 0; i < keys.size(); ++i) store[keys[i]] = rows[i];
+  }
+  py::list get(const std::vector<Key>& keys) {
+    py::list out;
+    for (Key k : keys) {
+      auto it = store.find(k);
+      if (it == store.end()) it = store.emplace(k, py::none()).first;
+      out.append(it->second);
+    }
+    return out;
+  }
+  void fill_zeros() {
+    for (auto& kv : store)
+      if (!kv.second.is_none()) kv.second.attr("fill_")(0);
+  }
+  // kvstore.h:28-32: only the map itself is counted; sizeof(at::Tensor) is one pointer
+  size_t memory_usage() const { return (sizeof(Key) + sizeof(void*)) * store.size(); }
 };
 
 }  // namespace
@@ -234,4 +275,11 @@ PYBIND11_MODULE(libgnnflow, m) {
              check(rc);
              return r;
            });
+
+  py::class_<KVStore>(m, "KVStore")
+      .def(py::init<>())
+      .def("set", &KVStore::set)
+      .def("get", &KVStore::get)
+      .def("memory_usage", &KVStore::memory_usage)
+      .def("fill_zeros", &KVStore::fill_zeros);
 }

@@ -100,3 +100,75 @@ def test_numpy_types_and_errors():
     r = s._sampler.sample_layer(np.array([0, 1]), np.array([5, 5]), 0, 0)   # int ts, as upstream tests
     assert r.row().dtype == np.int64 and r.delta_timestamps().dtype == np.float32
     assert r.num_dst_nodes() == 2 and r.num_src_nodes() == 5
+
+
+def test_script_shaped_cache_sequence_on_the_swapped_module():
+    """INTEGRATION route 1, in the order scripts/offline_edge_prediction.py:248-300,343-346 runs
+    it: graph + sampler from the native module `libgnnflow`, MFGs wrapped the way
+    gnnflow/temporal_sampler.py:149-165 does (dgl.create_block + from_numpy), mfgs_to_cuda,
+    the cache looked up BY NAME (`caches.__dict__[args.cache]`, :282) with the script's 13
+    positional arguments, init_cache / fetch_feature / reset — rows against feats[ids] —
+    and libgnnflow.KVStore (api.cc:122-127) holding device rows."""
+    import torch
+    import gnnflow_amd.cache as caches
+    from gnnflow_amd import dgl_compat
+    from gnnflow_amd.utils import get_pinned_buffers, mfgs_to_cuda
+    from tests import synth
+    L = _lib()
+    dgl = dgl_compat.install(force=True)
+    N, E, dn, de, B = 400, 9000, 20, 12, 60
+    src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=3, tie_levels=500)
+    g = RefStyleGraph(minimum_block_size=16)
+    for lo in range(0, E, 2000):
+        g.add_edges(src[lo:lo + 2000], dst[lo:lo + 2000], ts[lo:lo + 2000], eid[lo:lo + 2000])
+    fanouts = [5, 5]
+    sampler = L._TemporalSampler(g._dgraph, fanouts, L.SamplingPolicy.RECENT, 1, 0.0, False, 1234)
+    rng = np.random.RandomState(0)
+    node_feats = torch.from_numpy(rng.rand(N, dn).astype(np.float32))
+    edge_feats = torch.from_numpy(rng.rand(E, de).astype(np.float32))
+    device = torch.device("cuda:0")
+    num_nodes, num_edges = g.max_vertex_id() + 1, g.num_edges()          # :248-249
+    pin_n, pin_e = get_pinned_buffers(fanouts, 1, B, dn, de)
+    names = sorted(n for n in caches.__dict__ if not n.startswith("__") and callable(caches.__dict__[n]))
+    assert "LRUCache" in names
+    cache = caches.__dict__["LRUCache"](0.2, 0.2, num_nodes, num_edges, device, node_feats,
+                                        edge_feats, dn, de, pin_n, pin_e, None, False)
+    cache.init_cache()
+    assert cache.get_mem_size() > 0
+    for epoch in range(2):
+        cache.reset()
+        for lo in range(E - 6 * B, E, B):
+            roots = np.concatenate([src[lo:lo + B], dst[lo:lo + B],
+                                    rng.randint(0, N, B)]).astype(np.int64)
+            t = np.tile(ts[lo:lo + B], 3).astype(np.float32)
+            mfgs = []
+            for layer in sampler.sample(roots, t):
+                for r in layer:
+                    b = dgl.create_block((r.col(), r.row()), num_src_nodes=r.num_src_nodes(),
+                                         num_dst_nodes=r.num_dst_nodes())
+                    b.srcdata["ID"] = torch.from_numpy(r.all_nodes())
+                    b.edata["dt"] = torch.from_numpy(r.delta_timestamps())
+                    b.srcdata["ts"] = torch.from_numpy(r.all_timestamps())
+                    b.edata["ID"] = torch.from_numpy(r.eids())
+                    mfgs.append(b)
+            mfgs = list(map(list, zip(*[iter(mfgs)] * 1)))
+            mfgs.reverse()
+            mfgs_to_cuda(mfgs, device)
+            mfgs = cache.fetch_feature(mfgs, eid[lo:lo + B])
+            want_h = node_feats[mfgs[0][0].srcdata["ID"].cpu()]
+            assert torch.equal(mfgs[0][0].srcdata["h"].cpu(), want_h)
+            for layer in mfgs:
+                for b in layer:
+                    assert torch.equal(b.edata["f"].cpu(), edge_feats[b.edata["ID"].cpu()])
+            assert torch.equal(cache.target_edge_features.cpu(),
+                               edge_feats[torch.from_numpy(eid[lo:lo + B])])
+            assert 0.0 <= cache.cache_node_ratio <= 1.0 and 0.0 <= cache.cache_edge_ratio <= 1.0
+    # KVStore over device rows: what KVStoreServer.push / pull do with it (kvstore.py:85,192)
+    kv = L.KVStore()
+    rows = mfgs[0][0].srcdata["h"][:32]
+    keys = list(range(100, 132))
+    kv.set(keys, rows)
+    assert torch.equal(torch.stack(kv.get(keys[::-1])), rows.flip(0))
+    assert kv.memory_usage() == 32 * 12
+    kv.fill_zeros()
+    assert float(torch.stack(kv.get(keys)).abs().sum()) == 0.0

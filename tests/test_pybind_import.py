@@ -33,6 +33,28 @@ def test_surface_matches_api_cc(lib):
               "num_src_nodes", "num_dst_nodes"):
         assert hasattr(lib.SamplingResult, m), m
     assert hasattr(lib._TemporalSampler, "sample") and hasattr(lib._TemporalSampler, "sample_layer")
+    for m in ("set", "get", "memory_usage", "fill_zeros"):     # api.cc:122-127
+        assert hasattr(lib.KVStore, m), m
+
+
+def test_kvstore_is_the_reference_host_map(lib):
+    """kvstore.cc: set keeps values[i] per key (a view, so fill_zeros reaches the caller's
+    tensor), get returns rows in key order, memory_usage counts map entries only."""
+    import torch
+    kv = lib.KVStore()
+    vals = torch.arange(20, dtype=torch.float32).view(5, 4)
+    kv.set([7, 3, 4000000000, 0, 9], vals)
+    got = torch.stack(kv.get([9, 7, 4000000000]))
+    assert torch.equal(got, vals[[4, 0, 2]])
+    kv.set([7], torch.full((1, 4), -1.0))                    # overwrite one key
+    assert torch.equal(kv.get([7])[0], torch.full((4,), -1.0))
+    assert kv.memory_usage() == 5 * 12                        # (sizeof(Key) + sizeof(at::Tensor))
+    kv.fill_zeros()
+    assert float(vals[1:].abs().sum()) == 0.0 and float(torch.stack(kv.get([7, 3])).abs().sum()) == 0.0
+    assert kv.get([12345]) == [None]                          # operator[] default-constructs
+    assert kv.memory_usage() == 6 * 12
+    with pytest.raises(TypeError):
+        kv.set([-1], vals[:1])                                # Key is unsigned int
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/gnnflow"),
@@ -53,3 +75,55 @@ def test_reference_wrappers_import_against_our_module(lib):
     # bad strings are rejected by the reference wrapper before any native call
     with pytest.raises(ValueError):
         mod.DynamicGraph(1, 2, "bogus", 4, 8, "insert")
+
+
+_CHAIN = r"""
+import sys
+sys.dont_write_bytecode = True
+sys.path[:0] = [{csrc!r}, {repo!r}, "/root/reference"]
+import gnnflow_amd.dgl_compat as compat
+compat.install(force=True)
+import libgnnflow
+import gnnflow.cache as caches                       # scripts/offline_edge_prediction.py:20
+import gnnflow.cache.cache, gnnflow.distributed.kvstore as kvs
+from gnnflow.temporal_sampler import TemporalSampler  # :28
+from gnnflow.utils import build_dynamic_graph, mfgs_to_cuda   # :29-32
+from gnnflow.config import get_default_config
+assert kvs.KVStore is libgnnflow.KVStore
+assert gnnflow.cache.cache.KVStoreClient is kvs.KVStoreClient
+names = sorted(n for n in caches.__dict__ if not n.startswith("__") and callable(caches.__dict__[n]))
+assert names == ["FIFOCache", "GNNLabStaticCache", "LFUCache", "LRUCache"], names   # :36-38
+import gnnflow
+assert gnnflow.DynamicGraph.__module__ == "gnnflow.dynamic_graph"
+assert TemporalSampler.__module__ == "gnnflow.temporal_sampler"
+import inspect
+assert inspect.getsourcefile(caches.LRUCache).startswith("/root/reference/")
+# the reference's own server class on top of our KVStore (USE_CPP_KVSTORE=1, kvstore.py:28-41)
+import os, torch
+os.environ["USE_CPP_KVSTORE"] = "1"
+srv = kvs.KVStoreServer.__new__(kvs.KVStoreServer)
+srv._use_cpp_kvstore = True
+srv._node_feat_kvstore, srv._edge_feat_kvstore, srv._memory_kvstore = (libgnnflow.KVStore() for _ in range(3))
+vals = torch.arange(12.).view(4, 3)
+srv._node_feat_kvstore.set([1, 2, 3, 4], vals)
+assert torch.equal(torch.stack(srv._node_feat_kvstore.get([4, 1])), vals[[3, 0]])   # kvstore.py:192
+print("chain ok")
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/gnnflow"),
+                    reason="reference tree only exists in the build container")
+def test_unmodified_import_chain_of_the_training_script(lib):
+    """scripts/offline_edge_prediction.py:20 `import gnnflow.cache as caches` ->
+    gnnflow/cache/cache.py:7 -> gnnflow/distributed/kvstore.py:12 `from libgnnflow import
+    KVStore`, plus gnnflow/temporal_sampler.py and gnnflow/utils.py: the reference's WHOLE
+    package imports against our module (and `dgl_compat` for the dgl names), in a fresh
+    interpreter so nothing of it leaks into this one.  (The script's other imports —
+    GPUtil, and gnnflow/data.py's `torch._six` — fail on this image for reasons that have
+    nothing to do with libgnnflow)"""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _CHAIN.format(csrc=os.path.dirname(lib.__file__), repo=repo)
+    r = subprocess.run([sys.executable, "-B", "-c", code], capture_output=True, text=True,
+                       cwd="/tmp", timeout=300)
+    assert r.returncode == 0 and "chain ok" in r.stdout, r.stdout + r.stderr
