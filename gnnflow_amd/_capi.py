@@ -236,6 +236,7 @@ PROTOTYPES = {
     "gf_block_reduce_max_backward": (C.c_int, [_sz, _p, _sz, _p, _p, _p, _sz, C.c_int, _p]),
     "gf_debug_part_host_us": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "gf_debug_merge_recounts": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "gf_debug_lru_recounts": (C.c_int, [C.POINTER(C.c_uint64)]),
     "gf_profile_enable": (C.c_int, [C.c_int]),
     "gf_profile_reset": (C.c_int, []),
     "gf_profile_get": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -276,6 +276,8 @@ namespace gf {
 // sampler.hip
 void part_host_us(double out[8], bool reset);
 uint64_t merge_recounts();
+// feature_cache.hip
+uint64_t lru_recounts();
 // partition.hip
 size_t partition_scratch_bytes(size_t R, int world_size);
 void partition_plan(const int64_t* d_nodes, const float* d_ts, size_t R, int world_size, int rank,
@@ -1115,6 +1117,12 @@ int gf_debug_merge_recounts(uint64_t* out) {
   return guarded([&] {
     GF_REQUIRE(out != nullptr, "gf_debug_merge_recounts: null output");
     *out = gf::merge_recounts();
+  });
+}
+int gf_debug_lru_recounts(uint64_t* out) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_debug_lru_recounts: null output");
+    *out = gf::lru_recounts();
   });
 }
 int gf_debug_part_host_us(double* out, int reset) {

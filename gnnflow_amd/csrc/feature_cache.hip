@@ -122,7 +122,10 @@ struct Counters {
 constexpr uint32_t kCounterWords = sizeof(Counters) / 4;
 
 // Everything one block fetch needs on the device.  `update` == 0: gather only.
-struct QueueState { uint32_t parity, head, tail, lone_walks; };
+// {parity, flip_tag} form ONE aligned 64-bit word: the fused list update flips the parity with
+// a single store of {new parity, its launch tag}, so a workgroup of the same launch that starts
+// late and reads the word knows from the tag that it already sees the NEW parity.
+struct QueueState { uint32_t parity, flip_tag, head, tail, lone_walks, pad; };
 
 struct Ctx {
   const int64_t* ids;
@@ -182,6 +185,15 @@ struct Ctx {
   uint32_t* v_slot;         // [(v_chunks * kRowTile) + n] candidates per chunk (+ the lone walk's)
   uint32_t* v_pos;          // their queue positions
   uint32_t* v_count;        // [v_chunks + 1]
+  // LRU list form, ONE launch (lru_list_fused_kernel): granules {launch tag, count} per list
+  // tile / per row workgroup, and the front tiles' entries staged with the id they hold
+  int fused;
+  uint32_t fuse_tag;        // unique per launch and cache (never reset), > 0
+  uint32_t fuse_rows;       // block rows per row workgroup (kInstRows or kWide)
+  unsigned long long* g_cnt;   // [kFuseMaxTiles]
+  unsigned long long* g_row;   // [kFuseMaxRowWgs]
+  long long* v_old;         // id held by v_slot's entry
+  long long* v_hold;        // ... by v_pos's (the hit entries)
   uint32_t capacity;
   uint32_t epoch_new;
   int update;
@@ -1005,7 +1017,7 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
                                                               uint32_t list_blocks,
                                                               uint32_t victim_blocks) {
   const Ctx& c = r.c[blockIdx.y];
-  if (!c.update || c.policy != GF_CACHE_LRU) return;
+  if (!c.update || c.policy != GF_CACHE_LRU || c.fused) return;
   const int tid = threadIdx.x;
   __shared__ uint32_t ws[kWide / 64];
   const uint32_t parity = c.qstate->parity;
@@ -1307,7 +1319,7 @@ __device__ inline void copy_installed(const Ctx& c, const uint2* inst, const int
 __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32_t row_blocks,
                                                                  uint32_t list_blocks) {
   const Ctx& c = r.c[blockIdx.y];
-  if (!c.update || c.policy != GF_CACHE_LRU) return;
+  if (!c.update || c.policy != GF_CACHE_LRU || c.fused) return;
   const int tid = threadIdx.x;
   __shared__ uint32_t ws[kWide / 64];
   const uint32_t row_tiles = (c.n + kLruRows - 1) / kLruRows;
@@ -1572,6 +1584,367 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
   if (blockIdx.x == row_blocks && tid == 0) c.qstate->parity = parity ^ 1u;
 }
 
+// ---- LRU list form in ONE launch ----------------------------------------------------------
+// lru_list_scan_kernel + lru_list_install_kernel as one launch: what the second launch read
+// from the first — counts per tile, the victims at the front of the list — travels between
+// workgroups of the SAME launch: counts as 8-byte granules {launch tag, count} (one relaxed
+// agent-scope store; the mechanism of merge_slots_fused_kernel, sampler.hip), the staged
+// victims as write-through (sc1) stores that are drained (s_waitcnt vmcnt(0), workgroup
+// barrier) before the tile's granule is published, and read with sc1 loads only
+// (MI355X_MICROARCH, inter-workgroup visibility, "valid forms": row 1 of the table).
+//
+// Three kinds of workgroups, in this order of blockIdx.x — every wait is for a workgroup with
+// a LOWER index, which was dispatched earlier:
+//  * count  [0, cb)            a tile of kFuseTile list entries: marks read densely (they are
+//                              indexed by list position), hits counted; the tiles that can
+//                              hold one of the block's victims (those below `want` + hit rows)
+//                              stage their not-hit entries packed in list order, each with
+//                              the id it holds (the row role then needs no hop through
+//                              slot_id[]); publishes {tag, #hits}.  Waits for nobody.
+//  * row    [cb, cb + rb)      fuse_rows block rows: representatives of the distinct missed
+//                              ids ranked in the span; publishes {tag, #representatives},
+//                              looks back over the row workgroups before it (global rank m),
+//                              reads every count granule (the m-th entry of not-hit ++ hit
+//                              entries = the victim: tile by binary search in LDS, entry from
+//                              the staging arrays), installs — map / slot_id / row copy.
+//  * write  [cb + rb, …)       a tile of kFuseTile list entries: needs #distinct misses (all
+//                              row granules) and the hits before it (count granules), writes
+//                              the permuted list into the other buffer and qpos[]; the first
+//                              one flips the parity.
+// A poll that has not seen its granule after kFuseSpins tries stops waiting and computes the
+// value itself from the kernel's immutable inputs (marks, list, claims), so termination does
+// not depend on dispatch order (several such launches of different processes sharing the
+// GPU can fill an XCD with waiters: DESIGN 6.1).  The one input that is NOT immutable is the
+// claim map[id] == -(row + 1) of a representative, which the row role overwrites when it
+// installs: a representative therefore first marks slot_of_row[row] = kRepMark (write-through,
+// drained) and a recount reads the claim first, the mark second.
+constexpr uint32_t kFuseTile = kWide;         // list entries per count / write tile
+constexpr uint32_t kFuseMaxTiles = 2048;      // list tiles (LDS prefix arrays): <= 2 M slots
+constexpr uint32_t kFuseMaxRowWgs = 1024;     // row workgroups: <= 1 M block rows
+constexpr uint32_t kFuseSpins = 1u << 12;
+constexpr int32_t kRepMark = -3;              // slot_of_row[]: representative of a missed id
+__device__ unsigned int g_lru_recounts;       // granules a waiter had to recompute itself
+
+#define GF_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ inline bool fuse_poll(const unsigned long long* g, uint32_t tag, uint32_t* value) {
+  for (uint32_t spins = 0; spins < kFuseSpins; ++spins) {
+    const unsigned long long x = __hip_atomic_load(g, GF_RLX_AGENT);
+    if (static_cast<uint32_t>(x >> 32) == tag) {
+      *value = static_cast<uint32_t>(x);
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  atomicAdd(&g_lru_recounts, 1u);
+  return false;
+}
+
+__device__ inline void fuse_publish(unsigned long long* g, uint32_t tag, uint32_t value) {
+  __hip_atomic_store(g, (static_cast<unsigned long long>(tag) << 32) | value, GF_RLX_AGENT);
+}
+
+__device__ inline uint32_t total_hits(const Counters* c) {
+  uint32_t h = 0;
+#pragma unroll
+  for (int i = 0; i < kShards; ++i) h += c->shard[i].hits;
+  return h;
+}
+
+// parity of the list buffer that is current DURING the launch tagged `tag`
+__device__ inline uint32_t fuse_parity(const Ctx& c) {
+  const unsigned long long w = *reinterpret_cast<const unsigned long long*>(c.qstate);
+  const uint32_t parity = static_cast<uint32_t>(w), flip = static_cast<uint32_t>(w >> 32);
+  return (flip == c.fuse_tag ? parity ^ 1u : parity) & 1u;
+}
+
+// hits in list tile t, from the marks (what a count workgroup publishes)
+__device__ inline uint32_t fuse_recount_tile(const Ctx& c, uint32_t t) {
+  uint32_t h = 0;
+  const uint32_t lo = t * kFuseTile, hi = min(lo + kFuseTile, c.capacity);
+  for (uint32_t p = lo; p < hi; ++p) h += c.touched[p] == c.epoch_new ? 1u : 0u;
+  return h;
+}
+
+// representatives among the rows of row workgroup b (what it publishes)
+__device__ inline uint32_t fuse_recount_rows(const Ctx& c, uint32_t b) {
+  uint32_t m = 0;
+  const uint32_t lo = b * c.fuse_rows, hi = min(lo + c.fuse_rows, c.n);
+  for (uint32_t i = lo; i < hi; ++i) {
+    const int64_t id = c.ids[i];
+    if (id < 0 || static_cast<uint64_t>(id) >= c.num_ids) continue;
+    // the claim first, the mark second (see above)
+    const int32_t claim = __hip_atomic_load(&c.map[id], GF_RLX_AGENT);
+    const int32_t sr = __hip_atomic_load(&c.slot_of_row[i], GF_RLX_AGENT);
+    if (sr == kRepMark || (sr == -1 && claim == -static_cast<int32_t>(i + 1))) ++m;
+  }
+  return m;
+}
+
+// the x-th hit (want_hit) / not-hit entry of list tile t, walked serially (fallback of a row
+// thread whose tile never published its staged entries)
+__device__ inline uint32_t fuse_walk_tile(const Ctx& c, const uint32_t* list, uint32_t t,
+                                          uint32_t x, bool want_hit) {
+  const uint32_t lo = t * kFuseTile, hi = min(lo + kFuseTile, c.capacity);
+  uint32_t seen = 0;
+  for (uint32_t p = lo; p < hi; ++p) {
+    const bool hit = c.touched[p] == c.epoch_new;
+    if (hit == want_hit) {
+      if (seen == x) return list[p];
+      ++seen;
+    }
+  }
+  return list[lo];   // unreachable: the prefix said the tile has more than x such entries
+}
+
+__global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t count_blocks,
+                                                               uint32_t row_blocks,
+                                                               uint32_t write_blocks) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (!c.update || c.policy != GF_CACHE_LRU || !c.fused) return;
+  const int tid = threadIdx.x;
+  __shared__ uint32_t ws[kWide / 64];
+  const uint32_t cap = c.capacity, tag = c.fuse_tag;
+  const uint32_t tiles = (cap + kFuseTile - 1) / kFuseTile;
+  const uint32_t row_wgs = (c.n + c.fuse_rows - 1) / c.fuse_rows;
+
+  if (blockIdx.x < count_blocks) {
+    // ---- count role ----
+    bool first = true;
+    uint32_t par = 0, bound = 0;
+    bool stage_hits = false;
+    for (uint32_t t = blockIdx.x; t < tiles; t += count_blocks) {
+      const uint32_t p = t * kFuseTile + tid;
+      const bool in = p < cap;
+      const uint32_t tc = in ? c.touched[p] : 0u;
+      uint32_t sl;
+      if (first) {
+        // both buffers while the parity word is on its way (one dependent hop less)
+        const uint32_t a0 = in ? c.queue[0][p] : 0u;
+        const uint32_t a1 = in ? c.queue[1][p] : 0u;
+        par = fuse_parity(c);
+        const uint32_t missed = total_miss(c.ctr);
+        if (missed == 0) return;   // uniform across the launch
+        const uint32_t hit_rows = total_hits(c.ctr);
+        const uint32_t want = min(missed, cap);
+        // the m-th not-hit entry (m < want) lies below list position want + #hit entries
+        bound = min(cap, want + hit_rows);
+        // victims beyond the not-hit entries: only if misses + hits exceed the capacity
+        stage_hits = static_cast<uint64_t>(want) + hit_rows > cap;
+        sl = par ? a1 : a0;
+        first = false;
+      } else {
+        sl = in ? c.queue[par][p] : 0u;
+      }
+      const bool hit = in && tc == c.epoch_new;
+      const bool stage = t * kFuseTile < bound;
+      long long old = -1;
+      if (stage && in && (!hit || stage_hits)) old = c.slot_id[sl];
+      uint32_t total;
+      const uint32_t hb = wide_excl_scan(hit ? 1u : 0u, ws, &total);
+      if (stage && in) {
+        if (!hit) {
+          const uint32_t at = t * kFuseTile + (tid - hb);
+          __hip_atomic_store(&c.v_slot[at], sl, GF_RLX_AGENT);
+          __hip_atomic_store(&c.v_old[at], old, GF_RLX_AGENT);
+        } else if (stage_hits) {
+          const uint32_t at = t * kFuseTile + hb;
+          __hip_atomic_store(&c.v_pos[at], sl, GF_RLX_AGENT);
+          __hip_atomic_store(&c.v_hold[at], old, GF_RLX_AGENT);
+        }
+      }
+      // every storing wave drains its write-through stores, then the barrier, then ONE lane
+      // publishes
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) fuse_publish(&c.g_cnt[t], tag, total);
+    }
+    return;
+  }
+
+  __shared__ uint32_t s_keep[kFuseMaxTiles + 1], s_hitp[kFuseMaxTiles + 1];
+  __shared__ uint32_t s_direct;
+
+  if (blockIdx.x < count_blocks + row_blocks) {
+    // ---- row role ----
+    const uint32_t b = blockIdx.x - count_blocks;
+    if (b >= row_wgs) return;
+    __shared__ uint2 inst[kWide];        // {slot, row} installed by this workgroup
+    __shared__ int64_t inst_id[kWide];
+    __shared__ uint32_t n_inst;
+    const uint32_t i = b * c.fuse_rows + tid;
+    const bool in = tid < static_cast<int>(c.fuse_rows) && i < c.n;
+    const int32_t sr = in ? c.slot_of_row[i] : -2;
+    const int64_t id = in ? c.ids[i] : 0;
+    const uint32_t par = fuse_parity(c);
+    if (total_miss(c.ctr) == 0) return;   // uniform
+    const bool fm = sr == -1 && c.map[id] == -static_cast<int32_t>(i + 1);
+    if (fm) __hip_atomic_store(&c.slot_of_row[i], kRepMark, GF_RLX_AGENT);
+    uint32_t cnt;
+    const uint32_t rank = wide_excl_scan(fm ? 1u : 0u, ws, &cnt);
+    if (tid == 0) {
+      fuse_publish(&c.g_row[b], tag, cnt);
+      n_inst = 0;
+      s_direct = 0;
+    }
+    // look-back over the row workgroups before this one
+    uint32_t part = 0;
+    for (uint32_t j = tid; j < b; j += kWide) {
+      uint32_t v;
+      if (!fuse_poll(&c.g_row[j], tag, &v)) v = fuse_recount_rows(c, j);
+      part += v;
+    }
+    const uint32_t pm = wide_sum(part, ws);
+    // hits per list tile -> prefix of not-hit / hit entries per tile
+    constexpr uint32_t kPer = kFuseMaxTiles / kWide;
+    uint32_t hv[kPer], run_h = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+      const uint32_t t = tid * kPer + k;
+      hv[k] = 0;
+      if (t < tiles) {
+        if (!fuse_poll(&c.g_cnt[t], tag, &hv[k])) {
+          hv[k] = fuse_recount_tile(c, t);
+          s_direct = 1u;   // its staged entries may never arrive: walk the tiles instead
+        }
+      }
+      run_h += hv[k];
+    }
+    uint32_t th;
+    uint32_t hb = wide_excl_scan(run_h, ws, &th);
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+      const uint32_t t = tid * kPer + k;
+      if (t <= tiles) {
+        s_hitp[t] = hb;
+        s_keep[t] = min(t * kFuseTile, cap) - hb;
+      }
+      hb += hv[k];
+    }
+    __syncthreads();
+    const uint32_t n_kept = cap - th;
+    if (fm) {
+      const uint32_t m = pm + rank;
+      if (m < cap) {   // "we only cache the first self.capacity", lru_cache.py:127-133
+        const bool keep = m < n_kept;
+        const uint32_t x = keep ? m : m - n_kept;
+        const uint32_t* pref = keep ? s_keep : s_hitp;
+        uint32_t lo = 0, hi = tiles;   // largest tile with pref[tile] <= x
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (pref[mid] <= x) lo = mid; else hi = mid;
+        }
+        uint32_t slot;
+        long long old;
+        if (s_direct) {
+          slot = fuse_walk_tile(c, c.queue[par], lo, x - pref[lo], !keep);
+          old = c.slot_id[slot];
+        } else {
+          const uint32_t at = lo * kFuseTile + (x - pref[lo]);
+          slot = __hip_atomic_load(keep ? &c.v_slot[at] : &c.v_pos[at], GF_RLX_AGENT);
+          old = __hip_atomic_load(keep ? &c.v_old[at] : &c.v_hold[at], GF_RLX_AGENT);
+        }
+        // (the mark store above has long been drained by the waits in between)
+        if (old >= 0) c.map[old] = kAbsent;
+        c.slot_id[slot] = id;
+        c.map[id] = static_cast<int32_t>(slot);
+        const uint32_t at = atomicAdd(&n_inst, 1u);
+        inst[at] = make_uint2(slot, i);
+        inst_id[at] = id;
+      } else {
+        c.map[id] = kAbsent;
+      }
+    }
+    __syncthreads();
+    const uint32_t total = n_inst * c.dimv;
+    if (c.vec4) {
+      if (c.fuse_rows > kInstRows) copy_installed<float4, 6>(c, inst, inst_id, n_inst, c.dimv * 4, tid);
+      else copy_installed<float4, 2>(c, inst, inst_id, n_inst, c.dimv * 4, tid);
+    } else if (c.odd4) {
+      if (c.fuse_rows > kInstRows) copy_installed<uf4, 6>(c, inst, inst_id, n_inst, c.dim, tid);
+      else copy_installed<uf4, 2>(c, inst, inst_id, n_inst, c.dim, tid);
+    } else {
+      for (uint32_t f = tid; f < total; f += kWide) {
+        const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
+        const uint2 pr = inst[j];
+        c.cache_buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] =
+            c.inst_from_table ? c.feats[static_cast<uint64_t>(inst_id[j]) * c.dimv + cc]
+                              : c.out[static_cast<uint64_t>(pr.y) * c.dimv + cc];
+      }
+    }
+    return;
+  }
+
+  // ---- write role ----
+  const uint32_t wb = blockIdx.x - count_blocks - row_blocks;
+  if (wb >= write_blocks || wb >= tiles) return;
+  uint32_t sl0, tc0, par;
+  {
+    const uint32_t p = wb * kFuseTile + tid;
+    const uint32_t a0 = p < cap ? c.queue[0][p] : 0u;
+    const uint32_t a1 = p < cap ? c.queue[1][p] : 0u;
+    tc0 = p < cap ? c.touched[p] : 0u;
+    par = fuse_parity(c);
+    sl0 = par ? a1 : a0;
+  }
+  if (total_miss(c.ctr) == 0) return;   // the list stays as it is
+  // #distinct misses of the whole block
+  uint32_t part = 0;
+  for (uint32_t j = tid; j < row_wgs; j += kWide) {
+    uint32_t v;
+    if (!fuse_poll(&c.g_row[j], tag, &v)) v = fuse_recount_rows(c, j);
+    part += v;
+  }
+  const uint32_t tm = wide_sum(part, ws);
+  // hits per tile -> hits before every tile
+  constexpr uint32_t kPer = kFuseMaxTiles / kWide;
+  uint32_t hv[kPer], run_h = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kPer; ++k) {
+    const uint32_t t = tid * kPer + k;
+    hv[k] = 0;
+    if (t < tiles && !fuse_poll(&c.g_cnt[t], tag, &hv[k])) hv[k] = fuse_recount_tile(c, t);
+    run_h += hv[k];
+  }
+  uint32_t th;
+  uint32_t hbt = wide_excl_scan(run_h, ws, &th);
+#pragma unroll
+  for (uint32_t k = 0; k < kPer; ++k) {
+    const uint32_t t = tid * kPer + k;
+    if (t <= tiles) s_hitp[t] = hbt;
+    hbt += hv[k];
+  }
+  __syncthreads();
+  const uint32_t k = min(tm, cap), n_kept = cap - th;
+  const uint32_t* list = c.queue[par];
+  uint32_t* next = c.queue[par ^ 1u];
+  for (uint32_t t = wb; t < tiles; t += write_blocks) {
+    const uint32_t p = t * kFuseTile + tid;
+    uint32_t sl, tc;
+    if (t == wb) {
+      sl = sl0; tc = tc0;
+    } else {
+      sl = p < cap ? list[p] : 0u;
+      tc = p < cap ? c.touched[p] : 0u;
+    }
+    const uint32_t hit = (p < cap && tc == c.epoch_new) ? 1u : 0u;
+    uint32_t total;
+    const uint32_t hb = s_hitp[t] + wide_excl_scan(hit, ws, &total);   // hit entries before p
+    if (p < cap) {
+      const uint32_t l = hit ? n_kept + hb : p - hb;   // index in (not-hit ++ hit entries)
+      const uint32_t at = l < k ? cap - k + l : l - k;
+      next[at] = sl;
+      c.qpos[sl] = at;   // where the next block's hits of this slot leave their mark
+    }
+  }
+  if (wb == 0 && tid == 0) {
+    // {new parity, this launch's tag} in ONE store: fuse_parity() of a late workgroup of this
+    // launch still resolves to `par`
+    *reinterpret_cast<unsigned long long*>(c.qstate) =
+        (static_cast<unsigned long long>(tag) << 32) | (par ^ 1u);
+  }
+}
+
 // list of a freshly initialised cache: slot order; `prefix` new slots [first, first + prefix)
 // go in front of the `old_n` entries of `old` (Cache.resize)
 __global__ void list_fill_kernel(uint32_t* list, uint32_t first, uint32_t prefix,
@@ -1780,6 +2153,17 @@ inline size_t stage_entries(size_t n, size_t capacity) {
   return std::max(list_form, victim_chunks(n)) * kRowTile + n;
 }
 
+// fused list update: entries of the staged front tiles (the ids they hold; the slots share
+// the v_slot / v_pos arrays): at most min(capacity, rows) list positions, in whole tiles
+inline size_t fuse_stage_entries(size_t n, size_t capacity) {
+  return (std::min(n, capacity) / kFuseTile + 2) * kFuseTile;
+}
+
+inline bool lru_fused_enabled() {
+  const char* e = std::getenv("GNNFLOW_LRU_FUSED");   // 0: list scan + list install (A/B, tests)
+  return e ? std::atoi(e) != 0 : true;
+}
+
 // bitmap over the queue positions, in whole tiles of kRowTile words (+ one tile)
 inline size_t qbits_bytes(size_t queue_cap) {
   const size_t words = (queue_cap + 64 + 31) / 32;
@@ -1852,10 +2236,14 @@ void launch_round(Round& r, hipStream_t stream) {
   size_t q_scan_blocks = 0, q_rows = 0, q_cap = 0, q_bit_tiles = 0, q_victim_blocks = 1;
   size_t q_append_blocks = 0, q_inst_blocks = 0;
   size_t h_n = 0, h_cap = 0, h_tiles = 0;
+  size_t f_tiles = 0, f_rows = 0;
   for (int i = 0; i < r.count; ++i) {
     const Ctx& c = r.c[i];
     if (!c.update) continue;
-    if (c.policy == GF_CACHE_LRU) {
+    if (c.policy == GF_CACHE_LRU && c.fused) {
+      f_tiles = std::max<size_t>(f_tiles, (c.capacity + kFuseTile - 1) / kFuseTile);
+      f_rows = std::max<size_t>(f_rows, (c.n + c.fuse_rows - 1) / c.fuse_rows);
+    } else if (c.policy == GF_CACHE_LRU) {
       const size_t row_tiles = (c.n + kLruRows - 1) / kLruRows;
       q_scan_blocks = std::max(q_scan_blocks, (row_tiles + c.tiles_per_wg - 1) / c.tiles_per_wg);
       q_rows = std::max<size_t>(q_rows, c.n);
@@ -1876,6 +2264,13 @@ void launch_round(Round& r, hipStream_t stream) {
       h_cap = std::max<size_t>(h_cap, c.capacity);
       h_tiles = std::max<size_t>(h_tiles, (c.capacity + kTile - 1) / kTile);
     }
+  }
+  if (f_tiles) {   // LRU list form, one launch
+    const unsigned cb = static_cast<unsigned>(std::min<size_t>(f_tiles, 1024));
+    const unsigned rb = static_cast<unsigned>(std::max<size_t>(f_rows, 1));
+    const unsigned wb = static_cast<unsigned>(std::min<size_t>(f_tiles, kFuseMaxTiles));
+    lru_list_fused_kernel<<<dim3(cb + rb + wb, r.count), dim3(kWide), 0, stream>>>(r, cb, rb, wb);
+    GF_HIP(hipGetLastError());
   }
   if (q_rows) {   // LRU: list scan + list install
     const unsigned rb = static_cast<unsigned>(q_scan_blocks);
@@ -2022,7 +2417,7 @@ void FeatureCache::init_queue(hipStream_t stream) {
         queue_.as<uint32_t>(), 0u, static_cast<uint32_t>(capacity_), nullptr, 0u);
     GF_HIP(hipGetLastError());
   }
-  const QueueState qs{0u, 0u, static_cast<uint32_t>(capacity_), 0u};
+  const QueueState qs{0u, 0u, 0u, static_cast<uint32_t>(capacity_), 0u, 0u};
   GF_HIP(hipMemcpyAsync(qstate_.data(), &qs, sizeof(qs), hipMemcpyHostToDevice, stream));
   GF_HIP(hipStreamSynchronize(stream));   // qs is a stack variable
   tail_bound_ = capacity_;
@@ -2230,7 +2625,7 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
         static_cast<uint32_t>(new_capacity - old_capacity), cur.as<uint32_t>(),
         static_cast<uint32_t>(old_capacity));
     GF_HIP(hipGetLastError());
-    const QueueState fresh{0u, 0u, static_cast<uint32_t>(new_capacity), 0u};
+    const QueueState fresh{0u, 0u, 0u, static_cast<uint32_t>(new_capacity), 0u, 0u};
     GF_HIP(hipMemcpyAsync(qstate_.data(), &fresh, sizeof(fresh), hipMemcpyHostToDevice, stream));
     GF_HIP(hipStreamSynchronize(stream));
     std::swap(queue_, na);
@@ -2269,7 +2664,8 @@ void FeatureCache::reserve_workspace(size_t n, hipStream_t stream) {
                  align_up((kMaxRowTiles + 1) * 4, 16) + 64;
   if (policy_ == GF_CACHE_LRU)   // staged victims per list tile / queue chunk, chunk counts
     bytes += 2 * align_up(stage_entries(ws_rows_, capacity_) * 4, 256) +
-             align_up((victim_chunks(ws_rows_) + 2) * 4, 256) + 256;
+             align_up((victim_chunks(ws_rows_) + 2) * 4, 256) + 256 +
+             2 * align_up(fuse_stage_entries(ws_rows_, capacity_) * 8, 256);
   // Kernels already queued on `stream` may still use the old scratch: it is retired behind
   // an event on that stream and freed once the event has completed — a stream-ordered swap,
   // no device-wide stall when a larger block arrives mid-run.
@@ -2337,6 +2733,10 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
       c.v_slot = reinterpret_cast<uint32_t*>(qscratch);
       c.v_pos = reinterpret_cast<uint32_t*>(qscratch + stage);
       c.v_count = reinterpret_cast<uint32_t*>(qscratch + 2 * stage);
+      const size_t vc = align_up((victim_chunks(ws_rows_) + 2) * 4, 256) + 256;
+      const size_t fst = align_up(fuse_stage_entries(ws_rows_, capacity_) * 8, 256);
+      c.v_old = reinterpret_cast<long long*>(qscratch + 2 * stage + vc);
+      c.v_hold = reinterpret_cast<long long*>(qscratch + 2 * stage + vc + fst);
       // list form: the tiles at the front of the list that stage their entries
       const size_t list_tiles = (capacity_ + kRowTile - 1) / kRowTile;
       const size_t st = std::min(list_tiles, (2 * n + kRowTile - 1) / kRowTile + 2);
@@ -2365,6 +2765,20 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
         compact_queue(stream);
         ++list_form_updates_;
       }
+    }
+    // list form in one launch (lru_list_fused_kernel) where its LDS tables and granule arrays fit
+    c.fuse_rows = n >= 65536 ? kWide : kInstRows;
+    if (!c.qmode && lru_fused_enabled() &&
+        (capacity_ + kFuseTile - 1) / kFuseTile <= kFuseMaxTiles &&
+        (n + c.fuse_rows - 1) / c.fuse_rows <= kFuseMaxRowWgs) {
+      if (!granules_.data()) {
+        granules_.reserve((kFuseMaxTiles + kFuseMaxRowWgs) * sizeof(unsigned long long), 0, stream);
+        GF_HIP(hipMemsetAsync(granules_.data(), 0, granules_.bytes(), stream));
+      }
+      c.fused = 1;
+      c.fuse_tag = ++fuse_tag_;
+      c.g_cnt = granules_.as<unsigned long long>();
+      c.g_row = c.g_cnt + kFuseMaxTiles;
     }
   }
 }
@@ -2780,6 +3194,14 @@ void FeatureCache::lru_state(uint64_t out[7]) const {
   out[4] = compactions_;
   out[5] = list_form_updates_;
   out[6] = qs.lone_walks;
+}
+
+// Granules of the fused LRU list update that did not arrive within the polling budget and were
+// recomputed by the waiting thread (since the library was loaded, current device).
+uint64_t lru_recounts() {
+  unsigned int v = 0;
+  GF_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_lru_recounts), sizeof(v)));
+  return v;
 }
 
 size_t FeatureCache::mem_bytes() const {

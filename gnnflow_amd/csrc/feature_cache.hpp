@@ -127,6 +127,9 @@ class FeatureCache {
   DeviceBuffer fifo_ptr_;  // uint32: FIFO rotation pointer
   DeviceBuffer ws_;        // per-fetch scratch
   size_t ws_rows_ = 0;
+  DeviceBuffer granules_;  // LRU list form in one launch: {launch tag, count} per list tile / row
+                           // workgroup (feature_cache.hip, lru_list_fused_kernel)
+  uint32_t fuse_tag_ = 0;  // tag of the last such launch: unique per cache, never reset
   uint32_t epoch_ = 0;     // fetches with update so far (host side; kernel argument)
   uint64_t ring_pos_ = 0;
   int policy_ = GF_CACHE_LRU;

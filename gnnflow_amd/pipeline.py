@@ -29,16 +29,31 @@ class ReplayPipeline:
                      critical path), fetch_feature(async_enqueue=True) on the current stream.
     pipelined=False: the plain loop `mfgs = sampler.sample(r, t); cache.fetch_feature(mfgs, e)`.
     cache=None     : sampling only.
+    sample_lanes   : consecutive batches are sampled round-robin by this many samplers (clones
+                     of `sampler` over the same graph: own native workspace, own side stream),
+                     so the four dependent launches of one sample() overlap the next one's.  A
+                     sample is a pure function of (graph, roots, timestamps) only for
+                     most-recent sampling — uniform draws depend on the sampler's call counter
+                     — so other strategies keep one lane.  Default: GNNFLOW_SAMPLE_LANES or 2.
     """
 
     def __init__(self, sampler, cache, batches: Sequence[Tuple[torch.Tensor, torch.Tensor,
                                                                 torch.Tensor]],
-                 device: torch.device, pipelined: bool = True, depth: int = 2):
+                 device: torch.device, pipelined: bool = True, depth: int = 2,
+                 sample_lanes: Optional[int] = None):
         self.sampler, self.cache, self.batches = sampler, cache, batches
         self.device = torch.device(device)
         self.pipelined = bool(pipelined) and cache is not None and \
             hasattr(sampler, "sample_async")
         self.side = torch.cuda.Stream(device=self.device) if self.pipelined else None
+        if sample_lanes is None:
+            sample_lanes = int(os.environ.get("GNNFLOW_SAMPLE_LANES", "2"))
+        self.lanes = [(sampler, self.side)]
+        if self.pipelined and sample_lanes > 1 and hasattr(sampler, "clone") and \
+                getattr(sampler, "_strategy", None) == "recent" and \
+                not hasattr(sampler, "chain_samples"):
+            for _ in range(min(int(sample_lanes), 4) - 1):
+                self.lanes.append((sampler.clone(), torch.cuda.Stream(device=self.device)))
         # a sampler (of a lane of the partitioned sampler: one per sample of a shared chain)
         # holds 4 begun samples at most
         self.depth = max(1, min(int(depth), 3 * max(1, getattr(self.sampler, "lanes", 1)) *
@@ -69,30 +84,33 @@ class ReplayPipeline:
                 if on_step:
                     on_step(i % nb, mfgs)
             return
-        sampler, cache, side = self.sampler, self.cache, self.side
+        cache, lanes, nl = self.cache, self.lanes, len(self.lanes)
         batches = self.batches
         main = torch.cuda.current_stream(self.device)
         last = first + count
         pending = deque()
         nxt = first
+
+        def begin(j):
+            r, t, _ = batches[j % nb]
+            sampler, side = lanes[j % nl]
+            return sampler.sample_async(r, t, stream=side, worker_enqueue=True)
+
         while nxt < last and len(pending) < self.depth:
-            r, t, _ = batches[nxt % nb]
-            pending.append(sampler.sample_async(r, t, stream=side, worker_enqueue=True))
+            pending.append(begin(nxt))
             nxt += 1
         fetch_first = self.fetch_first
         for i in range(first, last):
             mfgs = pending.popleft().wait()
             if nxt < last and not fetch_first:
-                r, t, _ = batches[nxt % nb]
-                pending.append(sampler.sample_async(r, t, stream=side, worker_enqueue=True))
+                pending.append(begin(nxt))
                 nxt += 1
             for mfg in mfgs:
                 for b in mfg:
                     b.record_stream(main)
             cache.fetch_feature(mfgs, batches[i % nb][2], async_enqueue=True)
             if nxt < last and fetch_first:
-                r, t, _ = batches[nxt % nb]
-                pending.append(sampler.sample_async(r, t, stream=side, worker_enqueue=True))
+                pending.append(begin(nxt))
                 nxt += 1
             if on_step:
                 on_step(i % nb, mfgs)

@@ -671,6 +671,10 @@ GF_API int gf_debug_part_host_us(double out[8], int reset);
  * was loaded).  0 in normal operation; non-zero when the GPU is heavily oversubscribed (several
  * rank processes sharing one card).  Synchronises nothing but the copy itself. */
 GF_API int gf_debug_merge_recounts(uint64_t* out);
+/* The same for the one-launch LRU list update (lru_list_fused_kernel): granules {launch tag,
+ * count} a waiting workgroup did not see within its polling budget and recomputed from the
+ * launch's inputs.  0 in normal operation. */
+GF_API int gf_debug_lru_recounts(uint64_t* out);
 /* All launches of a family seen since the last reset while it was enabled, timed or not. */
 GF_API int gf_profile_launches(int which, uint64_t* launches);
 

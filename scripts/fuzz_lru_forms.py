@@ -30,6 +30,10 @@ def run(seed, steps, form):
         os.environ["GNNFLOW_LRU_QUEUE_MIN_CAPACITY"] = "1"
     else:
         os.environ.pop("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", None)
+    if form == "list2":      # list scan + list install (two launches) instead of the fused update
+        os.environ["GNNFLOW_LRU_FUSED"] = "0"
+    else:
+        os.environ.pop("GNNFLOW_LRU_FUSED", None)
     rng = np.random.RandomState(9000 + seed)
     cap = int(rng.choice([3, 50, 700, 5000, 40000, 100000]))
     E = cap * int(rng.choice([2, 5, 20]))
@@ -84,9 +88,13 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     args = ap.parse_args()
     for seed in range(args.seeds):
-        for form in ("list", "queue"):
+        for form in ("list", "list2", "queue"):
             run(seed, args.steps, form)
-    print("all ok")
+    from gnnflow_amd import _capi
+    import ctypes
+    v = ctypes.c_uint64()
+    _capi.load().gf_debug_lru_recounts(ctypes.byref(v))
+    print("all ok (fused-update granules recomputed by waiters: %d)" % v.value)
 
 
 if __name__ == "__main__":

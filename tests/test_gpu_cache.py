@@ -11,17 +11,23 @@ from tests.test_oracle_cache import Blk, load, policy_of, replay
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["list", "queue"])
+@pytest.fixture(autouse=True, params=["list", "list2", "queue"])
 def lru_form(request, monkeypatch):
-    """Every test of this module runs twice: with the LRU order kept as a list (small caches)
-    and as a queue with dead entries (what caches of >= 2 M slots use; forced here by lowering
-    that bound to 1 slot, which also exercises its compaction every other update and the
-    fall-back to the list form for blocks of more than capacity / 4 rows).  Both must make
-    the oracle's decisions."""
+    """Every test of this module runs three times: with the LRU order kept as a list and
+    updated in ONE launch (small caches, the default), as a list updated by the two launches
+    list scan + list install (what caches beyond the one-launch kernel's tables use;
+    GNNFLOW_LRU_FUSED=0), and as a queue with dead entries (what caches of >= 2 M slots use;
+    forced here by lowering that bound to 1 slot, which also exercises its compaction every
+    other update and the fall-back to the list form for blocks of more than capacity / 4
+    rows).  All must make the oracle's decisions."""
     if request.param == "queue":
         monkeypatch.setenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", "1")
     else:
         monkeypatch.delenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", raising=False)
+    if request.param == "list2":
+        monkeypatch.setenv("GNNFLOW_LRU_FUSED", "0")
+    else:
+        monkeypatch.delenv("GNNFLOW_LRU_FUSED", raising=False)
     return request.param
 
 

@@ -194,7 +194,7 @@ class _StepView:
         return self._value
 
 
-@pytest.mark.parametrize("lru_form", ["list", "queue"])
+@pytest.mark.parametrize("lru_form", ["list", "list2", "queue"])
 def test_stepwise_cached_sets_and_alias_equivalence(lru_form, monkeypatch):
     """Same loop with a host check after every step (cached-id sets at EVERY step), once with
     the prefix alias and once without: both must agree with the oracle, hence with each
@@ -206,6 +206,10 @@ def test_stepwise_cached_sets_and_alias_equivalence(lru_form, monkeypatch):
         monkeypatch.setenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", "1")
     else:
         monkeypatch.delenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", raising=False)
+    if lru_form == "list2":     # list scan + list install instead of the one-launch update
+        monkeypatch.setenv("GNNFLOW_LRU_FUSED", "0")
+    else:
+        monkeypatch.delenv("GNNFLOW_LRU_FUSED", raising=False)
     for alias in (True, False):
         w = _World(900, 48, prefix_alias=alias)
         pipe = ReplayPipeline(w.sampler, w.cache, w.dev_batches, w.dev, pipelined=True)
