@@ -1627,17 +1627,40 @@ __device__ unsigned int g_lru_recounts;       // granules a waiter had to recomp
 
 #define GF_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-__device__ inline bool fuse_poll(const unsigned long long* g, uint32_t tag, uint32_t* value) {
-  for (uint32_t spins = 0; spins < kFuseSpins; ++spins) {
-    const unsigned long long x = __hip_atomic_load(g, GF_RLX_AGENT);
-    if (static_cast<uint32_t>(x >> 32) == tag) {
-      *value = static_cast<uint32_t>(x);
-      return true;
-    }
-    __builtin_amdgcn_s_sleep(1);
+// Polls up to three granules with all loads in flight per round (a look-back granule and two
+// count granules cost one round trip, not three); out[k] = the count, or ~0u for a granule
+// that never showed the tag (null pointer: not wanted, 0).
+__device__ inline void fuse_poll3(const unsigned long long* g0, const unsigned long long* g1,
+                                  const unsigned long long* g2, uint32_t tag, uint32_t* out) {
+  const unsigned long long* g[3] = {g0, g1, g2};
+  bool need[3], any = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    need[k] = g[k] != nullptr;
+    out[k] = need[k] ? ~0u : 0u;
+    any |= need[k];
   }
-  atomicAdd(&g_lru_recounts, 1u);
-  return false;
+  for (uint32_t spins = 0; any && spins < kFuseSpins; ++spins) {
+    unsigned long long x[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = need[k] ? __hip_atomic_load(g[k], GF_RLX_AGENT) : 0ull;
+    any = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (need[k]) {
+        if (static_cast<uint32_t>(x[k] >> 32) == tag) {
+          out[k] = static_cast<uint32_t>(x[k]);
+          need[k] = false;
+        } else {
+          any = true;
+        }
+      }
+    }
+    if (any) __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (need[k]) atomicAdd(&g_lru_recounts, 1u);
 }
 
 __device__ inline void fuse_publish(unsigned long long* g, uint32_t tag, uint32_t value) {
@@ -1787,26 +1810,24 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
       n_inst = 0;
       s_direct = 0;
     }
-    // look-back over the row workgroups before this one
-    uint32_t part = 0;
-    for (uint32_t j = tid; j < b; j += kWide) {
-      uint32_t v;
-      if (!fuse_poll(&c.g_row[j], tag, &v)) v = fuse_recount_rows(c, j);
-      part += v;
-    }
-    const uint32_t pm = wide_sum(part, ws);
-    // hits per list tile -> prefix of not-hit / hit entries per tile
+    // look-back over the row workgroups before this one (at most kFuseMaxRowWgs = kWide: one
+    // per thread) and the hits per list tile (two per thread), all in flight together
     constexpr uint32_t kPer = kFuseMaxTiles / kWide;
+    static_assert(kPer == 2 && kFuseMaxRowWgs <= kWide, "fuse_poll3: one row + two count granules");
+    uint32_t pv[3];
+    fuse_poll3(static_cast<uint32_t>(tid) < b ? &c.g_row[tid] : nullptr,
+               tid * kPer < tiles ? &c.g_cnt[tid * kPer] : nullptr,
+               tid * kPer + 1 < tiles ? &c.g_cnt[tid * kPer + 1] : nullptr, tag, pv);
+    if (pv[0] == ~0u) pv[0] = fuse_recount_rows(c, tid);
+    const uint32_t pm = wide_sum(pv[0], ws);
+    // hits per list tile -> prefix of not-hit / hit entries per tile
     uint32_t hv[kPer], run_h = 0;
 #pragma unroll
     for (uint32_t k = 0; k < kPer; ++k) {
-      const uint32_t t = tid * kPer + k;
-      hv[k] = 0;
-      if (t < tiles) {
-        if (!fuse_poll(&c.g_cnt[t], tag, &hv[k])) {
-          hv[k] = fuse_recount_tile(c, t);
-          s_direct = 1u;   // its staged entries may never arrive: walk the tiles instead
-        }
+      hv[k] = pv[1 + k];
+      if (hv[k] == ~0u) {
+        hv[k] = fuse_recount_tile(c, tid * kPer + k);
+        s_direct = 1u;   // its staged entries may never arrive: walk the tiles instead
       }
       run_h += hv[k];
     }
@@ -1888,22 +1909,21 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
     sl0 = par ? a1 : a0;
   }
   if (total_miss(c.ctr) == 0) return;   // the list stays as it is
-  // #distinct misses of the whole block
-  uint32_t part = 0;
-  for (uint32_t j = tid; j < row_wgs; j += kWide) {
-    uint32_t v;
-    if (!fuse_poll(&c.g_row[j], tag, &v)) v = fuse_recount_rows(c, j);
-    part += v;
-  }
-  const uint32_t tm = wide_sum(part, ws);
-  // hits per tile -> hits before every tile
+  // #distinct misses of the whole block (every row granule) and the hits per tile, all in
+  // flight together
   constexpr uint32_t kPer = kFuseMaxTiles / kWide;
+  uint32_t pv[3];
+  fuse_poll3(static_cast<uint32_t>(tid) < row_wgs ? &c.g_row[tid] : nullptr,
+             tid * kPer < tiles ? &c.g_cnt[tid * kPer] : nullptr,
+             tid * kPer + 1 < tiles ? &c.g_cnt[tid * kPer + 1] : nullptr, tag, pv);
+  if (pv[0] == ~0u) pv[0] = fuse_recount_rows(c, tid);
+  const uint32_t tm = wide_sum(pv[0], ws);
+  // hits per tile -> hits before every tile
   uint32_t hv[kPer], run_h = 0;
 #pragma unroll
   for (uint32_t k = 0; k < kPer; ++k) {
-    const uint32_t t = tid * kPer + k;
-    hv[k] = 0;
-    if (t < tiles && !fuse_poll(&c.g_cnt[t], tag, &hv[k])) hv[k] = fuse_recount_tile(c, t);
+    hv[k] = pv[1 + k];
+    if (hv[k] == ~0u) hv[k] = fuse_recount_tile(c, tid * kPer + k);
     run_h += hv[k];
   }
   uint32_t th;
