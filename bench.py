@@ -230,6 +230,78 @@ class Ctx:
     pass
 
 
+# the N > 1 ladder (main()): arrangement, what it is
+RUNGS = [("hash", "graph hash-partitioned over the ranks; sampling lanes x shared chains of up to "
+                  "four samples, one communicator per lane"),
+         ("hash-simple", "graph hash-partitioned over the ranks; ONE lane, single chains, slot "
+                         "capacity 2.0 x the even share: one communicator, never two collectives "
+                         "in flight"),
+         ("replica", "a full replica of the graph per GPU, no data-path collective")]
+
+
+def multi_gpu_record(ctx, sampler, cache):
+    """What the N > 1 line says about the exchange beyond its rate (the reference all-gathers
+    its per-rank sampling timers, gnnflow/distributed/dist_sampler.py:108-127): RCCL's own rank
+    count per lane communicator, the ranks' devices, overflowed samples, bytes per step and rank
+    on the links, and — DESIGN 6.2's two free parameters — the device time x of one all-to-all
+    of the layer-1 reply / request size and the issuing thread's cost c per exchange."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    rec = {"lanes": getattr(sampler, "lanes", 1), "chain_samples": getattr(sampler, "chain_samples", 1),
+           "overflowed_samples": int(getattr(sampler, "overflows", 0))}
+    comms = sampler.comms() if hasattr(sampler, "comms") else []
+    infos = [c.info() for c in comms]
+    rec["transport"] = infos[0]["transport"] if infos else \
+        "torch.distributed ({})".format(ctx.backend)
+    rec["rccl_nranks"] = [i["nranks"] for i in infos] if infos and infos[0]["transport"] == "rccl" \
+        else None
+    rec["communicator_nranks"] = [i["nranks"] for i in infos]
+    buf = C.create_string_buffer(64)
+    bus = buf.value.decode() if ctx.lib.gf_device_pci_bus_id(ctx.local_rank, buf, 64) == 0 else "?"
+    mine = {"rank": ctx.rank, "device": ctx.local_rank, "pci_bus_id": bus,
+            "name": torch.cuda.get_device_name(ctx.dev),
+            "overflowed_samples": rec["overflowed_samples"]}
+    ranks = [None] * ctx.world
+    dist.all_gather_object(ranks, mine)
+    rec["ranks"] = ranks
+    rec["distinct_devices"] = len({r["pci_bus_id"] for r in ranks})
+    if hasattr(sampler, "wire_bytes_per_sample"):
+        wb = sampler.wire_bytes_per_sample()
+        rec["wire"] = wb
+        rec["request_bytes_per_step_and_rank"] = (ctx.world - 1) * wb["request_bytes_to_each_peer"]
+        rec["reply_bytes_per_step_and_rank"] = (ctx.world - 1) * wb["reply_bytes_to_each_peer"]
+    # x and c, on lane 0's communicator, at the sizes a chain's layer-1 exchanges have
+    if comms and hasattr(sampler, "_plan") and sampler._slack > 0:
+        lay = sampler._plan(max(sampler._slot_roots, 1), sampler._slack)[0][-1]
+        m = getattr(sampler, "chain_samples", 1)
+        rows = int(lay.slot_stride) * m
+        sizes = {"request_layer1": rows * 16,
+                 "reply_layer1": rows * sampler._fanouts[-1] * (12 if sampler._narrow else 24)}
+        torch.cuda.synchronize()
+        dist.barrier()
+        x = {}
+        for name, nbytes in sizes.items():
+            dev_us, host_us = comms[0].time_all_to_all(nbytes, 30, torch.cuda.current_stream(ctx.dev))
+            x[name] = {"bytes_per_peer": nbytes, "device_us": dev_us, "issue_us": host_us}
+        rec["all_to_all"] = x
+        k = 7.0 * 13.5          # a chain of four: 7 kernels, ~95 us (DESIGN 6.2, measured at P = 1)
+        layers = len(sampler._fanouts)
+        # (every layer priced at the last layer's sizes: an upper bound — layer 0's slots are
+        # a tenth of layer 1's at fanout 10)
+        xs = layers * (x["request_layer1"]["device_us"] + x["reply_layer1"]["device_us"])
+        rec["projection"] = {
+            "formula": "a chain of m samples on one of L lanes = K us of kernels + the device time "
+                       "of its 2 x layers all-to-alls; the lanes sustain one step per "
+                       "(K + sum x) / (m L) us; the issuing thread needs (7 x 3 + 2 x layers x c) / m "
+                       "+ 9 us per step",
+            "K_us": k, "sum_x_us": xs, "m": m, "L": rec["lanes"],
+            "chains_sustain_us_per_step": (k + xs) / (m * rec["lanes"]),
+            "issuing_thread_us_per_step":
+                (21.0 + 2 * layers * x["reply_layer1"]["issue_us"]) / m + 9.0}
+    return rec
+
+
 def build_leg(ctx, kind, always_exchange=None):
     """Graph + sampler of one kind over this rank's GPU: "replica" = the whole graph, "hash" =
     this rank's shard + the partitioned sampler."""
@@ -263,6 +335,7 @@ def build_leg(ctx, kind, always_exchange=None):
                                            always_exchange=always_exchange,
                                            lanes=args.part_lanes,
                                            chain_samples=args.part_chain)
+    ctx.live_sampler = sampler      # (a rung that hangs aborts its communicators: main())
     return graph, sampler, build_s
 
 
@@ -284,6 +357,7 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
                                                         2 * chain)
     pipe = ReplayPipeline(sampler, cache, ctx.dev_batches, ctx.dev,
                           pipelined=cache is not None and not args.no_pipeline, depth=depth)
+    ctx.live_pipe = pipe
 
     def reduce(value, op):
         if world == 1:
@@ -361,11 +435,109 @@ def agree(ctx, ok):
     return bool(int(t))
 
 
+GIVE_UP = 75     # exit status of a rung's worker that hands over to the next rung
+
+
+def supervise(args, argv):
+    """One RANK of an N > 1 run (started by torchrun or by launch_ranks): this process never
+    touches the GPU.  It runs the rungs of the ladder (RUNGS) one after the other, each as a
+    WORKER process of its own on a new rendezvous port, until one of them prints the line:
+      * a worker that finishes prints the ONE JSON line (rank 0) and exits 0;
+      * a worker whose hash-partitioned loop RAISES (the ranks agree through an all-reduce) or
+        HANGS (its watchdog fires after GNNFLOW_HASH_MAIN_TIMEOUT: 150 s on rung 0, 120 s on
+        rung 1 — all three rungs fit the driver's 600 s) leaves a ladder entry and exits
+        GIVE_UP; one that does not even do that is killed.  Either way the process is GONE —
+        and with it its communicators and whatever kernels it still had on the GPU — before
+        the next rung's worker starts: no figure shares the GPU with an abandoned run.
+    RCCL between two ranks has never run on this code before the driver's first scaling run;
+    the likeliest first failure is a collective that some rank never joins."""
+    import subprocess
+    import tempfile
+    import threading
+    rank = int(os.environ.get("RANK", "0"))
+    base_port = int(os.environ.get("MASTER_PORT", "29500"))
+    history, rc, lines = [], 1, []
+    for rung in range(len(RUNGS)):
+        fd, path = tempfile.mkstemp(prefix="gnnflow_rung{}_rank{}_".format(rung, rank))
+        os.close(fd)
+        os.unlink(path)
+        env = dict(os.environ)
+        env.update(GNNFLOW_BENCH_WORKER="1", GNNFLOW_BENCH_RUNG=str(rung),
+                   GNNFLOW_BENCH_LADDER=json.dumps(history), GNNFLOW_BENCH_LADDER_FILE=path,
+                   MASTER_PORT=str(base_port + 17 * (rung + 1)))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)   # the worker's rank 0 hosts its own store
+        limit = None
+        if rung < len(RUNGS) - 1:
+            # the worker's own watchdog covers its main loop; this covers everything else
+            # (set-up included) should the worker be too wedged to exit by itself
+            limit = float(os.environ.get("GNNFLOW_HASH_MAIN_TIMEOUT", "150" if rung == 0 else "120")) + \
+                float(os.environ.get("GNNFLOW_RUNG_SETUP_ALLOWANCE", "90"))
+        t0 = time.time()
+        kid = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                               stdin=subprocess.DEVNULL,
+                               stdout=subprocess.PIPE if rank == 0 else sys.stderr)
+        lines = []
+
+        def relay(k=kid, out=lines):
+            for raw in k.stdout:
+                line = raw.decode(errors="replace")
+                (out.append if line.startswith("{") else sys.stderr.write)(line)
+        reader = None
+        if rank == 0:
+            reader = threading.Thread(target=relay, daemon=True)
+            reader.start()
+        killed = False
+        try:
+            rc = kid.wait(timeout=limit)
+        except subprocess.TimeoutExpired:
+            killed = True
+            kid.kill()
+            rc = kid.wait()
+        if reader is not None:
+            reader.join(timeout=10.0)
+        entry = None
+        try:
+            with open(path) as f:
+                entry = json.load(f)
+            os.unlink(path)
+        except (OSError, ValueError):
+            pass
+        if rc == 0:
+            break
+        if rung == len(RUNGS) - 1:
+            break                               # the last rung's failure is the run's failure
+        if entry is None:
+            entry = {"rung": rung, "arrangement": RUNGS[rung][0], "hung": bool(killed),
+                     "error": "the worker was killed after {:.0f} s without a word".format(
+                         time.time() - t0) if killed else
+                     "the worker exited with status {}".format(rc)}
+        entry["worker_killed"] = bool(killed)
+        entry["seconds"] = round(time.time() - t0, 1)
+        history.append(entry)
+        sys.stderr.write("bench.py rank {}: rung {} ({}) is over after {:.0f} s: {}; starting rung "
+                         "{} ({})\n".format(rank, rung, RUNGS[rung][0], time.time() - t0,
+                                            entry["error"], rung + 1, RUNGS[rung + 1][0]))
+    if rank == 0:
+        if lines:
+            sys.stdout.write(lines[-1])         # exactly one line
+        else:
+            sys.stdout.write(json.dumps({
+                "metric": "sampled_edges_per_s", "value": 0.0, "unit": "edges/s",
+                "n_gpus": args.gpus, "ladder": history,
+                "error": "no rung printed a record; last exit status {}".format(rc)}) + "\n")
+            rc = rc or 1
+        sys.stdout.flush()
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, argv))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "GNNFLOW_BENCH_WORKER" not in os.environ \
+            and args.partition in (None, "hash") and not args.shard_features:
+        sys.exit(supervise(args, argv))
     # stdout carries exactly ONE line, the JSON record: everything else that libraries print
     # there (RCCL's version banner on communicator creation, for one) goes to stderr
     sys.stdout.flush()
@@ -488,53 +660,60 @@ def main():
         res.update(graph=graph, sampler=sampler, build_s=build_s, kind=kind)
         return res
 
-    main_kind, hash_error, res = args.partition, None, None
-    if os.environ.get("GNNFLOW_BENCH_HASH_ERROR"):
-        # this process is one of the fresh ranks started after the hash-partitioned loop hung
-        hash_error = os.environ["GNNFLOW_BENCH_HASH_ERROR"]
-    # An exception in the hash-partitioned loop is handled below, in this process.  A HANG (a
-    # collective some rank never joins: the likeliest way for a first run over RCCL to fail) is
-    # not recoverable here — the stream is stuck behind a kernel that waits for its peers — so
-    # after GNNFLOW_HASH_MAIN_TIMEOUT seconds every rank starts a FRESH process (a child, not an
-    # exec: this process has initialised the GPU) that times the replica loop on a new
-    # rendezvous port, lets it print the line, and exits with its status.
+    # ---- the N > 1 ladder (this process is the WORKER of one rung: supervise() above) ---------
+    rung = int(os.environ.get("GNNFLOW_BENCH_RUNG", "0"))
+    history = json.loads(os.environ.get("GNNFLOW_BENCH_LADDER", "[]"))
+    laddered = "GNNFLOW_BENCH_WORKER" in os.environ and world > 1
+    if not laddered:
+        rung = 2 if args.partition == "replica" else 0
+    if laddered and rung == 1:
+        args.part_lanes, args.part_chain, args.part_slack = 1, 1, 2.0
+    if laddered and rung >= 2:
+        args.partition = "replica"
+    main_kind, res = args.partition, None
+    ctx.rung, ctx.history = rung, history
+
+    def give_up(why, hung):
+        """This rung is over on this rank: leave the ladder entry for the supervisor and exit
+        with GIVE_UP — the supervisor starts the next rung once this process (and with it every
+        kernel it still has on the GPU) is gone.  Never returns."""
+        main.superseded = True
+        sys.stderr.write("bench.py rank {}: rung {} ({}) gave up: {}\n".format(
+            rank, rung, RUNGS[rung][0], why))
+        entry = {"rung": rung, "arrangement": RUNGS[rung][0], "error": why, "hung": bool(hung)}
+        path = os.environ.get("GNNFLOW_BENCH_LADDER_FILE")
+        if path:
+            try:
+                with open(path, "w") as f:
+                    json.dump(entry, f)
+            except OSError:
+                pass
+        os._exit(GIVE_UP)
+
     hang_guard = None
-    if world > 1 and main_kind == "hash" and not sharded:
-        import subprocess
+    if laddered and rung < 2:
         import threading
         hang_guard = threading.Event()
-        hang_limit = float(os.environ.get("GNNFLOW_HASH_MAIN_TIMEOUT", "240"))
+        hang_limit = float(os.environ.get("GNNFLOW_HASH_MAIN_TIMEOUT", "150" if rung == 0 else "120"))
 
         def hash_hang_watchdog():
             if hang_guard.wait(hang_limit):
                 return
-            main.superseded = True
-            if getattr(main, "done", None) is not None:
-                main.done.set()
-            why = "the hash-partitioned loop did not finish within {:.0f} s (a collective " \
-                  "that some rank never joined?)".format(hang_limit)
-            sys.stderr.write("bench.py rank {}: {}; timing the replica loop in fresh "
-                             "processes\n".format(rank, why))
-            env = dict(os.environ)
-            env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
-            env["GNNFLOW_BENCH_HASH_ERROR"] = why
-            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)   # the new rank 0 hosts its own store
-            env.pop("GNNFLOW_BENCH_HANG_HASH", None)
-            cmd = [sys.executable, os.path.abspath(__file__)] + list(argv) + \
-                ["--partition", "replica"]
-            try:
-                rc = subprocess.Popen(cmd, env=env, stdin=subprocess.DEVNULL, stdout=json_fd,
-                                      stderr=2).wait()
-            except Exception as e:              # noqa: BLE001
-                sys.stderr.write("bench.py rank {}: could not start the fallback: {}\n".format(rank, e))
-                rc = 3
-            os._exit(rc)
+            give_up("the hash-partitioned loop did not finish within {:.0f} s (a collective "
+                    "that some rank never joined?)".format(hang_limit), hung=True)
         threading.Thread(target=hash_hang_watchdog, daemon=True).start()
+
+    def hooked(name, rungs_default):
+        # test hooks: GNNFLOW_BENCH_FAIL_HASH / GNNFLOW_BENCH_HANG_HASH act on the hash rungs
+        # named by GNNFLOW_BENCH_FAIL_RUNGS / GNNFLOW_BENCH_HANG_RUNGS
+        v = os.environ.get("GNNFLOW_BENCH_{}_HASH".format(name))
+        on = os.environ.get("GNNFLOW_BENCH_{}_RUNGS".format(name), rungs_default).split(",")
+        return v if (v is not None and main_kind == "hash" and str(rung) in on) else None
     try:
-        if os.environ.get("GNNFLOW_BENCH_FAIL_HASH") and main_kind == "hash":   # test hook
+        if hooked("FAIL", "0,1"):
             raise RuntimeError("GNNFLOW_BENCH_FAIL_HASH is set")
-        hang = os.environ.get("GNNFLOW_BENCH_HANG_HASH")                        # test hook
-        if hang is not None and main_kind == "hash" and hang in ("all", str(rank)):
+        hang = hooked("HANG", "0,1")
+        if hang is not None and hang in ("all", str(rank)):
             time.sleep(1e6)
         res = run_main(main_kind)
         failure = None
@@ -545,28 +724,18 @@ def main():
     agreed = agree(ctx, failure is None)
     if hang_guard is not None:
         hang_guard.set()
-    if getattr(main, "superseded", False):      # the fresh ranks have the job now
+    if getattr(main, "superseded", False):      # the next rung's ranks have the job now
         time.sleep(1e6)
     if not agreed:
         failure = failure or "the loop failed on another rank"
-        if main_kind == "hash" and not sharded:
-            hash_error, main_kind = failure, "replica"
-            try:
-                res = run_main("replica")
-                failure = None
-            except Exception as e:              # noqa: BLE001
-                import traceback
-                traceback.print_exc()
-                failure = "hash: {}; replica: {}: {}".format(hash_error, type(e).__name__, e)
-            if not agree(ctx, failure is None):
-                failure = failure or "the replica loop failed on another rank"
-        if failure is not None:
-            if rank == 0:
-                emit({"metric": "sampled_edges_per_s", "value": 0.0, "unit": "edges/s",
-                      "n_gpus": world, "error": failure})
-            if getattr(main, "done", None) is not None:
-                main.done.set()
-            os._exit(1)
+        if laddered and rung < 2:
+            give_up(failure, hung=False)
+        if rank == 0:
+            emit({"metric": "sampled_edges_per_s", "value": 0.0, "unit": "edges/s",
+                  "n_gpus": world, "error": failure, "ladder": history})
+        if getattr(main, "done", None) is not None:
+            main.done.set()
+        os._exit(1)
     sampler, pipe = res["sampler"], res["pipe"]
     elapsed_max, edges_all, edges = res["elapsed"], res["edges_all"], res["edges"]
     repeats, timed_steps = res["repeats"], res["timed_steps"]
@@ -673,8 +842,16 @@ def main():
             "sharded by owner: {} rows pulled, {} count read-backs in {} steps".format(
                 cache._shards.rows_pulled, cache._shards.host_syncs, timed_steps + args.warmup)
             if cache is not None and cache.distributed else "replicated on every GPU")
-    if hash_error is not None:
-        out["hash_partition"] = {"error": hash_error, "fallback": "replica loop timed instead"}
+    if world > 1:
+        out["ladder"] = {"rung": rung, "arrangement": RUNGS[rung][0], "what": RUNGS[rung][1],
+                         "tried_before": history}
+        # (every rung runs in processes of its own and the next one starts only when they are
+        # gone — killed if need be — so no abandoned kernel shares the GPU with this figure)
+    if main_kind == "hash" and world > 1:
+        out["multi_gpu"] = multi_gpu_record(ctx, sampler, cache)
+    if history and main_kind == "replica":
+        out["hash_partition"] = {"error": history[0]["error"], "ladder": history,
+                                 "fallback": "replica loop timed instead"}
     elif cache is not None and not args.no_second_leg:
         # The other kind of graph in the same line, over the same batches, cache and pipeline:
         # the hash-partitioned one when the main loop ran on replicas (at P = 1 every root is
@@ -684,6 +861,10 @@ def main():
         other = "hash" if main_kind == "replica" else "replica"
         second_leg.pending_line = out
         out["hash_partition" if other == "hash" else "replica"] = second_leg(ctx, other, cache)
+        if other == "replica" and out["replica"].get("value"):
+            # weak-scaling efficiency can only be formed against N = 1 by the driver; what this
+            # run can say itself: what the exchange costs against replicas on the same GPUs
+            out["efficiency_vs_replica_same_run"] = out["value"] / out["replica"]["value"]
         if world == 1 and other == "hash" and not args.always_exchange and backend == "nccl":
             # ... and the chain the ranks of an N > 1 run really issue — slotted exchange, lanes,
             # two samples per chain — with every message travelling through RCCL to this rank
@@ -829,6 +1010,9 @@ def second_leg(ctx, kind, cache, always_exchange=None):
                 "timed_seconds": res["elapsed"], "world_size": ctx.world,
                 "pipelined": bool(res["pipe"].pipelined),
                 "pipeline_depth": res["pipe"].depth,
+                # what RCCL itself says about every lane's communicator (ncclCommCount)
+                "rccl_nranks": [c.info()["nranks"] for c in sampler.comms()
+                                if c.transport == "rccl"] if hasattr(sampler, "comms") else [],
                 "exchange": exchange_note(sampler, ctx.world, ctx.backend) if kind == "hash" else
                 "none (a full replica of the graph per GPU, no data-path collective)"}
     except Exception as e:   # the main figure above must survive a failing second leg

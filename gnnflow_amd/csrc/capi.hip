@@ -913,6 +913,60 @@ int gf_loopback_comm_create(gf_comm** out, int world_size, int device) {
     for (int r = 0; r < world_size; ++r) out[r] = new gf_comm(ranks[r].release());
   });
 }
+int gf_comm_info(gf_comm* c, int32_t* out) {
+  return guarded([&] {
+    GF_REQUIRE(c != nullptr && out != nullptr, "gf_comm_info: null argument");
+    int v[4];
+    c->impl.info(v);
+    if (v[3] < 0) v[3] = c->ipc ? 1 : 2;
+    for (int i = 0; i < 4; ++i) out[i] = v[i];
+  });
+}
+int gf_comm_abort(gf_comm* c) {
+  return guarded([&] {
+    GF_REQUIRE(c != nullptr, "null communicator");
+    c->impl.abort();
+  });
+}
+// `iters` equal-split all-to-alls of bytes_per_peer bytes per peer on scratch buffers, one after
+// the other on `stream`: device time per exchange from events around the batch, host time per
+// exchange of the issuing thread.  Collective: every rank calls it with the same arguments.
+int gf_comm_time_all_to_all(gf_comm* c, size_t bytes_per_peer, int iters, void* stream,
+                            double* device_us, double* host_us) {
+  return guarded([&] {
+    GF_REQUIRE(c != nullptr && device_us != nullptr && host_us != nullptr && iters > 0,
+               "gf_comm_time_all_to_all: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t bytes = std::max<size_t>(bytes_per_peer, 8) * static_cast<size_t>(c->impl.world());
+    gf::DeviceBuffer send, recv;
+    send.reserve(bytes);
+    recv.reserve(bytes);
+    GF_HIP(hipMemsetAsync(send.data(), 0, bytes, st));
+    hipEvent_t e0, e1;
+    GF_HIP(hipEventCreate(&e0));
+    GF_HIP(hipEventCreate(&e1));
+    for (int w = 0; w < 3; ++w) c->impl.all_to_all(send.data(), recv.data(), bytes_per_peer, st);
+    GF_HIP(hipStreamSynchronize(st));
+    GF_HIP(hipEventRecord(e0, st));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) c->impl.all_to_all(send.data(), recv.data(), bytes_per_peer, st);
+    const auto t1 = std::chrono::steady_clock::now();
+    GF_HIP(hipEventRecord(e1, st));
+    GF_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GF_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *device_us = 1e3 * ms / iters;
+    *host_us = std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
+  });
+}
+int gf_device_pci_bus_id(int device, char* out, size_t len) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr && len >= 16, "gf_device_pci_bus_id: output too small");
+    GF_HIP(hipDeviceGetPCIBusId(out, static_cast<int>(len), device));
+  });
+}
 int gf_comm_all_to_all(gf_comm* c, const void* d_send, void* d_recv, size_t bytes_per_peer,
                        void* stream) {
   return guarded([&] {

@@ -34,6 +34,10 @@ struct Api {
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 
 const Api& api() {
@@ -64,6 +68,10 @@ const Api& api() {
     a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
     a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
     a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(sym("ncclCommCount"));
+    a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(sym("ncclCommUserRank"));
+    a.CommCuDevice = reinterpret_cast<decltype(a.CommCuDevice)>(sym("ncclCommCuDevice"));
+    a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(sym("ncclCommAbort"));
   });
   if (!err.empty()) throw Error(GF_ERR_INVALID_ARGUMENT, err);
   return a;
@@ -103,12 +111,31 @@ RcclComm::RcclComm(const uint8_t idb[kIdBytes], int world, int rank, int device)
 RcclComm::~RcclComm() {
   DeviceGuard dg(device_);
   if (side_) {
-    (void)hipStreamSynchronize(side_);
+    if (comm_) (void)hipStreamSynchronize(side_);   // (aborted: its kernels may never finish)
     (void)hipStreamDestroy(side_);
   }
   if (fork_) (void)hipEventDestroy(fork_);
   if (done_) (void)hipEventDestroy(done_);
   if (comm_) (void)api().CommDestroy(static_cast<ncclComm_t>(comm_));
+}
+
+// RCCL's own view of the communicator (the driver's question after a first multi-GPU run:
+// did RCCL see N ranks, on N devices?)
+void RcclComm::info(int out[4]) const {
+  out[0] = out[1] = out[2] = -1;
+  out[3] = 0;
+  if (!comm_) return;
+  ncclComm_t c = static_cast<ncclComm_t>(comm_);
+  GF_RCCL(api().CommCount(c, &out[0]));
+  GF_RCCL(api().CommUserRank(c, &out[1]));
+  GF_RCCL(api().CommCuDevice(c, &out[2]));
+}
+
+void RcclComm::abort() {
+  if (!comm_) return;
+  ncclComm_t c = static_cast<ncclComm_t>(comm_);
+  comm_ = nullptr;            // the destructor must not wait for peers that will never come
+  (void)api().CommAbort(c);
 }
 
 void RcclComm::all_to_all(const void* send, void* recv, size_t bytes_per_peer,

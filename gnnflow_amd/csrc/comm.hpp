@@ -35,6 +35,12 @@ class Exchange {
   virtual void all_to_all_v(const void* send, const size_t* send_bytes, const size_t* send_off,
                             void* recv, const size_t* recv_bytes, const size_t* recv_off,
                             hipStream_t stream) = 0;
+  // what the TRANSPORT itself says it is: out = {ranks, this rank, device, kind (0 RCCL, 1
+  // hipIpc, 2 loopback)} — RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice
+  virtual void info(int out[4]) const { out[0] = world(); out[1] = rank(); out[2] = -1; out[3] = -1; }
+  // gives up the communicator without waiting for its peers (a rank whose collective never
+  // completes); it must not be used afterwards
+  virtual void abort() {}
 };
 
 class RcclComm : public Exchange {
@@ -52,6 +58,8 @@ class RcclComm : public Exchange {
   void join(hipStream_t stream) override;
   void all_to_all_v(const void* send, const size_t* send_bytes, const size_t* send_off, void* recv,
                     const size_t* recv_bytes, const size_t* recv_off, hipStream_t stream) override;
+  void info(int out[4]) const override;
+  void abort() override;
 
  private:
   void* comm_ = nullptr;   // ncclComm_t

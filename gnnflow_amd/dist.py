@@ -386,6 +386,31 @@ class NativeComm:
             self._lib.gf_comm_destroy(self.h)
             self.h = None
 
+    def info(self) -> dict:
+        """What the transport itself reports (include/gnnflow_hip.h gf_comm_info): for RCCL
+        ncclCommCount / ncclCommUserRank / ncclCommCuDevice."""
+        import ctypes as C
+        from . import _capi
+        out = (C.c_int32 * 4)()
+        _capi.check(self._lib.gf_comm_info(self.h, out))
+        return {"nranks": int(out[0]), "rank": int(out[1]), "device": int(out[2]),
+                "transport": {0: "rccl", 1: "ipc", 2: "loopback"}.get(int(out[3]), "?")}
+
+    def abort(self):
+        """Gives the communicator up without waiting for its peers (a hung collective)."""
+        if getattr(self, "h", None) is not None and self.h.value:
+            self._lib.gf_comm_abort(self.h)
+
+    def time_all_to_all(self, bytes_per_peer: int, iters: int = 50, stream=None):
+        """(device us, host us) per equal-split all-to-all of `bytes_per_peer` — collective."""
+        import ctypes as C
+        from . import _capi
+        dev_us, host_us = C.c_double(0), C.c_double(0)
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        _capi.check(self._lib.gf_comm_time_all_to_all(self.h, int(bytes_per_peer), int(iters), st,
+                                                      C.byref(dev_us), C.byref(host_us)))
+        return dev_us.value, host_us.value
+
     def __del__(self):
         self.close()
 
@@ -678,6 +703,27 @@ class DevicePartitionedSampler:
         self._rr = 0               # round-robin cursor over the lanes
         self._layouts = {}     # (R0, slack) -> ([layouts per layer], [workspace offsets], total)
         self.overflows = 0     # slotted samples that had to be redone
+
+    def comms(self):
+        """The lanes' native communicators (those created so far)."""
+        return [lane.comm for lane in self._lanes if lane.comm is not None]
+
+    def wire_bytes_per_sample(self, R0=None) -> dict:
+        """Bytes ONE rank sends to EACH peer for one sample() of `R0` roots (default: the agreed
+        slot_roots) through the slotted exchange: the request slots (16 B per row, header row
+        included) and the reply slots (fanout records of 12 / 24 B per row) of every layer and
+        snapshot — fixed by the slot capacity, whatever the slots really hold."""
+        R0 = int(R0 or max(self._slot_roots, 1))
+        lays = self._plan(R0, self._slack)[0] if self._slack > 0 else []
+        rec = 12 if self._narrow else 24
+        req = rep = 0
+        for lay, F in zip(lays, self._fanouts):
+            rows = int(lay.slot_stride) * self._S
+            req += rows * 16
+            rep += rows * F * rec
+        return {"request_bytes_to_each_peer": req, "reply_bytes_to_each_peer": rep,
+                "bytes_on_links_per_rank": (self._P - 1) * (req + rep),
+                "reply_record_bytes": rec, "slot_roots": R0, "slack": self._slack}
 
     # the plain sampler's attributes the pipeline / cache helpers look at
     @property

@@ -520,6 +520,21 @@ GF_API int gf_comm_all_to_all(gf_comm* c, const void* d_send, void* d_recv, size
 GF_API int gf_comm_all_to_all_v(gf_comm* c, const void* d_send, const size_t* send_bytes,
                                 const size_t* send_offsets, void* d_recv, const size_t* recv_bytes,
                                 const size_t* recv_offsets, void* stream);
+/* What the transport itself reports: out = {ranks, this rank, device, kind (0 RCCL, 1 hipIpc, 2
+ * loopback)}; for RCCL these are ncclCommCount / ncclCommUserRank / ncclCommCuDevice — bench.py
+ * puts them into the N > 1 line ("did RCCL see N ranks on N devices?").  The reference all-gathers
+ * its per-rank sampling timers the same way (gnnflow/distributed/dist_sampler.py:108-127). */
+GF_API int gf_comm_info(gf_comm* c, int32_t out[4]);
+/* Gives the communicator up without waiting for its peers (ncclCommAbort): for a rank whose
+ * collective never completes.  Only gf_comm_destroy may follow. */
+GF_API int gf_comm_abort(gf_comm* c);
+/* `iters` back-to-back equal-split all-to-alls of `bytes_per_peer` on scratch buffers: device time
+ * (events around the batch) and the issuing thread's host time, per exchange, in microseconds —
+ * the x and c of DESIGN 6.2's projection.  Collective. */
+GF_API int gf_comm_time_all_to_all(gf_comm* c, size_t bytes_per_peer, int iters, void* stream,
+                                   double* device_us, double* host_us);
+/* PCI bus id of a HIP device ("0000:c1:00.0"), len >= 16. */
+GF_API int gf_device_pci_bus_id(int device, char* out, size_t len);
 /* The same exchanges between processes that map each other's device memory (hipIpc*) — the ranks
  * of one node, several ranks SHARING one GPU included (where RCCL refuses to run): a
  * host-synchronising test / single-box transport (copy-out, process barrier over POSIX shared

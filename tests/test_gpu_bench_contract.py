@@ -76,6 +76,7 @@ def test_single_gpu_line_with_roofline_and_cpu_baseline():
     hr = d["hash_partition_over_rccl_one_rank"]
     assert "error" not in hr and hr["value"] > 0.4 * d["value"]
     assert "RCCL communicator" in hr["exchange"] and "samples each on average" in hr["exchange"]
+    assert hr["rccl_nranks"] and set(hr["rccl_nranks"]) == {1}    # ncclCommCount of every lane
     # BASELINE configs[2] (here on a small graph) rides in the same line
     c3 = d["config3"]
     assert "error" not in c3 and [r["batch"] for r in c3["rows"]] == [600, 6000]
@@ -124,11 +125,22 @@ def test_bench_launches_its_own_ranks():
     _check_common(d, 2, 20, 5)
     assert d["config"]["parallelism"] == "hash-dp2"
     assert "error" not in d["replica"] and d["replica"]["world_size"] == 2
+    # the N > 1 line describes itself: which rung of the ladder produced it, the ranks' devices,
+    # what travelled, and the figure against replicas on the same GPUs
+    assert d["ladder"]["rung"] == 0 and d["ladder"]["arrangement"] == "hash" and \
+        d["ladder"]["tried_before"] == []
+    m = d["multi_gpu"]
+    assert [r["rank"] for r in m["ranks"]] == [0, 1] and all(r["pci_bus_id"] for r in m["ranks"])
+    assert m["distinct_devices"] == 1           # both ranks share the test box's one GPU
+    assert m["overflowed_samples"] == 0 and m["rccl_nranks"] is None   # staged through gloo here
+    assert m["request_bytes_per_step_and_rank"] > 0 and \
+        m["reply_bytes_per_step_and_rank"] > m["request_bytes_per_step_and_rank"]
+    assert d["efficiency_vs_replica_same_run"] == pytest.approx(d["value"] / d["replica"]["value"])
 
 
 def test_failing_hash_loop_falls_back_to_the_replica_figure():
-    """The hash-partitioned loop raising on every rank must not cost the line: the replica
-    loop is timed instead and the record says so."""
+    """The hash-partitioned loop raising on every rank (on both hash rungs of the ladder) must
+    not cost the line: fresh ranks time the replica loop and the record says so."""
     d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5",
               "--min-replays", "1", "--min-seconds", "0.2"],
              env={"GNNFLOW_BENCH_DEVICE": "0", "GNNFLOW_BENCH_BACKEND": "gloo",
@@ -136,15 +148,23 @@ def test_failing_hash_loop_falls_back_to_the_replica_figure():
     _check_common(d, 2, 20, 5)
     assert d["config"]["parallelism"] == "replica-dp2"
     assert "GNNFLOW_BENCH_FAIL_HASH" in d["hash_partition"]["error"]
+    lad = d["ladder"]
+    assert lad["rung"] == 2 and lad["arrangement"] == "replica"
+    assert [h["arrangement"] for h in lad["tried_before"]] == ["hash", "hash-simple"]
+    assert all(h["hung"] is False for h in lad["tried_before"])
 
 
-@pytest.mark.parametrize("who", ["1", "all"])
-def test_hanging_hash_loop_is_replaced_by_fresh_replica_ranks(who):
+@pytest.mark.parametrize("who,rungs,final", [("1", "0", "hash-simple"), ("all", "0,1", "replica")])
+def test_hanging_hash_loop_walks_down_the_ladder(who, rungs, final):
     """A collective that some rank never joins does not raise, it HANGS: after
-    GNNFLOW_HASH_MAIN_TIMEOUT every rank starts a fresh process that times the replica loop on a
-    new rendezvous port, and the ONE line says what happened (own launcher and torchrun alike)."""
+    GNNFLOW_HASH_MAIN_TIMEOUT every rank's worker process gives up and exits, and the rank's
+    supervisor (which never touches the GPU) starts a fresh worker for the NEXT rung on a new
+    rendezvous port — the hash loop in its simplest arrangement (1 lane, single chains), then
+    the replica loop — and the ONE line says what happened on the way (own launcher and torchrun
+    alike)."""
     env = {"GNNFLOW_BENCH_DEVICE": "0", "GNNFLOW_BENCH_BACKEND": "gloo",
-           "GNNFLOW_BENCH_HANG_HASH": who, "GNNFLOW_HASH_MAIN_TIMEOUT": "15"}
+           "GNNFLOW_BENCH_HANG_HASH": who, "GNNFLOW_BENCH_HANG_RUNGS": rungs,
+           "GNNFLOW_HASH_MAIN_TIMEOUT": "15", "GNNFLOW_PART_TRANSPORT": "ipc"}
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5",
            "--min-replays", "1", "--min-seconds", "0.2"]
     if who == "all":        # the driver's torchrun form: the agent's store must not be reused
@@ -152,8 +172,26 @@ def test_hanging_hash_loop_is_replaced_by_fresh_replica_ranks(who):
                "--master-addr", "127.0.0.1", "--master-port", "29577"] + cmd[1:]
     d = _run(cmd, env=env)
     _check_common(d, 2, 20, 5)
-    assert d["config"]["parallelism"] == "replica-dp2"
-    assert "did not finish within 15 s" in d["hash_partition"]["error"]
+    lad = d["ladder"]
+    assert lad["arrangement"] == final
+    tried = lad["tried_before"]
+    assert [h["arrangement"] for h in tried] == ["hash", "hash-simple"][:len(tried)]
+    assert all(h["hung"] and "did not finish within 15 s" in h["error"] for h in tried)
+    # every rung's ranks were gone (here: by themselves, after their watchdog fired) before the
+    # next rung's started
+    assert all(h["worker_killed"] is False and 15 <= h["seconds"] < 90 for h in tried)
+    if final == "replica":
+        assert d["config"]["parallelism"] == "replica-dp2" and len(tried) == 2
+        assert "did not finish within 15 s" in d["hash_partition"]["error"]
+    else:
+        # rung 1: the native chains over the library's communicator, one lane, single chains
+        assert d["config"]["parallelism"] == "hash-dp2" and len(tried) == 1
+        m = d["multi_gpu"]
+        assert m["lanes"] == 1 and m["chain_samples"] == 1 and m["transport"] == "ipc"
+        assert m["communicator_nranks"] == [2] and m["wire"]["slack"] == 2.0
+        a = m["all_to_all"]["reply_layer1"]
+        assert a["device_us"] > 0 and a["issue_us"] > 0 and a["bytes_per_peer"] > 0
+        assert m["projection"]["chains_sustain_us_per_step"] > 0
 
 
 def test_a_dying_rank_ends_the_launcher_non_zero_with_one_line():
