@@ -1029,6 +1029,10 @@ int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c, const in
         }));
   });
 }
+// `narrow_ids` of the shared-chain entry points: bit 0 = 12-byte reply records; bits 8..23 = the
+// compact reply slots' edge fill in 1/1000 (0: the fixed records travel)
+inline bool flag_narrow(int f) { return (f & 1) != 0; }
+inline double flag_edge_fill(int f) { return ((f >> 8) & 0xFFFF) / 1000.0; }
 int gf_sampler_part_group_ws_bytes(const gf_sampler* s, const size_t* roots, int m, int world_size,
                                    double slack, size_t slot_roots, int narrow_ids,
                                    size_t* bytes) {
@@ -1041,7 +1045,7 @@ int gf_sampler_part_group_ws_bytes(const gf_sampler* s, const size_t* roots, int
     for (int j = 0; j < m; ++j) R[j] = std::max<size_t>(roots[j], 1);
     *bytes = (slack > 0.0 && s->impl.group_ok(R, m))
                  ? gf::Sampler::group_ws_bytes(s->impl, R, m, world_size, slack, slot_roots,
-                                               narrow_ids != 0)
+                                               flag_narrow(narrow_ids), flag_edge_fill(narrow_ids))
                  : 0;
   });
 }
@@ -1075,7 +1079,7 @@ int gf_sampler_sample_partitioned_comm_group(gf_comm* c, const gf_group_sample* 
     }
     gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots,
                                           c ? &c->impl : nullptr, static_cast<hipStream_t>(stream),
-                                          static_cast<unsigned>(force_overflow), narrow_ids != 0);
+                                          static_cast<unsigned>(force_overflow), flag_narrow(narrow_ids), flag_edge_fill(narrow_ids));
     for (int j = 0; j < m; ++j) samples[j].sampler->begin_tickets.push_back(0);
   });
 }
@@ -1102,7 +1106,7 @@ int gf_sampler_sample_partitioned_comm_group_async(gf_comm* c, const gf_group_sa
          narrow_ids]() {
           gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots,
                                                 comm, st, static_cast<unsigned>(force_overflow),
-                                                narrow_ids != 0);
+                                                flag_narrow(narrow_ids), flag_edge_fill(narrow_ids));
         });
     for (int j = 0; j < m; ++j) samples[j].sampler->begin_tickets.push_back(t);
   });

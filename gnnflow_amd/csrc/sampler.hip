@@ -775,6 +775,7 @@ struct PaddedJob {
   uint64_t own_skip = 0;
   uint32_t m = 0;
   uint32_t* d_overflow_of[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* row_cnt = nullptr;   // inbox job, compact replies: valid slots of every served row
 };
 
 // d_own != null: "this rank's own share" of a chained partitioned layer — the last *d_own
@@ -837,6 +838,7 @@ __device__ inline void padded_job(const GraphView& g, const PaddedCommon& c, Pad
     }
     const uint32_t valid = valid_slots(n_cand, fanout, c.uniform);
     if (j.rec_cnt && lane == 0) j.rec_cnt[root_of[r]] = valid;
+    if (j.row_cnt && lane == 0) j.row_cnt[r] = valid;
     for (uint32_t k = lane; k < fanout; k += GROUP) {
       const uint64_t slot = r * fanout + k;
       if (c.narrow) {
@@ -1139,6 +1141,11 @@ struct MergeJob {
   uint32_t* d_overflow;
   int64_t* all_nodes; float* all_ts; float* dt; int64_t* eids; int64_t* row; int64_t* col;
   uint64_t* out_R; uint64_t* out_S; uint64_t* next_R;
+  // compact replies (null: the slots' rows are fixed-fanout rows of `rep` like the own share's):
+  // the received slots, cslot bytes each — u32 [0] edges of the slot, [r] edges before row r,
+  // [stride] the sender's overflow word, then the edges, edge_cap at most
+  const char* crep = nullptr;
+  uint32_t cslot = 0, edge_cap = 0, m = 1, jidx = 0, off_bytes = 4;
 };
 
 __device__ inline void merge_slots_fused_body(
@@ -1148,10 +1155,40 @@ __device__ inline void merge_slots_fused_body(
     uint32_t slot_rows, uint64_t* granules, uint64_t tag, uint32_t* d_overflow,
     int64_t* __restrict__ all_nodes, float* __restrict__ all_ts, float* __restrict__ dt,
     int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col,
-    uint64_t* out_R, uint64_t* out_S, uint64_t* next_R, int narrow = 0) {
+    uint64_t* out_R, uint64_t* out_S, uint64_t* next_R, int narrow = 0,
+    const char* __restrict__ crep = nullptr, uint32_t cslot = 0, uint32_t edge_cap = 0,
+    uint32_t gm = 1, uint32_t gj = 0, uint32_t off_bytes = 4) {
   // narrow: 0 = 24 B reply slots; 1 = 12 B slots {dst, eid, edge time}, the out time is the
   // edge's; 2 = 12 B slots, the out time is the root's (prop_time)
   const uint32_t* __restrict__ rep32 = reinterpret_cast<const uint32_t*>(rep);
+  const uint32_t cedges = (off_bytes * (stride + 1) + 15) & ~15u;   // a compact slot's edges
+  auto offset_at = [&](const char* base, uint32_t i) -> uint32_t {
+    return off_bytes == 2 ? reinterpret_cast<const uint16_t*>(base)[i]
+                          : reinterpret_cast<const uint32_t*>(base)[i];
+  };
+  // where slot j of the reply row p is: null = no such edge.  Rows of the peers' slots come
+  // in the compact form when `crep` is set, everything else as fixed-fanout rows of `rep`.
+  auto record = [&](uint32_t p, uint32_t j) -> const void* {
+    if (crep && p < slot_rows) {
+      const uint32_t sl = p / stride, rw = p - sl * stride;
+      const char* base = crep + static_cast<uint64_t>(sl) * cslot;
+      const uint32_t lo = min(offset_at(base, rw), edge_cap);
+      const uint32_t hi = min(offset_at(base, rw + 1 < stride ? rw + 1 : 0), edge_cap);
+      if (j >= hi - lo) return nullptr;
+      return base + cedges + static_cast<uint64_t>(lo + j) * (narrow ? 12 : 24);
+    }
+    if (narrow) {
+      const uint32_t* q = rep32 + (static_cast<uint64_t>(p) * fanout + j) * 3;
+      return q[0] != 0xFFFFFFFFu ? q : nullptr;
+    }
+    const int64_t* q = rep + (static_cast<uint64_t>(p) * fanout + j) * 3;
+    return q[0] >= 0 ? q : nullptr;
+  };
+  // a sender whose compact slot overflowed says so in every slot it sends: all ranks redo
+  if (crep && blockIdx.x == 0 && threadIdx.x * gm + gj < slot_rows / stride) {
+    const char* base = crep + static_cast<uint64_t>(threadIdx.x * gm + gj) * cslot;
+    if (offset_at(base, stride)) atomicOr(d_overflow, 1u);
+  }
   __shared__ uint32_t wave_cnt[kEmitThreads / 64];
   __shared__ uint32_t red[kEmitThreads / 64];
   const uint64_t R = d_R ? *d_R : R_host;
@@ -1177,24 +1214,19 @@ __device__ inline void merge_slots_fused_body(
     const uint32_t j = static_cast<uint32_t>(t - static_cast<uint64_t>(r) * fanout);
     const uint32_t p = pos[r];
     if (!(p < slot_rows && p % stride == 0)) {
-      if (narrow) {
-        const uint32_t* s = rep32 + (static_cast<uint64_t>(p) * fanout + j) * 3;
-        const uint32_t d = s[0];
-        valid = d != 0xFFFFFFFFu;
-        if (valid) {
-          s0 = static_cast<int64_t>(d);
-          s1 = static_cast<int64_t>(s[1]);
-          const float t = root_ts[r], ets = __uint_as_float(s[2]);
-          packed = static_cast<uint64_t>(pack_f32_pair(narrow == 2 ? t : ets, t - ets));
-        }
-      } else {
-        const int64_t* s = rep + (static_cast<uint64_t>(p) * fanout + j) * 3;
+      const void* rec = record(p, j);
+      valid = rec != nullptr;
+      if (valid && narrow) {
+        const uint32_t* s = static_cast<const uint32_t*>(rec);
+        s0 = static_cast<int64_t>(s[0]);
+        s1 = static_cast<int64_t>(s[1]);
+        const float t = root_ts[r], ets = __uint_as_float(s[2]);
+        packed = static_cast<uint64_t>(pack_f32_pair(narrow == 2 ? t : ets, t - ets));
+      } else if (valid) {
+        const int64_t* s = static_cast<const int64_t*>(rec);
         s0 = s[0];
-        valid = s0 >= 0;
-        if (valid) {
-          s1 = s[1];
-          packed = static_cast<uint64_t>(s[2]);
-        }
+        s1 = s[1];
+        packed = static_cast<uint64_t>(s[2]);
       }
     }
   }
@@ -1233,10 +1265,7 @@ __device__ inline void merge_slots_fused_body(
           const uint32_t ru = static_cast<uint32_t>(u / fanout);
           const uint32_t ju = static_cast<uint32_t>(u - static_cast<uint64_t>(ru) * fanout);
           const uint32_t pu = pos[ru];
-          if (!(pu < slot_rows && pu % stride == 0)) {
-            const uint64_t at = (static_cast<uint64_t>(pu) * fanout + ju) * 3;
-            cnt += (narrow ? rep32[at] != 0xFFFFFFFFu : rep[at] >= 0) ? 1u : 0u;
-          }
+          if (!(pu < slot_rows && pu % stride == 0)) cnt += record(pu, ju) != nullptr ? 1u : 0u;
         }
         g = cnt;
         atomicAdd(&g_merge_recounts, 1u);   // diagnostics (gf_debug_merge_recounts)
@@ -1295,7 +1324,87 @@ __global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_group_kernel(
   const MergeJob& j = jobs.j[blockIdx.y];
   merge_slots_fused_body(j.roots, j.root_ts, j.d_R, j.R_host, fanout, j.rep, j.pos, stride,
                          j.slot_rows, j.granules, j.tag, j.d_overflow, j.all_nodes, j.all_ts, j.dt,
-                         j.eids, j.row, j.col, j.out_R, j.out_S, j.next_R, narrow);
+                         j.eids, j.row, j.col, j.out_R, j.out_S, j.next_R, narrow, j.crep, j.cslot,
+                         j.edge_cap, j.m, j.jidx, j.off_bytes);
+}
+
+// Compact replies of a shared chain: one workgroup per received request slot turns the slot's
+// served rows (fixed `fanout` records each, of which a few hold an edge) into what travels back:
+// u32 [0] = edges of the slot, [r] = edges of the rows before row r (1 <= r < stride),
+// [stride] = "a slot of this sender overflowed its edge capacity" (written for ALL slots of the
+// sample by whichever workgroup finishes last: one atomic carries the ticket and the flag), then
+// the edges packed in row order.  Rows the request header does not announce hold nothing.
+// (The reference ships back exactly the sampled edges of a partition,
+// gnnflow/distributed/common.py:4-19, dist_sampler.py:244-314.)
+struct CompactArgs {
+  const int64_t* inbox;
+  const void* served;
+  const uint32_t* row_cnt;
+  char* cserved;
+  uint32_t* ticket;          // [m], zero between launches
+  uint32_t stride, fanout, m, world, edge_cap, cslot, narrow, off_bytes;
+};
+constexpr int kCompactThreads = 1024;
+__global__ __launch_bounds__(kCompactThreads) void reply_compact_kernel(CompactArgs a) {
+  const uint32_t sl = blockIdx.x, tid = threadIdx.x, stride = a.stride, F = a.fanout;
+  const uint64_t announced = static_cast<uint64_t>(a.inbox[2 * static_cast<uint64_t>(sl) * stride]);
+  const uint32_t rows = static_cast<uint32_t>(min(announced, static_cast<uint64_t>(stride - 1)));
+  char* base = a.cserved + static_cast<uint64_t>(sl) * a.cslot;
+  auto put = [&](char* slot, uint32_t i, uint32_t v) {
+    if (a.off_bytes == 2) reinterpret_cast<uint16_t*>(slot)[i] = static_cast<uint16_t>(min(v, 65535u));
+    else reinterpret_cast<uint32_t*>(slot)[i] = v;
+  };
+  char* edges = base + ((a.off_bytes * (stride + 1) + 15) & ~15u);
+  const uint32_t rb = a.narrow ? 12u : 24u;
+  __shared__ uint32_t wsum[kCompactThreads / 64];
+  __shared__ uint32_t carry;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b0 = 1; b0 < stride; b0 += kCompactThreads) {
+    const uint32_t r = b0 + tid;                         // row of the slot (row 0 is its header)
+    const uint64_t grow = static_cast<uint64_t>(sl) * stride + r;
+    const uint32_t cnt = (r < stride && r - 1 < rows) ? a.row_cnt[grow] : 0u;
+    uint32_t incl = cnt;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = carry, total = 0;
+#pragma unroll
+    for (int w = 0; w < kCompactThreads / 64; ++w) {
+      const uint32_t x = wsum[w];
+      if (w < wave) before += x;
+      total += x;
+    }
+    const uint32_t at = before + incl - cnt;
+    if (r < stride) put(base, r, at);
+    for (uint32_t k = 0; k < cnt; ++k) {
+      if (at + k >= a.edge_cap) break;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(
+          static_cast<const char*>(a.served) + (grow * F + k) * rb);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(edges + static_cast<uint64_t>(at + k) * rb);
+      for (uint32_t w = 0; w < rb / 4; ++w) dst[w] = src[w];
+    }
+    __syncthreads();
+    if (tid == 0) carry += total;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const uint32_t total = carry;
+    put(base, 0, total);
+    const uint32_t j = sl % a.m, ovf = total > a.edge_cap ? 1u : 0u;
+    const uint32_t prev = atomicAdd(&a.ticket[j], 1u + (ovf << 16));
+    if ((prev & 0xFFFFu) == a.world - 1) {       // the last of this sample's `world` slots
+      const uint32_t any = ((prev >> 16) + ovf) ? 1u : 0u;
+      for (uint32_t q = 0; q < a.world; ++q)
+        put(a.cserved + static_cast<uint64_t>(q * a.m + j) * a.cslot, stride, any);
+      a.ticket[j] = 0;
+    }
+  }
 }
 
 inline unsigned capped_grid(uint64_t work_items, unsigned per_block, unsigned cap) {
@@ -2384,11 +2493,11 @@ void part_host_us(double out[8], bool reset) {
 // fanout <= 256).  Layout of the shared workspace of layer l, rows of 16 B (requests) and
 // fanout x 24 B (replies):  [m P slots of `stride` rows | own share 0 | ... | own share m-1].
 size_t Sampler::group_ws_bytes(const Sampler& a, const size_t* R, int m, int world, double slack,
-                               size_t slot_roots, bool narrow) {
+                               size_t slot_roots, bool narrow, double edge_fill) {
   size_t total = 0;
   for (size_t l = 0; l < a.fanouts_.size(); ++l) {
     GroupLayout lay;
-    a.group_layout(R, m, static_cast<uint32_t>(l), world, slack, slot_roots, narrow, &lay);
+    a.group_layout(R, m, static_cast<uint32_t>(l), world, slack, slot_roots, narrow, edge_fill, &lay);
     total += lay.total;
   }
   return total;
@@ -2407,7 +2516,8 @@ bool Sampler::group_ok(const size_t* R, int m) const {
 }
 
 void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, double slack,
-                           size_t slot_roots, bool narrow, GroupLayout* out) const {
+                           size_t slot_roots, bool narrow, double edge_fill,
+                           GroupLayout* out) const {
   GF_REQUIRE(m >= 1 && m <= kMaxGroup, "group layout: 1..4 samples");
   gf_part_layout one;
   part_layout(std::max<size_t>(R[0], 1), layer, world, slack, slot_roots, &one);   // slot stride
@@ -2430,12 +2540,32 @@ void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, do
   out->served = at;   at = align_up(at + slot_rows * F * rb, 256);
   for (int j = 0; j < m; ++j) { out->counts[j] = at; at = align_up(at + static_cast<size_t>(world) * 8, 256); }
   for (int j = 0; j < m; ++j) { out->pos[j] = at; at = align_up(at + bound[j] * 4, 256); }
+  out->edge_cap = out->cslot = out->row_cnt = out->cserved = out->creplies = out->off_bytes = 0;
+  if (edge_fill > 0.0 && world > 1) {
+    // compact reply slot: offsets [0] = its edges, [r] = edges of the rows before row r
+    // (1 <= r < stride), [stride] = "a slot of this sender overflowed"; then the edges.  The
+    // first layer's roots are the batch itself — most of them have edges — while deeper layers
+    // thin out: layer l gets the share edge_fill^(l / (L - 1)) of its fixed records (1 for the
+    // first layer, edge_fill for the last).  16-bit offsets while the capacity allows.
+    const size_t L = fanouts_.size();
+    const double f = L > 1 ? std::pow(edge_fill, static_cast<double>(layer) / (L - 1)) : 1.0;
+    const size_t cap = static_cast<size_t>(
+        std::ceil(f * static_cast<double>((one.slot_stride - 1) * F)));
+    out->edge_cap = std::max<size_t>(cap, F);
+    out->off_bytes = out->edge_cap < 65535 ? 2 : 4;
+    out->cslot = align_up(out->off_bytes * (one.slot_stride + 1), 16) + align_up(out->edge_cap * rb, 16);
+    const size_t slots = static_cast<size_t>(m) * world;
+    out->row_cnt = at;  at = align_up(at + slot_rows * 4, 256);
+    out->cserved = at;  at = align_up(at + slots * out->cslot, 256);
+    out->creplies = at; at = align_up(at + slots * out->cslot, 256);
+  }
   out->total = at;
 }
 
 void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
                                        double slack, size_t slot_roots, Exchange* ex,
-                                       hipStream_t stream, unsigned force_overflow, bool narrow) {
+                                       hipStream_t stream, unsigned force_overflow, bool narrow,
+                                       double edge_fill) {
   GF_REQUIRE(gs != nullptr && m >= 1 && m <= kMaxGroup, "sample_partitioned_group: 1..4 samples");
   Sampler& a = *gs[0].s;
   size_t Rin[kMaxGroup];
@@ -2486,7 +2616,7 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
     for (int j = 0; j < m; ++j) Rs[j] = gs[j].s->part_.Rs;
     for (size_t l = 0; l < L; ++l) {
       GroupLayout lay;
-      a.group_layout(Rs, m, static_cast<uint32_t>(l), P, slack, slot_roots, narrow, &lay);
+      a.group_layout(Rs, m, static_cast<uint32_t>(l), P, slack, slot_roots, narrow, edge_fill, &lay);
       GF_REQUIRE(off + lay.total <= ws_bytes, "sample_partitioned_group: workspace too small");
       const size_t rb = narrow ? 12 : 24;
       char* base = w + off;
@@ -2544,6 +2674,8 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
                             a.part_overflow()};
       jobs.j[0].m = static_cast<uint32_t>(m);
       for (int j = 0; j < m; ++j) jobs.j[0].d_overflow_of[j] = gs[j].s->part_overflow();
+      const bool compact = ex != nullptr && lay.edge_cap > 0;
+      if (compact) jobs.j[0].row_cnt = reinterpret_cast<uint32_t*>(base + lay.row_cnt);
       for (int j = 0; j < m; ++j) {
         PaddedJob& own = jobs.j[1 + j];
         own = PaddedJob{requests, 0, gs[j].s->calls_++, replies,
@@ -2557,8 +2689,24 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
         GF_HIP(hipGetLastError());
       }
       lap(3);
-      // 4. the replies back
-      if (ex) ex->all_to_all(base + lay.served, replies, static_cast<size_t>(m) * stride * F * rb, stream);
+      // 4. the replies back: the sampled edges packed per slot (compact), or the fixed slots
+      if (compact) {
+        if (!a.part_ticket_.data()) {   // zero once: its last user of a launch clears it again
+          a.part_ticket_.reserve(256);
+          GF_HIP(hipMemsetAsync(a.part_ticket_.data(), 0, 256, stream));
+        }
+        reply_compact_kernel<<<dim3(static_cast<unsigned>(m * P)), dim3(kCompactThreads), 0, stream>>>(
+            CompactArgs{reinterpret_cast<const int64_t*>(base + lay.inbox), base + lay.served,
+                        reinterpret_cast<const uint32_t*>(base + lay.row_cnt), base + lay.cserved,
+                        a.part_ticket_.as<uint32_t>(), stride, F,
+                        static_cast<uint32_t>(m), static_cast<uint32_t>(P),
+                        static_cast<uint32_t>(lay.edge_cap), static_cast<uint32_t>(lay.cslot),
+                        narrow ? 1u : 0u, static_cast<uint32_t>(lay.off_bytes)});
+        GF_HIP(hipGetLastError());
+        ex->all_to_all(base + lay.cserved, base + lay.creplies, static_cast<size_t>(m) * lay.cslot, stream);
+      } else if (ex) {
+        ex->all_to_all(base + lay.served, replies, static_cast<size_t>(m) * stride * F * rb, stream);
+      }
       lap(4);
       // 5. all merges
       MergeJobs mj;
@@ -2572,6 +2720,14 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
                            reinterpret_cast<uint64_t*>(s.ws_.as<char>()), next_merge_tag(),
                            s.part_overflow(), out.all_nodes, out.all_ts, out.dt, out.eids, out.row,
                            out.col, cslot, cslot + 1, (l + 1 < L) ? cslot + 2 : nullptr};
+        if (compact) {
+          mj.j[j].crep = base + lay.creplies;
+          mj.j[j].cslot = static_cast<uint32_t>(lay.cslot);
+          mj.j[j].edge_cap = static_cast<uint32_t>(lay.edge_cap);
+          mj.j[j].m = static_cast<uint32_t>(m);
+          mj.j[j].jidx = static_cast<uint32_t>(j);
+          mj.j[j].off_bytes = static_cast<uint32_t>(lay.off_bytes);
+        }
       }
       {
         ProfileScope ps(kProfEmit, stream);

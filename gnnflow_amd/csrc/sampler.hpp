@@ -88,17 +88,22 @@ class Sampler {
   struct GroupLayout {
     size_t stride, slot_rows, own[kMaxGroup];                                   // rows
     size_t requests, replies, inbox, served, counts[kMaxGroup], pos[kMaxGroup], total;  // bytes
+    // compact replies (part_edge_fill_ > 0): what travels back is, per slot, the rows' edge
+    // offsets + the edges packed behind them — cslot bytes per slot, edge_cap edges at most
+    size_t edge_cap, off_bytes, cslot, row_cnt, cserved, creplies;
   };
+  // edge_fill: compact reply slots — a slot carries at most this share of its stride x fanout
+  // fixed-fanout records (0: the fixed records themselves travel).  Part of the wire format.
   bool group_ok(const size_t* R, int m) const;
   // narrow: 12-byte reply slots (ids that fit 32 bits; sampler.hip PaddedCommon)
   void group_layout(const size_t* R, int m, uint32_t layer, int world, double slack,
-                    size_t slot_roots, bool narrow, GroupLayout* out) const;
+                    size_t slot_roots, bool narrow, double edge_fill, GroupLayout* out) const;
   static size_t group_ws_bytes(const Sampler& a, const size_t* R, int m, int world, double slack,
-                               size_t slot_roots, bool narrow);
+                               size_t slot_roots, bool narrow, double edge_fill = 0.0);
   static void sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
                                        double slack, size_t slot_roots, Exchange* ex,
                                        hipStream_t stream, unsigned force_overflow = 0,
-                                       bool narrow = false);
+                                       bool narrow = false, double edge_fill = 0.0);
   void sample_partitioned(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                           size_t out_bytes, void* d_ws, size_t ws_bytes, hipStream_t stream);
   // several ranks, slotted form, the exchanges issued through `ex` (RCCL): the whole chain in
@@ -133,6 +138,7 @@ class Sampler {
   float window_;
   bool prop_time_;
   uint64_t seed_;
+  DeviceBuffer part_ticket_;   // reply_compact_kernel: "last slot of the sample" tickets
   uint64_t calls_ = 0;  // sample_layer invocations so far (uniform RNG counter)
   int search_group_ = 16;   // lanes per root, layers of <= 32 768 roots
   int large_group_ = 4;     // lanes per root, larger layers (sampler.hip: group_width_from_env)

@@ -579,7 +579,7 @@ class DevicePartitionedSampler:
 
     def __init__(self, sampler, group=None, always_exchange=False, slack=None, slot_roots=None,
                  comm=None, overlap=None, lanes=None, pair=None, chain_samples=None,
-                 narrow_ids=None, adapt_slack=None):
+                 narrow_ids=None, adapt_slack=None, edge_fill=None):
         """always_exchange: take the multi-rank path — request / reply exchange, served
         requests, merge — even with one rank (where every message is empty).  For tests: it
         is the only way to run the RCCL branch on a one-GPU box.
@@ -629,7 +629,18 @@ class DevicePartitionedSampler:
         before the first shared chain, from `graph.ids_fit_u32()` of every rank (one
         all-reduce; ranks that do not share a torch process group — the loopback transport —
         stay wide unless told).  Should a shard stop fitting later, its rank flags every sample
-        of its chains as overflowed and all ranks redo them through the wide form."""
+        of its chains as overflowed and all ranks redo them through the wide form.
+        edge_fill: COMPACT replies of the shared chains: a reply slot travels as its rows' edge
+        offsets + the sampled edges packed behind them (the reference ships back exactly the
+        sampled edges, gnnflow/distributed/common.py:4-19), with room for this share of the
+        slot's rows x fanout fixed records; a fuller slot flags the sample as overflowed (redo),
+        and with adapt_slack two of those within 64 samples raise the share by half.  Part of
+        the wire format: the same on every rank.  The share applies to the LAST layer; layer l
+        gets edge_fill^(l / (L - 1)) — the first layer, whose roots are the batch itself, all of
+        its records.  Default GNNFLOW_PART_EDGE_FILL, else 0.1 (on the REDDIT-shaped replay the
+        fullest layer-1 slot holds 0.045 of its records, a layer-0 slot half of them:
+        scripts/slack_needed.py);
+        0 = the fixed records travel (always so for single chains and the variable-size form)."""
         import ctypes as C
         import os
         from . import _capi
@@ -697,12 +708,22 @@ class DevicePartitionedSampler:
             self._lanes.append(_Lane(sampler.clone(), comms[k] if k < len(comms) else None,
                                      chain - 1))
         self.lanes = lanes
+        if edge_fill is None:
+            edge_fill = float(os.environ.get("GNNFLOW_PART_EDGE_FILL", "0.1"))
+        self._edge_fill = 0.0
+        self._set_edge_fill(max(0.0, min(float(edge_fill), 1.0)) if chain > 1 else 0.0)
         self._held = []            # samples (of one lane) waiting for their chain to fill
         self.pairs = 0             # chains that carried more than one sample
         self.chained = 0           # samples that travelled in such chains
         self._rr = 0               # round-robin cursor over the lanes
         self._layouts = {}     # (R0, slack) -> ([layouts per layer], [workspace offsets], total)
         self.overflows = 0     # slotted samples that had to be redone
+
+    def _set_edge_fill(self, fill: float):
+        """The compact reply slots' edge capacity (in 1/1000: it travels in the flags word of
+        the native calls, by value with every chain)."""
+        self._edge_fill = int(round(float(fill) * 1000)) / 1000.0
+        self._layouts = {}
 
     def comms(self):
         """The lanes' native communicators (those created so far)."""
@@ -716,14 +737,27 @@ class DevicePartitionedSampler:
         R0 = int(R0 or max(self._slot_roots, 1))
         lays = self._plan(R0, self._slack)[0] if self._slack > 0 else []
         rec = 12 if self._narrow else 24
-        req = rep = 0
-        for lay, F in zip(lays, self._fanouts):
-            rows = int(lay.slot_stride) * self._S
-            req += rows * 16
-            rep += rows * F * rec
+        fill = self._edge_fill if self.chain_samples > 1 else 0.0
+        req = rep = fixed = 0
+
+        def up16(x):
+            return (x + 15) & ~15
+        L = len(self._fanouts)
+        for l, (lay, F) in enumerate(zip(lays, self._fanouts)):
+            stride = int(lay.slot_stride)
+            req += stride * self._S * 16
+            fixed += stride * self._S * F * rec
+            if fill > 0:      # sampler.hip group_layout: offsets + packed edges
+                f = fill ** (l / (L - 1)) if L > 1 else 1.0
+                cap = max(int(np.ceil(f * (stride - 1) * F)), F)
+                rep += self._S * (up16((2 if cap < 65535 else 4) * (stride + 1)) + up16(cap * rec))
+            else:
+                rep += stride * self._S * F * rec
         return {"request_bytes_to_each_peer": req, "reply_bytes_to_each_peer": rep,
+                "reply_bytes_to_each_peer_fixed_slots": fixed,
                 "bytes_on_links_per_rank": (self._P - 1) * (req + rep),
-                "reply_record_bytes": rec, "slot_roots": R0, "slack": self._slack}
+                "reply_record_bytes": rec, "reply_edge_fill": fill, "slot_roots": R0,
+                "slack": self._slack}
 
     # the plain sampler's attributes the pipeline / cache helpers look at
     @property
@@ -870,10 +904,12 @@ class DevicePartitionedSampler:
         ws_bytes = 0
         if self._narrow is None:
             self._narrow = self._agree_on_narrow_ids(comm)
-        narrow = 1 if self._narrow else 0
+        # flags word of the native calls: bit 0 narrow records, bits 8.. the edge fill in 1/1000
+        narrow = (1 if self._narrow else 0) | \
+            ((int(round(self._edge_fill * 1000)) << 8) if (comm is not None and self._P > 1) else 0)
 
         def group_bytes(roots):
-            key = ("chain",) + tuple(roots)
+            key = ("chain", narrow) + tuple(roots)
             n = self._layouts.get(key)
             if n is None:
                 arr = (C.c_size_t * len(roots))(*roots)
@@ -900,7 +936,7 @@ class DevicePartitionedSampler:
                         Rs[j] = 0
                 ws_bytes = group_bytes([max(R, 1) for R in Rs])
                 assert ws_bytes, "a chain of fitting samples has a workspace"
-                if narrow and not self._sampler._graph.ids_fit_u32():
+                if (narrow & 1) and not self._sampler._graph.ids_fit_u32():
                     # this rank's shard outgrew the 12-byte slots: the wire format cannot change
                     # on one rank's say-so, so every sample of the chain is flagged and redone
                     force = (1 << m) - 1
@@ -1051,13 +1087,16 @@ class DevicePartitionedSampler:
         (chains that went out before the last step do not count) raise the capacity for the
         chains issued from now on — deterministically, so on every rank at the same sample."""
         self.overflows += 1
-        if not self._adapt_slack or epoch != self._slack_epoch or self._slack >= self._slack_cap:
+        if not self._adapt_slack or epoch != self._slack_epoch or \
+                (self._slack >= self._slack_cap and not 0.0 < self._edge_fill < 1.0):
             return
         recent = [w for w in self._recent_overflows if self._waited - w < 64] + [self._waited]
         self._recent_overflows = recent
         if len(recent) < 2:
             return
         self._slack = min(self._slack * 1.25, self._slack_cap)
+        if 0.0 < self._edge_fill < 1.0:     # a compact slot may have run out of edge room instead
+            self._set_edge_fill(min(self._edge_fill * 1.5, 1.0))
         self._slack_epoch += 1
         self._recent_overflows = []
         self._layouts = {}

@@ -604,6 +604,14 @@ typedef struct gf_group_sample {
   void* d_out;          /* gf_sampler_output_bytes(num_roots) bytes, as for gf_sampler_sample */
   size_t out_bytes;
 } gf_group_sample;
+/* `narrow_ids` of the three entry points below is a flags word: bit 0 = 12-byte reply records;
+ * bits 8..23 = COMPACT replies, the edge fill in 1/1000: a reply slot that travels back then holds,
+ * per request row, the offset of its edges and, packed behind the offsets, the edges themselves —
+ * at most fill x (slot rows x fanout) of them — instead of `fanout` fixed records per row, most of
+ * which are empty (the reference ships back exactly a partition's sampled edges,
+ * gnnflow/distributed/common.py:4-19, dist_sampler.py:244-314).  A slot with more edges flags the
+ * sample as overflowed on every rank (it is redone through the variable-size exchange).  Part of
+ * the wire format: the same on every rank; 0 = the fixed records travel. */
 GF_API int gf_sampler_part_group_ws_bytes(const gf_sampler* s, const size_t* roots, int m,
                                           int world_size, double slack, size_t slot_roots,
                                           int narrow_ids, size_t* bytes);

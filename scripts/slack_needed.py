@@ -29,20 +29,33 @@ smp = O.OracleSampler(full, F, "recent", threads=8)
 R0 = 1800
 bound = [R0, R0 * (1 + F[0])]
 need = {P: [0.0, 0.0] for P in (2, 4, 8)}       # largest bucket / (bound / P)
+eneed = {P: [0.0, 0.0] for P in (2, 4, 8)}      # most edges of one owner / (bound / P x fanout)
 fill = [0.0, 0.0]                                # largest root count / bound
 for i, (r, t, _) in enumerate(synthetic.replay_batches(g, 600)):
     if i % args.every:
         continue
     m = smp.sample(r, t)
     roots = [np.asarray(r), np.asarray(m[-1][0].srcdata["ID"])]     # layer 0, layer 1
+    blocks = [m[-1][0], m[0][0]]                                    # their sampled edges
     for l in range(2):
         fill[l] = max(fill[l], len(roots[l]) / bound[l])
+        erow = np.asarray(blocks[l].edges()[1])                     # root index of every edge
         for P in need:
-            b = np.bincount(owner_of_np(roots[l], P), minlength=P).max()
+            own = owner_of_np(roots[l], P)
+            b = np.bincount(own, minlength=P).max()
             need[P][l] = max(need[P][l], b / (bound[l] / P))
+            e = np.bincount(own[erow], minlength=P).max() if len(erow) else 0
+            eneed[P][l] = max(eneed[P][l], e / (bound[l] / P * F[l]))
 print(json.dumps({"what": "largest per-owner bucket over the replay, in units of the even share of "
                           "the layer's worst-case root count (= the smallest slack without overflow)",
                   "batches_used": "every {}th of 1121".format(args.every),
                   "largest_layer_over_worst_case": {"layer0": round(fill[0], 3), "layer1": round(fill[1], 3)},
                   "slack_needed": {"P={}".format(P): {"layer0": round(v[0], 3), "layer1": round(v[1], 3)}
-                                   for P, v in need.items()}}))
+                                   for P, v in need.items()},
+                  "edges_of_the_fullest_owner": {
+                      "what": "most sampled edges any one owner returns for a layer, in units of "
+                              "(even share of the worst-case roots) x fanout; divided by the slack "
+                              "it is the share of a reply slot's fixed records that hold an edge "
+                              "(the compact slots' edge_fill must cover it)",
+                      **{"P={}".format(P): {"layer0": round(v[0], 3), "layer1": round(v[1], 3)}
+                         for P, v in eneed.items()}}}))
