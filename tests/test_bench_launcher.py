@@ -20,8 +20,12 @@ def test_launcher_reports_failing_ranks_with_one_line():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    assert d["value"] == 0.0 and d["n_gpus"] == 2 and "exit codes" in d["error"]
-    assert "bench.py needs a GPU" in p.stderr          # the children's own message got through
+    # every rank is a supervisor that walks the ladder (hash, hash-simple, replica) with a fresh
+    # worker per rung; here every worker dies at once, and rank 0's supervisor says so
+    assert d["value"] == 0.0 and d["n_gpus"] == 2 and "no rung printed a record" in d["error"]
+    assert [h["arrangement"] for h in d["ladder"]] == ["hash", "hash-simple"]
+    assert all("exited with status" in h["error"] and not h["worker_killed"] for h in d["ladder"])
+    assert "bench.py needs a GPU" in p.stderr          # the workers' own message got through
 
 
 def test_launcher_parent_does_not_load_torch():
