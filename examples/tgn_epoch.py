@@ -3,7 +3,7 @@ the stand-in for BASELINE config 5's "end-to-end offline_edge_prediction.py epoc
 
 The reference's script and its model classes cannot travel to the GPU box (and need dgl), so
 this is the builder's OWN loop in the shape of scripts/offline_edge_prediction.py:343-454 —
-sample (prefetched one batch ahead) -> fetch_feature -> memory.prepare_input -> memory updater
+sample (prefetched two batches ahead, roots resident in HBM) -> fetch_feature -> memory.prepare_input -> memory updater
 -> model -> update_mem_mail -> loss / backward / step — over this package only:
 `TemporalSampler` (1 layer, fanout [10], most-recent, batch 4000 = 12 000 roots),
 `LRUCache` ratio 0.2 over 768-d node features, `gnnflow_amd.memory.Memory` (dim 100), and a
@@ -16,6 +16,7 @@ reference's loop accumulates them (the sample time is what the prefetch does not
     python examples/tgn_epoch.py [--nodes 1220000 --edges 13000000 --epochs 2]
 """
 import argparse
+from collections import deque
 import json
 import os
 import sys
@@ -142,7 +143,7 @@ def main():
     N, E, B = args.nodes, args.edges, args.batch
     t0 = time.time()
     g = synthetic.powerlaw_device(N, E, dev, seed=5, alpha=1.0, t_max=1e5)
-    del g["device"]
+    gd = g.pop("device")        # the same arrays, resident in HBM
     # gnnflow/config.py:169-179 (MAG): minimum block 11
     graph = gnnflow_amd.DynamicGraph(256 << 20, 16 << 30, "cuda", 11, 65536, "insert")
     for lo in range(0, E, 5_000_000):
@@ -160,15 +161,22 @@ def main():
     nb = n_train // B
     if args.max_batches:
         nb = min(nb, args.max_batches)
-    rng = np.random.RandomState(0)
     side = torch.cuda.Stream(device=dev)
     main_stream = torch.cuda.current_stream(dev)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    depth = 2                       # samples begun ahead of the batch being trained on
 
-    def roots_of(i):
-        lo = i * B
-        neg = rng.randint(0, N, B).astype(np.int64)
-        r = np.concatenate([g["src"][lo:lo + B], g["dst"][lo:lo + B], neg])
-        return torch.from_numpy(r).to(dev), torch.from_numpy(np.tile(g["ts"][lo:lo + B], 3)).to(dev)
+    def epoch_roots():
+        """Roots / timestamps of EVERY batch of the split, resident in HBM: [nb, 3 B] =
+        [src || dst || negatives] (gnnflow/utils.py:385-391), drawn once per epoch on the
+        device.  (Until round 5 each batch's roots were assembled in numpy and copied H2D on
+        the training stream, i.e. BEHIND the previous batch's model kernels: 1.0 ms of every
+        batch's "sample" time.)"""
+        n = nb * B
+        neg = torch.randint(0, N, (nb, B), device=dev, generator=gen, dtype=torch.int64)
+        roots = torch.cat([gd["src"][:n].view(nb, B), gd["dst"][:n].view(nb, B), neg], dim=1)
+        ts = gd["ts"][:n].view(nb, B).repeat(1, 3)
+        return roots.contiguous(), ts.contiguous()
 
     out = []
     for epoch in range(args.epochs):
@@ -178,14 +186,16 @@ def main():
         edges = 0
         torch.cuda.synchronize()
         e0 = time.perf_counter()
-        r, t = roots_of(0)
-        pending = sampler.sample_async(r, t, stream=side, worker_enqueue=True)
+        roots, rts = epoch_roots()
+        side.wait_stream(main_stream)               # the sampler reads them on the side stream
+        pending = deque(sampler.sample_async(roots[j], rts[j], stream=side, worker_enqueue=True)
+                        for j in range(min(depth, nb)))
         for i in range(nb):
             t0 = time.perf_counter()
-            mfgs = pending.wait()                     # what the prefetch did not hide
-            if i + 1 < nb:
-                r, t = roots_of(i + 1)
-                pending = sampler.sample_async(r, t, stream=side, worker_enqueue=True)
+            mfgs = pending.popleft().wait()           # what the prefetch did not hide
+            if i + depth < nb:
+                pending.append(sampler.sample_async(roots[i + depth], rts[i + depth], stream=side,
+                                                    worker_enqueue=True))
             for mfg in mfgs:
                 for b in mfg:
                     b.record_stream(main_stream)

@@ -2541,7 +2541,7 @@ void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, do
   for (int j = 0; j < m; ++j) { out->counts[j] = at; at = align_up(at + static_cast<size_t>(world) * 8, 256); }
   for (int j = 0; j < m; ++j) { out->pos[j] = at; at = align_up(at + bound[j] * 4, 256); }
   out->edge_cap = out->cslot = out->row_cnt = out->cserved = out->creplies = out->off_bytes = 0;
-  if (edge_fill > 0.0 && world > 1) {
+  if (edge_fill > 0.0) {
     // compact reply slot: offsets [0] = its edges, [r] = edges of the rows before row r
     // (1 <= r < stride), [stride] = "a slot of this sender overflowed"; then the edges.  The
     // first layer's roots are the batch itself — most of them have edges — while deeper layers

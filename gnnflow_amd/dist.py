@@ -839,7 +839,11 @@ class DevicePartitionedSampler:
         if lane.stream is None:
             import os
             prio = int(os.environ.get("GNNFLOW_PART_LANE_PRIORITY", "0"))
-            lane.stream = torch.cuda.Stream(device=self._device, priority=prio)
+            if prio:
+                lane.stream = torch.cuda.Stream(device=self._device, priority=prio)
+            else:       # from the process-wide set (pipeline.side_stream: hardware queues)
+                from .pipeline import side_stream
+                lane.stream = side_stream(self._device, k)
         return lane, lane.stream
 
     def sample_async(self, nodes, ts, stream=None, worker_enqueue=False):
@@ -906,7 +910,7 @@ class DevicePartitionedSampler:
             self._narrow = self._agree_on_narrow_ids(comm)
         # flags word of the native calls: bit 0 narrow records, bits 8.. the edge fill in 1/1000
         narrow = (1 if self._narrow else 0) | \
-            ((int(round(self._edge_fill * 1000)) << 8) if (comm is not None and self._P > 1) else 0)
+            ((int(round(self._edge_fill * 1000)) << 8) if comm is not None else 0)
 
         def group_bytes(roots):
             key = ("chain", narrow) + tuple(roots)
