@@ -398,7 +398,9 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
         # launch is timed: an event pair costs stream time, which at ~40 us per step would
         # distort the throughput measured in the same pass.
         ctx.lib.gf_profile_set_stride(args.event_stride)
-        ctx.lib.gf_profile_enable(1 << ctx.capi.PROFILE_SLOTS["gather"])
+        # ... and stream events around the LRU update behind every 17th gather
+        ctx.lib.gf_profile_enable((1 << ctx.capi.PROFILE_SLOTS["gather"]) |
+                                  (1 << ctx.capi.PROFILE_SLOTS["lru"]))
     acc = {"edges": 0}
 
     def account(_i, mfgs):
@@ -835,6 +837,28 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/" + PMC_TRAFFIC_FILE
         out["cache_edge_ratio"] = float(cache.cache_edge_ratio)
         out["cache_node_ratio"] = float(cache.cache_node_ratio)
+        # The other kernel of a step's fetch chain: the LRU list update (one launch:
+        # lru_list_fused_kernel).  Algorithmic bytes per update: the list rewrite (per slot:
+        # entry + mark read, entry + qpos written = 16 B, both caches), the block's rows (id +
+        # claim = 12 B each) and the installed rows (2 x 4 x d + 24 B of map / slot_id each;
+        # counted from the miss RATIOS, so repeated ids count twice: an upper bound).  A chain of
+        # dependent hops, not a bandwidth kernel: the fraction says how far from one it is.
+        l_ms, l_n = C.c_double(0), C.c_uint64(0)
+        lib.gf_profile_get(_capi.PROFILE_SLOTS["lru"], C.byref(l_ms), C.byref(l_n))
+        if l_n.value:
+            rows = rows_moved / max(n_launches, 1)
+            miss = 1.0 - 0.5 * (out["cache_edge_ratio"] + out["cache_node_ratio"])
+            lru_bytes = 16.0 * (cache.edge_capacity + cache.node_capacity) + 12.0 * rows + \
+                miss * rows * (8.0 * d_e + 24.0)
+            lru_us = 1e3 * l_ms.value / l_n.value
+            out["roofline_lru"] = {
+                "bound": "hbm", "kernel": "lru_list_fused_kernel", "unit": "GB/s",
+                "algorithmic_bytes_per_launch": lru_bytes, "avg_launch_us": lru_us,
+                "achieved": lru_bytes / (lru_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                "frac": lru_bytes / (lru_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "launches_timed": int(l_n.value),
+                "note": "stream events around the update's launch(es); latency chain of ~7 "
+                        "dependent hops, see DESIGN 3.4"}
 
     if main_kind == "hash":
         out["config"]["exchange"] = exchange_note(sampler, world, backend)

@@ -276,6 +276,7 @@ namespace gf {
 // sampler.hip
 void part_host_us(double out[8], bool reset);
 uint64_t merge_recounts();
+void philox_on_device(const uint64_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream);
 // feature_cache.hip
 uint64_t lru_recounts();
 // partition.hip
@@ -1171,6 +1172,12 @@ int gf_block_reduce_max_backward(size_t num_dst, const int64_t* d_col, size_t di
   });
 }
 
+int gf_debug_philox(const uint64_t* d_in, size_t n, uint32_t* d_out, void* stream) {
+  return guarded([&] {
+    GF_REQUIRE(n == 0 || (d_in != nullptr && d_out != nullptr), "gf_debug_philox: null buffer");
+    gf::philox_on_device(d_in, n, d_out, static_cast<hipStream_t>(stream));
+  });
+}
 int gf_debug_merge_recounts(uint64_t* out) {
   return guarded([&] {
     GF_REQUIRE(out != nullptr, "gf_debug_merge_recounts: null output");

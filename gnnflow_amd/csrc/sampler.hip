@@ -2461,6 +2461,22 @@ void Sampler::sample_partitioned_slotted(const int64_t* d_roots, const float* d_
   }
 }
 
+// gf_philox4x32_10_first evaluated ON THE DEVICE for n (seed, slot, call) triples: the uniform
+// sampler's draws share include/gnnflow_rng.h with the CPU oracle, so a device-side miscompile
+// of the Philox rounds would not show in HIP-vs-oracle parity; the Random123 known-answer
+// vectors evaluated here would (tests/test_gpu_sampler_parity.py).
+__global__ void philox_debug_kernel(const uint64_t* __restrict__ in, size_t n,
+                                    uint32_t* __restrict__ out) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = gf_philox4x32_10_first(in[3 * i], in[3 * i + 1], in[3 * i + 2]);
+}
+void philox_on_device(const uint64_t* d_in, size_t n, uint32_t* d_out, hipStream_t stream) {
+  if (n == 0) return;
+  philox_debug_kernel<<<dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream>>>(
+      d_in, n, d_out);
+  GF_HIP(hipGetLastError());
+}
+
 // Tiles whose look-back granule did not arrive in time and were recounted by the waiting thread
 // (fused merge), since the library was loaded, on the current device.
 uint64_t merge_recounts() {

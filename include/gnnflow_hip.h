@@ -694,6 +694,10 @@ GF_API int gf_debug_part_host_us(double out[8], int reset);
  * was loaded).  0 in normal operation; non-zero when the GPU is heavily oversubscribed (several
  * rank processes sharing one card).  Synchronises nothing but the copy itself. */
 GF_API int gf_debug_merge_recounts(uint64_t* out);
+/* d_out[i] = gf_philox4x32_10_first(seed, slot, call) of d_in[i] = {seed, slot, call}, evaluated by
+ * a kernel: the Random123 known-answer vectors checked ON THE DEVICE (include/gnnflow_rng.h is
+ * shared with the CPU oracle, so parity alone would not catch a device-side miscompile). */
+GF_API int gf_debug_philox(const uint64_t* d_in, size_t n, uint32_t* d_out, void* stream);
 /* The same for the one-launch LRU list update (lru_list_fused_kernel): granules {launch tag,
  * count} a waiting workgroup did not see within its polling budget and recomputed from the
  * launch's inputs.  0 in normal operation. */

@@ -411,3 +411,33 @@ def test_many_asynchronous_samples_in_flight_and_a_failing_one():
         assert torch.equal(mf[0][0].edata["ID"], want[0][0].edata["ID"])
     assert len(s._inflight) == 0
     assert s.sample(nb, tb)[0][0].num_dst_nodes() > 0   # the same roots work once sized right
+
+
+def test_philox_known_answers_on_the_device():
+    """The three Random123 Philox4x32-10 known-answer vectors (kat_vectors) evaluated by a
+    KERNEL (gf_debug_philox), not on the host: the uniform sampler and the CPU oracle share
+    include/gnnflow_rng.h, so HIP-vs-oracle parity alone would not notice a device-side
+    miscompile of the rounds that stayed uniform.  Plus 20 000 random (seed, slot, call)
+    triples against the oracle's host evaluation."""
+    import ctypes as C
+    import torch
+    from gnnflow_amd import _capi
+    from oracle import oracle as O
+    lib = _capi.load()
+    full = 0xFFFFFFFFFFFFFFFF
+    kat = [((0, 0, 0), 0x6627E8D5), ((full, full, full), 0x408F276D),
+           (((0x299F31D0 << 32) | 0xA4093822, (0x85A308D3 << 32) | 0x243F6A88,
+             (0x03707344 << 32) | 0x13198A2E), 0xD16CFE09)]      # counter / key = digits of pi
+    rng = np.random.RandomState(7)
+    extra = rng.randint(0, 1 << 63, size=(20000, 3)).astype(np.uint64) * 2 + \
+        rng.randint(0, 2, size=(20000, 3)).astype(np.uint64)
+    triples = np.concatenate([np.array([k for k, _ in kat], dtype=np.uint64), extra])
+    d_in = torch.from_numpy(triples.view(np.int64)).cuda()
+    d_out = torch.zeros(len(triples), dtype=torch.int32, device="cuda")
+    _capi.check(lib.gf_debug_philox(C.c_void_p(d_in.data_ptr()), len(triples),
+                                    C.c_void_p(d_out.data_ptr()), None))
+    got = d_out.cpu().numpy().view(np.uint32)
+    assert [int(x) for x in got[:3]] == [v for _, v in kat]
+    want = np.array([O.philox_first(int(s), int(t), int(c)) for s, t, c in extra[:2000]],
+                    dtype=np.uint32)
+    assert np.array_equal(got[3:2003], want)
