@@ -65,7 +65,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
-PMC_TRAFFIC_FILE = "r04_pmc_gather_traffic.json"
+PMC_TRAFFIC_FILE = "r05_pmc_gather_traffic.json"
 
 
 def workload_key(args):
@@ -132,7 +132,7 @@ def parse(argv=None):
     ap.add_argument("--pipeline-depth", type=int, default=None,
                     help="batches whose sample() is in flight ahead of the fetch (default 2; "
                          "three per lane of the partitioned sampler)")
-    ap.add_argument("--event-stride", type=int, default=17,
+    ap.add_argument("--event-stride", type=int, default=61,
                     help="time every n-th gather launch with HIP events (1 = all)")
     ap.add_argument("--breakdown", action="store_true",
                     help="extra untimed pass with per-kernel-family HIP-event times")
@@ -394,11 +394,13 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
         cache.rows_moved = 0
     if main_leg:
         ctx.lib.gf_profile_reset()
-        # HIP events on the gather launches of the timed region, on their stream.  Every 17th
-        # launch is timed: an event pair costs stream time, which at ~40 us per step would
-        # distort the throughput measured in the same pass.
+        # HIP events on the gather launches of the timed region, on their stream.  Every 61st
+        # launch is timed: an event pair costs stream time, which at ~30 us per step distorts
+        # both the throughput measured in the same pass and the launches it times (same box,
+        # round 5: gather 13.4 us with every launch timed at 42 us per step, 13.9 at every 5th,
+        # 15.3 at every 17th, 14.3 at every 64th at 28.1 us per step; rocprofv3: 12.7-13.1).
         ctx.lib.gf_profile_set_stride(args.event_stride)
-        # ... and stream events around the LRU update behind every 17th gather
+        # ... and stream events around the LRU update behind every 61st gather
         ctx.lib.gf_profile_enable((1 << ctx.capi.PROFILE_SLOTS["gather"]) |
                                   (1 << ctx.capi.PROFILE_SLOTS["lru"]))
     acc = {"edges": 0}

@@ -82,10 +82,18 @@ def sweep(N, E, batches, policies, dev, reps=10, emit=None):
             # per root 12 (id, ts) + 16 (table entry) + 8 * ceil(log2 deg) + 4
             # (count); per edge 20 read + 40 written
             search_bytes = 0.0
-            for b in blocks:
-                ids = b.srcdata["ID"][:b.num_dst_nodes()]
-                d = deg[ids].clamp(min=2).to(torch.float64)
-                search_bytes += float((28 + 4 + 8 * torch.ceil(torch.log2(d))).sum())
+            per_layer = []
+            for li, mfg in enumerate(reversed(m)):          # m[-1] is the roots' layer
+                lb = 0.0
+                for b in mfg:
+                    ids = b.srcdata["ID"][:b.num_dst_nodes()]
+                    d = deg[ids].clamp(min=2).to(torch.float64)
+                    lb += float((28 + 4 + 8 * torch.ceil(torch.log2(d))).sum())
+                search_bytes += lb
+                per_layer.append({"layer": li, "roots": int(sum(b.num_dst_nodes() for b in mfg)),
+                                  "edges": int(sum(b.num_edges() for b in mfg)),
+                                  "search_alg_MB": lb / 1e6,
+                                  "emit_alg_MB": sum(b.num_edges() for b in mfg) * 60.0 / 1e6})
             emit_bytes = edges * 60.0
             ms_s, _ = prof("search")
             ms_e, _ = prof("emit")
@@ -99,6 +107,7 @@ def sweep(N, E, batches, policies, dev, reps=10, emit=None):
                 "wall_us": 1e6 * wall, "edges_per_s": edges / wall,
                 "search_us": us(ms_s), "emit_us": us(ms_e), "scan_us": us(ms_c),
                 "search_alg_MB": search_bytes / 1e6, "emit_alg_MB": emit_bytes / 1e6,
+                "layers": per_layer,
                 "search_GBps": search_bytes / (us(ms_s) * 1e-6) / 1e9 if ms_s else None,
                 "emit_GBps": emit_bytes / (us(ms_e) * 1e-6) / 1e9 if ms_e else None,
                 # the whole sample(): against the kernels' summed time, and against the wall clock
