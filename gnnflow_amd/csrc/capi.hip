@@ -1034,6 +1034,8 @@ int gf_sampler_sample_partitioned_comm_async(gf_sampler* s, gf_comm* c, const in
 // compact reply slots' edge fill in 1/1000 (0: the fixed records travel)
 inline bool flag_narrow(int f) { return (f & 1) != 0; }
 inline double flag_edge_fill(int f) { return ((f >> 8) & 0xFFFF) / 1000.0; }
+// bit 1: layer l + 1 does not request layer l's roots again (most-recent, equal fanouts)
+inline bool flag_reuse(int f) { return (f & 2) != 0; }
 int gf_sampler_part_group_ws_bytes(const gf_sampler* s, const size_t* roots, int m, int world_size,
                                    double slack, size_t slot_roots, int narrow_ids,
                                    size_t* bytes) {
@@ -1080,7 +1082,7 @@ int gf_sampler_sample_partitioned_comm_group(gf_comm* c, const gf_group_sample* 
     }
     gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots,
                                           c ? &c->impl : nullptr, static_cast<hipStream_t>(stream),
-                                          static_cast<unsigned>(force_overflow), flag_narrow(narrow_ids), flag_edge_fill(narrow_ids));
+                                          static_cast<unsigned>(force_overflow), flag_narrow(narrow_ids), flag_edge_fill(narrow_ids), flag_reuse(narrow_ids));
     for (int j = 0; j < m; ++j) samples[j].sampler->begin_tickets.push_back(0);
   });
 }
@@ -1107,7 +1109,8 @@ int gf_sampler_sample_partitioned_comm_group_async(gf_comm* c, const gf_group_sa
          narrow_ids]() {
           gf::Sampler::sample_partitioned_group(gs.data(), m, d_ws, ws_bytes, slack, slot_roots,
                                                 comm, st, static_cast<unsigned>(force_overflow),
-                                                flag_narrow(narrow_ids), flag_edge_fill(narrow_ids));
+                                                flag_narrow(narrow_ids), flag_edge_fill(narrow_ids),
+                                                flag_reuse(narrow_ids));
         });
     for (int j = 0; j < m; ++j) samples[j].sampler->begin_tickets.push_back(t);
   });

@@ -172,8 +172,11 @@ __device__ inline void plan_fused_body(
     int64_t* __restrict__ requests, uint32_t* __restrict__ pos, uint64_t* __restrict__ counts,
     uint32_t* __restrict__ root_of, uint32_t stride, uint32_t* __restrict__ d_overflow,
     int overflow_store, uint32_t slot_mul, uint32_t slot_add, uint32_t own_base,
-    uint32_t force_overflow = 0) {
+    uint32_t force_overflow = 0, const uint64_t* __restrict__ d_skip = nullptr,
+    uint64_t skip_host = 0) {
   const uint32_t P = od.P;
+  // roots [0, skip) are not requested (PlanJob::d_skip): they count for nobody
+  const uint32_t skip = static_cast<uint32_t>(d_skip ? *d_skip : skip_host);
   __shared__ uint32_t s_before[kFusedThreads / 64][kMaxParts];
   __shared__ uint32_t s_total[kFusedThreads / 64][kMaxParts];
   __shared__ uint32_t s_tile[kFusedThreads / 64][kMaxParts];   // this tile, per wave
@@ -199,7 +202,7 @@ __device__ inline void plan_fused_body(
     for (uint32_t b = 0; b < kBatch; ++b) {
       const uint32_t k = k0 + b;
       const uint32_t i = k * kFusedThreads + tid;
-      const uint32_t o = i < R ? owner_of(v[b], od) : P;   // P = "no root"
+      const uint32_t o = (i < R && i >= skip) ? owner_of(v[b], od) : P;   // P = "no root"
       if (k == tile) { my_owner = o; my_node = v[b]; }
       uint32_t mine = 0;
       for (uint32_t q = 0; q < P; ++q) {
@@ -262,6 +265,10 @@ __device__ inline void plan_fused_body(
   __syncthreads();
   const uint32_t i = tile * kFusedThreads + tid;
   if (i >= R) return;
+  if (i < skip) {
+    pos[i] = kPosReused;
+    return;
+  }
   uint32_t p = s_start[my_owner] + s_before[0][my_owner] + before_in_wave;
   for (int w = 0; w < wave; ++w) p += s_tile[w][my_owner];
   if (stride && my_owner != rank && p - s_start[my_owner] >= stride - 1) {   // beyond the slot
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(kFusedThreads) void partition_plan_jobs_kernel(
   const PlanJob& j = jobs.j[blockIdx.y];
   plan_fused_body(j.nodes, j.ts, j.d_R, j.R_host, od, rank, j.requests, j.pos, j.counts, nullptr,
                   stride, j.d_overflow, j.overflow_store, j.slot_mul, j.slot_add, j.own_base,
-                  j.force_overflow);
+                  j.force_overflow, j.d_skip, j.skip_host);
 }
 
 }  // namespace

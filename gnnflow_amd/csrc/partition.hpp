@@ -37,7 +37,13 @@ struct PlanJob {
   uint32_t force_overflow;  // 1: flag the sample as overflowed whatever its slots hold (the
                             // caller submitted an empty stand-in for a batch too large for
                             // this chain; every rank then redoes that sample)
+  // The first *d_skip (or skip_host) roots are NOT requested: they are the previous layer's own
+  // roots with the same timestamps, whose most recent neighbours the previous block already
+  // holds (the merge takes them from there); their pos[] is kPosReused.
+  const uint64_t* d_skip = nullptr;
+  uint64_t skip_host = 0;
 };
+constexpr uint32_t kPosReused = 0xFFFFFFFEu;
 // `n` jobs (1..4) in one launch; R_bound sizes the grid (the largest job's bound).
 void partition_plan_jobs(const PlanJob* jobs, int n, size_t R_bound, int world_size, int rank,
                          uint32_t stride, int device, hipStream_t stream);

@@ -1146,6 +1146,21 @@ struct MergeJob {
   // [stride] the sender's overflow word, then the edges, edge_cap at most
   const char* crep = nullptr;
   uint32_t cslot = 0, edge_cap = 0, m = 1, jidx = 0, off_bytes = 4;
+  // reuse of the previous layer (roots whose pos[] is kPosReused): root r < R_prev of this
+  // layer IS root r of the previous one, same timestamp, and its edges are entries
+  // [first_prev[r], first_prev[r + 1]) of the previous block; first_out[r] = this block's first
+  // edge of root r (R + 1 entries), for the next layer
+  const uint32_t* first_prev = nullptr;
+  const uint64_t* d_R_prev = nullptr;
+  uint64_t R_prev_host = 0;
+  const int64_t* nodes_prev = nullptr; const float* ts_prev = nullptr;
+  const float* dt_prev = nullptr; const int64_t* eids_prev = nullptr;
+  uint32_t* first_out = nullptr;
+};
+struct MergeReuse {
+  const uint32_t* first_prev; uint64_t R_prev;
+  const int64_t* nodes_prev; const float* ts_prev; const float* dt_prev; const int64_t* eids_prev;
+  uint32_t* first_out;
 };
 
 __device__ inline void merge_slots_fused_body(
@@ -1157,7 +1172,8 @@ __device__ inline void merge_slots_fused_body(
     int64_t* __restrict__ eids, int64_t* __restrict__ row, int64_t* __restrict__ col,
     uint64_t* out_R, uint64_t* out_S, uint64_t* next_R, int narrow = 0,
     const char* __restrict__ crep = nullptr, uint32_t cslot = 0, uint32_t edge_cap = 0,
-    uint32_t gm = 1, uint32_t gj = 0, uint32_t off_bytes = 4) {
+    uint32_t gm = 1, uint32_t gj = 0, uint32_t off_bytes = 4,
+    MergeReuse reuse = MergeReuse{nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr}) {
   // narrow: 0 = 24 B reply slots; 1 = 12 B slots {dst, eid, edge time}, the out time is the
   // edge's; 2 = 12 B slots, the out time is the root's (prop_time)
   const uint32_t* __restrict__ rep32 = reinterpret_cast<const uint32_t*>(rep);
@@ -1198,6 +1214,7 @@ __device__ inline void merge_slots_fused_body(
       *out_R = 0;
       *out_S = 0;
       if (next_R) *next_R = 0;
+      if (reuse.first_out) reuse.first_out[0] = 0;
     }
     return;
   }
@@ -1213,7 +1230,18 @@ __device__ inline void merge_slots_fused_body(
     r = static_cast<uint32_t>(t / fanout);
     const uint32_t j = static_cast<uint32_t>(t - static_cast<uint64_t>(r) * fanout);
     const uint32_t p = pos[r];
-    if (!(p < slot_rows && p % stride == 0)) {
+    if (p == kPosReused) {
+      // the previous block holds this root's edges (same root, same time, same fanout)
+      const uint32_t lo = reuse.first_prev[r], hi = reuse.first_prev[r + 1];
+      valid = j < hi - lo;
+      if (valid) {
+        const uint32_t e = lo + j;
+        s0 = reuse.nodes_prev[reuse.R_prev + e];
+        s1 = reuse.eids_prev[e];
+        packed = static_cast<uint64_t>(
+            pack_f32_pair(reuse.ts_prev[reuse.R_prev + e], reuse.dt_prev[e]));
+      }
+    } else if (!(p < slot_rows && p % stride == 0)) {
       const void* rec = record(p, j);
       valid = rec != nullptr;
       if (valid && narrow) {
@@ -1265,7 +1293,9 @@ __device__ inline void merge_slots_fused_body(
           const uint32_t ru = static_cast<uint32_t>(u / fanout);
           const uint32_t ju = static_cast<uint32_t>(u - static_cast<uint64_t>(ru) * fanout);
           const uint32_t pu = pos[ru];
-          if (!(pu < slot_rows && pu % stride == 0)) cnt += record(pu, ju) != nullptr ? 1u : 0u;
+          if (pu == kPosReused)
+            cnt += ju < reuse.first_prev[ru + 1] - reuse.first_prev[ru] ? 1u : 0u;
+          else if (!(pu < slot_rows && pu % stride == 0)) cnt += record(pu, ju) != nullptr ? 1u : 0u;
         }
         g = cnt;
         atomicAdd(&g_merge_recounts, 1u);   // diagnostics (gf_debug_merge_recounts)
@@ -1286,6 +1316,8 @@ __device__ inline void merge_slots_fused_body(
       all_nodes[t] = roots[t];
       all_ts[t] = root_ts[t];
     }
+    if (reuse.first_out && t % fanout == 0)   // slot 0 of root r: the edges before root r
+      reuse.first_out[r] = base + wbase + before;
     if (valid) {
       const uint64_t o = static_cast<uint64_t>(base) + wbase + before;
       all_nodes[R + o] = s0;
@@ -1301,6 +1333,7 @@ __device__ inline void merge_slots_fused_body(
     *out_R = R;
     *out_S = S;
     if (next_R) *next_R = R + S;
+    if (reuse.first_out) reuse.first_out[R] = static_cast<uint32_t>(S);
   }
 }
 
@@ -1325,7 +1358,9 @@ __global__ __launch_bounds__(kEmitThreads) void merge_slots_fused_group_kernel(
   merge_slots_fused_body(j.roots, j.root_ts, j.d_R, j.R_host, fanout, j.rep, j.pos, stride,
                          j.slot_rows, j.granules, j.tag, j.d_overflow, j.all_nodes, j.all_ts, j.dt,
                          j.eids, j.row, j.col, j.out_R, j.out_S, j.next_R, narrow, j.crep, j.cslot,
-                         j.edge_cap, j.m, j.jidx, j.off_bytes);
+                         j.edge_cap, j.m, j.jidx, j.off_bytes,
+                         MergeReuse{j.first_prev, j.d_R_prev ? *j.d_R_prev : j.R_prev_host,
+                                    j.nodes_prev, j.ts_prev, j.dt_prev, j.eids_prev, j.first_out});
 }
 
 // Compact replies of a shared chain: one workgroup per received request slot turns the slot's
@@ -2556,6 +2591,9 @@ void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, do
   out->served = at;   at = align_up(at + slot_rows * F * rb, 256);
   for (int j = 0; j < m; ++j) { out->counts[j] = at; at = align_up(at + static_cast<size_t>(world) * 8, 256); }
   for (int j = 0; j < m; ++j) { out->pos[j] = at; at = align_up(at + bound[j] * 4, 256); }
+  // first edge of every root in the merged block (+ the total): what the NEXT layer needs to
+  // take the edges of the roots it does not request again from this block
+  for (int j = 0; j < m; ++j) { out->first[j] = at; at = align_up(at + (bound[j] + 1) * 4, 256); }
   out->edge_cap = out->cslot = out->row_cnt = out->cserved = out->creplies = out->off_bytes = 0;
   if (edge_fill > 0.0) {
     // compact reply slot: offsets [0] = its edges, [r] = edges of the rows before row r
@@ -2581,7 +2619,7 @@ void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, do
 void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
                                        double slack, size_t slot_roots, Exchange* ex,
                                        hipStream_t stream, unsigned force_overflow, bool narrow,
-                                       double edge_fill) {
+                                       double edge_fill, bool reuse_roots) {
   GF_REQUIRE(gs != nullptr && m >= 1 && m <= kMaxGroup, "sample_partitioned_group: 1..4 samples");
   Sampler& a = *gs[0].s;
   size_t Rin[kMaxGroup];
@@ -2630,7 +2668,15 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
     size_t off = 0;
     size_t Rs[kMaxGroup];
     for (int j = 0; j < m; ++j) Rs[j] = gs[j].s->part_.Rs;
+    const uint32_t* first_prev[kMaxGroup] = {nullptr, nullptr, nullptr, nullptr};
     for (size_t l = 0; l < L; ++l) {
+      // Layer l's first roots ARE layer l - 1's roots, with the same timestamps (all_nodes =
+      // roots ++ neighbours): with most-recent sampling and the same fanout their k most recent
+      // neighbours are what the previous block already holds, so they are neither bucketed nor
+      // requested nor sampled again — the merge copies their edges out of the previous block
+      // (the reference requests every root of every layer, dist_sampler.py:174-186).
+      const bool reuse = reuse_roots && l > 0 && a.policy_ != GF_SAMPLING_POLICY_UNIFORM &&
+                         a.fanouts_[l] == a.fanouts_[l - 1];
       GroupLayout lay;
       a.group_layout(Rs, m, static_cast<uint32_t>(l), P, slack, slot_roots, narrow, edge_fill, &lay);
       GF_REQUIRE(off + lay.total <= ws_bytes, "sample_partitioned_group: workspace too small");
@@ -2656,6 +2702,11 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
                         gs[j].s->part_overflow(), l == 0 ? 1 : 0, static_cast<uint32_t>(m),
                         static_cast<uint32_t>(j), static_cast<uint32_t>(lay.own[j]),
                         (force_overflow >> j) & 1u};
+        if (reuse) {
+          const int64_t* r_; const float* t_;
+          gs[j].s->part_roots(static_cast<uint32_t>(l - 1), 0, &r_, &t_, &pj[j].d_skip,
+                              &pj[j].skip_host);
+        }
       }
       partition_plan_jobs(pj, m, bound, P, me, stride, a.graph_->device(), stream);
       lap(1);
@@ -2744,6 +2795,19 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
           mj.j[j].jidx = static_cast<uint32_t>(j);
           mj.j[j].off_bytes = static_cast<uint32_t>(lay.off_bytes);
         }
+        mj.j[j].first_out = reinterpret_cast<uint32_t*>(base + lay.first[j]);
+        if (reuse) {
+          const int64_t* r_; const float* t_;
+          s.part_roots(static_cast<uint32_t>(l - 1), 0, &r_, &t_, &mj.j[j].d_R_prev,
+                       &mj.j[j].R_prev_host);
+          const BlockPtrs& pb = s.part_.slot->ptrs[l - 1];
+          mj.j[j].first_prev = first_prev[j];
+          mj.j[j].nodes_prev = pb.all_nodes;
+          mj.j[j].ts_prev = pb.all_ts;
+          mj.j[j].dt_prev = pb.dt;
+          mj.j[j].eids_prev = pb.eids;
+        }
+        first_prev[j] = reinterpret_cast<const uint32_t*>(base + lay.first[j]);
       }
       {
         ProfileScope ps(kProfEmit, stream);

@@ -88,6 +88,7 @@ class Sampler {
   struct GroupLayout {
     size_t stride, slot_rows, own[kMaxGroup];                                   // rows
     size_t requests, replies, inbox, served, counts[kMaxGroup], pos[kMaxGroup], total;  // bytes
+    size_t first[kMaxGroup];   // u32 [roots + 1]: first edge of every root in the merged block
     // compact replies (part_edge_fill_ > 0): what travels back is, per slot, the rows' edge
     // offsets + the edges packed behind them — cslot bytes per slot, edge_cap edges at most
     size_t edge_cap, off_bytes, cslot, row_cnt, cserved, creplies;
@@ -103,7 +104,8 @@ class Sampler {
   static void sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
                                        double slack, size_t slot_roots, Exchange* ex,
                                        hipStream_t stream, unsigned force_overflow = 0,
-                                       bool narrow = false, double edge_fill = 0.0);
+                                       bool narrow = false, double edge_fill = 0.0,
+                                       bool reuse_roots = false);
   void sample_partitioned(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                           size_t out_bytes, void* d_ws, size_t ws_bytes, hipStream_t stream);
   // several ranks, slotted form, the exchanges issued through `ex` (RCCL): the whole chain in

@@ -579,7 +579,7 @@ class DevicePartitionedSampler:
 
     def __init__(self, sampler, group=None, always_exchange=False, slack=None, slot_roots=None,
                  comm=None, overlap=None, lanes=None, pair=None, chain_samples=None,
-                 narrow_ids=None, adapt_slack=None, edge_fill=None):
+                 narrow_ids=None, adapt_slack=None, edge_fill=None, reuse_roots=None):
         """always_exchange: take the multi-rank path — request / reply exchange, served
         requests, merge — even with one rank (where every message is empty).  For tests: it
         is the only way to run the RCCL branch on a one-GPU box.
@@ -640,7 +640,12 @@ class DevicePartitionedSampler:
         its records.  Default GNNFLOW_PART_EDGE_FILL, else 0.1 (on the REDDIT-shaped replay the
         fullest layer-1 slot holds 0.045 of its records, a layer-0 slot half of them:
         scripts/slack_needed.py);
-        0 = the fixed records travel (always so for single chains and the variable-size form)."""
+        0 = the fixed records travel (always so for single chains and the variable-size form).
+        reuse_roots: layer l + 1's first roots ARE layer l's roots with the same timestamps; with
+        most-recent sampling and equal fanouts the shared chains neither request nor sample them
+        again — the merge takes their edges from layer l's block (the reference requests every
+        root of every layer, dist_sampler.py:174-186).  Part of the protocol: the same on every
+        rank.  Default GNNFLOW_PART_REUSE_ROOTS or on."""
         import ctypes as C
         import os
         from . import _capi
@@ -708,6 +713,9 @@ class DevicePartitionedSampler:
             self._lanes.append(_Lane(sampler.clone(), comms[k] if k < len(comms) else None,
                                      chain - 1))
         self.lanes = lanes
+        if reuse_roots is None:
+            reuse_roots = os.environ.get("GNNFLOW_PART_REUSE_ROOTS", "1") != "0"
+        self._reuse_roots = bool(reuse_roots)
         if edge_fill is None:
             edge_fill = float(os.environ.get("GNNFLOW_PART_EDGE_FILL", "0.1"))
         self._edge_fill = 0.0
@@ -909,7 +917,7 @@ class DevicePartitionedSampler:
         if self._narrow is None:
             self._narrow = self._agree_on_narrow_ids(comm)
         # flags word of the native calls: bit 0 narrow records, bits 8.. the edge fill in 1/1000
-        narrow = (1 if self._narrow else 0) | \
+        narrow = (1 if self._narrow else 0) | (2 if self._reuse_roots else 0) | \
             ((int(round(self._edge_fill * 1000)) << 8) if comm is not None else 0)
 
         def group_bytes(roots):

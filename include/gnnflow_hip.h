@@ -605,6 +605,10 @@ typedef struct gf_group_sample {
   size_t out_bytes;
 } gf_group_sample;
 /* `narrow_ids` of the three entry points below is a flags word: bit 0 = 12-byte reply records;
+ * bit 1 = a layer does not request the previous layer's roots again (its first roots ARE those,
+ * with the same timestamps: with most-recent sampling and equal fanouts the merge takes their
+ * edges from the previous layer's block; the reference requests every root of every layer,
+ * gnnflow/distributed/dist_sampler.py:174-186);
  * bits 8..23 = COMPACT replies, the edge fill in 1/1000: a reply slot that travels back then holds,
  * per request row, the offset of its edges and, packed behind the offsets, the edges themselves —
  * at most fill x (slot rows x fanout) of them — instead of `fanout` fixed records per row, most of

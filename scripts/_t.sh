@@ -1,6 +1,8 @@
-for st in 1 5 17 64; do
-python bench.py --no-hash-leg --no-config3 --no-cpu-baseline --event-stride $st 2>/dev/null | python -c "
+run() { env $1 python bench.py --no-config3 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('stride $st: %.2f us/step gather %.2f us (%d timed) lru %.2f us' % (d['ms_per_step']*1e3, r['avg_launch_us'], r['launches_timed'], d['roofline_lru']['avg_launch_us']))"
-done
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$1: replica %.2f us  hash(no exchange) %.2f us  hash over rccl one rank %.2f us' % (d['ms_per_step']*1e3, d['hash_partition']['ms_per_step']*1e3, d['hash_partition_over_rccl_one_rank']['ms_per_step']*1e3))"; }
+run GNNFLOW_PART_REUSE_ROOTS=0
+run GNNFLOW_PART_REUSE_ROOTS=1
+run GNNFLOW_PART_REUSE_ROOTS=0
+run GNNFLOW_PART_REUSE_ROOTS=1

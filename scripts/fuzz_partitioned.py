@@ -46,6 +46,9 @@ def one(seed, dev):
     adapt = bool(rng.randint(0, 2))
     # compact reply slots (shared chains): none / far too small (overflow -> redo) / roomy / all
     edge_fill = float(rng.choice([0.0, 0.02, 0.1, 0.4, 1.0]))
+    reuse = bool(rng.randint(0, 2))        # do not request the previous layer's roots again
+    if rng.randint(0, 2) and L > 1:        # ... which needs equal fanouts: make them so half the time
+        fan = [fan[0]] * L
     minblk = int(rng.choice([4, 8, 62]))
     src, dst, ts, eid = synth.powerlaw_graph(N, E, seed=seed, tie_levels=int(rng.choice([50, 500, 5000])))
     full = O.OracleGraph(minimum_block_size=minblk)
@@ -76,7 +79,8 @@ def one(seed, dev):
                 part = DevicePartitionedSampler(TemporalSampler(shards[r], **kw), comm=comms[r],
                                                 slack=slack, slot_roots=slot_roots,
                                                 chain_samples=chain, narrow_ids=narrow,
-                                                adapt_slack=adapt, edge_fill=edge_fill)
+                                                adapt_slack=adapt, edge_fill=edge_fill,
+                                                reuse_roots=reuse)
                 side = torch.cuda.Stream()
                 got = []
                 for lo in range(0, n_samples, inflight):
@@ -97,7 +101,7 @@ def one(seed, dev):
     [t.join(timeout=300) for t in th]
     desc = dict(seed=seed, P=P, N=N, E=E, fan=fan, snaps=snaps, window=window, prop=prop, slack=slack,
                 chain=chain, narrow=narrow, adapt=adapt, inflight=inflight, slot_roots=slot_roots,
-                edge_fill=edge_fill)
+                edge_fill=edge_fill, reuse=reuse)
     if any(t.is_alive() for t in th):
         return "HANG", desc
     if any(err):
