@@ -542,6 +542,29 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "GNNFLOW_BENCH_WORKER" not in os.environ \
             and args.partition in (None, "hash") and not args.shard_features:
         sys.exit(supervise(args, argv))
+    fake = os.environ.get("GNNFLOW_BENCH_FAKE_WORKER")
+    if fake and "GNNFLOW_BENCH_WORKER" in os.environ:
+        # test hook (tests/test_bench_launcher.py, no GPU): this worker only ACTS its rung's
+        # outcome — "ok" prints a line, "giveup" leaves a ladder entry and exits GIVE_UP, "hang"
+        # never exits, "die" exits 9 — so that launcher + supervisor + ladder run end to end
+        rung = int(os.environ["GNNFLOW_BENCH_RUNG"])
+        act = fake.split(",")[rung]
+        if act == "hang":
+            time.sleep(1e6)
+        if act == "die":
+            os._exit(9)
+        if act == "giveup":
+            with open(os.environ["GNNFLOW_BENCH_LADDER_FILE"], "w") as f:
+                json.dump({"rung": rung, "arrangement": RUNGS[rung][0], "hung": True,
+                           "error": "acted: gave up"}, f)
+            os._exit(GIVE_UP)
+        if os.environ.get("RANK", "0") == "0":
+            print(json.dumps({"metric": "sampled_edges_per_s", "value": 1.0, "unit": "edges/s",
+                              "n_gpus": args.gpus, "master_port": os.environ.get("MASTER_PORT"),
+                              "ladder": {"rung": rung, "arrangement": RUNGS[rung][0],
+                                         "tried_before": json.loads(
+                                             os.environ.get("GNNFLOW_BENCH_LADDER", "[]"))}}))
+        sys.exit(0)
     # stdout carries exactly ONE line, the JSON record: everything else that libraries print
     # there (RCCL's version banner on communicator creation, for one) goes to stderr
     sys.stdout.flush()

@@ -37,3 +37,51 @@ def test_launcher_parent_does_not_load_torch():
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True,
                        timeout=60)
     assert p.returncode == 0, p.stderr
+
+
+def _acted(outcomes, extra_env=None):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    env["GNNFLOW_BENCH_FAKE_WORKER"] = outcomes
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.stdout, p.stderr[-2000:])      # exactly ONE line, whatever happens
+    return p.returncode, json.loads(lines[0]), p.stderr
+
+
+def test_ladder_first_rung_succeeds():
+    rc, d, _ = _acted("ok,ok,ok")
+    assert rc == 0 and d["ladder"]["rung"] == 0 and d["ladder"]["tried_before"] == []
+
+
+def test_ladder_walks_down_when_rungs_give_up():
+    """Launcher -> two supervisors (never a GPU call) -> a worker per rung (here: acting its
+    outcome): rung 0 gives up on both ranks, rung 1 gives up, the replica rung prints the line;
+    every rung rendezvous on its own port."""
+    rc, d, err = _acted("giveup,giveup,ok")
+    assert rc == 0
+    lad = d["ladder"]
+    assert lad["rung"] == 2 and lad["arrangement"] == "replica"
+    assert [h["arrangement"] for h in lad["tried_before"]] == ["hash", "hash-simple"]
+    assert all(h["hung"] and not h["worker_killed"] for h in lad["tried_before"])
+    assert "starting rung 1 (hash-simple)" in err and "starting rung 2 (replica)" in err
+
+
+def test_ladder_kills_a_worker_that_neither_finishes_nor_gives_up():
+    rc, d, _ = _acted("hang,ok,ok", {"GNNFLOW_HASH_MAIN_TIMEOUT": "2",
+                                     "GNNFLOW_RUNG_SETUP_ALLOWANCE": "1"})
+    assert rc == 0 and d["ladder"]["rung"] == 1
+    (h,) = d["ladder"]["tried_before"]
+    assert h["worker_killed"] is True and h["hung"] is True and "killed after" in h["error"]
+    assert 3 <= h["seconds"] < 30
+
+
+def test_ladder_ports_differ_per_rung_and_a_dying_last_rung_fails_the_run():
+    rc0, d0, _ = _acted("ok,ok,ok", {"MASTER_PORT": "29900"})
+    rc1, d1, _ = _acted("die,ok,ok", {"MASTER_PORT": "29900"})
+    assert d0["master_port"] != d1["master_port"]            # rung 0 and rung 1 rendezvous apart
+    rc, d, _ = _acted("die,die,die")
+    assert rc != 0 and d["value"] == 0.0 and "no rung printed a record" in d["error"]
+    assert [h["arrangement"] for h in d["ladder"]] == ["hash", "hash-simple"]
