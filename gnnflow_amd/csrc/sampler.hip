@@ -788,7 +788,7 @@ struct PaddedJob {
 // a header announces are served (reply row = request row); a sender's overflow flag is
 // folded into this rank's word, so every rank learns of it in the same exchange.
 template <int GROUP>
-__device__ inline void padded_job(const GraphView& g, const PaddedCommon& c, PaddedJob j) {
+__device__ inline void padded_job(const GraphView& g, const PaddedCommon& c, const PaddedJob& j) {
   const int64_t* __restrict__ req = j.req;
   int64_t* __restrict__ out = j.out;
   const uint32_t* __restrict__ root_of = j.root_of;
@@ -893,7 +893,8 @@ __global__ __launch_bounds__(kSearchThreads) void sample_padded_kernel(
 template <int GROUP>
 __global__ __launch_bounds__(kSearchThreads) void sample_padded_pair_kernel(
     GraphView g, PaddedCommon c, PaddedJob a, PaddedJob b) {
-  padded_job<GROUP>(g, c, blockIdx.y == 0 ? a : b);
+  if (blockIdx.y == 0) padded_job<GROUP>(g, c, a);
+  else padded_job<GROUP>(g, c, b);
 }
 // ... and up to five: the shared inbox of m <= 4 samples and their own shares
 struct PaddedJobs { PaddedJob j[5]; };
