@@ -2799,6 +2799,10 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
         granules_.reserve((kFuseMaxTiles + kFuseMaxRowWgs) * sizeof(unsigned long long), 0, stream);
         GF_HIP(hipMemsetAsync(granules_.data(), 0, granules_.bytes(), stream));
       }
+      if (fuse_tag_ == 0xFFFFFFFFu) {   // the tags wrap: no granule may carry one from last time round
+        GF_HIP(hipMemsetAsync(granules_.data(), 0, granules_.bytes(), stream));
+        fuse_tag_ = 0;
+      }
       c.fused = 1;
       c.fuse_tag = ++fuse_tag_;
       c.g_cnt = granules_.as<unsigned long long>();
