@@ -225,6 +225,65 @@ def launch_ranks(args, argv):
     return rc if rc >= 0 else 128 - rc
 
 
+def guarded_aux(ctx, pending, key, limit, fn):
+    """An AUXILIARY part of the line (another leg, a collective micro-measurement) that may hang
+    on a first multi-GPU run: after `limit` seconds rank 0 prints the line it has, with a note
+    under `key`, and every rank exits 0 — the main figure is measured and valid, and a non-zero
+    status would send the rank's supervisor on to the next rung of the ladder and lose it."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(limit):
+            if ctx.rank == 0:
+                pending[key] = {"error": "timed out after {:.0f} s (the main figure above is "
+                                         "complete)".format(limit)}
+                main.emit(pending)
+            os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        return fn()
+    finally:
+        done.set()
+
+
+def all_to_all_record(ctx, sampler, rec):
+    """DESIGN 6.2's two free parameters, measured: device time x and issue cost c of one
+    equal-split all-to-all at the sizes a chain's layer-1 exchanges have (lane 0's
+    communicator), and the projection evaluated on them.  Collective."""
+    import torch
+    import torch.distributed as dist
+    comms = sampler.comms() if hasattr(sampler, "comms") else []
+    # x and c, on lane 0's communicator, at the sizes a chain's layer-1 exchanges have
+    if comms and hasattr(sampler, "_plan") and sampler._slack > 0:
+        m = getattr(sampler, "chain_samples", 1)
+        last = sampler.wire_bytes_per_sample()["per_layer"][-1]      # what really travels
+        sizes = {"request_layer1": m * last["request_bytes_to_each_peer"],
+                 "reply_layer1": m * last["reply_bytes_to_each_peer"]}
+        torch.cuda.synchronize()
+        dist.barrier()
+        x = {}
+        for name, nbytes in sizes.items():
+            dev_us, host_us = comms[0].time_all_to_all(nbytes, 30, torch.cuda.current_stream(ctx.dev))
+            x[name] = {"bytes_per_peer": nbytes, "device_us": dev_us, "issue_us": host_us}
+        rec["all_to_all"] = x
+        k = 7.0 * 13.5          # a chain of four: 7 kernels, ~95 us (DESIGN 6.2, measured at P = 1)
+        layers = len(sampler._fanouts)
+        # (every layer priced at the last layer's sizes: an upper bound — layer 0's slots are
+        # a tenth of layer 1's at fanout 10)
+        xs = layers * (x["request_layer1"]["device_us"] + x["reply_layer1"]["device_us"])
+        rec["projection"] = {
+            "formula": "a chain of m samples on one of L lanes = K us of kernels + the device time "
+                       "of its 2 x layers all-to-alls; the lanes sustain one step per "
+                       "(K + sum x) / (m L) us; the issuing thread needs (7 x 3 + 2 x layers x c) / m "
+                       "+ 9 us per step",
+            "K_us": k, "sum_x_us": xs, "m": m, "L": rec["lanes"],
+            "chains_sustain_us_per_step": (k + xs) / (m * rec["lanes"]),
+            "issuing_thread_us_per_step":
+                (21.0 + 2 * layers * x["reply_layer1"]["issue_us"]) / m + 9.0}
+    return rec
+
+
 # ---- one rank -------------------------------------------------------------------------------
 class Ctx:
     pass
@@ -271,34 +330,6 @@ def multi_gpu_record(ctx, sampler, cache):
         rec["wire"] = wb
         rec["request_bytes_per_step_and_rank"] = (ctx.world - 1) * wb["request_bytes_to_each_peer"]
         rec["reply_bytes_per_step_and_rank"] = (ctx.world - 1) * wb["reply_bytes_to_each_peer"]
-    # x and c, on lane 0's communicator, at the sizes a chain's layer-1 exchanges have
-    if comms and hasattr(sampler, "_plan") and sampler._slack > 0:
-        lay = sampler._plan(max(sampler._slot_roots, 1), sampler._slack)[0][-1]
-        m = getattr(sampler, "chain_samples", 1)
-        rows = int(lay.slot_stride) * m
-        sizes = {"request_layer1": rows * 16,
-                 "reply_layer1": rows * sampler._fanouts[-1] * (12 if sampler._narrow else 24)}
-        torch.cuda.synchronize()
-        dist.barrier()
-        x = {}
-        for name, nbytes in sizes.items():
-            dev_us, host_us = comms[0].time_all_to_all(nbytes, 30, torch.cuda.current_stream(ctx.dev))
-            x[name] = {"bytes_per_peer": nbytes, "device_us": dev_us, "issue_us": host_us}
-        rec["all_to_all"] = x
-        k = 7.0 * 13.5          # a chain of four: 7 kernels, ~95 us (measured at P = 1)
-        layers = len(sampler._fanouts)
-        # (every layer priced at the last layer's sizes: an upper bound — layer 0's slots are
-        # a tenth of layer 1's at fanout 10)
-        xs = layers * (x["request_layer1"]["device_us"] + x["reply_layer1"]["device_us"])
-        rec["projection"] = {
-            "formula": "a chain of m samples on one of L lanes = K us of kernels + the device time "
-                       "of its 2 x layers all-to-alls; the lanes sustain one step per "
-                       "(K + sum x) / (m L) us; the issuing thread needs (7 x 3 + 2 x layers x c) / m "
-                       "+ 9 us per step",
-            "K_us": k, "sum_x_us": xs, "m": m, "L": rec["lanes"],
-            "chains_sustain_us_per_step": (k + xs) / (m * rec["lanes"]),
-            "issuing_thread_us_per_step":
-                (21.0 + 2 * layers * x["reply_layer1"]["issue_us"]) / m + 9.0}
     return rec
 
 
@@ -474,8 +505,9 @@ def supervise(args, argv):
         if rung < len(RUNGS) - 1:
             # the worker's own watchdog covers its main loop; this covers everything else
             # (set-up included) should the worker be too wedged to exit by itself
+            # (the first worker of a fresh box also pages torch in: 1-2 minutes)
             limit = float(os.environ.get("GNNFLOW_HASH_MAIN_TIMEOUT", "150" if rung == 0 else "120")) + \
-                float(os.environ.get("GNNFLOW_RUNG_SETUP_ALLOWANCE", "90"))
+                float(os.environ.get("GNNFLOW_RUNG_SETUP_ALLOWANCE", "180" if rung == 0 else "90"))
         t0 = time.time()
         kid = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                stdin=subprocess.DEVNULL,
@@ -920,6 +952,10 @@ def main():
             # itself: what the multi-rank path costs before any real peer exists
             out["hash_partition_over_rccl_one_rank"] = second_leg(ctx, "hash", cache,
                                                                   always_exchange=True)
+    if main_kind == "hash" and world > 1 and "multi_gpu" in out:
+        # last of all, and guarded: a collective micro-measurement on the lanes' communicators
+        guarded_aux(ctx, out, "all_to_all_measurement", 45.0,
+                    lambda: all_to_all_record(ctx, sampler, out["multi_gpu"]))
 
     if args.breakdown and rank == 0:
         lib.gf_profile_reset()
@@ -1026,7 +1062,8 @@ def second_leg(ctx, kind, cache, always_exchange=None):
     import threading
     # RCCL with more than one rank has never run on this code path before the first scaling
     # run: a watchdog ends every rank if a collective hangs — rank 0 first prints the line it
-    # has, with an error note, then every rank exits NON-ZERO.
+    # has, with an error note for THIS leg, then every rank exits 0: the main figure is complete,
+    # and a non-zero status would make the rank's supervisor try the next rung and lose it.
     limit = float(os.environ.get("GNNFLOW_HASH_LEG_TIMEOUT", "180"))
     done = threading.Event()
     key = "replica" if kind != "hash" else (
@@ -1038,7 +1075,7 @@ def second_leg(ctx, kind, cache, always_exchange=None):
             if ctx.rank == 0 and second_leg.pending_line is not None:
                 second_leg.pending_line[key] = {"error": "timed out after {} s".format(limit)}
                 main.emit(second_leg.pending_line)
-            os._exit(3)
+            os._exit(0)
     threading.Thread(target=watchdog, daemon=True).start()
     try:
         if always_exchange and ctx.world == 1:

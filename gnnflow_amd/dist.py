@@ -751,21 +751,25 @@ class DevicePartitionedSampler:
         def up16(x):
             return (x + 15) & ~15
         L = len(self._fanouts)
+        per_layer = []
         for l, (lay, F) in enumerate(zip(lays, self._fanouts)):
             stride = int(lay.slot_stride)
-            req += stride * self._S * 16
+            rq = stride * self._S * 16
             fixed += stride * self._S * F * rec
             if fill > 0:      # sampler.hip group_layout: offsets + packed edges
                 f = fill ** (l / (L - 1)) if L > 1 else 1.0
                 cap = max(int(np.ceil(f * (stride - 1) * F)), F)
-                rep += self._S * (up16((2 if cap < 65535 else 4) * (stride + 1)) + up16(cap * rec))
+                rp = self._S * (up16((2 if cap < 65535 else 4) * (stride + 1)) + up16(cap * rec))
             else:
-                rep += stride * self._S * F * rec
+                rp = stride * self._S * F * rec
+            req += rq
+            rep += rp
+            per_layer.append({"request_bytes_to_each_peer": rq, "reply_bytes_to_each_peer": rp})
         return {"request_bytes_to_each_peer": req, "reply_bytes_to_each_peer": rep,
                 "reply_bytes_to_each_peer_fixed_slots": fixed,
                 "bytes_on_links_per_rank": (self._P - 1) * (req + rep),
                 "reply_record_bytes": rec, "reply_edge_fill": fill, "slot_roots": R0,
-                "slack": self._slack}
+                "slack": self._slack, "per_layer": per_layer}
 
     # the plain sampler's attributes the pipeline / cache helpers look at
     @property
