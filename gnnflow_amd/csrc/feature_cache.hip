@@ -2145,9 +2145,11 @@ inline bool vec4_ok(size_t dim, const void* a, const void* b, const void* c) {
 // 30 k-row fetch with update costs 30 / 42 / 77 / 152 / 352 us in the list form at 0.13 / 1 / 4
 // / 16 / 40 M slots and 45 / 45 / 49 us in the queue form at 4 / 16 / 40 M
 // (profiles/r02_lru_capacity_sweep.jsonl)
+// (round 5, 30 k-row blocks, one-launch list update: 23.7 / 36.2 / 47.8 / 68.8 us per fetch at
+// 0.13 / 0.5 / 1 / 2 M slots, queue form 54.0 / 48.5 / 45.5 / 45.8: they cross at ~1 M slots)
 inline size_t queue_min_capacity() {
   const char* v = std::getenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY");   // tuning / tests
-  return v ? static_cast<size_t>(std::atoll(v)) : (size_t{2} << 20);
+  return v ? static_cast<size_t>(std::atoll(v)) : (size_t{1} << 20);
 }
 
 // chunks of kRowTile queue entries the victim walk covers behind the head: twice the rows
