@@ -236,6 +236,7 @@ PROTOTYPES = {
     "gf_block_reduce_max_backward": (C.c_int, [_sz, _p, _sz, _p, _p, _p, _sz, C.c_int, _p]),
     "gf_debug_part_host_us": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "gf_debug_merge_recounts": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "gf_debug_part_reused_roots": (C.c_int, [C.POINTER(C.c_uint64)]),
     "gf_debug_philox": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "gf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gf_comm_abort": (C.c_int, [C.c_void_p]),

@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "edge_store.hpp"
 #include "feature_cache.hpp"
+#include "partition.hpp"
 #include "sampler.hpp"
 
 struct gf_graph { gf::EdgeStore impl; template <typename... A> explicit gf_graph(A&&... a) : impl(std::forward<A>(a)...) {} };
@@ -1179,6 +1180,12 @@ int gf_debug_philox(const uint64_t* d_in, size_t n, uint32_t* d_out, void* strea
   return guarded([&] {
     GF_REQUIRE(n == 0 || (d_in != nullptr && d_out != nullptr), "gf_debug_philox: null buffer");
     gf::philox_on_device(d_in, n, d_out, static_cast<hipStream_t>(stream));
+  });
+}
+int gf_debug_part_reused_roots(uint64_t* out) {
+  return guarded([&] {
+    GF_REQUIRE(out != nullptr, "gf_debug_part_reused_roots: null output");
+    *out = gf::part_reused_roots();
   });
 }
 int gf_debug_merge_recounts(uint64_t* out) {

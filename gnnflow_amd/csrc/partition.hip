@@ -163,6 +163,7 @@ __global__ __launch_bounds__(kTileThreads) void partition_scatter_kernel(
 // owners need no LDS atomics.
 constexpr int kFusedThreads = 1024;
 constexpr uint32_t kFusedPlanRoots = 32768;
+__device__ unsigned long long g_part_reused_roots;   // roots plans did not request (diagnostics)
 
 // slot_mul / slot_add / own_base: several samples sharing one request buffer (PlanJob); a single
 // sample: 1, 0, P * stride.
@@ -177,6 +178,7 @@ __device__ inline void plan_fused_body(
   const uint32_t P = od.P;
   // roots [0, skip) are not requested (PlanJob::d_skip): they count for nobody
   const uint32_t skip = static_cast<uint32_t>(d_skip ? *d_skip : skip_host);
+  if (skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_part_reused_roots, skip);
   __shared__ uint32_t s_before[kFusedThreads / 64][kMaxParts];
   __shared__ uint32_t s_total[kFusedThreads / 64][kMaxParts];
   __shared__ uint32_t s_tile[kFusedThreads / 64][kMaxParts];   // this tile, per wave
@@ -388,6 +390,14 @@ void partition_plan_jobs(const PlanJob* jobs, int n, size_t R_bound, int world_s
   partition_plan_jobs_kernel<<<dim3(grid, static_cast<unsigned>(n)), dim3(kFusedThreads), 0,
                                stream>>>(all, od, static_cast<uint32_t>(rank), stride);
   GF_HIP(hipGetLastError());
+}
+
+// Roots that plans did NOT bucket / request because the previous layer's block already holds
+// their edges (PlanJob::d_skip), since the library was loaded, on the current device.
+uint64_t part_reused_roots() {
+  unsigned long long v = 0;
+  GF_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_part_reused_roots), sizeof(v)));
+  return v;
 }
 
 void partition_plan(const int64_t* d_nodes, const float* d_ts, size_t R, int world_size, int rank,

@@ -48,5 +48,6 @@ constexpr uint32_t kPosReused = 0xFFFFFFFEu;
 void partition_plan_jobs(const PlanJob* jobs, int n, size_t R_bound, int world_size, int rank,
                          uint32_t stride, int device, hipStream_t stream);
 constexpr size_t kPlanJobsMaxRoots = 32768;
+uint64_t part_reused_roots();
 
 }  // namespace gf

@@ -698,6 +698,10 @@ GF_API int gf_debug_part_host_us(double out[8], int reset);
  * was loaded).  0 in normal operation; non-zero when the GPU is heavily oversubscribed (several
  * rank processes sharing one card).  Synchronises nothing but the copy itself. */
 GF_API int gf_debug_merge_recounts(uint64_t* out);
+/* Roots the plans of the shared partitioned chains did NOT request because the previous layer's
+ * block already holds their edges (flags bit 1 of the group entry points), summed since the
+ * library was loaded, current device.  Diagnostics / tests. */
+GF_API int gf_debug_part_reused_roots(uint64_t* out);
 /* d_out[i] = gf_philox4x32_10_first(seed, slot, call) of d_in[i] = {seed, slot, call}, evaluated by
  * a kernel: the Random123 known-answer vectors checked ON THE DEVICE (include/gnnflow_rng.h is
  * shared with the CPU oracle, so parity alone would not catch a device-side miscompile). */

@@ -468,3 +468,59 @@ def test_one_rank_shared_chains_without_exchange(chain):
                         assert torch.equal(a, b), (chain, len(n))
     assert part.pairs >= 2 and part.chained >= 2 * 2
     assert part.overflows == 1          # the 5000-root batch, redone without slots
+
+
+def _reused_roots():
+    import ctypes
+    from gnnflow_amd import _capi
+    v = ctypes.c_uint64(0)
+    _capi.check(_capi.load().gf_debug_part_reused_roots(ctypes.byref(v)))
+    return int(v.value)
+
+
+@pytest.mark.parametrize("fanouts,strategy,reuse,expect", [
+    ([7, 7], "recent", True, True),       # layer 1's first R roots ARE layer 0's roots
+    ([7, 5], "recent", True, False),      # another fanout: layer 0's block does not answer them
+    ([7, 7], "uniform", True, False),     # fresh draws per layer
+    ([7, 7], "recent", False, False),     # switched off (GNNFLOW_PART_REUSE_ROOTS=0)
+])
+def test_layer_roots_are_not_requested_twice(fanouts, strategy, reuse, expect):
+    """gf_debug_part_reused_roots counts the roots a plan skipped because the previous layer's
+    block already holds their edges (flags bit 1).  It moves exactly when the rule of DESIGN
+    6.2 applies — equal fanouts, most-recent sampling, one snapshot — and the MFGs are the
+    single-process sampler's either way."""
+    import torch
+    from gnnflow_amd import DynamicGraph, TemporalSampler
+    from gnnflow_amd.dist import DevicePartitionedSampler, NativeComm
+    from tests import synth
+    src, dst, ts, eid = _graph()
+    g = DynamicGraph(1 << 20, 64 << 20, "cuda", 8, 64, "insert")
+    g.add_edges(src, dst, ts, eid, add_reverse=True)
+    kw = dict(fanouts=fanouts, sample_strategy=strategy, seed=11)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream()
+    comm = NativeComm.loopback(1, dev)[0]
+    part = DevicePartitionedSampler(TemporalSampler(g, **kw), comm=comm, always_exchange=True,
+                                    slot_roots=600, chain_samples=2, edge_fill=1.0,
+                                    reuse_roots=reuse)
+    plain = TemporalSampler(g, **kw)
+    reqs = [synth.random_roots(400, R, 1000.0, seed=31 + R) for R in (600, 211)]
+    before = _reused_roots()
+    pend = [part.sample_async(torch.from_numpy(n).to(dev), torch.from_numpy(t).to(dev), stream=side)
+            for n, t in reqs]
+    got = [p.wait() for p in pend]
+    moved = _reused_roots() - before
+    assert part.chained == 2 and part.overflows == 0
+    if expect:
+        assert moved == sum(len(n) for n, _ in reqs), moved     # every layer-0 root, once
+    else:
+        assert moved == 0, moved
+    if strategy == "recent":
+        for (n, t), mf in zip(reqs, got):
+            for gl, wl in zip(mf, plain.sample(n, t)):
+                for gb, wb in zip(gl, wl):
+                    for a, b in ((gb.srcdata["ID"], wb.srcdata["ID"]), (gb.srcdata["ts"], wb.srcdata["ts"]),
+                                 (gb.edata["ID"], wb.edata["ID"]), (gb.edata["dt"], wb.edata["dt"]),
+                                 (gb.edges()[0], wb.edges()[0]), (gb.edges()[1], wb.edges()[1])):
+                        assert torch.equal(a, b)
+    comm.close()
