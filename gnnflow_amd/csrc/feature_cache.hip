@@ -96,6 +96,8 @@ constexpr uint32_t kInstRows = 256;     // LRU: block rows per install workgroup
 // 20 k-row block wants 20 CUs on it, not 5 (kRowTile rows per workgroup).
 constexpr uint32_t kLruRows = 1024;
 constexpr uint32_t kMaxStageTiles = 1024;   // LRU list form: list tiles that stage their victims
+constexpr uint32_t kBitTile = 4096;         // LRU queue form: words of the hit bitmap per tile (kWide x 4)
+constexpr uint32_t kMaxBitGroups = 1024;    // ... entries of the install kernel's LDS prefix over the tiles
 
 // One record per fetch.  hits / misses are accumulated once per workgroup into one of 8
 // shards that sit on separate 128-byte lines: same-address atomics retire at only
@@ -171,9 +173,10 @@ struct Ctx {
   // LRU of a LARGE cache (queue form, see "LRU as a queue" below); qmode == 0: list form
   int qmode;                // this update appends to the queue instead of rewriting the list
   uint32_t* qpos;           // [capacity] position of the slot's live queue entry
-  uint32_t* hit_rep;        // [capacity] one of the rows that hit the slot in this block
   uint32_t* qbits;          // one bit per queue position: entry of a slot hit by this block
-                            // (all zero between updates)
+                            // (set by the gather; all zero between updates)
+  uint2* wsnap;             // per word of qbits: {the word, hit entries before it in its tile}
+  uint32_t q_group;         // bitmap tiles per entry of the install kernel's LDS prefix
   // list form: the first stage_tiles list tiles leave their not-hit entries (the victims, in
   // list order) packed per tile in v_slot and — if that is the whole list — their hit entries
   // in v_pos (the next victims when a block needs more slots than its hits leave over);
@@ -257,6 +260,11 @@ __device__ inline void nt_store(const uf4& v, uf4* p) { __builtin_nontemporal_st
 template <> __device__ inline float vec_zero<float>() { return 0.0f; }
 template <> __device__ inline float4 vec_zero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// rep_flag[row]: representative of a distinct missed id (rank among them in the low bits) /
+// queue form: THE row that stands for a hit slot (the old queue position of its entry)
+constexpr uint32_t kRepMiss = 1u << 31, kRepRank = kRepMiss - 1u;
+constexpr uint32_t kRepHit = 1u << 30, kRepPos = kRepHit - 1u;
+
 // ---- the gather kernel -------------------------------------------------------------
 template <typename VecT, bool kOdd = false>
 __device__ inline void gather_body(const Ctx& c) {
@@ -292,6 +300,7 @@ __device__ inline void gather_body(const Ctx& c) {
     const uint32_t rows = min(tile_rows, n - row0);
     const Unit* src = nullptr;
     int32_t slot = -2;
+    uint32_t hit_code = 0;
     if (lane < static_cast<int>(rows)) {
       const int64_t id = c.ids[row0 + lane];
       if (id >= 0 && static_cast<uint64_t>(id) < c.num_ids) {
@@ -301,11 +310,15 @@ __device__ inline void gather_body(const Ctx& c) {
           src = cache_buf + static_cast<uint64_t>(slot) * rowu;
           // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
           // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161).
-          if (c.update && c.policy != GF_CACHE_FIFO)
-            c.touched[(c.policy == GF_CACHE_LRU && !c.qmode) ? c.qpos[slot] : slot] = c.epoch_new;
-          // queue form: any ONE of the rows that hit the slot stands for it (plain stores of
-          // different values to one word: exactly one of them remains)
-          if (c.qmode) c.hit_rep[slot] = row0 + lane;
+          if (c.qmode) {
+            // queue form: the mark is the bit of the entry's queue position; the row whose
+            // atomic set it stands for the slot (it will append the slot's new entry)
+            const uint32_t pos = c.qpos[slot], bit = 1u << (pos & 31u);
+            const uint32_t was = atomicOr(&c.qbits[pos >> 5], bit);
+            hit_code = (was & bit) ? 0u : (kRepHit | pos);
+          } else if (c.update && c.policy != GF_CACHE_FIFO) {
+            c.touched[c.policy == GF_CACHE_LRU ? c.qpos[slot] : slot] = c.epoch_new;
+          }
         } else {
           slot = -1;
           if (c.miss_rows) {
@@ -368,6 +381,8 @@ __device__ inline void gather_body(const Ctx& c) {
     if (c.inflight >= 12) copy(std::integral_constant<int, 12>{});
     else if (c.inflight >= 8) copy(std::integral_constant<int, 8>{});
     else copy(std::integral_constant<int, 4>{});
+    // (behind the copy: the atomic's return value has long arrived)
+    if (c.qmode && lane < static_cast<int>(rows)) c.rep_flag[row0 + lane] = hit_code;
   }
   if (c.ctr) {
     __shared__ uint32_t wg_hits, wg_miss;
@@ -943,7 +958,6 @@ __global__ __launch_bounds__(kTile) void lru_install_kernel(Round r) {
 // ---- LRU as a list ------------------------------------------------------------------
 // (see the file header).  c.touched[slot] = epoch of the slot's last hit (plain stores by the
 // gather); c.queue[0 / 1] are the two list buffers, qstate->parity says which one is current.
-constexpr uint32_t kRepMiss = 1u << 31, kRepRank = kRepMiss - 1u;
 
 // Exclusive scan of one value per thread over a kWide-wide workgroup; *total gets the sum.
 // Every thread calls it (barriers inside); `ws` is kWide / 64 words of LDS.
@@ -982,25 +996,27 @@ __device__ inline uint32_t wide_sum(uint32_t v, uint32_t* ws) {
 }
 
 // Queue form: four consecutive queue entries from p0 (16-byte aligned); bit j of the result:
-// entry p0 + j is live (qpos points at it) and its slot was not hit by this block.
+// entry p0 + j is live (qpos points at it) and its slot was not hit by this block (the
+// gather marked the hit entries' positions in qbits: read densely here).
 __device__ inline uint32_t victim_walk4(const Ctx& c, const uint32_t* list, uint32_t head,
                                         uint32_t tail, uint32_t p0, uint32_t* sl) {
   // the buffers are allocated 16 entries past queue_cap: a whole vector is readable
   const uint4 v = p0 < tail ? *reinterpret_cast<const uint4*>(list + p0)
                             : make_uint4(0u, 0u, 0u, 0u);
-  uint32_t qp[4], tc[4], mask = 0;
+  // the four positions share one word of the hit bitmap (p0 is a multiple of 4)
+  const uint32_t hitw = p0 < tail ? c.qbits[p0 >> 5] >> (p0 & 31u) : 0u;
+  uint32_t qp[4], mask = 0;
   sl[0] = v.x; sl[1] = v.y; sl[2] = v.z; sl[3] = v.w;
 #pragma unroll
   for (uint32_t j = 0; j < 4; ++j) {
     const bool in = p0 + j >= head && p0 + j < tail;
     if (!in) sl[j] = 0u;   // beyond the tail: not initialised
     qp[j] = c.qpos[sl[j]];
-    tc[j] = c.touched[sl[j]];
   }
 #pragma unroll
   for (uint32_t j = 0; j < 4; ++j) {
     const bool in = p0 + j >= head && p0 + j < tail;
-    if (in && qp[j] == p0 + j && tc[j] != c.epoch_new) mask |= 1u << j;
+    if (in && qp[j] == p0 + j && !((hitw >> j) & 1u)) mask |= 1u << j;
   }
   return mask;
 }
@@ -1052,25 +1068,13 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
         fm[k] = (sr[k] == -1 && c.map[idv[k]] == -static_cast<int32_t>(i0 + k + 1)) ? 1u : 0u;
         lm += fm[k];
       }
-      if (c.qmode) {
-        // every distinct hit slot marks the queue position of its entry, once (the row that
-        // stands for the slot does it: different slots rarely share a word)
-        uint32_t rep[kItems], pos[kItems];
-#pragma unroll
-        for (uint32_t k = 0; k < kItems; ++k) {
-          rep[k] = sr[k] >= 0 ? c.hit_rep[sr[k]] : ~0u;
-          pos[k] = sr[k] >= 0 ? c.qpos[sr[k]] : 0u;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kItems; ++k)
-          if (sr[k] >= 0 && rep[k] == i0 + k)
-            atomicOr(&c.qbits[pos[k] >> 5], 1u << (pos[k] & 31u));
-      }
       uint32_t tm;
       uint32_t run = carry + wide_excl_scan(lm, ws, &tm);
 #pragma unroll
       for (uint32_t k = 0; k < kItems; ++k) {
-        if (i0 + k < c.n) c.rep_flag[i0 + k] = fm[k] ? (kRepMiss | run) : 0u;
+        // (queue form: the gather left kRepHit | position for the rows that stand for a hit
+        // slot and 0 for the others)
+        if (i0 + k < c.n && (fm[k] || !c.qmode)) c.rep_flag[i0 + k] = fm[k] ? (kRepMiss | run) : 0u;
         run += fm[k];
       }
       __syncthreads();
@@ -1082,7 +1086,36 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
   }
   const uint32_t cap = c.capacity;
   if (blockIdx.x < row_blocks + list_blocks) {
-    if (c.qmode) return;   // queue form: nothing is proportional to the capacity
+    if (c.qmode) {
+      // queue form: the hit bitmap (set by the gather: 1/32 of the queue positions [head, tail))
+      // per tile of kBitTile words — hit entries per tile, and per word a snapshot {word, hit
+      // entries before it in its tile}: the rank of a hit entry among all of them = tile
+      // prefix (the install kernel's LDS) + that + the bits below its own.  The words
+      // themselves are cleared by the rows that set them, once the snapshot is all anyone reads.
+      const uint32_t head = c.qstate->head, tail = c.qstate->tail;
+      const uint32_t w_lo = head >> 5, w_hi = (tail + 31u) >> 5;
+      const uint32_t t0 = w_lo / kBitTile;
+      const uint32_t btiles = (w_hi + kBitTile - 1) / kBitTile - t0;
+      const bool none = total_miss(c.ctr) == 0;
+      for (uint32_t t = blockIdx.x - row_blocks; t < btiles; t += list_blocks) {
+        const size_t wi = static_cast<size_t>(t0 + t) * kBitTile + tid * 4;   // four words per thread
+        const uint4 wd = *reinterpret_cast<const uint4*>(c.qbits + wi);
+        if (none) {
+          // a block without a miss leaves the cache as it is (lru_cache.py: update() is only
+          // called with missed ids): its hit marks are dropped
+          if (wd.x | wd.y | wd.z | wd.w) *reinterpret_cast<uint4*>(c.qbits + wi) = make_uint4(0u, 0u, 0u, 0u);
+          continue;
+        }
+        const uint32_t p0 = __popc(wd.x), p1 = __popc(wd.y), p2 = __popc(wd.z), p3 = __popc(wd.w);
+        uint32_t total;
+        const uint32_t b = wide_excl_scan(p0 + p1 + p2 + p3, ws, &total);
+        uint4* sn = reinterpret_cast<uint4*>(c.wsnap + wi);
+        sn[0] = make_uint4(wd.x, b, wd.y, b + p0);
+        sn[1] = make_uint4(wd.z, b + p0 + p1, wd.w, b + p0 + p1 + p2);
+        if (tid == 0) c.tile_tie[t] = total;
+      }
+      return;
+    }
     const uint32_t list_tiles = (cap + kRowTile - 1) / kRowTile;
     if (blockIdx.x == row_blocks && tid == 0) c.ctr->q_parity = parity;
     bool first = true, staged = false;
@@ -1148,9 +1181,9 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
     // are always enough).  The walk is spread over the victim workgroups — one CU alone is
     // bound by its 64-line-per-instruction address rate on the two scattered loads per entry
     // (measured 27-37 us for 20 k victims) — in chunks of kRowTile entries: every chunk leaves
-    // its candidates and their count, the count kernel packs the chunks.  The chunks cover
-    // 2 * rows + 2 tiles from the head; should that not yield `want` candidates (many dead
-    // entries right behind the head), one workgroup of the count kernel walks on alone.
+    // its candidates and their count (the install kernel finds the m-th of them through the
+    // counts).  The chunks cover 2 * rows + 2 tiles from the head; should that not yield `want`
+    // candidates (many dead entries right behind the head), lru_queue_walk_kernel walks on.
     // (No "last workgroup" ticket here: the __threadfence() it needs writes the XCD's whole
     // L2 back on this part — measured +15 us.)
     const uint32_t vb = blockIdx.x - row_blocks - list_blocks;
@@ -1203,51 +1236,24 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
   if (tid == 0) c.ctr->q_found = min(found, want);
 }
 
-// Queue form, between the two kernels:
-//  * hit entries per tile of kWide words of qbits (the queue positions [head, tail) only) and
-//    per group of kQGroup tiles;
-//  * the victim candidates of the chunks, packed in queue order: rep_row[m] = slot of the m-th
-//    candidate, rep_rank[m] = its queue position.
-__global__ __launch_bounds__(kWide) void lru_queue_count_kernel(Round r) {
+// Queue form, between the two kernels, ONE workgroup per context: did the chunks yield enough
+// victim candidates?  If not (many dead entries right behind the head) it walks on alone, tile
+// by tile, and leaves what it finds as one more chunk (index v_chunks).  Leaves q_found.
+__global__ __launch_bounds__(kWide) void lru_queue_walk_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
   if (!c.update || c.policy != GF_CACHE_LRU || !c.qmode) return;
   const int tid = threadIdx.x;
   __shared__ uint32_t ws[kWide / 64];
-  const uint32_t head = c.ctr->q_head, tail = c.ctr->q_tail;
   const uint32_t want = min(total_miss(c.ctr), c.capacity);
   if (want == 0) return;
-  const uint32_t w_lo = head >> 5, w_hi = (tail + 31u) >> 5;
-  const uint32_t t0 = w_lo / kWide;
-  const uint32_t btiles = (w_hi + kWide - 1) / kWide - t0;
-  for (uint32_t t = blockIdx.x; t < btiles; t += gridDim.x) {
-    const uint32_t local = __popc(c.qbits[static_cast<size_t>(t0 + t) * kWide + tid]);
-    const uint32_t total = wide_sum(local, ws);
-    if (tid == 0) {
-      c.tile_tie[t] = total;
-      if (total) atomicAdd(&c.tile_old[t / kQGroup], total);   // zeroed by the gather
-    }
-  }
+  const uint32_t head = c.ctr->q_head, tail = c.ctr->q_tail;
   const uint32_t chunks = c.v_chunks;
-  for (uint32_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-    uint32_t before = 0;
-    for (uint32_t u = tid; u < ch; u += kWide) before += c.v_count[u];
-    before = wide_sum(before, ws);
-    const uint32_t cnt = c.v_count[ch];
-    for (uint32_t i = tid; i < cnt && before + i < want; i += kWide) {
-      const uint32_t slot = c.v_slot[ch * kRowTile + i];
-      c.rep_row[before + i] = slot;
-      c.rep_rank[before + i] = c.v_pos[ch * kRowTile + i];
-      c.rep_id[before + i] = c.slot_id[slot];   // the id it evicts: one hop less when installing
-    }
-  }
-  if (blockIdx.x != gridDim.x - 1) return;
-  // the last workgroup: did the chunks yield enough?  If not (many dead entries right behind
-  // the head) it walks on alone, tile by tile
   uint32_t sum = 0;
   for (uint32_t u = tid; u < chunks; u += kWide) sum += c.v_count[u];
-  uint32_t found = wide_sum(sum, ws);
-  const uint32_t parity = c.ctr->q_parity;
-  const uint32_t* list = c.queue[parity & 1u];
+  const uint32_t found0 = wide_sum(sum, ws);
+  uint32_t found = found0;
+  const uint32_t* list = c.queue[c.ctr->q_parity & 1u];
+  const uint32_t limit = want > found0 ? want - found0 : 0u;   // <= block rows: fits behind the chunks
   bool walked = false;
   for (uint32_t base = (head & ~3u) + chunks * kRowTile; base < tail && found < want;
        base += kRowTile) {
@@ -1256,14 +1262,13 @@ __global__ __launch_bounds__(kWide) void lru_queue_count_kernel(Round r) {
     uint32_t sl[4];
     const uint32_t mask = victim_walk4(c, list, head, tail, p0, sl);
     uint32_t total;
-    uint32_t at = found + wide_excl_scan(__popc(mask), ws, &total);
+    uint32_t at = found - found0 + wide_excl_scan(__popc(mask), ws, &total);
 #pragma unroll
     for (uint32_t j = 0; j < 4; ++j) {
       if (mask & (1u << j)) {
-        if (at < want) {
-          c.rep_row[at] = sl[j];
-          c.rep_rank[at] = p0 + j;
-          c.rep_id[at] = c.slot_id[sl[j]];
+        if (at < limit) {
+          c.v_slot[chunks * kRowTile + at] = sl[j];
+          c.v_pos[chunks * kRowTile + at] = p0 + j;
         }
         ++at;
       }
@@ -1271,26 +1276,52 @@ __global__ __launch_bounds__(kWide) void lru_queue_count_kernel(Round r) {
     found += total;
   }
   if (tid == 0) {
+    c.v_count[chunks] = min(found - found0, limit);
     c.ctr->q_found = min(found, want);
     if (walked) c.qstate->lone_walks += 1u;
   }
 }
 
+// workgroup-wide helpers for kBlock threads (the queue form's install kernel runs many small
+// workgroups per CU; the wide_* ones above are for kWide)
+template <int kBlock>
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* ws, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  __syncthreads();            // ws may still be read from a previous call
+  if (lane == 63) ws[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, sum = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    const uint32_t x = ws[w];
+    if (w < wave) base += x;
+    sum += x;
+  }
+  *total = sum;
+  return base + incl - v;
+}
+
 // Copies the rows a workgroup installed — inst[j] = {slot, row} — from the block's output into
-// the cache, as one flat array of 16-byte vectors, kWide threads, K loads in flight per thread
+// the cache, as one flat array of 16-byte vectors, kBlock threads, K loads in flight per thread
 // (rows of `rowf` floats; VecT float4 for 16-byte-aligned rows, uf4 otherwise).
-template <typename VecT, int K>
+template <typename VecT, int K, uint32_t kBlock = kWide>
 __device__ inline void copy_installed(const Ctx& c, const uint2* inst, const int64_t* inst_id,
                                       uint32_t n_inst, uint32_t rowf, int tid) {
   const uint32_t total = n_inst * c.dimv;
   const bool table = c.inst_from_table != 0;
 #pragma unroll 1
-  for (uint32_t f0 = tid; f0 < total; f0 += K * kWide) {
+  for (uint32_t f0 = tid; f0 < total; f0 += K * kBlock) {
     float4 v[K];   // (an array of the under-aligned uf4 would live in scratch)
     uint32_t dj[K], dc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const uint32_t f = f0 + k * kWide;
+      const uint32_t f = f0 + k * kBlock;
       const bool ok = f < total;
       const uint32_t j = ok ? f / c.dimv : 0u, cc = ok ? f - j * c.dimv : 0u;
       const uint2 pr = inst[j];
@@ -1312,6 +1343,156 @@ __device__ inline void copy_installed(const Ctx& c, const uint2* inst, const int
   }
 }
 
+// Queue form: applies the update, one thread per block row, kQInst rows per workgroup (many
+// small workgroups per CU: every step is a chain of scattered word accesses, which only
+// independent workgroups overlap):
+//  * the m-th distinct missed id (m < k = min(#distinct misses, capacity, victims found))
+//    takes the m-th victim candidate's slot — chunk through the chunk counts' prefix (LDS,
+//    binary search), then map / slot_id / row copy as in the list form — and appends the
+//    slot's new entry at tail + #hit entries + m; the one with m = k - 1 moves the head behind
+//    its victim;
+//  * the row that stands for a hit slot (the gather's kRepHit | old position) appends the
+//    slot's new entry at tail + (hit entries before the old one) and clears its bitmap word;
+//  * old entries die because qpos[] moves on.
+constexpr int kQInst = 256;
+constexpr uint32_t kMaxVChunks = 2048;   // victim chunks (+ the walk's) the LDS prefix holds
+__global__ __launch_bounds__(kQInst) void lru_queue_install_kernel(Round r) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (!c.update || c.policy != GF_CACHE_LRU || !c.qmode) return;
+  const int tid = threadIdx.x;
+  const uint32_t row_chunks = (c.n + kQInst - 1) / kQInst;
+  if (blockIdx.x >= row_chunks || total_miss(c.ctr) == 0) return;   // uniform
+  __shared__ uint32_t ws[kQInst / 64];
+  __shared__ uint32_t s_tpre[kMaxBitGroups];   // hit entries before a group of bitmap tiles
+  __shared__ uint32_t s_cpre[kMaxVChunks];     // victim candidates before a chunk
+  __shared__ uint2 inst[kQInst];               // {slot, row} installed by this workgroup
+  __shared__ int64_t inst_id[kQInst];
+  __shared__ uint32_t n_inst;
+  const uint32_t cap = c.capacity;
+  const uint32_t q_found = c.ctr->q_found, head = c.ctr->q_head, tail = c.ctr->q_tail;
+  uint32_t* q = c.queue[c.ctr->q_parity & 1u];
+  const uint32_t w_lo = head >> 5, w_hi = (tail + 31u) >> 5;
+  const uint32_t t0 = w_lo / kBitTile;
+  const uint32_t btiles = (w_hi + kBitTile - 1) / kBitTile - t0;
+  const uint32_t G = c.q_group, ngroups = (btiles + G - 1) / G;   // <= kMaxBitGroups
+  const uint32_t nchunks = c.v_chunks + 1;                        // <= kMaxVChunks
+  // every independent load first: the counts of the bitmap tiles (a run of consecutive groups
+  // per thread), of the victim chunks (likewise) and of the scan workgroups
+  constexpr uint32_t kPerT = kMaxBitGroups / kQInst, kPerC = kMaxVChunks / kQInst;
+  uint32_t tv[kPerT], cv[kPerC], tm_part = 0;
+  const uint32_t per_t = (ngroups + kQInst - 1) / kQInst, per_c = (nchunks + kQInst - 1) / kQInst;
+#pragma unroll
+  for (uint32_t j = 0; j < kPerT; ++j) {
+    const uint32_t g = tid * per_t + j;
+    tv[j] = 0;
+    if (j < per_t && g < ngroups)
+      for (uint32_t u = g * G; u < min((g + 1) * G, btiles); ++u) tv[j] += c.tile_tie[u];
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < kPerC; ++j) {
+    const uint32_t ch = tid * per_c + j;
+    cv[j] = (j < per_c && ch < nchunks) ? c.v_count[ch] : 0u;
+  }
+  const uint32_t row_tiles = (c.n + kLruRows - 1) / kLruRows;
+  const uint32_t spans = (row_tiles + c.tiles_per_wg - 1) / c.tiles_per_wg;
+  const uint32_t span_rows = c.tiles_per_wg * kLruRows;
+  for (uint32_t t = tid; t < spans; t += kQInst) tm_part += c.row_tile_sum[t];
+  // exclusive prefixes into LDS: one workgroup scan of the runs' sums each
+  uint32_t th, tm, unused;
+  {
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kPerT; ++j) sum += tv[j];
+    uint32_t run = block_excl_scan<kQInst>(sum, ws, &th);
+#pragma unroll
+    for (uint32_t j = 0; j < kPerT; ++j) {
+      const uint32_t g = tid * per_t + j;
+      if (j < per_t && g < ngroups) s_tpre[g] = run;
+      run += tv[j];
+    }
+  }
+  {
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kPerC; ++j) sum += cv[j];
+    uint32_t run = block_excl_scan<kQInst>(sum, ws, &unused);
+#pragma unroll
+    for (uint32_t j = 0; j < kPerC; ++j) {
+      const uint32_t ch = tid * per_c + j;
+      if (j < per_c && ch < nchunks) s_cpre[ch] = run;
+      run += cv[j];
+    }
+  }
+  block_excl_scan<kQInst>(tm_part, ws, &tm);
+  const uint32_t k = min(min(tm, cap), q_found);
+  if (blockIdx.x == 0 && tid == 0) c.qstate->tail = tail + th + k;   // (head: by the last victim's row)
+  for (uint32_t chunk = blockIdx.x; chunk < row_chunks; chunk += gridDim.x) {
+    const uint32_t i = chunk * kQInst + tid;
+    const bool in = i < c.n;
+    const uint32_t code = in ? c.rep_flag[i] : 0u;
+    const int64_t id = in ? c.ids[i] : 0;
+    const uint32_t w = (chunk * kQInst) / span_rows;   // scan workgroup of these rows
+    uint32_t pm_part = 0;
+    for (uint32_t t = tid; t < w; t += kQInst) pm_part += c.row_tile_sum[t];
+    uint32_t pm;
+    block_excl_scan<kQInst>(pm_part, ws, &pm);
+    if (tid == 0) n_inst = 0;
+    __syncthreads();
+    if (code & kRepMiss) {
+      const uint32_t m = pm + (code & kRepRank);
+      if (m < k) {
+        uint32_t lo = 0, hi = nchunks;   // largest chunk with s_cpre[chunk] <= m
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_cpre[mid] <= m) lo = mid; else hi = mid;
+        }
+        const uint32_t at = lo * kRowTile + (m - s_cpre[lo]);
+        const uint32_t slot = c.v_slot[at];
+        const int64_t old = c.slot_id[slot];
+        if (m == k - 1) c.qstate->head = c.v_pos[at] + 1u;
+        if (old >= 0) c.map[old] = kAbsent;
+        c.slot_id[slot] = id;
+        c.map[id] = static_cast<int32_t>(slot);
+        const uint32_t qa = tail + th + m;   // behind the hit entries, in victim order
+        q[qa] = slot;
+        c.qpos[slot] = qa;
+        const uint32_t j = atomicAdd(&n_inst, 1u);
+        inst[j] = make_uint2(slot, i);
+        inst_id[j] = id;
+      } else {
+        c.map[id] = kAbsent;   // "we only cache the first self.capacity", lru_cache.py:127-133
+      }
+    } else if (code & kRepHit) {
+      const uint32_t pos = code & kRepPos, wd = pos >> 5;
+      const uint2 sn = c.wsnap[wd];
+      const uint32_t slot = static_cast<uint32_t>(c.slot_of_row[i]);
+      const uint32_t t = wd / kBitTile - t0, g = t / G;
+      uint32_t rank = s_tpre[g] + sn.y + __popc(sn.x & ((1u << (pos & 31u)) - 1u));
+      for (uint32_t u = g * G; u < t; ++u) rank += c.tile_tie[u];
+      q[tail + rank] = slot;
+      c.qpos[slot] = tail + rank;
+      c.qbits[wd] = 0u;   // all zero again for the next update (rows sharing a word all store 0)
+    }
+    __syncthreads();
+    // copy the installed rows out of the block's output, as one flat array
+    if (c.vec4) {
+      copy_installed<float4, 8, kQInst>(c, inst, inst_id, n_inst, c.dimv * 4, tid);
+    } else if (c.odd4) {
+      copy_installed<uf4, 8, kQInst>(c, inst, inst_id, n_inst, c.dim, tid);
+    } else {
+      const uint32_t total = n_inst * c.dimv;
+      for (uint32_t f = tid; f < total; f += kQInst) {
+        const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
+        const uint2 pr = inst[j];
+        c.cache_buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] =
+            c.inst_from_table ? c.feats[static_cast<uint64_t>(inst_id[j]) * c.dimv + cc]
+                              : c.out[static_cast<uint64_t>(pr.y) * c.dimv + cc];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Applies the update; two kinds of workgroups:
 //  * row workgroups [0, row_blocks), one thread per block row: the m-th distinct missed id
 //    (m < k = min(#distinct misses, capacity)) takes the m-th victim's slot — map / slot_id /
@@ -1322,7 +1503,7 @@ __device__ inline void copy_installed(const Ctx& c, const uint2* inst, const int
 __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32_t row_blocks,
                                                                  uint32_t list_blocks) {
   const Ctx& c = r.c[blockIdx.y];
-  if (!c.update || c.policy != GF_CACHE_LRU || c.fused) return;
+  if (!c.update || c.policy != GF_CACHE_LRU || c.fused || c.qmode) return;
   const int tid = threadIdx.x;
   __shared__ uint32_t ws[kWide / 64];
   const uint32_t row_tiles = (c.n + kLruRows - 1) / kLruRows;
@@ -1355,7 +1536,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
         if (t < w) pm += m;
       }
       const uint32_t q_found = c.ctr->q_found;
-      const bool staged = !c.qmode && use_staged_victims(c.stage_tiles, total_miss(c.ctr), c.stage_min);
+      const bool staged = use_staged_victims(c.stage_tiles, total_miss(c.ctr), c.stage_min);
       uint32_t stage_hit = 0, stage_len = 0, th_part = 0;
       if (staged && chunk == blockIdx.x) {
         // list form: hit counts of the tiles that staged their entries, and of the whole list
@@ -1382,7 +1563,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
       }
       if (tid == 0) n_inst = 0;
       __syncthreads();
-      const uint32_t k = c.qmode ? min(min(tm, cap), q_found) : min(tm, cap);
+      const uint32_t k = min(tm, cap);
       if (code & kRepMiss) {
         const uint32_t m = pm + (code & kRepRank);
         if (m < k) {
@@ -1403,7 +1584,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
             old = c.slot_id[slot];
           } else {
             slot = m < q_found ? c.rep_row[m] : c.rep_rank[m - q_found];
-            old = c.qmode ? c.rep_id[m] : c.slot_id[slot];
+            old = c.slot_id[slot];
           }
           if (old >= 0) c.map[old] = kAbsent;
           c.slot_id[slot] = id;
@@ -1439,89 +1620,6 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
   }
   if (blockIdx.x >= row_blocks + list_blocks) return;
   const uint32_t parity = c.ctr->q_parity;
-  if (c.qmode) {
-    // queue form: the distinct hit slots (in the order of their old entries = list order:
-    // the set bits of qbits, ascending) and then the k victims (in victim order) are
-    // APPENDED; the old entries of both die — qpos[] now points at the new ones — and the
-    // head moves behind the k-th victim
-    uint32_t* q = c.queue[parity & 1u];
-    const uint32_t head = c.ctr->q_head, tail = c.ctr->q_tail, q_found = c.ctr->q_found;
-    const uint32_t w_lo = head >> 5, w_hi = (tail + 31u) >> 5;
-    const uint32_t t0 = w_lo / kWide;
-    const uint32_t btiles = (w_hi + kWide - 1) / kWide - t0;
-    const uint32_t bgroups = (btiles + kQGroup - 1) / kQGroup;
-    uint32_t tm = 0, th = 0;
-    for (uint32_t t = tid; t < spans; t += kWide) tm += c.row_tile_sum[t];
-    for (uint32_t g = tid; g < bgroups; g += kWide) th += c.tile_old[g];
-    if (total_miss(c.ctr) == 0) return;
-    tm = wide_sum(tm, ws);
-    th = wide_sum(th, ws);
-    const uint32_t k = min(min(tm, cap), q_found);
-    // bitmap tiles (kWide words, 32 queue positions per word, one word per thread) are dealt
-    // round-robin — the hit entries sit close together near the tail, so neighbouring tiles
-    // must not land in one workgroup — and the empty ones, nearly all, are skipped
-    __shared__ uint32_t s_cnt[kWide], s_word[kWide], s_rank[kWide];
-    const uint32_t wg = blockIdx.x - row_blocks;
-    for (uint32_t tbase = wg; tbase < btiles; tbase += kWide * list_blocks) {
-      __syncthreads();
-      const uint32_t mine = tbase + tid * list_blocks;
-      s_cnt[tid] = mine < btiles ? c.tile_tie[mine] : 0u;
-      __syncthreads();
-      const uint32_t mine_n =
-          min(static_cast<uint32_t>(kWide), (btiles - tbase + list_blocks - 1) / list_blocks);
-      for (uint32_t i = 0; i < mine_n; ++i) {
-        if (s_cnt[i] == 0) continue;   // uniform
-        const uint32_t t = tbase + i * list_blocks;
-        const size_t wi = static_cast<size_t>(t0 + t) * kWide + tid;
-        const uint32_t word = c.qbits[wi];
-        uint32_t before = 0;
-        const uint32_t g0 = t / kQGroup;
-        for (uint32_t g = tid; g < g0; g += kWide) before += c.tile_old[g];
-        for (uint32_t u = g0 * kQGroup + tid; u < t; u += kWide) before += c.tile_tie[u];
-        before = wide_sum(before, ws);
-        uint32_t total;
-        const uint32_t rank = before + wide_excl_scan(__popc(word), ws, &total);
-        // expand the tile's set bits, lanes on consecutive queue positions (coalesced reads
-        // of the old entries and writes of the new ones), eight positions per thread in flight
-        __syncthreads();
-        s_word[tid] = word;
-        s_rank[tid] = rank;
-        if (word) c.qbits[wi] = 0u;   // all zero again for the next update
-        __syncthreads();
-        const uint32_t pos0 = static_cast<uint32_t>((t0 + t) * kWide) << 5;
-        const uint32_t bit = tid & 31u, below = (1u << bit) - 1u;
-#pragma unroll 1   // fully unrolled, the 32 loads' registers spill (128 VGPRs at 1024 threads)
-        for (uint32_t j0 = 0; j0 < 32; j0 += 8) {
-          uint32_t slot[8], at[8];
-#pragma unroll
-          for (uint32_t j = 0; j < 8; ++j) {
-            const uint32_t rel = (j0 + j) * kWide + tid;
-            const uint32_t w = s_word[rel >> 5];
-            at[j] = (w >> bit) & 1u ? tail + s_rank[rel >> 5] + __popc(w & below) : ~0u;
-            slot[j] = at[j] != ~0u ? q[pos0 + rel] : 0u;
-          }
-#pragma unroll
-          for (uint32_t j = 0; j < 8; ++j) {
-            if (at[j] != ~0u) {
-              q[at[j]] = slot[j];
-              c.qpos[slot[j]] = at[j];
-            }
-          }
-        }
-      }
-    }
-    const uint32_t stride = list_blocks * kWide;
-    for (uint32_t m = (blockIdx.x - row_blocks) * kWide + tid; m < k; m += stride) {
-      const uint32_t slot = c.rep_row[m];
-      q[tail + th + m] = slot;
-      c.qpos[slot] = tail + th + m;
-    }
-    if (blockIdx.x == row_blocks && tid == 0) {
-      c.qstate->tail = tail + th + k;
-      c.qstate->head = k ? c.rep_rank[k - 1] + 1u : head;
-    }
-    return;
-  }
   const uint32_t* list = c.queue[parity & 1u];
   uint32_t* next = c.queue[(parity & 1u) ^ 1u];
   // A workgroup rewrites SUB-tiles of kWide entries, one per thread (the scan kernel counted
@@ -1980,22 +2078,33 @@ __global__ void list_fill_kernel(uint32_t* list, uint32_t first, uint32_t prefix
 // ---- LRU as a queue (large caches) --------------------------------------------------------
 // The list passes above cost O(capacity) per update: 352 us for a 30 k-row block on a 40 M-slot
 // cache (GDELT scale) against 17 us for the gather itself.  From queue_min_capacity() slots on
-// (2 M), the SAME list is therefore kept as a queue with dead entries: `queue` holds entries
+// (0.5 M), the SAME list is therefore kept as a queue with dead entries: `queue` holds entries
 // [head, tail) (capacity * 3/2 allocated), qpos[slot] is the position of the slot's one LIVE
 // entry, and an update only appends — the distinct hit slots in the order of their old entries,
 // then the k victims, which are the first k live, not-hit entries from the head.  Old entries
 // die because qpos[] moves on.  Reading the live entries from head to tail gives exactly the
 // list of the list form, so both forms — and the oracle — make the same decisions.
-//   gather       : additionally leaves, per hit slot, one of the rows that hit it (hit_rep)
-//   list scan    : row role — the row that stands for a hit slot sets the bit of the slot's
-//                  queue position in `qbits` (so the hit slots come out deduplicated AND in
-//                  queue order without a sort: a 7-launch device radix sort cost 35 us here);
-//                  victim role — chunks of the queue behind the head, one workgroup each,
-//                  keep their live, not-hit entries
-//   queue count  : set bits per bitmap tile (the bitmap is 1/32 of the queue: 7.5 MB at 40 M
-//                  slots) and the chunks' candidates packed into one victim list
-//   list install : row role as in the list form; append role — the non-empty bitmap tiles
-//                  are expanded to the tail, the victims follow, head / tail move
+//   gather       : a hit sets the bit of the slot's queue position in `qbits` (atomicOr); the
+//                  row whose atomic set it stands for the slot (rep_flag = kRepHit | position).
+//                  The hit slots thus come out deduplicated AND in queue order without a sort
+//                  (a 7-launch device radix sort cost 35 us here), and nothing else in the
+//                  update touches a per-slot hit mark
+//   list scan    : row role — representatives of the distinct missed ids, as in the list form;
+//                  victim role — chunks of the queue behind the head, one workgroup each, keep
+//                  their live, not-hit entries (one scattered load per entry: qpos; the hit
+//                  bits are read densely)
+//   queue count  : per bitmap tile (the bitmap is 1/32 of the queue: 7.5 MB at 40 M slots) the
+//                  hit entries, per word a snapshot {word, hits before it in the tile}; the
+//                  chunks' candidates packed into one victim list
+//   list install : one thread per block row.  The m-th distinct missed id takes the m-th
+//                  victim's slot (as in the list form) and appends its entry at tail + hits +
+//                  m; the row that stands for a hit slot appends at tail + (hit entries before
+//                  its old one: tile prefix from LDS + the snapshot) and clears its bitmap
+//                  word; head / tail move.  Every step is O(block rows) and row-parallel: on
+//                  the GDELT-shaped step (38 M slots, 198 k-row blocks) the three launches
+//                  cost 247 us per step with the position-parallel append of round 4 (the
+//                  non-empty bitmap tiles expanded serially per workgroup) — see
+//                  profiles/README for this form
 // When the queue's tail would pass its allocation it is compacted into the other buffer (two
 // launches, O(capacity), once per ~capacity / (2 * block rows) updates); a block of more than
 // capacity / 4 rows is handled by the list form on the compacted queue (its passes are no
@@ -2148,11 +2257,12 @@ inline bool vec4_ok(size_t dim, const void* a, const void* b, const void* c) {
 // 30 k-row fetch with update costs 30 / 42 / 77 / 152 / 352 us in the list form at 0.13 / 1 / 4
 // / 16 / 40 M slots and 45 / 45 / 49 us in the queue form at 4 / 16 / 40 M
 // (profiles/r02_lru_capacity_sweep.jsonl)
-// (round 5, 30 k-row blocks, one-launch list update: 23.7 / 36.2 / 47.8 / 68.8 us per fetch at
-// 0.13 / 0.5 / 1 / 2 M slots, queue form 54.0 / 48.5 / 45.5 / 45.8: they cross at ~1 M slots)
+// (round 5, 30 k-row blocks, one-launch list update: 23.9 / 36.3 / 48.5 / 68.8 us per fetch at
+// 0.13 / 0.5 / 1 / 2 M slots; row-parallel queue form 41.6 / 36.8 / 35.0 / 34.9 / 34.5 / 37.7 at
+// 0.13 / 0.5 / 1 / 2 / 16 / 40 M: they cross at ~0.5 M slots; profiles/r05_lru_capacity_sweep.txt)
 inline size_t queue_min_capacity() {
   const char* v = std::getenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY");   // tuning / tests
-  return v ? static_cast<size_t>(std::atoll(v)) : (size_t{1} << 20);
+  return v ? static_cast<size_t>(std::atoll(v)) : (size_t{1} << 19);
 }
 
 // chunks of kRowTile queue entries the victim walk covers behind the head: twice the rows
@@ -2259,7 +2369,7 @@ void launch_round(Round& r, hipStream_t stream) {
   if (!any_update) return;
   ProfileScope ps(kProfLru, stream);
   size_t q_scan_blocks = 0, q_rows = 0, q_cap = 0, q_bit_tiles = 0, q_victim_blocks = 1;
-  size_t q_append_blocks = 0, q_inst_blocks = 0;
+  size_t q_inst_blocks = 0, qq_rows = 0;
   size_t h_n = 0, h_cap = 0, h_tiles = 0;
   size_t f_tiles = 0, f_rows = 0;
   for (int i = 0; i < r.count; ++i) {
@@ -2272,17 +2382,16 @@ void launch_round(Round& r, hipStream_t stream) {
       const size_t row_tiles = (c.n + kLruRows - 1) / kLruRows;
       q_scan_blocks = std::max(q_scan_blocks, (row_tiles + c.tiles_per_wg - 1) / c.tiles_per_wg);
       q_rows = std::max<size_t>(q_rows, c.n);
-      q_inst_blocks = std::max<size_t>(q_inst_blocks, (c.n + c.inst_rows - 1) / c.inst_rows);
       if (c.qmode) {
-        // queue form: bitmap tiles of kWide words (32 queue positions per word; the tail is
-        // below 1.5 * capacity + 64)
-        const size_t bit_tiles = ((size_t{c.capacity} * 3 / 2 + 128) / 32 + kWide - 1) / kWide + 1;
-        q_bit_tiles = std::max(q_bit_tiles, std::max<size_t>(bit_tiles, c.v_chunks) + 1);
+        // queue form: bitmap tiles of kBitTile words (32 queue positions per word; the tail
+        // is below 1.5 * capacity + 64)
+        const size_t bit_tiles = ((size_t{c.capacity} * 3 / 2 + 128) / 32 + kBitTile - 1) / kBitTile + 1;
+        q_bit_tiles = std::max(q_bit_tiles, bit_tiles);
         q_victim_blocks = std::max<size_t>(q_victim_blocks, std::min<size_t>(c.v_chunks, 1024));
-        q_append_blocks = std::max(q_append_blocks,
-                                   std::min<size_t>(std::max<size_t>(bit_tiles / 4, 16), 256));
+        qq_rows = std::max<size_t>(qq_rows, c.n);
       } else {
         q_cap = std::max<size_t>(q_cap, c.capacity);
+        q_inst_blocks = std::max<size_t>(q_inst_blocks, (c.n + c.inst_rows - 1) / c.inst_rows);
       }
     } else {
       h_n = std::max<size_t>(h_n, c.n);
@@ -2302,18 +2411,23 @@ void launch_round(Round& r, hipStream_t stream) {
     // list workgroups: per kRowTile list entries of the list-form contexts (none: queue form
     // only); the install kernel's also append for the queue-form contexts
     const unsigned lb_list = static_cast<unsigned>(
-        std::min<size_t>((q_cap + kRowTile - 1) / kRowTile, 1024));
+        std::min<size_t>(std::max((q_cap + kRowTile - 1) / kRowTile, q_bit_tiles), 1024));
     // install: sub-tiles of kWide list entries per workgroup for the list-form contexts
     const unsigned lb_sub = static_cast<unsigned>(std::min<size_t>((q_cap + kWide - 1) / kWide, 1024));
-    const unsigned lb = std::max<unsigned>(1, std::max(lb_sub, static_cast<unsigned>(q_append_blocks)));
+    const unsigned lb = std::max<unsigned>(1, lb_sub);
     const unsigned vb = static_cast<unsigned>(q_victim_blocks);
     lru_list_scan_kernel<<<dim3(rb + lb_list + vb, r.count), dim3(kWide), 0, stream>>>(
         r, rb, lb_list, vb);
-    if (q_bit_tiles)
-      lru_queue_count_kernel<<<dim3(static_cast<unsigned>(std::min<size_t>(q_bit_tiles, 1024)),
-                                    r.count), dim3(kWide), 0, stream>>>(r);
-    const unsigned ib = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(q_inst_blocks, 4096)));
-    lru_list_install_kernel<<<dim3(ib + lb, r.count), dim3(kWide), 0, stream>>>(r, ib, lb);
+    if (q_bit_tiles) {
+      lru_queue_walk_kernel<<<dim3(1, r.count), dim3(kWide), 0, stream>>>(r);
+      const unsigned qb = static_cast<unsigned>(
+          std::max<size_t>(1, std::min<size_t>((qq_rows + kQInst - 1) / kQInst, 16384)));
+      lru_queue_install_kernel<<<dim3(qb, r.count), dim3(kQInst), 0, stream>>>(r);
+    }
+    if (q_inst_blocks) {
+      const unsigned ib = static_cast<unsigned>(std::min<size_t>(q_inst_blocks, 4096));
+      lru_list_install_kernel<<<dim3(ib + lb, r.count), dim3(kWide), 0, stream>>>(r, ib, lb);
+    }
     GF_HIP(hipGetLastError());
   }
   if (!h_cap) return;
@@ -2448,7 +2562,8 @@ void FeatureCache::init_queue(hipStream_t stream) {
   tail_bound_ = capacity_;
   qpos_.reserve(std::max<size_t>(capacity_, 4) * sizeof(uint32_t), 0, stream);
   if (queue_form_) {
-    hit_rep_.reserve(capacity_ * sizeof(uint32_t), 0, stream);
+    GF_REQUIRE(queue_cap_ < (size_t{1} << 30), "LRU queue form: more than 2^30 queue positions");
+    wsnap_.reserve(2 * qbits_bytes(queue_cap_), 0, stream);
     qbits_.reserve(qbits_bytes(queue_cap_), 0, stream);
     GF_HIP(hipMemsetAsync(qbits_.data(), 0, qbits_bytes(queue_cap_), stream));
     const size_t tiles = (queue_cap_ + kRowTile - 1) / kRowTile + 1;
@@ -2456,7 +2571,7 @@ void FeatureCache::init_queue(hipStream_t stream) {
     compact_.reserve(align_up(tiles * (kRowTile / 64) * 8, 256) + align_up(tiles * 4, 256) +
                      align_up(groups * 4, 256) + 256, 0, stream);
   } else {
-    hit_rep_.release();
+    wsnap_.release();
     qbits_.release();
     compact_.release();
   }
@@ -2535,7 +2650,7 @@ void FeatureCache::set_policy(int policy) {
     queue_.release();
     queue_alt_.release();
     qpos_.release();
-    hit_rep_.release();
+    wsnap_.release();
     qbits_.release();
     compact_.release();
     queue_form_ = false;
@@ -2662,8 +2777,9 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
       std::swap(qpos_, np);
     }
     if (queue_form_) {
+      GF_REQUIRE(queue_cap_ < (size_t{1} << 30), "LRU queue form: more than 2^30 queue positions");
       DeviceBuffer nh, nc, nbits;
-      nh.reserve(new_capacity * sizeof(uint32_t));
+      nh.reserve(2 * qbits_bytes(queue_cap_));
       nbits.reserve(qbits_bytes(queue_cap_));
       GF_HIP(hipMemsetAsync(nbits.data(), 0, qbits_bytes(queue_cap_), stream));
       std::swap(qbits_, nbits);
@@ -2671,7 +2787,7 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
       const size_t groups = (tiles + kQGroup - 1) / kQGroup + 1;
       nc.reserve(align_up(tiles * (kRowTile / 64) * 8, 256) + align_up(tiles * 4, 256) +
                  align_up(groups * 4, 256) + 256);
-      std::swap(hit_rep_, nh);
+      std::swap(wsnap_, nh);
       std::swap(compact_, nc);
     }
     index_queue(stream);
@@ -2775,13 +2891,15 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
     }
     c.qpos = qpos_.as<uint32_t>();
     if (queue_form_) {
-      c.hit_rep = hit_rep_.as<uint32_t>();
-      if (n <= capacity_ / 4) {
+      if (n <= capacity_ / 4 && victim_chunks(n) + 1 <= kMaxVChunks) {
         // appends at most n entries (#distinct hit slots + #victims <= rows)
         if (tail_bound_ + n > queue_cap_) compact_queue(stream);
         tail_bound_ += n;
         c.qmode = 1;
         c.qbits = qbits_.as<uint32_t>();
+        c.wsnap = wsnap_.as<uint2>();
+        const size_t bit_tiles = ((queue_cap_ + 64) / 32 + kBitTile - 1) / kBitTile + 1;
+        c.q_group = static_cast<uint32_t>((bit_tiles + kMaxBitGroups - 1) / kMaxBitGroups);
         c.v_chunks = static_cast<uint32_t>(victim_chunks(n));
         c.stage_tiles = 0;
       } else {

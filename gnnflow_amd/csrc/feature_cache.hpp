@@ -113,7 +113,7 @@ class FeatureCache {
   // LRU of a large cache is kept as a queue with dead entries (feature_cache.hip, "LRU as a
   // queue"): updates cost O(block rows), not O(capacity)
   DeviceBuffer qpos_;      // uint32[capacity]  position of the slot's (live) list / queue entry
-  DeviceBuffer hit_rep_;   // uint32[capacity]  a row of the current block that hit the slot
+  DeviceBuffer wsnap_;     // uint2 per word of qbits_: {word, hit entries before it in its tile}
   DeviceBuffer qbits_;     // one bit per queue position: entries hit by the current block
   DeviceBuffer compact_;   // scratch of the (rare) queue compaction
   bool queue_form_ = false;
