@@ -2336,6 +2336,46 @@ inline unsigned gather_grid_for(size_t n, uint32_t tile_rows) {
   return static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>((waves + 3) / 4, 1024)));
 }
 
+// Side stream of the calling host thread for rounds that update caches of two forms (created on
+// first use only: an extra stream shifts the process's hardware-queue mapping).
+struct RoundFork {
+  hipStream_t side = nullptr;
+  hipEvent_t begin = nullptr, end = nullptr;
+  int device = -1;
+  ~RoundFork() {
+    if (side) (void)hipStreamDestroy(side);
+    if (begin) (void)hipEventDestroy(begin);
+    if (end) (void)hipEventDestroy(end);
+  }
+};
+inline RoundFork& round_fork() {
+  static thread_local RoundFork f;
+  return f;
+}
+inline bool fork_round(hipStream_t stream, hipStream_t* side) {
+  static const bool enabled = [] {
+    const char* v = std::getenv("GNNFLOW_LRU_FORK");   // tuning / tests; 0: one stream
+    return !(v && std::atoi(v) == 0);
+  }();
+  if (!enabled) return false;
+  RoundFork& f = round_fork();
+  int dev = 0;
+  GF_HIP(hipGetDevice(&dev));
+  if (f.side && f.device != dev) return false;   // one device per host thread in practice
+  if (!f.side) {
+    GF_HIP(hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking));
+    GF_HIP(hipEventCreateWithFlags(&f.begin, hipEventDisableTiming));
+    GF_HIP(hipEventCreateWithFlags(&f.end, hipEventDisableTiming));
+    f.device = dev;
+  }
+  GF_HIP(hipEventRecord(f.begin, stream));
+  GF_HIP(hipStreamWaitEvent(f.side, f.begin, 0));
+  *side = f.side;
+  return true;
+}
+inline void fork_done() { GF_HIP(hipEventRecord(round_fork().end, round_fork().side)); }
+inline void join_round(hipStream_t stream) { GF_HIP(hipStreamWaitEvent(stream, round_fork().end, 0)); }
+
 // Issues one round: the gather for every context, then (if any context updates its cache)
 // the four bookkeeping launches.
 void launch_round(Round& r, hipStream_t stream) {
@@ -2372,6 +2412,8 @@ void launch_round(Round& r, hipStream_t stream) {
   size_t q_inst_blocks = 0, qq_rows = 0;
   size_t h_n = 0, h_cap = 0, h_tiles = 0;
   size_t f_tiles = 0, f_rows = 0;
+  bool forked = false;
+  hipStream_t side = nullptr;
   for (int i = 0; i < r.count; ++i) {
     const Ctx& c = r.c[i];
     if (!c.update) continue;
@@ -2403,8 +2445,14 @@ void launch_round(Round& r, hipStream_t stream) {
     const unsigned cb = static_cast<unsigned>(std::min<size_t>(f_tiles, 1024));
     const unsigned rb = static_cast<unsigned>(std::max<size_t>(f_rows, 1));
     const unsigned wb = static_cast<unsigned>(std::min<size_t>(f_tiles, kFuseMaxTiles));
-    lru_list_fused_kernel<<<dim3(cb + rb + wb, r.count), dim3(kWide), 0, stream>>>(r, cb, rb, wb);
+    // a round that also carries a queue-form (or two-launch) update — a small node cache beside a
+    // GDELT-scale edge cache — runs this launch on a side stream, beside those launches: the
+    // contexts are different caches, and both chains are bound by dependent accesses, not by CUs
+    forked = q_rows != 0 && fork_round(stream, &side);
+    lru_list_fused_kernel<<<dim3(cb + rb + wb, r.count), dim3(kWide), 0, forked ? side : stream>>>(
+        r, cb, rb, wb);
     GF_HIP(hipGetLastError());
+    if (forked) fork_done();
   }
   if (q_rows) {   // LRU: list scan + list install
     const unsigned rb = static_cast<unsigned>(q_scan_blocks);
@@ -2429,6 +2477,7 @@ void launch_round(Round& r, hipStream_t stream) {
       lru_list_install_kernel<<<dim3(ib + lb, r.count), dim3(kWide), 0, stream>>>(r, ib, lb);
     }
     GF_HIP(hipGetLastError());
+    if (forked) join_round(stream);
   }
   if (!h_cap) return;
   max_n = h_n; max_cap = h_cap; max_tiles = h_tiles;
