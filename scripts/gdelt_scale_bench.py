@@ -104,11 +104,27 @@ def main():
     warm = min(args.warmup, nb // 4)
     pipe.run(0, warm, None)
     torch.cuda.synchronize()
+    # HIP events on every 7th gather launch of the timed region (bench.py's mechanism); the
+    # algorithmic bytes of the fetches: rows * row bytes, read + written
+    import ctypes as C
+    from gnnflow_amd import _capi
+    lib = _capi.load()
+    lib.gf_profile_reset()
+    lib.gf_profile_set_stride(7)
+    lib.gf_profile_enable(1 << _capi.PROFILE_SLOTS["gather"])
+    cache.algorithmic_bytes = 0
     t0 = time.time()
     pipe.run(warm, nb - warm, on_step)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    lib.gf_profile_enable(0)
+    lib.gf_profile_set_stride(1)
+    g_ms, g_n, g_all = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+    lib.gf_profile_get(_capi.PROFILE_SLOTS["gather"], C.byref(g_ms), C.byref(g_n))
+    lib.gf_profile_launches(_capi.PROFILE_SLOTS["gather"], C.byref(g_all))
     steps = nb - warm
+    gather_us = g_ms.value * 1e3 / max(1, g_n.value)            # per launch, sampled
+    gather_bytes = cache.algorithmic_bytes / max(1, g_all.value)  # per launch, all of them
     # every row fetched in the last step equals its table row
     ok = True
     for k, mfg in enumerate(last[0]):
@@ -125,6 +141,11 @@ def main():
         "nodes": N, "edges": E, "steps": steps, "us_per_step": round(dt / steps * 1e6, 1),
         "sampled_edges_per_step": round(edges[0] / steps, 1),
         "sampled_edges_per_s": round(edges[0] / dt),
+        "gather": {"launches_per_step": round(g_all.value / steps, 2), "timed_launches": int(g_n.value),
+                   "us_per_launch": round(gather_us, 1),
+                   "algorithmic_MB_per_launch": round(gather_bytes / 1e6, 1),
+                   "GB_per_s": round(gather_bytes / max(gather_us, 1e-9) / 1e3, 1),
+                   "frac_of_8TBps": round(gather_bytes / max(gather_us, 1e-9) / 1e3 / 8000.0, 3)},
         "cache_edge_ratio": round(float(cache.cache_edge_ratio), 4),
         "cache_node_ratio": round(float(cache.cache_node_ratio), 4),
         "edge_cache_slots": cache.edge_capacity,
