@@ -266,7 +266,9 @@ constexpr uint32_t kRepMiss = 1u << 31, kRepRank = kRepMiss - 1u;
 constexpr uint32_t kRepHit = 1u << 30, kRepPos = kRepHit - 1u;
 
 // ---- the gather kernel -------------------------------------------------------------
-template <typename VecT, bool kOdd = false>
+// kLean: the instantiation for rounds of float4 rows on list-form / cache-free contexts with
+// the default 12 loads in flight (no queue-form hit path, one copy loop)
+template <typename VecT, bool kOdd = false, bool kLean = false>
 __device__ inline void gather_body(const Ctx& c) {
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * kThreads + threadIdx.x;
@@ -310,7 +312,7 @@ __device__ inline void gather_body(const Ctx& c) {
           src = cache_buf + static_cast<uint64_t>(slot) * rowu;
           // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
           // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161).
-          if (c.qmode) {
+          if (!kLean && c.qmode) {
             // queue form: the mark is the bit of the entry's queue position; the row whose
             // atomic set it stands for the slot (it will append the slot's new entry)
             const uint32_t pos = c.qpos[slot], bit = 1u << (pos & 31u);
@@ -378,11 +380,11 @@ __device__ inline void gather_body(const Ctx& c) {
           if (p[k]) nt_store(v[k], reinterpret_cast<VecT*>(o + at[k]));
       }
     };
-    if (c.inflight >= 12) copy(std::integral_constant<int, 12>{});
+    if (kLean || c.inflight >= 12) copy(std::integral_constant<int, 12>{});
     else if (c.inflight >= 8) copy(std::integral_constant<int, 8>{});
     else copy(std::integral_constant<int, 4>{});
     // (behind the copy: the atomic's return value has long arrived)
-    if (c.qmode && lane < static_cast<int>(rows)) c.rep_flag[row0 + lane] = hit_code;
+    if (!kLean && c.qmode && lane < static_cast<int>(rows)) c.rep_flag[row0 + lane] = hit_code;
   }
   if (c.ctr) {
     __shared__ uint32_t wg_hits, wg_miss;
@@ -409,6 +411,15 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
   if (c.vec4) gather_body<float4>(c);
   else if (c.odd4) gather_body<uf4, true>(c);
   else gather_body<float>(c);
+}
+
+// The same for rounds whose contexts all take the float4 / list-form / 12-in-flight path (the
+// headline replay): a third of the code — a 14 us launch over 256 CUs pays for the instruction
+// bytes it has to fetch (same box A/B, round 5: see profiles/README)
+__global__ __launch_bounds__(kThreads) void gather_rows_lean_kernel(Round r) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (c.n == 0) return;
+  gather_body<float4, false, true>(c);
 }
 
 // ---- planning a pull from sharded feature tables -------------------------------------------
@@ -2395,14 +2406,17 @@ void launch_round(Round& r, hipStream_t stream) {
     }
   }
   {
+    bool lean = true;
+    for (int i = 0; i < r.count; ++i)
+      lean = lean && r.c[i].vec4 && !r.c[i].qmode && r.c[i].inflight >= 12;
+    auto* kernel = lean ? gather_rows_lean_kernel : gather_rows_kernel;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile_begin(kProfGather, &e0, &e1)) {
       // the events ride on the dispatch itself: its begin / end timestamps
-      hipExtLaunchKernelGGL(gather_rows_kernel, dim3(ggrid, r.count), dim3(kThreads), 0, stream,
-                            e0, e1, 0, r);
+      hipExtLaunchKernelGGL(kernel, dim3(ggrid, r.count), dim3(kThreads), 0, stream, e0, e1, 0, r);
       profile_end(kProfGather, e0, e1);
     } else {
-      gather_rows_kernel<<<dim3(ggrid, r.count), dim3(kThreads), 0, stream>>>(r);
+      kernel<<<dim3(ggrid, r.count), dim3(kThreads), 0, stream>>>(r);
     }
     GF_HIP(hipGetLastError());
   }
