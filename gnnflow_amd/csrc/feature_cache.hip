@@ -2963,6 +2963,11 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
         c.wsnap = wsnap_.as<uint2>();
         const size_t bit_tiles = ((queue_cap_ + 64) / 32 + kBitTile - 1) / kBitTile + 1;
         c.q_group = static_cast<uint32_t>((bit_tiles + kMaxBitGroups - 1) / kMaxBitGroups);
+        static const uint32_t forced_group = [] {
+          const char* e = std::getenv("GNNFLOW_LRU_QUEUE_GROUP");   // tests: the > 89 M-slot path
+          return e ? static_cast<uint32_t>(std::atoi(e)) : 0u;
+        }();
+        c.q_group = std::max(c.q_group, forced_group);
         c.v_chunks = static_cast<uint32_t>(victim_chunks(n));
         c.stage_tiles = 0;
       } else {

@@ -533,3 +533,46 @@ def test_many_updates_cross_several_compactions(lru_form):
     else:
         assert st == dict(queue_form=0, queue_entries=cap, head=0, tail=cap, compactions=0,
                           list_form_updates=0, lone_walks=0)
+
+
+def test_blocks_without_a_miss_leave_no_marks_behind(lru_form):
+    """cache.py:318-323 / lru_cache.py: update only runs for a block that misses, so the hits of
+    an all-hit block refresh nothing.  The queue form marks hit entries in a bitmap DURING the
+    gather: those marks must be gone before the next block, or it would spare their slots."""
+    cap = 4096
+    hip, ora, ef = _edge_only_pair(E=8 * cap, cap_ratio=0.125, seed=21)
+    rng = np.random.RandomState(9)
+    step = 0
+    first = rng.permutation(cap)[:3000]
+    _fetch_both(hip, ora, ef, first, step); step += 1           # identity-filled cache: all hits
+    _fetch_both(hip, ora, ef, np.arange(cap, cap + 900), step); step += 1   # misses: 900 evictions
+    for _ in range(3):
+        # the most recently installed ids again — every row hits, nothing may move ...
+        _fetch_both(hip, ora, ef, np.arange(cap, cap + 900)[rng.permutation(900)[:500]], step); step += 1
+        # ... then blocks that miss and evict in the order the oracle's untouched list gives
+        _fetch_both(hip, ora, ef, rng.randint(2 * cap, 8 * cap, 700), step); step += 1
+        _fetch_both(hip, ora, ef, np.concatenate([rng.randint(0, cap, 300),
+                                                  rng.randint(2 * cap, 8 * cap, 300)]), step); step += 1
+    if lru_form == "queue":
+        assert hip._edge.lru_state()["queue_form"] == 1
+
+
+def test_queue_form_bitmap_spanning_several_tiles_and_groups(monkeypatch):
+    """A 300 k-slot queue-form cache: its hit bitmap spans several tiles of 131 072 queue positions;
+    GNNFLOW_LRU_QUEUE_GROUP=2 makes the install kernel's LDS prefix hold one entry per TWO tiles
+    (what caches beyond 89 M slots get), so a hit entry's rank also sums the tiles of its group."""
+    monkeypatch.setenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", "1")
+    monkeypatch.setenv("GNNFLOW_LRU_QUEUE_GROUP", "2")
+    monkeypatch.delenv("GNNFLOW_LRU_FUSED", raising=False)
+    E, cap = 1_500_000, 300_000
+    hip, ora, ef = _edge_only_pair(E=E, cap_ratio=0.2, seed=33)
+    assert hip.edge_capacity == cap
+    rng = np.random.RandomState(13)
+    for step in range(10):
+        lo = cap + step * 9000
+        ids = np.concatenate([rng.randint(lo, lo + 60000, 15000),      # recent ids: hits near the tail
+                              rng.randint(0, cap, 6000),                # old residents: hits anywhere
+                              rng.randint(0, E, 4000)])                 # cold ids
+        _fetch_both(hip, ora, ef, ids, step)
+    st = hip._edge.lru_state()
+    assert st["queue_form"] == 1 and st["tail"] > 2 * 131072 and st["list_form_updates"] == 0
