@@ -473,6 +473,16 @@ def agree(ctx, ok):
 GIVE_UP = 75     # exit status of a rung's worker that hands over to the next rung
 
 
+def rung_seconds(name, rung, defaults):
+    """A time limit of the ladder from the environment: one value for every rung, or one per
+    rung, comma-separated ("15,150": rung 0 gives up after 15 s, rung 1 after 150)."""
+    v = os.environ.get(name)
+    if not v:
+        return float(defaults[min(rung, len(defaults) - 1)])
+    parts = [p for p in v.split(",") if p.strip()]
+    return float(parts[min(rung, len(parts) - 1)])
+
+
 def supervise(args, argv):
     """One RANK of an N > 1 run (started by torchrun or by launch_ranks): this process never
     touches the GPU.  It runs the rungs of the ladder (RUNGS) one after the other, each as a
@@ -506,8 +516,8 @@ def supervise(args, argv):
             # the worker's own watchdog covers its main loop; this covers everything else
             # (set-up included) should the worker be too wedged to exit by itself
             # (the first worker of a fresh box also pages torch in: 1-2 minutes)
-            limit = float(os.environ.get("GNNFLOW_HASH_MAIN_TIMEOUT", "150" if rung == 0 else "120")) + \
-                float(os.environ.get("GNNFLOW_RUNG_SETUP_ALLOWANCE", "180" if rung == 0 else "90"))
+            limit = rung_seconds("GNNFLOW_HASH_MAIN_TIMEOUT", rung, (150, 120)) + \
+                rung_seconds("GNNFLOW_RUNG_SETUP_ALLOWANCE", rung, (180, 90))
         t0 = time.time()
         kid = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                stdin=subprocess.DEVNULL,
@@ -753,7 +763,7 @@ def main():
     if laddered and rung < 2:
         import threading
         hang_guard = threading.Event()
-        hang_limit = float(os.environ.get("GNNFLOW_HASH_MAIN_TIMEOUT", "150" if rung == 0 else "120"))
+        hang_limit = rung_seconds("GNNFLOW_HASH_MAIN_TIMEOUT", rung, (150, 120))
 
         def hash_hang_watchdog():
             if hang_guard.wait(hang_limit):
