@@ -44,11 +44,12 @@ the roots travel to their owners and the sampled neighbours back as RCCL all-to-
 inside a sample).  Feature tables (REDDIT-shaped: 463 MB) are replicated, the LRU cache is
 per GPU.  The per-GPU-replica figure (no data-path collective; what the reference does
 inside one machine) rides along as the extra key "replica"; `--partition replica` makes
-it the main loop.  Should the hash-partitioned loop FAIL (RCCL between ranks ran for the first
-time in the driver's scaling run), every rank falls back to the replica loop: the line then
-says "parallelism": "replica-dpN" and carries the failure under "hash_partition": {"error"}.
-Should it HANG (a collective some rank never joins), after GNNFLOW_HASH_MAIN_TIMEOUT (240) seconds
-every rank starts a fresh process that times the replica loop on a new rendezvous port; same line.
+it the main loop.  RCCL between ranks runs for the first time in the driver's scaling run, so
+an N > 1 run walks a LADDER (supervise(), RUNGS), each rung in fresh worker processes: the hash
+loop as above; should it FAIL or HANG (a collective some rank never joins: the worker's watchdog
+fires after GNNFLOW_HASH_MAIN_TIMEOUT seconds), the hash loop on ONE lane (one communicator) with
+shared chains; then on one lane with single chains and slot capacity 2.0; then the replica loop.
+The one line says which rung produced it and what happened before ("ladder").
 At N = 1 the main loop is the plain single-GPU path; the hash path rides along twice: "hash_partition"
 (every root is the rank's own, no exchange) and "hash_partition_over_rccl_one_rank" (the chain an
 N > 1 run issues — slotted exchange, lanes, up to four samples per chain — with every message
@@ -290,8 +291,14 @@ class Ctx:
 
 
 # the N > 1 ladder (main()): arrangement, what it is
+# (time limits per rung: rung_seconds(); the whole ladder fits the driver's 600 s)
+RUNG_MAIN_SECONDS = (100, 70, 70)      # the hash loop's own watchdog
+RUNG_SETUP_SECONDS = (150, 60, 60)     # on top of it before the supervisor kills the worker
 RUNGS = [("hash", "graph hash-partitioned over the ranks; sampling lanes x shared chains of up to "
                   "four samples, one communicator per lane"),
+         ("hash-one-lane", "graph hash-partitioned over the ranks; ONE lane — one communicator, "
+                           "never two collectives in flight — with shared chains of up to four "
+                           "samples"),
          ("hash-simple", "graph hash-partitioned over the ranks; ONE lane, single chains, slot "
                          "capacity 2.0 x the even share: one communicator, never two collectives "
                          "in flight"),
@@ -489,8 +496,8 @@ def supervise(args, argv):
     WORKER process of its own on a new rendezvous port, until one of them prints the line:
       * a worker that finishes prints the ONE JSON line (rank 0) and exits 0;
       * a worker whose hash-partitioned loop RAISES (the ranks agree through an all-reduce) or
-        HANGS (its watchdog fires after GNNFLOW_HASH_MAIN_TIMEOUT: 150 s on rung 0, 120 s on
-        rung 1 — all three rungs fit the driver's 600 s) leaves a ladder entry and exits
+        HANGS (its watchdog fires after GNNFLOW_HASH_MAIN_TIMEOUT: RUNG_MAIN_SECONDS — the
+        whole ladder fits the driver's 600 s) leaves a ladder entry and exits
         GIVE_UP; one that does not even do that is killed.  Either way the process is GONE —
         and with it its communicators and whatever kernels it still had on the GPU — before
         the next rung's worker starts: no figure shares the GPU with an abandoned run.
@@ -516,8 +523,8 @@ def supervise(args, argv):
             # the worker's own watchdog covers its main loop; this covers everything else
             # (set-up included) should the worker be too wedged to exit by itself
             # (the first worker of a fresh box also pages torch in: 1-2 minutes)
-            limit = rung_seconds("GNNFLOW_HASH_MAIN_TIMEOUT", rung, (150, 120)) + \
-                rung_seconds("GNNFLOW_RUNG_SETUP_ALLOWANCE", rung, (180, 90))
+            limit = rung_seconds("GNNFLOW_HASH_MAIN_TIMEOUT", rung, RUNG_MAIN_SECONDS) + \
+                rung_seconds("GNNFLOW_RUNG_SETUP_ALLOWANCE", rung, RUNG_SETUP_SECONDS)
         t0 = time.time()
         kid = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                stdin=subprocess.DEVNULL,
@@ -590,7 +597,8 @@ def main():
         # outcome — "ok" prints a line, "giveup" leaves a ladder entry and exits GIVE_UP, "hang"
         # never exits, "die" exits 9 — so that launcher + supervisor + ladder run end to end
         rung = int(os.environ["GNNFLOW_BENCH_RUNG"])
-        act = fake.split(",")[rung]
+        acts = fake.split(",")
+        act = acts[min(rung, len(acts) - 1)]
         if act == "hang":
             time.sleep(1e6)
         if act == "die":
@@ -733,11 +741,14 @@ def main():
     rung = int(os.environ.get("GNNFLOW_BENCH_RUNG", "0"))
     history = json.loads(os.environ.get("GNNFLOW_BENCH_LADDER", "[]"))
     laddered = "GNNFLOW_BENCH_WORKER" in os.environ and world > 1
+    last_rung = len(RUNGS) - 1
     if not laddered:
-        rung = 2 if args.partition == "replica" else 0
+        rung = last_rung if args.partition == "replica" else 0
     if laddered and rung == 1:
+        args.part_lanes = 1
+    if laddered and rung == 2:
         args.part_lanes, args.part_chain, args.part_slack = 1, 1, 2.0
-    if laddered and rung >= 2:
+    if laddered and rung >= last_rung:
         args.partition = "replica"
     main_kind, res = args.partition, None
     ctx.rung, ctx.history = rung, history
@@ -760,10 +771,10 @@ def main():
         os._exit(GIVE_UP)
 
     hang_guard = None
-    if laddered and rung < 2:
+    if laddered and rung < last_rung:
         import threading
         hang_guard = threading.Event()
-        hang_limit = rung_seconds("GNNFLOW_HASH_MAIN_TIMEOUT", rung, (150, 120))
+        hang_limit = rung_seconds("GNNFLOW_HASH_MAIN_TIMEOUT", rung, RUNG_MAIN_SECONDS)
 
         def hash_hang_watchdog():
             if hang_guard.wait(hang_limit):
@@ -779,9 +790,9 @@ def main():
         on = os.environ.get("GNNFLOW_BENCH_{}_RUNGS".format(name), rungs_default).split(",")
         return v if (v is not None and main_kind == "hash" and str(rung) in on) else None
     try:
-        if hooked("FAIL", "0,1"):
+        if hooked("FAIL", "0,1,2"):
             raise RuntimeError("GNNFLOW_BENCH_FAIL_HASH is set")
-        hang = hooked("HANG", "0,1")
+        hang = hooked("HANG", "0,1,2")
         if hang is not None and hang in ("all", str(rank)):
             time.sleep(1e6)
         res = run_main(main_kind)
@@ -797,7 +808,7 @@ def main():
         time.sleep(1e6)
     if not agreed:
         failure = failure or "the loop failed on another rank"
-        if laddered and rung < 2:
+        if laddered and rung < last_rung:
             give_up(failure, hung=False)
         if rank == 0:
             emit({"metric": "sampled_edges_per_s", "value": 0.0, "unit": "edges/s",

@@ -20,10 +20,10 @@ def test_launcher_reports_failing_ranks_with_one_line():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    # every rank is a supervisor that walks the ladder (hash, hash-simple, replica) with a fresh
+    # every rank is a supervisor that walks the ladder (hash, hash-one-lane, hash-simple, replica) with a fresh
     # worker per rung; here every worker dies at once, and rank 0's supervisor says so
     assert d["value"] == 0.0 and d["n_gpus"] == 2 and "no rung printed a record" in d["error"]
-    assert [h["arrangement"] for h in d["ladder"]] == ["hash", "hash-simple"]
+    assert [h["arrangement"] for h in d["ladder"]] == ["hash", "hash-one-lane", "hash-simple"]
     assert all("exited with status" in h["error"] and not h["worker_killed"] for h in d["ladder"])
     assert "bench.py needs a GPU" in p.stderr          # the workers' own message got through
 
@@ -52,25 +52,29 @@ def _acted(outcomes, extra_env=None):
 
 
 def test_ladder_first_rung_succeeds():
-    rc, d, _ = _acted("ok,ok,ok")
+    rc, d, _ = _acted("ok,ok,ok,ok")
     assert rc == 0 and d["ladder"]["rung"] == 0 and d["ladder"]["tried_before"] == []
 
 
 def test_ladder_walks_down_when_rungs_give_up():
     """Launcher -> two supervisors (never a GPU call) -> a worker per rung (here: acting its
-    outcome): rung 0 gives up on both ranks, rung 1 gives up, the replica rung prints the line;
-    every rung rendezvous on its own port."""
-    rc, d, err = _acted("giveup,giveup,ok")
+    outcome): the three hash rungs give up on both ranks one after the other, the replica rung
+    prints the line; every rung rendezvous on its own port.  A rung in the middle that works ends
+    the walk there."""
+    rc, d, err = _acted("giveup,giveup,giveup,ok")
     assert rc == 0
     lad = d["ladder"]
-    assert lad["rung"] == 2 and lad["arrangement"] == "replica"
-    assert [h["arrangement"] for h in lad["tried_before"]] == ["hash", "hash-simple"]
+    assert lad["rung"] == 3 and lad["arrangement"] == "replica"
+    assert [h["arrangement"] for h in lad["tried_before"]] == ["hash", "hash-one-lane", "hash-simple"]
     assert all(h["hung"] and not h["worker_killed"] for h in lad["tried_before"])
-    assert "starting rung 1 (hash-simple)" in err and "starting rung 2 (replica)" in err
+    assert "starting rung 1 (hash-one-lane)" in err and "starting rung 2 (hash-simple)" in err
+    assert "starting rung 3 (replica)" in err
+    rc, d, _ = _acted("giveup,giveup,ok,ok")
+    assert rc == 0 and d["ladder"]["rung"] == 2 and d["ladder"]["arrangement"] == "hash-simple"
 
 
 def test_ladder_kills_a_worker_that_neither_finishes_nor_gives_up():
-    rc, d, _ = _acted("hang,ok,ok", {"GNNFLOW_HASH_MAIN_TIMEOUT": "2",
+    rc, d, _ = _acted("hang,ok,ok,ok", {"GNNFLOW_HASH_MAIN_TIMEOUT": "2",
                                      "GNNFLOW_RUNG_SETUP_ALLOWANCE": "1"})
     assert rc == 0 and d["ladder"]["rung"] == 1
     (h,) = d["ladder"]["tried_before"]
@@ -79,9 +83,9 @@ def test_ladder_kills_a_worker_that_neither_finishes_nor_gives_up():
 
 
 def test_ladder_ports_differ_per_rung_and_a_dying_last_rung_fails_the_run():
-    rc0, d0, _ = _acted("ok,ok,ok", {"MASTER_PORT": "29900"})
-    rc1, d1, _ = _acted("die,ok,ok", {"MASTER_PORT": "29900"})
+    rc0, d0, _ = _acted("ok,ok,ok,ok", {"MASTER_PORT": "29900"})
+    rc1, d1, _ = _acted("die,ok,ok,ok", {"MASTER_PORT": "29900"})
     assert d0["master_port"] != d1["master_port"]            # rung 0 and rung 1 rendezvous apart
-    rc, d, _ = _acted("die,die,die")
+    rc, d, _ = _acted("die,die,die,die")
     assert rc != 0 and d["value"] == 0.0 and "no rung printed a record" in d["error"]
-    assert [h["arrangement"] for h in d["ladder"]] == ["hash", "hash-simple"]
+    assert [h["arrangement"] for h in d["ladder"]] == ["hash", "hash-one-lane", "hash-simple"]

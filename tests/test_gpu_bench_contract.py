@@ -139,7 +139,7 @@ def test_bench_launches_its_own_ranks():
 
 
 def test_failing_hash_loop_falls_back_to_the_replica_figure():
-    """The hash-partitioned loop raising on every rank (on both hash rungs of the ladder) must
+    """The hash-partitioned loop raising on every rank (on all three hash rungs of the ladder) must
     not cost the line: fresh ranks time the replica loop and the record says so."""
     d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5",
               "--min-replays", "1", "--min-seconds", "0.2"],
@@ -149,24 +149,25 @@ def test_failing_hash_loop_falls_back_to_the_replica_figure():
     assert d["config"]["parallelism"] == "replica-dp2"
     assert "GNNFLOW_BENCH_FAIL_HASH" in d["hash_partition"]["error"]
     lad = d["ladder"]
-    assert lad["rung"] == 2 and lad["arrangement"] == "replica"
-    assert [h["arrangement"] for h in lad["tried_before"]] == ["hash", "hash-simple"]
+    assert lad["rung"] == 3 and lad["arrangement"] == "replica"
+    assert [h["arrangement"] for h in lad["tried_before"]] == ["hash", "hash-one-lane", "hash-simple"]
     assert all(h["hung"] is False for h in lad["tried_before"])
 
 
-@pytest.mark.parametrize("who,rungs,final", [("1", "0", "hash-simple"), ("all", "0,1", "replica")])
+@pytest.mark.parametrize("who,rungs,final", [("1", "0", "hash-one-lane"), ("1", "0,1", "hash-simple"),
+                                             ("all", "0,1,2", "replica")])
 def test_hanging_hash_loop_walks_down_the_ladder(who, rungs, final):
     """A collective that some rank never joins does not raise, it HANGS: after
     GNNFLOW_HASH_MAIN_TIMEOUT every rank's worker process gives up and exits, and the rank's
     supervisor (which never touches the GPU) starts a fresh worker for the NEXT rung on a new
-    rendezvous port — the hash loop in its simplest arrangement (1 lane, single chains), then
-    the replica loop — and the ONE line says what happened on the way (own launcher and torchrun
-    alike)."""
+    rendezvous port — the hash loop on ONE lane (one communicator) with shared chains, then in
+    its simplest arrangement (1 lane, single chains), then the replica loop — and the ONE line
+    says what happened on the way (own launcher and torchrun alike)."""
     env = {"GNNFLOW_BENCH_DEVICE": "0", "GNNFLOW_BENCH_BACKEND": "gloo",
            "GNNFLOW_BENCH_HANG_HASH": who, "GNNFLOW_BENCH_HANG_RUNGS": rungs,
            # the rungs that hang give up after 15 s; a rung that runs gets the time a slow,
            # shared box may need (the whole suite has taken 1.8 x its usual time on one)
-           "GNNFLOW_HASH_MAIN_TIMEOUT": "15,150" if rungs == "0" else "15",
+           "GNNFLOW_HASH_MAIN_TIMEOUT": {"0": "15,150", "0,1": "15,15,150"}.get(rungs, "15"),
            "GNNFLOW_PART_TRANSPORT": "ipc"}
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5",
            "--min-replays", "1", "--min-seconds", "0.2"]
@@ -178,20 +179,24 @@ def test_hanging_hash_loop_walks_down_the_ladder(who, rungs, final):
     lad = d["ladder"]
     assert lad["arrangement"] == final
     tried = lad["tried_before"]
-    assert [h["arrangement"] for h in tried] == ["hash", "hash-simple"][:len(tried)]
+    assert [h["arrangement"] for h in tried] == ["hash", "hash-one-lane", "hash-simple"][:len(tried)]
     assert all(h["hung"] and "did not finish within 15 s" in h["error"] for h in tried)
     # every rung's ranks were gone (here: by themselves, after their watchdog fired) before the
     # next rung's started
     assert all(h["worker_killed"] is False and 15 <= h["seconds"] < 90 for h in tried)
     if final == "replica":
-        assert d["config"]["parallelism"] == "replica-dp2" and len(tried) == 2
+        assert d["config"]["parallelism"] == "replica-dp2" and len(tried) == 3
         assert "did not finish within 15 s" in d["hash_partition"]["error"]
     else:
-        # rung 1: the native chains over the library's communicator, one lane, single chains
-        assert d["config"]["parallelism"] == "hash-dp2" and len(tried) == 1
+        # the native chains over the library's communicator on ONE lane: shared chains of four
+        # (rung 1), single chains with slot capacity 2.0 (rung 2)
+        simple = final == "hash-simple"
+        assert d["config"]["parallelism"] == "hash-dp2" and len(tried) == (2 if simple else 1)
         m = d["multi_gpu"]
-        assert m["lanes"] == 1 and m["chain_samples"] == 1 and m["transport"] == "ipc"
-        assert m["communicator_nranks"] == [2] and m["wire"]["slack"] == 2.0
+        assert m["lanes"] == 1 and m["chain_samples"] == (1 if simple else 4) and m["transport"] == "ipc"
+        assert m["communicator_nranks"] == [2]
+        if simple:
+            assert m["wire"]["slack"] == 2.0
         a = m["all_to_all"]["reply_layer1"]
         assert a["device_us"] > 0 and a["issue_us"] > 0 and a["bytes_per_peer"] > 0
         assert m["projection"]["chains_sustain_us_per_step"] > 0
