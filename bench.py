@@ -292,8 +292,10 @@ class Ctx:
 
 # the N > 1 ladder (main()): arrangement, what it is
 # (time limits per rung: rung_seconds(); the whole ladder fits the driver's 600 s)
-RUNG_MAIN_SECONDS = (100, 70, 70)      # the hash loop's own watchdog
-RUNG_SETUP_SECONDS = (150, 60, 60)     # on top of it before the supervisor kills the worker
+# (rung 0 creates one RCCL communicator per lane inside its watched loop, on a box that may
+# still be paging torch in: it gets the most; worst case 260 + 120 + 120 s + the replica rung)
+RUNG_MAIN_SECONDS = (130, 70, 70)      # the hash loop's own watchdog
+RUNG_SETUP_SECONDS = (130, 50, 50)     # on top of it before the supervisor kills the worker
 RUNGS = [("hash", "graph hash-partitioned over the ranks; sampling lanes x shared chains of up to "
                   "four samples, one communicator per lane"),
          ("hash-one-lane", "graph hash-partitioned over the ranks; ONE lane — one communicator, "
