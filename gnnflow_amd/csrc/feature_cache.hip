@@ -405,7 +405,9 @@ __device__ inline void gather_body(const Ctx& c) {
   if (c.stats && gtid == 0) atomicAdd(&c.stats[1], n);
 }
 
-__global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
+// Every kind of row and context: float4 rows, odd widths (16-byte vectors at 4-byte alignment),
+// scalar rows; list-form, queue-form and cache-free contexts; 4 / 8 / 12 loads in flight.
+__global__ __launch_bounds__(kThreads) void gather_rows_any_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
   if (c.n == 0) return;
   if (c.vec4) gather_body<float4>(c);
@@ -413,10 +415,10 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
   else gather_body<float>(c);
 }
 
-// The same for rounds whose contexts all take the float4 / list-form / 12-in-flight path (the
-// headline replay): a third of the code — a 14 us launch over 256 CUs pays for the instruction
-// bytes it has to fetch (same box A/B, round 5: see profiles/README)
-__global__ __launch_bounds__(kThreads) void gather_rows_lean_kernel(Round r) {
+// The same for rounds whose contexts ALL take the float4 / list-form or cache-free / 12-in-flight
+// path (the headline replay; launch_round picks): a third of the code and 104 instead of 138
+// VGPRs (4 waves per SIMD) — same-box A/B in profiles/README, round 5
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
   if (c.n == 0) return;
   gather_body<float4, false, true>(c);
@@ -2409,7 +2411,7 @@ void launch_round(Round& r, hipStream_t stream) {
     bool lean = true;
     for (int i = 0; i < r.count; ++i)
       lean = lean && r.c[i].vec4 && !r.c[i].qmode && r.c[i].inflight >= 12;
-    auto* kernel = lean ? gather_rows_lean_kernel : gather_rows_kernel;
+    auto* kernel = lean ? gather_rows_kernel : gather_rows_any_kernel;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile_begin(kProfGather, &e0, &e1)) {
       // the events ride on the dispatch itself: its begin / end timestamps
