@@ -89,3 +89,19 @@ def test_ladder_ports_differ_per_rung_and_a_dying_last_rung_fails_the_run():
     rc, d, _ = _acted("die,die,die,die")
     assert rc != 0 and d["value"] == 0.0 and "no rung printed a record" in d["error"]
     assert [h["arrangement"] for h in d["ladder"]] == ["hash", "hash-one-lane", "hash-simple"]
+
+
+def test_rung_time_limits_parse_one_value_or_one_per_rung(monkeypatch):
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.delenv("GNNFLOW_HASH_MAIN_TIMEOUT", raising=False)
+    assert [bench.rung_seconds("GNNFLOW_HASH_MAIN_TIMEOUT", r, bench.RUNG_MAIN_SECONDS)
+            for r in range(3)] == [float(x) for x in bench.RUNG_MAIN_SECONDS]
+    monkeypatch.setenv("GNNFLOW_HASH_MAIN_TIMEOUT", "15")
+    assert [bench.rung_seconds("GNNFLOW_HASH_MAIN_TIMEOUT", r, (1, 2, 3)) for r in range(3)] == [15.0] * 3
+    monkeypatch.setenv("GNNFLOW_HASH_MAIN_TIMEOUT", "15,150")
+    assert [bench.rung_seconds("GNNFLOW_HASH_MAIN_TIMEOUT", r, (1, 2, 3)) for r in range(3)] == [15.0, 150.0, 150.0]
+    # the whole ladder fits the driver's 600 s with a minute left for the replica rung
+    assert sum(bench.RUNG_MAIN_SECONDS) + sum(bench.RUNG_SETUP_SECONDS) <= 540
+    assert len(bench.RUNGS) == len(bench.RUNG_MAIN_SECONDS) + 1

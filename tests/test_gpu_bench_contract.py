@@ -183,7 +183,7 @@ def test_hanging_hash_loop_walks_down_the_ladder(who, rungs, final):
     assert all(h["hung"] and "did not finish within 15 s" in h["error"] for h in tried)
     # every rung's ranks were gone (here: by themselves, after their watchdog fired) before the
     # next rung's started
-    assert all(h["worker_killed"] is False and 15 <= h["seconds"] < 90 for h in tried)
+    assert all(h["worker_killed"] is False and 15 <= h["seconds"] < 240 for h in tried)
     if final == "replica":
         assert d["config"]["parallelism"] == "replica-dp2" and len(tried) == 3
         assert "did not finish within 15 s" in d["hash_partition"]["error"]
