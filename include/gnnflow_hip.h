@@ -382,7 +382,7 @@ GF_API int gf_memory_update(float* d_node_memory, float* d_node_memory_ts, float
 GF_API int gf_cache_slot_ids(const gf_cache* c, int64_t* out, size_t capacity);
 GF_API int gf_cache_mem_bytes(const gf_cache* c, size_t* out);
 /* LRU bookkeeping state (no reference counterpart; diagnostics and tests).  out[0] = 1 if the
- * replacement order is kept as a queue with dead entries (caches of >= 2 M slots),
+ * replacement order is kept as a queue with dead entries (caches of >= 0.5 M slots),
  * 0 if as a list; out[1] = entries allocated per queue buffer; out[2] = head, out[3] = tail of
  * the queue; out[4] = compactions so far; out[5] = updates of a queue-form cache that went
  * through the list form (block > capacity / 4 rows); out[6] = updates whose victim search had

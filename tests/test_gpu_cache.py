@@ -16,7 +16,7 @@ def lru_form(request, monkeypatch):
     """Every test of this module runs three times: with the LRU order kept as a list and
     updated in ONE launch (small caches, the default), as a list updated by the two launches
     list scan + list install (what caches beyond the one-launch kernel's tables use;
-    GNNFLOW_LRU_FUSED=0), and as a queue with dead entries (what caches of >= 2 M slots use;
+    GNNFLOW_LRU_FUSED=0), and as a queue with dead entries (what caches of >= 0.5 M slots use;
     forced here by lowering that bound to 1 slot, which also exercises its compaction every
     other update and the fall-back to the list form for blocks of more than capacity / 4
     rows).  All must make the oracle's decisions."""
