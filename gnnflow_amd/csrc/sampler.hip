@@ -52,6 +52,7 @@ constexpr int kEmitThreads = 256;
 constexpr int kScanThreads = 1024;
 constexpr int kScanItems = 4;  // per thread per tile
 constexpr size_t kSmallRoots = 32768;  // layers up to this many roots skip the scan launch
+constexpr uint32_t kGranuleSpins = 1u << 12;   // ~ a few ms of polling before a tile is recounted
 static size_t kLaneSearchRoots = [] {   // layers from this many roots: lane-per-root pass
   const char* v = std::getenv("GNNFLOW_LANE_SEARCH_MIN_ROOTS");   // tuning
   return v ? static_cast<size_t>(std::atoll(v)) : (size_t{1} << 20);
@@ -736,6 +737,58 @@ __global__ __launch_bounds__(kEmitThreads) void sample_emit_prefix_kernel(
   }
 }
 
+// Decoupled look-back of the one-launch kernels: the sum of the counts that the `n_before`
+// workgroups before this one published as granules {tag | count} (count in the bits of `mask`).
+// Every thread polls up to kLookBatch granules PER ROUND TRIP — all loads of a batch are issued
+// before the first is looked at (polled one after the other, a thread's 3-5 granules cost 3-5
+// dependent agent-scope loads) — and a granule that has not
+// shown the tag after kGranuleSpins rounds is recomputed by `recount(b)` (termination does not
+// depend on dispatch order).  Returns this THREAD's partial sum; `recounts` counts fallbacks.
+constexpr int kLookBatch = 8;
+template <int kBlock, typename Recount>
+__device__ inline uint32_t lookback_partial(const uint64_t* granules, uint32_t n_before,
+                                            uint64_t tag, uint64_t mask, unsigned int* recounts,
+                                            Recount recount) {
+  uint32_t part = 0;
+  for (uint32_t base = 0; base < n_before; base += kLookBatch * kBlock) {   // uniform trip count
+    uint64_t gr[kLookBatch];
+    bool need[kLookBatch];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < kLookBatch; ++k) {
+      need[k] = base + k * kBlock + threadIdx.x < n_before;
+      any |= need[k];
+    }
+    for (uint32_t spins = 0; any && spins < kGranuleSpins; ++spins) {
+#pragma unroll
+      for (int k = 0; k < kLookBatch; ++k)
+        gr[k] = need[k] ? __hip_atomic_load(&granules[base + k * kBlock + threadIdx.x],
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : 0ull;
+      any = false;
+#pragma unroll
+      for (int k = 0; k < kLookBatch; ++k) {
+        if (!need[k]) continue;
+        if ((gr[k] & ~mask) == tag) {
+          part += static_cast<uint32_t>(gr[k] & mask);
+          need[k] = false;
+        } else {
+          any = true;
+        }
+      }
+      if (any) __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < kLookBatch; ++k) {
+      if (need[k]) {
+        part += recount(base + k * kBlock + threadIdx.x);
+        atomicAdd(recounts, 1u);
+      }
+    }
+  }
+  return part;
+}
+
 // ---- partitioned sampling: fixed-slot replies and their merge ---------
 __device__ inline int64_t pack_f32_pair(float lo, float hi) {
   return static_cast<int64_t>(static_cast<uint64_t>(__float_as_uint(lo)) |
@@ -1128,7 +1181,6 @@ __global__ __launch_bounds__(kEmitThreads) void merge_emit_prefix_kernel(
 // by the host thread that issues its launches, so one launch less per layer is ~3 us per sample.
 __device__ unsigned int g_merge_recounts;          // tiles a look-back had to count itself
 constexpr uint64_t kGranuleCountMask = 0x3FF;      // a tile has kEmitThreads = 256 slots
-constexpr uint32_t kGranuleSpins = 1u << 12;   // ~ a few ms of polling before a tile is recounted
 struct MergeJob {
   const int64_t* roots;
   const float* root_ts;
@@ -1279,14 +1331,8 @@ __device__ inline void merge_slots_fused_body(
   // such kernels of different streams or processes in flight, workgroups dealt to the XCDs
   // independently) a tile could otherwise wait for one that cannot be dispatched because its
   // XCD is full of waiters: observed with 4 rank processes sharing one GPU.
-  uint32_t part = 0;
-  for (uint32_t b = tid; b < blockIdx.x; b += kEmitThreads) {
-    uint64_t g = 0;
-    uint32_t spins = 0;
-    for (;;) {
-      g = __hip_atomic_load(&granules[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((g & ~kGranuleCountMask) == tag) break;
-      if (++spins == kGranuleSpins) {
+  uint32_t part = lookback_partial<kEmitThreads>(
+      granules, blockIdx.x, tag, kGranuleCountMask, &g_merge_recounts, [&](uint32_t b) {
         uint32_t cnt = 0;
         const uint64_t lo = static_cast<uint64_t>(b) * kEmitThreads;
         const uint64_t hi = min(lo + kEmitThreads, total);
@@ -1298,14 +1344,8 @@ __device__ inline void merge_slots_fused_body(
             cnt += ju < reuse.first_prev[ru + 1] - reuse.first_prev[ru] ? 1u : 0u;
           else if (!(pu < slot_rows && pu % stride == 0)) cnt += record(pu, ju) != nullptr ? 1u : 0u;
         }
-        g = cnt;
-        atomicAdd(&g_merge_recounts, 1u);   // diagnostics (gf_debug_merge_recounts)
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    part += static_cast<uint32_t>(g & kGranuleCountMask);
-  }
+        return cnt;
+      });
   for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
   if (lane == 0) red[wave] = part;
   __syncthreads();
@@ -1628,7 +1668,10 @@ void Sampler::enqueue_layer(const int64_t* d_roots, const float* d_ts, size_t Rb
   uint32_t* wg_sum = reinterpret_cast<uint32_t*>(w);
   const GraphView gv = view_for(graph_, Rb);
   const uint64_t call = calls_++;
-  // small layers: search publishes per-workgroup sums and emit does its own prefix
+  // small layers: search publishes per-workgroup sums and emit does its own prefix.  (Search +
+  // prefix + emit in ONE launch through look-back granules was built and measured: 17 us per
+  // layer against 6.5 + 6 us + a 1.5 us boundary — across XCDs a count reaches its readers
+  // through memory, which a kernel boundary does for free; profiles/README, round 5.)
   const bool small = fused_scan_ && Rb <= kSmallRoots;
   const unsigned roots_per_wg = kSearchThreads / search_group_;
   {
