@@ -2105,19 +2105,19 @@ __global__ void list_fill_kernel(uint32_t* list, uint32_t first, uint32_t prefix
 //   list scan    : row role — representatives of the distinct missed ids, as in the list form;
 //                  victim role — chunks of the queue behind the head, one workgroup each, keep
 //                  their live, not-hit entries (one scattered load per entry: qpos; the hit
-//                  bits are read densely)
-//   queue count  : per bitmap tile (the bitmap is 1/32 of the queue: 7.5 MB at 40 M slots) the
-//                  hit entries, per word a snapshot {word, hits before it in the tile}; the
-//                  chunks' candidates packed into one victim list
-//   list install : one thread per block row.  The m-th distinct missed id takes the m-th
-//                  victim's slot (as in the list form) and appends its entry at tail + hits +
-//                  m; the row that stands for a hit slot appends at tail + (hit entries before
-//                  its old one: tile prefix from LDS + the snapshot) and clears its bitmap
-//                  word; head / tail move.  Every step is O(block rows) and row-parallel: on
-//                  the GDELT-shaped step (38 M slots, 198 k-row blocks) the three launches
-//                  cost 247 us per step with the position-parallel append of round 4 (the
-//                  non-empty bitmap tiles expanded serially per workgroup) — see
-//                  profiles/README for this form
+//                  bits are read densely); bitmap role — per tile of kBitTile words (the
+//                  bitmap is 1/32 of the queue: 7.5 MB at 40 M slots) the hit entries, per word
+//                  a snapshot {word, hits before it in the tile}
+//   queue walk   : ONE workgroup: did the chunks yield enough candidates?  If not it walks on
+//                  and leaves what it finds as one more chunk
+//   queue install: 256-thread workgroups, one thread per block row.  The m-th distinct missed
+//                  id takes the m-th victim candidate's slot (chunk through the counts' prefix
+//                  in LDS) and appends its entry at tail + hits + m; the row that stands for a
+//                  hit slot appends at tail + (hit entries before its old one: tile prefix
+//                  from LDS + the snapshot) and clears its bitmap word; head / tail move.
+// Every step is O(block rows) and row-parallel: on the GDELT-shaped step (38 M slots, 198 k-
+// row blocks) the update costs 108 us per step against 232 with round 4's position-parallel
+// append (the non-empty bitmap tiles expanded serially per workgroup); profiles/README.
 // When the queue's tail would pass its allocation it is compacted into the other buffer (two
 // launches, O(capacity), once per ~capacity / (2 * block rows) updates); a block of more than
 // capacity / 4 rows is handled by the list form on the compacted queue (its passes are no
