@@ -1011,6 +1011,13 @@ __device__ inline uint32_t wide_sum(uint32_t v, uint32_t* ws) {
 // Queue form: four consecutive queue entries from p0 (16-byte aligned); bit j of the result:
 // entry p0 + j is live (qpos points at it) and its slot was not hit by this block (the
 // gather marked the hit entries' positions in qbits: read densely here).
+// Chunks of the queue behind the head the victim walk covers for a block that missed `want`
+// rows: the host sizes everything for 2 x block rows + 2 tiles (it does not know the misses);
+// the device needs that much only if every row missed.  Scan, walk and install agree on it.
+__device__ inline uint32_t victim_chunks_used(const Ctx& c, uint32_t want) {
+  return min(c.v_chunks, (2u * want + kRowTile - 1) / kRowTile + 2u);
+}
+
 __device__ inline uint32_t victim_walk4(const Ctx& c, const uint32_t* list, uint32_t head,
                                         uint32_t tail, uint32_t p0, uint32_t* sl) {
   // the buffers are allocated 16 entries past queue_cap: a whole vector is readable
@@ -1203,7 +1210,7 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
     const uint32_t head = c.qstate->head, tail = c.qstate->tail;
     if (vb == 0 && tid == 0) { c.ctr->q_parity = parity; c.ctr->q_head = head; c.ctr->q_tail = tail; }
     if (want == 0) return;
-    const uint32_t hbase = head & ~3u, chunks = c.v_chunks;
+    const uint32_t hbase = head & ~3u, chunks = victim_chunks_used(c, want);
     for (uint32_t ch = vb; ch < chunks; ch += victim_blocks) {
       const uint32_t p0 = hbase + ch * kRowTile + tid * 4;
       uint32_t sl[4];
@@ -1260,7 +1267,7 @@ __global__ __launch_bounds__(kWide) void lru_queue_walk_kernel(Round r) {
   const uint32_t want = min(total_miss(c.ctr), c.capacity);
   if (want == 0) return;
   const uint32_t head = c.ctr->q_head, tail = c.ctr->q_tail;
-  const uint32_t chunks = c.v_chunks;
+  const uint32_t chunks = victim_chunks_used(c, want);
   uint32_t sum = 0;
   for (uint32_t u = tid; u < chunks; u += kWide) sum += c.v_count[u];
   const uint32_t found0 = wide_sum(sum, ws);
@@ -1388,7 +1395,7 @@ __global__ __launch_bounds__(kQInst) void lru_queue_install_kernel(Round r) {
   const uint32_t t0 = w_lo / kBitTile;
   const uint32_t btiles = (w_hi + kBitTile - 1) / kBitTile - t0;
   const uint32_t G = c.q_group, ngroups = (btiles + G - 1) / G;   // <= kMaxBitGroups
-  const uint32_t nchunks = c.v_chunks + 1;                        // <= kMaxVChunks
+  const uint32_t nchunks = victim_chunks_used(c, min(total_miss(c.ctr), cap)) + 1;   // <= kMaxVChunks
   // every independent load first: the counts of the bitmap tiles (a run of consecutive groups
   // per thread), of the victim chunks (likewise) and of the scan workgroups
   constexpr uint32_t kPerT = kMaxBitGroups / kQInst, kPerC = kMaxVChunks / kQInst;
