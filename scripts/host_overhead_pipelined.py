@@ -19,8 +19,8 @@ side = torch.cuda.Stream(device=dev); main = torch.cuda.current_stream(dev)
 from collections import deque
 T = dict(wait=0.0, begin=0.0, rec=0.0, fetch=0.0, wq=0.0)
 orig_wait = cache.wait_enqueued
-def timed_wait():
-    t0 = time.perf_counter(); orig_wait(); T["wq"] += time.perf_counter() - t0
+def timed_wait(upto=None):
+    t0 = time.perf_counter(); orig_wait(upto); T["wq"] += time.perf_counter() - t0
 cache.wait_enqueued = timed_wait
 DEPTH = 2
 for rep in range(3):
