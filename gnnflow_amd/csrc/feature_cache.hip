@@ -1129,9 +1129,10 @@ __global__ __launch_bounds__(kWide) void lru_list_scan_kernel(Round r, uint32_t 
         const uint32_t p0 = __popc(wd.x), p1 = __popc(wd.y), p2 = __popc(wd.z), p3 = __popc(wd.w);
         uint32_t total;
         const uint32_t b = wide_excl_scan(p0 + p1 + p2 + p3, ws, &total);
+        // (only words with a bit set are ever looked up: 5-10 % of them on the GDELT-shaped step)
         uint4* sn = reinterpret_cast<uint4*>(c.wsnap + wi);
-        sn[0] = make_uint4(wd.x, b, wd.y, b + p0);
-        sn[1] = make_uint4(wd.z, b + p0 + p1, wd.w, b + p0 + p1 + p2);
+        if (wd.x | wd.y) sn[0] = make_uint4(wd.x, b, wd.y, b + p0);
+        if (wd.z | wd.w) sn[1] = make_uint4(wd.z, b + p0 + p1, wd.w, b + p0 + p1 + p2);
         if (tid == 0) c.tile_tie[t] = total;
       }
       return;
