@@ -194,16 +194,21 @@ class _StepView:
         return self._value
 
 
-@pytest.mark.parametrize("lru_form", ["list", "list2", "queue"])
+@pytest.mark.parametrize("lru_form", ["list", "list2", "queue", "mixed"])
 def test_stepwise_cached_sets_and_alias_equivalence(lru_form, monkeypatch):
     """Same loop with a host check after every step (cached-id sets at EVERY step), once with
     the prefix alias and once without: both must agree with the oracle, hence with each
     other.  Also with the LRU order kept as a queue (the form of caches of >= 2 M slots,
     forced here): the edge cache then appends, the node cache — blocks larger than a quarter
-    of its 2196 slots — goes through the list form and re-indexes, in the same launches."""
+    of its 2196 slots — goes through the list form and re-indexes, in the same launches.
+    "mixed": the bound between the two caches' sizes — the edge cache a queue, the node cache a
+    list updated in ONE launch on the round's side stream beside the queue-form launches (what a
+    GDELT-scale step does)."""
     from gnnflow_amd.pipeline import ReplayPipeline
     if lru_form == "queue":
         monkeypatch.setenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", "1")
+    elif lru_form == "mixed":
+        monkeypatch.setenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", "10000")
     else:
         monkeypatch.delenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", raising=False)
     if lru_form == "list2":     # list scan + list install instead of the one-launch update
@@ -222,6 +227,9 @@ def test_stepwise_cached_sets_and_alias_equivalence(lru_form, monkeypatch):
             assert snap["span"][4] == (1 if alias else 0)
 
         pipe.run(0, 48, on_step)
+        if lru_form == "mixed":
+            assert w.cache._edge.lru_state()["queue_form"] == 1
+            assert w.cache._node.lru_state()["queue_form"] == 0
 
 
 @pytest.mark.parametrize("fanouts,policy", [((10, 10, 10), "recent"), ((10, 5), "recent"),
