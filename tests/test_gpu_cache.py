@@ -11,7 +11,7 @@ from tests.test_oracle_cache import Blk, load, policy_of, replay
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["list", "list2", "queue"])
+@pytest.fixture(autouse=True, params=["list", "list2", "queue", "mixed"])
 def lru_form(request, monkeypatch):
     """Every test of this module runs three times: with the LRU order kept as a list and
     updated in ONE launch (small caches, the default), as a list updated by the two launches
@@ -19,9 +19,13 @@ def lru_form(request, monkeypatch):
     GNNFLOW_LRU_FUSED=0), and as a queue with dead entries (what caches of >= 0.5 M slots use;
     forced here by lowering that bound to 1 slot, which also exercises its compaction every
     other update and the fall-back to the list form for blocks of more than capacity / 4
-    rows).  All must make the oracle's decisions."""
+    rows).  "mixed": the bound at 200 slots, so that a test's larger cache is a queue and its
+    smaller one a list updated on the round's side stream beside it.  All must make the
+    oracle's decisions."""
     if request.param == "queue":
         monkeypatch.setenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", "1")
+    elif request.param == "mixed":
+        monkeypatch.setenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", "200")
     else:
         monkeypatch.delenv("GNNFLOW_LRU_QUEUE_MIN_CAPACITY", raising=False)
     if request.param == "list2":
@@ -503,8 +507,8 @@ def test_dead_entries_right_behind_the_head(lru_form):
     _fetch_both(hip, ora, ef, np.concatenate([np.arange(cap + 1, cap + 51),
                                               np.arange(60000, 60050)]), step); step += 1
     st = hip._edge.lru_state()
-    assert st["queue_form"] == (1 if lru_form == "queue" else 0)
-    if lru_form == "queue":
+    assert st["queue_form"] == (1 if lru_form in ("queue", "mixed") else 0)
+    if lru_form in ("queue", "mixed"):
         assert st["lone_walks"] == 1 and st["head"] > 14000 and st["tail"] > cap
     rng = np.random.RandomState(5)
     for _ in range(6):
@@ -526,7 +530,7 @@ def test_many_updates_cross_several_compactions(lru_form):
         ids = np.concatenate([rng.randint(lo, lo + cap, n), rng.randint(0, 8 * cap, n // 8 + 1)])
         _fetch_both(hip, ora, ef, ids, step)
     st = hip._edge.lru_state()
-    if lru_form == "queue":
+    if lru_form in ("queue", "mixed"):
         assert st["queue_form"] == 1 and st["queue_entries"] == cap + cap // 2 + 64
         assert st["compactions"] >= 20 and st["list_form_updates"] >= 10
         assert st["tail"] - st["head"] >= cap
@@ -553,7 +557,7 @@ def test_blocks_without_a_miss_leave_no_marks_behind(lru_form):
         _fetch_both(hip, ora, ef, rng.randint(2 * cap, 8 * cap, 700), step); step += 1
         _fetch_both(hip, ora, ef, np.concatenate([rng.randint(0, cap, 300),
                                                   rng.randint(2 * cap, 8 * cap, 300)]), step); step += 1
-    if lru_form == "queue":
+    if lru_form in ("queue", "mixed"):
         assert hip._edge.lru_state()["queue_form"] == 1
 
 
