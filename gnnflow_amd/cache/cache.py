@@ -102,7 +102,8 @@ class Cache:
                  kvstore_client=None,
                  distributed: Optional[bool] = False,
                  neg_sample_ratio: Optional[int] = 1,
-                 feature_placement: Optional[str] = None):
+                 feature_placement: Optional[str] = None,
+                 staging=None):
         if device == 'cpu' or device == torch.device('cpu'):
             raise ValueError('Cache must be on GPU')
         shards = None
@@ -160,6 +161,29 @@ class Cache:
         self._target_edge_features = None
         self._tickets = deque()    # (ticket, keepalive) of asynchronous fetches not yet enqueued
         self.feature_placement = placement
+        # Staging ring of a host-resident table (feature_placement="pinned"; include/gnnflow_hip.h
+        # gf_cache_set_staging): prefetch_feature() pulls the rows a coming fetch_feature() will
+        # miss into HBM on a side stream.  `staging`: None = GNNFLOW_STAGING or "auto" (16
+        # generations, rows per generation sized from the blocks prefetched), 0 / False = off,
+        # (generations, rows_per_generation) = fixed.
+        if staging is None:
+            staging = os.environ.get('GNNFLOW_STAGING', 'auto')
+        if isinstance(staging, str):
+            staging = staging.strip().lower()
+            if staging in ('0', 'off', 'false', ''):
+                staging = None
+            elif staging != 'auto':
+                g, _, r = staging.partition(',')
+                staging = (int(g), int(r) if r else 0)
+        elif not staging:
+            staging = None
+        elif staging is True:
+            staging = 'auto'
+        if placement != 'pinned' or distributed:
+            staging = None
+        self._staging = staging          # None | 'auto' | (generations, rows; 0 rows: auto)
+        self._staging_rows = 0           # rows per generation the native rings were set up with
+        self._prefetch_stream = None
         # serve an edge block that is a prefix of the previously fetched one from that
         # block's rows (LRU only; fetch_feature); GNNFLOW_PREFIX_ALIAS=0 turns it off
         self.prefix_alias = os.environ.get('GNNFLOW_PREFIX_ALIAS', '1') != '0'
@@ -361,7 +385,17 @@ class Cache:
             return self._fetch_distributed(mfgs, eid, update_cache, target_edge_features)
         upd = 1 if update_cache else 0
         dev = self.device
-        # jobs: (kind, ids address, n, dim, block, which, key, keepalive)
+        jobs, n_node, n_cached, aliases = self._jobs(mfgs, eid, upd, target_edge_features)
+        if not jobs:
+            return mfgs
+        if _current_device() != dev.index:
+            with torch.cuda.device(dev):
+                return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
+        return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
+
+    def _jobs(self, mfgs, eid, upd, target_edge_features):
+        """The block gathers of one fetch_feature() call: (jobs, #node jobs, #jobs through a
+        cache, aliases); job = (kind, ids address, n, keepalive, dim, block, which, key)."""
         jobs = []
         if self._node is not None:
             dim = self.dim_node_feat
@@ -403,12 +437,100 @@ class Cache:
         if self._edge is not None and target_edge_features and eid is not None:
             t = self._ids(eid)
             jobs.append((2, t.data_ptr(), int(t.shape[0]), t, self.dim_edge_feat, None, None, None))
+        return jobs, n_node, n_cached, aliases
+
+    # ---- host-resident tables: pulling the coming misses ahead of the fetch ------------------
+    @property
+    def staging(self) -> bool:
+        """True when prefetch_feature() does something (pinned tables with a staging ring)."""
+        return self._staging is not None
+
+    def _ensure_staging(self, rows: int):
+        """Sets the native rings up (or enlarges them: a synchronising call) so that a
+        generation holds an eighth of the rows of the round being prefetched."""
+        st = self._staging
+        gens, fixed = (16, 0) if st == 'auto' else (int(st[0]), int(st[1]))
+        want = fixed or (1 << max(int(max(rows, 1) // 8 - 1).bit_length(), 10))
+        if want <= self._staging_rows:
+            return
+        self.wait_enqueued()
+        for k in (self._node, self._edge):
+            if k is not None:
+                _capi.check(self._lib.gf_cache_set_staging(k.h, gens, want))
+        self._staging_rows = want
+
+    def prefetch_feature(self, mfgs: List[List], eid: Optional[np.ndarray] = None,
+                         update_cache: bool = True, target_edge_features: bool = True,
+                         stream: Optional[torch.cuda.Stream] = None,
+                         async_enqueue: bool = False) -> bool:
+        """Announces a coming `fetch_feature(mfgs, eid, ...)` (same arguments): with the tables
+        in pinned host memory, the rows of the ids that are neither cached nor staged yet are
+        pulled into the staging ring in HBM on `stream` (default: a side stream of this cache),
+        beside whatever the fetch stream is doing; the fetch then waits for the pull on its own
+        stream and reads those rows from HBM.  The reference does the host -> pinned -> device
+        trip inside fetch_feature (cache.py:288-313,381-388).  A hint: results, hit ratios and
+        the cache's contents do not depend on it.  Returns False if there is nothing to do."""
+        if self._staging is None:
+            return False
+        upd = 1 if update_cache else 0
+        jobs, _n_node, _n_cached, _aliases = self._jobs(mfgs, eid, upd, target_edge_features)
         if not jobs:
-            return mfgs
-        if _current_device() != dev.index:
-            with torch.cuda.device(dev):
-                return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
-        return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
+            return False
+        dev = self.device
+        self._ensure_staging(sum(job[2] for job in jobs))
+        if stream is None:
+            stream = self._prefetch_stream
+            if stream is None:
+                from ..pipeline import side_stream
+                stream = self._prefetch_stream = side_stream(dev, 3)
+        for mfg in mfgs:
+            for b in mfg:
+                if hasattr(b, "record_stream"):
+                    b.record_stream(stream)
+        nj = len(jobs)
+        descs, cdescs, cdescs_ref = self._desc_buf(nj)
+        pack = _DESC.pack_into
+        for i, (kind, ids_ptr, n, _keep, _dim, _b, _which, _key) in enumerate(jobs):
+            pack(descs, i * _DESC.size, kind, upd, ids_ptr or 0, n, 0, 0)
+        node_h = self._node.h if self._node is not None else None
+        edge_h = self._edge.h if self._edge is not None else None
+        st = C.c_void_p(stream.cuda_stream)
+        with torch.cuda.device(dev):
+            if async_enqueue:
+                q = self._tickets
+                if len(q) >= _MAX_QUEUED:
+                    self.wait_enqueued(q[0][0])
+                t = C.c_uint64(0)
+                _capi.check(self._lib.gf_cache_prefetch_blocks_async(
+                    node_h, edge_h, cdescs_ref, nj, st, C.byref(t)))
+                q.append((t.value, (jobs, descs, cdescs, mfgs)))
+                return True
+            issued = C.c_int(0)
+            _capi.check(self._lib.gf_cache_prefetch_blocks(
+                node_h, edge_h, cdescs_ref, nj, st, C.byref(issued)))
+            return bool(issued.value)
+
+    def staging_state(self) -> dict:
+        """Per kind: generations, rows per generation, generations issued / dropped, rows pulled
+        over the host link so far, HBM bytes of the ring + index (synchronises)."""
+        self.wait_enqueued()
+        out = {}
+        keys = ("generations", "rows_per_generation", "issued", "dropped", "rows_pulled",
+                "ring_bytes")
+        for name, k in (("node", self._node), ("edge", self._edge)):
+            if k is None:
+                continue
+            v = (C.c_uint64 * 6)()
+            _capi.check(self._lib.gf_cache_staging_state(k.h, v))
+            out[name] = dict(zip(keys, (int(x) for x in v)))
+        return out
+
+    def invalidate_staging(self):
+        """The feature tables' contents changed in place: staged rows are forgotten."""
+        self.wait_enqueued()
+        for k in (self._node, self._edge):
+            if k is not None:
+                _capi.check(self._lib.gf_cache_invalidate_staging(k.h))
 
     # ---- sharded feature tables (distributed=True) ----------------------------------------
     def _init_cache_distributed(self):

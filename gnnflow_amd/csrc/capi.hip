@@ -660,6 +660,43 @@ int gf_cache_fetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
     });
   });
 }
+int gf_cache_set_staging(gf_cache* c, size_t generations, size_t rows_per_generation) {
+  return guarded([&] { GF_C(c); c->impl.set_staging(generations, rows_per_generation); });
+}
+int gf_cache_invalidate_staging(gf_cache* c) {
+  return guarded([&] { GF_C(c); c->impl.invalidate_staging(); });
+}
+int gf_cache_staging_state(gf_cache* c, uint64_t* out) {
+  return guarded([&] {
+    GF_C(c);
+    GF_REQUIRE(out != nullptr, "gf_cache_staging_state: null output");
+    c->impl.staging_state(out);
+  });
+}
+int gf_cache_prefetch_blocks(gf_cache* node_cache, gf_cache* edge_cache,
+                             const gf_fetch_desc* descs, size_t n, void* stream, int* issued) {
+  return guarded([&] {
+    const bool did = gf::prefetch_blocks(node_cache ? &node_cache->impl : nullptr,
+                                         edge_cache ? &edge_cache->impl : nullptr, descs, n,
+                                         static_cast<hipStream_t>(stream));
+    if (issued) *issued = did ? 1 : 0;
+  });
+}
+int gf_cache_prefetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
+                                   const gf_fetch_desc* descs, size_t n, void* stream,
+                                   uint64_t* ticket) {
+  return guarded([&] {
+    GF_REQUIRE(ticket != nullptr, "prefetch_blocks_async: null ticket");
+    GF_REQUIRE(descs != nullptr || n == 0, "prefetch_blocks_async: null descriptors");
+    gf::FeatureCache* node = node_cache ? &node_cache->impl : nullptr;
+    gf::FeatureCache* edge = edge_cache ? &edge_cache->impl : nullptr;
+    std::vector<gf_fetch_desc> copy(descs, descs + n);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    *ticket = gf::EnqueueWorker::get().submit([node, edge, copy = std::move(copy), st]() {
+      gf::prefetch_blocks(node, edge, copy.data(), copy.size(), st);
+    });
+  });
+}
 int gf_cache_fetch_wait(uint64_t ticket) {
   std::string err;
   const int rc = gf::EnqueueWorker::get().wait(ticket, &err);

@@ -67,6 +67,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <type_traits>
 #include <cstdlib>
@@ -157,6 +158,14 @@ struct Ctx {
   // -> *flag is raised and row 0 is served)
   const int32_t* remap;
   uint32_t* flag;
+  // host-resident table with a staging ring ("staging ring" below): a missed id whose pmap entry
+  // {generation, row} lies in [st_lo, st_lo + st_span] is read from that row of the generation's
+  // region of the ring — an HBM copy of its table row pulled ahead of this launch
+  const unsigned long long* pmap;
+  const float* ring;
+  uint32_t st_lo, st_span, st_mask, st_cap;
+  uint32_t* progress;       // pinned host word: this launch stores progress_val = the number of
+  uint32_t progress_val;    // ring-reading launches enqueued before it (all finished by now)
   uint64_t num_ids;
   int32_t* map;             // null: no cache (plain gather)
   float* cache_buf;
@@ -268,7 +277,7 @@ constexpr uint32_t kRepHit = 1u << 30, kRepPos = kRepHit - 1u;
 // ---- the gather kernel -------------------------------------------------------------
 // kLean: the instantiation for rounds of float4 rows on list-form / cache-free contexts with
 // the default 12 loads in flight (no queue-form hit path, one copy loop)
-template <typename VecT, bool kOdd = false, bool kLean = false>
+template <typename VecT, bool kOdd = false, bool kLean = false, bool kStaged = !kLean>
 __device__ inline void gather_body(const Ctx& c) {
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * kThreads + threadIdx.x;
@@ -334,6 +343,13 @@ __device__ inline void gather_body(const Ctx& c) {
             src = feats + static_cast<uint64_t>(local) * rowu;
           } else {
             src = feats + static_cast<uint64_t>(id) * rowu;
+            if (kStaged && c.pmap) {
+              const unsigned long long p = c.pmap[id];
+              const uint32_t g = static_cast<uint32_t>(p >> 32);
+              if (g - c.st_lo <= c.st_span)
+                src = reinterpret_cast<const Unit*>(c.ring) +
+                      (static_cast<uint64_t>(g & c.st_mask) * c.st_cap + static_cast<uint32_t>(p)) * rowu;
+            }
           }
           if (c.update) atomicMax(&c.map[id], -static_cast<int32_t>(row0 + lane + 1));
         }
@@ -403,6 +419,8 @@ __device__ inline void gather_body(const Ctx& c) {
     }
   }
   if (c.stats && gtid == 0) atomicAdd(&c.stats[1], n);
+  if (kStaged && c.progress && gtid == 0)
+    __hip_atomic_store(c.progress, c.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Every kind of row and context: float4 rows, odd widths (16-byte vectors at 4-byte alignment),
@@ -422,6 +440,134 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
   if (c.n == 0) return;
   gather_body<float4, false, true>(c);
+}
+
+// ... and the lean kernel for rounds over a host-resident table with a staging ring
+__global__ __launch_bounds__(kThreads) void gather_rows_staged_kernel(Round r) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (c.n == 0) return;
+  gather_body<float4, false, true, true>(c);
+}
+
+// ---- staging ring: rows of a HOST-resident table pulled into HBM ahead of the gather ----------
+// Reference: the tables live in host memory and every miss travels host -> pinned -> device inside
+// fetch_feature (cache.py:288-313,381-388, utils.py:284-297).  Here the ids of batch i+1 exist
+// while batch i is fetched (ReplayPipeline), so a kernel on a side stream pulls the table rows of
+// the ids that are not cached into a ring in HBM — over PCIe, beside the fetch chain — and the
+// gather then takes a missed row from the ring.  The ring is G regions of C rows, one region per
+// prefetch GENERATION; pmap[id] = {generation, row in its region}.  A prefetch stages an id only
+// if it is neither cached (nor claimed by the fetch in flight) nor staged in a generation that is
+// still readable, so a row pulled for one batch (the batch's own target edges, above all: the next
+// batches sample exactly those) serves the misses of the next G - D - 1 batches too.  It is a
+// HINT: the cache's state (map, slots, hit counts) never depends on it, and an id the speculation
+// missed — evicted by the update in between, or a region that was full — is read from the host
+// table by the gather as before.  Rows are feats[ids] bit for bit either way.
+struct StageCtx {
+  const int64_t* ids;
+  uint32_t n;
+  const int32_t* map;          // null: cache-free context (target rows)
+  uint64_t num_ids;
+  unsigned long long* pmap;
+  const float* feats;
+  float* ring;
+  uint32_t* region_rows;       // [G] rows taken in each region
+  unsigned long long* pulled;  // rows pulled so far (diagnostics)
+  uint32_t dim, vec4;
+  uint32_t gen, lo, mask, cap;
+};
+struct StageRound {
+  StageCtx c[kMaxCtx];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void stage_rows_kernel(StageRound r) {
+  const StageCtx& c = r.c[blockIdx.y];
+  __shared__ long long s_id[256];
+  __shared__ uint32_t s_pos[256];
+  __shared__ uint32_t s_n;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t region = c.gen & c.mask, span = c.gen - c.lo;
+  // the next generation's region starts empty (prefetches run in order on one stream)
+  if (blockIdx.x == 0 && tid == 0) c.region_rows[(c.gen + 1u) & c.mask] = 0u;
+  uint32_t pulled = 0;
+  for (uint32_t base = blockIdx.x * 256u; base < c.n; base += gridDim.x * 256u) {
+    const uint32_t i = base + tid;
+    long long id = -1;
+    unsigned long long p = 0;
+    bool want = false;
+    if (i < c.n) {
+      id = c.ids[i];
+      if (id >= 0 && static_cast<uint64_t>(id) < c.num_ids) {
+        // (a negative map value other than kAbsent is the claim of a fetch in flight: its
+        // update installs the id before the gather this prefetch works for)
+        if ((c.map ? c.map[id] : kAbsent) == kAbsent) {
+          p = c.pmap[id];
+          want = static_cast<uint32_t>(p >> 32) - c.lo > span;
+        }
+      }
+    }
+    const unsigned long long wm = __ballot(want);
+    uint32_t pos = c.cap;
+    if (wm) {
+      const int leader = __ffsll(static_cast<long long>(wm)) - 1;
+      uint32_t wbase = 0;
+      if (static_cast<int>(lane) == leader) wbase = atomicAdd(&c.region_rows[region], static_cast<uint32_t>(__popcll(wm)));
+      wbase = __shfl(wbase, leader, 64);
+      if (want) pos = wbase + static_cast<uint32_t>(__popcll(wm & ((1ull << lane) - 1ull)));
+    }
+    bool won = false;
+    if (want && pos < c.cap) {
+      const unsigned long long mine = (static_cast<unsigned long long>(c.gen) << 32) | pos;
+      for (;;) {
+        const unsigned long long old = atomicCAS(&c.pmap[id], p, mine);
+        if (old == p) { won = true; break; }
+        if (static_cast<uint32_t>(old >> 32) - c.lo <= span) break;   // another row of this id was first
+        p = old;
+      }
+    }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    if (won) {
+      const uint32_t k = atomicAdd(&s_n, 1u);
+      s_id[k] = id;
+      s_pos[k] = pos;
+    }
+    __syncthreads();
+    const uint32_t cnt = s_n;
+    if (tid == 0) pulled += cnt;
+    // a wave pulls four rows at a time: their loads leave back to back (PCIe latency ~2 us)
+    const uint64_t rbase = static_cast<uint64_t>(region) * c.cap;
+    if (c.vec4) {
+      const uint32_t dimv = c.dim >> 2;
+      for (uint32_t e = wave * 4u; e < cnt; e += 16u) {
+        for (uint32_t off = lane; off < dimv; off += 64u) {
+          float4 v[4];
+#pragma unroll
+          for (uint32_t k = 0; k < 4u; ++k)
+            if (e + k < cnt)
+              v[k] = reinterpret_cast<const float4*>(c.feats + static_cast<uint64_t>(s_id[e + k]) * c.dim)[off];
+#pragma unroll
+          for (uint32_t k = 0; k < 4u; ++k)
+            if (e + k < cnt)
+              reinterpret_cast<float4*>(c.ring + (rbase + s_pos[e + k]) * c.dim)[off] = v[k];
+        }
+      }
+    } else {
+      for (uint32_t e = wave * 4u; e < cnt; e += 16u) {
+        for (uint32_t off = lane; off < c.dim; off += 64u) {
+          float v[4];
+#pragma unroll
+          for (uint32_t k = 0; k < 4u; ++k)
+            if (e + k < cnt) v[k] = c.feats[static_cast<uint64_t>(s_id[e + k]) * c.dim + off];
+#pragma unroll
+          for (uint32_t k = 0; k < 4u; ++k)
+            if (e + k < cnt) c.ring[(rbase + s_pos[e + k]) * c.dim + off] = v[k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && pulled) atomicAdd(c.pulled, static_cast<unsigned long long>(pulled));
 }
 
 // ---- planning a pull from sharded feature tables -------------------------------------------
@@ -2418,10 +2564,13 @@ void launch_round(Round& r, hipStream_t stream) {
     }
   }
   {
-    bool lean = true;
-    for (int i = 0; i < r.count; ++i)
+    bool lean = true, staged = false;
+    for (int i = 0; i < r.count; ++i) {
       lean = lean && r.c[i].vec4 && !r.c[i].qmode && r.c[i].inflight >= 12;
-    auto* kernel = lean ? gather_rows_kernel : gather_rows_any_kernel;
+      staged = staged || r.c[i].pmap != nullptr;
+    }
+    auto* kernel = !lean ? gather_rows_any_kernel
+                         : (staged ? gather_rows_staged_kernel : gather_rows_kernel);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile_begin(kProfGather, &e0, &e1)) {
       // the events ride on the dispatch itself: its begin / end timestamps
@@ -2599,7 +2748,174 @@ FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const fl
   GF_HIP(hipStreamSynchronize(nullptr));
 }
 
-FeatureCache::~FeatureCache() = default;
+FeatureCache::~FeatureCache() {
+  for (hipEvent_t e : stage_events_)
+    if (e) (void)hipEventDestroy(e);
+}
+
+// ---- staging ring, host side ---------------------------------------------------------------
+void FeatureCache::set_staging(size_t generations, size_t rows_per_generation) {
+  DeviceGuard dg(device_);
+  GF_HIP(hipDeviceSynchronize());   // (a configuration call: nothing of this cache is in flight after it)
+  if (generations == 0 || rows_per_generation == 0) {
+    stage_gens_ = stage_cap_ = 0;
+    ring_.release();
+    pmap_.release();
+    region_rows_.release();
+    stage_wait_ = nullptr;
+    return;
+  }
+  GF_REQUIRE(!table_on_device_, "staging ring: the feature table is already in device memory");
+  GF_REQUIRE(generations >= 2 * kStageAhead && generations <= 64 &&
+                 (generations & (generations - 1)) == 0,
+             "staging ring: generations must be a power of two in 8..64");
+  GF_REQUIRE(rows_per_generation < (size_t{1} << 31), "staging ring: too many rows per generation");
+  stage_gens_ = static_cast<uint32_t>(generations);
+  stage_cap_ = static_cast<uint32_t>(rows_per_generation);
+  ring_.release();
+  ring_.reserve(generations * rows_per_generation * dim_ * sizeof(float) + 16);
+  pmap_.reserve(std::max<size_t>(num_ids_ * sizeof(unsigned long long), 16));
+  region_rows_.reserve(64 * sizeof(uint32_t) + 16);
+  progress_.reserve(64);
+  *progress_.as<volatile uint32_t>() = 0;
+  for (hipEvent_t& e : stage_events_)
+    if (!e) GF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  GF_HIP(hipMemset(pmap_.data(), 0, pmap_.bytes()));
+  GF_HIP(hipMemset(region_rows_.data(), 0, region_rows_.bytes()));
+  gen_issued_ = 0;
+  stage_reads_ = 0;
+  stage_read_pending_ = false;
+  stage_wait_ = nullptr;
+  std::memset(reads_at_gen_, 0, sizeof(reads_at_gen_));
+}
+
+void FeatureCache::invalidate_staging() {
+  if (!staging()) return;
+  // every entry staged so far falls out of every window a later launch accepts; the regions
+  // the skipped generations would have used are simply never read
+  gen_issued_ += stage_gens_ + 1;
+  for (uint32_t& v : reads_at_gen_) v = stage_reads_;
+  DeviceGuard dg(device_);
+  GF_HIP(hipDeviceSynchronize());
+  GF_HIP(hipMemset(region_rows_.data(), 0, 64 * sizeof(uint32_t)));
+  *progress_.as<volatile uint32_t>() = stage_reads_;   // (device idle: every launch has finished)
+  stage_wait_ = nullptr;
+}
+
+void FeatureCache::staging_state(uint64_t out[6]) {
+  out[0] = stage_gens_;
+  out[1] = stage_cap_;
+  out[2] = gen_issued_;
+  out[3] = stage_drops_;
+  out[4] = 0;
+  out[5] = staging() ? ring_.bytes() + pmap_.bytes() : 0;
+  if (staging()) {
+    DeviceGuard dg(device_);
+    GF_HIP(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    GF_HIP(hipMemcpy(&v, region_rows_.as<uint32_t>() + 64, sizeof(v), hipMemcpyDeviceToHost));
+    out[4] = v;
+  }
+}
+
+// The window of generations a launch may read when `issued` is the newest one: region g & mask
+// is rewritten by generation g + G, and up to kStageAhead newer generations may be pulled while
+// the launch runs.
+static inline uint32_t stage_window_lo(uint32_t issued, uint32_t gens, uint32_t ahead) {
+  const uint32_t keep = gens - ahead;   // generations issued, issued - 1, ..., issued - keep + 1
+  return issued >= keep ? issued - keep + 1u : 1u;
+}
+
+// The next generation X rewrites the region of generation X - G.  Launches that may read that
+// region were enqueued before generation X - kStageAhead was issued; they are known to have
+// finished once a LATER ring-reading launch has started (it stores the number of such launches
+// before it in `progress`).  The issuing thread waits for that — it is what keeps the host from
+// running arbitrarily far ahead of the fetch stream, where a prefetch would see a cache state
+// many updates old — and gives the generation up after GNNFLOW_STAGE_SPIN_US (a hint may be
+// dropped; waiting for ever may not: nothing guarantees that the caller fetches again).
+bool FeatureCache::stage_advance() {
+  const uint32_t next = gen_issued_ + 1u;
+  if (next > kStageAhead) {
+    const uint32_t need = reads_at_gen_[(next - kStageAhead) & 63u];
+    volatile uint32_t* progress = progress_.as<volatile uint32_t>();
+    if (static_cast<int32_t>(*progress - need) < 0) {
+      static const long spin_us = [] {
+        const char* v = std::getenv("GNNFLOW_STAGE_SPIN_US");
+        return v ? std::atol(v) : 20000L;
+      }();
+      bool ok = false;
+      if (stage_reads_ != need && spin_us > 0) {   // (== : no later launch exists that could report)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t i = 0;; ++i) {
+          if (static_cast<int32_t>(*progress - need) >= 0) { ok = true; break; }
+          __builtin_ia32_pause();
+          if ((i & 255u) == 255u &&
+              std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+        }
+      }
+      if (!ok) { ++stage_drops_; return false; }
+    }
+  }
+  gen_issued_ = next;
+  reads_at_gen_[next & 63u] = stage_reads_;
+  return true;
+}
+
+// the fetch stream waits for the prefetches issued so far (one wait per distinct event)
+void FeatureCache::stage_sync(hipStream_t stream, hipEvent_t* seen, int* num_seen) {
+  if (!stage_wait_) return;
+  bool dup = false;
+  for (int i = 0; i < *num_seen; ++i) dup = dup || seen[i] == stage_wait_;
+  if (!dup) {
+    GF_HIP(hipStreamWaitEvent(stream, stage_wait_, 0));
+    seen[(*num_seen)++] = stage_wait_;
+  }
+  stage_wait_ = nullptr;
+}
+
+// Context of one block for the next prefetch generation.  false: not to be staged.
+bool FeatureCache::stage_begin(void* stage_ctx_out, const int64_t* d_ids, size_t n, bool cached) {
+  StageCtx& c = *static_cast<StageCtx*>(stage_ctx_out);
+  std::memset(&c, 0, sizeof(c));
+  c.ids = d_ids;
+  c.n = static_cast<uint32_t>(n);
+  c.map = (cached && capacity_) ? map_.as<int32_t>() : nullptr;
+  c.num_ids = num_ids_;
+  c.pmap = pmap_.as<unsigned long long>();
+  c.feats = feats_;
+  c.ring = ring_.as<float>();
+  c.region_rows = region_rows_.as<uint32_t>();
+  c.pulled = reinterpret_cast<unsigned long long*>(region_rows_.as<uint32_t>() + 64);
+  c.dim = static_cast<uint32_t>(dim_);
+  c.vec4 = vec4_ok(dim_, feats_, ring_.data(), ring_.data()) ? 1u : 0u;
+  c.gen = gen_issued_;
+  c.lo = stage_window_lo(gen_issued_, stage_gens_, kStageAhead);
+  c.mask = stage_gens_ - 1u;
+  c.cap = stage_cap_;
+  return true;
+}
+
+void FeatureCache::stage_fill(void* ctx_out) {
+  if (!staging() || gen_issued_ == 0) return;
+  Ctx& c = *static_cast<Ctx*>(ctx_out);
+  if (c.miss_rows || c.remap) return;
+  c.pmap = pmap_.as<unsigned long long>();
+  c.ring = ring_.as<float>();
+  c.st_lo = stage_window_lo(gen_issued_, stage_gens_, kStageAhead);
+  c.st_span = gen_issued_ - c.st_lo;
+  c.st_mask = stage_gens_ - 1u;
+  c.st_cap = stage_cap_;
+  c.progress = progress_.as<uint32_t>();
+  c.progress_val = stage_reads_;
+  stage_read_pending_ = true;
+}
+
+void FeatureCache::stage_round_done() {
+  if (stage_read_pending_) {
+    ++stage_reads_;
+    stage_read_pending_ = false;
+  }
+}
 
 // Cache.init_cache (cache.py:175-195) / LRUCache.reset (lru_cache.py:91-105)
 void FeatureCache::init(hipStream_t stream) {
@@ -2823,6 +3139,11 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
   num_ids_ = new_num_ids;
   capacity_ = new_capacity;
   ws_rows_ = 0;   // tile arrays depend on the capacity
+  if (staging()) {   // new table, more ids: the ring starts over
+    const size_t gens = stage_gens_, rows = stage_cap_;
+    if (table_on_device_) set_staging(0, 0);
+    else set_staging(gens, rows);
+  }
   if (policy_ == GF_CACHE_LRU && new_capacity > old_capacity) {
     // the new (empty) slots are the first to be refilled, in slot order: they go to the front
     // of the list, the old entries follow in their order
@@ -3021,8 +3342,13 @@ void FeatureCache::fetch(const int64_t* d_ids, size_t n, float* d_out, bool upda
   DeviceGuard dg(device_);
   Round r;
   r.count = 1;
+  hipEvent_t seen[2];
+  int num_seen = 0;
+  stage_sync(stream, seen, &num_seen);
   prepare(d_ids, n, d_out, update, d_stats, &r.c[0], stream);
+  stage_fill(&r.c[0]);
   launch_round(r, stream);
+  stage_round_done();
 }
 
 // Cache(distributed=True): the slots of a block's ids, so that the caller can pull the
@@ -3093,6 +3419,16 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
   for (const gf_fetch_desc* d : edges) max_edge_rows = std::max(max_edge_rows, d->n);
   if (node && max_node_rows) node->reserve_workspace(max_node_rows, stream);
   if (edge && max_edge_rows) edge->reserve_workspace(max_edge_rows, stream);
+  {   // host-resident tables: rows pulled ahead of this fetch must have landed
+    hipEvent_t seen[2];
+    int num_seen = 0;
+    if (node) node->stage_sync(stream, seen, &num_seen);
+    if (edge) edge->stage_sync(stream, seen, &num_seen);
+  }
+  auto done = [&] {
+    if (node) node->stage_round_done();
+    if (edge) edge->stage_round_done();
+  };
   size_t pi = 0;
   const size_t rounds = std::max(nodes.size(), edges.size());
   for (size_t i = 0; i < rounds; ++i) {
@@ -3100,27 +3436,84 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
     r.count = 0;
     if (i < nodes.size()) {
       const gf_fetch_desc& d = *nodes[i];
-      node->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &r.c[r.count++], stream);
+      node->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &r.c[r.count], stream);
+      node->stage_fill(&r.c[r.count++]);
     }
     if (i < edges.size()) {
       const gf_fetch_desc& d = *edges[i];
-      edge->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &r.c[r.count++], stream);
+      edge->prepare(d.d_ids, d.n, d.d_out, d.update != 0, d.d_stats, &r.c[r.count], stream);
+      edge->stage_fill(&r.c[r.count++]);
     }
     while (pi < plain.size() && r.count < kMaxCtx) {
       const gf_fetch_desc& d = *plain[pi++];
-      r.c[r.count++] = plain_ctx(edge->feats_, edge->num_ids_, edge->dim_, d.d_ids, d.n, d.d_out);
+      r.c[r.count] = plain_ctx(edge->feats_, edge->num_ids_, edge->dim_, d.d_ids, d.n, d.d_out);
+      edge->stage_fill(&r.c[r.count++]);
     }
     launch_round(r, stream);
+    done();
   }
   while (pi < plain.size()) {   // cache-free gathers that did not fit into a round
     Round r;
     r.count = 0;
     while (pi < plain.size() && r.count < kMaxCtx) {
       const gf_fetch_desc& d = *plain[pi++];
-      r.c[r.count++] = plain_ctx(edge->feats_, edge->num_ids_, edge->dim_, d.d_ids, d.n, d.d_out);
+      r.c[r.count] = plain_ctx(edge->feats_, edge->num_ids_, edge->dim_, d.d_ids, d.n, d.d_out);
+      edge->stage_fill(&r.c[r.count++]);
     }
     launch_round(r, stream);
+    done();
   }
+}
+
+// Cache.prefetch_feature: one staging generation per cache for the blocks a coming
+// fetch_blocks(descs) will gather (feature_cache.hpp)
+bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
+                     hipStream_t stream) {
+  GF_REQUIRE(descs != nullptr || n == 0, "prefetch_blocks: null descriptors");
+  const bool node_on = node && node->staging(), edge_on = edge && edge->staging();
+  if (!node_on && !edge_on) return false;
+  const int device = node ? node->device() : edge->device();
+  DeviceGuard dg(device);
+  bool node_use = false, edge_use = false;
+  for (size_t i = 0; i < n; ++i) {
+    const gf_fetch_desc& d = descs[i];
+    GF_REQUIRE(d.kind >= 0 && d.kind <= 2, "prefetch_blocks: bad kind");
+    if (d.n == 0) continue;
+    GF_REQUIRE(d.d_ids != nullptr, "prefetch_blocks: null ids");
+    GF_REQUIRE(d.n < 0x7FFFFFFFull, "prefetch_blocks: more than 2^31-1 rows in one block");
+    if (d.kind == 0) node_use = node_use || node_on;
+    else edge_use = edge_use || edge_on;
+  }
+  if (node_use) node_use = node->stage_advance();
+  if (edge_use) edge_use = edge->stage_advance();
+  if (!node_use && !edge_use) return false;
+  StageRound r;
+  r.count = 0;
+  size_t max_n = 0;
+  auto flush = [&] {
+    if (r.count == 0) return;
+    const unsigned grid = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>((max_n + 255) / 256, 512)));
+    stage_rows_kernel<<<dim3(grid, r.count), dim3(256), 0, stream>>>(r);
+    GF_HIP(hipGetLastError());
+    r.count = 0;
+    max_n = 0;
+  };
+  for (size_t i = 0; i < n; ++i) {
+    const gf_fetch_desc& d = descs[i];
+    if (d.n == 0) continue;
+    FeatureCache* c = d.kind == 0 ? (node_use ? node : nullptr) : (edge_use ? edge : nullptr);
+    if (!c) continue;
+    c->stage_begin(&r.c[r.count++], d.d_ids, d.n, d.kind != 2);
+    max_n = std::max(max_n, d.n);
+    if (r.count == kMaxCtx) flush();
+  }
+  flush();
+  FeatureCache* lead = edge_use ? edge : node;
+  hipEvent_t ev = lead->stage_events_[lead->gen_issued_ % FeatureCache::kStageEvents];
+  GF_HIP(hipEventRecord(ev, stream));
+  if (node_use) node->stage_wait_ = ev;
+  if (edge_use) edge->stage_wait_ = ev;
+  return true;
 }
 
 // ---- sharded feature tables: plan, serve, fetch (kernels above: "planning a pull") ---------

@@ -28,6 +28,12 @@ void memory_update(float* node_memory, float* node_memory_ts, float* mailbox, fl
 class FeatureCache;
 void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
                   hipStream_t stream);
+// Pulls the table rows of the ids a coming fetch_blocks(descs) will miss into the caches' staging
+// rings, on `stream` (a side stream); d_out / d_stats / update of the descriptors are ignored.
+// Returns false when nothing was issued (no cache has a staging ring, or the generation had to be
+// dropped because fetches that may still read the region it would overwrite are in flight).
+bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
+                     hipStream_t stream);
 // sharded feature tables (Cache(distributed=True)): plan the pull of a round's contexts,
 // serve received ids from a shard, fetch with the pulled rows (feature_cache.hip)
 void pull_count(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
@@ -82,10 +88,21 @@ class FeatureCache {
   int device() const { return device_; }
   size_t num_ids() const { return num_ids_; }
   int32_t* pull_map() { return capacity_ ? map_.as<int32_t>() : nullptr; }
+  // Staging ring for a HOST-resident table (feature_cache.hip, "staging ring"): `generations`
+  // (a power of two, >= 4) regions of `rows_per_generation` rows; 0 generations: off.
+  void set_staging(size_t generations, size_t rows_per_generation);
+  bool staging() const { return stage_gens_ != 0; }
+  // forget every staged row (the table's contents changed)
+  void invalidate_staging();
+  // out[0..5]: generations, rows per generation, generations issued, generations dropped,
+  // rows pulled over the host link so far (reads a device counter: synchronises), ring bytes
+  void staging_state(uint64_t out[6]);
 
  private:
   friend void fetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
                            hipStream_t);
+  friend bool prefetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
+                              hipStream_t);
   friend void fetch_blocks_pulled(FeatureCache*, FeatureCache*, const gf_fetch_pulled_desc*, size_t,
                                   hipStream_t);
   void reserve_workspace(size_t n, hipStream_t stream);
@@ -131,6 +148,27 @@ class FeatureCache {
                            // workgroup (feature_cache.hip, lru_list_fused_kernel)
   uint32_t fuse_tag_ = 0;  // tag of the last such launch: unique per cache, never reset
   uint32_t epoch_ = 0;     // fetches with update so far (host side; kernel argument)
+  // staging ring (set_staging)
+  static constexpr uint32_t kStageEvents = 8;
+  // generations that may be pulled while a gather that reads the ring is still running
+  static constexpr uint32_t kStageAhead = 4;
+  DeviceBuffer ring_;         // float[generations * rows * dim]
+  DeviceBuffer pmap_;         // uint64[num_ids]  {generation, row in its region}; 0: never staged
+  DeviceBuffer region_rows_;  // uint32[generations] rows taken per region, + uint64 rows pulled
+  PinnedBuffer progress_;     // uint32: ring-reading launches known to have finished
+  uint32_t stage_gens_ = 0, stage_cap_ = 0;
+  uint32_t gen_issued_ = 0;   // last generation handed to a prefetch
+  uint32_t stage_reads_ = 0;  // ring-reading launches enqueued so far
+  bool stage_read_pending_ = false;       // ... the round being built reads the ring
+  uint32_t reads_at_gen_[64] = {};        // stage_reads_ when generation g was issued
+  uint64_t stage_drops_ = 0;
+  hipEvent_t stage_events_[kStageEvents] = {};
+  hipEvent_t stage_wait_ = nullptr;       // event behind the last prefetch, not yet waited for
+  bool stage_advance();                   // takes the next generation; false: dropped
+  bool stage_begin(void* stage_ctx_out, const int64_t* d_ids, size_t n, bool cached);
+  void stage_sync(hipStream_t stream, hipEvent_t* seen, int* num_seen);
+  void stage_fill(void* ctx_out);         // ring fields of a gather context
+  void stage_round_done();
   uint64_t ring_pos_ = 0;
   int policy_ = GF_CACHE_LRU;
 };

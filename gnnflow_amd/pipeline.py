@@ -114,12 +114,24 @@ class ReplayPipeline:
             sampler, side = lanes[j % nl]
             return sampler.sample_async(r, t, stream=side, worker_enqueue=True)
 
-        while nxt < last and len(pending) < self.depth:
+        # Host-resident feature tables (feature_placement="pinned" with a staging ring): batch
+        # i+1's sample is waited for one step early and its coming misses are pulled over the
+        # host link on a side stream while batch i is fetched (Cache.prefetch_feature; the
+        # reference moves a miss host -> pinned -> device inside fetch_feature,
+        # gnnflow/cache/cache.py:288-313,381-388) — one more sample in flight pays for the
+        # earlier wait.
+        staged = bool(getattr(cache, "staging", False))
+        depth = self.depth + (1 if staged else 0)
+        while nxt < last and len(pending) < depth:
             pending.append(begin(nxt))
             nxt += 1
         fetch_first = self.fetch_first
+        ahead = None      # MFGs of the next batch, already announced to the cache
+        if staged:
+            ahead = pending.popleft().wait()
+            cache.prefetch_feature(ahead, batches[first % nb][2], async_enqueue=True)
         for i in range(first, last):
-            mfgs = pending.popleft().wait()
+            mfgs = ahead if staged else pending.popleft().wait()
             if nxt < last and not fetch_first:
                 pending.append(begin(nxt))
                 nxt += 1
@@ -130,6 +142,9 @@ class ReplayPipeline:
             if nxt < last and fetch_first:
                 pending.append(begin(nxt))
                 nxt += 1
+            if staged and i + 1 < last:
+                ahead = pending.popleft().wait()
+                cache.prefetch_feature(ahead, batches[(i + 1) % nb][2], async_enqueue=True)
             if on_step:
                 on_step(i % nb, mfgs)
         cache.wait_enqueued()

@@ -344,6 +344,34 @@ GF_API int gf_cache_fetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cach
                                        const gf_fetch_desc* descs, size_t n, void* stream,
                                        uint64_t* ticket);
 GF_API int gf_cache_fetch_wait(uint64_t ticket);
+
+/* ---- host-resident feature tables: the staging ring ---------------------------------------
+ * Reference: the tables live in host memory and every miss is host -> pinned -> device inside
+ * fetch_feature (gnnflow/cache/cache.py:288-313,381-388, gnnflow/utils.py:284-297).  With
+ * gf_cache_set_staging(generations, rows) a cache over a HOST table (pinned, device-mapped) owns
+ * a ring of `generations` x `rows` table rows in HBM; gf_cache_prefetch_blocks(descs) — same
+ * descriptors as the coming gf_cache_fetch_blocks, d_out / d_stats / update ignored — pulls, on
+ * `stream` (a side stream), the rows of the ids that are neither cached nor already in the ring,
+ * one generation per call; the next gf_cache_fetch_blocks makes its stream wait for the pulls
+ * issued so far and reads a missed row from the ring when it is there, from the host table
+ * otherwise.  A hint: cache state, hit counts and the fetched rows never depend on it.
+ * *issued = 0 when the call issued nothing (no ring, or the generation was dropped because
+ * fetches that may still read the region it would overwrite had not finished).
+ * generations: a power of two in 8..64, or 0 = ring off.  gf_cache_invalidate_staging: the
+ * table's contents changed.  gf_cache_staging_state out[6]: generations, rows per generation,
+ * generations issued, generations dropped, rows pulled over the host link (synchronises), bytes
+ * of HBM the ring and its index take. */
+GF_API int gf_cache_set_staging(gf_cache* c, size_t generations, size_t rows_per_generation);
+GF_API int gf_cache_invalidate_staging(gf_cache* c);
+GF_API int gf_cache_staging_state(gf_cache* c, uint64_t* out);
+GF_API int gf_cache_prefetch_blocks(gf_cache* node_cache, gf_cache* edge_cache,
+                                    const gf_fetch_desc* descs, size_t n, void* stream,
+                                    int* issued);
+/* ... through the enqueue thread that issues the asynchronous fetches (same order of issue);
+ * the ticket is waited for with gf_cache_fetch_wait. */
+GF_API int gf_cache_prefetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
+                                          const gf_fetch_desc* descs, size_t n, void* stream,
+                                          uint64_t* ticket);
 /* Diagnostics: cumulative time the enqueue thread spent issuing work, and jobs done. */
 GF_API int gf_worker_stats(double* busy_us, uint64_t* jobs);
 

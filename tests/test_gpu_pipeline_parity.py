@@ -25,7 +25,7 @@ class _World:
     """Config 2 on both sides: HIP graph / sampler / cache and their oracles."""
 
     def __init__(self, first_batch, num_batches, policy="recent", fanouts=(10, 10),
-                 cache_ratio=0.2, prefix_alias=True):
+                 cache_ratio=0.2, prefix_alias=True, placement="device", staging=None):
         import torch
         import gnnflow_amd
         from gnnflow_amd import synthetic
@@ -48,7 +48,8 @@ class _World:
         self.nfeat = rng.rand(N, D).astype(np.float32)
         dev = torch.device("cuda", 0)
         self.cache = LRUCache(cache_ratio, cache_ratio, N, E, dev, torch.from_numpy(self.nfeat),
-                              torch.from_numpy(self.efeat), D, D)
+                              torch.from_numpy(self.efeat), D, D, feature_placement=placement,
+                              staging=staging)
         self.cache.prefix_alias = prefix_alias
         self.cache.init_cache()
         self.ocache = OracleLRUCache(cache_ratio, cache_ratio, N, E, self.nfeat, self.efeat, D, D)
@@ -259,3 +260,99 @@ def test_prefix_property_only_where_it_holds(fanouts, policy):
             assert set(seen) == {0}
         elif ratio == 0.2:
             assert set(seen) == {len(fanouts) - 1}
+
+
+def _run_chunks(w, pipe, steps, chunk):
+    """bench.py's free-running loop in chunks, every step's snapshot checked against the oracle."""
+    for c0 in range(0, steps, chunk):
+        snaps, held = [], []
+
+        def on_step(i, mfgs):
+            if held:
+                pi, pm = held.pop()
+                snaps.append((pi, _snapshot(w.cache_prev, pm)))
+            held.append((i, mfgs))
+            w.cache_prev = _StepView(w.cache)
+
+        pipe.run(c0, chunk, on_step)
+        pi, pm = held.pop()
+        snaps.append((pi, _snapshot(w.cache_prev, pm)))
+        w.torch.cuda.synchronize()
+        assert [i for i, _ in snaps] == list(range(c0, c0 + chunk))
+        for i, snap in snaps:
+            _check_step(w, i, snap)
+        _cached_sets_equal(w)
+
+
+@pytest.mark.parametrize("staging", ["auto", (8, 64), None])
+def test_pinned_tables_pipelined_replay_bit_exact(staging):
+    """The reference's feature placement — tables in (pinned) host memory, LRU 0.2 on the GPU
+    (gnnflow/cache/cache.py:288-313,381-388) — through the pipelined loop: batch i+1's coming
+    misses are pulled into the staging ring on a side stream while batch i is fetched.  Rows,
+    hit counts and cached-id sets must equal the oracle's whatever the ring does: "auto" (the
+    default), a ring of 8 x 64 rows (nearly every generation overflows: most missed rows fall
+    back to the host table inside the gather), and no ring at all."""
+    from gnnflow_amd.pipeline import ReplayPipeline
+    steps, chunk = int(os.environ.get("GNNFLOW_PARITY_STEPS_PINNED", 320)), 32
+    steps -= steps % chunk
+    for first_batch in (0, 800):
+        w = _World(first_batch, steps, placement="pinned", staging=staging or 0)
+        assert w.cache.staging == (staging is not None)
+        pipe = ReplayPipeline(w.sampler, w.cache, w.dev_batches, w.dev, pipelined=True)
+        _run_chunks(w, pipe, steps, chunk)
+        if staging is not None:
+            st = w.cache.staging_state()
+            for kind in ("node", "edge"):
+                # (an "auto" ring that grew with the blocks started counting again)
+                assert st[kind]["issued"] + st[kind]["dropped"] <= steps, st
+                assert st[kind]["issued"] >= steps // 2, st     # the loop keeps up with its ring
+                assert st[kind]["rows_pulled"] > 0, st
+            if staging == "auto":
+                # the batch's own 600 target edges are pulled once and serve the next batches'
+                # edge misses: far fewer rows cross the link than the fetches missed
+                assert st["edge"]["rows_pulled"] < 1300 * steps, st
+                print("staging state after", steps, "steps from batch", first_batch, st)
+            else:
+                assert st["edge"]["rows_per_generation"] == 64
+
+
+def test_pinned_tables_prefetch_is_only_a_hint(monkeypatch):
+    """prefetch_feature() by hand around the plain loop: announcing a batch twice, never, for
+    another batch's MFGs, with generations that are dropped at once (GNNFLOW_STAGE_SPIN_US=0 and
+    no fetch in between), or after invalidate_staging() changes nothing in what is fetched."""
+    monkeypatch.setenv("GNNFLOW_STAGE_SPIN_US", "0")
+    w = _World(900, 24, placement="pinned", staging=(8, 4096))
+    samp, cache = w.sampler, w.cache
+    mf = [None] * 24
+
+    def sample(i):
+        if mf[i] is None:
+            r, t, _ = w.dev_batches[i]
+            mf[i] = samp.sample(r, t)
+        return mf[i]
+
+    for i in range(24):
+        mfgs = sample(i)
+        e = w.dev_batches[i][2]
+        if i % 4 == 0:
+            assert cache.prefetch_feature(mfgs, e)
+            cache.prefetch_feature(mfgs, e)                     # twice
+        elif i % 4 == 1 and i + 1 < 24:
+            cache.prefetch_feature(sample(i + 1), w.dev_batches[i + 1][2])   # someone else's
+        elif i % 4 == 2:
+            for _ in range(12):                                 # more generations than regions
+                cache.prefetch_feature(mfgs, e)
+        if i == 13:
+            cache.invalidate_staging()
+        cache.fetch_feature(mfgs, e)
+        snap = _snapshot(cache, mfgs)
+        w.torch.cuda.synchronize()
+        _check_step(w, i, snap)
+        _cached_sets_equal(w)
+    st = cache.staging_state()
+    assert st["edge"]["dropped"] > 0 and st["edge"]["issued"] > 0, st
+    # a cache over device-resident tables has no ring and says so
+    w2 = _World(900, 1)
+    assert not w2.cache.staging
+    assert w2.cache.prefetch_feature(w2.sampler.sample(*w2.dev_batches[0][:2]),
+                                     w2.dev_batches[0][2]) is False
