@@ -137,6 +137,8 @@ def parse(argv=None):
                     help="time every n-th gather launch with HIP events (1 = all)")
     ap.add_argument("--breakdown", action="store_true",
                     help="extra untimed pass with per-kernel-family HIP-event times")
+    ap.add_argument("--no-placement-legs", action="store_true",
+                    help="skip the sample_only / cache_free_device / pinned_placement legs")
     ap.add_argument("--no-config3", action="store_true",
                     help="skip the config-3 sweep (10 M nodes / 200 M edges, uniform) at N = 1")
     ap.add_argument("--config3-batches", default="600,6000,60000,600000")
@@ -379,7 +381,7 @@ def build_leg(ctx, kind, always_exchange=None):
     return graph, sampler, build_s
 
 
-def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
+def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays, probe=None):
     """Warm-up, calibration, then the timed region over this rank's share of the replay.
     Returns a dict with elapsed (max over ranks), edges (sum over ranks), this rank's edges,
     timed_steps, repeats and the pipeline."""
@@ -396,7 +398,7 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
         depth = 2 if lanes == 1 and chain == 1 else max(3 * lanes, (3 * lanes * chain) // 2,
                                                         2 * chain)
     pipe = ReplayPipeline(sampler, cache, ctx.dev_batches, ctx.dev,
-                          pipelined=cache is not None and not args.no_pipeline, depth=depth)
+                          pipelined=not args.no_pipeline, depth=depth)
     ctx.live_pipe = pipe
 
     def reduce(value, op):
@@ -443,6 +445,7 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
         # ... and stream events around the LRU update behind every 61st gather
         ctx.lib.gf_profile_enable((1 << ctx.capi.PROFILE_SLOTS["gather"]) |
                                   (1 << ctx.capi.PROFILE_SLOTS["lru"]))
+    probe0 = probe() if probe else None     # (may synchronise: outside the timed region)
     acc = {"edges": 0}
 
     def account(_i, mfgs):
@@ -464,7 +467,8 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays):
     else:
         elapsed_max, edges_all = elapsed, float(acc["edges"])
     return dict(elapsed=elapsed_max, edges_all=edges_all, edges=acc["edges"], steps=steps,
-                repeats=repeats, timed_steps=timed_steps, pipe=pipe)
+                repeats=repeats, timed_steps=timed_steps, pipe=pipe, probe0=probe0,
+                probe1=probe() if probe else None)
 
 
 def agree(ctx, ok):
@@ -849,6 +853,9 @@ def main():
         "timed_seconds": elapsed_max,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed_max / timed_steps,
+        # the harness's own unit (benchmarks/benchmark_sampler.py: target edges per second of the
+        # replayed stream): batch size x ranks / step time
+        "target_edges_per_s": args.batch_size * world * timed_steps / elapsed_max,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -993,6 +1000,9 @@ def main():
             bd[name] = {"total_ms": ms.value, "intervals": int(n.value)}
         out["kernel_breakdown_200_steps"] = bd
 
+    if rank == 0 and world == 1 and main_kind == "replica" and cache is not None \
+            and not args.no_placement_legs and not sharded:
+        placement_legs(ctx, out, res["sampler"], node_feats, edge_feats)
     if rank == 0 and world == 1 and not args.no_config3:
         out["config3"] = config3_leg(args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1081,6 +1091,108 @@ def exchange_note(sampler, world, backend):
     return "2 all-to-all-v per layer over {} (one host sync per layer)".format(via)
 
 
+def placement_legs(ctx, out, sampler, node_feats, edge_feats):
+    """The other feature placements and the sampler alone, beside the headline (N = 1, replica
+    main loop), over the same replay and the same pipelined loop (ReplayPipeline.run, the function
+    tests/test_gpu_pipeline_parity.py checks in each of these arrangements):
+      sample_only        sample() alone — what benchmarks/benchmark_sampler.py:71-87 times and
+                         what north_star's ">= 10x the reference CPU sampler" is written on;
+      cache_free_device  tables in HBM, cache ratio 0: the gather without any LRU bookkeeping —
+                         the headline minus this is what the reference's cache protocol costs on
+                         a placement where a hit and a miss read the same memory;
+      pinned_placement   the reference's placement (gnnflow/cache/cache.py:288-313,381-388,
+                         gnnflow/utils.py:284-297): tables in pinned HOST memory, LRU 0.2 in HBM,
+                         batch i+1's misses pulled over the host link into the staging ring on a
+                         side stream while batch i is fetched; rows that crossed the link, bytes
+                         and GB/s per step ride along."""
+    import torch
+    from gnnflow_amd import synthetic
+    from gnnflow_amd.cache import LRUCache
+    args, g, dev = ctx.args, ctx.g, ctx.dev
+    d_e, d_n = synthetic.REDDIT["dim_edge"], synthetic.REDDIT["dim_node"]
+    secs = min(args.min_seconds, 1.0)
+
+    def line(res):
+        ms = 1e3 * res["elapsed"] / res["timed_steps"]
+        return {"value": res["edges_all"] / res["elapsed"], "unit": "edges/s", "ms_per_step": ms,
+                "target_edges_per_s": args.batch_size / (ms * 1e-3),
+                "steps": res["steps"], "repeats": res["repeats"],
+                "timed_seconds": res["elapsed"], "pipelined": bool(res["pipe"].pipelined)}
+
+    def sample_only():
+        rec = line(time_leg(ctx, sampler, None, False, secs, 1.0))
+        rec["what"] = "sample() alone, {} samples in flight over {} lanes".format(
+            max(2 * len(ctx.live_pipe.lanes), ctx.live_pipe.depth), len(ctx.live_pipe.lanes))
+        return rec
+
+    def cache_free_device():
+        cache = LRUCache(0, 0, g["num_nodes"], g["num_edges"], dev, node_feats, edge_feats,
+                         d_n, d_e, feature_placement="device")
+        cache.init_cache()
+        rec = line(time_leg(ctx, sampler, cache, False, secs, 1.0))
+        rec["what"] = "tables in HBM, cache ratio 0: sample() + cache-free gather of the same rows"
+        rec["rows_per_step"] = cache.rows_moved / max(rec["steps"] * rec["repeats"], 1)
+        return rec
+
+    def pinned_placement():
+        cache = LRUCache(args.cache_ratio, args.cache_ratio, g["num_nodes"], g["num_edges"], dev,
+                         node_feats.cpu(), edge_feats.cpu(), d_n, d_e, feature_placement="pinned")
+        cache.init_cache()
+        res = time_leg(ctx, sampler, cache, False, secs, 1.0, probe=cache.staging_state)
+        rec = line(res)
+        steps = max(res["timed_steps"], 1)
+        s0, s1 = res["probe0"], res["probe1"]
+        pulled = sum(s1[k]["rows_pulled"] - s0[k]["rows_pulled"] for k in s1) / steps
+        host = sum(s1[k]["rows_read_from_host"] - s0[k]["rows_read_from_host"] for k in s1) / steps
+        nbytes = (pulled + host) * 4.0 * d_e
+        rec.update({
+            "what": "tables in pinned host memory, LRUCache ratio {} in HBM, staging ring {} "
+                    "generations x {} rows per kind ({:.0f} MB of HBM with its index); "
+                    "prefetch_feature(batch i+1) on a side stream beside fetch_feature(batch "
+                    "i)".format(args.cache_ratio, s1["edge"]["generations"],
+                                s1["edge"]["rows_per_generation"],
+                                sum(s1[k]["ring_bytes"] for k in s1) / 1e6),
+            "rows_per_step": cache.rows_moved / steps,
+            "rows_pulled_into_ring_per_step": pulled,
+            "rows_read_from_host_by_gather_per_step": host,
+            "host_link_bytes_per_step": nbytes,
+            "host_link_GBps_over_the_step": nbytes / (rec["ms_per_step"] * 1e-3) / 1e9,
+            "generations_dropped": sum(s1[k]["dropped"] - s0[k]["dropped"] for k in s1),
+            "cache_edge_ratio": float(cache.cache_edge_ratio),
+            "cache_node_ratio": float(cache.cache_node_ratio)})
+        # what the link gives a plain copy on this box
+        src = cache._edge.table.view(-1)[:1 << 26]
+        dst = torch.empty_like(src, device=dev)
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        rec["host_link_GBps_memcpy_256MB"] = 3 * src.numel() * 4 / (time.perf_counter() - t0) / 1e9
+        # ... and the same leg without the ring: every missed row is read from the host table by
+        # the gather itself, inside the launch every hit also waits in (round 2-5's pinned path)
+        del dst
+        plain = LRUCache(args.cache_ratio, args.cache_ratio, g["num_nodes"], g["num_edges"], dev,
+                         cache._node.table, cache._edge.table, d_n, d_e,
+                         feature_placement="pinned", staging=0)
+        plain.init_cache()
+        rec["without_staging_ring"] = line(time_leg(ctx, sampler, plain, False, min(secs, 0.5), 1.0))
+        return rec
+
+    for key, fn, limit in (("sample_only", sample_only, 60.0),
+                           ("cache_free_device", cache_free_device, 60.0),
+                           ("pinned_placement", pinned_placement, 120.0)):
+        def guarded(fn=fn):
+            try:
+                return fn()
+            except Exception as e:       # noqa: BLE001 — the headline must survive this leg
+                import traceback
+                traceback.print_exc()
+                return {"error": "{}: {}".format(type(e).__name__, e)}
+        out[key] = guarded_aux(ctx, out, key, limit, guarded)
+
+
 def second_leg(ctx, kind, cache, always_exchange=None):
     import threading
     # RCCL with more than one rank has never run on this code path before the first scaling
@@ -1115,6 +1227,7 @@ def second_leg(ctx, kind, cache, always_exchange=None):
         res = time_leg(ctx, sampler, cache, False, min(ctx.args.min_seconds, 1.0), 1.0)
         return {"value": res["edges_all"] / res["elapsed"], "unit": "edges/s",
                 "ms_per_step": 1e3 * res["elapsed"] / res["timed_steps"],
+                "target_edges_per_s": ctx.args.batch_size * ctx.world * res["timed_steps"] / res["elapsed"],
                 "steps": res["steps"], "repeats": res["repeats"],
                 "timed_seconds": res["elapsed"], "world_size": ctx.world,
                 "pipelined": bool(res["pipe"].pipelined),
@@ -1189,7 +1302,7 @@ def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather)
     # its rows are the first rows of the outer block's gather and are not gathered again.
     alias = args.strategy == "recent" and len(set(fanouts)) == 1
 
-    def run(threads, budget_s):
+    def run(threads, budget_s, with_gather=with_gather):
         """Whole passes over `batches` (the batch sequence of the GPU's timed region, so
         edges per step are the same on both sides) until the budget is spent; >= 1 pass."""
         osamp = O.OracleSampler(og, fanouts, args.strategy, seed=1234, threads=threads)
@@ -1238,7 +1351,25 @@ def cpu_baseline(g, batches, fanouts, args, edge_feats, node_feats, with_gather)
     if all_cores > 1:
         runs.append(run(all_cores, 2 * args.cpu_seconds / 3))
     best = max(runs, key=lambda r: r["value"])
+    # the sampler alone (benchmarks/benchmark_sampler.py:71-87 times only `sample`; north_star's
+    # ">= 10x the reference CPU sampler" is written on this): same oracle, same batches, no gather
+    so = None
+    if with_gather:
+        so_runs = [run(1, args.cpu_seconds / 6, with_gather=False)]
+        if all_cores > 1:
+            so_runs.append(run(all_cores, args.cpu_seconds / 3, with_gather=False))
+        so_best = max(so_runs, key=lambda r: r["value"])
+        so = {"value": so_best["value"], "unit": "edges/s", "cores": so_best["cores"],
+              "ms_per_step": so_best["ms_per_step"],
+              "target_edges_per_s": args.batch_size / (so_best["ms_per_step"] * 1e-3),
+              "single_thread_value": so_runs[0]["value"],
+              "sample": "oracle sample() alone on the same batches, fastest whole pass: " +
+                        "; ".join("{} thread{}: {:.2f} M edges/s".format(
+                            r["cores"], "" if r["cores"] == 1 else "s", r["value"] / 1e6)
+                            for r in so_runs)}
     return {
+        "sample_only": so,
+        "target_edges_per_s": args.batch_size / (best["ms_per_step"] * 1e-3),
         "value": best["value"], "unit": "edges/s", "cores": best["cores"], "kind": "port",
         "sample": "batches 0..{} of the chronological replay — the batch sequence of the GPU's "
                   "timed region — in whole passes, fastest pass reported ({:.1f} s of CPU work in "

@@ -163,7 +163,7 @@ class Cache:
         self.feature_placement = placement
         # Staging ring of a host-resident table (feature_placement="pinned"; include/gnnflow_hip.h
         # gf_cache_set_staging): prefetch_feature() pulls the rows a coming fetch_feature() will
-        # miss into HBM on a side stream.  `staging`: None = GNNFLOW_STAGING or "auto" (16
+        # miss into HBM on a side stream.  `staging`: None = GNNFLOW_STAGING or "auto" (32
         # generations, rows per generation sized from the blocks prefetched), 0 / False = off,
         # (generations, rows_per_generation) = fixed.
         if staging is None:
@@ -425,9 +425,12 @@ class Cache:
                     if n <= 0:
                         prev = None
                         continue
+                    # (no edge cache at all — capacity 0: nothing to keep consistent, the rows
+                    # are the outer block's first rows whatever its size)
                     if can_alias and prev is not None and job[3] is b \
                             and getattr(b, "_edge_prefix_of", None) is prev[0] \
-                            and n <= jobs[prev[1]][2] <= self.edge_capacity:
+                            and n <= jobs[prev[1]][2] \
+                            and (jobs[prev[1]][2] <= self.edge_capacity or not self.edge_capacity):
                         aliases.append((b, prev[1], n))
                         prev = (b, prev[1])
                         continue
@@ -447,10 +450,10 @@ class Cache:
 
     def _ensure_staging(self, rows: int):
         """Sets the native rings up (or enlarges them: a synchronising call) so that a
-        generation holds an eighth of the rows of the round being prefetched."""
+        generation holds a sixteenth of the rows of the round being prefetched."""
         st = self._staging
-        gens, fixed = (16, 0) if st == 'auto' else (int(st[0]), int(st[1]))
-        want = fixed or (1 << max(int(max(rows, 1) // 8 - 1).bit_length(), 10))
+        gens, fixed = (32, 0) if st == 'auto' else (int(st[0]), int(st[1]))
+        want = fixed or (1 << max(int(max(rows, 1) // 16 - 1).bit_length(), 10))
         if want <= self._staging_rows:
             return
         self.wait_enqueued()
@@ -512,15 +515,16 @@ class Cache:
 
     def staging_state(self) -> dict:
         """Per kind: generations, rows per generation, generations issued / dropped, rows pulled
-        over the host link so far, HBM bytes of the ring + index (synchronises)."""
+        over the host link so far, HBM bytes of the ring + index, rows the gathers read from the
+        host table after all (synchronises)."""
         self.wait_enqueued()
         out = {}
         keys = ("generations", "rows_per_generation", "issued", "dropped", "rows_pulled",
-                "ring_bytes")
+                "ring_bytes", "rows_read_from_host")
         for name, k in (("node", self._node), ("edge", self._edge)):
             if k is None:
                 continue
-            v = (C.c_uint64 * 6)()
+            v = (C.c_uint64 * 7)()
             _capi.check(self._lib.gf_cache_staging_state(k.h, v))
             out[name] = dict(zip(keys, (int(x) for x in v)))
         return out
@@ -968,7 +972,9 @@ class Cache:
         else:
             _capi.check(self._lib.gf_cache_fetch_blocks(
                 node_h, edge_h, cdescs_ref, nj, self._stream()))
-        self._stats_span = (stats_pos, n_node, n_cached, self._stats_ring, len(aliases))
+        # (aliased blocks count as all hits — of a cache that exists)
+        self._stats_span = (stats_pos, n_node, n_cached, self._stats_ring,
+                            len(aliases) if self.edge_capacity else 0)
         return mfgs
 
     def _out_buffer(self, total):

@@ -67,6 +67,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <chrono>
 #include <climits>
 #include <type_traits>
@@ -166,6 +167,7 @@ struct Ctx {
   uint32_t st_lo, st_span, st_mask, st_cap;
   uint32_t* progress;       // pinned host word: this launch stores progress_val = the number of
   uint32_t progress_val;    // ring-reading launches enqueued before it (all finished by now)
+  unsigned long long* st_fallback;   // rows this cache's gathers read from the HOST table
   uint64_t num_ids;
   int32_t* map;             // null: no cache (plain gather)
   float* cache_buf;
@@ -306,12 +308,14 @@ __device__ inline void gather_body(const Ctx& c) {
   const uint32_t num_waves = nthreads >> 6;
   const uint32_t tiles = (n + tile_rows - 1) / tile_rows;
   uint32_t acc_hits = 0, acc_miss = 0;   // wave-uniform
+  uint32_t acc_host = 0;                 // rows read from the host table (staged contexts)
   for (uint32_t tile = wave; tile < tiles; tile += num_waves) {
     const uint32_t row0 = tile * tile_rows;
     const uint32_t rows = min(tile_rows, n - row0);
     const Unit* src = nullptr;
     int32_t slot = -2;
     uint32_t hit_code = 0;
+    bool from_host = false;   // staged context: the row is read from the host table after all
     if (lane < static_cast<int>(rows)) {
       const int64_t id = c.ids[row0 + lane];
       if (id >= 0 && static_cast<uint64_t>(id) < c.num_ids) {
@@ -349,6 +353,8 @@ __device__ inline void gather_body(const Ctx& c) {
               if (g - c.st_lo <= c.st_span)
                 src = reinterpret_cast<const Unit*>(c.ring) +
                       (static_cast<uint64_t>(g & c.st_mask) * c.st_cap + static_cast<uint32_t>(p)) * rowu;
+              else
+                from_host = true;
             }
           }
           if (c.update) atomicMax(&c.map[id], -static_cast<int32_t>(row0 + lane + 1));
@@ -358,6 +364,7 @@ __device__ inline void gather_body(const Ctx& c) {
     }
     acc_hits += __popcll(__ballot(slot >= 0));
     acc_miss += __popcll(__ballot(slot == -1));
+    if (kStaged && c.pmap) acc_host += __popcll(__ballot(from_host));
     const uint64_t src_bits = reinterpret_cast<uint64_t>(src);
     const uint32_t total = rows * dimv;
     Unit* o = out + static_cast<uint64_t>(row0) * rowu;
@@ -419,6 +426,8 @@ __device__ inline void gather_body(const Ctx& c) {
     }
   }
   if (c.stats && gtid == 0) atomicAdd(&c.stats[1], n);
+  if (kStaged && c.pmap && acc_host && lane == 0)
+    atomicAdd(c.st_fallback, static_cast<unsigned long long>(acc_host));
   if (kStaged && c.progress && gtid == 0)
     __hip_atomic_store(c.progress, c.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -468,30 +477,33 @@ struct StageCtx {
   const int32_t* map;          // null: cache-free context (target rows)
   uint64_t num_ids;
   unsigned long long* pmap;
-  const float* feats;
-  float* ring;
   uint32_t* region_rows;       // [G] rows taken in each region
-  unsigned long long* pulled;  // rows pulled so far (diagnostics)
-  uint32_t dim, vec4;
+  long long* region_ids;       // [C] id staged in each row of THIS generation's region
   uint32_t gen, lo, mask, cap;
+  // LRU: a CACHED id whose entry is among the first `risk` of the eviction order may be gone
+  // when the fetch this prefetch works for runs (up to kStageAhead updates lie in between, each
+  // taking at most its block's rows from the front) — it is staged as well.  A small cache that
+  // a block turns over (the headline's node cache: 2 196 slots, ~800 installs per step) would
+  // otherwise send a few hundred rows per step to the host table from inside the gather.
+  const uint32_t* qpos;        // null: no such rule (LFU / FIFO, cache-free context)
+  const QueueState* qstate;    // queue form: the head the positions count from
+  uint32_t risk;
 };
 struct StageRound {
   StageCtx c[kMaxCtx];
   int count;
 };
 
-__global__ __launch_bounds__(256) void stage_rows_kernel(StageRound r) {
+// claim: one thread per block row.  A row whose id is neither cached nor staged in a readable
+// generation takes the next row of this generation's region (one atomic per wave) and settles the
+// id's pmap entry with a compare-and-swap — of several rows with the same id one wins, the others'
+// region rows stay unused.
+__global__ __launch_bounds__(256) void stage_claim_kernel(StageRound r) {
   const StageCtx& c = r.c[blockIdx.y];
-  __shared__ long long s_id[256];
-  __shared__ uint32_t s_pos[256];
-  __shared__ uint32_t s_n;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
   const uint32_t region = c.gen & c.mask, span = c.gen - c.lo;
-  // the next generation's region starts empty (prefetches run in order on one stream)
-  if (blockIdx.x == 0 && tid == 0) c.region_rows[(c.gen + 1u) & c.mask] = 0u;
-  uint32_t pulled = 0;
   for (uint32_t base = blockIdx.x * 256u; base < c.n; base += gridDim.x * 256u) {
-    const uint32_t i = base + tid;
+    const uint32_t i = base + threadIdx.x;
     long long id = -1;
     unsigned long long p = 0;
     bool want = false;
@@ -500,74 +512,102 @@ __global__ __launch_bounds__(256) void stage_rows_kernel(StageRound r) {
       if (id >= 0 && static_cast<uint64_t>(id) < c.num_ids) {
         // (a negative map value other than kAbsent is the claim of a fetch in flight: its
         // update installs the id before the gather this prefetch works for)
-        if ((c.map ? c.map[id] : kAbsent) == kAbsent) {
+        const int32_t slot = c.map ? c.map[id] : kAbsent;
+        bool maybe = slot == kAbsent;
+        if (slot >= 0 && c.qpos) {
+          uint32_t at = c.qpos[slot];
+          if (c.qstate) at -= c.qstate->head;
+          maybe = at < c.risk;
+        }
+        if (maybe) {
           p = c.pmap[id];
           want = static_cast<uint32_t>(p >> 32) - c.lo > span;
         }
       }
     }
     const unsigned long long wm = __ballot(want);
-    uint32_t pos = c.cap;
-    if (wm) {
-      const int leader = __ffsll(static_cast<long long>(wm)) - 1;
-      uint32_t wbase = 0;
-      if (static_cast<int>(lane) == leader) wbase = atomicAdd(&c.region_rows[region], static_cast<uint32_t>(__popcll(wm)));
-      wbase = __shfl(wbase, leader, 64);
-      if (want) pos = wbase + static_cast<uint32_t>(__popcll(wm & ((1ull << lane) - 1ull)));
+    if (!wm) continue;
+    const int leader = __ffsll(static_cast<long long>(wm)) - 1;
+    uint32_t wbase = 0;
+    if (static_cast<int>(lane) == leader)
+      wbase = atomicAdd(&c.region_rows[region], static_cast<uint32_t>(__popcll(wm)));
+    wbase = __shfl(wbase, leader, 64);
+    const uint32_t pos = wbase + static_cast<uint32_t>(__popcll(wm & ((1ull << lane) - 1ull)));
+    if (!want || pos >= c.cap) continue;
+    const unsigned long long mine = (static_cast<unsigned long long>(c.gen) << 32) | pos;
+    long long staged = -1;   // a row of the region that nobody reads is not pulled either
+    for (;;) {
+      const unsigned long long old = atomicCAS(&c.pmap[id], p, mine);
+      if (old == p) { staged = id; break; }
+      if (static_cast<uint32_t>(old >> 32) - c.lo <= span) break;   // another row of this id was first
+      p = old;
     }
-    bool won = false;
-    if (want && pos < c.cap) {
-      const unsigned long long mine = (static_cast<unsigned long long>(c.gen) << 32) | pos;
-      for (;;) {
-        const unsigned long long old = atomicCAS(&c.pmap[id], p, mine);
-        if (old == p) { won = true; break; }
-        if (static_cast<uint32_t>(old >> 32) - c.lo <= span) break;   // another row of this id was first
-        p = old;
-      }
-    }
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    if (won) {
-      const uint32_t k = atomicAdd(&s_n, 1u);
-      s_id[k] = id;
-      s_pos[k] = pos;
-    }
-    __syncthreads();
-    const uint32_t cnt = s_n;
-    if (tid == 0) pulled += cnt;
-    // a wave pulls four rows at a time: their loads leave back to back (PCIe latency ~2 us)
-    const uint64_t rbase = static_cast<uint64_t>(region) * c.cap;
-    if (c.vec4) {
-      const uint32_t dimv = c.dim >> 2;
-      for (uint32_t e = wave * 4u; e < cnt; e += 16u) {
-        for (uint32_t off = lane; off < dimv; off += 64u) {
-          float4 v[4];
-#pragma unroll
-          for (uint32_t k = 0; k < 4u; ++k)
-            if (e + k < cnt)
-              v[k] = reinterpret_cast<const float4*>(c.feats + static_cast<uint64_t>(s_id[e + k]) * c.dim)[off];
-#pragma unroll
-          for (uint32_t k = 0; k < 4u; ++k)
-            if (e + k < cnt)
-              reinterpret_cast<float4*>(c.ring + (rbase + s_pos[e + k]) * c.dim)[off] = v[k];
-        }
-      }
-    } else {
-      for (uint32_t e = wave * 4u; e < cnt; e += 16u) {
-        for (uint32_t off = lane; off < c.dim; off += 64u) {
-          float v[4];
-#pragma unroll
-          for (uint32_t k = 0; k < 4u; ++k)
-            if (e + k < cnt) v[k] = c.feats[static_cast<uint64_t>(s_id[e + k]) * c.dim + off];
-#pragma unroll
-          for (uint32_t k = 0; k < 4u; ++k)
-            if (e + k < cnt) c.ring[(rbase + s_pos[e + k]) * c.dim + off] = v[k];
-        }
-      }
-    }
-    __syncthreads();
+    c.region_ids[pos] = staged;
   }
-  if (tid == 0 && pulled) atomicAdd(c.pulled, static_cast<unsigned long long>(pulled));
+}
+
+// pull: the rows the claim kernel settled, host table -> this generation's region of the ring.
+// A wave owns 8 consecutive ring rows — one contiguous run of stores — and keeps 6 16-byte loads
+// per lane in flight over the host link (PCIe round trips are ~2 us: what counts is the number of
+// reads in flight, and every wave of the grid has its own rows — a first version that copied the
+// winners of a 256-row tile inside the claim workgroup took 82 us for the 600 target rows of
+// three workgroups).
+struct PullJob {
+  const long long* ids;        // [cap] (-1: unused row)
+  const float* feats;
+  float* dst;                  // the region's first row
+  uint32_t* region_rows;       // rows taken in the region (may exceed cap: the excess was dropped)
+  uint32_t* next_rows;         // the next generation's counter, cleared here
+  unsigned long long* pulled;  // rows pulled so far (diagnostics)
+  uint32_t cap, dim, vec4;
+};
+struct PullJobs {
+  PullJob j[2];
+  int count;
+};
+
+template <typename VecT>
+__device__ inline void stage_pull_body(const PullJob& j, uint32_t n) {
+  constexpr uint32_t kRows = 8, K = 6;
+  constexpr uint32_t kPer = sizeof(VecT) / sizeof(float);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
+  const uint32_t dimv = j.dim / kPer;
+  const VecT* feats = reinterpret_cast<const VecT*>(j.feats);
+  VecT* dst = reinterpret_cast<VecT*>(j.dst);
+  for (uint32_t row0 = wave * kRows; row0 < n; row0 += nwaves * kRows) {
+    const uint32_t rows = min(kRows, n - row0);
+    const long long id = lane < rows ? j.ids[row0 + lane] : -1;
+    const uint32_t valid = static_cast<uint32_t>(__popcll(__ballot(id >= 0)));
+    if (lane == 0 && valid) atomicAdd(j.pulled, static_cast<unsigned long long>(valid));
+    const uint32_t total = rows * dimv;
+    VecT* o = dst + static_cast<uint64_t>(row0) * dimv;
+    for (uint32_t base = 0; base < total; base += 64u * K) {
+      VecT v[K];
+      bool ok[K];
+#pragma unroll
+      for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t f = base + lane + 64u * k;
+        const uint32_t rr = f < total ? f / dimv : 0u;
+        const long long src = __shfl(id, rr, 64);     // (every lane executes the cross-lane read)
+        ok[k] = f < total && src >= 0;
+        if (ok[k]) v[k] = feats[static_cast<uint64_t>(src) * dimv + (f - rr * dimv)];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < K; ++k)
+        if (ok[k]) o[base + lane + 64u * k] = v[k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void stage_pull_kernel(PullJobs jobs) {
+  const PullJob& j = jobs.j[blockIdx.y];
+  const uint32_t n = min(*j.region_rows, j.cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *j.next_rows = 0u;   // (prefetch generations run in order on one stream)
+  }
+  if (j.vec4) stage_pull_body<float4>(j, n);
+  else stage_pull_body<float>(j, n);
 }
 
 // ---- planning a pull from sharded feature tables -------------------------------------------
@@ -2762,6 +2802,7 @@ void FeatureCache::set_staging(size_t generations, size_t rows_per_generation) {
     ring_.release();
     pmap_.release();
     region_rows_.release();
+    region_ids_.release();
     stage_wait_ = nullptr;
     return;
   }
@@ -2775,7 +2816,9 @@ void FeatureCache::set_staging(size_t generations, size_t rows_per_generation) {
   ring_.release();
   ring_.reserve(generations * rows_per_generation * dim_ * sizeof(float) + 16);
   pmap_.reserve(std::max<size_t>(num_ids_ * sizeof(unsigned long long), 16));
-  region_rows_.reserve(64 * sizeof(uint32_t) + 16);
+  region_rows_.reserve(64 * sizeof(uint32_t) + 32);   // + rows pulled, + rows read from the host
+  region_ids_.release();
+  region_ids_.reserve(rows_per_generation * sizeof(long long) + 16);
   progress_.reserve(64);
   *progress_.as<volatile uint32_t>() = 0;
   for (hipEvent_t& e : stage_events_)
@@ -2802,20 +2845,30 @@ void FeatureCache::invalidate_staging() {
   stage_wait_ = nullptr;
 }
 
-void FeatureCache::staging_state(uint64_t out[6]) {
+void FeatureCache::staging_state(uint64_t out[7]) {
   out[0] = stage_gens_;
   out[1] = stage_cap_;
   out[2] = gen_issued_;
   out[3] = stage_drops_;
   out[4] = 0;
   out[5] = staging() ? ring_.bytes() + pmap_.bytes() : 0;
+  out[6] = 0;
   if (staging()) {
     DeviceGuard dg(device_);
     GF_HIP(hipDeviceSynchronize());
-    unsigned long long v = 0;
-    GF_HIP(hipMemcpy(&v, region_rows_.as<uint32_t>() + 64, sizeof(v), hipMemcpyDeviceToHost));
-    out[4] = v;
+    unsigned long long v[2] = {0, 0};
+    GF_HIP(hipMemcpy(v, region_rows_.as<uint32_t>() + 64, sizeof(v), hipMemcpyDeviceToHost));
+    out[4] = v[0];
+    out[6] = v[1];
   }
+}
+
+static inline bool stage_risk_enabled() {
+  static const bool on = [] {
+    const char* v = std::getenv("GNNFLOW_STAGE_AT_RISK");   // tuning / tests; 0: absent ids only
+    return !(v && std::atoi(v) == 0);
+  }();
+  return on;
 }
 
 // The window of generations a launch may read when `issued` is the newest one: region g & mask
@@ -2873,7 +2926,7 @@ void FeatureCache::stage_sync(hipStream_t stream, hipEvent_t* seen, int* num_see
   stage_wait_ = nullptr;
 }
 
-// Context of one block for the next prefetch generation.  false: not to be staged.
+// Context of one block for the generation just taken (stage_advance).
 bool FeatureCache::stage_begin(void* stage_ctx_out, const int64_t* d_ids, size_t n, bool cached) {
   StageCtx& c = *static_cast<StageCtx*>(stage_ctx_out);
   std::memset(&c, 0, sizeof(c));
@@ -2882,17 +2935,37 @@ bool FeatureCache::stage_begin(void* stage_ctx_out, const int64_t* d_ids, size_t
   c.map = (cached && capacity_) ? map_.as<int32_t>() : nullptr;
   c.num_ids = num_ids_;
   c.pmap = pmap_.as<unsigned long long>();
-  c.feats = feats_;
-  c.ring = ring_.as<float>();
   c.region_rows = region_rows_.as<uint32_t>();
-  c.pulled = reinterpret_cast<unsigned long long*>(region_rows_.as<uint32_t>() + 64);
-  c.dim = static_cast<uint32_t>(dim_);
-  c.vec4 = vec4_ok(dim_, feats_, ring_.data(), ring_.data()) ? 1u : 0u;
+  c.region_ids = region_ids_.as<long long>();
   c.gen = gen_issued_;
   c.lo = stage_window_lo(gen_issued_, stage_gens_, kStageAhead);
   c.mask = stage_gens_ - 1u;
   c.cap = stage_cap_;
+  // (only a cache that kStageAhead blocks of this size can turn over: for a larger one the
+  // entries at the front of the order are rarely among a block's hits, and the rule pulled 370
+  // rows per step for the headline's edge cache — 134 k slots, 9.5 k-row blocks — to save 4)
+  if (c.map && policy_ == GF_CACHE_LRU && stage_risk_enabled() &&
+      capacity_ <= size_t{kStageAhead} * n) {
+    c.qpos = qpos_.as<uint32_t>();
+    c.qstate = queue_form_ ? qstate_.as<QueueState>() : nullptr;
+    c.risk = static_cast<uint32_t>(capacity_);
+  }
   return true;
+}
+
+// ... and the pull of what its blocks claimed
+void FeatureCache::stage_pull(void* pull_job_out) {
+  PullJob& j = *static_cast<PullJob*>(pull_job_out);
+  const uint32_t region = gen_issued_ & (stage_gens_ - 1u);
+  j.ids = region_ids_.as<long long>();
+  j.feats = feats_;
+  j.dst = ring_.as<float>() + static_cast<uint64_t>(region) * stage_cap_ * dim_;
+  j.region_rows = region_rows_.as<uint32_t>() + region;
+  j.next_rows = region_rows_.as<uint32_t>() + ((gen_issued_ + 1u) & (stage_gens_ - 1u));
+  j.pulled = reinterpret_cast<unsigned long long*>(region_rows_.as<uint32_t>() + 64);
+  j.cap = stage_cap_;
+  j.dim = static_cast<uint32_t>(dim_);
+  j.vec4 = vec4_ok(dim_, feats_, ring_.data(), ring_.data()) ? 1u : 0u;
 }
 
 void FeatureCache::stage_fill(void* ctx_out) {
@@ -2907,6 +2980,7 @@ void FeatureCache::stage_fill(void* ctx_out) {
   c.st_cap = stage_cap_;
   c.progress = progress_.as<uint32_t>();
   c.progress_val = stage_reads_;
+  c.st_fallback = reinterpret_cast<unsigned long long*>(region_rows_.as<uint32_t>() + 66);
   stage_read_pending_ = true;
 }
 
@@ -3489,11 +3563,11 @@ bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc
   if (!node_use && !edge_use) return false;
   StageRound r;
   r.count = 0;
-  size_t max_n = 0;
+  size_t max_n = 0, node_rows = 0, edge_rows = 0;
   auto flush = [&] {
     if (r.count == 0) return;
     const unsigned grid = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>((max_n + 255) / 256, 512)));
-    stage_rows_kernel<<<dim3(grid, r.count), dim3(256), 0, stream>>>(r);
+    stage_claim_kernel<<<dim3(grid, r.count), dim3(256), 0, stream>>>(r);
     GF_HIP(hipGetLastError());
     r.count = 0;
     max_n = 0;
@@ -3505,9 +3579,32 @@ bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc
     if (!c) continue;
     c->stage_begin(&r.c[r.count++], d.d_ids, d.n, d.kind != 2);
     max_n = std::max(max_n, d.n);
+    (d.kind == 0 ? node_rows : edge_rows) += d.n;
     if (r.count == kMaxCtx) flush();
   }
   flush();
+  {
+    PullJobs jobs;
+    jobs.count = 0;
+    size_t most = 0;
+    if (node_use) {
+      node->stage_pull(&jobs.j[jobs.count++]);
+      most = std::max(most, std::min<size_t>(node_rows, node->stage_cap_));
+    }
+    if (edge_use) {
+      edge->stage_pull(&jobs.j[jobs.count++]);
+      most = std::max(most, std::min<size_t>(edge_rows, edge->stage_cap_));
+    }
+    // 8 rows per wave, 4 waves per workgroup; the kernel reads the rows really claimed
+    // (grid-stride: 64 workgroups = 256 waves x 6 loads in flight cover the link's latency)
+    static const size_t max_wgs = [] {
+      const char* v = std::getenv("GNNFLOW_STAGE_PULL_WGS");   // tuning
+      return v ? static_cast<size_t>(std::max(1, std::atoi(v))) : size_t{64};
+    }();
+    const unsigned grid = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>((most + 31) / 32, max_wgs)));
+    stage_pull_kernel<<<dim3(grid, jobs.count), dim3(256), 0, stream>>>(jobs);
+    GF_HIP(hipGetLastError());
+  }
   FeatureCache* lead = edge_use ? edge : node;
   hipEvent_t ev = lead->stage_events_[lead->gen_issued_ % FeatureCache::kStageEvents];
   GF_HIP(hipEventRecord(ev, stream));

@@ -94,9 +94,10 @@ class FeatureCache {
   bool staging() const { return stage_gens_ != 0; }
   // forget every staged row (the table's contents changed)
   void invalidate_staging();
-  // out[0..5]: generations, rows per generation, generations issued, generations dropped,
-  // rows pulled over the host link so far (reads a device counter: synchronises), ring bytes
-  void staging_state(uint64_t out[6]);
+  // out[0..6]: generations, rows per generation, generations issued, generations dropped,
+  // rows pulled over the host link so far (reads a device counter: synchronises), ring bytes,
+  // rows the gathers read from the host table after all (not staged, or staged too long ago)
+  void staging_state(uint64_t out[7]);
 
  private:
   friend void fetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
@@ -155,6 +156,7 @@ class FeatureCache {
   DeviceBuffer ring_;         // float[generations * rows * dim]
   DeviceBuffer pmap_;         // uint64[num_ids]  {generation, row in its region}; 0: never staged
   DeviceBuffer region_rows_;  // uint32[generations] rows taken per region, + uint64 rows pulled
+  DeviceBuffer region_ids_;   // int64[rows] ids claimed for the generation being pulled
   PinnedBuffer progress_;     // uint32: ring-reading launches known to have finished
   uint32_t stage_gens_ = 0, stage_cap_ = 0;
   uint32_t gen_issued_ = 0;   // last generation handed to a prefetch
@@ -166,6 +168,7 @@ class FeatureCache {
   hipEvent_t stage_wait_ = nullptr;       // event behind the last prefetch, not yet waited for
   bool stage_advance();                   // takes the next generation; false: dropped
   bool stage_begin(void* stage_ctx_out, const int64_t* d_ids, size_t n, bool cached);
+  void stage_pull(void* pull_job_out);
   void stage_sync(hipStream_t stream, hipEvent_t* seen, int* num_seen);
   void stage_fill(void* ctx_out);         // ring fields of a gather context
   void stage_round_done();

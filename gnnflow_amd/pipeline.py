@@ -46,7 +46,9 @@ class ReplayPipeline:
                      for, which takes the sampler's issue + execution latency off the
                      critical path), fetch_feature(async_enqueue=True) on the current stream.
     pipelined=False: the plain loop `mfgs = sampler.sample(r, t); cache.fetch_feature(mfgs, e)`.
-    cache=None     : sampling only.
+    cache=None     : sampling only; pipelined=True keeps `depth` (at least 2 per lane) samples in
+                     flight over the lanes and waits for them in batch order — what
+                     benchmarks/benchmark_sampler.py:71-87 times, without its host wait per batch.
     sample_lanes   : consecutive batches are sampled round-robin by this many samplers (clones
                      of `sampler` over the same graph: own native workspace, own side stream),
                      so the four dependent launches of one sample() overlap the next one's.  A
@@ -61,8 +63,7 @@ class ReplayPipeline:
                  sample_lanes: Optional[int] = None):
         self.sampler, self.cache, self.batches = sampler, cache, batches
         self.device = torch.device(device)
-        self.pipelined = bool(pipelined) and cache is not None and \
-            hasattr(sampler, "sample_async")
+        self.pipelined = bool(pipelined) and hasattr(sampler, "sample_async")
         self.side = side_stream(self.device, 0) if self.pipelined else None
         if sample_lanes is None:
             sample_lanes = int(os.environ.get("GNNFLOW_SAMPLE_LANES", "2"))
@@ -120,6 +121,19 @@ class ReplayPipeline:
         # reference moves a miss host -> pinned -> device inside fetch_feature,
         # gnnflow/cache/cache.py:288-313,381-388) — one more sample in flight pays for the
         # earlier wait.
+        if cache is None:
+            depth = max(self.depth, 2 * nl)
+            while nxt < last and len(pending) < depth:
+                pending.append(begin(nxt))
+                nxt += 1
+            for i in range(first, last):
+                mfgs = pending.popleft().wait()
+                if nxt < last:
+                    pending.append(begin(nxt))
+                    nxt += 1
+                if on_step:
+                    on_step(i % nb, mfgs)
+            return
         staged = bool(getattr(cache, "staging", False))
         depth = self.depth + (1 if staged else 0)
         while nxt < last and len(pending) < depth:

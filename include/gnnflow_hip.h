@@ -358,9 +358,9 @@ GF_API int gf_cache_fetch_wait(uint64_t ticket);
  * *issued = 0 when the call issued nothing (no ring, or the generation was dropped because
  * fetches that may still read the region it would overwrite had not finished).
  * generations: a power of two in 8..64, or 0 = ring off.  gf_cache_invalidate_staging: the
- * table's contents changed.  gf_cache_staging_state out[6]: generations, rows per generation,
+ * table's contents changed.  gf_cache_staging_state out[7]: generations, rows per generation,
  * generations issued, generations dropped, rows pulled over the host link (synchronises), bytes
- * of HBM the ring and its index take. */
+ * of HBM the ring and its index take, rows the gathers still read from the host table. */
 GF_API int gf_cache_set_staging(gf_cache* c, size_t generations, size_t rows_per_generation);
 GF_API int gf_cache_invalidate_staging(gf_cache* c);
 GF_API int gf_cache_staging_state(gf_cache* c, uint64_t* out);

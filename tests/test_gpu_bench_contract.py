@@ -77,6 +77,29 @@ def test_single_gpu_line_with_roofline_and_cpu_baseline():
     assert "error" not in hr and hr["value"] > 0.4 * d["value"]
     assert "RCCL communicator" in hr["exchange"] and "samples each on average" in hr["exchange"]
     assert hr["rccl_nranks"] and set(hr["rccl_nranks"]) == {1}    # ncclCommCount of every lane
+    # the harness's own unit and the sampler-only comparison north_star's ">= 10x the reference
+    # CPU sampler" is written on (benchmarks/benchmark_sampler.py:71-87), on both legs
+    assert d["target_edges_per_s"] == pytest.approx(600 / (d["ms_per_step"] * 1e-3))
+    assert h["target_edges_per_s"] > 0 and hr["target_edges_per_s"] > 0
+    so, cso = d["sample_only"], c["sample_only"]
+    assert "error" not in so and so["pipelined"] and so["value"] > d["value"]
+    assert so["target_edges_per_s"] == pytest.approx(600 / (so["ms_per_step"] * 1e-3))
+    assert cso["value"] >= c["value"] and cso["single_thread_value"] > 0 and cso["cores"] >= 1
+    assert c["target_edges_per_s"] > 0 and cso["target_edges_per_s"] > 0
+    assert so["value"] > 10 * cso["value"]                 # north_star's target, sampler on sampler
+    # the other feature placements beside the headline: the gather without a cache (tables in
+    # HBM), and the reference's placement — tables in pinned host memory behind LRU 0.2
+    cf, pp = d["cache_free_device"], d["pinned_placement"]
+    assert "error" not in cf and cf["value"] > 0
+    assert cf["rows_per_step"] == pytest.approx(d["config"]["rows_per_step"], rel=0.02)
+    assert "error" not in pp and pp["value"] > 0
+    assert pp["rows_per_step"] == pytest.approx(d["config"]["rows_per_step"], rel=0.02)
+    assert pp["cache_edge_ratio"] == pytest.approx(d["cache_edge_ratio"])
+    assert pp["rows_pulled_into_ring_per_step"] > 0
+    assert pp["host_link_bytes_per_step"] == pytest.approx(
+        688 * (pp["rows_pulled_into_ring_per_step"] + pp["rows_read_from_host_by_gather_per_step"]))
+    assert pp["host_link_GBps_memcpy_256MB"] > 1
+    assert pp["value"] > pp["without_staging_ring"]["value"]    # the ring pays
     # BASELINE configs[2] (here on a small graph) rides in the same line
     c3 = d["config3"]
     assert "error" not in c3 and [r["batch"] for r in c3["rows"]] == [600, 6000]
