@@ -452,6 +452,27 @@ int gf_sampler_sample_begin_async(gf_sampler* s, const int64_t* d_roots, const f
         }));
   });
 }
+int gf_sampler_call_counter(const gf_sampler* s, uint64_t* out) {
+  return guarded([&] {
+    GF_S(s);
+    GF_REQUIRE(out != nullptr, "gf_sampler_call_counter: null output");
+    *out = s->impl.call_counter();
+  });
+}
+int gf_sampler_set_call_counter(gf_sampler* s, uint64_t value, int through_enqueue_thread) {
+  return guarded([&] {
+    GF_S(s);
+    gf::Sampler* impl = &s->impl;
+    if (through_enqueue_thread) {
+      // (jobs of the sampling lane run in submission order: the begin submitted next sees it)
+      gf::EnqueueWorker::get(1).submit([impl, value]() { impl->set_call_counter(value); });
+    } else {
+      GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
+                 "set_call_counter: samples begun through the enqueue thread are in flight");
+      impl->set_call_counter(value);
+    }
+  });
+}
 int gf_sampler_sample_end(gf_sampler* s, gf_block* blocks) {
   if (s && !s->begin_tickets.empty()) {
     const uint64_t t = s->begin_tickets.front();

@@ -142,6 +142,10 @@ class Sampler {
   uint64_t seed_;
   DeviceBuffer part_ticket_;   // reply_compact_kernel: "last slot of the sample" tickets
   uint64_t calls_ = 0;  // sample_layer invocations so far (uniform RNG counter)
+ public:
+  uint64_t call_counter() const { return calls_; }
+  void set_call_counter(uint64_t v) { calls_ = v; }
+ private:
   int search_group_ = 16;   // lanes per root, layers of <= 32 768 roots
   int large_group_ = 4;     // lanes per root, larger layers (sampler.hip: group_width_from_env)
   bool fused_scan_ = true;

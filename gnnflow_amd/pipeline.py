@@ -51,10 +51,11 @@ class ReplayPipeline:
                      benchmarks/benchmark_sampler.py:71-87 times, without its host wait per batch.
     sample_lanes   : consecutive batches are sampled round-robin by this many samplers (clones
                      of `sampler` over the same graph: own native workspace, own side stream),
-                     so the four dependent launches of one sample() overlap the next one's.  A
-                     sample is a pure function of (graph, roots, timestamps) only for
-                     most-recent sampling — uniform draws depend on the sampler's call counter
-                     — so other strategies keep one lane.  Default: GNNFLOW_SAMPLE_LANES or 2.
+                     so the four dependent launches of one sample() overlap the next one's.
+                     Uniform draws are keyed by the sampler's call counter: every sample is
+                     begun with the call number it would have had on the one sampler
+                     (sample_async(call_base=...)), so the lanes reproduce its stream of draws
+                     bit for bit.  Default: GNNFLOW_SAMPLE_LANES or 2.
     """
 
     def __init__(self, sampler, cache, batches: Sequence[Tuple[torch.Tensor, torch.Tensor,
@@ -69,7 +70,8 @@ class ReplayPipeline:
             sample_lanes = int(os.environ.get("GNNFLOW_SAMPLE_LANES", "2"))
         self.lanes = [(sampler, self.side)]
         if self.pipelined and sample_lanes > 1 and hasattr(sampler, "clone") and \
-                getattr(sampler, "_strategy", None) == "recent" and \
+                getattr(sampler, "_strategy", None) in ("recent", "uniform") and \
+                hasattr(sampler, "set_call_counter") and \
                 not hasattr(sampler, "chain_samples"):
             for k in range(1, min(int(sample_lanes), 4)):
                 self.lanes.append((sampler.clone(), side_stream(self.device, k)))
@@ -110,9 +112,19 @@ class ReplayPipeline:
         pending = deque()
         nxt = first
 
+        # several lanes + uniform sampling: sample j draws from the call number it would have on
+        # the one sampler; afterwards the primary sampler's counter stands where it would
+        keyed = nl > 1 and getattr(self.sampler, "_strategy", None) == "uniform"
+        if keyed:
+            per = self.sampler.calls_per_sample
+            call0 = self.sampler.call_counter() - first * per
+
         def begin(j):
             r, t, _ = batches[j % nb]
             sampler, side = lanes[j % nl]
+            if keyed:
+                return sampler.sample_async(r, t, stream=side, worker_enqueue=True,
+                                            call_base=call0 + j * per)
             return sampler.sample_async(r, t, stream=side, worker_enqueue=True)
 
         # Host-resident feature tables (feature_placement="pinned" with a staging ring): batch
@@ -133,6 +145,8 @@ class ReplayPipeline:
                     nxt += 1
                 if on_step:
                     on_step(i % nb, mfgs)
+            if keyed:
+                self.sampler.set_call_counter(call0 + last * per)
             return
         staged = bool(getattr(cache, "staging", False))
         depth = self.depth + (1 if staged else 0)
@@ -162,3 +176,5 @@ class ReplayPipeline:
             if on_step:
                 on_step(i % nb, mfgs)
         cache.wait_enqueued()
+        if keyed:
+            self.sampler.set_call_counter(call0 + last * per)

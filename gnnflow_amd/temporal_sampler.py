@@ -198,16 +198,40 @@ class TemporalSampler:
         """
         return self.sample_async(target_vertices, timestamps).wait()
 
+    def call_counter(self) -> int:
+        """Number of sample_layer invocations so far = the `call` word of the next uniform draw
+        (include/gnnflow_hip.h gf_sampler_call_counter).  No sample may be in flight."""
+        n = C.c_uint64(0)
+        _capi.check(self._lib.gf_sampler_call_counter(self._h, C.byref(n)))
+        return int(n.value)
+
+    def set_call_counter(self, value: int, through_enqueue_thread: bool = False):
+        """The next begun sample draws from call number `value` on."""
+        _capi.check(self._lib.gf_sampler_set_call_counter(
+            self._h, int(value), 1 if through_enqueue_thread else 0))
+
+    @property
+    def calls_per_sample(self) -> int:
+        return self._num_layers * self._num_snapshots
+
     def sample_async(self, target_vertices, timestamps, stream=None,
-                     worker_enqueue=False) -> "PendingSample":
+                     worker_enqueue=False, call_base=None) -> "PendingSample":
         """Enqueues sample() on `stream` (default: the current stream) and returns at
         once; `.wait()` blocks until the kernels finished and returns the MFGs.  Lets a
         single Python thread overlap the sampling of batch i+1 with the feature fetch /
         training of batch i (the reference uses a prefetch thread for this,
         scripts/offline_edge_prediction.py:343-346).  One sample in flight per sampler.
-        worker_enqueue=True lets the library's enqueue thread issue the launches."""
+        worker_enqueue=True lets the library's enqueue thread issue the launches.
+        call_base: the call number this sample's uniform draws start from (default: where the
+        sampler's previous sample left off) — lets clones of a sampler take turns and reproduce
+        the one sampler's stream (gnnflow_amd.pipeline.ReplayPipeline's lanes)."""
         if len(self._inflight) >= self._max_inflight:
             self._inflight[0].wait()   # the native ring holds kMaxInFlight begun samples
+        if call_base is not None:
+            rc = self._lib.gf_sampler_set_call_counter(self._h, call_base,
+                                                       1 if worker_enqueue else 0)
+            if rc:
+                _capi.check(rc)
         if stream is None:
             stream = torch.cuda.current_stream(self._device)
         nodes, ts = self._to_device(target_vertices, timestamps, stream)

@@ -154,6 +154,15 @@ GF_API int gf_sampler_sample_begin(gf_sampler* s, const int64_t* d_roots,
                                    const float* d_root_ts, size_t num_roots, void* d_out,
                                    size_t out_bytes, void* stream);
 GF_API int gf_sampler_sample_end(gf_sampler* s, gf_block* blocks);
+/* Uniform sampling draws philox4x32-10(seed; slot, call) (include/gnnflow_rng.h), `call` = the
+ * number of sample_layer invocations of the sampler so far — one per layer and snapshot of a
+ * sample() (the reference draws from per-thread curand states, sampling_kernels.cu:109-273).
+ * gf_sampler_call_counter reads it; gf_sampler_set_call_counter sets the number the NEXT begun
+ * sample starts from (through_enqueue_thread != 0: ordered with gf_sampler_sample_begin_async).
+ * Clones of one sampler over the same graph can then take turns — sampling lanes — and still
+ * reproduce the one sampler's stream of draws: sample j starts at j x layers x snapshots. */
+GF_API int gf_sampler_call_counter(const gf_sampler* s, uint64_t* out);
+GF_API int gf_sampler_set_call_counter(gf_sampler* s, uint64_t value, int through_enqueue_thread);
 /* As gf_sampler_sample_begin, but the launches are issued by the library's enqueue thread
  * (the one gf_cache_fetch_blocks_async uses, in submission order); gf_sampler_sample_end
  * waits for it.  The inputs must stay alive until gf_sampler_sample_end returns. */

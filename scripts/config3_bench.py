@@ -76,6 +76,19 @@ def sweep(N, E, batches, policies, dev, reps=10, emit=None):
             torch.cuda.synchronize(dev)
             wall = (time.perf_counter() - t0) / reps
             lib.gf_profile_enable(0)
+            # ... and as a stream of samples: the pipelined sample-only loop (ReplayPipeline with
+            # no cache: two sampling lanes, four samples in flight, uniform draws keyed by call
+            # number so the lanes reproduce the one sampler's stream) — the launch gaps and the
+            # host wait of one sample hide behind the other lane's kernels
+            from gnnflow_amd.pipeline import ReplayPipeline
+            pipe = ReplayPipeline(s, None, [(r, t, None)], dev, pipelined=True)
+            n_pipe = max(reps, min(400, int(2e-2 / max(wall, 1e-6))))
+            pipe.run(0, min(n_pipe, 8))
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            pipe.run(0, n_pipe)
+            torch.cuda.synchronize(dev)
+            wall_pipe = (time.perf_counter() - t0) / n_pipe
             blocks = [b for mfg in m for b in mfg]
             edges = sum(b.num_edges() for b in blocks)
             roots_total = sum(b.num_dst_nodes() for b in blocks)
@@ -105,6 +118,8 @@ def sweep(N, E, batches, policies, dev, reps=10, emit=None):
             rec = {
                 "policy": policy, "batch": B, "roots": int(roots_total), "edges": int(edges),
                 "wall_us": 1e6 * wall, "edges_per_s": edges / wall,
+                "pipelined_wall_us": 1e6 * wall_pipe, "pipelined_edges_per_s": edges / wall_pipe,
+                "pipelined_lanes": len(pipe.lanes),
                 "search_us": us(ms_s), "emit_us": us(ms_e), "scan_us": us(ms_c),
                 "search_alg_MB": search_bytes / 1e6, "emit_alg_MB": emit_bytes / 1e6,
                 "layers": per_layer,

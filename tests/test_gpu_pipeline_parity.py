@@ -356,3 +356,40 @@ def test_pinned_tables_prefetch_is_only_a_hint(monkeypatch):
     assert not w2.cache.staging
     assert w2.cache.prefetch_feature(w2.sampler.sample(*w2.dev_batches[0][:2]),
                                      w2.dev_batches[0][2]) is False
+
+
+@pytest.mark.parametrize("fanouts", [(10, 10), (5, 10, 3)])
+def test_uniform_sampling_on_two_lanes_reproduces_the_one_samplers_draws(fanouts):
+    """Uniform sampling through the pipelined loop: consecutive batches go to two samplers (the
+    sampler and a clone, a stream each), every sample begun with the call number it would have had
+    on the one sampler — the MFGs must equal the oracle's, whose draws come from ONE sampler's
+    counter (philox keyed by (seed, slot, call); sampling_kernels.cu:109-273 draws from curand
+    states instead).  Then the plain loop continues on the primary sampler: its counter must stand
+    where the oracle's does."""
+    from gnnflow_amd.pipeline import ReplayPipeline
+    w = _World(1000, 40, policy="uniform", fanouts=fanouts)
+    pipe = ReplayPipeline(w.sampler, w.cache, w.dev_batches, w.dev, pipelined=True)
+    assert pipe.pipelined and len(pipe.lanes) == 2
+    _run_chunks(w, pipe, 32, 16)
+    assert w.sampler.call_counter() == 32 * len(fanouts)
+    # the sampler alone, pipelined without a cache (config 3's loop): same stream of draws
+    got = []
+    pipe2 = ReplayPipeline(w.sampler, None, w.dev_batches, w.dev, pipelined=True)
+    assert len(pipe2.lanes) == 2
+    pipe2.run(32, 4, lambda i, mfgs: got.append((i, [[(b.edata["ID"].cpu().numpy(),
+                                                        b.srcdata["ID"].cpu().numpy())
+                                                       for b in mfg] for mfg in mfgs])))
+    for i, mf in got:
+        r, t, _ = w.host_batches[i]
+        om = w.osampler.sample(r, t)
+        for a, b in zip(mf, om):
+            for (eid, nid), ob in zip(a, b):
+                assert np.array_equal(eid, ob.edata["ID"]) and np.array_equal(nid, ob.srcdata["ID"])
+    # ... and back on the primary sampler through the plain call
+    for i in range(36, 40):
+        r, t, _ = w.dev_batches[i]
+        hm = w.sampler.sample(r, t)
+        om = w.osampler.sample(*w.host_batches[i][:2])
+        for a, b in zip(hm, om):
+            for hb, ob in zip(a, b):
+                assert np.array_equal(hb.edata["ID"].cpu().numpy(), ob.edata["ID"])
