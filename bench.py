@@ -496,6 +496,63 @@ def rung_seconds(name, rung, defaults):
     return float(parts[min(rung, len(parts) - 1)])
 
 
+class RungBarrier:
+    """The supervisors of one run leave a rung TOGETHER.  Without this a rank whose worker dies
+    early starts the next rung at once — on the next port — while its peers sit in the old rung
+    until their watchdogs fire; its new worker then waits in a rendezvous nobody joins, is killed
+    before the others arrive, and from then on the ranks are on different rungs for good (rungs 1
+    and 2 are never really tried).  All ranks of a run are on one node (the driver's contract:
+    --nnodes=1) and children of one launcher, so the barrier is a directory under the temp dir
+    named after the launcher's pid and the run's base port: a rank that has left rung r (whatever
+    the outcome) drops a file there and waits until every rank's file is there — or until the
+    longest a peer's rung can still last, after which it goes on alone, as before.  The
+    supervisors never touch the GPU."""
+
+    def __init__(self, rank, world, base_port):
+        import tempfile
+        self.rank, self.world = rank, world
+        self.dir = os.path.join(tempfile.gettempdir(), "gnnflow_ladder_{}_{}".format(
+            os.getppid(), base_port))
+        try:
+            os.makedirs(self.dir, exist_ok=True)
+            for name in os.listdir(self.dir):            # this rank's files of an earlier run
+                if name.endswith("_rank{}".format(rank)):
+                    os.unlink(os.path.join(self.dir, name))
+        except OSError:
+            self.dir = None
+
+    def leave(self, rung, status, wait_s):
+        """Announces that this rank's worker of `rung` is gone; returns how many ranks had left
+        the rung when the wait ended (world: everybody)."""
+        if self.dir is None:
+            return 0
+        try:
+            with open(os.path.join(self.dir, "left_{}_rank{}".format(rung, self.rank)), "w") as f:
+                f.write(str(status))
+        except OSError:
+            return 0
+        deadline = time.time() + max(wait_s, 0.0)
+        while True:
+            try:
+                n = sum(1 for name in os.listdir(self.dir) if name.startswith("left_{}_".format(rung)))
+            except OSError:
+                return 0
+            if n >= self.world or time.time() >= deadline:
+                return n
+            time.sleep(0.05)
+
+    def close(self):
+        if self.dir is None:
+            return
+        try:
+            for name in os.listdir(self.dir):
+                if name.endswith("_rank{}".format(self.rank)):
+                    os.unlink(os.path.join(self.dir, name))
+            os.rmdir(self.dir)            # (the last rank out succeeds)
+        except OSError:
+            pass
+
+
 def supervise(args, argv):
     """One RANK of an N > 1 run (started by torchrun or by launch_ranks): this process never
     touches the GPU.  It runs the rungs of the ladder (RUNGS) one after the other, each as a
@@ -514,6 +571,7 @@ def supervise(args, argv):
     import threading
     rank = int(os.environ.get("RANK", "0"))
     base_port = int(os.environ.get("MASTER_PORT", "29500"))
+    barrier = RungBarrier(rank, int(os.environ.get("WORLD_SIZE", "1")), base_port)
     history, rc, lines = [], 1, []
     for rung in range(len(RUNGS)):
         fd, path = tempfile.mkstemp(prefix="gnnflow_rung{}_rank{}_".format(rung, rank))
@@ -561,6 +619,10 @@ def supervise(args, argv):
             os.unlink(path)
         except (OSError, ValueError):
             pass
+        if rung < len(RUNGS) - 1:
+            # leave the rung together with the peers: one of them may still be inside its
+            # watchdog's time (they started the rung when this rank did)
+            left = barrier.leave(rung, rc, (limit - (time.time() - t0) + 15.0) if rc != 0 else 0.0)
         if rc == 0:
             break
         if rung == len(RUNGS) - 1:
@@ -572,10 +634,12 @@ def supervise(args, argv):
                      "the worker exited with status {}".format(rc)}
         entry["worker_killed"] = bool(killed)
         entry["seconds"] = round(time.time() - t0, 1)
+        entry["ranks_left_together"] = left
         history.append(entry)
         sys.stderr.write("bench.py rank {}: rung {} ({}) is over after {:.0f} s: {}; starting rung "
                          "{} ({})\n".format(rank, rung, RUNGS[rung][0], time.time() - t0,
                                             entry["error"], rung + 1, RUNGS[rung + 1][0]))
+    barrier.close()
     if rank == 0:
         if lines:
             sys.stdout.write(lines[-1])         # exactly one line
@@ -603,6 +667,8 @@ def main():
         # outcome — "ok" prints a line, "giveup" leaves a ladder entry and exits GIVE_UP, "hang"
         # never exits, "die" exits 9 — so that launcher + supervisor + ladder run end to end
         rung = int(os.environ["GNNFLOW_BENCH_RUNG"])
+        # (GNNFLOW_BENCH_FAKE_WORKER_RANK<r>: that rank acts differently from the others)
+        fake = os.environ.get("GNNFLOW_BENCH_FAKE_WORKER_RANK" + os.environ.get("RANK", "0"), fake)
         acts = fake.split(",")
         act = acts[min(rung, len(acts) - 1)]
         if act == "hang":
@@ -902,8 +968,12 @@ def main():
         bytes_per_launch = gather_bytes / max(n_launches, 1)
         avg_us = 1e3 * g_ms.value / g_n.value
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
+        lean = d_e % 4 == 0 and d_n % 4 == 0 and not any(
+            k.lru_state()["queue_form"] for k in (cache._node, cache._edge) if k is not None)
         out["roofline"] = {
-            "bound": "hbm", "kernel": "gather_rows_kernel",
+            "bound": "hbm",
+            "kernel": "gather_rows_any_kernel" if not lean else
+            ("gather_rows_staged_kernel" if cache.staging else "gather_rows_kernel"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             # PMC counters cannot be read inside this process: `traffic` stays null in the run,
@@ -935,17 +1005,32 @@ def main():
         if l_n.value:
             rows = rows_moved / max(n_launches, 1)
             miss = 1.0 - 0.5 * (out["cache_edge_ratio"] + out["cache_node_ratio"])
-            lru_bytes = 16.0 * (cache.edge_capacity + cache.node_capacity) + 12.0 * rows + \
-                miss * rows * (8.0 * d_e + 24.0)
+            # which kernels the update really ran (gf_cache_lru_state + GNNFLOW_LRU_FUSED): the
+            # byte model and the clock follow the form
+            forms = [k.lru_state()["queue_form"] for k in (cache._node, cache._edge) if k is not None]
+            fused = os.environ.get("GNNFLOW_LRU_FUSED", "1") != "0"
+            installs = miss * rows * (8.0 * d_e + 24.0)
+            if not any(forms):
+                lru_bytes = 16.0 * (cache.edge_capacity + cache.node_capacity) + 12.0 * rows + installs
+                kernel = "lru_list_fused_kernel" if fused else \
+                    "lru_list_scan_kernel + lru_list_install_kernel"
+                clock = "dispatch begin / end of the one launch (the clock rocprofv3 reads)" \
+                    if fused else "stream events around the two launches"
+            else:
+                # queue form: no O(capacity) pass — per block row id + claim + slot + mark +
+                # appended entry + qpos (28 B), plus the installed rows
+                lru_bytes = 28.0 * rows + installs
+                kernel = "lru_list_scan_kernel + lru_queue_walk_kernel + lru_queue_install_kernel" + \
+                    ("" if all(forms) else " (+ lru_list_fused_kernel of the list-form cache)")
+                clock = "stream events around the update's launches"
             lru_us = 1e3 * l_ms.value / l_n.value
             out["roofline_lru"] = {
-                "bound": "hbm", "kernel": "lru_list_fused_kernel", "unit": "GB/s",
+                "bound": "hbm", "kernel": kernel, "unit": "GB/s",
                 "algorithmic_bytes_per_launch": lru_bytes, "avg_launch_us": lru_us,
                 "achieved": lru_bytes / (lru_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                 "frac": lru_bytes / (lru_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "launches_timed": int(l_n.value),
-                "note": "stream events around the update's launch(es); latency chain of ~7 "
-                        "dependent hops, see DESIGN 3.4"}
+                "launches_timed": int(l_n.value), "clock": clock,
+                "note": "latency chain of ~7 dependent hops, not a bandwidth kernel: see DESIGN 3.4"}
 
     if main_kind == "hash":
         out["config"]["exchange"] = exchange_note(sampler, world, backend)

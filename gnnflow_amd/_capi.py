@@ -207,6 +207,8 @@ PROTOTYPES = {
     "gf_sampler_part_merge": (C.c_int, [_p, C.c_uint32, C.c_uint32, _p, _sz]),
     "gf_sampler_part_layout_slotted": (C.c_int, [_p, _sz, C.c_uint32, C.c_int, C.c_double, _sz,
                                                  C.POINTER(GfPartLayout)]),
+    "gf_sampler_part_group_slot": (C.c_int, [_p, _sz, C.c_uint32, C.c_int, C.c_double, _sz, C.c_int,
+                                             C.c_double, C.POINTER(C.c_uint64)]),
     "gf_sampler_part_begin_slotted": (C.c_int, [_p, _p, _p, _sz, _p, _sz, C.c_int, C.c_int,
                                                 C.c_double, _sz, _p]),
     "gf_sampler_part_serve": (C.c_int, [_p, C.c_uint32, C.c_uint32, _p, _sz]),

@@ -94,6 +94,7 @@ void set_last_error(const std::string& msg) { g_last_error = msg; }
 bool profile_enabled() { return g_prof_mask.load(std::memory_order_relaxed) != 0; }
 
 ProfileScope::ProfileScope(int slot_, hipStream_t stream_) : slot(slot_), stream(stream_) {
+  if (slot < 0) return;   // (the caller times the launch itself)
   if (!(g_prof_mask.load(std::memory_order_relaxed) & (1u << slot))) return;
   if (g_prof_seq[slot].fetch_add(1, std::memory_order_relaxed) %
           g_prof_stride.load(std::memory_order_relaxed) != 0) return;
@@ -835,6 +836,25 @@ int gf_sampler_part_layout_slotted(const gf_sampler* s, size_t num_roots, uint32
     GF_REQUIRE(world_size >= 1 && world_size <= 64, "partition: world size must be 1..64");
     GF_REQUIRE(slack > 0.0, "part_layout_slotted: slack must be positive");
     s->impl.part_layout(std::max<size_t>(num_roots, 1), layer, world_size, slack, slot_roots, out);
+  });
+}
+int gf_sampler_part_group_slot(const gf_sampler* s, size_t num_roots, uint32_t layer,
+                               int world_size, double slack, size_t slot_roots, int narrow,
+                               double edge_fill, uint64_t* out) {
+  return guarded([&] {
+    GF_REQUIRE(s != nullptr, "null sampler handle");
+    GF_REQUIRE(out != nullptr, "part_group_slot: null output");
+    GF_REQUIRE(world_size >= 1 && world_size <= 64, "partition: world size must be 1..64");
+    GF_REQUIRE(slack > 0.0, "part_group_slot: slack must be positive");
+    GF_REQUIRE(layer < s->impl.num_layers(), "layer out of range");
+    gf::Sampler::GroupLayout lay;
+    const size_t R[1] = {std::max<size_t>(num_roots, 1)};
+    s->impl.group_layout(R, 1, layer, world_size, slack, slot_roots, narrow != 0, edge_fill, &lay);
+    const size_t rb = narrow ? 12 : 24;
+    out[0] = lay.stride;
+    out[1] = edge_fill > 0.0 ? lay.cslot : lay.stride * s->impl.fanout(layer) * rb;
+    out[2] = lay.edge_cap;
+    out[3] = lay.off_bytes;
   });
 }
 int gf_sampler_part_begin(gf_sampler* s, const int64_t* d_roots, const float* d_root_ts,

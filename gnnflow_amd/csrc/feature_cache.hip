@@ -67,6 +67,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cstdio>
 #include <chrono>
 #include <climits>
@@ -1921,7 +1922,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
 //                              row granules) and the hits before it (count granules), writes
 //                              the permuted list into the other buffer and qpos[]; the first
 //                              one flips the parity.
-// A poll that has not seen its granule after kFuseSpins tries stops waiting and computes the
+// A poll that has not seen its granule after g_fuse_spins (4 096) tries stops waiting and computes the
 // value itself from the kernel's immutable inputs (marks, list, claims), so termination does
 // not depend on dispatch order (several such launches of different processes sharing the
 // GPU can fill an XCD with waiters: DESIGN 6.1).  The one input that is NOT immutable is the
@@ -1931,7 +1932,10 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
 constexpr uint32_t kFuseTile = kWide;         // list entries per count / write tile
 constexpr uint32_t kFuseMaxTiles = 2048;      // list tiles (LDS prefix arrays): <= 2 M slots
 constexpr uint32_t kFuseMaxRowWgs = 1024;     // row workgroups: <= 1 M block rows
-constexpr uint32_t kFuseSpins = 1u << 12;
+constexpr uint32_t kFuseSpinsDefault = 1u << 12;
+// (a device word so that a test can force every wait into its recount path:
+// GNNFLOW_LRU_FUSE_SPINS, read when the library loads its first cache)
+__device__ uint32_t g_fuse_spins = kFuseSpinsDefault;
 constexpr int32_t kRepMark = -3;              // slot_of_row[]: representative of a missed id
 __device__ unsigned int g_lru_recounts;       // granules a waiter had to recompute itself
 
@@ -1950,7 +1954,8 @@ __device__ inline void fuse_poll3(const unsigned long long* g0, const unsigned l
     out[k] = need[k] ? ~0u : 0u;
     any |= need[k];
   }
-  for (uint32_t spins = 0; any && spins < kFuseSpins; ++spins) {
+  const uint32_t budget = g_fuse_spins;
+  for (uint32_t spins = 0; any && spins < budget; ++spins) {
     unsigned long long x[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) x[k] = need[k] ? __hip_atomic_load(g[k], GF_RLX_AGENT) : 0ull;
@@ -2112,7 +2117,13 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
     const uint32_t par = fuse_parity(c);
     if (total_miss(c.ctr) == 0) return;   // uniform
     const bool fm = sr == -1 && c.map[id] == -static_cast<int32_t>(i + 1);
-    if (fm) __hip_atomic_store(&c.slot_of_row[i], kRepMark, GF_RLX_AGENT);
+    if (fm) {
+      // write-through and DRAINED before this workgroup stores anything else: a recount by
+      // another workgroup reads the claim first, the mark second, and must find the mark once
+      // the install below has overwritten the claim
+      __hip_atomic_store(&c.slot_of_row[i], kRepMark, GF_RLX_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     uint32_t cnt;
     const uint32_t rank = wide_excl_scan(fm ? 1u : 0u, ws, &cnt);
     if (tid == 0) {
@@ -2622,7 +2633,12 @@ void launch_round(Round& r, hipStream_t stream) {
     GF_HIP(hipGetLastError());
   }
   if (!any_update) return;
-  ProfileScope ps(kProfLru, stream);
+  // the LRU slot of the profile: ONE fused launch carries its own dispatch events (the clock
+  // rocprofv3 reads: begin / end of the dispatch); several launches sit between two stream events
+  bool only_fused = true;
+  for (int i = 0; i < r.count; ++i)
+    only_fused = only_fused && (!r.c[i].update || (r.c[i].policy == GF_CACHE_LRU && r.c[i].fused));
+  ProfileScope ps(only_fused ? -1 : kProfLru, stream);
   size_t q_scan_blocks = 0, q_rows = 0, q_cap = 0, q_bit_tiles = 0, q_victim_blocks = 1;
   size_t q_inst_blocks = 0, qq_rows = 0;
   size_t h_n = 0, h_cap = 0, h_tiles = 0;
@@ -2664,8 +2680,15 @@ void launch_round(Round& r, hipStream_t stream) {
     // GDELT-scale edge cache — runs this launch on a side stream, beside those launches: the
     // contexts are different caches, and both chains are bound by dependent accesses, not by CUs
     forked = q_rows != 0 && fork_round(stream, &side);
-    lru_list_fused_kernel<<<dim3(cb + rb + wb, r.count), dim3(kWide), 0, forked ? side : stream>>>(
-        r, cb, rb, wb);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (only_fused && profile_begin(kProfLru, &e0, &e1)) {
+      hipExtLaunchKernelGGL(lru_list_fused_kernel, dim3(cb + rb + wb, r.count), dim3(kWide), 0, stream,
+                            e0, e1, 0, r, cb, rb, wb);
+      profile_end(kProfLru, e0, e1);
+    } else {
+      lru_list_fused_kernel<<<dim3(cb + rb + wb, r.count), dim3(kWide), 0, forked ? side : stream>>>(
+          r, cb, rb, wb);
+    }
     GF_HIP(hipGetLastError());
     if (forked) fork_done();
   }
@@ -2768,6 +2791,20 @@ FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const fl
   GF_REQUIRE(capacity <= num_ids, "cache: capacity larger than the id space");
   GF_REQUIRE(capacity < 0x7FFFFFFFull, "cache: capacity must be < 2^31");
   DeviceGuard dg(device_);
+  {
+    // GNNFLOW_LRU_FUSE_SPINS (tests): the polls' budget before a waiter recomputes the value
+    // itself — 0 sends EVERY look-back of the one-launch LRU update through its fallback
+    static std::mutex mu;
+    static std::vector<int> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (std::find(done.begin(), done.end(), device_) == done.end()) {
+      done.push_back(device_);
+      if (const char* v = std::getenv("GNNFLOW_LRU_FUSE_SPINS")) {
+        const uint32_t spins = static_cast<uint32_t>(std::atoll(v));
+        GF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fuse_spins), &spins, sizeof(spins)));
+      }
+    }
+  }
   table_on_device_ = pointer_on_device(d_feats);
   buffer_.reserve(std::max<size_t>(capacity * dim * sizeof(float), 16), 0, nullptr, true);
   map_.reserve(std::max<size_t>(num_ids * sizeof(int32_t), 16));

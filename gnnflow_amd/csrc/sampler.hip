@@ -1417,8 +1417,10 @@ struct CompactArgs {
   const void* served;
   const uint32_t* row_cnt;
   char* cserved;
-  uint32_t* ticket;          // [m], zero between launches
-  uint32_t stride, fanout, m, world, edge_cap, cslot, narrow, off_bytes;
+  // [m] {launch tag, overflow count << 16 | slots done}: a word that carries another launch's tag
+  // (a chain abandoned half-way, whatever the reason) starts over — nothing relies on a reset
+  unsigned long long* ticket;
+  uint32_t stride, fanout, m, world, edge_cap, cslot, narrow, off_bytes, tag;
 };
 constexpr int kCompactThreads = 1024;
 __global__ __launch_bounds__(kCompactThreads) void reply_compact_kernel(CompactArgs a) {
@@ -1473,12 +1475,19 @@ __global__ __launch_bounds__(kCompactThreads) void reply_compact_kernel(CompactA
     const uint32_t total = carry;
     put(base, 0, total);
     const uint32_t j = sl % a.m, ovf = total > a.edge_cap ? 1u : 0u;
-    const uint32_t prev = atomicAdd(&a.ticket[j], 1u + (ovf << 16));
+    const unsigned long long fresh = static_cast<unsigned long long>(a.tag) << 32;
+    unsigned long long old = __hip_atomic_load(&a.ticket[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t prev;
+    for (;;) {
+      const unsigned long long cur = static_cast<uint32_t>(old >> 32) == a.tag ? old : fresh;
+      const unsigned long long seen = atomicCAS(&a.ticket[j], old, cur + 1u + (ovf << 16));
+      if (seen == old) { prev = static_cast<uint32_t>(cur); break; }
+      old = seen;
+    }
     if ((prev & 0xFFFFu) == a.world - 1) {       // the last of this sample's `world` slots
       const uint32_t any = ((prev >> 16) + ovf) ? 1u : 0u;
       for (uint32_t q = 0; q < a.world; ++q)
         put(a.cserved + static_cast<uint64_t>(q * a.m + j) * a.cslot, stride, any);
-      a.ticket[j] = 0;
     }
   }
 }
@@ -2802,17 +2811,18 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
       lap(3);
       // 4. the replies back: the sampled edges packed per slot (compact), or the fixed slots
       if (compact) {
-        if (!a.part_ticket_.data()) {   // zero once: its last user of a launch clears it again
+        if (!a.part_ticket_.data()) {
           a.part_ticket_.reserve(256);
           GF_HIP(hipMemsetAsync(a.part_ticket_.data(), 0, 256, stream));
         }
+        if (++a.part_tag_ == 0) ++a.part_tag_;   // (a zeroed ticket must never look current)
         reply_compact_kernel<<<dim3(static_cast<unsigned>(m * P)), dim3(kCompactThreads), 0, stream>>>(
             CompactArgs{reinterpret_cast<const int64_t*>(base + lay.inbox), base + lay.served,
                         reinterpret_cast<const uint32_t*>(base + lay.row_cnt), base + lay.cserved,
-                        a.part_ticket_.as<uint32_t>(), stride, F,
+                        a.part_ticket_.as<unsigned long long>(), stride, F,
                         static_cast<uint32_t>(m), static_cast<uint32_t>(P),
                         static_cast<uint32_t>(lay.edge_cap), static_cast<uint32_t>(lay.cslot),
-                        narrow ? 1u : 0u, static_cast<uint32_t>(lay.off_bytes)});
+                        narrow ? 1u : 0u, static_cast<uint32_t>(lay.off_bytes), a.part_tag_});
         GF_HIP(hipGetLastError());
         ex->all_to_all(base + lay.cserved, base + lay.creplies, static_cast<size_t>(m) * lay.cslot, stream);
       } else if (ex) {

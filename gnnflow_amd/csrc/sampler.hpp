@@ -19,6 +19,7 @@ class Sampler {
   ~Sampler();
 
   size_t num_layers() const { return fanouts_.size(); }
+  uint32_t fanout(size_t layer) const { return fanouts_[layer]; }
   uint32_t num_snapshots() const { return num_snapshots_; }
   int device() const { return graph_->device(); }
 
@@ -141,6 +142,7 @@ class Sampler {
   bool prop_time_;
   uint64_t seed_;
   DeviceBuffer part_ticket_;   // reply_compact_kernel: "last slot of the sample" tickets
+  uint32_t part_tag_ = 0;      // ... tagged per launch
   uint64_t calls_ = 0;  // sample_layer invocations so far (uniform RNG counter)
  public:
   uint64_t call_counter() const { return calls_; }

@@ -743,25 +743,21 @@ class DevicePartitionedSampler:
         included) and the reply slots (fanout records of 12 / 24 B per row) of every layer and
         snapshot — fixed by the slot capacity, whatever the slots really hold."""
         R0 = int(R0 or max(self._slot_roots, 1))
-        lays = self._plan(R0, self._slack)[0] if self._slack > 0 else []
         rec = 12 if self._narrow else 24
         fill = self._edge_fill if self.chain_samples > 1 else 0.0
         req = rep = fixed = 0
-
-        def up16(x):
-            return (x + 15) & ~15
-        L = len(self._fanouts)
         per_layer = []
-        for l, (lay, F) in enumerate(zip(lays, self._fanouts)):
-            stride = int(lay.slot_stride)
+        C = self._C
+        out = (C.c_uint64 * 4)()
+        for layer, F in enumerate(self._fanouts if self._slack > 0 else []):
+            # the native layout itself (sampler.hip group_layout), not a restatement of it
+            self._capi.check(self._lib.gf_sampler_part_group_slot(
+                self._sampler._h, R0, layer, self._P, self._slack, self._slot_roots,
+                1 if self._narrow else 0, fill, out))
+            stride = int(out[0])
             rq = stride * self._S * 16
+            rp = self._S * int(out[1])
             fixed += stride * self._S * F * rec
-            if fill > 0:      # sampler.hip group_layout: offsets + packed edges
-                f = fill ** (l / (L - 1)) if L > 1 else 1.0
-                cap = max(int(np.ceil(f * (stride - 1) * F)), F)
-                rp = self._S * (up16((2 if cap < 65535 else 4) * (stride + 1)) + up16(cap * rec))
-            else:
-                rp = stride * self._S * F * rec
             req += rq
             rep += rp
             per_layer.append({"request_bytes_to_each_peer": rq, "reply_bytes_to_each_peer": rp})

@@ -522,6 +522,15 @@ GF_API int gf_sampler_part_abort(gf_sampler* s);
 GF_API int gf_sampler_part_layout_slotted(const gf_sampler* s, size_t num_roots, uint32_t layer,
                                           int world_size, double slack, size_t slot_roots,
                                           gf_part_layout* out);
+/* What one slot of a shared chain's exchanges takes on the wire for `layer` (the layout the
+ * native chains use, sampler.hip group_layout): out[0] = rows per request slot (16 B each, header
+ * row included), out[1] = bytes of one reply slot (compact: offsets + packed edges; edge_fill 0:
+ * the fixed records), out[2] = edges a compact reply slot holds at most, out[3] = bytes of its
+ * offsets (2 / 4).  gnnflow_amd.dist.DevicePartitionedSampler.wire_bytes_per_sample reports from
+ * this, so the figures in bench.py's line are the native layout's, not a restatement. */
+GF_API int gf_sampler_part_group_slot(const gf_sampler* s, size_t num_roots, uint32_t layer,
+                                      int world_size, double slack, size_t slot_roots, int narrow,
+                                      double edge_fill, uint64_t* out);
 GF_API int gf_sampler_part_begin_slotted(gf_sampler* s, const int64_t* d_roots,
                                          const float* d_root_ts, size_t num_roots, void* d_out,
                                          size_t out_bytes, int world_size, int rank, double slack,

@@ -1,7 +1,7 @@
 """How the CPU oracle baseline of bench.py behaves on this box: one chronological pass of the
 REDDIT-shaped replay per thread count (diagnostic; prints edges/s and ms per step)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gnnflow_amd import synthetic
 from oracle import oracle as O

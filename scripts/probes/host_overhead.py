@@ -1,6 +1,6 @@
 """Where does the host time of one step go?  (diagnostic, not part of the bench)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import gnnflow_amd
 from gnnflow_amd import _capi, synthetic

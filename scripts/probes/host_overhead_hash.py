@@ -3,7 +3,7 @@
 step (waiting for the sample, sample_async, record_stream, fetch_feature) and the enqueue
 threads' busy time.  Diagnostic for DESIGN 6 (lanes)."""
 import argparse, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.distributed as dist
 import gnnflow_amd

@@ -1,6 +1,6 @@
 """Host-time breakdown of the pipelined bench loop (diagnostic)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import gnnflow_amd
 from gnnflow_amd import _capi, synthetic

@@ -82,6 +82,29 @@ def test_ladder_kills_a_worker_that_neither_finishes_nor_gives_up():
     assert 3 <= h["seconds"] < 30
 
 
+def test_ladder_ranks_leave_a_rung_together_when_only_one_worker_dies():
+    """Rank 1's rung-0 worker dies at once, rank 0's hangs until the supervisor kills it (3 s):
+    rank 1 must WAIT for rank 0 to leave rung 0 instead of racing ahead to rung 1 on the next
+    port — where its worker would wait alone, be killed before rank 0 arrives, and leave the ranks
+    on different rungs for good.  Both then meet in rung 1, which works."""
+    rc, d, err = _acted("hang,ok,ok,ok", {"GNNFLOW_BENCH_FAKE_WORKER_RANK1": "die,ok,ok,ok",
+                                          "GNNFLOW_HASH_MAIN_TIMEOUT": "2",
+                                          "GNNFLOW_RUNG_SETUP_ALLOWANCE": "1"})
+    assert rc == 0 and d["ladder"]["rung"] == 1
+    (h,) = d["ladder"]["tried_before"]            # rank 0's view: its worker was killed ...
+    assert h["worker_killed"] is True and h["ranks_left_together"] == 2
+    # ... and rank 1, whose worker was gone within a second, started rung 1 only after ~3 s
+    import re
+    m = re.search(r"rank 1: rung 0 \(hash\) is over after (\d+) s", err)
+    assert m and int(m.group(1)) >= 2, err[-1500:]
+    # the other way round (rank 0 dies, rank 1 hangs): the line still comes from rung 1
+    rc, d, _ = _acted("die,ok,ok,ok", {"GNNFLOW_BENCH_FAKE_WORKER_RANK1": "hang,ok,ok,ok",
+                                       "GNNFLOW_HASH_MAIN_TIMEOUT": "2",
+                                       "GNNFLOW_RUNG_SETUP_ALLOWANCE": "1"})
+    assert rc == 0 and d["ladder"]["rung"] == 1
+    assert d["ladder"]["tried_before"][0]["ranks_left_together"] == 2
+
+
 def test_ladder_ports_differ_per_rung_and_a_dying_last_rung_fails_the_run():
     rc0, d0, _ = _acted("ok,ok,ok,ok", {"MASTER_PORT": "29900"})
     rc1, d1, _ = _acted("die,ok,ok,ok", {"MASTER_PORT": "29900"})

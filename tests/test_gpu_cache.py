@@ -580,3 +580,4 @@ def test_queue_form_bitmap_spanning_several_tiles_and_groups(monkeypatch):
         _fetch_both(hip, ora, ef, ids, step)
     st = hip._edge.lru_state()
     assert st["queue_form"] == 1 and st["tail"] > 2 * 131072 and st["list_form_updates"] == 0
+

@@ -393,3 +393,23 @@ def test_uniform_sampling_on_two_lanes_reproduces_the_one_samplers_draws(fanouts
         for a, b in zip(hm, om):
             for hb, ob in zip(a, b):
                 assert np.array_equal(hb.edata["ID"].cpu().numpy(), ob.edata["ID"])
+
+
+def test_fused_lru_update_fallback_paths():
+    """The one-launch list update never waits for ever: a look-back that has not seen its granule
+    recomputes the value from the launch's inputs.  With the polls' budget forced to 0
+    (GNNFLOW_LRU_FUSE_SPINS, read when a process creates its first cache — hence a child process)
+    EVERY wait takes that path; rows, hit counts and cached-id sets must still equal the oracle's
+    at every step, and the recount counter must show that the path ran."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GNNFLOW_LRU_FUSE_SPINS="0")
+    for k in ("GNNFLOW_LRU_FUSED", "GNNFLOW_LRU_QUEUE_MIN_CAPACITY"):   # (this module's arrangements)
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "lru_fallback_child.py")],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    last = [l for l in p.stdout.splitlines() if l.startswith("recounts")][-1]
+    assert int(last.split()[1]) > 100, last
