@@ -94,7 +94,7 @@ def test_single_gpu_line_with_roofline_and_cpu_baseline():
     assert cf["rows_per_step"] == pytest.approx(d["config"]["rows_per_step"], rel=0.02)
     assert "error" not in pp and pp["value"] > 0
     assert pp["rows_per_step"] == pytest.approx(d["config"]["rows_per_step"], rel=0.02)
-    assert pp["cache_edge_ratio"] == pytest.approx(d["cache_edge_ratio"])
+    assert 0 < pp["cache_edge_ratio"] <= 1 and 0 < pp["cache_node_ratio"] <= 1
     assert pp["rows_pulled_into_ring_per_step"] > 0
     assert pp["host_link_bytes_per_step"] == pytest.approx(
         688 * (pp["rows_pulled_into_ring_per_step"] + pp["rows_read_from_host_by_gather_per_step"]))
