@@ -1223,10 +1223,20 @@ def placement_legs(ctx, out, sampler, node_feats, edge_feats):
         cache = LRUCache(args.cache_ratio, args.cache_ratio, g["num_nodes"], g["num_edges"], dev,
                          node_feats.cpu(), edge_feats.cpu(), d_n, d_e, feature_placement="pinned")
         cache.init_cache()
-        res = time_leg(ctx, sampler, cache, False, secs, 1.0, probe=cache.staging_state)
+        import ctypes as C
+
+        def probe():
+            busy, jobs = C.c_double(0), C.c_uint64(0)
+            ctx.lib.gf_worker_stats(C.byref(busy), C.byref(jobs))
+            st = cache.staging_state()
+            st["_worker"] = (busy.value, jobs.value)
+            return st
+        res = time_leg(ctx, sampler, cache, False, secs, 1.0, probe=probe)
         rec = line(res)
         steps = max(res["timed_steps"], 1)
         s0, s1 = res["probe0"], res["probe1"]
+        w0, w1 = s0.pop("_worker"), s1.pop("_worker")
+        rec["enqueue_threads_busy_us_per_step"] = (w1[0] - w0[0]) / steps
         pulled = sum(s1[k]["rows_pulled"] - s0[k]["rows_pulled"] for k in s1) / steps
         host = sum(s1[k]["rows_read_from_host"] - s0[k]["rows_read_from_host"] for k in s1) / steps
         nbytes = (pulled + host) * 4.0 * d_e
@@ -1243,6 +1253,8 @@ def placement_legs(ctx, out, sampler, node_feats, edge_feats):
             "host_link_bytes_per_step": nbytes,
             "host_link_GBps_over_the_step": nbytes / (rec["ms_per_step"] * 1e-3) / 1e9,
             "generations_dropped": sum(s1[k]["dropped"] - s0[k]["dropped"] for k in s1),
+            "issue_wait_us_per_step": sum(s1[k]["issue_wait_us"] - s0[k]["issue_wait_us"]
+                                          for k in s1) / steps,
             "cache_edge_ratio": float(cache.cache_edge_ratio),
             "cache_node_ratio": float(cache.cache_node_ratio)})
         # what the link gives a plain copy on this box

@@ -163,7 +163,7 @@ class Cache:
         self.feature_placement = placement
         # Staging ring of a host-resident table (feature_placement="pinned"; include/gnnflow_hip.h
         # gf_cache_set_staging): prefetch_feature() pulls the rows a coming fetch_feature() will
-        # miss into HBM on a side stream.  `staging`: None = GNNFLOW_STAGING or "auto" (32
+        # miss into HBM on a side stream.  `staging`: None = GNNFLOW_STAGING or "auto" (64
         # generations, rows per generation sized from the blocks prefetched), 0 / False = off,
         # (generations, rows_per_generation) = fixed.
         if staging is None:
@@ -184,6 +184,7 @@ class Cache:
         self._staging = staging          # None | 'auto' | (generations, rows; 0 rows: auto)
         self._staging_rows = 0           # rows per generation the native rings were set up with
         self._prefetch_stream = None
+        self._prefetch_handle = None
         # serve an edge block that is a prefix of the previously fetched one from that
         # block's rows (LRU only; fetch_feature); GNNFLOW_PREFIX_ALIAS=0 turns it off
         self.prefix_alias = os.environ.get('GNNFLOW_PREFIX_ALIAS', '1') != '0'
@@ -363,7 +364,7 @@ class Cache:
 
     def fetch_feature(self, mfgs: List[List], eid: Optional[np.ndarray] = None,
                       update_cache: bool = True, target_edge_features: bool = True,
-                      async_enqueue: bool = False):
+                      async_enqueue: bool = False, announce=None):
         """Fetching the node/edge features of input_node_ids (cache.py:255-413):
         node features for the blocks of mfgs[0] -> srcdata['h'], edge features for every
         block -> edata['f'], target edge features for TGN memory.  One native call
@@ -373,7 +374,11 @@ class Cache:
         async_enqueue=True returns as soon as the work has been handed to the library's
         enqueue thread; `b.srcdata['h']` / `b.edata['f']` / `target_edge_features` then wait
         for the enqueue on first access (blocks built by gnnflow_amd.TemporalSampler), or
-        call wait_enqueued()."""
+        call wait_enqueued().
+
+        announce=(next_mfgs, next_eid, next_eid_range): with async_enqueue, the NEXT batch's
+        prefetch_feature() rides in the same submission (one hand-over to the enqueue thread
+        per pipelined step instead of two)."""
         # at most _MAX_QUEUED submissions with the enqueue thread: when that thread also issues
         # the partitioned sampler's chains (tens of microseconds each, up to four batches' worth
         # in one job), the previous fetches may still be queued behind one, and waiting for them
@@ -387,11 +392,50 @@ class Cache:
         dev = self.device
         jobs, n_node, n_cached, aliases = self._jobs(mfgs, eid, upd, target_edge_features)
         if not jobs:
+            if announce is not None:
+                self.prefetch_feature(announce[0], announce[1], update_cache, target_edge_features,
+                                      async_enqueue=async_enqueue, eid_range=announce[2])
             return mfgs
+        ann = None
+        if announce is not None and self._staging is not None:
+            if async_enqueue:
+                ann = self._announce_descs(announce, upd, target_edge_features)
+            else:
+                self.prefetch_feature(announce[0], announce[1], update_cache, target_edge_features,
+                                      eid_range=announce[2])
         if _current_device() != dev.index:
             with torch.cuda.device(dev):
-                return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
-        return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases)
+                return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases, ann)
+        return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases, ann)
+
+    def _announce_descs(self, announce, upd, target_edge_features):
+        """Descriptors of the next batch's prefetch for a combined submission:
+        (descriptor buffer, its reference, count, first target id, target count, stream handle,
+        keepalive) or None."""
+        mfgs, eid, eid_range = announce
+        t_first = t_n = 0
+        if eid_range is not None and self._edge is not None and target_edge_features:
+            t_first, t_n = int(eid_range[0]), int(eid_range[1])
+            eid = None
+        jobs = self._jobs(mfgs, eid, upd, target_edge_features)[0]
+        if not jobs and not t_n:
+            return None
+        self._ensure_staging(sum(job[2] for job in jobs) + t_n)
+        st = self._prefetch_handle
+        if st is None:
+            from ..pipeline import side_stream
+            self._prefetch_stream = side_stream(self.device, 3)
+            st = self._prefetch_handle = C.c_void_p(self._prefetch_stream.cuda_stream)
+        stream = self._prefetch_stream
+        for mfg in mfgs:
+            for b in mfg:
+                if hasattr(b, "record_stream"):
+                    b.record_stream(stream)
+        descs, cdescs, cdescs_ref = self._desc_buf(len(jobs))
+        pack = _DESC.pack_into
+        for i, job in enumerate(jobs):
+            pack(descs, i * _DESC.size, job[0], upd, job[1] or 0, job[2], 0, 0)
+        return descs, cdescs_ref, len(jobs), t_first, t_n, st, (jobs, cdescs, mfgs)
 
     def _jobs(self, mfgs, eid, upd, target_edge_features):
         """The block gathers of one fetch_feature() call: (jobs, #node jobs, #jobs through a
@@ -450,10 +494,12 @@ class Cache:
 
     def _ensure_staging(self, rows: int):
         """Sets the native rings up (or enlarges them: a synchronising call) so that a
-        generation holds a sixteenth of the rows of the round being prefetched."""
+        generation holds 1/32 of the rows of the round being prefetched (64 generations: the ring
+        takes twice the rows of one round's blocks — the reference's pinned staging buffers,
+        utils.py get_pinned_buffers, take once that)."""
         st = self._staging
-        gens, fixed = (32, 0) if st == 'auto' else (int(st[0]), int(st[1]))
-        want = fixed or (1 << max(int(max(rows, 1) // 16 - 1).bit_length(), 10))
+        gens, fixed = (64, 0) if st == 'auto' else (int(st[0]), int(st[1]))
+        want = fixed or (1 << max(int(max(rows, 1) // 32 - 1).bit_length(), 10))
         if want <= self._staging_rows:
             return
         self.wait_enqueued()
@@ -465,22 +511,29 @@ class Cache:
     def prefetch_feature(self, mfgs: List[List], eid: Optional[np.ndarray] = None,
                          update_cache: bool = True, target_edge_features: bool = True,
                          stream: Optional[torch.cuda.Stream] = None,
-                         async_enqueue: bool = False) -> bool:
+                         async_enqueue: bool = False, eid_range=None) -> bool:
         """Announces a coming `fetch_feature(mfgs, eid, ...)` (same arguments): with the tables
         in pinned host memory, the rows of the ids that are neither cached nor staged yet are
         pulled into the staging ring in HBM on `stream` (default: a side stream of this cache),
         beside whatever the fetch stream is doing; the fetch then waits for the pull on its own
         stream and reads those rows from HBM.  The reference does the host -> pinned -> device
         trip inside fetch_feature (cache.py:288-313,381-388).  A hint: results, hit ratios and
-        the cache's contents do not depend on it.  Returns False if there is nothing to do."""
+        the cache's contents do not depend on it.  Returns False if there is nothing to do.
+        eid_range=(first, count): `eid` is the consecutive ids first .. first + count - 1 — a
+        chronological batch's own edges (gnnflow/utils.py get_batch slices the edge list) — so
+        their rows are one contiguous piece of the table and are staged by ONE DMA copy."""
         if self._staging is None:
             return False
         upd = 1 if update_cache else 0
+        t_first = t_n = 0
+        if eid_range is not None and self._edge is not None and target_edge_features:
+            t_first, t_n = int(eid_range[0]), int(eid_range[1])
+            eid = None
         jobs, _n_node, _n_cached, _aliases = self._jobs(mfgs, eid, upd, target_edge_features)
-        if not jobs:
+        if not jobs and not t_n:
             return False
         dev = self.device
-        self._ensure_staging(sum(job[2] for job in jobs))
+        self._ensure_staging(sum(job[2] for job in jobs) + t_n)
         if stream is None:
             stream = self._prefetch_stream
             if stream is None:
@@ -505,12 +558,12 @@ class Cache:
                     self.wait_enqueued(q[0][0])
                 t = C.c_uint64(0)
                 _capi.check(self._lib.gf_cache_prefetch_blocks_async(
-                    node_h, edge_h, cdescs_ref, nj, st, C.byref(t)))
+                    node_h, edge_h, cdescs_ref, nj, t_first, t_n, st, C.byref(t)))
                 q.append((t.value, (jobs, descs, cdescs, mfgs)))
                 return True
             issued = C.c_int(0)
             _capi.check(self._lib.gf_cache_prefetch_blocks(
-                node_h, edge_h, cdescs_ref, nj, st, C.byref(issued)))
+                node_h, edge_h, cdescs_ref, nj, t_first, t_n, st, C.byref(issued)))
             return bool(issued.value)
 
     def staging_state(self) -> dict:
@@ -520,11 +573,11 @@ class Cache:
         self.wait_enqueued()
         out = {}
         keys = ("generations", "rows_per_generation", "issued", "dropped", "rows_pulled",
-                "ring_bytes", "rows_read_from_host")
+                "ring_bytes", "rows_read_from_host", "issue_wait_us")
         for name, k in (("node", self._node), ("edge", self._edge)):
             if k is None:
                 continue
-            v = (C.c_uint64 * 7)()
+            v = (C.c_uint64 * 8)()
             _capi.check(self._lib.gf_cache_staging_state(k.h, v))
             out[name] = dict(zip(keys, (int(x) for x in v)))
         return out
@@ -911,7 +964,7 @@ class Cache:
         t = self._ids((b.srcdata if which == "src" else b.edata)['ID'])
         return t.data_ptr(), int(t.shape[0]), t
 
-    def _submit(self, mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases=()):
+    def _submit(self, mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases=(), ann=None):
         # one output allocation for the whole call; every block's rows start 16-byte aligned
         offs, total, alg, moved = [], 0, 0, 0
         for job in jobs:
@@ -961,14 +1014,19 @@ class Cache:
                 t = C.c_uint64(0)
                 word = self._ticket_word = (t, C.byref(t))
             ticket = word[0]
-            rc = self._lib.gf_cache_fetch_blocks_async(
-                node_h, edge_h, cdescs_ref, nj, self._stream(), word[1])
+            if ann is not None:
+                rc = self._lib.gf_cache_fetch_announce_async(
+                    node_h, edge_h, cdescs_ref, nj, self._stream(), ann[1], ann[2], ann[3], ann[4],
+                    ann[5], word[1])
+            else:
+                rc = self._lib.gf_cache_fetch_blocks_async(
+                    node_h, edge_h, cdescs_ref, nj, self._stream(), word[1])
             if rc:
                 _capi.check(rc)
             box[0] = ticket.value
             # ids / outputs / descriptors must outlive the enqueue
             self._tickets.append((ticket.value, (jobs, descs, cdescs, mfgs, out_all,
-                                                 self._stats_ring)))
+                                                 self._stats_ring, ann)))
         else:
             _capi.check(self._lib.gf_cache_fetch_blocks(
                 node_h, edge_h, cdescs_ref, nj, self._stream()))

@@ -696,17 +696,18 @@ int gf_cache_staging_state(gf_cache* c, uint64_t* out) {
   });
 }
 int gf_cache_prefetch_blocks(gf_cache* node_cache, gf_cache* edge_cache,
-                             const gf_fetch_desc* descs, size_t n, void* stream, int* issued) {
+                             const gf_fetch_desc* descs, size_t n, int64_t target_first,
+                             size_t target_n, void* stream, int* issued) {
   return guarded([&] {
     const bool did = gf::prefetch_blocks(node_cache ? &node_cache->impl : nullptr,
                                          edge_cache ? &edge_cache->impl : nullptr, descs, n,
-                                         static_cast<hipStream_t>(stream));
+                                         target_first, target_n, static_cast<hipStream_t>(stream));
     if (issued) *issued = did ? 1 : 0;
   });
 }
 int gf_cache_prefetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
-                                   const gf_fetch_desc* descs, size_t n, void* stream,
-                                   uint64_t* ticket) {
+                                   const gf_fetch_desc* descs, size_t n, int64_t target_first,
+                                   size_t target_n, void* stream, uint64_t* ticket) {
   return guarded([&] {
     GF_REQUIRE(ticket != nullptr, "prefetch_blocks_async: null ticket");
     GF_REQUIRE(descs != nullptr || n == 0, "prefetch_blocks_async: null descriptors");
@@ -714,9 +715,32 @@ int gf_cache_prefetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
     gf::FeatureCache* edge = edge_cache ? &edge_cache->impl : nullptr;
     std::vector<gf_fetch_desc> copy(descs, descs + n);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    *ticket = gf::EnqueueWorker::get().submit([node, edge, copy = std::move(copy), st]() {
-      gf::prefetch_blocks(node, edge, copy.data(), copy.size(), st);
-    });
+    *ticket = gf::EnqueueWorker::get().submit(
+        [node, edge, copy = std::move(copy), target_first, target_n, st]() {
+          gf::prefetch_blocks(node, edge, copy.data(), copy.size(), target_first, target_n, st);
+        });
+  });
+}
+int gf_cache_fetch_announce_async(gf_cache* node_cache, gf_cache* edge_cache,
+                                  const gf_fetch_desc* descs, size_t n, void* stream,
+                                  const gf_fetch_desc* next_descs, size_t next_n,
+                                  int64_t next_target_first, size_t next_target_n,
+                                  void* prefetch_stream, uint64_t* ticket) {
+  return guarded([&] {
+    GF_REQUIRE(ticket != nullptr, "fetch_announce_async: null ticket");
+    GF_REQUIRE((descs != nullptr || n == 0) && (next_descs != nullptr || next_n == 0),
+               "fetch_announce_async: null descriptors");
+    gf::FeatureCache* node = node_cache ? &node_cache->impl : nullptr;
+    gf::FeatureCache* edge = edge_cache ? &edge_cache->impl : nullptr;
+    std::vector<gf_fetch_desc> copy(descs, descs + n), next(next_descs, next_descs + next_n);
+    hipStream_t st = static_cast<hipStream_t>(stream), pst = static_cast<hipStream_t>(prefetch_stream);
+    *ticket = gf::EnqueueWorker::get().submit(
+        [node, edge, copy = std::move(copy), next = std::move(next), next_target_first,
+         next_target_n, st, pst]() {
+          gf::fetch_blocks(node, edge, copy.data(), copy.size(), st);
+          gf::prefetch_blocks(node, edge, next.data(), next.size(), next_target_first,
+                              next_target_n, pst);
+        });
   });
 }
 int gf_cache_fetch_wait(uint64_t ticket) {

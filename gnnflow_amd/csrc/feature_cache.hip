@@ -547,6 +547,25 @@ __global__ __launch_bounds__(256) void stage_claim_kernel(StageRound r) {
   }
 }
 
+// range: ids first .. first + n - 1 take rows 0 .. n - 1 of this generation's region (their table
+// rows arrive by ONE copy of the DMA engine: contiguous in the table, contiguous in the ring).
+// Unconditional — an id staged before simply points at its new row — and first in the generation:
+// the claim kernel goes on from row n.
+__global__ __launch_bounds__(256) void stage_range_kernel(unsigned long long* pmap, long long first,
+                                                          uint32_t n, uint32_t gen,
+                                                          uint32_t* region_rows, long long* region_ids,
+                                                          unsigned long long* pulled) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i == 0) {
+    *region_rows = n;
+    atomicAdd(pulled, static_cast<unsigned long long>(n));
+  }
+  if (i < n) {
+    pmap[first + i] = (static_cast<unsigned long long>(gen) << 32) | i;
+    region_ids[i] = -1;   // nothing for the pull kernel to do in this row
+  }
+}
+
 // pull: the rows the claim kernel settled, host table -> this generation's region of the ring.
 // A wave owns 8 consecutive ring rows — one contiguous run of stores — and keeps 6 16-byte loads
 // per lane in flight over the host link (PCIe round trips are ~2 us: what counts is the number of
@@ -2828,6 +2847,9 @@ FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const fl
 FeatureCache::~FeatureCache() {
   for (hipEvent_t e : stage_events_)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : copy_events_)
+    if (e) (void)hipEventDestroy(e);
+  if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
 }
 
 // ---- staging ring, host side ---------------------------------------------------------------
@@ -2860,6 +2882,10 @@ void FeatureCache::set_staging(size_t generations, size_t rows_per_generation) {
   *progress_.as<volatile uint32_t>() = 0;
   for (hipEvent_t& e : stage_events_)
     if (!e) GF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t& e : copy_events_)
+    if (!e) GF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (!copy_stream_) GF_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+  copy_wait_ = nullptr;
   GF_HIP(hipMemset(pmap_.data(), 0, pmap_.bytes()));
   GF_HIP(hipMemset(region_rows_.data(), 0, region_rows_.bytes()));
   gen_issued_ = 0;
@@ -2880,9 +2906,11 @@ void FeatureCache::invalidate_staging() {
   GF_HIP(hipMemset(region_rows_.data(), 0, 64 * sizeof(uint32_t)));
   *progress_.as<volatile uint32_t>() = stage_reads_;   // (device idle: every launch has finished)
   stage_wait_ = nullptr;
+  copy_wait_ = nullptr;
 }
 
-void FeatureCache::staging_state(uint64_t out[7]) {
+void FeatureCache::staging_state(uint64_t out[8]) {
+  out[7] = static_cast<uint64_t>(stage_spin_us_);
   out[0] = stage_gens_;
   out[1] = stage_cap_;
   out[2] = gen_issued_;
@@ -2934,6 +2962,7 @@ bool FeatureCache::stage_advance() {
         return v ? std::atol(v) : 20000L;
       }();
       bool ok = false;
+      const auto t_spin = std::chrono::steady_clock::now();
       if (stage_reads_ != need && spin_us > 0) {   // (== : no later launch exists that could report)
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t i = 0;; ++i) {
@@ -2943,6 +2972,8 @@ bool FeatureCache::stage_advance() {
               std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
         }
       }
+      stage_spin_us_ += std::chrono::duration<double, std::micro>(
+                            std::chrono::steady_clock::now() - t_spin).count();
       if (!ok) { ++stage_drops_; return false; }
     }
   }
@@ -2952,12 +2983,27 @@ bool FeatureCache::stage_advance() {
 }
 
 // the fetch stream waits for the prefetches issued so far (one wait per distinct event)
+// (an event that has completed by now — the usual case: the pull was issued two steps ago — costs
+// one query; only one that has not is handed to the stream, whose wait for another queue's signal
+// takes 12-20 us to resolve)
+static inline void stage_wait_on(hipStream_t stream, hipEvent_t ev) {
+  const hipError_t q = hipEventQuery(ev);
+  if (q == hipSuccess) return;
+  if (q != hipErrorNotReady) GF_HIP(q);
+  (void)hipGetLastError();
+  GF_HIP(hipStreamWaitEvent(stream, ev, 0));
+}
+
 void FeatureCache::stage_sync(hipStream_t stream, hipEvent_t* seen, int* num_seen) {
+  if (copy_wait_) {
+    stage_wait_on(stream, copy_wait_);
+    copy_wait_ = nullptr;
+  }
   if (!stage_wait_) return;
   bool dup = false;
   for (int i = 0; i < *num_seen; ++i) dup = dup || seen[i] == stage_wait_;
   if (!dup) {
-    GF_HIP(hipStreamWaitEvent(stream, stage_wait_, 0));
+    stage_wait_on(stream, stage_wait_);
     seen[(*num_seen)++] = stage_wait_;
   }
   stage_wait_ = nullptr;
@@ -3579,8 +3625,13 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
 // Cache.prefetch_feature: one staging generation per cache for the blocks a coming
 // fetch_blocks(descs) will gather (feature_cache.hpp)
 bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
-                     hipStream_t stream) {
+                     int64_t target_first, size_t target_n, hipStream_t stream) {
   GF_REQUIRE(descs != nullptr || n == 0, "prefetch_blocks: null descriptors");
+  if (target_n) {
+    GF_REQUIRE(edge != nullptr, "prefetch_blocks: a target range without an edge cache");
+    GF_REQUIRE(target_first >= 0 && static_cast<uint64_t>(target_first) + target_n <= edge->num_ids_,
+               "prefetch_blocks: target range outside the edge table");
+  }
   const bool node_on = node && node->staging(), edge_on = edge && edge->staging();
   if (!node_on && !edge_on) return false;
   const int device = node ? node->device() : edge->device();
@@ -3595,12 +3646,33 @@ bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc
     if (d.kind == 0) node_use = node_use || node_on;
     else edge_use = edge_use || edge_on;
   }
+  if (target_n) edge_use = edge_use || edge_on;
   if (node_use) node_use = node->stage_advance();
   if (edge_use) edge_use = edge->stage_advance();
   if (!node_use && !edge_use) return false;
+  size_t max_n = 0, node_rows = 0, edge_rows = 0;
+  if (edge_use && target_n && target_n <= edge->stage_cap_) {
+    // the batch's own edges: one contiguous piece of the table, one DMA copy (no wave of the GPU
+    // waits on the host link for them — profiles/r06_host_read_latency.txt: host reads issued by
+    // kernels stretch every latency chain running beside them)
+    const uint32_t gen = edge->gen_issued_, region = gen & (edge->stage_gens_ - 1u);
+    float* dst = edge->ring_.as<float>() + static_cast<uint64_t>(region) * edge->stage_cap_ * edge->dim_;
+    stage_range_kernel<<<dim3(static_cast<unsigned>((target_n + 255) / 256)), dim3(256), 0, stream>>>(
+        edge->pmap_.as<unsigned long long>(), target_first, static_cast<uint32_t>(target_n), gen,
+        edge->region_rows_.as<uint32_t>() + region, edge->region_ids_.as<long long>(),
+        reinterpret_cast<unsigned long long*>(edge->region_rows_.as<uint32_t>() + 64));
+    GF_HIP(hipGetLastError());
+    // (the region is free: stage_advance saw every launch that may read its old rows finish)
+    GF_HIP(hipMemcpyAsync(dst, edge->feats_ + static_cast<uint64_t>(target_first) * edge->dim_,
+                          target_n * edge->dim_ * sizeof(float), hipMemcpyHostToDevice,
+                          edge->copy_stream_));
+    hipEvent_t cev = edge->copy_events_[gen % FeatureCache::kStageEvents];
+    GF_HIP(hipEventRecord(cev, edge->copy_stream_));
+    edge->copy_wait_ = cev;
+    edge_rows += target_n;
+  }
   StageRound r;
   r.count = 0;
-  size_t max_n = 0, node_rows = 0, edge_rows = 0;
   auto flush = [&] {
     if (r.count == 0) return;
     const unsigned grid = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>((max_n + 255) / 256, 512)));

@@ -32,8 +32,10 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
 // rings, on `stream` (a side stream); d_out / d_stats / update of the descriptors are ignored.
 // Returns false when nothing was issued (no cache has a staging ring, or the generation had to be
 // dropped because fetches that may still read the region it would overwrite are in flight).
+// target_first / target_n: the coming fetch's cache-free target rows are that contiguous id range
+// (staged by one DMA copy; 0 rows: none)
 bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
-                     hipStream_t stream);
+                     int64_t target_first, size_t target_n, hipStream_t stream);
 // sharded feature tables (Cache(distributed=True)): plan the pull of a round's contexts,
 // serve received ids from a shard, fetch with the pulled rows (feature_cache.hip)
 void pull_count(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
@@ -97,13 +99,14 @@ class FeatureCache {
   // out[0..6]: generations, rows per generation, generations issued, generations dropped,
   // rows pulled over the host link so far (reads a device counter: synchronises), ring bytes,
   // rows the gathers read from the host table after all (not staged, or staged too long ago)
-  void staging_state(uint64_t out[7]);
+  // out[7]: microseconds the issuing thread waited in all for fetches to leave a region
+  void staging_state(uint64_t out[8]);
 
  private:
   friend void fetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
                            hipStream_t);
-  friend bool prefetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
-                              hipStream_t);
+  friend bool prefetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t, int64_t,
+                              size_t, hipStream_t);
   friend void fetch_blocks_pulled(FeatureCache*, FeatureCache*, const gf_fetch_pulled_desc*, size_t,
                                   hipStream_t);
   void reserve_workspace(size_t n, hipStream_t stream);
@@ -164,8 +167,14 @@ class FeatureCache {
   bool stage_read_pending_ = false;       // ... the round being built reads the ring
   uint32_t reads_at_gen_[64] = {};        // stage_reads_ when generation g was issued
   uint64_t stage_drops_ = 0;
+  double stage_spin_us_ = 0;
   hipEvent_t stage_events_[kStageEvents] = {};
   hipEvent_t stage_wait_ = nullptr;       // event behind the last prefetch, not yet waited for
+  // a contiguous target range is copied by the DMA engine on a stream of its own (a copy between
+  // two kernels of one stream costs two engine hand-overs), with its own events
+  hipStream_t copy_stream_ = nullptr;
+  hipEvent_t copy_events_[kStageEvents] = {};
+  hipEvent_t copy_wait_ = nullptr;
   bool stage_advance();                   // takes the next generation; false: dropped
   bool stage_begin(void* stage_ctx_out, const int64_t* d_ids, size_t n, bool cached);
   void stage_pull(void* pull_job_out);

@@ -84,6 +84,19 @@ class ReplayPipeline:
         # issuing thread; measured: no consistent difference, profiles/README.md round 4)
         ff = os.environ.get("GNNFLOW_PIPELINE_FETCH_FIRST")
         self.fetch_first = ff is not None and ff != "0"
+        # a staging cache (host-resident tables) stages a batch's own edges with one DMA copy when
+        # their ids are consecutive — true of a chronological replay; checked once, here
+        self.eid_ranges = None
+        if cache is not None and getattr(cache, "staging", False):
+            self.eid_ranges = []
+            for _r, _t, e in batches:
+                rng = None
+                if isinstance(e, torch.Tensor) and e.numel() > 0:
+                    h = e.detach().cpu()
+                    if int(h[-1]) - int(h[0]) == h.numel() - 1 and \
+                            bool((h[1:] - h[:-1] == 1).all()):
+                        rng = (int(h[0]), int(h.numel()))
+                self.eid_ranges.append(rng)
 
     def step(self, i: int):
         r, t, e = self.batches[i % len(self.batches)]
@@ -149,17 +162,52 @@ class ReplayPipeline:
                 self.sampler.set_call_counter(call0 + last * per)
             return
         staged = bool(getattr(cache, "staging", False))
-        depth = self.depth + (1 if staged else 0)
+        depth = self.depth
         while nxt < last and len(pending) < depth:
             pending.append(begin(nxt))
             nxt += 1
         fetch_first = self.fetch_first
-        ahead = None      # MFGs of the next batch, already announced to the cache
         if staged:
-            ahead = pending.popleft().wait()
-            cache.prefetch_feature(ahead, batches[first % nb][2], async_enqueue=True)
+            # Batch i+2's announcement rides in batch i's fetch submission: the pull has two steps
+            # to land, so that the fetch finds its events complete when it is issued — a stream
+            # that really has to wait for another stream's event loses 12-20 us per hand-over
+            # (profiles/README.md, round 6).
+            ranges = self.eid_ranges
+            lead = int(os.environ.get("GNNFLOW_STAGE_LEAD", "2"))
+            ready = deque()           # MFGs waited for and announced, in batch order
+            j = first
+            while j < last and len(ready) < lead:
+                m = pending.popleft().wait()
+                if nxt < last:
+                    pending.append(begin(nxt))
+                    nxt += 1
+                cache.prefetch_feature(m, batches[j % nb][2], async_enqueue=True,
+                                       eid_range=ranges[j % nb])
+                ready.append(m)
+                j += 1
+            for i in range(first, last):
+                mfgs = ready.popleft()
+                for mfg in mfgs:
+                    for b in mfg:
+                        b.record_stream(main)
+                ann = None
+                if j < last:
+                    ahead = pending.popleft().wait()
+                    if nxt < last:
+                        pending.append(begin(nxt))
+                        nxt += 1
+                    ann = (ahead, batches[j % nb][2], ranges[j % nb])
+                    ready.append(ahead)
+                    j += 1
+                cache.fetch_feature(mfgs, batches[i % nb][2], async_enqueue=True, announce=ann)
+                if on_step:
+                    on_step(i % nb, mfgs)
+            cache.wait_enqueued()
+            if keyed:
+                self.sampler.set_call_counter(call0 + last * per)
+            return
         for i in range(first, last):
-            mfgs = ahead if staged else pending.popleft().wait()
+            mfgs = pending.popleft().wait()
             if nxt < last and not fetch_first:
                 pending.append(begin(nxt))
                 nxt += 1
@@ -170,9 +218,6 @@ class ReplayPipeline:
             if nxt < last and fetch_first:
                 pending.append(begin(nxt))
                 nxt += 1
-            if staged and i + 1 < last:
-                ahead = pending.popleft().wait()
-                cache.prefetch_feature(ahead, batches[(i + 1) % nb][2], async_enqueue=True)
             if on_step:
                 on_step(i % nb, mfgs)
         cache.wait_enqueued()

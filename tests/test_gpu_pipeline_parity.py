@@ -337,6 +337,11 @@ def test_pinned_tables_prefetch_is_only_a_hint(monkeypatch):
         if i % 4 == 0:
             assert cache.prefetch_feature(mfgs, e)
             cache.prefetch_feature(mfgs, e)                     # twice
+        elif i % 4 == 3:
+            # the batch's own edges as a contiguous range (one DMA copy) — a chronological batch
+            h = w.host_batches[i][2]
+            assert int(h[-1]) - int(h[0]) == len(h) - 1
+            assert cache.prefetch_feature(mfgs, e, eid_range=(int(h[0]), len(h)))
         elif i % 4 == 1 and i + 1 < 24:
             cache.prefetch_feature(sample(i + 1), w.dev_batches[i + 1][2])   # someone else's
         elif i % 4 == 2:
