@@ -803,9 +803,18 @@ def main():
     # The main loop.  A failing hash-partitioned loop (it runs over RCCL between ranks for the
     # first time in the driver's scaling run) must not cost the line: every rank then times
     # the replica loop instead and the record says so.
+    def staging_probe():
+        import ctypes as C
+        busy, jobs = C.c_double(0), C.c_uint64(0)
+        lib.gf_worker_stats(C.byref(busy), C.byref(jobs))
+        st = cache.staging_state()
+        st["_worker"] = (busy.value, jobs.value)
+        return st
+
     def run_main(kind):
         graph, sampler, build_s = build_leg(ctx, kind)
-        res = time_leg(ctx, sampler, cache, True, args.min_seconds, args.min_replays)
+        res = time_leg(ctx, sampler, cache, True, args.min_seconds, args.min_replays,
+                       probe=staging_probe if (cache is not None and cache.staging) else None)
         res.update(graph=graph, sampler=sampler, build_s=build_s, kind=kind)
         return res
 
@@ -994,6 +1003,46 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/" + PMC_TRAFFIC_FILE
         out["cache_edge_ratio"] = float(cache.cache_edge_ratio)
         out["cache_node_ratio"] = float(cache.cache_node_ratio)
+        if res.get("probe1") is not None:
+            # host-resident tables: what crossed the host link (gnnflow/cache/cache.py:288-313,
+            # 381-388 move every miss host -> pinned -> device inside fetch_feature)
+            s0, s1 = res["probe0"], res["probe1"]
+            w0, w1 = s0.pop("_worker"), s1.pop("_worker")
+            steps_t = max(timed_steps, 1)
+            pulled = sum(s1[k]["rows_pulled"] - s0[k]["rows_pulled"] for k in s1) / steps_t
+            host = sum(s1[k]["rows_read_from_host"] - s0[k]["rows_read_from_host"]
+                       for k in s1) / steps_t
+            nbytes = (pulled + host) * 4.0 * d_e
+            src = cache._edge.table.view(-1)[:1 << 26]
+            dst = torch.empty_like(src, device=dev)
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            link = 3 * src.numel() * 4 / (time.perf_counter() - t0) / 1e9
+            del dst
+            out["staging"] = {
+                "what": "tables in pinned host memory, LRUCache ratio {} in HBM, staging ring {} "
+                        "generations x {} rows per kind ({:.0f} MB of HBM with its index); batch "
+                        "i+1's misses pulled over the host link on a side stream beside "
+                        "fetch_feature(batch i)".format(
+                            args.cache_ratio, s1["edge"]["generations"],
+                            s1["edge"]["rows_per_generation"],
+                            sum(s1[k]["ring_bytes"] for k in s1) / 1e6),
+                "rows_pulled_into_ring_per_step": pulled,
+                "rows_read_from_host_by_gather_per_step": host,
+                "host_link_bytes_per_step": nbytes,
+                "host_link_GBps_over_the_step": nbytes / (elapsed_max / steps_t) / 1e9,
+                "host_link_GBps_memcpy_256MB": link,
+                "host_link_floor_us_per_step": nbytes / (link * 1e9) * 1e6,
+                "generations_dropped": sum(s1[k]["dropped"] - s0[k]["dropped"] for k in s1),
+                "issue_wait_us_per_step": sum(s1[k]["issue_wait_us"] - s0[k]["issue_wait_us"]
+                                              for k in s1) / steps_t,
+                "fetches_that_waited_for_a_pull": (s1["edge"]["stream_waits"] -
+                                                   s0["edge"]["stream_waits"]) / steps_t,
+                "enqueue_threads_busy_us_per_step": (w1[0] - w0[0]) / steps_t}
         # The other kernel of a step's fetch chain: the LRU list update (one launch:
         # lru_list_fused_kernel).  Algorithmic bytes per update: the list rewrite (per slot:
         # entry + mark read, entry + qpos written = 16 B, both caches), the block's rows (id +
@@ -1220,61 +1269,46 @@ def placement_legs(ctx, out, sampler, node_feats, edge_feats):
         return rec
 
     def pinned_placement():
-        cache = LRUCache(args.cache_ratio, args.cache_ratio, g["num_nodes"], g["num_edges"], dev,
-                         node_feats.cpu(), edge_feats.cpu(), d_n, d_e, feature_placement="pinned")
-        cache.init_cache()
-        import ctypes as C
+        # In a FRESH process: which hardware queue a stream lands on depends on how many streams
+        # the process created before it (HIP spreads them over four queues in creation order), and
+        # after the legs above the pull stream of this one shares a queue with busy streams —
+        # 58 us per step here against 38 in a process of its own, same build, same box.
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--feature-placement", "pinned",
+               "--no-config3", "--no-hash-leg", "--no-cpu-baseline", "--no-placement-legs",
+               "--min-seconds", str(secs), "--steps", str(ctx.nb), "--warmup", str(args.warmup),
+               "--batch-size", str(args.batch_size), "--fanouts", args.fanouts,
+               "--strategy", args.strategy, "--cache-ratio", str(args.cache_ratio)]
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+            env.pop(k, None)
+        env["GNNFLOW_BENCH_DEVICE"] = str(ctx.local_rank)
 
-        def probe():
-            busy, jobs = C.c_double(0), C.c_uint64(0)
-            ctx.lib.gf_worker_stats(C.byref(busy), C.byref(jobs))
-            st = cache.staging_state()
-            st["_worker"] = (busy.value, jobs.value)
-            return st
-        res = time_leg(ctx, sampler, cache, False, secs, 1.0, probe=probe)
-        rec = line(res)
-        steps = max(res["timed_steps"], 1)
-        s0, s1 = res["probe0"], res["probe1"]
-        w0, w1 = s0.pop("_worker"), s1.pop("_worker")
-        rec["enqueue_threads_busy_us_per_step"] = (w1[0] - w0[0]) / steps
-        pulled = sum(s1[k]["rows_pulled"] - s0[k]["rows_pulled"] for k in s1) / steps
-        host = sum(s1[k]["rows_read_from_host"] - s0[k]["rows_read_from_host"] for k in s1) / steps
-        nbytes = (pulled + host) * 4.0 * d_e
-        rec.update({
-            "what": "tables in pinned host memory, LRUCache ratio {} in HBM, staging ring {} "
-                    "generations x {} rows per kind ({:.0f} MB of HBM with its index); "
-                    "prefetch_feature(batch i+1) on a side stream beside fetch_feature(batch "
-                    "i)".format(args.cache_ratio, s1["edge"]["generations"],
-                                s1["edge"]["rows_per_generation"],
-                                sum(s1[k]["ring_bytes"] for k in s1) / 1e6),
-            "rows_per_step": cache.rows_moved / steps,
-            "rows_pulled_into_ring_per_step": pulled,
-            "rows_read_from_host_by_gather_per_step": host,
-            "host_link_bytes_per_step": nbytes,
-            "host_link_GBps_over_the_step": nbytes / (rec["ms_per_step"] * 1e-3) / 1e9,
-            "generations_dropped": sum(s1[k]["dropped"] - s0[k]["dropped"] for k in s1),
-            "issue_wait_us_per_step": sum(s1[k]["issue_wait_us"] - s0[k]["issue_wait_us"]
-                                          for k in s1) / steps,
-            "cache_edge_ratio": float(cache.cache_edge_ratio),
-            "cache_node_ratio": float(cache.cache_node_ratio)})
-        # what the link gives a plain copy on this box
-        src = cache._edge.table.view(-1)[:1 << 26]
-        dst = torch.empty_like(src, device=dev)
-        dst.copy_(src, non_blocking=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            dst.copy_(src, non_blocking=True)
-        torch.cuda.synchronize()
-        rec["host_link_GBps_memcpy_256MB"] = 3 * src.numel() * 4 / (time.perf_counter() - t0) / 1e9
-        # ... and the same leg without the ring: every missed row is read from the host table by
-        # the gather itself, inside the launch every hit also waits in (round 2-5's pinned path)
-        del dst
-        plain = LRUCache(args.cache_ratio, args.cache_ratio, g["num_nodes"], g["num_edges"], dev,
-                         cache._node.table, cache._edge.table, d_n, d_e,
-                         feature_placement="pinned", staging=0)
-        plain.init_cache()
-        rec["without_staging_ring"] = line(time_leg(ctx, sampler, plain, False, min(secs, 0.5), 1.0))
+        def child(extra_env):
+            e = dict(env)
+            e.update(extra_env)
+            p = subprocess.run(cmd, env=e, stdin=subprocess.DEVNULL, capture_output=True,
+                               text=True, timeout=110)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                raise RuntimeError("the pinned-placement process failed: " + p.stderr[-600:])
+            return json.loads(lines[-1])
+        d = child({})
+        rec = {k: d[k] for k in ("value", "unit", "ms_per_step", "target_edges_per_s", "steps",
+                                 "repeats", "timed_seconds")}
+        rec["pipelined"] = d["config"]["pipelined"]
+        rec["process"] = "a fresh process (python bench.py --feature-placement pinned ...)"
+        rec["rows_per_step"] = d["config"]["rows_per_step"]
+        rec.update(d.get("staging", {}))
+        for k in ("roofline", "roofline_lru"):
+            if k in d:
+                rec[k] = {x: d[k][x] for x in ("kernel", "avg_launch_us", "frac") if x in d[k]}
+        rec["cache_edge_ratio"], rec["cache_node_ratio"] = d["cache_edge_ratio"], d["cache_node_ratio"]
+        # ... and the same without the ring: every missed row is read from the host table by the
+        # gather itself, inside the launch every hit also waits in (round 2-5's pinned path)
+        d0 = child({"GNNFLOW_STAGING": "0"})
+        rec["without_staging_ring"] = {k: d0[k] for k in ("value", "unit", "ms_per_step",
+                                                          "target_edges_per_s")}
         return rec
 
     for key, fn, limit in (("sample_only", sample_only, 60.0),

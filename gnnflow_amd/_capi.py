@@ -180,15 +180,16 @@ PROTOTYPES = {
                                               C.POINTER(C.c_uint64)]),
     "gf_cache_fetch_wait": (C.c_int, [C.c_uint64]),
     "gf_cache_fetch_announce_async": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p,
-                                                C.POINTER(GfFetchDesc), _sz, C.c_int64, _sz, _p,
+                                                C.POINTER(GfFetchDesc), _sz, _p, _sz, _sz, _p,
                                                 C.POINTER(C.c_uint64)]),
     "gf_cache_set_staging": (C.c_int, [_p, _sz, _sz]),
     "gf_cache_invalidate_staging": (C.c_int, [_p]),
     "gf_cache_staging_state": (C.c_int, [_p, C.POINTER(C.c_uint64)]),
-    "gf_cache_prefetch_blocks": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, C.c_int64, _sz, _p,
+    "gf_cache_prefetch_blocks": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p,
                                            C.POINTER(C.c_int)]),
-    "gf_cache_prefetch_blocks_async": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, C.c_int64,
-                                                 _sz, _p, C.POINTER(C.c_uint64)]),
+    "gf_cache_prefetch_blocks_async": (C.c_int, [_p, _p, C.POINTER(GfFetchDesc), _sz, _p,
+                                                 C.POINTER(C.c_uint64)]),
+    "gf_cache_set_staging_lag": (C.c_int, [_p, _sz]),
     "gf_memory_prepare_input": (C.c_int, [_p, _p, _p, _p, _sz, _sz, _sz, _p, _sz, _p, _p, _p, _p,
                                           C.c_int, _p]),
     "gf_memory_update": (C.c_int, [_p, _p, _p, _p, _sz, _sz, _sz, _p, _p, _p, _p, _sz, C.c_int,

@@ -376,7 +376,7 @@ class Cache:
         for the enqueue on first access (blocks built by gnnflow_amd.TemporalSampler), or
         call wait_enqueued().
 
-        announce=(next_mfgs, next_eid, next_eid_range): with async_enqueue, the NEXT batch's
+        announce=(later_mfgs, later_eid): with async_enqueue, a later batch's
         prefetch_feature() rides in the same submission (one hand-over to the enqueue thread
         per pipelined step instead of two)."""
         # at most _MAX_QUEUED submissions with the enqueue thread: when that thread also issues
@@ -394,48 +394,54 @@ class Cache:
         if not jobs:
             if announce is not None:
                 self.prefetch_feature(announce[0], announce[1], update_cache, target_edge_features,
-                                      async_enqueue=async_enqueue, eid_range=announce[2])
+                                      async_enqueue=async_enqueue)
             return mfgs
         ann = None
         if announce is not None and self._staging is not None:
             if async_enqueue:
                 ann = self._announce_descs(announce, upd, target_edge_features)
             else:
-                self.prefetch_feature(announce[0], announce[1], update_cache, target_edge_features,
-                                      eid_range=announce[2])
+                self.prefetch_feature(announce[0], announce[1], update_cache, target_edge_features)
         if _current_device() != dev.index:
             with torch.cuda.device(dev):
                 return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases, ann)
         return self._submit(mfgs, jobs, n_node, n_cached, upd, async_enqueue, aliases, ann)
 
     def _announce_descs(self, announce, upd, target_edge_features):
-        """Descriptors of the next batch's prefetch for a combined submission:
-        (descriptor buffer, its reference, count, first target id, target count, stream handle,
-        keepalive) or None."""
-        mfgs, eid, eid_range = announce
-        t_first = t_n = 0
-        if eid_range is not None and self._edge is not None and target_edge_features:
-            t_first, t_n = int(eid_range[0]), int(eid_range[1])
-            eid = None
-        jobs = self._jobs(mfgs, eid, upd, target_edge_features)[0]
-        if not jobs and not t_n:
-            return None
-        self._ensure_staging(sum(job[2] for job in jobs) + t_n)
+        """A later batch's prefetch for a combined submission: (descriptor reference or None,
+        count, gf_block array or None, layers, snapshots, stream handle, keepalive) or None."""
+        mfgs, eid = announce[0], announce[1]
         st = self._prefetch_handle
         if st is None:
             from ..pipeline import side_stream
             self._prefetch_stream = side_stream(self.device, 3)
             st = self._prefetch_handle = C.c_void_p(self._prefetch_stream.cuda_stream)
-        stream = self._prefetch_stream
-        for mfg in mfgs:
-            for b in mfg:
-                if hasattr(b, "record_stream"):
-                    b.record_stream(stream)
+        # (no record_stream: the blocks stay alive until their own fetch, which is issued after
+        # the pull that reads their ids has been)
+        b0 = mfgs[0][0]
+        sb = getattr(b0, "_sample_blocks", None)
+        want_target = self._edge is not None and target_edge_features and eid is not None
+        if sb is not None:
+            # the sampler's own block array (+ the target ids): nothing to assemble on this side
+            rows = b0._num_src + b0._num_edges
+            if not want_target:
+                self._ensure_staging(rows)
+                return None, 0, sb[0], sb[1], sb[2], st, mfgs
+            t = self._ids(eid)
+            n = int(t.shape[0])
+            self._ensure_staging(rows + n)
+            descs, cdescs, cdescs_ref = self._desc_buf(1)
+            _DESC.pack_into(descs, 0, 2, upd, t.data_ptr(), n, 0, 0)
+            return cdescs_ref, 1, sb[0], sb[1], sb[2], st, (mfgs, t, descs, cdescs)
+        jobs = self._jobs(mfgs, eid, upd, target_edge_features)[0]
+        if not jobs:
+            return None
+        self._ensure_staging(sum(job[2] for job in jobs))
         descs, cdescs, cdescs_ref = self._desc_buf(len(jobs))
         pack = _DESC.pack_into
         for i, job in enumerate(jobs):
             pack(descs, i * _DESC.size, job[0], upd, job[1] or 0, job[2], 0, 0)
-        return descs, cdescs_ref, len(jobs), t_first, t_n, st, (jobs, cdescs, mfgs)
+        return cdescs_ref, len(jobs), None, 0, 0, st, (jobs, descs, cdescs, mfgs)
 
     def _jobs(self, mfgs, eid, upd, target_edge_features):
         """The block gathers of one fetch_feature() call: (jobs, #node jobs, #jobs through a
@@ -511,29 +517,22 @@ class Cache:
     def prefetch_feature(self, mfgs: List[List], eid: Optional[np.ndarray] = None,
                          update_cache: bool = True, target_edge_features: bool = True,
                          stream: Optional[torch.cuda.Stream] = None,
-                         async_enqueue: bool = False, eid_range=None) -> bool:
+                         async_enqueue: bool = False) -> bool:
         """Announces a coming `fetch_feature(mfgs, eid, ...)` (same arguments): with the tables
         in pinned host memory, the rows of the ids that are neither cached nor staged yet are
         pulled into the staging ring in HBM on `stream` (default: a side stream of this cache),
         beside whatever the fetch stream is doing; the fetch then waits for the pull on its own
         stream and reads those rows from HBM.  The reference does the host -> pinned -> device
         trip inside fetch_feature (cache.py:288-313,381-388).  A hint: results, hit ratios and
-        the cache's contents do not depend on it.  Returns False if there is nothing to do.
-        eid_range=(first, count): `eid` is the consecutive ids first .. first + count - 1 — a
-        chronological batch's own edges (gnnflow/utils.py get_batch slices the edge list) — so
-        their rows are one contiguous piece of the table and are staged by ONE DMA copy."""
+        the cache's contents do not depend on it.  Returns False if there is nothing to do."""
         if self._staging is None:
             return False
         upd = 1 if update_cache else 0
-        t_first = t_n = 0
-        if eid_range is not None and self._edge is not None and target_edge_features:
-            t_first, t_n = int(eid_range[0]), int(eid_range[1])
-            eid = None
         jobs, _n_node, _n_cached, _aliases = self._jobs(mfgs, eid, upd, target_edge_features)
-        if not jobs and not t_n:
+        if not jobs:
             return False
         dev = self.device
-        self._ensure_staging(sum(job[2] for job in jobs) + t_n)
+        self._ensure_staging(sum(job[2] for job in jobs))
         if stream is None:
             stream = self._prefetch_stream
             if stream is None:
@@ -558,13 +557,23 @@ class Cache:
                     self.wait_enqueued(q[0][0])
                 t = C.c_uint64(0)
                 _capi.check(self._lib.gf_cache_prefetch_blocks_async(
-                    node_h, edge_h, cdescs_ref, nj, t_first, t_n, st, C.byref(t)))
+                    node_h, edge_h, cdescs_ref, nj, st, C.byref(t)))
                 q.append((t.value, (jobs, descs, cdescs, mfgs)))
                 return True
             issued = C.c_int(0)
             _capi.check(self._lib.gf_cache_prefetch_blocks(
-                node_h, edge_h, cdescs_ref, nj, t_first, t_n, st, C.byref(issued)))
+                node_h, edge_h, cdescs_ref, nj, st, C.byref(issued)))
             return bool(issued.value)
+
+    def set_staging_lag(self, lag: int):
+        """A loop that announces a batch `lag` + 1 steps before fetching it says so: a fetch then
+        depends on (waits for, reads rows of) all but the `lag` newest announcements
+        (include/gnnflow_hip.h gf_cache_set_staging_lag)."""
+        self.wait_enqueued()
+        self._staging_lag = int(lag)
+        for k in (self._node, self._edge):
+            if k is not None:
+                _capi.check(self._lib.gf_cache_set_staging_lag(k.h, int(lag)))
 
     def staging_state(self) -> dict:
         """Per kind: generations, rows per generation, generations issued / dropped, rows pulled
@@ -573,11 +582,11 @@ class Cache:
         self.wait_enqueued()
         out = {}
         keys = ("generations", "rows_per_generation", "issued", "dropped", "rows_pulled",
-                "ring_bytes", "rows_read_from_host", "issue_wait_us")
+                "ring_bytes", "rows_read_from_host", "issue_wait_us", "stream_waits")
         for name, k in (("node", self._node), ("edge", self._edge)):
             if k is None:
                 continue
-            v = (C.c_uint64 * 8)()
+            v = (C.c_uint64 * 9)()
             _capi.check(self._lib.gf_cache_staging_state(k.h, v))
             out[name] = dict(zip(keys, (int(x) for x in v)))
         return out
@@ -1016,8 +1025,8 @@ class Cache:
             ticket = word[0]
             if ann is not None:
                 rc = self._lib.gf_cache_fetch_announce_async(
-                    node_h, edge_h, cdescs_ref, nj, self._stream(), ann[1], ann[2], ann[3], ann[4],
-                    ann[5], word[1])
+                    node_h, edge_h, cdescs_ref, nj, self._stream(), ann[0], ann[1], ann[2], ann[3],
+                    ann[4], ann[5], word[1])
             else:
                 rc = self._lib.gf_cache_fetch_blocks_async(
                     node_h, edge_h, cdescs_ref, nj, self._stream(), word[1])

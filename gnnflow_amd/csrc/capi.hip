@@ -685,6 +685,9 @@ int gf_cache_fetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
 int gf_cache_set_staging(gf_cache* c, size_t generations, size_t rows_per_generation) {
   return guarded([&] { GF_C(c); c->impl.set_staging(generations, rows_per_generation); });
 }
+int gf_cache_set_staging_lag(gf_cache* c, size_t lag) {
+  return guarded([&] { GF_C(c); c->impl.set_staging_lag(lag); });
+}
 int gf_cache_invalidate_staging(gf_cache* c) {
   return guarded([&] { GF_C(c); c->impl.invalidate_staging(); });
 }
@@ -696,18 +699,17 @@ int gf_cache_staging_state(gf_cache* c, uint64_t* out) {
   });
 }
 int gf_cache_prefetch_blocks(gf_cache* node_cache, gf_cache* edge_cache,
-                             const gf_fetch_desc* descs, size_t n, int64_t target_first,
-                             size_t target_n, void* stream, int* issued) {
+                             const gf_fetch_desc* descs, size_t n, void* stream, int* issued) {
   return guarded([&] {
     const bool did = gf::prefetch_blocks(node_cache ? &node_cache->impl : nullptr,
                                          edge_cache ? &edge_cache->impl : nullptr, descs, n,
-                                         target_first, target_n, static_cast<hipStream_t>(stream));
+                                         static_cast<hipStream_t>(stream));
     if (issued) *issued = did ? 1 : 0;
   });
 }
 int gf_cache_prefetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
-                                   const gf_fetch_desc* descs, size_t n, int64_t target_first,
-                                   size_t target_n, void* stream, uint64_t* ticket) {
+                                   const gf_fetch_desc* descs, size_t n, void* stream,
+                                   uint64_t* ticket) {
   return guarded([&] {
     GF_REQUIRE(ticket != nullptr, "prefetch_blocks_async: null ticket");
     GF_REQUIRE(descs != nullptr || n == 0, "prefetch_blocks_async: null descriptors");
@@ -715,17 +717,16 @@ int gf_cache_prefetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
     gf::FeatureCache* edge = edge_cache ? &edge_cache->impl : nullptr;
     std::vector<gf_fetch_desc> copy(descs, descs + n);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    *ticket = gf::EnqueueWorker::get().submit(
-        [node, edge, copy = std::move(copy), target_first, target_n, st]() {
-          gf::prefetch_blocks(node, edge, copy.data(), copy.size(), target_first, target_n, st);
-        });
+    *ticket = gf::EnqueueWorker::get().submit([node, edge, copy = std::move(copy), st]() {
+      gf::prefetch_blocks(node, edge, copy.data(), copy.size(), st);
+    });
   });
 }
 int gf_cache_fetch_announce_async(gf_cache* node_cache, gf_cache* edge_cache,
                                   const gf_fetch_desc* descs, size_t n, void* stream,
                                   const gf_fetch_desc* next_descs, size_t next_n,
-                                  int64_t next_target_first, size_t next_target_n,
-                                  void* prefetch_stream, uint64_t* ticket) {
+                                  const gf_block* next_blocks, size_t next_layers,
+                                  size_t next_snapshots, void* prefetch_stream, uint64_t* ticket) {
   return guarded([&] {
     GF_REQUIRE(ticket != nullptr, "fetch_announce_async: null ticket");
     GF_REQUIRE((descs != nullptr || n == 0) && (next_descs != nullptr || next_n == 0),
@@ -733,13 +734,23 @@ int gf_cache_fetch_announce_async(gf_cache* node_cache, gf_cache* edge_cache,
     gf::FeatureCache* node = node_cache ? &node_cache->impl : nullptr;
     gf::FeatureCache* edge = edge_cache ? &edge_cache->impl : nullptr;
     std::vector<gf_fetch_desc> copy(descs, descs + n), next(next_descs, next_descs + next_n);
+    if (next_blocks != nullptr) {
+      const size_t L = next_layers, NS = next_snapshots;
+      GF_REQUIRE(L >= 1 && NS >= 1, "fetch_announce_async: empty block array");
+      for (size_t s = 0; node && s < NS; ++s) {   // mfgs[0]: the last sampled layer
+        const gf_block& b = next_blocks[(L - 1) * NS + s];
+        if (b.num_src_nodes) next.push_back(gf_fetch_desc{0, 1, b.all_nodes, b.num_src_nodes, nullptr, nullptr});
+      }
+      for (size_t i = 0; edge && i < L * NS; ++i) {
+        const gf_block& b = next_blocks[i];
+        if (b.num_edges) next.push_back(gf_fetch_desc{1, 1, b.eids, b.num_edges, nullptr, nullptr});
+      }
+    }
     hipStream_t st = static_cast<hipStream_t>(stream), pst = static_cast<hipStream_t>(prefetch_stream);
     *ticket = gf::EnqueueWorker::get().submit(
-        [node, edge, copy = std::move(copy), next = std::move(next), next_target_first,
-         next_target_n, st, pst]() {
+        [node, edge, copy = std::move(copy), next = std::move(next), st, pst]() {
           gf::fetch_blocks(node, edge, copy.data(), copy.size(), st);
-          gf::prefetch_blocks(node, edge, next.data(), next.size(), next_target_first,
-                              next_target_n, pst);
+          gf::prefetch_blocks(node, edge, next.data(), next.size(), pst);
         });
   });
 }
@@ -784,6 +795,9 @@ int gf_worker_stats(double* busy_us, uint64_t* jobs) {
     uint64_t j1 = 0;
     if (&gf::EnqueueWorker::get(1) != &gf::EnqueueWorker::get(0)) {
       gf::EnqueueWorker::get(1).stats(&b1, &j1);
+      if (std::getenv("GNNFLOW_WORKER_STATS"))
+        std::fprintf(stderr, "[worker] lane0 %.0f us / %llu jobs, lane1 %.0f us / %llu jobs\n", *busy_us,
+                     (unsigned long long)*jobs, b1, (unsigned long long)j1);
       *busy_us += b1;
       *jobs += j1;
     }

@@ -67,6 +67,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <cstdio>
 #include <chrono>
@@ -544,25 +545,6 @@ __global__ __launch_bounds__(256) void stage_claim_kernel(StageRound r) {
       p = old;
     }
     c.region_ids[pos] = staged;
-  }
-}
-
-// range: ids first .. first + n - 1 take rows 0 .. n - 1 of this generation's region (their table
-// rows arrive by ONE copy of the DMA engine: contiguous in the table, contiguous in the ring).
-// Unconditional — an id staged before simply points at its new row — and first in the generation:
-// the claim kernel goes on from row n.
-__global__ __launch_bounds__(256) void stage_range_kernel(unsigned long long* pmap, long long first,
-                                                          uint32_t n, uint32_t gen,
-                                                          uint32_t* region_rows, long long* region_ids,
-                                                          unsigned long long* pulled) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i == 0) {
-    *region_rows = n;
-    atomicAdd(pulled, static_cast<unsigned long long>(n));
-  }
-  if (i < n) {
-    pmap[first + i] = (static_cast<unsigned long long>(gen) << 32) | i;
-    region_ids[i] = -1;   // nothing for the pull kernel to do in this row
   }
 }
 
@@ -2847,12 +2829,11 @@ FeatureCache::FeatureCache(size_t num_ids, size_t capacity, size_t dim, const fl
 FeatureCache::~FeatureCache() {
   for (hipEvent_t e : stage_events_)
     if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : copy_events_)
-    if (e) (void)hipEventDestroy(e);
-  if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
 }
 
 // ---- staging ring, host side ---------------------------------------------------------------
+static std::atomic<uint64_t> g_stage_stream_waits{0};
+
 void FeatureCache::set_staging(size_t generations, size_t rows_per_generation) {
   DeviceGuard dg(device_);
   GF_HIP(hipDeviceSynchronize());   // (a configuration call: nothing of this cache is in flight after it)
@@ -2862,7 +2843,7 @@ void FeatureCache::set_staging(size_t generations, size_t rows_per_generation) {
     pmap_.release();
     region_rows_.release();
     region_ids_.release();
-    stage_wait_ = nullptr;
+    synced_gen_ = 0;
     return;
   }
   GF_REQUIRE(!table_on_device_, "staging ring: the feature table is already in device memory");
@@ -2875,23 +2856,20 @@ void FeatureCache::set_staging(size_t generations, size_t rows_per_generation) {
   ring_.release();
   ring_.reserve(generations * rows_per_generation * dim_ * sizeof(float) + 16);
   pmap_.reserve(std::max<size_t>(num_ids_ * sizeof(unsigned long long), 16));
-  region_rows_.reserve(64 * sizeof(uint32_t) + 32);   // + rows pulled, + rows read from the host
+  region_rows_.reserve(64 * sizeof(uint32_t) + 64);   // + rows pulled, + rows read from the host, + ticket
   region_ids_.release();
   region_ids_.reserve(rows_per_generation * sizeof(long long) + 16);
   progress_.reserve(64);
   *progress_.as<volatile uint32_t>() = 0;
   for (hipEvent_t& e : stage_events_)
     if (!e) GF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (hipEvent_t& e : copy_events_)
-    if (!e) GF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  if (!copy_stream_) GF_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-  copy_wait_ = nullptr;
   GF_HIP(hipMemset(pmap_.data(), 0, pmap_.bytes()));
   GF_HIP(hipMemset(region_rows_.data(), 0, region_rows_.bytes()));
   gen_issued_ = 0;
   stage_reads_ = 0;
   stage_read_pending_ = false;
-  stage_wait_ = nullptr;
+  synced_gen_ = 0;
+  std::memset(gen_event_, 0, sizeof(gen_event_));
   std::memset(reads_at_gen_, 0, sizeof(reads_at_gen_));
 }
 
@@ -2905,12 +2883,13 @@ void FeatureCache::invalidate_staging() {
   GF_HIP(hipDeviceSynchronize());
   GF_HIP(hipMemset(region_rows_.data(), 0, 64 * sizeof(uint32_t)));
   *progress_.as<volatile uint32_t>() = stage_reads_;   // (device idle: every launch has finished)
-  stage_wait_ = nullptr;
-  copy_wait_ = nullptr;
+  synced_gen_ = gen_issued_;
+  std::memset(gen_event_, 0, sizeof(gen_event_));
 }
 
-void FeatureCache::staging_state(uint64_t out[8]) {
+void FeatureCache::staging_state(uint64_t out[9]) {
   out[7] = static_cast<uint64_t>(stage_spin_us_);
+  out[8] = g_stage_stream_waits.load(std::memory_order_relaxed);
   out[0] = stage_gens_;
   out[1] = stage_cap_;
   out[2] = gen_issued_;
@@ -2983,30 +2962,31 @@ bool FeatureCache::stage_advance() {
 }
 
 // the fetch stream waits for the prefetches issued so far (one wait per distinct event)
-// (an event that has completed by now — the usual case: the pull was issued two steps ago — costs
-// one query; only one that has not is handed to the stream, whose wait for another queue's signal
-// takes 12-20 us to resolve)
-static inline void stage_wait_on(hipStream_t stream, hipEvent_t ev) {
+// The newest generation a fetch issued now depends on: all but the `stage_lag_` newest.
+uint32_t FeatureCache::stage_hi() const {
+  return gen_issued_ > stage_lag_ ? gen_issued_ - stage_lag_ : 0u;
+}
+
+// The fetch stream waits for the pulls this fetch depends on — the generations up to stage_hi(),
+// i.e. for the newest of them (the pull stream runs them in order).  An event that has completed
+// by now — the usual case when the loop announces a batch two steps ahead of its fetch
+// (gf_cache_set_staging_lag) — costs one query; one that has not is handed to the stream, whose
+// wait for another queue's signal takes 12-20 us to resolve.
+void FeatureCache::stage_sync(hipStream_t stream, hipEvent_t* seen, int* num_seen) {
+  const uint32_t hi = stage_hi();
+  if (!staging() || hi == 0 || hi <= synced_gen_) return;
+  synced_gen_ = hi;
+  hipEvent_t ev = gen_event_[hi % kStageEvents];
+  if (!ev) return;
+  for (int i = 0; i < *num_seen; ++i)
+    if (seen[i] == ev) return;
+  seen[(*num_seen)++] = ev;
   const hipError_t q = hipEventQuery(ev);
   if (q == hipSuccess) return;
   if (q != hipErrorNotReady) GF_HIP(q);
   (void)hipGetLastError();
+  g_stage_stream_waits.fetch_add(1, std::memory_order_relaxed);
   GF_HIP(hipStreamWaitEvent(stream, ev, 0));
-}
-
-void FeatureCache::stage_sync(hipStream_t stream, hipEvent_t* seen, int* num_seen) {
-  if (copy_wait_) {
-    stage_wait_on(stream, copy_wait_);
-    copy_wait_ = nullptr;
-  }
-  if (!stage_wait_) return;
-  bool dup = false;
-  for (int i = 0; i < *num_seen; ++i) dup = dup || seen[i] == stage_wait_;
-  if (!dup) {
-    stage_wait_on(stream, stage_wait_);
-    seen[(*num_seen)++] = stage_wait_;
-  }
-  stage_wait_ = nullptr;
 }
 
 // Context of one block for the generation just taken (stage_advance).
@@ -3052,13 +3032,17 @@ void FeatureCache::stage_pull(void* pull_job_out) {
 }
 
 void FeatureCache::stage_fill(void* ctx_out) {
-  if (!staging() || gen_issued_ == 0) return;
+  const uint32_t hi = stage_hi();
+  if (!staging() || hi == 0) return;
   Ctx& c = *static_cast<Ctx*>(ctx_out);
   if (c.miss_rows || c.remap) return;
   c.pmap = pmap_.as<unsigned long long>();
   c.ring = ring_.as<float>();
+  // (the window's lower end follows the newest generation ISSUED: that one's successors are the
+  // ones that may overwrite regions while this launch runs)
   c.st_lo = stage_window_lo(gen_issued_, stage_gens_, kStageAhead);
-  c.st_span = gen_issued_ - c.st_lo;
+  if (hi < c.st_lo) return;
+  c.st_span = hi - c.st_lo;
   c.st_mask = stage_gens_ - 1u;
   c.st_cap = stage_cap_;
   c.progress = progress_.as<uint32_t>();
@@ -3625,13 +3609,8 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
 // Cache.prefetch_feature: one staging generation per cache for the blocks a coming
 // fetch_blocks(descs) will gather (feature_cache.hpp)
 bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
-                     int64_t target_first, size_t target_n, hipStream_t stream) {
+                     hipStream_t stream) {
   GF_REQUIRE(descs != nullptr || n == 0, "prefetch_blocks: null descriptors");
-  if (target_n) {
-    GF_REQUIRE(edge != nullptr, "prefetch_blocks: a target range without an edge cache");
-    GF_REQUIRE(target_first >= 0 && static_cast<uint64_t>(target_first) + target_n <= edge->num_ids_,
-               "prefetch_blocks: target range outside the edge table");
-  }
   const bool node_on = node && node->staging(), edge_on = edge && edge->staging();
   if (!node_on && !edge_on) return false;
   const int device = node ? node->device() : edge->device();
@@ -3646,31 +3625,10 @@ bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc
     if (d.kind == 0) node_use = node_use || node_on;
     else edge_use = edge_use || edge_on;
   }
-  if (target_n) edge_use = edge_use || edge_on;
   if (node_use) node_use = node->stage_advance();
   if (edge_use) edge_use = edge->stage_advance();
   if (!node_use && !edge_use) return false;
   size_t max_n = 0, node_rows = 0, edge_rows = 0;
-  if (edge_use && target_n && target_n <= edge->stage_cap_) {
-    // the batch's own edges: one contiguous piece of the table, one DMA copy (no wave of the GPU
-    // waits on the host link for them — profiles/r06_host_read_latency.txt: host reads issued by
-    // kernels stretch every latency chain running beside them)
-    const uint32_t gen = edge->gen_issued_, region = gen & (edge->stage_gens_ - 1u);
-    float* dst = edge->ring_.as<float>() + static_cast<uint64_t>(region) * edge->stage_cap_ * edge->dim_;
-    stage_range_kernel<<<dim3(static_cast<unsigned>((target_n + 255) / 256)), dim3(256), 0, stream>>>(
-        edge->pmap_.as<unsigned long long>(), target_first, static_cast<uint32_t>(target_n), gen,
-        edge->region_rows_.as<uint32_t>() + region, edge->region_ids_.as<long long>(),
-        reinterpret_cast<unsigned long long*>(edge->region_rows_.as<uint32_t>() + 64));
-    GF_HIP(hipGetLastError());
-    // (the region is free: stage_advance saw every launch that may read its old rows finish)
-    GF_HIP(hipMemcpyAsync(dst, edge->feats_ + static_cast<uint64_t>(target_first) * edge->dim_,
-                          target_n * edge->dim_ * sizeof(float), hipMemcpyHostToDevice,
-                          edge->copy_stream_));
-    hipEvent_t cev = edge->copy_events_[gen % FeatureCache::kStageEvents];
-    GF_HIP(hipEventRecord(cev, edge->copy_stream_));
-    edge->copy_wait_ = cev;
-    edge_rows += target_n;
-  }
   StageRound r;
   r.count = 0;
   auto flush = [&] {
@@ -3717,8 +3675,8 @@ bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc
   FeatureCache* lead = edge_use ? edge : node;
   hipEvent_t ev = lead->stage_events_[lead->gen_issued_ % FeatureCache::kStageEvents];
   GF_HIP(hipEventRecord(ev, stream));
-  if (node_use) node->stage_wait_ = ev;
-  if (edge_use) edge->stage_wait_ = ev;
+  if (node_use) node->gen_event_[node->gen_issued_ % FeatureCache::kStageEvents] = ev;
+  if (edge_use) edge->gen_event_[edge->gen_issued_ % FeatureCache::kStageEvents] = ev;
   return true;
 }
 

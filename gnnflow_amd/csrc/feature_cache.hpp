@@ -32,10 +32,8 @@ void fetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* d
 // rings, on `stream` (a side stream); d_out / d_stats / update of the descriptors are ignored.
 // Returns false when nothing was issued (no cache has a staging ring, or the generation had to be
 // dropped because fetches that may still read the region it would overwrite are in flight).
-// target_first / target_n: the coming fetch's cache-free target rows are that contiguous id range
-// (staged by one DMA copy; 0 rows: none)
 bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc* descs, size_t n,
-                     int64_t target_first, size_t target_n, hipStream_t stream);
+                     hipStream_t stream);
 // sharded feature tables (Cache(distributed=True)): plan the pull of a round's contexts,
 // serve received ids from a shard, fetch with the pulled rows (feature_cache.hip)
 void pull_count(const gf_pull_desc* descs, size_t n, int world, FeatureCache* const* caches,
@@ -96,17 +94,19 @@ class FeatureCache {
   bool staging() const { return stage_gens_ != 0; }
   // forget every staged row (the table's contents changed)
   void invalidate_staging();
+  void set_staging_lag(size_t lag) { stage_lag_ = static_cast<uint32_t>(std::min<size_t>(lag, kStageAhead - 1)); }
   // out[0..6]: generations, rows per generation, generations issued, generations dropped,
   // rows pulled over the host link so far (reads a device counter: synchronises), ring bytes,
   // rows the gathers read from the host table after all (not staged, or staged too long ago)
   // out[7]: microseconds the issuing thread waited in all for fetches to leave a region
-  void staging_state(uint64_t out[8]);
+  // out[8]: fetches (process-wide) that had to make their stream wait for a pull's event
+  void staging_state(uint64_t out[9]);
 
  private:
   friend void fetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
                            hipStream_t);
-  friend bool prefetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t, int64_t,
-                              size_t, hipStream_t);
+  friend bool prefetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
+                              hipStream_t);
   friend void fetch_blocks_pulled(FeatureCache*, FeatureCache*, const gf_fetch_pulled_desc*, size_t,
                                   hipStream_t);
   void reserve_workspace(size_t n, hipStream_t stream);
@@ -169,16 +169,14 @@ class FeatureCache {
   uint64_t stage_drops_ = 0;
   double stage_spin_us_ = 0;
   hipEvent_t stage_events_[kStageEvents] = {};
-  hipEvent_t stage_wait_ = nullptr;       // event behind the last prefetch, not yet waited for
-  // a contiguous target range is copied by the DMA engine on a stream of its own (a copy between
-  // two kernels of one stream costs two engine hand-overs), with its own events
-  hipStream_t copy_stream_ = nullptr;
-  hipEvent_t copy_events_[kStageEvents] = {};
-  hipEvent_t copy_wait_ = nullptr;
+  hipEvent_t gen_event_[kStageEvents] = {};   // event behind generation g's pull: [g % kStageEvents]
+  uint32_t synced_gen_ = 0;               // newest generation a fetch stream has waited for
+  uint32_t stage_lag_ = 0;                // newest generations a fetch does not depend on
   bool stage_advance();                   // takes the next generation; false: dropped
   bool stage_begin(void* stage_ctx_out, const int64_t* d_ids, size_t n, bool cached);
   void stage_pull(void* pull_job_out);
   void stage_sync(hipStream_t stream, hipEvent_t* seen, int* num_seen);
+  uint32_t stage_hi() const;
   void stage_fill(void* ctx_out);         // ring fields of a gather context
   void stage_round_done();
   uint64_t ring_pos_ = 0;

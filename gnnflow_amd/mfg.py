@@ -67,7 +67,7 @@ class MFGBlock:
     reads the id arrays through `raw_ids()` without creating any."""
 
     __slots__ = ("_num_src", "_num_dst", "_col", "_row", "_num_edges", "_device",
-                 "_srcdata", "_dstdata", "_edata", "_keepalive", "_raw", "_pending",
+                 "_srcdata", "_dstdata", "_edata", "_keepalive", "_raw", "_pending", "_sample_blocks",
                  "_segments", "_edge_prefix_of", "_stream_marks")
 
     def __init__(self, num_src_nodes: int, num_dst_nodes: int, col=None, row=None,
@@ -83,6 +83,9 @@ class MFGBlock:
         self._srcdata = self._dstdata = self._edata = None
         self._keepalive = keepalive
         self._raw = raw
+        # first block of a sample(): (bytes of the sample's gf_block array, layers, snapshots) —
+        # lets Cache announce the whole sample to its staging ring without touching the blocks
+        self._sample_blocks = None
         self._pending = None     # [(which dict, key, thunk)] registered before the dicts exist
         self._segments = None    # (offsets[num_dst + 1], col grouped by destination, perm)
         # set by TemporalSampler: the block of the NEXT sampled layer whose edge arrays start

@@ -22,7 +22,7 @@ import torch
 _SIDE_STREAMS = {}
 
 
-def side_stream(device, k: int = 0) -> torch.cuda.Stream:
+def side_stream(device, k: int = 0, priority: int = 0) -> torch.cuda.Stream:
     """The k-th side stream of `device`, created once per process.  HIP maps streams onto a few
     hardware queues in the order they are created, and two busy streams that land on one queue
     serialise: a pipeline that made a fresh stream per sampling lane shifted the mapping of
@@ -33,7 +33,7 @@ def side_stream(device, k: int = 0) -> torch.cuda.Stream:
     key = (device.index if device.index is not None else torch.cuda.current_device(), int(k))
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
     return st
 
 
@@ -84,19 +84,6 @@ class ReplayPipeline:
         # issuing thread; measured: no consistent difference, profiles/README.md round 4)
         ff = os.environ.get("GNNFLOW_PIPELINE_FETCH_FIRST")
         self.fetch_first = ff is not None and ff != "0"
-        # a staging cache (host-resident tables) stages a batch's own edges with one DMA copy when
-        # their ids are consecutive — true of a chronological replay; checked once, here
-        self.eid_ranges = None
-        if cache is not None and getattr(cache, "staging", False):
-            self.eid_ranges = []
-            for _r, _t, e in batches:
-                rng = None
-                if isinstance(e, torch.Tensor) and e.numel() > 0:
-                    h = e.detach().cpu()
-                    if int(h[-1]) - int(h[0]) == h.numel() - 1 and \
-                            bool((h[1:] - h[:-1] == 1).all()):
-                        rng = (int(h[0]), int(h.numel()))
-                self.eid_ranges.append(rng)
 
     def step(self, i: int):
         r, t, e = self.batches[i % len(self.batches)]
@@ -169,22 +156,23 @@ class ReplayPipeline:
         fetch_first = self.fetch_first
         if staged:
             # Batch i+2's announcement rides in batch i's fetch submission: the pull has two steps
-            # to land, so that the fetch finds its events complete when it is issued — a stream
-            # that really has to wait for another stream's event loses 12-20 us per hand-over
-            # (profiles/README.md, round 6).
-            ranges = self.eid_ranges
-            lead = int(os.environ.get("GNNFLOW_STAGE_LEAD", "2"))
+            # to land, and the fetch of batch i depends on the announcements up to batch i's own
+            # only (set_staging_lag), so that it finds the event it needs complete when it is
+            # issued — a stream that really has to wait for another stream's event loses
+            # 12-20 us per hand-over (profiles/README.md, round 6).
+            lead = max(1, min(int(os.environ.get("GNNFLOW_STAGE_LEAD", "1")), 3))
             ready = deque()           # MFGs waited for and announced, in batch order
+            cache.set_staging_lag(0)
             j = first
             while j < last and len(ready) < lead:
                 m = pending.popleft().wait()
                 if nxt < last:
                     pending.append(begin(nxt))
                     nxt += 1
-                cache.prefetch_feature(m, batches[j % nb][2], async_enqueue=True,
-                                       eid_range=ranges[j % nb])
+                cache.prefetch_feature(m, batches[j % nb][2], async_enqueue=True)
                 ready.append(m)
                 j += 1
+            cache.set_staging_lag(lead - 1)
             for i in range(first, last):
                 mfgs = ready.popleft()
                 for mfg in mfgs:
@@ -196,13 +184,18 @@ class ReplayPipeline:
                     if nxt < last:
                         pending.append(begin(nxt))
                         nxt += 1
-                    ann = (ahead, batches[j % nb][2], ranges[j % nb])
+                    ann = (ahead, batches[j % nb][2])
                     ready.append(ahead)
                     j += 1
+                elif last - 1 - i < lead - 1:
+                    # the tail: no announcement rides along any more — the newest generation
+                    # moves no further, so the fetches' lag shrinks with the batches left
+                    cache.set_staging_lag(last - 1 - i)
                 cache.fetch_feature(mfgs, batches[i % nb][2], async_enqueue=True, announce=ann)
                 if on_step:
                     on_step(i % nb, mfgs)
             cache.wait_enqueued()
+            cache.set_staging_lag(0)
             if keyed:
                 self.sampler.set_call_counter(call0 + last * per)
             return

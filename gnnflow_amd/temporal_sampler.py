@@ -306,6 +306,8 @@ class TemporalSampler:
                     for s in range(ns):
                         mfgs[layer][s]._edge_prefix_of = mfgs[layer + 1][s]
         mfgs.reverse()
+        # (a private copy of the block array: `blocks` is reused by this sampler's next sample)
+        mfgs[0][0]._sample_blocks = (type(blocks).from_buffer_copy(blocks), self._num_layers, ns)
         return mfgs
 
     def sample_layer(self, target_vertices: np.ndarray, timestamps: np.ndarray,

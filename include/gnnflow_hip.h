@@ -364,38 +364,41 @@ GF_API int gf_cache_fetch_wait(uint64_t ticket);
  * one generation per call; the next gf_cache_fetch_blocks makes its stream wait for the pulls
  * issued so far and reads a missed row from the ring when it is there, from the host table
  * otherwise.  A hint: cache state, hit counts and the fetched rows never depend on it.
- * target_first / target_n: the cache-free target rows (kind 2) of the coming fetch are the
- * CONSECUTIVE edge ids target_first .. target_first + target_n - 1 — what a chronological batch's
- * own edges are (gnnflow/utils.py get_batch: df.index slices) — and therefore one contiguous piece
- * of the table: it is staged with ONE copy by the DMA engine instead of row by row by a kernel
- * (no kind-2 descriptor is passed for them then; target_n = 0: no such range).
  * *issued = 0 when the call issued nothing (no ring, or the generation was dropped because
  * fetches that may still read the region it would overwrite had not finished).
  * generations: a power of two in 8..64, or 0 = ring off.  gf_cache_invalidate_staging: the
- * table's contents changed.  gf_cache_staging_state out[8]: generations, rows per generation,
+ * table's contents changed.  gf_cache_staging_state out[9]: generations, rows per generation,
  * generations issued, generations dropped, rows pulled over the host link (synchronises), bytes
  * of HBM the ring and its index take, rows the gathers still read from the host table,
- * microseconds the issuing thread waited for fetches to leave a region before reusing it. */
+ * microseconds the issuing thread waited for fetches to leave a region before reusing it,
+ * fetches (of the process) whose stream had to wait for a pull's event (it had not landed). */
 GF_API int gf_cache_set_staging(gf_cache* c, size_t generations, size_t rows_per_generation);
 GF_API int gf_cache_invalidate_staging(gf_cache* c);
 GF_API int gf_cache_staging_state(gf_cache* c, uint64_t* out);
 GF_API int gf_cache_prefetch_blocks(gf_cache* node_cache, gf_cache* edge_cache,
-                                    const gf_fetch_desc* descs, size_t n, int64_t target_first,
-                                    size_t target_n, void* stream, int* issued);
+                                    const gf_fetch_desc* descs, size_t n, void* stream,
+                                    int* issued);
 /* ... through the enqueue thread that issues the asynchronous fetches (same order of issue);
  * the ticket is waited for with gf_cache_fetch_wait. */
 GF_API int gf_cache_prefetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
-                                          const gf_fetch_desc* descs, size_t n,
-                                          int64_t target_first, size_t target_n, void* stream,
+                                          const gf_fetch_desc* descs, size_t n, void* stream,
                                           uint64_t* ticket);
 /* One submission for a pipelined step: gf_cache_fetch_blocks_async(descs) of batch i followed by
- * gf_cache_prefetch_blocks_async(next_descs, next_target_*) of batch i+1 (one hand-over to the
- * enqueue thread, one ticket). */
+ * the prefetch of a later batch (one hand-over to the enqueue thread, one ticket).  The later
+ * batch is given by descriptors (next_descs) and / or by the block array a sample() of it filled
+ * (next_blocks: [next_layers x next_snapshots] as gf_sampler_sample_end wrote it, copied before
+ * the call returns): the node ids of the last layer's blocks and the edge ids of every block are
+ * announced — the ring's index drops the ids that blocks share. */
 GF_API int gf_cache_fetch_announce_async(gf_cache* node_cache, gf_cache* edge_cache,
                                          const gf_fetch_desc* descs, size_t n, void* stream,
                                          const gf_fetch_desc* next_descs, size_t next_n,
-                                         int64_t next_target_first, size_t next_target_n,
-                                         void* prefetch_stream, uint64_t* ticket);
+                                         const gf_block* next_blocks, size_t next_layers,
+                                         size_t next_snapshots, void* prefetch_stream,
+                                         uint64_t* ticket);
+/* A pipelined loop announces batches `lag` + 1 steps before it fetches them, so that a pull has
+ * landed when its fetch is issued: a fetch then depends on — waits for, and reads rows of — the
+ * generations up to the newest one but `lag` (default 0: every generation issued so far). */
+GF_API int gf_cache_set_staging_lag(gf_cache* c, size_t lag);
 /* Diagnostics: cumulative time the enqueue thread spent issuing work, and jobs done. */
 GF_API int gf_worker_stats(double* busy_us, uint64_t* jobs);
 

@@ -338,10 +338,11 @@ def test_pinned_tables_prefetch_is_only_a_hint(monkeypatch):
             assert cache.prefetch_feature(mfgs, e)
             cache.prefetch_feature(mfgs, e)                     # twice
         elif i % 4 == 3:
-            # the batch's own edges as a contiguous range (one DMA copy) — a chronological batch
-            h = w.host_batches[i][2]
-            assert int(h[-1]) - int(h[0]) == len(h) - 1
-            assert cache.prefetch_feature(mfgs, e, eid_range=(int(h[0]), len(h)))
+            # announced two batches ahead, fetched with a lag of one (what the pipelined loop does)
+            if i + 1 < 24:
+                cache.prefetch_feature(mfgs, e)
+                cache.prefetch_feature(sample(i + 1), w.dev_batches[i + 1][2])
+                cache.set_staging_lag(1)
         elif i % 4 == 1 and i + 1 < 24:
             cache.prefetch_feature(sample(i + 1), w.dev_batches[i + 1][2])   # someone else's
         elif i % 4 == 2:
@@ -350,6 +351,7 @@ def test_pinned_tables_prefetch_is_only_a_hint(monkeypatch):
         if i == 13:
             cache.invalidate_staging()
         cache.fetch_feature(mfgs, e)
+        cache.set_staging_lag(0)
         snap = _snapshot(cache, mfgs)
         w.torch.cuda.synchronize()
         _check_step(w, i, snap)
