@@ -163,7 +163,7 @@ class Cache:
         self.feature_placement = placement
         # Staging ring of a host-resident table (feature_placement="pinned"; include/gnnflow_hip.h
         # gf_cache_set_staging): prefetch_feature() pulls the rows a coming fetch_feature() will
-        # miss into HBM on a side stream.  `staging`: None = GNNFLOW_STAGING or "auto" (64
+        # miss into HBM on a side stream.  `staging`: None = GNNFLOW_STAGING or "auto" (32
         # generations, rows per generation sized from the blocks prefetched), 0 / False = off,
         # (generations, rows_per_generation) = fixed.
         if staging is None:
@@ -500,12 +500,14 @@ class Cache:
 
     def _ensure_staging(self, rows: int):
         """Sets the native rings up (or enlarges them: a synchronising call) so that a
-        generation holds 1/32 of the rows of the round being prefetched (64 generations: the ring
-        takes twice the rows of one round's blocks — the reference's pinned staging buffers,
-        utils.py get_pinned_buffers, take once that)."""
+        generation holds an eighth of the rows of the round being prefetched — a round of uniform
+        sampling over a large graph misses that many (GDELT-shaped, LRU 0.2: hit ratio 0.66, every
+        ninth row a distinct miss); 32 generations: the ring takes four times the rows of one
+        round's blocks (the reference's pinned staging buffers, utils.py get_pinned_buffers, take
+        once that)."""
         st = self._staging
-        gens, fixed = (64, 0) if st == 'auto' else (int(st[0]), int(st[1]))
-        want = fixed or (1 << max(int(max(rows, 1) // 32 - 1).bit_length(), 10))
+        gens, fixed = (32, 0) if st == 'auto' else (int(st[0]), int(st[1]))
+        want = fixed or (1 << max(int(max(rows, 1) // 8 - 1).bit_length(), 10))
         if want <= self._staging_rows:
             return
         self.wait_enqueued()

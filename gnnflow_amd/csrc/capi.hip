@@ -682,6 +682,16 @@ int gf_cache_fetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
     });
   });
 }
+int gf_debug_lru_trace_enable(gf_cache* c, int on) {
+  return guarded([&] { GF_C(c); c->impl.lru_trace_enable(on != 0); });
+}
+int gf_debug_lru_trace(gf_cache* c, uint64_t* out, size_t capacity_words, size_t* words) {
+  return guarded([&] {
+    GF_C(c);
+    GF_REQUIRE(out != nullptr && words != nullptr, "gf_debug_lru_trace: null output");
+    *words = c->impl.lru_trace_read(out, capacity_words);
+  });
+}
 int gf_cache_set_staging(gf_cache* c, size_t generations, size_t rows_per_generation) {
   return guarded([&] { GF_C(c); c->impl.set_staging(generations, rows_per_generation); });
 }

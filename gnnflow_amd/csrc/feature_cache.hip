@@ -170,6 +170,9 @@ struct Ctx {
   uint32_t* progress;       // pinned host word: this launch stores progress_val = the number of
   uint32_t progress_val;    // ring-reading launches enqueued before it (all finished by now)
   unsigned long long* st_fallback;   // rows this cache's gathers read from the HOST table
+  // diagnostics (gf_debug_lru_trace): per workgroup of the one-launch list update, 8 stamps of the
+  // 100 MHz wall clock; [0 .. 3] of the buffer: count / row / write workgroups, launch tag
+  unsigned long long* trace;
   uint64_t num_ids;
   int32_t* map;             // null: no cache (plain gather)
   float* cache_buf;
@@ -512,10 +515,12 @@ __global__ __launch_bounds__(256) void stage_claim_kernel(StageRound r) {
     if (i < c.n) {
       id = c.ids[i];
       if (id >= 0 && static_cast<uint64_t>(id) < c.num_ids) {
-        // (a negative map value other than kAbsent is the claim of a fetch in flight: its
-        // update installs the id before the gather this prefetch works for)
+        // (a negative map value other than kAbsent is the claim of a fetch in flight; its update
+        // installs the id — unless the block misses more ids than the cache has slots, a small
+        // cache's every step — so it counts as absent: an id the fetch in flight misses is in
+        // the ring already and costs nothing here)
         const int32_t slot = c.map ? c.map[id] : kAbsent;
-        bool maybe = slot == kAbsent;
+        bool maybe = slot < 0;
         if (slot >= 0 && c.qpos) {
           uint32_t at = c.qpos[slot];
           if (c.qstate) at -= c.qstate->head;
@@ -2036,23 +2041,36 @@ __device__ inline uint32_t fuse_walk_tile(const Ctx& c, const uint32_t* list, ui
   return list[lo];   // unreachable: the prefix said the tile has more than x such entries
 }
 
+#define GF_STAMP(k) \
+  do { if (c.trace && threadIdx.x == 0) c.trace[4 + vx * 8 + (k)] = wall_clock64(); } while (0)
+
 __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t count_blocks,
                                                                uint32_t row_blocks,
                                                                uint32_t write_blocks) {
+  // (the roles in THIS order of blockIdx.x — count, row, write — because every wait is for a
+  // workgroup dispatched earlier; dispatching the row role, whose chain is the longest, first
+  // saved 0.5 us of an isolated launch and cost 7 us per step in the pipelined loop, where the
+  // row workgroups then spin for count workgroups that other kernels keep from starting:
+  // profiles/README.md, round 6)
   const Ctx& c = r.c[blockIdx.y];
+  const uint32_t vx = blockIdx.x;
   if (!c.update || c.policy != GF_CACHE_LRU || !c.fused) return;
   const int tid = threadIdx.x;
+  if (c.trace && vx == 0 && tid == 0) {
+    c.trace[0] = count_blocks; c.trace[1] = row_blocks; c.trace[2] = write_blocks; c.trace[3] = c.fuse_tag;
+  }
+  GF_STAMP(0);
   __shared__ uint32_t ws[kWide / 64];
   const uint32_t cap = c.capacity, tag = c.fuse_tag;
   const uint32_t tiles = (cap + kFuseTile - 1) / kFuseTile;
   const uint32_t row_wgs = (c.n + c.fuse_rows - 1) / c.fuse_rows;
 
-  if (blockIdx.x < count_blocks) {
+  if (vx < count_blocks) {
     // ---- count role ----
     bool first = true;
     uint32_t par = 0, bound = 0;
     bool stage_hits = false;
-    for (uint32_t t = blockIdx.x; t < tiles; t += count_blocks) {
+    for (uint32_t t = vx; t < tiles; t += count_blocks) {
       const uint32_t p = t * kFuseTile + tid;
       const bool in = p < cap;
       const uint32_t tc = in ? c.touched[p] : 0u;
@@ -2077,6 +2095,7 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
       }
       const bool hit = in && tc == c.epoch_new;
       const bool stage = t * kFuseTile < bound;
+      if (t == vx) GF_STAMP(1);   // marks, list entries, parity and counters are in
       long long old = -1;
       if (stage && in && (!hit || stage_hits)) old = c.slot_id[sl];
       uint32_t total;
@@ -2097,6 +2116,7 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) fuse_publish(&c.g_cnt[t], tag, total);
+      if (t == vx) GF_STAMP(2);   // staged entries drained, count published
     }
     return;
   }
@@ -2104,9 +2124,9 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
   __shared__ uint32_t s_keep[kFuseMaxTiles + 1], s_hitp[kFuseMaxTiles + 1];
   __shared__ uint32_t s_direct;
 
-  if (blockIdx.x < count_blocks + row_blocks) {
+  if (vx < count_blocks + row_blocks) {
     // ---- row role ----
-    const uint32_t b = blockIdx.x - count_blocks;
+    const uint32_t b = vx - count_blocks;
     if (b >= row_wgs) return;
     __shared__ uint2 inst[kWide];        // {slot, row} installed by this workgroup
     __shared__ int64_t inst_id[kWide];
@@ -2132,6 +2152,7 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
       n_inst = 0;
       s_direct = 0;
     }
+    GF_STAMP(1);   // rows read (slot_of_row, ids, claims), representatives ranked and published
     // look-back over the row workgroups before this one (at most kFuseMaxRowWgs = kWide: one
     // per thread) and the hits per list tile (two per thread), all in flight together
     constexpr uint32_t kPer = kFuseMaxTiles / kWide;
@@ -2165,6 +2186,7 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
       hb += hv[k];
     }
     __syncthreads();
+    GF_STAMP(2);   // every granule before this workgroup is in, prefixes in LDS
     const uint32_t n_kept = cap - th;
     if (fm) {
       const uint32_t m = pm + rank;
@@ -2199,6 +2221,7 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
       }
     }
     __syncthreads();
+    GF_STAMP(3);   // victims read, map / slot_id written
     const uint32_t total = n_inst * c.dimv;
     if (c.vec4) {
       if (c.fuse_rows > kInstRows) copy_installed<float4, 6>(c, inst, inst_id, n_inst, c.dimv * 4, tid);
@@ -2215,11 +2238,12 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
                               : c.out[static_cast<uint64_t>(pr.y) * c.dimv + cc];
       }
     }
+    GF_STAMP(4);   // installed rows copied
     return;
   }
 
   // ---- write role ----
-  const uint32_t wb = blockIdx.x - count_blocks - row_blocks;
+  const uint32_t wb = vx - count_blocks - row_blocks;
   if (wb >= write_blocks || wb >= tiles) return;
   uint32_t sl0, tc0, par;
   {
@@ -2257,6 +2281,7 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
     hbt += hv[k];
   }
   __syncthreads();
+  GF_STAMP(1);   // every row and count granule is in
   const uint32_t k = min(tm, cap), n_kept = cap - th;
   const uint32_t* list = c.queue[par];
   uint32_t* next = c.queue[par ^ 1u];
@@ -2279,6 +2304,7 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
       c.qpos[sl] = at;   // where the next block's hits of this slot leave their mark
     }
   }
+  GF_STAMP(2);   // list tile(s) rewritten
   if (wb == 0 && tid == 0) {
     // {new parity, this launch's tag} in ONE store: fuse_parity() of a late workgroup of this
     // launch still resolves to `par`
@@ -2887,6 +2913,23 @@ void FeatureCache::invalidate_staging() {
   std::memset(gen_event_, 0, sizeof(gen_event_));
 }
 
+// diagnostics: stamps of the one-launch list update (gf_debug_lru_trace)
+void FeatureCache::lru_trace_enable(bool on) {
+  DeviceGuard dg(device_);
+  GF_HIP(hipDeviceSynchronize());
+  if (!on) { trace_.release(); return; }
+  trace_.reserve((4 + 8 * (2 * kFuseMaxTiles + kFuseMaxRowWgs)) * sizeof(unsigned long long));
+  GF_HIP(hipMemset(trace_.data(), 0, trace_.bytes()));
+}
+size_t FeatureCache::lru_trace_read(uint64_t* out, size_t capacity_words) {
+  if (!trace_.data()) return 0;
+  DeviceGuard dg(device_);
+  GF_HIP(hipDeviceSynchronize());
+  const size_t words = std::min(capacity_words, trace_.bytes() / sizeof(unsigned long long));
+  GF_HIP(hipMemcpy(out, trace_.data(), words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return words;
+}
+
 void FeatureCache::staging_state(uint64_t out[9]) {
   out[7] = static_cast<uint64_t>(stage_spin_us_);
   out[8] = g_stage_stream_waits.load(std::memory_order_relaxed);
@@ -3001,7 +3044,9 @@ bool FeatureCache::stage_begin(void* stage_ctx_out, const int64_t* d_ids, size_t
   c.region_rows = region_rows_.as<uint32_t>();
   c.region_ids = region_ids_.as<long long>();
   c.gen = gen_issued_;
-  c.lo = stage_window_lo(gen_issued_, stage_gens_, kStageAhead);
+  // (an id staged in one of the two oldest readable generations is staged again: its fetch is
+  // issued one to three generations from now, when those have left the window)
+  c.lo = std::min(gen_issued_, stage_window_lo(gen_issued_, stage_gens_, kStageAhead) + kStageAhead - 1u);
   c.mask = stage_gens_ - 1u;
   c.cap = stage_cap_;
   // (only a cache that kStageAhead blocks of this size can turn over: for a larger one the
@@ -3469,6 +3514,7 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
         fuse_tag_ = 0;
       }
       c.fused = 1;
+      c.trace = trace_.data() ? trace_.as<unsigned long long>() : nullptr;
       c.fuse_tag = ++fuse_tag_;
       c.g_cnt = granules_.as<unsigned long long>();
       c.g_row = c.g_cnt + kFuseMaxTiles;

@@ -101,6 +101,9 @@ class FeatureCache {
   // out[7]: microseconds the issuing thread waited in all for fetches to leave a region
   // out[8]: fetches (process-wide) that had to make their stream wait for a pull's event
   void staging_state(uint64_t out[9]);
+  // diagnostics: 100 MHz wall-clock stamps of every workgroup of the last one-launch list update
+  void lru_trace_enable(bool on);
+  size_t lru_trace_read(uint64_t* out, size_t capacity_words);
 
  private:
   friend void fetch_blocks(FeatureCache*, FeatureCache*, const gf_fetch_desc*, size_t,
@@ -151,6 +154,7 @@ class FeatureCache {
   DeviceBuffer granules_;  // LRU list form in one launch: {launch tag, count} per list tile / row
                            // workgroup (feature_cache.hip, lru_list_fused_kernel)
   uint32_t fuse_tag_ = 0;  // tag of the last such launch: unique per cache, never reset
+  DeviceBuffer trace_;     // gf_debug_lru_trace
   uint32_t epoch_ = 0;     // fetches with update so far (host side; kernel argument)
   // staging ring (set_staging)
   static constexpr uint32_t kStageEvents = 8;

@@ -372,6 +372,14 @@ GF_API int gf_cache_fetch_wait(uint64_t ticket);
  * of HBM the ring and its index take, rows the gathers still read from the host table,
  * microseconds the issuing thread waited for fetches to leave a region before reusing it,
  * fetches (of the process) whose stream had to wait for a pull's event (it had not landed). */
+/* Diagnostics of the one-launch LRU list update (lru_list_fused_kernel): with tracing on, every
+ * workgroup of an update stamps the 100 MHz wall clock at its role's stages; gf_debug_lru_trace
+ * copies the last update's stamps out — words [0..3] = count / row / write workgroups and the
+ * launch tag, then 8 words per workgroup (0: entry; count role 1: inputs in, 2: published; row
+ * role 1: ranked + published, 2: look-back complete, 3: installed, 4: rows copied; write role 1:
+ * granules in, 2: list written).  scripts/lru_hop_trace.py prints the account. */
+GF_API int gf_debug_lru_trace_enable(gf_cache* c, int on);
+GF_API int gf_debug_lru_trace(gf_cache* c, uint64_t* out, size_t capacity_words, size_t* words);
 GF_API int gf_cache_set_staging(gf_cache* c, size_t generations, size_t rows_per_generation);
 GF_API int gf_cache_invalidate_staging(gf_cache* c);
 GF_API int gf_cache_staging_state(gf_cache* c, uint64_t* out);

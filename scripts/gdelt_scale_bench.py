@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--batches", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--policy", default="uniform")
+    ap.add_argument("--feature-placement", default="device", choices=["device", "pinned"],
+                    help="pinned: the reference's placement — both tables in pinned HOST memory, the "
+                         "LRU caches in HBM, the coming misses pulled into the staging ring")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     from gnnflow_amd.utils import bind_to_device_cpus
@@ -72,9 +75,21 @@ def main():
         graph.add_edges(g["src"][lo:hi], g["dst"][lo:hi], g["ts"][lo:hi], g["eid"][lo:hi])
     build_s = time.time() - t0
     t0 = time.time()
-    efeat = feature_table(E, args.dim_edge, dev)
-    nfeat = feature_table(N, args.dim_node, dev)
-    cache = LRUCache(args.ratio, args.ratio, N, E, dev, nfeat, efeat, args.dim_node, args.dim_edge)
+    if args.feature_placement == "pinned":
+        # made on the GPU in pieces, kept in pinned host memory
+        efeat = torch.empty((E, args.dim_edge), dtype=torch.float32, pin_memory=True)
+        step = 1 << 24
+        for lo in range(0, E, step):
+            hi = min(E, lo + step)
+            i = torch.arange(lo, hi, device=dev, dtype=torch.float64)
+            col = torch.arange(args.dim_edge, device=dev, dtype=torch.float32) / 1024.0
+            efeat[lo:hi].copy_(torch.frac(i * 0.6180339887).to(torch.float32)[:, None] + col[None, :])
+        nfeat = feature_table(N, args.dim_node, dev).cpu().pin_memory()
+    else:
+        efeat = feature_table(E, args.dim_edge, dev)
+        nfeat = feature_table(N, args.dim_node, dev)
+    cache = LRUCache(args.ratio, args.ratio, N, E, dev, nfeat, efeat, args.dim_node, args.dim_edge,
+                     feature_placement=args.feature_placement)
     cache.init_cache()
     torch.cuda.synchronize()
     feat_s = time.time() - t0
@@ -113,10 +128,12 @@ def main():
     lib.gf_profile_set_stride(7)
     lib.gf_profile_enable(1 << _capi.PROFILE_SLOTS["gather"])
     cache.algorithmic_bytes = 0
+    st0 = cache.staging_state() if cache.staging else None
     t0 = time.time()
     pipe.run(warm, nb - warm, on_step)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    st1 = cache.staging_state() if cache.staging else None
     lib.gf_profile_enable(0)
     lib.gf_profile_set_stride(1)
     g_ms, g_n, g_all = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
@@ -151,6 +168,18 @@ def main():
         "edge_cache_slots": cache.edge_capacity,
         "edge_lru_state": cache._edge.lru_state(),
         "rows_checked_equal_table": ok,
+        "feature_placement": args.feature_placement,
+        "staging": None if st1 is None else {
+            k: {"generations": st1[k]["generations"], "rows_per_generation": st1[k]["rows_per_generation"],
+                "ring_GB": round(st1[k]["ring_bytes"] / 1e9, 2),
+                "rows_pulled_per_step": round((st1[k]["rows_pulled"] - st0[k]["rows_pulled"]) / steps, 1),
+                "rows_read_from_host_by_gather_per_step":
+                    round((st1[k]["rows_read_from_host"] - st0[k]["rows_read_from_host"]) / steps, 1),
+                "host_link_MB_per_step": round(
+                    ((st1[k]["rows_pulled"] - st0[k]["rows_pulled"]) +
+                     (st1[k]["rows_read_from_host"] - st0[k]["rows_read_from_host"])) / steps *
+                    4 * (args.dim_node if k == "node" else args.dim_edge) / 1e6, 2),
+                "generations_dropped": st1[k]["dropped"] - st0[k]["dropped"]} for k in st1},
         "gen_s": round(gen_s, 2), "graph_build_s": round(build_s, 2),
         "graph_build_Medges_per_s": round(E / build_s / 1e6, 1), "features_s": round(feat_s, 2),
         "edge_feature_table_GB": round(E * args.dim_edge * 4 / 1e9, 1),
