@@ -336,6 +336,20 @@ def multi_gpu_record(ctx, sampler, cache):
     dist.all_gather_object(ranks, mine)
     rec["ranks"] = ranks
     rec["distinct_devices"] = len({r["pci_bus_id"] for r in ranks})
+    if cache is not None and getattr(cache, "distributed", False):
+        # --shard-features: what the owner-sharded feature pull put on the links (rows of misses
+        # and target edges pulled from their owners; gnnflow/distributed/kvstore.py:285-339)
+        sh = cache._shards
+        mine_pull = {"rows_pulled": int(sh.rows_pulled), "bytes_sent": int(sh.bytes_sent),
+                     "count_read_backs": int(sh.host_syncs)}
+        pulls = [None] * ctx.world
+        dist.all_gather_object(pulls, mine_pull)
+        steps_all = max(ctx.steps_issued, 1)
+        rec["feature_pull"] = {
+            "rows_pulled_per_step_and_rank": sum(p["rows_pulled"] for p in pulls) / ctx.world / steps_all,
+            "bytes_sent_per_step_and_rank": sum(p["bytes_sent"] for p in pulls) / ctx.world / steps_all,
+            "count_read_backs_per_step": pulls[0]["count_read_backs"] / steps_all,
+            "ranks": pulls}
     if hasattr(sampler, "wire_bytes_per_sample"):
         wb = sampler.wire_bytes_per_sample()
         rec["wire"] = wb
@@ -400,6 +414,12 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays, probe=None
     pipe = ReplayPipeline(sampler, cache, ctx.dev_batches, ctx.dev,
                           pipelined=not args.no_pipeline, depth=depth)
     ctx.live_pipe = pipe
+    _run = pipe.run
+
+    def counted_run(first, count, on_step=None):     # steps issued so far (per-step averages
+        ctx.steps_issued = getattr(ctx, "steps_issued", 0) + max(count, 0)   # of cumulative counters)
+        return _run(first, count, on_step)
+    pipe.run = counted_run
 
     def reduce(value, op):
         if world == 1:
@@ -659,7 +679,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, argv))
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "GNNFLOW_BENCH_WORKER" not in os.environ \
-            and args.partition in (None, "hash") and not args.shard_features:
+            and args.partition in (None, "hash"):
         sys.exit(supervise(args, argv))
     fake = os.environ.get("GNNFLOW_BENCH_FAKE_WORKER")
     if fake and "GNNFLOW_BENCH_WORKER" in os.environ:

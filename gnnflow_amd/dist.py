@@ -719,7 +719,15 @@ class DevicePartitionedSampler:
         if edge_fill is None:
             edge_fill = float(os.environ.get("GNNFLOW_PART_EDGE_FILL", "0.1"))
         self._edge_fill = 0.0
-        self._set_edge_fill(max(0.0, min(float(edge_fill), 1.0)) if chain > 1 else 0.0)
+        # a chain of ONE sample may use the shared chains' machinery too (compact replies: the
+        # reference ships back a partition's sampled edges, not fanout records per root,
+        # gnnflow/distributed/dist_sampler.py:244-314) — rung "hash-simple" of bench.py's ladder
+        groupable = self._slack > 0 and self._S == 1
+        self._chain_of_one = (chain == 1 and groupable and
+                              os.environ.get("GNNFLOW_PART_SINGLE_COMPACT", "1") != "0")
+        self._set_edge_fill(max(0.0, min(float(edge_fill), 1.0))
+                            if (chain > 1 or self._chain_of_one) else 0.0)
+        self._chain_of_one = self._chain_of_one and self._edge_fill > 0.0
         self._held = []            # samples (of one lane) waiting for their chain to fill
         self.pairs = 0             # chains that carried more than one sample
         self.chained = 0           # samples that travelled in such chains
@@ -744,7 +752,7 @@ class DevicePartitionedSampler:
         snapshot — fixed by the slot capacity, whatever the slots really hold."""
         R0 = int(R0 or max(self._slot_roots, 1))
         rec = 12 if self._narrow else 24
-        fill = self._edge_fill if self.chain_samples > 1 else 0.0
+        fill = self._edge_fill
         req = rep = fixed = 0
         per_layer = []
         C = self._C
@@ -858,7 +866,7 @@ class DevicePartitionedSampler:
         """TemporalSampler.sample_async for the partitioned graph: returns a pending sample;
         `.wait()` gives the MFGs.  With more than one rank the launches and the collectives
         are enqueued by this call without any host synchronisation (slotted form)."""
-        if self.chain_samples > 1 and stream is not None:
+        if (self.chain_samples > 1 or self._chain_of_one) and stream is not None:
             return self._sample_chained(nodes, ts, stream, worker_enqueue)
         lane, stream = self._pick_lane(stream)
         smp = lane.sampler
@@ -901,7 +909,10 @@ class DevicePartitionedSampler:
             if len(smp._inflight) >= smp._max_inflight:
                 smp._inflight[0].wait()
         solo = self._solo
-        if len(held) == 1:
+        # (a lone sample of a lane that chains travels as a chain of one when compact replies are
+        # on: the same wire format as its neighbours' — every rank decides alike, the samples held
+        # are the same on all of them)
+        if len(held) == 1 and not (self._edge_fill > 0.0 and not solo):
             p = held[0]
             p._attach(self._sample_one_rank(lane, p._nodes, p._ts, stream, worker_enqueue, p._smp)
                       if solo else

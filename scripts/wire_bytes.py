@@ -26,10 +26,13 @@ out = {"batch": "600 edges = 1800 roots, fanouts [10, 10], 12-byte reply records
 for P in (2, 4, 8):
     comms = NativeComm.loopback(P, dev)
     row = {}
-    for name, fill in (("fixed_reply_slots_round4", 0.0), ("compact_reply_slots", 0.1)):
+    for name, fill, chain in (("fixed_reply_slots_round4", 0.0, 4), ("compact_reply_slots", 0.1, 4),
+                              # round 6: a chain of ONE sample (rung "hash-simple" of bench.py's
+                              # ladder) ships compact replies too; before, the fixed records
+                              ("single_chain_compact_round6", 0.1, 1)):
         part = DevicePartitionedSampler(gnnflow_amd.TemporalSampler(g, [10, 10], "recent"),
                                         comm=comms[0], slot_roots=1800, narrow_ids=True,
-                                        edge_fill=fill)
+                                        edge_fill=fill, chain_samples=chain)
         w = part.wire_bytes_per_sample()
         row[name] = {"slack": w["slack"], "edge_fill": w["reply_edge_fill"],
                      "request_KB_to_each_peer": round(w["request_bytes_to_each_peer"] / 1e3, 1),

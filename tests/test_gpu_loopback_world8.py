@@ -284,9 +284,10 @@ def test_shared_chains_with_ragged_and_empty_batches(ranks, chain):
                 assert over == 0
             else:
                 assert over > 0 and over == res[0][2]      # the same samples on every rank
-            # 4 samples, all waited for, then 5: chains of 2: 2 + 2 (+ the last alone); of 3:
-            # 1 (+ one alone), then 1 + the two held ones; of 4: 1, then 1 (+ the last alone)
-            want = ({2: 4, 3: 3, 4: 2}[chain], 8) if kw["num_snapshots"] == 1 else (0, 0)
+            # 4 samples, all waited for, then 5: chains of 2: 2 + 2, then 2 + 2 + the last alone;
+            # of 3: 3 + one alone, then 3 + the two held ones; of 4: 4, then 4 + the last alone —
+            # a sample alone travels as a chain of ONE (compact replies, same wire format)
+            want = ({2: 5, 3: 4, 4: 3}[chain], 9) if kw["num_snapshots"] == 1 else (0, 0)
             assert pairs == want
             for (n, t), mfgs in zip(batches[r], got):
                 for gl, wl in zip(mfgs, ref.sample(n, t)):
