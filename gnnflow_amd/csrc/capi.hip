@@ -897,8 +897,9 @@ int gf_sampler_part_group_slot(const gf_sampler* s, size_t num_roots, uint32_t l
     GF_REQUIRE(layer < s->impl.num_layers(), "layer out of range");
     gf::Sampler::GroupLayout lay;
     const size_t R[1] = {std::max<size_t>(num_roots, 1)};
-    s->impl.group_layout(R, 1, layer, world_size, slack, slot_roots, narrow != 0, edge_fill, &lay);
-    const size_t rb = narrow ? 12 : 24;
+    s->impl.group_layout(R, 1, layer, world_size, slack, slot_roots, (narrow & 1) != 0, edge_fill,
+                         &lay, (narrow & 2) != 0);
+    const size_t rb = (narrow & 1) ? 12 : 24;
     out[0] = lay.stride;
     out[1] = edge_fill > 0.0 ? lay.cslot : lay.stride * s->impl.fanout(layer) * rb;
     out[2] = lay.edge_cap;
@@ -1175,7 +1176,8 @@ int gf_sampler_part_group_ws_bytes(const gf_sampler* s, const size_t* roots, int
     for (int j = 0; j < m; ++j) R[j] = std::max<size_t>(roots[j], 1);
     *bytes = (slack > 0.0 && s->impl.group_ok(R, m))
                  ? gf::Sampler::group_ws_bytes(s->impl, R, m, world_size, slack, slot_roots,
-                                               flag_narrow(narrow_ids), flag_edge_fill(narrow_ids))
+                                               flag_narrow(narrow_ids), flag_edge_fill(narrow_ids),
+                                               flag_reuse(narrow_ids))
                  : 0;
   });
 }

@@ -2067,7 +2067,7 @@ inline uint64_t next_merge_tag() { return (g_merge_epoch.fetch_add(1) + 1) << 10
 // the block sizes like sample_begin does and sample_end() returns them.  With one rank there
 // is no exchange and sample_partitioned() issues the whole chain in one call.
 void Sampler::part_layout(size_t R0, uint32_t layer, int world_size, double slack,
-                          size_t slot_roots, gf_part_layout* out) const {
+                          size_t slot_roots, gf_part_layout* out, bool skip_prev) const {
   GF_REQUIRE(layer < fanouts_.size(), "part_layout: layer out of range");
   GF_REQUIRE(out != nullptr, "part_layout: null output");
   GF_REQUIRE(slack >= 0.0, "part_layout: negative slack");
@@ -2078,7 +2078,10 @@ void Sampler::part_layout(size_t R0, uint32_t layer, int world_size, double slac
   // agreed on — not from this rank's own R0: the slots must have the same size on all ranks.
   size_t stride = 0, rows = Rb;
   if (slack > 0.0) {
-    const size_t Sb = root_bound(std::max<size_t>(slot_roots, 1), layer);
+    // (skip_prev: the layer's first roots — the previous layer's — are not requested again, so
+    // the slots hold at most the roots that are new in this layer)
+    const size_t Sb = root_bound(std::max<size_t>(slot_roots, 1), layer) -
+                      ((skip_prev && layer > 0) ? root_bound(std::max<size_t>(slot_roots, 1), layer - 1) : 0);
     const double share = std::ceil(static_cast<double>(Sb) * slack / world_size);
     const size_t cap = std::max<size_t>(1, std::min<size_t>(Sb, static_cast<size_t>(share)));
     stride = cap + 1;
@@ -2597,11 +2600,12 @@ void part_host_us(double out[8], bool reset) {
 // fanout <= 256).  Layout of the shared workspace of layer l, rows of 16 B (requests) and
 // fanout x 24 B (replies):  [m P slots of `stride` rows | own share 0 | ... | own share m-1].
 size_t Sampler::group_ws_bytes(const Sampler& a, const size_t* R, int m, int world, double slack,
-                               size_t slot_roots, bool narrow, double edge_fill) {
+                               size_t slot_roots, bool narrow, double edge_fill, bool reuse_roots) {
   size_t total = 0;
   for (size_t l = 0; l < a.fanouts_.size(); ++l) {
     GroupLayout lay;
-    a.group_layout(R, m, static_cast<uint32_t>(l), world, slack, slot_roots, narrow, edge_fill, &lay);
+    a.group_layout(R, m, static_cast<uint32_t>(l), world, slack, slot_roots, narrow, edge_fill, &lay,
+                   reuse_roots);
     total += lay.total;
   }
   return total;
@@ -2621,10 +2625,11 @@ bool Sampler::group_ok(const size_t* R, int m) const {
 
 void Sampler::group_layout(const size_t* R, int m, uint32_t layer, int world, double slack,
                            size_t slot_roots, bool narrow, double edge_fill,
-                           GroupLayout* out) const {
+                           GroupLayout* out, bool reuse_roots) const {
   GF_REQUIRE(m >= 1 && m <= kMaxGroup, "group layout: 1..4 samples");
   gf_part_layout one;
-  part_layout(std::max<size_t>(R[0], 1), layer, world, slack, slot_roots, &one);   // slot stride
+  part_layout(std::max<size_t>(R[0], 1), layer, world, slack, slot_roots, &one,
+              layer_reuses_roots(reuse_roots, layer));   // slot stride
   const size_t F = fanouts_[layer];
   const size_t slot_rows = static_cast<size_t>(m) * world * one.slot_stride;
   size_t bound[kMaxGroup], rows = slot_rows;
@@ -2728,10 +2733,10 @@ void Sampler::sample_partitioned_group(const GroupSample* gs, int m, void* d_ws,
       // neighbours are what the previous block already holds, so they are neither bucketed nor
       // requested nor sampled again — the merge copies their edges out of the previous block
       // (the reference requests every root of every layer, dist_sampler.py:174-186).
-      const bool reuse = reuse_roots && l > 0 && a.policy_ != GF_SAMPLING_POLICY_UNIFORM &&
-                         a.fanouts_[l] == a.fanouts_[l - 1];
+      const bool reuse = a.layer_reuses_roots(reuse_roots, l);
       GroupLayout lay;
-      a.group_layout(Rs, m, static_cast<uint32_t>(l), P, slack, slot_roots, narrow, edge_fill, &lay);
+      a.group_layout(Rs, m, static_cast<uint32_t>(l), P, slack, slot_roots, narrow, edge_fill, &lay,
+                     reuse_roots);
       GF_REQUIRE(off + lay.total <= ws_bytes, "sample_partitioned_group: workspace too small");
       const size_t rb = narrow ? 12 : 24;
       char* base = w + off;

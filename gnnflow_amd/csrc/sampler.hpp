@@ -57,8 +57,9 @@ class Sampler {
   // slack > 0: the slotted form (fixed-capacity slots per peer, equal-split exchange, no count
   // read-back; partition.hip), capacity = slack x the even share of the layer's worst case
   // of a sample that starts from `slot_roots` roots — the same number on every rank
+  // skip_prev: the slots are sized without the previous layer's roots (see group_layout)
   void part_layout(size_t R0, uint32_t layer, int world_size, double slack, size_t slot_roots,
-                   gf_part_layout* out) const;
+                   gf_part_layout* out, bool skip_prev = false) const;
   void part_begin(const int64_t* d_roots, const float* d_ts, size_t R, void* d_out,
                   size_t out_bytes, int world_size, int rank, double slack, size_t slot_roots,
                   hipStream_t stream);
@@ -98,10 +99,18 @@ class Sampler {
   // fixed-fanout records (0: the fixed records themselves travel).  Part of the wire format.
   bool group_ok(const size_t* R, int m) const;
   // narrow: 12-byte reply slots (ids that fit 32 bits; sampler.hip PaddedCommon)
+  // reuse_roots: layer l + 1 does not request layer l's roots again (most-recent, equal
+  // fanouts) — its slots are sized for the roots it still requests.  Part of the wire format.
+  bool layer_reuses_roots(bool reuse_roots, size_t layer) const {
+    return reuse_roots && layer > 0 && policy_ != GF_SAMPLING_POLICY_UNIFORM &&
+           fanouts_[layer] == fanouts_[layer - 1];
+  }
   void group_layout(const size_t* R, int m, uint32_t layer, int world, double slack,
-                    size_t slot_roots, bool narrow, double edge_fill, GroupLayout* out) const;
+                    size_t slot_roots, bool narrow, double edge_fill, GroupLayout* out,
+                    bool reuse_roots = false) const;
   static size_t group_ws_bytes(const Sampler& a, const size_t* R, int m, int world, double slack,
-                               size_t slot_roots, bool narrow, double edge_fill = 0.0);
+                               size_t slot_roots, bool narrow, double edge_fill = 0.0,
+                               bool reuse_roots = false);
   static void sample_partitioned_group(const GroupSample* gs, int m, void* d_ws, size_t ws_bytes,
                                        double slack, size_t slot_roots, Exchange* ex,
                                        hipStream_t stream, unsigned force_overflow = 0,

@@ -761,7 +761,9 @@ class DevicePartitionedSampler:
             # the native layout itself (sampler.hip group_layout), not a restatement of it
             self._capi.check(self._lib.gf_sampler_part_group_slot(
                 self._sampler._h, R0, layer, self._P, self._slack, self._slot_roots,
-                1 if self._narrow else 0, fill, out))
+                (1 if self._narrow else 0) |
+                (2 if (self._reuse_roots and (self.chain_samples > 1 or self._chain_of_one)) else 0),
+                fill, out))
             stride = int(out[0])
             rq = stride * self._S * 16
             rp = self._S * int(out[1])

@@ -552,8 +552,10 @@ GF_API int gf_sampler_part_layout_slotted(const gf_sampler* s, size_t num_roots,
  * native chains use, sampler.hip group_layout): out[0] = rows per request slot (16 B each, header
  * row included), out[1] = bytes of one reply slot (compact: offsets + packed edges; edge_fill 0:
  * the fixed records), out[2] = edges a compact reply slot holds at most, out[3] = bytes of its
- * offsets (2 / 4).  gnnflow_amd.dist.DevicePartitionedSampler.wire_bytes_per_sample reports from
- * this, so the figures in bench.py's line are the native layout's, not a restatement. */
+ * offsets (2 / 4).  narrow: bit 0 = 12-byte reply records, bit 1 = layer l + 1 does not request
+ * layer l's roots again (its slots are sized for the roots that are new in it).
+ * gnnflow_amd.dist.DevicePartitionedSampler.wire_bytes_per_sample reports from this, so the
+ * figures in bench.py's line are the native layout's, not a restatement. */
 GF_API int gf_sampler_part_group_slot(const gf_sampler* s, size_t num_roots, uint32_t layer,
                                       int world_size, double slack, size_t slot_roots, int narrow,
                                       double edge_fill, uint64_t* out);
