@@ -33,7 +33,7 @@ class _Kind:
     """One cache kind (node or edge): C handle + the device-readable feature table."""
 
     def __init__(self, lib, num_ids, capacity, feats: torch.Tensor, dim, device, placement,
-                 policy="lru"):
+                 policy="lru", row_mirror=True):
         self.lib = lib
         self.num_ids, self.capacity, self.dim = int(num_ids), int(capacity), int(dim)
         self.device = device
@@ -52,6 +52,10 @@ class _Kind:
         _capi.check(lib.gf_cache_create(C.byref(self.h), self.num_ids, self.capacity,
                                         self.dim, self.table.data_ptr(), device.index))
         _capi.check(lib.gf_cache_set_policy(self.h, _capi.CACHE_POLICY[policy]))
+        if not row_mirror and placement != "pinned":
+            # the table itself is in HBM: no second copy of the cached rows (include/gnnflow_hip.h
+            # gf_cache_set_row_mirror) — GNNFLOW_CACHE_ROW_MIRROR=1 keeps it (A/B, tests)
+            _capi.check(lib.gf_cache_set_row_mirror(self.h, 0))
 
     def close(self):
         if self.h is not None and self.h.value:
@@ -205,12 +209,14 @@ class Cache:
                                        stub(self.dim_edge_feat), self.dim_edge_feat, device,
                                        "device", self._policy)
             else:
+                mirror = placement == "pinned" or \
+                    os.environ.get("GNNFLOW_CACHE_ROW_MIRROR", "0") == "1"
                 if self.dim_node_feat != 0:
                     self._node = _Kind(self._lib, num_nodes, self.node_capacity, node_feats,
-                                       self.dim_node_feat, device, placement, self._policy)
+                                       self.dim_node_feat, device, placement, self._policy, mirror)
                 if self.dim_edge_feat != 0:
                     self._edge = _Kind(self._lib, num_edges, self.edge_capacity, edge_feats,
-                                       self.dim_edge_feat, device, placement, self._policy)
+                                       self.dim_edge_feat, device, placement, self._policy, mirror)
         self._stats_span = None
         self._target_edge_thunk = None
         self.num_gather_launches = 0   # gather launches issued so far (one per round)

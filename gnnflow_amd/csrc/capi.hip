@@ -682,6 +682,9 @@ int gf_cache_fetch_blocks_async(gf_cache* node_cache, gf_cache* edge_cache,
     });
   });
 }
+int gf_cache_set_row_mirror(gf_cache* c, int on) {
+  return guarded([&] { GF_C(c); c->impl.set_row_mirror(on != 0); });
+}
 int gf_debug_lru_trace_enable(gf_cache* c, int on) {
   return guarded([&] { GF_C(c); c->impl.lru_trace_enable(on != 0); });
 }

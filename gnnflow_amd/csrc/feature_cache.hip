@@ -327,7 +327,9 @@ __device__ inline void gather_body(const Ctx& c) {
         slot = c.map ? c.map[id] : -1;
         const int32_t claim = slot;   // a missed id of a planned pull: -(representative row + 1)
         if (slot >= 0) {
-          src = cache_buf + static_cast<uint64_t>(slot) * rowu;
+          // (no row mirror — table in HBM, gf_cache_set_row_mirror: a hit is the table's row too)
+          src = c.cache_buf ? cache_buf + static_cast<uint64_t>(slot) * rowu
+                            : feats + static_cast<uint64_t>(id) * rowu;
           // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
           // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161).
           if (!kLean && c.qmode) {
@@ -1144,7 +1146,7 @@ __device__ inline void install_body(const Ctx& c) {
     __syncthreads();
     // copy the installed rows out of the block's output; the workgroup sweeps the m rows as
     // one flat array so that all of them are in flight together
-    const uint32_t total = n_inst * c.dimv;
+    const uint32_t total = cache_buf ? n_inst * c.dimv : 0u;   // (no row mirror: ids only)
     for (uint32_t f = threadIdx.x; f < total; f += kTile) {
       const uint32_t i = f / c.dimv, cc = f - i * c.dimv;
       const uint2 p = inst[i];
@@ -1529,6 +1531,7 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* ws, uint32_t* t
 template <typename VecT, int K, uint32_t kBlock = kWide>
 __device__ inline void copy_installed(const Ctx& c, const uint2* inst, const int64_t* inst_id,
                                       uint32_t n_inst, uint32_t rowf, int tid) {
+  if (!c.cache_buf) return;   // no row mirror: the slots hold ids only
   const uint32_t total = n_inst * c.dimv;
   const bool table = c.inst_from_table != 0;
 #pragma unroll 1
@@ -1696,7 +1699,7 @@ __global__ __launch_bounds__(kQInst) void lru_queue_install_kernel(Round r) {
     } else if (c.odd4) {
       copy_installed<uf4, 8, kQInst>(c, inst, inst_id, n_inst, c.dim, tid);
     } else {
-      const uint32_t total = n_inst * c.dimv;
+      const uint32_t total = c.cache_buf ? n_inst * c.dimv : 0u;
       for (uint32_t f = tid; f < total; f += kQInst) {
         const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
         const uint2 pr = inst[j];
@@ -1822,7 +1825,7 @@ __global__ __launch_bounds__(kWide) void lru_list_install_kernel(Round r, uint32
         if (c.inst_rows > kInstRows) copy_installed<uf4, 6>(c, inst, inst_id, n_inst, c.dim, tid);
         else copy_installed<uf4, 2>(c, inst, inst_id, n_inst, c.dim, tid);
       } else {
-        for (uint32_t f = tid; f < total; f += kWide) {
+        for (uint32_t f = tid; c.cache_buf && f < total; f += kWide) {
           const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
           const uint2 pr = inst[j];
           c.cache_buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] =
@@ -2230,7 +2233,7 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
       if (c.fuse_rows > kInstRows) copy_installed<uf4, 6>(c, inst, inst_id, n_inst, c.dim, tid);
       else copy_installed<uf4, 2>(c, inst, inst_id, n_inst, c.dim, tid);
     } else {
-      for (uint32_t f = tid; f < total; f += kWide) {
+      for (uint32_t f = tid; c.cache_buf && f < total; f += kWide) {
         const uint32_t j = f / c.dimv, cc = f - j * c.dimv;
         const uint2 pr = inst[j];
         c.cache_buf[static_cast<uint64_t>(pr.x) * c.dimv + cc] =
@@ -3114,7 +3117,7 @@ void FeatureCache::init(hipStream_t stream) {
   epoch_ = 0;
   rewind_fifo(stream);
   init_queue(stream);
-  if (capacity_)
+  if (capacity_ && mirror_)
     GF_HIP(hipMemcpyAsync(buffer_.data(), feats_, capacity_ * dim_ * sizeof(float),
                           hipMemcpyDefault, stream));
 }
@@ -3247,7 +3250,7 @@ __global__ void cache_install_ids_kernel(const int64_t* __restrict__ ids, uint64
     const int64_t id = ids[s];
     if (id < 0 || static_cast<uint64_t>(id) >= num_ids) continue;
     if (lane == 0) { map[id] = static_cast<int32_t>(s); slot_id[s] = id; }
-    for (uint32_t c = lane; c < dim; c += 64)
+    for (uint32_t c = lane; buffer && c < dim; c += 64)
       buffer[s * dim + c] = rows ? rows[s * dim + c] : feats[static_cast<uint64_t>(id) * dim + c];
   }
 }
@@ -3269,7 +3272,7 @@ void FeatureCache::init_ids(const int64_t* d_ids, size_t n, hipStream_t stream,
     const unsigned grid = static_cast<unsigned>(std::min<size_t>((n + 3) / 4, 4096));
     cache_install_ids_kernel<<<dim3(grid), dim3(256), 0, stream>>>(
         d_ids, n, num_ids_, static_cast<uint32_t>(dim_), feats_, d_rows, map_.as<int32_t>(),
-        slot_id_.as<int64_t>(), buffer_.as<float>());
+        slot_id_.as<int64_t>(), mirror_ ? buffer_.as<float>() : nullptr);
   }
   GF_HIP(hipGetLastError());
 }
@@ -3285,6 +3288,8 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
   if (d_feats) {
     feats_ = d_feats;
     table_on_device_ = pointer_on_device(d_feats);
+    GF_REQUIRE(mirror_ || table_on_device_,
+               "cache: a table in host memory needs the row mirror (gf_cache_set_row_mirror)");
   }
   if (policy_ == GF_CACHE_LRU && new_capacity > capacity_) compact_queue(stream);   // dense list
   if (new_num_ids > num_ids_) {
@@ -3299,8 +3304,9 @@ void FeatureCache::resize(size_t new_num_ids, size_t new_capacity, const float* 
     std::swap(map_, nmap);
   }
   if (new_capacity > capacity_) {
-    buffer_.reserve(new_capacity * dim_ * sizeof(float), capacity_ * dim_ * sizeof(float),
-                    stream, true);
+    if (mirror_)
+      buffer_.reserve(new_capacity * dim_ * sizeof(float), capacity_ * dim_ * sizeof(float),
+                      stream, true);
     DeviceBuffer nid, nst, ntc;
     nid.reserve(new_capacity * sizeof(int64_t));
     nst.reserve(new_capacity * sizeof(uint32_t));
@@ -3421,7 +3427,7 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
   char* qscratch = reinterpret_cast<char*>(align_up(reinterpret_cast<uintptr_t>(p), 256));
   c.ids = d_ids;
   c.n = static_cast<uint32_t>(n);
-  c.vec4 = vec4_ok(dim_, buffer_.data(), feats_, d_out) ? 1 : 0;
+  c.vec4 = vec4_ok(dim_, mirror_ ? buffer_.data() : feats_, feats_, d_out) ? 1 : 0;
   c.dimv = static_cast<uint32_t>(c.vec4 ? dim_ / 4 : dim_);
   c.inst_from_table = table_on_device_ ? 1 : 0;
   set_odd4(c, dim_, policy_ == GF_CACHE_LRU || !update || capacity_ == 0);
@@ -3431,7 +3437,7 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
   c.feats = feats_;
   c.num_ids = num_ids_;
   c.map = capacity_ ? map_.as<int32_t>() : nullptr;
-  c.cache_buf = buffer_.as<float>();
+  c.cache_buf = mirror_ ? buffer_.as<float>() : nullptr;
   c.slot_id = slot_id_.as<int64_t>();
   c.stamp = stamp_.as<uint32_t>();
   c.touched = touched_.as<uint32_t>();
@@ -3556,6 +3562,7 @@ void FeatureCache::fetch_pulled(const int64_t* d_ids, size_t n, float* d_out, bo
                                 const uint32_t* d_miss_index, hipStream_t stream) {
   if (n == 0) return;
   GF_REQUIRE(d_miss_rows && d_miss_index, "cache fetch: null pulled rows");
+  GF_REQUIRE(mirror_, "cache fetch: pulled rows need the row mirror (gf_cache_set_row_mirror)");
   DeviceGuard dg(device_);
   Round r;
   r.count = 1;
@@ -3820,6 +3827,8 @@ void fetch_blocks_pulled(FeatureCache* node, FeatureCache* edge, const gf_fetch_
   for (size_t i = 0; i < n; ++i) {
     const gf_fetch_pulled_desc& d = descs[i];
     GF_REQUIRE(d.kind == 0 || d.kind == 1, "fetch_blocks_pulled: kind must be 0 (node) or 1 (edge)");
+    GF_REQUIRE((d.kind == 0 ? node : edge) == nullptr || (d.kind == 0 ? node : edge)->mirror_,
+               "fetch_blocks_pulled: pulled rows need the row mirror");
     if (d.n == 0) continue;
     GF_REQUIRE(d.d_pulled_rows && d.d_req_pos, "fetch_blocks_pulled: null pulled rows");
     GF_REQUIRE((d.kind == 0 ? node : edge) != nullptr, "fetch_blocks_pulled: block without its cache");
@@ -4039,8 +4048,31 @@ uint64_t lru_recounts() {
 }
 
 size_t FeatureCache::mem_bytes() const {
-  return capacity_ * dim_ * sizeof(float) + num_ids_ * sizeof(int32_t) +
+  return (mirror_ ? capacity_ * dim_ * sizeof(float) : 0) + num_ids_ * sizeof(int32_t) +
          capacity_ * (sizeof(int64_t) + 2 * sizeof(uint32_t));
+}
+
+// The cached rows' copy in HBM (`buffer`).  With the feature table itself in HBM a hit and a miss
+// are the same bytes at the same distance: without the mirror the slots hold ids only, every
+// row is read from the table, an install moves nothing — the replacement state (what the
+// reference's protocol lets a caller observe: hit ratios, which ids are cached) is unchanged.
+void FeatureCache::set_row_mirror(bool on) {
+  DeviceGuard dg(device_);
+  GF_HIP(hipDeviceSynchronize());
+  GF_REQUIRE(on || table_on_device_, "cache: only a table in device memory can do without the row mirror");
+  if (on == mirror_) return;
+  mirror_ = on;
+  if (!on) { buffer_.release(); return; }
+  buffer_.reserve(std::max<size_t>(capacity_ * dim_ * sizeof(float), 16), 0, nullptr, true);
+  // the rows of the ids cached right now
+  if (capacity_) {
+    std::vector<int64_t> ids(capacity_);
+    GF_HIP(hipMemcpy(ids.data(), slot_id_.data(), capacity_ * sizeof(int64_t), hipMemcpyDeviceToHost));
+    for (size_t s2 = 0; s2 < capacity_; ++s2)
+      if (ids[s2] >= 0)
+        GF_HIP(hipMemcpy(buffer_.as<float>() + s2 * dim_, feats_ + static_cast<size_t>(ids[s2]) * dim_,
+                         dim_ * sizeof(float), hipMemcpyDefault));
+  }
 }
 
 }  // namespace gf

@@ -76,6 +76,9 @@ class FeatureCache {
                     uint32_t* d_stats, const float* d_miss_rows, const uint32_t* d_miss_index,
                     hipStream_t stream);
   void set_policy(int policy);
+  // off: no copy of the cached rows (the table is in HBM: hits read it too); see feature_cache.hip
+  void set_row_mirror(bool on);
+  bool row_mirror() const { return mirror_; }
   void reset_order(hipStream_t stream);
   void rewind_fifo(hipStream_t stream);
   void resize(size_t new_num_ids, size_t new_capacity, const float* d_feats, hipStream_t stream);
@@ -123,6 +126,7 @@ class FeatureCache {
   const float* feats_;
   int device_;
   bool table_on_device_ = false;   // the feature table is HBM-resident (not pinned host memory)
+  bool mirror_ = true;             // `buffer_` holds a copy of every cached row
 
   DeviceBuffer buffer_;    // float[capacity * dim]        cache rows
   DeviceBuffer map_;       // int32[num_ids]               id -> slot (kAbsent if none)

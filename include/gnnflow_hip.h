@@ -372,6 +372,14 @@ GF_API int gf_cache_fetch_wait(uint64_t ticket);
  * of HBM the ring and its index take, rows the gathers still read from the host table,
  * microseconds the issuing thread waited for fetches to leave a region before reusing it,
  * fetches (of the process) whose stream had to wait for a pull's event (it had not landed). */
+/* The cached rows' copy in HBM.  on (default): slot s holds a copy of its id's row, a hit reads
+ * it (the reference's cache buffer, gnnflow/cache/cache.py:84-99).  off — only for a feature
+ * table that is itself in device memory: the slots hold ids only, every row is read from the
+ * table (a hit and a miss are the same bytes at the same distance there), an install moves
+ * nothing; hit ratios and the set of cached ids — the state the reference's protocol lets a
+ * caller observe — are unchanged.  gnnflow_amd.cache.Cache turns it off for
+ * feature_placement="device"; pinned / sharded tables keep it. */
+GF_API int gf_cache_set_row_mirror(gf_cache* c, int on);
 /* Diagnostics of the one-launch LRU list update (lru_list_fused_kernel): with tracing on, every
  * workgroup of an update stamps the 100 MHz wall clock at its role's stages; gf_debug_lru_trace
  * copies the last update's stamps out — words [0..3] = count / row / write workgroups and the

@@ -420,3 +420,20 @@ def test_fused_lru_update_fallback_paths():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     last = [l for l in p.stdout.splitlines() if l.startswith("recounts")][-1]
     assert int(last.split()[1]) > 100, last
+
+
+@pytest.mark.parametrize("mirror", ["0", "1"])
+def test_device_tables_with_and_without_the_row_mirror(mirror, monkeypatch):
+    """With the tables in HBM the cache keeps no second copy of the cached rows by default
+    (gf_cache_set_row_mirror: slots hold ids, every row is read from the table, an install moves
+    nothing); GNNFLOW_CACHE_ROW_MIRROR=1 keeps the reference's buffer (cache.py:84-99).  Rows, hit
+    counts and cached-id sets are the oracle's either way; only the memory differs."""
+    from gnnflow_amd.pipeline import ReplayPipeline
+    monkeypatch.setenv("GNNFLOW_CACHE_ROW_MIRROR", mirror)
+    w = _World(900, 64)
+    rows = w.cache.edge_capacity * D * 4 + w.cache.node_capacity * D * 4
+    size = w.cache.get_mem_size()
+    index = 4 * (w.cache.num_nodes + w.cache.num_edges) + 16 * (w.cache.edge_capacity + w.cache.node_capacity)
+    assert size == index + (rows if mirror == "1" else 0)
+    pipe = ReplayPipeline(w.sampler, w.cache, w.dev_batches, w.dev, pipelined=True)
+    _run_chunks(w, pipe, 64, 32)
