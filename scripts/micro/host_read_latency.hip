@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <sys/mman.h>
+#include <chrono>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 __host__ __device__ inline uint64_t mix(uint64_t x) {
@@ -98,6 +99,27 @@ int main(int argc, char** argv) {
       CK(hipEventElapsedTime(&ms, e0, e1));
       CK(hipDeviceSynchronize());
       printf("%-26s HBM chase (1 GB array) beside a pull of %3d workgroups: %6.2f us per hop\n", name, W, ms * 1e3 / 256);
+    }
+    // ... and beside DMA copies of the same host memory (hipMemcpyAsync, 413 KB each, back to back)
+    {
+      chase<<<1, 64, 0, s0>>>(d, out, 0, 4096); CK(hipStreamSynchronize(s0));
+      for (int i = 0; i < 64; ++i)
+        CK(hipMemcpyAsync(dst, reinterpret_cast<const char*>(h) + static_cast<size_t>(i) * 4000000, 412800, hipMemcpyHostToDevice, s1));
+      CK(hipEventRecord(e0, s0));
+      chase<<<1, 64, 0, s0>>>(d, out, 16, 4096);
+      CK(hipEventRecord(e1, s0)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const auto t0 = std::chrono::steady_clock::now();
+      CK(hipDeviceSynchronize());
+      const double tail_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      printf("%-26s HBM chase (4096 hops) beside 64 DMA copies of 413 KB: %6.2f us per hop (chase %.0f us; the copies went on for another %.0f us)\n",
+             name, ms * 1e3 / 4096, ms * 1e3, tail_us);
+      chase<<<1, 64, 0, s0>>>(d, out, 32, 4096); CK(hipStreamSynchronize(s0));
+      CK(hipEventRecord(e0, s0));
+      chase<<<1, 64, 0, s0>>>(d, out, 48, 4096);
+      CK(hipEventRecord(e1, s0)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("%-26s HBM chase (4096 hops) alone, clocks up: %6.2f us per hop\n", name, ms * 1e3 / 4096);
     }
     // the pull's own rate
     for (int W : {8, 64, 256}) {
