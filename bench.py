@@ -1114,6 +1114,11 @@ def main():
         # gone — killed if need be — so no abandoned kernel shares the GPU with this figure)
     if main_kind == "hash" and world > 1:
         out["multi_gpu"] = multi_gpu_record(ctx, sampler, cache)
+    # (before the hash legs: their lanes, clones and communicators create streams, and which
+    # hardware queue a stream lands on depends on how many the process created before it)
+    if rank == 0 and world == 1 and main_kind == "replica" and cache is not None \
+            and not args.no_placement_legs and not sharded:
+        placement_legs(ctx, out, res["sampler"], node_feats, edge_feats)
     if history and main_kind == "replica":
         out["hash_partition"] = {"error": history[0]["error"], "ladder": history,
                                  "fallback": "replica loop timed instead"}
@@ -1154,9 +1159,6 @@ def main():
             bd[name] = {"total_ms": ms.value, "intervals": int(n.value)}
         out["kernel_breakdown_200_steps"] = bd
 
-    if rank == 0 and world == 1 and main_kind == "replica" and cache is not None \
-            and not args.no_placement_legs and not sharded:
-        placement_legs(ctx, out, res["sampler"], node_feats, edge_feats)
     if rank == 0 and world == 1 and not args.no_config3:
         out["config3"] = config3_leg(args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -183,6 +183,7 @@ PROTOTYPES = {
                                                 C.POINTER(GfFetchDesc), _sz, _p, _sz, _sz, _p,
                                                 C.POINTER(C.c_uint64)]),
     "gf_cache_set_row_mirror": (C.c_int, [_p, C.c_int]),
+    "gf_streams_share_queue": (C.c_int, [C.c_int, _p, _p, C.c_uint, C.POINTER(C.c_int)]),
     "gf_debug_lru_trace_enable": (C.c_int, [_p, C.c_int]),
     "gf_debug_lru_trace": (C.c_int, [_p, C.POINTER(C.c_uint64), _sz, C.POINTER(_sz)]),
     "gf_cache_set_staging": (C.c_int, [_p, _sz, _sz]),

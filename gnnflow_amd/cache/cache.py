@@ -420,7 +420,7 @@ class Cache:
         st = self._prefetch_handle
         if st is None:
             from ..pipeline import side_stream
-            self._prefetch_stream = side_stream(self.device, 3)
+            self._prefetch_stream = side_stream(self.device, int(os.environ.get('GNNFLOW_PREFETCH_STREAM_K', '3')))
             st = self._prefetch_handle = C.c_void_p(self._prefetch_stream.cuda_stream)
         # (no record_stream: the blocks stay alive until their own fetch, which is issued after
         # the pull that reads their ids has been)
@@ -545,7 +545,7 @@ class Cache:
             stream = self._prefetch_stream
             if stream is None:
                 from ..pipeline import side_stream
-                stream = self._prefetch_stream = side_stream(dev, 3)
+                stream = self._prefetch_stream = side_stream(dev, int(os.environ.get('GNNFLOW_PREFETCH_STREAM_K', '3')))
         for mfg in mfgs:
             for b in mfg:
                 if hasattr(b, "record_stream"):

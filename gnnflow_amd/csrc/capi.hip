@@ -1093,6 +1093,50 @@ int gf_comm_time_all_to_all(gf_comm* c, size_t bytes_per_peer, int iters, void* 
     *host_us = std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
   });
 }
+namespace {
+__global__ void probe_spin_kernel(unsigned long long ticks) {   // 100 MHz wall clock
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void probe_touch_kernel(unsigned* out) { if (out) *out = 1u; }
+}  // namespace
+int gf_streams_share_queue(int device, void* a, void* b, unsigned spin_us, int* shared) {
+  return guarded([&] {
+    GF_REQUIRE(shared != nullptr, "gf_streams_share_queue: null output");
+    GF_REQUIRE(spin_us >= 20 && spin_us <= 100000, "gf_streams_share_queue: spin_us out of range");
+    gf::DeviceGuard dg(device);
+    hipStream_t sa = static_cast<hipStream_t>(a), sb = static_cast<hipStream_t>(b);
+    hipEvent_t ea = nullptr, eb = nullptr;
+    GF_HIP(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+    GF_HIP(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    GF_HIP(hipStreamSynchronize(sa));
+    GF_HIP(hipStreamSynchronize(sb));
+    int votes = 0;
+    for (int round = 0; round < 3; ++round) {   // (a busy box may delay the small kernel once)
+      probe_spin_kernel<<<dim3(1), dim3(64), 0, sa>>>(static_cast<unsigned long long>(spin_us) * 100ull);
+      GF_HIP(hipEventRecord(ea, sa));
+      probe_touch_kernel<<<dim3(1), dim3(1), 0, sb>>>(nullptr);
+      GF_HIP(hipEventRecord(eb, sb));
+      // b's kernel done while a's still spins -> the two run side by side
+      bool beside = false;
+      for (;;) {
+        const hipError_t qb = hipEventQuery(eb);
+        const hipError_t qa = hipEventQuery(ea);
+        if (qb == hipSuccess && qa == hipErrorNotReady) { beside = true; break; }
+        if (qa == hipSuccess) break;
+        if (qa != hipErrorNotReady) GF_HIP(qa);
+        if (qb != hipSuccess && qb != hipErrorNotReady) GF_HIP(qb);
+      }
+      (void)hipGetLastError();
+      GF_HIP(hipStreamSynchronize(sa));
+      GF_HIP(hipStreamSynchronize(sb));
+      if (beside) ++votes;
+    }
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    *shared = votes >= 2 ? 0 : 1;
+  });
+}
 int gf_device_pci_bus_id(int device, char* out, size_t len) {
   return guarded([&] {
     GF_REQUIRE(out != nullptr && len >= 16, "gf_device_pci_bus_id: output too small");

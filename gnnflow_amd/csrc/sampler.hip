@@ -1595,7 +1595,9 @@ Sampler::Sampler(EdgeStore* graph, const uint32_t* fanouts, size_t num_layers, i
   h_counts_.reserve(kMaxInFlight * rec_words_ * sizeof(uint64_t));
   std::memset(h_counts_.data(), 0, kMaxInFlight * rec_words_ * sizeof(uint64_t));
   h_layer_counts_.reserve(2 * sizeof(uint64_t));
-  GF_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+  // (own_stream_ — the stream of the host-array entry points — is created on first use: every
+  // stream a process creates shifts the hardware-queue placement of the ones created after it,
+  // and a pipelined loop clones its sampler per lane)
 }
 
 Sampler::~Sampler() {
@@ -2939,6 +2941,7 @@ void Sampler::sample_host(const int64_t* nodes, const float* ts, size_t R, gf_bl
   DeviceGuard dg(graph_->device());
   const size_t in_bytes = align_up(R * 8, 16) + align_up(R * 4, 16);
   const size_t out_bytes = output_bytes(R);
+  if (!own_stream_) GF_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   host_io_.reserve(in_bytes + out_bytes, 0, own_stream_);
   char* d = host_io_.as<char>();
   int64_t* d_nodes = reinterpret_cast<int64_t*>(d);
@@ -2969,6 +2972,7 @@ void Sampler::sample_layer_host(const int64_t* nodes, const float* ts, size_t R,
   DeviceGuard dg(graph_->device());
   const size_t in_bytes = align_up(R * 8, 16) + align_up(R * 4, 16);
   const size_t out_bytes = layer_output_bytes(R, layer);
+  if (!own_stream_) GF_HIP(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   host_io_.reserve(in_bytes + out_bytes, 0, own_stream_);
   char* d = host_io_.as<char>();
   int64_t* d_nodes = reinterpret_cast<int64_t*>(d);

@@ -22,18 +22,44 @@ import torch
 _SIDE_STREAMS = {}
 
 
+def _shares_queue(device, a: torch.cuda.Stream, b: torch.cuda.Stream) -> bool:
+    import ctypes as C
+    from . import _capi
+    out = C.c_int(0)
+    _capi.check(_capi.load().gf_streams_share_queue(
+        device.index, C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream), 150, C.byref(out)))
+    return bool(out.value)
+
+
 def side_stream(device, k: int = 0, priority: int = 0) -> torch.cuda.Stream:
-    """The k-th side stream of `device`, created once per process.  HIP maps streams onto a few
-    hardware queues in the order they are created, and two busy streams that land on one queue
-    serialise: a pipeline that made a fresh stream per sampling lane shifted the mapping of
-    every stream created after it (the hash-partitioned loop timed in the same process went
-    from 31.6 to 46.7 us per step).  The pipeline's sampling lanes and the partitioned sampler's
-    lanes therefore take their streams from this one small set."""
+    """The k-th side stream of `device`, created once per process.  HIP spreads its streams over
+    four hardware queues, and two busy streams that land on one queue serialise: a pipeline that
+    made a fresh stream per sampling lane shifted the mapping of every stream created after it
+    (the hash-partitioned loop timed in the same process went from 31.6 to 46.7 us per step), and
+    the staging ring's pull stream, created as the process's fifth stream, shared the FETCH
+    stream's queue (50 us per pinned step against 39).  So a side stream is not taken as it comes:
+    a candidate that shares its queue with the current stream or with a side stream picked before
+    (include/gnnflow_hip.h gf_streams_share_queue: does a small kernel on the one finish while a
+    spinning kernel holds the other?) is set aside and the next one is tried — the four busy
+    streams of a pipelined step (fetch, two sampling lanes, the pull) end up on the four queues
+    whatever else the process created before.  The pipeline's sampling lanes and the partitioned
+    sampler's lanes take their streams from this one small set."""
     device = torch.device(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(k))
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (device.index, int(k))
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+        probe = os.environ.get("GNNFLOW_STREAM_PROBE", "1") != "0" and priority == 0
+        taken = [torch.cuda.current_stream(device)] + \
+            [v for (d, _k), v in _SIDE_STREAMS.items() if d == device.index]
+        rejected = _SIDE_STREAMS.setdefault(("rejected", device.index), [])
+        for _ in range(8 if probe else 1):
+            st = torch.cuda.Stream(device=device, priority=priority)
+            if not probe or len(taken) >= 4 or not any(_shares_queue(device, t, st) for t in taken):
+                break
+            rejected.append(st)     # (kept alive: a stream given back may be handed out again)
+        _SIDE_STREAMS[key] = st
     return st
 
 
@@ -160,7 +186,7 @@ class ReplayPipeline:
             # only (set_staging_lag), so that it finds the event it needs complete when it is
             # issued — a stream that really has to wait for another stream's event loses
             # 12-20 us per hand-over (profiles/README.md, round 6).
-            lead = max(1, min(int(os.environ.get("GNNFLOW_STAGE_LEAD", "1")), 3))
+            lead = max(1, min(int(os.environ.get("GNNFLOW_STAGE_LEAD", "2")), 3))
             ready = deque()           # MFGs waited for and announced, in batch order
             cache.set_staging_lag(0)
             j = first

@@ -617,6 +617,14 @@ GF_API int gf_comm_time_all_to_all(gf_comm* c, size_t bytes_per_peer, int iters,
                                    double* device_us, double* host_us);
 /* PCI bus id of a HIP device ("0000:c1:00.0"), len >= 16. */
 GF_API int gf_device_pci_bus_id(int device, char* out, size_t len);
+/* Do two streams of `device` run on the same hardware queue?  HIP spreads its streams over four
+ * hardware queues and kernels of streams that share one run one after the other: a side stream
+ * meant to work BESIDE another (a sampling lane, the staging ring's pull stream) must not share
+ * its queue.  The probe holds stream `a` with a kernel that spins for `spin_us` microseconds of
+ * wall clock and looks whether a one-thread kernel on stream `b` finishes meanwhile.
+ * *shared = 1: it did not (same queue, or the device would not run the two side by side).
+ * Synchronises both streams.  gnnflow_amd.pipeline.side_stream picks its streams with it. */
+GF_API int gf_streams_share_queue(int device, void* a, void* b, unsigned spin_us, int* shared);
 /* The same exchanges between processes that map each other's device memory (hipIpc*) — the ranks
  * of one node, several ranks SHARING one GPU included (where RCCL refuses to run): a
  * host-synchronising test / single-box transport (copy-out, process barrier over POSIX shared

@@ -9,6 +9,6 @@ ARGS="$*"
 if [ -z "$ARGS" ]; then ARGS="--steps 300 --warmup 10"; fi
 if [ "$ARGS" = "default" ]; then ARGS=""; fi
 mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o $TAG -- python3 bench.py --no-cpu-baseline $ARGS ${BENCH_ARGS} > gpurun_out/prof/${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o $TAG -- python3 bench.py --no-cpu-baseline --no-placement-legs $ARGS ${BENCH_ARGS} > gpurun_out/prof/${TAG}_bench.log 2>&1
 tail -1 gpurun_out/prof/${TAG}_bench.log | cut -c1-400
 python3 scripts/analyze_trace.py $TAG

@@ -8,13 +8,13 @@ shift
 ARGS="${*:---steps 20 --warmup 5}"
 mkdir -p gpurun_out/pmc
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc -o ${TAG}_$C -- python3 bench.py --no-cpu-baseline --no-hash-leg --no-config3 --min-seconds 0.2 $ARGS > gpurun_out/pmc/${TAG}_$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc -o ${TAG}_$C -- python3 bench.py --no-cpu-baseline --no-hash-leg --no-config3 --no-placement-legs --min-seconds 0.2 $ARGS > gpurun_out/pmc/${TAG}_$C.log 2>&1
 done
 ls gpurun_out/pmc | head
 python3 - <<PY
 import csv, collections, re, glob, json
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (one counter per pass) -- python3 bench.py "
-                  "--no-cpu-baseline --no-hash-leg --no-config3 --min-seconds 0.2 $ARGS",
+                  "--no-cpu-baseline --no-hash-leg --no-config3 --no-placement-legs --min-seconds 0.2 $ARGS",
        "kernel": "gather_rows_kernel", "all_kernels": {}}
 for line in open("gpurun_out/pmc/${TAG}_FETCH_SIZE.log"):
     if line.startswith("{"):

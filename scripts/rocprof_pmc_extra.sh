@@ -7,7 +7,7 @@ TAG=${1:-r1}
 mkdir -p gpurun_out/pmc
 for C in "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES_sum" "SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_LDS_ATOMIC"; do
   N=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc -o ${TAG}_$N -- python3 bench.py --no-cpu-baseline --no-pipeline --steps 400 > gpurun_out/pmc/${TAG}_$N.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc -o ${TAG}_$N -- python3 bench.py --no-cpu-baseline --no-placement-legs --no-pipeline --steps 400 > gpurun_out/pmc/${TAG}_$N.log 2>&1
 done
 python3 - <<PY
 import csv, collections, re, glob, json
