@@ -66,7 +66,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
-PMC_TRAFFIC_FILE = "r05_pmc_gather_traffic.json"
+PMC_TRAFFIC_FILE = "r06_pmc_gather_traffic.json"
 
 
 def workload_key(args):
