@@ -593,29 +593,32 @@ __device__ inline void stage_pull_body(const PullJob& j, uint32_t n) {
     VecT* o = dst + static_cast<uint64_t>(row0) * dimv;
     for (uint32_t base = 0; base < total; base += 64u * K) {
       VecT v[K];
-      bool ok[K];
+      uint32_t ok = 0;   // (a bit per load: an array of flags went to scratch)
 #pragma unroll
       for (uint32_t k = 0; k < K; ++k) {
         const uint32_t f = base + lane + 64u * k;
         const uint32_t rr = f < total ? f / dimv : 0u;
         const long long src = __shfl(id, rr, 64);     // (every lane executes the cross-lane read)
-        ok[k] = f < total && src >= 0;
-        if (ok[k]) v[k] = feats[static_cast<uint64_t>(src) * dimv + (f - rr * dimv)];
+        if (f < total && src >= 0) {
+          v[k] = feats[static_cast<uint64_t>(src) * dimv + (f - rr * dimv)];
+          ok |= 1u << k;
+        }
       }
 #pragma unroll
       for (uint32_t k = 0; k < K; ++k)
-        if (ok[k]) o[base + lane + 64u * k] = v[k];
+        if (ok & (1u << k)) o[base + lane + 64u * k] = v[k];
     }
   }
 }
 
 __global__ __launch_bounds__(256) void stage_pull_kernel(PullJobs jobs) {
-  const PullJob& j = jobs.j[blockIdx.y];
+  // (selected, not indexed: a dynamic index into the by-value argument sent it to scratch)
+  const PullJob j = blockIdx.y == 0 ? jobs.j[0] : jobs.j[1];
   const uint32_t n = min(*j.region_rows, j.cap);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *j.next_rows = 0u;   // (prefetch generations run in order on one stream)
   }
-  if (j.vec4) stage_pull_body<float4>(j, n);
+  if (j.vec4) stage_pull_body<nf4>(j, n);   // (the clang vector type: an array of HIP's float4 went to scratch here)
   else stage_pull_body<float>(j, n);
 }
 
