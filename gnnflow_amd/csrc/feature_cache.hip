@@ -556,11 +556,12 @@ __global__ __launch_bounds__(256) void stage_claim_kernel(StageRound r) {
 }
 
 // pull: the rows the claim kernel settled, host table -> this generation's region of the ring.
-// A wave owns 8 consecutive ring rows — one contiguous run of stores — and keeps 6 16-byte loads
+// A wave owns 8 consecutive ring rows — one contiguous run of stores — and keeps 2 16-byte loads
 // per lane in flight over the host link (PCIe round trips are ~2 us: what counts is the number of
-// reads in flight, and every wave of the grid has its own rows — a first version that copied the
-// winners of a 256-row tile inside the claim workgroup took 82 us for the 600 target rows of
-// three workgroups).
+// reads in flight, which the number of waves provides — 6 per lane was 1.3 us per step slower in
+// every grid shape, profiles/r06_pinned_pull_arrangements.txt — and every wave of the grid has
+// its own rows; a first version that copied the winners of a 256-row tile inside the claim
+// workgroup took 82 us for the 600 target rows of three workgroups).
 struct PullJob {
   const long long* ids;        // [cap] (-1: unused row)
   const float* feats;
@@ -577,7 +578,7 @@ struct PullJobs {
 
 template <typename VecT>
 __device__ inline void stage_pull_body(const PullJob& j, uint32_t n) {
-  constexpr uint32_t kRows = 8, K = 6;
+  constexpr uint32_t kRows = 8, K = 2;
   constexpr uint32_t kPer = sizeof(VecT) / sizeof(float);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
@@ -3719,7 +3720,7 @@ bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc
       most = std::max(most, std::min<size_t>(edge_rows, edge->stage_cap_));
     }
     // 8 rows per wave, 4 waves per workgroup; the kernel reads the rows really claimed
-    // (grid-stride: 64 workgroups = 256 waves x 6 loads in flight cover the link's latency)
+    // (grid-stride: 64 workgroups = 256 waves x 2 loads in flight cover the link's latency)
     static const size_t max_wgs = [] {
       const char* v = std::getenv("GNNFLOW_STAGE_PULL_WGS");   // tuning
       return v ? static_cast<size_t>(std::max(1, std::atoi(v))) : size_t{64};
