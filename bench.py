@@ -1002,7 +1002,9 @@ def main():
         out["roofline"] = {
             "bound": "hbm",
             "kernel": "gather_rows_any_kernel" if not lean else
-            ("gather_rows_staged_kernel" if cache.staging else "gather_rows_kernel"),
+            ("gather_rows_staged_kernel" if cache.staging else
+             "gather_rows_mirror_kernel" if os.environ.get("GNNFLOW_CACHE_ROW_MIRROR") == "1"
+             else "gather_rows_kernel"),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             # PMC counters cannot be read inside this process: `traffic` stays null in the run,

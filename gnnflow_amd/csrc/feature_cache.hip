@@ -267,6 +267,19 @@ __device__ inline void nt_store(const float4& v, float4* p) {
   __builtin_nontemporal_store(t, reinterpret_cast<nf4*>(p));
 }
 
+// loads through a pointer known to be global memory (global_load_*, not flat_load_*)
+template <typename VecT> __device__ inline VecT global_load(const void* p);
+template <> __device__ inline float global_load<float>(const void* p) {
+  return *(const __attribute__((address_space(1))) float*)p;
+}
+template <> __device__ inline uf4 global_load<uf4>(const void* p) {
+  return *(const __attribute__((address_space(1))) uf4*)p;
+}
+template <> __device__ inline float4 global_load<float4>(const void* p) {
+  const nf4 t = *(const __attribute__((address_space(1))) nf4*)p;
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+
 template <typename VecT> __device__ inline VecT vec_zero();
 template <> __device__ inline uf4 vec_zero<uf4>() { return uf4{0.f, 0.f, 0.f, 0.f}; }
 // (streaming, like the float4 rows: GDELT-shaped step 257 -> 233 us of gather per step; writing
@@ -284,7 +297,8 @@ constexpr uint32_t kRepHit = 1u << 30, kRepPos = kRepHit - 1u;
 // ---- the gather kernel -------------------------------------------------------------
 // kLean: the instantiation for rounds of float4 rows on list-form / cache-free contexts with
 // the default 12 loads in flight (no queue-form hit path, one copy loop)
-template <typename VecT, bool kOdd = false, bool kLean = false, bool kStaged = !kLean>
+template <typename VecT, bool kOdd = false, bool kLean = false, bool kStaged = !kLean,
+          bool kDirect = false>
 __device__ inline void gather_body(const Ctx& c) {
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * kThreads + threadIdx.x;
@@ -314,6 +328,10 @@ __device__ inline void gather_body(const Ctx& c) {
   const uint32_t tiles = (n + tile_rows - 1) / tile_rows;
   uint32_t acc_hits = 0, acc_miss = 0;   // wave-uniform
   uint32_t acc_host = 0;                 // rows read from the host table (staged contexts)
+  // direct: every row comes from feats[id] whatever the probe says (table in HBM, no row mirror,
+  // no pulled rows, no staging ring) — the probe then only feeds the counters and the marks
+  // (a template parameter: the two orders in one instantiation cost 180 instead of 104 VGPRs)
+  constexpr bool direct = kDirect;
   for (uint32_t tile = wave; tile < tiles; tile += num_waves) {
     const uint32_t row0 = tile * tile_rows;
     const uint32_t rows = min(tile_rows, n - row0);
@@ -321,58 +339,17 @@ __device__ inline void gather_body(const Ctx& c) {
     int32_t slot = -2;
     uint32_t hit_code = 0;
     bool from_host = false;   // staged context: the row is read from the host table after all
+    int64_t id = -1;
+    bool known = false;
     if (lane < static_cast<int>(rows)) {
-      const int64_t id = c.ids[row0 + lane];
-      if (id >= 0 && static_cast<uint64_t>(id) < c.num_ids) {
+      id = c.ids[row0 + lane];
+      known = id >= 0 && static_cast<uint64_t>(id) < c.num_ids;
+      if (known) {
         slot = c.map ? c.map[id] : -1;
-        const int32_t claim = slot;   // a missed id of a planned pull: -(representative row + 1)
-        if (slot >= 0) {
-          // (no row mirror — table in HBM, gf_cache_set_row_mirror: a hit is the table's row too)
-          src = c.cache_buf ? cache_buf + static_cast<uint64_t>(slot) * rowu
-                            : feats + static_cast<uint64_t>(id) * rowu;
-          // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
-          // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161).
-          if (!kLean && c.qmode) {
-            // queue form: the mark is the bit of the entry's queue position; the row whose
-            // atomic set it stands for the slot (it will append the slot's new entry)
-            const uint32_t pos = c.qpos[slot], bit = 1u << (pos & 31u);
-            const uint32_t was = atomicOr(&c.qbits[pos >> 5], bit);
-            hit_code = (was & bit) ? 0u : (kRepHit | pos);
-          } else if (c.update && c.policy != GF_CACHE_FIFO) {
-            c.touched[c.policy == GF_CACHE_LRU ? c.qpos[slot] : slot] = c.epoch_new;
-          }
-        } else {
-          slot = -1;
-          if (c.miss_rows) {
-            const uint32_t at = c.req_pos
-                ? c.req_pos[c.map ? static_cast<uint32_t>(-(claim + 1)) : row0 + lane]
-                : c.miss_index[row0 + lane];
-            src = reinterpret_cast<const Unit*>(c.miss_rows) + static_cast<uint64_t>(at) * rowu;
-          } else if (c.remap) {
-            int32_t local = c.remap[id];
-            if (local < 0) { *c.flag = 1u; local = 0; }
-            src = feats + static_cast<uint64_t>(local) * rowu;
-          } else {
-            src = feats + static_cast<uint64_t>(id) * rowu;
-            if (kStaged && c.pmap) {
-              const unsigned long long p = c.pmap[id];
-              const uint32_t g = static_cast<uint32_t>(p >> 32);
-              if (g - c.st_lo <= c.st_span)
-                src = reinterpret_cast<const Unit*>(c.ring) +
-                      (static_cast<uint64_t>(g & c.st_mask) * c.st_cap + static_cast<uint32_t>(p)) * rowu;
-              else
-                from_host = true;
-            }
-          }
-          if (c.update) atomicMax(&c.map[id], -static_cast<int32_t>(row0 + lane + 1));
-        }
+        if (direct) src = feats + static_cast<uint64_t>(id) * rowu;
       }
-      if (c.slot_of_row) c.slot_of_row[row0 + lane] = slot;
     }
-    acc_hits += __popcll(__ballot(slot >= 0));
-    acc_miss += __popcll(__ballot(slot == -1));
-    if (kStaged && c.pmap) acc_host += __popcll(__ballot(from_host));
-    const uint64_t src_bits = reinterpret_cast<uint64_t>(src);
+    uint64_t src_bits = reinterpret_cast<uint64_t>(src);
     const uint32_t total = rows * dimv;
     Unit* o = out + static_cast<uint64_t>(row0) * rowu;
     // The loop trip count is wave-uniform and every lane executes the cross-lane read:
@@ -387,15 +364,28 @@ __device__ inline void gather_body(const Ctx& c) {
       const uint32_t off = kOdd ? min(cc * kVF, rowu - kVF) : cc * kVF;
       *at = r * rowu + off;   // where it goes, in Units from the tile's first row
       const Unit* s = reinterpret_cast<const Unit*>(__shfl(src_bits, r, 64));
-      return (*valid && s) ? *reinterpret_cast<const VecT*>(s + off) : vec_zero<VecT>();
+      // An unconditional GLOBAL load (a lane with nothing to read reads the tile's first output
+      // row): a load under a per-lane branch, or a flat one — the pointer went through a
+      // cross-lane read and lost its address space — makes the compiler wait for ALL loads in
+      // flight (s_waitcnt vmcnt(0)) wherever it needs one of them.
+      const bool take = *valid && s != nullptr;
+      const VecT x = global_load<VecT>(take ? s + off : o);
+      return take ? x : vec_zero<VecT>();
     };
+    // direct context: the first trip's row loads are issued here, right behind the map load and
+    // before anything looks at its result — the chain is launch -> ids -> rows -> stores, the
+    // probe (map -> marks / claims, which only the update reads) hangs off its side
+    constexpr int K0 = 12;
+    VecT v0[K0];
+    bool p0[K0];
+    uint32_t at0[K0];
+    constexpr bool early = direct;   // (a direct body runs with 12 loads in flight: the callers)
     // K independent 16-byte loads in flight per lane, then the stores.  (12 covers a whole
     // 16-row tile of 172-d rows in one trip; measured 14.8-14.9 us per launch against 15.5-15.7
-    // with 4 on the same box — the launch is bound by its dependent chain launch -> ids -> map
-    // -> rows -> stores, not by memory-level parallelism.)
-    auto copy = [&](auto kk) {
+    // with 4 on the same box.)
+    auto copy = [&](auto kk, uint32_t first) {
       constexpr int K = decltype(kk)::value;
-      for (uint32_t base = 0; base < total; base += 64 * K) {
+      for (uint32_t base = first; base < total; base += 64 * K) {
         VecT v[K];
         bool p[K];
         uint32_t at[K];
@@ -410,9 +400,73 @@ __device__ inline void gather_body(const Ctx& c) {
           if (p[k]) nt_store(v[k], reinterpret_cast<VecT*>(o + at[k]));
       }
     };
-    if (kLean || c.inflight >= 12) copy(std::integral_constant<int, 12>{});
-    else if (c.inflight >= 8) copy(std::integral_constant<int, 8>{});
-    else copy(std::integral_constant<int, 4>{});
+    if (early) {
+      // ... and stored as they arrive; the probe's result is looked at behind the copy
+#pragma unroll
+      for (int k = 0; k < K0; ++k) v0[k] = load(lane + 64 * k, &p0[k], &at0[k]);
+#pragma unroll
+      for (int k = 0; k < K0; ++k)
+        if (p0[k]) nt_store(v0[k], reinterpret_cast<VecT*>(o + at0[k]));
+      copy(std::integral_constant<int, 12>{}, 64u * K0);
+    }
+    if (known) {
+      const int32_t claim = slot;   // a missed id of a planned pull: -(representative row + 1)
+      if (slot >= 0) {
+        // (no row mirror — table in HBM, gf_cache_set_row_mirror: a hit is the table's row too)
+        if (!direct)
+          src = c.cache_buf ? cache_buf + static_cast<uint64_t>(slot) * rowu
+                            : feats + static_cast<uint64_t>(id) * rowu;
+        // a hit is recorded (LRU: refreshes the slot, LFU: counts a use) but takes effect
+        // only if the block also misses; FIFO ignores hits (fifo_cache.py:77-161).
+        if (!kLean && c.qmode) {
+          // queue form: the mark is the bit of the entry's queue position; the row whose
+          // atomic set it stands for the slot (it will append the slot's new entry)
+          const uint32_t pos = c.qpos[slot], bit = 1u << (pos & 31u);
+          const uint32_t was = atomicOr(&c.qbits[pos >> 5], bit);
+          hit_code = (was & bit) ? 0u : (kRepHit | pos);
+        } else if (c.update && c.policy != GF_CACHE_FIFO) {
+          c.touched[c.policy == GF_CACHE_LRU ? c.qpos[slot] : slot] = c.epoch_new;
+        }
+      } else {
+        slot = -1;
+        if (direct) {
+        } else if (c.miss_rows) {
+          const uint32_t at = c.req_pos
+              ? c.req_pos[c.map ? static_cast<uint32_t>(-(claim + 1)) : row0 + lane]
+              : c.miss_index[row0 + lane];
+          src = reinterpret_cast<const Unit*>(c.miss_rows) + static_cast<uint64_t>(at) * rowu;
+        } else if (c.remap) {
+          int32_t local = c.remap[id];
+          if (local < 0) { *c.flag = 1u; local = 0; }
+          src = feats + static_cast<uint64_t>(local) * rowu;
+        } else {
+          src = feats + static_cast<uint64_t>(id) * rowu;
+          if (kStaged && c.pmap) {
+            const unsigned long long p = c.pmap[id];
+            const uint32_t g = static_cast<uint32_t>(p >> 32);
+            if (g - c.st_lo <= c.st_span)
+              src = reinterpret_cast<const Unit*>(c.ring) +
+                    (static_cast<uint64_t>(g & c.st_mask) * c.st_cap + static_cast<uint32_t>(p)) * rowu;
+            else
+              from_host = true;
+          }
+        }
+        if (c.update) atomicMax(&c.map[id], -static_cast<int32_t>(row0 + lane + 1));
+      }
+    }
+    if (lane < static_cast<int>(rows) && c.slot_of_row) c.slot_of_row[row0 + lane] = slot;
+    acc_hits += __popcll(__ballot(slot >= 0));
+    acc_miss += __popcll(__ballot(slot == -1));
+    if (kStaged && c.pmap) acc_host += __popcll(__ballot(from_host));
+    if (!direct) src_bits = reinterpret_cast<uint64_t>(src);
+    if (early) {
+    } else if (kLean || c.inflight >= 12) {
+      copy(std::integral_constant<int, 12>{}, 0u);
+    } else if (c.inflight >= 8) {
+      copy(std::integral_constant<int, 8>{}, 0u);
+    } else {
+      copy(std::integral_constant<int, 4>{}, 0u);
+    }
     // (behind the copy: the atomic's return value has long arrived)
     if (!kLean && c.qmode && lane < static_cast<int>(rows)) c.rep_flag[row0 + lane] = hit_code;
   }
@@ -441,18 +495,34 @@ __device__ inline void gather_body(const Ctx& c) {
 
 // Every kind of row and context: float4 rows, odd widths (16-byte vectors at 4-byte alignment),
 // scalar rows; list-form, queue-form and cache-free contexts; 4 / 8 / 12 loads in flight.
+__device__ inline bool ctx_direct(const Ctx& c) {
+  return !c.cache_buf && !c.miss_rows && !c.remap && !c.pmap;
+}
 __global__ __launch_bounds__(kThreads) void gather_rows_any_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
   if (c.n == 0) return;
+  if (ctx_direct(c) && c.inflight >= 12) {
+    if (c.vec4) gather_body<float4, false, false, false, true>(c);
+    else if (c.odd4) gather_body<uf4, true, false, false, true>(c);
+    else gather_body<float, false, false, false, true>(c);
+    return;
+  }
   if (c.vec4) gather_body<float4>(c);
   else if (c.odd4) gather_body<uf4, true>(c);
   else gather_body<float>(c);
 }
 
 // The same for rounds whose contexts ALL take the float4 / list-form or cache-free / 12-in-flight
-// path (the headline replay; launch_round picks): a third of the code and 104 instead of 138
-// VGPRs (4 waves per SIMD) — same-box A/B in profiles/README, round 5
+// path (launch_round picks): a third of the code and 104-128 instead of 138 VGPRs (4 waves per
+// SIMD) — same-box A/B in profiles/README, round 5.  gather_rows_kernel: every context direct
+// (tables in HBM, no row mirror: the headline replay); _mirror_: rows come from wherever the probe
+// says (row mirror, pulled rows, remapped local rows).
 __global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
+  const Ctx& c = r.c[blockIdx.y];
+  if (c.n == 0) return;
+  gather_body<float4, false, true, false, true>(c);
+}
+__global__ __launch_bounds__(kThreads) void gather_rows_mirror_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
   if (c.n == 0) return;
   gather_body<float4, false, true>(c);
@@ -2649,13 +2719,20 @@ void launch_round(Round& r, hipStream_t stream) {
     }
   }
   {
-    bool lean = true, staged = false;
+    bool lean = true, staged = false, direct = true;
     for (int i = 0; i < r.count; ++i) {
-      lean = lean && r.c[i].vec4 && !r.c[i].qmode && r.c[i].inflight >= 12;
-      staged = staged || r.c[i].pmap != nullptr;
+      const Ctx& c = r.c[i];
+      lean = lean && c.vec4 && !c.qmode && c.inflight >= 12;
+      staged = staged || c.pmap != nullptr;
+      direct = direct && !c.cache_buf && !c.miss_rows && !c.remap && !c.pmap;
     }
+    static const bool direct_on = [] {
+      const char* v = std::getenv("GNNFLOW_GATHER_DIRECT");   // A/B
+      return !(v && std::atoi(v) == 0);
+    }();
     auto* kernel = !lean ? gather_rows_any_kernel
-                         : (staged ? gather_rows_staged_kernel : gather_rows_kernel);
+                 : staged ? gather_rows_staged_kernel
+                 : (direct && direct_on) ? gather_rows_kernel : gather_rows_mirror_kernel;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile_begin(kProfGather, &e0, &e1)) {
       // the events ride on the dispatch itself: its begin / end timestamps
