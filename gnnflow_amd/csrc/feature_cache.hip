@@ -442,7 +442,12 @@ __device__ inline void gather_body(const Ctx& c) {
         } else {
           src = feats + static_cast<uint64_t>(id) * rowu;
           if (kStaged && c.pmap) {
-            const unsigned long long p = c.pmap[id];
+            // {newest entry, the one before it}: an id that a generation running beside this
+            // launch stages AGAIN is still readable where it was (the GDELT-shaped node block,
+            // every id a dozen times per block, sent 7 k rows per step to the host otherwise)
+            const ulonglong2 pq = reinterpret_cast<const ulonglong2*>(c.pmap)[id];
+            const bool newest = static_cast<uint32_t>(pq.x >> 32) - c.st_lo <= c.st_span;
+            const unsigned long long p = newest ? pq.x : pq.y;
             const uint32_t g = static_cast<uint32_t>(p >> 32);
             if (g - c.st_lo <= c.st_span)
               src = reinterpret_cast<const Unit*>(c.ring) +
@@ -541,7 +546,8 @@ __global__ __launch_bounds__(kThreads) void gather_rows_staged_kernel(Round r) {
 // while batch i is fetched (ReplayPipeline), so a kernel on a side stream pulls the table rows of
 // the ids that are not cached into a ring in HBM — over PCIe, beside the fetch chain — and the
 // gather then takes a missed row from the ring.  The ring is G regions of C rows, one region per
-// prefetch GENERATION; pmap[id] = {generation, row in its region}.  A prefetch stages an id only
+// prefetch GENERATION; pmap[id] = {generation, row in its region} of the newest staging of id and
+// of the one before it.  A prefetch stages an id only
 // if it is neither cached (nor claimed by the fetch in flight) nor staged in a generation that is
 // still readable, so a row pulled for one batch (the batch's own target edges, above all: the next
 // batches sample exactly those) serves the misses of the next G - D - 1 batches too.  It is a
@@ -599,7 +605,7 @@ __global__ __launch_bounds__(256) void stage_claim_kernel(StageRound r) {
           maybe = at < c.risk;
         }
         if (maybe) {
-          p = c.pmap[id];
+          p = c.pmap[2 * id];
           want = static_cast<uint32_t>(p >> 32) - c.lo > span;
         }
       }
@@ -616,7 +622,9 @@ __global__ __launch_bounds__(256) void stage_claim_kernel(StageRound r) {
     const unsigned long long mine = (static_cast<unsigned long long>(c.gen) << 32) | pos;
     long long staged = -1;   // a row of the region that nobody reads is not pulled either
     for (;;) {
-      const unsigned long long old = atomicCAS(&c.pmap[id], p, mine);
+      // (the entry it replaces stays behind it: launches already in flight read the id there)
+      c.pmap[2 * id + 1] = p;
+      const unsigned long long old = atomicCAS(&c.pmap[2 * id], p, mine);
       if (old == p) { staged = id; break; }
       if (static_cast<uint32_t>(old >> 32) - c.lo <= span) break;   // another row of this id was first
       p = old;
@@ -646,38 +654,46 @@ struct PullJobs {
   int count;
 };
 
-template <typename VecT>
+// kOdd: rows whose width is not a multiple of 4 floats move as 16-byte vectors at 4-byte alignment,
+// the last one ending with the row (as the gather's odd path: GDELT's 186-d / 413-d rows went as
+// single floats at first — 256 B per load on the link)
+template <typename VecT, bool kOdd, uint32_t K>
 __device__ inline void stage_pull_body(const PullJob& j, uint32_t n) {
-  constexpr uint32_t kRows = 8, K = 2;
-  constexpr uint32_t kPer = sizeof(VecT) / sizeof(float);
+  constexpr uint32_t kRows = 8;
+  using Unit = std::conditional_t<kOdd, float, VecT>;
+  constexpr uint32_t kVF = kOdd ? 4u : 1u;   // Units per VecT
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
-  const uint32_t dimv = j.dim / kPer;
-  const VecT* feats = reinterpret_cast<const VecT*>(j.feats);
-  VecT* dst = reinterpret_cast<VecT*>(j.dst);
+  const uint32_t dimv = kOdd ? (j.dim + 3u) / 4u : j.dim / (sizeof(VecT) / sizeof(float));
+  const uint32_t rowu = kOdd ? j.dim : dimv;
+  const Unit* feats = reinterpret_cast<const Unit*>(j.feats);
+  Unit* dst = reinterpret_cast<Unit*>(j.dst);
   for (uint32_t row0 = wave * kRows; row0 < n; row0 += nwaves * kRows) {
     const uint32_t rows = min(kRows, n - row0);
     const long long id = lane < rows ? j.ids[row0 + lane] : -1;
     const uint32_t valid = static_cast<uint32_t>(__popcll(__ballot(id >= 0)));
     if (lane == 0 && valid) atomicAdd(j.pulled, static_cast<unsigned long long>(valid));
     const uint32_t total = rows * dimv;
-    VecT* o = dst + static_cast<uint64_t>(row0) * dimv;
+    Unit* o = dst + static_cast<uint64_t>(row0) * rowu;
     for (uint32_t base = 0; base < total; base += 64u * K) {
       VecT v[K];
-      uint32_t ok = 0;   // (a bit per load: an array of flags went to scratch)
+      uint32_t at[K], ok = 0;   // (a bit per load: an array of flags went to scratch)
 #pragma unroll
       for (uint32_t k = 0; k < K; ++k) {
         const uint32_t f = base + lane + 64u * k;
         const uint32_t rr = f < total ? f / dimv : 0u;
+        const uint32_t cc = f - rr * dimv;
+        const uint32_t off = kOdd ? min(cc * kVF, rowu - kVF) : cc;
+        at[k] = rr * rowu + off;
         const long long src = __shfl(id, rr, 64);     // (every lane executes the cross-lane read)
         if (f < total && src >= 0) {
-          v[k] = feats[static_cast<uint64_t>(src) * dimv + (f - rr * dimv)];
+          v[k] = *reinterpret_cast<const VecT*>(feats + static_cast<uint64_t>(src) * rowu + off);
           ok |= 1u << k;
         }
       }
 #pragma unroll
       for (uint32_t k = 0; k < K; ++k)
-        if (ok & (1u << k)) o[base + lane + 64u * k] = v[k];
+        if (ok & (1u << k)) *reinterpret_cast<VecT*>(o + at[k]) = v[k];
     }
   }
 }
@@ -689,8 +705,10 @@ __global__ __launch_bounds__(256) void stage_pull_kernel(PullJobs jobs) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *j.next_rows = 0u;   // (prefetch generations run in order on one stream)
   }
-  if (j.vec4) stage_pull_body<nf4>(j, n);   // (the clang vector type: an array of HIP's float4 went to scratch here)
-  else stage_pull_body<float>(j, n);
+  // (nf4 / uf4, the clang vector types: an array of HIP's float4 went to scratch here)
+  if (j.vec4) stage_pull_body<nf4, false, 2>(j, n);
+  else if (j.dim >= 4u) stage_pull_body<uf4, true, 2>(j, n);
+  else stage_pull_body<float, false, 6>(j, n);
 }
 
 // ---- planning a pull from sharded feature tables -------------------------------------------
@@ -2965,7 +2983,7 @@ void FeatureCache::set_staging(size_t generations, size_t rows_per_generation) {
   stage_cap_ = static_cast<uint32_t>(rows_per_generation);
   ring_.release();
   ring_.reserve(generations * rows_per_generation * dim_ * sizeof(float) + 16);
-  pmap_.reserve(std::max<size_t>(num_ids_ * sizeof(unsigned long long), 16));
+  pmap_.reserve(std::max<size_t>(2 * num_ids_ * sizeof(unsigned long long), 16));
   region_rows_.reserve(64 * sizeof(uint32_t) + 64);   // + rows pulled, + rows read from the host, + ticket
   region_ids_.release();
   region_ids_.reserve(rows_per_generation * sizeof(long long) + 16);
@@ -3797,7 +3815,7 @@ bool prefetch_blocks(FeatureCache* node, FeatureCache* edge, const gf_fetch_desc
       most = std::max(most, std::min<size_t>(edge_rows, edge->stage_cap_));
     }
     // 8 rows per wave, 4 waves per workgroup; the kernel reads the rows really claimed
-    // (grid-stride: 64 workgroups = 256 waves x 2 loads in flight cover the link's latency)
+    // (grid-stride: 64 workgroups = 256 waves; 192 stretched the GDELT-scale gathers beside the pull from 254 to 578 us)
     static const size_t max_wgs = [] {
       const char* v = std::getenv("GNNFLOW_STAGE_PULL_WGS");   // tuning
       return v ? static_cast<size_t>(std::max(1, std::atoi(v))) : size_t{64};

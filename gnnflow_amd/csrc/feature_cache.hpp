@@ -165,7 +165,7 @@ class FeatureCache {
   // generations that may be pulled while a gather that reads the ring is still running
   static constexpr uint32_t kStageAhead = 4;
   DeviceBuffer ring_;         // float[generations * rows * dim]
-  DeviceBuffer pmap_;         // uint64[num_ids]  {generation, row in its region}; 0: never staged
+  DeviceBuffer pmap_;         // uint64[num_ids][2]  {generation, row in its region} newest, previous; 0: never staged
   DeviceBuffer region_rows_;  // uint32[generations] rows taken per region, + uint64 rows pulled
   DeviceBuffer region_ids_;   // int64[rows] ids claimed for the generation being pulled
   PinnedBuffer progress_;     // uint32: ring-reading launches known to have finished

@@ -25,7 +25,8 @@ class _World:
     """Config 2 on both sides: HIP graph / sampler / cache and their oracles."""
 
     def __init__(self, first_batch, num_batches, policy="recent", fanouts=(10, 10),
-                 cache_ratio=0.2, prefix_alias=True, placement="device", staging=None):
+                 cache_ratio=0.2, prefix_alias=True, placement="device", staging=None,
+                 dims=(D, D)):
         import torch
         import gnnflow_amd
         from gnnflow_amd import synthetic
@@ -44,15 +45,16 @@ class _World:
         self.sampler = gnnflow_amd.TemporalSampler(self.graph, list(fanouts), policy, seed=1234)
         self.osampler = O.OracleSampler(self.ograph, list(fanouts), policy, seed=1234, threads=8)
         rng = np.random.RandomState(7)
-        self.efeat = rng.rand(E, D).astype(np.float32)
-        self.nfeat = rng.rand(N, D).astype(np.float32)
+        dn, de = dims
+        self.efeat = rng.rand(E, de).astype(np.float32)
+        self.nfeat = rng.rand(N, dn).astype(np.float32)
         dev = torch.device("cuda", 0)
         self.cache = LRUCache(cache_ratio, cache_ratio, N, E, dev, torch.from_numpy(self.nfeat),
-                              torch.from_numpy(self.efeat), D, D, feature_placement=placement,
+                              torch.from_numpy(self.efeat), dn, de, feature_placement=placement,
                               staging=staging)
         self.cache.prefix_alias = prefix_alias
         self.cache.init_cache()
-        self.ocache = OracleLRUCache(cache_ratio, cache_ratio, N, E, self.nfeat, self.efeat, D, D)
+        self.ocache = OracleLRUCache(cache_ratio, cache_ratio, N, E, self.nfeat, self.efeat, dn, de)
         self.ocache.init_cache()
         all_batches = list(synthetic.replay_batches(g, 600, seed=42))
         self.host_batches = all_batches[first_batch:first_batch + num_batches]
@@ -314,6 +316,20 @@ def test_pinned_tables_pipelined_replay_bit_exact(staging):
                 print("staging state after", steps, "steps from batch", first_batch, st)
             else:
                 assert st["edge"]["rows_per_generation"] == 64
+
+
+@pytest.mark.parametrize("dims", [(13, 186), (3, 5)])
+def test_pinned_tables_odd_row_widths(dims):
+    """The same with row widths that are no multiple of four floats (GDELT's edge rows are 186-d,
+    gnnflow/config.py:157-167): the pull moves them as 16-byte vectors at 4-byte alignment, the last
+    one ending with the row; rows under four floats go float by float."""
+    from gnnflow_amd.pipeline import ReplayPipeline
+    steps, chunk = 96, 32
+    w = _World(850, steps, placement="pinned", staging="auto", dims=dims)
+    pipe = ReplayPipeline(w.sampler, w.cache, w.dev_batches, w.dev, pipelined=True)
+    _run_chunks(w, pipe, steps, chunk)
+    st = w.cache.staging_state()
+    assert st["edge"]["rows_pulled"] > 0 and st["node"]["rows_pulled"] > 0, st
 
 
 def test_pinned_tables_prefetch_is_only_a_hint(monkeypatch):
