@@ -362,7 +362,8 @@ __device__ inline void gather_body(const Ctx& c) {
       // odd rows: the last vector of a row ends with the row (it overlaps its neighbour by
       // 4 - dim % 4 floats, which are simply written twice) — no scalar tail pass
       const uint32_t off = kOdd ? min(cc * kVF, rowu - kVF) : cc * kVF;
-      *at = r * rowu + off;   // where it goes, in Units from the tile's first row
+      // where it goes, in Units from the tile's first row (even rows: r * dimv + cc = fu)
+      *at = kOdd ? r * rowu + off : fu;
       const Unit* s = reinterpret_cast<const Unit*>(__shfl(src_bits, r, 64));
       // An unconditional GLOBAL load (a lane with nothing to read reads the tile's first output
       // row): a load under a per-lane branch, or a flat one — the pointer went through a
@@ -407,7 +408,9 @@ __device__ inline void gather_body(const Ctx& c) {
 #pragma unroll
       for (int k = 0; k < K0; ++k)
         if (p0[k]) nt_store(v0[k], reinterpret_cast<VecT*>(o + at0[k]));
-      copy(std::integral_constant<int, 12>{}, 64u * K0);
+      // (rows wider than one trip covers are rare and this loop's registers count for the whole
+      // kernel: four in flight keeps it at 4 waves per SIMD)
+      copy(std::integral_constant<int, 4>{}, 64u * K0);
     }
     if (known) {
       const int32_t claim = slot;   // a missed id of a planned pull: -(representative row + 1)
@@ -2744,13 +2747,9 @@ void launch_round(Round& r, hipStream_t stream) {
       staged = staged || c.pmap != nullptr;
       direct = direct && !c.cache_buf && !c.miss_rows && !c.remap && !c.pmap;
     }
-    static const bool direct_on = [] {
-      const char* v = std::getenv("GNNFLOW_GATHER_DIRECT");   // A/B
-      return !(v && std::atoi(v) == 0);
-    }();
     auto* kernel = !lean ? gather_rows_any_kernel
                  : staged ? gather_rows_staged_kernel
-                 : (direct && direct_on) ? gather_rows_kernel : gather_rows_mirror_kernel;
+                 : direct ? gather_rows_kernel : gather_rows_mirror_kernel;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile_begin(kProfGather, &e0, &e1)) {
       // the events ride on the dispatch itself: its begin / end timestamps
