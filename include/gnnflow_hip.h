@@ -366,7 +366,8 @@ GF_API int gf_cache_fetch_wait(uint64_t ticket);
  * otherwise.  A hint: cache state, hit counts and the fetched rows never depend on it.
  * *issued = 0 when the call issued nothing (no ring, or the generation was dropped because
  * fetches that may still read the region it would overwrite had not finished).
- * generations: a power of two in 8..64, or 0 = ring off.  gf_cache_invalidate_staging: the
+ * generations: a power of two in 8..64, or 0 = ring off; the ring's index takes 16 bytes per
+ * table row (where an id was staged last and the time before).  gf_cache_invalidate_staging: the
  * table's contents changed.  gf_cache_staging_state out[9]: generations, rows per generation,
  * generations issued, generations dropped, rows pulled over the host link (synchronises), bytes
  * of HBM the ring and its index take, rows the gathers still read from the host table,
