@@ -299,10 +299,29 @@ constexpr uint32_t kRepHit = 1u << 30, kRepPos = kRepHit - 1u;
 // the default 12 loads in flight (no queue-form hit path, one copy loop)
 template <typename VecT, bool kOdd = false, bool kLean = false, bool kStaged = !kLean,
           bool kDirect = false>
-__device__ inline void gather_body(const Ctx& c) {
+__device__ inline void gather_body(const Ctx& kc) {
+  // The context lives in the kernel-argument segment and the compiler loads a field where it is
+  // first used: seven dependent rounds of scalar loads (each a trip to memory for a CU's first
+  // wave) stood before the first id was read.  Pinning the hot fields into SGPRs HERE makes them
+  // one round.
+  const Ctx& c = kc;
+  const uint32_t grid_x = gridDim.x;   // (a scalar load of its own, from the implicit arguments)
+  // (input operands: the values must be in SGPRs here — their loads are issued together before
+  // this point — and stay the kernel arguments they are, pointers into GLOBAL memory; as in/out
+  // operands they came back as generic pointers and every access through them was a flat one)
+  if (kLean)   // (the general kernel has no scalar registers to spare, and its launches are long)
+    asm volatile("" :: "s"(c.ids), "s"(c.n), "s"(c.num_ids), "s"(c.map), "s"(c.feats), "s"(c.out),
+                 "s"(c.dimv), "s"(c.tile_rows), "s"(c.update), "s"(c.policy), "s"(c.touched),
+                 "s"(c.qpos), "s"(c.epoch_new), "s"(c.slot_of_row), "s"(grid_x), "s"(c.dim),
+                 "s"(c.ctr), "s"(c.ctr_next), "s"(c.stats), "s"(c.tile_old), "s"(c.hist1),
+                 "s"(c.capacity));
+  if (kLean && !kDirect)
+    asm volatile("" :: "s"(c.cache_buf), "s"(c.miss_rows), "s"(c.remap), "s"(c.pmap), "s"(c.ring),
+                 "s"(c.st_lo), "s"(c.st_span), "s"(c.st_mask), "s"(c.st_cap));
+  if (c.n == 0) return;
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * kThreads + threadIdx.x;
-  const uint32_t nthreads = gridDim.x * kThreads;
+  const uint32_t nthreads = grid_x * kThreads;
   // housekeeping for later launches: this fetch's histograms and the NEXT fetch's counter
   // record are cleared here (neither is in use by anyone else at this point)
   if (c.update && c.policy == GF_CACHE_LRU) {   // per-group hit counts of the list scan
@@ -526,21 +545,15 @@ __global__ __launch_bounds__(kThreads) void gather_rows_any_kernel(Round r) {
 // (tables in HBM, no row mirror: the headline replay); _mirror_: rows come from wherever the probe
 // says (row mirror, pulled rows, remapped local rows).
 __global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
-  const Ctx& c = r.c[blockIdx.y];
-  if (c.n == 0) return;
-  gather_body<float4, false, true, false, true>(c);
+  gather_body<float4, false, true, false, true>(r.c[blockIdx.y]);
 }
 __global__ __launch_bounds__(kThreads) void gather_rows_mirror_kernel(Round r) {
-  const Ctx& c = r.c[blockIdx.y];
-  if (c.n == 0) return;
-  gather_body<float4, false, true>(c);
+  gather_body<float4, false, true>(r.c[blockIdx.y]);
 }
 
 // ... and the lean kernel for rounds over a host-resident table with a staging ring
 __global__ __launch_bounds__(kThreads) void gather_rows_staged_kernel(Round r) {
-  const Ctx& c = r.c[blockIdx.y];
-  if (c.n == 0) return;
-  gather_body<float4, false, true, true>(c);
+  gather_body<float4, false, true, true>(r.c[blockIdx.y]);
 }
 
 // ---- staging ring: rows of a HOST-resident table pulled into HBM ahead of the gather ----------
@@ -2150,7 +2163,15 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
   // saved 0.5 us of an isolated launch and cost 7 us per step in the pipelined loop, where the
   // row workgroups then spin for count workgroups that other kernels keep from starting:
   // profiles/README.md, round 6)
+  // (the hot fields pinned into SGPRs here: one round of scalar loads instead of one per field
+  // where it is first used — see gather_body)
   const Ctx& c = r.c[blockIdx.y];
+  asm volatile("" :: "s"(c.update), "s"(c.policy), "s"(c.fused), "s"(c.trace), "s"(c.n),
+               "s"(c.capacity), "s"(c.fuse_tag), "s"(c.fuse_rows), "s"(c.touched), "s"(c.queue[0]),
+               "s"(c.queue[1]), "s"(c.qstate), "s"(c.ctr), "s"(c.epoch_new), "s"(c.slot_id),
+               "s"(c.ids), "s"(c.map), "s"(c.slot_of_row), "s"(c.g_cnt), "s"(c.g_row),
+               "s"(c.v_slot), "s"(c.v_old), "s"(c.v_pos), "s"(c.v_hold), "s"(c.qpos),
+               "s"(c.num_ids), "s"(c.cache_buf));
   const uint32_t vx = blockIdx.x;
   if (!c.update || c.policy != GF_CACHE_LRU || !c.fused) return;
   const int tid = threadIdx.x;
