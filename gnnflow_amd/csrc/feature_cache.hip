@@ -82,7 +82,9 @@ namespace gf {
 namespace {
 
 constexpr int32_t kAbsent = INT32_MIN;  // map[] value of an uncached id
-constexpr int kThreads = 256;           // gather workgroup
+// gather workgroup (same-box A/B of the headline fetch, us per launch: 64 threads 23.5, 128 16.1,
+// 256 13.3, 512 13.9, 1024 15.3 — profiles/r06_gather_hop_trace.txt)
+constexpr int kThreads = 256;
 constexpr int kWide = 1024;             // slot kernels, scans
 constexpr int kFine = 2048;             // ages 0..2047: one bin each
 constexpr int kBins1 = 4096;            // + 2048 coarse bins of 2048 ages each
@@ -294,6 +296,12 @@ template <> __device__ inline float4 vec_zero<float4>() { return make_float4(0.f
 constexpr uint32_t kRepMiss = 1u << 31, kRepRank = kRepMiss - 1u;
 constexpr uint32_t kRepHit = 1u << 30, kRepPos = kRepHit - 1u;
 
+// gf_debug_lru_trace buffer: [0 .. 3] header, 8 stamps per workgroup of the one-launch update
+// (at most 2 * 2048 list tiles + 1024 row workgroups), then 8 per workgroup of the gather launch
+// before it (the traced cache's context)
+constexpr uint32_t kGatherTraceBase = 4u + 8u * (2u * 2048u + 1024u);
+constexpr uint32_t kGatherTraceWgs = 1024u;
+
 // ---- the gather kernel -------------------------------------------------------------
 // kLean: the instantiation for rounds of float4 rows on list-form / cache-free contexts with
 // the default 12 loads in flight (no queue-form hit path, one copy loop)
@@ -319,6 +327,12 @@ __device__ inline void gather_body(const Ctx& kc) {
     asm volatile("" :: "s"(c.cache_buf), "s"(c.miss_rows), "s"(c.remap), "s"(c.pmap), "s"(c.ring),
                  "s"(c.st_lo), "s"(c.st_span), "s"(c.st_mask), "s"(c.st_cap));
   if (c.n == 0) return;
+  // diagnostics (scripts/gather_hop_trace.py): wave 0 of every workgroup stamps the wall clock at
+  // the stages of its first tile
+  unsigned long long* tr = nullptr;
+  if (kLean && kDirect && c.trace && threadIdx.x == 0 && blockIdx.x < kGatherTraceWgs)
+    tr = c.trace + kGatherTraceBase + blockIdx.x * 8u;
+  if (tr) { tr[0] = wall_clock64(); }
   const int lane = threadIdx.x & 63;
   const uint32_t gtid = blockIdx.x * kThreads + threadIdx.x;
   const uint32_t nthreads = grid_x * kThreads;
@@ -367,6 +381,10 @@ __device__ inline void gather_body(const Ctx& kc) {
         slot = c.map ? c.map[id] : -1;
         if (direct) src = feats + static_cast<uint64_t>(id) * rowu;
       }
+    }
+    if (kLean && kDirect && c.trace && tile == wave) {   // (wave-uniform; traced launches only)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tr) tr[1] = wall_clock64();   // ids (and the map values) in
     }
     uint64_t src_bits = reinterpret_cast<uint64_t>(src);
     const uint32_t total = rows * dimv;
@@ -430,6 +448,11 @@ __device__ inline void gather_body(const Ctx& kc) {
       // (rows wider than one trip covers are rare and this loop's registers count for the whole
       // kernel: four in flight keeps it at 4 waves per SIMD)
       copy(std::integral_constant<int, 4>{}, 64u * K0);
+      if (kLean && c.trace && tile == wave) {
+        if (tr) tr[2] = wall_clock64();   // every row of the tile in, its stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tr) tr[3] = wall_clock64();   // stores acknowledged
+      }
     }
     if (known) {
       const int32_t claim = slot;   // a missed id of a planned pull: -(representative row + 1)
@@ -513,6 +536,7 @@ __device__ inline void gather_body(const Ctx& kc) {
       if (c.stats && wg_hits) atomicAdd(&c.stats[2 * sh], wg_hits);
     }
   }
+  if (tr) tr[4] = wall_clock64();       // marks, claims and counters issued
   if (c.stats && gtid == 0) atomicAdd(&c.stats[1], n);
   if (kStaged && c.pmap && acc_host && lane == 0)
     atomicAdd(c.st_fallback, static_cast<unsigned long long>(acc_host));
@@ -3040,7 +3064,7 @@ void FeatureCache::lru_trace_enable(bool on) {
   DeviceGuard dg(device_);
   GF_HIP(hipDeviceSynchronize());
   if (!on) { trace_.release(); return; }
-  trace_.reserve((4 + 8 * (2 * kFuseMaxTiles + kFuseMaxRowWgs)) * sizeof(unsigned long long));
+  trace_.reserve((kGatherTraceBase + 8 * kGatherTraceWgs) * sizeof(unsigned long long));
   GF_HIP(hipMemset(trace_.data(), 0, trace_.bytes()));
 }
 size_t FeatureCache::lru_trace_read(uint64_t* out, size_t capacity_words) {
