@@ -307,13 +307,12 @@ constexpr uint32_t kGatherTraceWgs = 1024u;
 // the default 12 loads in flight (no queue-form hit path, one copy loop)
 template <typename VecT, bool kOdd = false, bool kLean = false, bool kStaged = !kLean,
           bool kDirect = false>
-__device__ inline void gather_body(const Ctx& kc) {
+__device__ inline void gather_body(const Ctx& kc, uint32_t bx, uint32_t grid_x) {
   // The context lives in the kernel-argument segment and the compiler loads a field where it is
   // first used: seven dependent rounds of scalar loads (each a trip to memory for a CU's first
   // wave) stood before the first id was read.  Pinning the hot fields into SGPRs HERE makes them
   // one round.
   const Ctx& c = kc;
-  const uint32_t grid_x = gridDim.x;   // (a scalar load of its own, from the implicit arguments)
   // (input operands: the values must be in SGPRs here — their loads are issued together before
   // this point — and stay the kernel arguments they are, pointers into GLOBAL memory; as in/out
   // operands they came back as generic pointers and every access through them was a flat one)
@@ -330,11 +329,16 @@ __device__ inline void gather_body(const Ctx& kc) {
   // diagnostics (scripts/gather_hop_trace.py): wave 0 of every workgroup stamps the wall clock at
   // the stages of its first tile
   unsigned long long* tr = nullptr;
-  if (kLean && kDirect && c.trace && threadIdx.x == 0 && blockIdx.x < kGatherTraceWgs)
-    tr = c.trace + kGatherTraceBase + blockIdx.x * 8u;
-  if (tr) { tr[0] = wall_clock64(); }
+  if (kLean && kDirect && c.trace && threadIdx.x == 0 && bx < kGatherTraceWgs)
+    tr = c.trace + kGatherTraceBase + bx * 8u;
+  if (tr) {
+    tr[0] = wall_clock64();
+    // where it runs: HW_ID (cu 8-11, sh 12, se 13-15 on gfx9) and XCC_ID
+    tr[5] = static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(4 | (31 << 11))) |
+            (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(20 | (31 << 11))) << 32);
+  }
   const int lane = threadIdx.x & 63;
-  const uint32_t gtid = blockIdx.x * kThreads + threadIdx.x;
+  const uint32_t gtid = bx * kThreads + threadIdx.x;
   const uint32_t nthreads = grid_x * kThreads;
   // housekeeping for later launches: this fetch's histograms and the NEXT fetch's counter
   // record are cleared here (neither is in use by anyone else at this point)
@@ -413,7 +417,7 @@ __device__ inline void gather_body(const Ctx& kc) {
     // direct context: the first trip's row loads are issued here, right behind the map load and
     // before anything looks at its result — the chain is launch -> ids -> rows -> stores, the
     // probe (map -> marks / claims, which only the update reads) hangs off its side
-    constexpr int K0 = 12;
+    constexpr int K0 = kDirect ? 13 : 12;   // (13: a tile of 19 172-d rows still is one trip)
     VecT v0[K0];
     bool p0[K0];
     uint32_t at0[K0];
@@ -530,7 +534,7 @@ __device__ inline void gather_body(const Ctx& kc) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int sh = blockIdx.x & (kShards - 1);
+      const int sh = bx & (kShards - 1);
       if (wg_hits) atomicAdd(&c.ctr->shard[sh].hits, wg_hits);
       if (wg_miss) atomicAdd(&c.ctr->shard[sh].n_miss, wg_miss);
       if (c.stats && wg_hits) atomicAdd(&c.stats[2 * sh], wg_hits);
@@ -552,15 +556,16 @@ __device__ inline bool ctx_direct(const Ctx& c) {
 __global__ __launch_bounds__(kThreads) void gather_rows_any_kernel(Round r) {
   const Ctx& c = r.c[blockIdx.y];
   if (c.n == 0) return;
+  const uint32_t bx = blockIdx.x, gx = gridDim.x;
   if (ctx_direct(c) && c.inflight >= 12) {
-    if (c.vec4) gather_body<float4, false, false, false, true>(c);
-    else if (c.odd4) gather_body<uf4, true, false, false, true>(c);
-    else gather_body<float, false, false, false, true>(c);
+    if (c.vec4) gather_body<float4, false, false, false, true>(c, bx, gx);
+    else if (c.odd4) gather_body<uf4, true, false, false, true>(c, bx, gx);
+    else gather_body<float, false, false, false, true>(c, bx, gx);
     return;
   }
-  if (c.vec4) gather_body<float4>(c);
-  else if (c.odd4) gather_body<uf4, true>(c);
-  else gather_body<float>(c);
+  if (c.vec4) gather_body<float4>(c, bx, gx);
+  else if (c.odd4) gather_body<uf4, true>(c, bx, gx);
+  else gather_body<float>(c, bx, gx);
 }
 
 // The same for rounds whose contexts ALL take the float4 / list-form or cache-free / 12-in-flight
@@ -568,16 +573,25 @@ __global__ __launch_bounds__(kThreads) void gather_rows_any_kernel(Round r) {
 // SIMD) — same-box A/B in profiles/README, round 5.  gather_rows_kernel: every context direct
 // (tables in HBM, no row mirror: the headline replay); _mirror_: rows come from wherever the probe
 // says (row mirror, pulled rows, remapped local rows).
-__global__ __launch_bounds__(kThreads) void gather_rows_kernel(Round r) {
-  gather_body<float4, false, true, false, true>(r.c[blockIdx.y]);
+// gather_rows_kernel's grid is ONE row of workgroups, the contexts' workgroups back to back
+// (first[k] = first workgroup of context k + 1, first.w = all): the dispatcher hands workgroups to
+// the 256 CUs round robin and a CU moves its workgroups' rows at ~44 GB/s however many it holds —
+// the launch ends with the fullest CU (profiles/r06_gather_hop_trace.txt), and in a (x, context)
+// grid the contexts' unused workgroups shift the round robin so that some CUs get one more.
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(uint4 first, Round r) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t y = (b >= first.x ? 1u : 0u) + (b >= first.y ? 1u : 0u) + (b >= first.z ? 1u : 0u);
+  const uint32_t lo = y == 0 ? 0u : y == 1 ? first.x : y == 2 ? first.y : first.z;
+  const uint32_t hi = y == 0 ? first.x : y == 1 ? first.y : y == 2 ? first.z : first.w;
+  gather_body<float4, false, true, false, true>(r.c[y], b - lo, hi - lo);
 }
 __global__ __launch_bounds__(kThreads) void gather_rows_mirror_kernel(Round r) {
-  gather_body<float4, false, true>(r.c[blockIdx.y]);
+  gather_body<float4, false, true>(r.c[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // ... and the lean kernel for rounds over a host-resident table with a staging ring
 __global__ __launch_bounds__(kThreads) void gather_rows_staged_kernel(Round r) {
-  gather_body<float4, false, true, true>(r.c[blockIdx.y]);
+  gather_body<float4, false, true, true>(r.c[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // ---- staging ring: rows of a HOST-resident table pulled into HBM ahead of the gather ----------
@@ -2792,16 +2806,64 @@ void launch_round(Round& r, hipStream_t stream) {
       staged = staged || c.pmap != nullptr;
       direct = direct && !c.cache_buf && !c.miss_rows && !c.remap && !c.pmap;
     }
-    auto* kernel = !lean ? gather_rows_any_kernel
-                 : staged ? gather_rows_staged_kernel
-                 : direct ? gather_rows_kernel : gather_rows_mirror_kernel;
+    if (lean && direct) {
+      // Two workgroups per CU, not three: the dispatcher hands workgroups to the 256 CUs round
+      // robin, and the launch ends with the CUs that received a third one (~2.3 us per further
+      // workgroup: profiles/r06_gather_hop_trace.txt).  If slightly larger tiles — still one trip
+      // of loads — bring the round down to 512 workgroups, take them.
+      static const bool fit = [] {
+        const char* v = std::getenv("GNNFLOW_GATHER_FIT_CUS");   // A/B
+        return !(v && std::atoi(v) == 0);
+      }();
+      auto wgs = [&](uint32_t t) {
+        size_t total = 0;
+        for (int i = 0; i < r.count; ++i) total += ((r.c[i].n + t - 1) / t + 3) / 4;
+        return total;
+      };
+      uint32_t t0 = 0, dimv = 1;
+      bool same = true;
+      for (int i = 0; i < r.count; ++i) {
+        if (r.c[i].n == 0) continue;
+        if (t0 == 0) t0 = r.c[i].tile_rows;
+        same = same && (r.c[i].tile_rows == t0 || r.c[i].n <= 4u * r.c[i].tile_rows);
+        dimv = std::max(dimv, r.c[i].dimv);
+      }
+      const uint32_t t_max = std::min<uint32_t>(64u, 13u * 64u / dimv);
+      if (fit && same && t0 == 16 && wgs(t0) > 512 && t_max > t0) {
+        uint32_t t = t0 + 1;
+        while (t < t_max && wgs(t) > 512) ++t;
+        if (wgs(t) <= 512) {
+          ggrid = 1;
+          for (int i = 0; i < r.count; ++i) {
+            if (r.c[i].n > 4u * r.c[i].tile_rows) r.c[i].tile_rows = t;
+            ggrid = std::max(ggrid, gather_grid_for(r.c[i].n, r.c[i].tile_rows));
+          }
+        }
+      }
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (profile_begin(kProfGather, &e0, &e1)) {
-      // the events ride on the dispatch itself: its begin / end timestamps
-      hipExtLaunchKernelGGL(kernel, dim3(ggrid, r.count), dim3(kThreads), 0, stream, e0, e1, 0, r);
-      profile_end(kProfGather, e0, e1);
+    if (lean && direct && !staged) {
+      uint32_t first[5] = {0, 0, 0, 0, 0};
+      for (int i = 0; i < kMaxCtx; ++i)
+        first[i + 1] = first[i] + (i < r.count && r.c[i].n ? gather_grid_for(r.c[i].n, r.c[i].tile_rows) : 0u);
+      const uint4 f = make_uint4(first[1], first[2], first[3], first[4]);
+      const unsigned total = std::max(1u, first[4]);
+      if (profile_begin(kProfGather, &e0, &e1)) {
+        // the events ride on the dispatch itself: its begin / end timestamps
+        hipExtLaunchKernelGGL(gather_rows_kernel, dim3(total), dim3(kThreads), 0, stream, e0, e1, 0, f, r);
+        profile_end(kProfGather, e0, e1);
+      } else {
+        gather_rows_kernel<<<dim3(total), dim3(kThreads), 0, stream>>>(f, r);
+      }
     } else {
-      kernel<<<dim3(ggrid, r.count), dim3(kThreads), 0, stream>>>(r);
+      auto* kernel = !lean ? gather_rows_any_kernel
+                   : staged ? gather_rows_staged_kernel : gather_rows_mirror_kernel;
+      if (profile_begin(kProfGather, &e0, &e1)) {
+        hipExtLaunchKernelGGL(kernel, dim3(ggrid, r.count), dim3(kThreads), 0, stream, e0, e1, 0, r);
+        profile_end(kProfGather, e0, e1);
+      } else {
+        kernel<<<dim3(ggrid, r.count), dim3(kThreads), 0, stream>>>(r);
+      }
     }
     GF_HIP(hipGetLastError());
   }

@@ -139,3 +139,25 @@ for wg in order[:5] + order[-8:]:
     print("  wg {:3d} rows {:5d}-{:5d}: {:5.2f} us, {:2d} distinct, {:2d} seen earlier, median age {:8d}".format(
         wg, lo, hi, rows_t[wg], len(np.unique(part)), int(seen_before[lo:hi].sum()),
         int(np.median(ids.max() - part))))
+# where the last step's workgroups ran (HW_ID / XCC_ID of wave 0) and how long their rows took
+print("last step, both contexts: rows phase by the CU a workgroup ran on (xcc, se, sh, cu):")
+place = {}
+for k, sg in gs.items():
+    for wg in np.nonzero(sg[:, 1] > 0)[0]:
+        hw = int(sg[wg, 5]) & 0xFFFFFFFF
+        xcc = (int(sg[wg, 5]) >> 32) & 0xF
+        cu, sh, se = (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
+        place.setdefault((xcc, se, sh, cu), []).append((k, int(wg), (sg[wg, 2] - sg[wg, 1]) * 0.01,
+                                                       (sg[wg, 1] - t0) * 0.01))
+loads = sorted(place.items(), key=lambda kv: -max(x[2] for x in kv[1]))
+print("  CUs used: {}; workgroups per CU: {}".format(
+    len(place), dict(zip(*np.unique([len(v) for v in place.values()], return_counts=True)))))
+for key, v in loads[:10]:
+    print("  xcc {} se {} sh {} cu {:2d}: ".format(*key) +
+          ", ".join("{} wg {} rows {:.2f} us (ids in at {:.2f})".format(*x) for x in v))
+per_n = {}
+for v in place.values():
+    per_n.setdefault(len(v), []).extend(x[2] for x in v)
+for nn in sorted(per_n):
+    print("  CUs with {} traced workgroups: rows phase mean {:.2f} us, max {:.2f}".format(
+        nn, np.mean(per_n[nn]), np.max(per_n[nn])))
