@@ -3712,7 +3712,15 @@ void FeatureCache::prepare(const int64_t* d_ids, size_t n, float* d_out, bool up
     // small cache installs belong to the FIRST representatives, i.e. to the first few row
     // workgroups, which then copy all of its rows (GDELT-scale node cache, 3 336 slots, 218 k-row
     // blocks: 57 us per update with 1 024 rows per workgroup — four workgroups copied 5.5 MB)
-    c.fuse_rows = n > size_t{kInstRows} * kFuseMaxRowWgs ? kWide : kInstRows;
+    // Without a row mirror nothing is copied, and 1 024 rows per workgroup keep the launch small
+    // enough for every count and row workgroup to be resident from the start (1 024-thread
+    // workgroups: one per CU; with 256 rows the headline's row workgroups entered 2.6 us into the
+    // launch, behind the count workgroups — profiles/r06_lru_hop_trace.txt).
+    static const bool wide_rows = [] {
+      const char* v = std::getenv("GNNFLOW_LRU_FUSE_WIDE_ROWS");   // A/B
+      return !(v && std::atoi(v) == 0);
+    }();
+    c.fuse_rows = (n > size_t{kInstRows} * kFuseMaxRowWgs || (wide_rows && !mirror_)) ? kWide : kInstRows;
     if (!c.qmode && lru_fused_enabled() &&
         (capacity_ + kFuseTile - 1) / kFuseTile <= kFuseMaxTiles &&
         (n + c.fuse_rows - 1) / c.fuse_rows <= kFuseMaxRowWgs) {
