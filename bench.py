@@ -409,8 +409,9 @@ def time_leg(ctx, sampler, cache, main_leg, min_seconds, min_replays, probe=None
         # partitioned sampler: a chain carries up to `chain_samples` batches; per lane one
         # chain in flight and half a chain being gathered
         chain = getattr(sampler, "chain_samples", 1)
-        depth = 2 if lanes == 1 and chain == 1 else max(3 * lanes, (3 * lanes * chain) // 2,
-                                                        2 * chain)
+        # (replica: ReplayPipeline's own default, 3 with two sampling lanes)
+        depth = None if lanes == 1 and chain == 1 else max(3 * lanes, (3 * lanes * chain) // 2,
+                                                           2 * chain)
     pipe = ReplayPipeline(sampler, cache, ctx.dev_batches, ctx.dev,
                           pipelined=not args.no_pipeline, depth=depth)
     ctx.live_pipe = pipe

@@ -68,9 +68,10 @@ class ReplayPipeline:
     `sampler.sample` + `cache.fetch_feature`.
 
     pipelined=True : sample_async(stream=side, worker_enqueue=True) `depth` batches ahead
-                     (2: the sampling of batch i+2 is issued before batch i+1's is waited
-                     for, which takes the sampler's issue + execution latency off the
-                     critical path), fetch_feature(async_enqueue=True) on the current stream.
+                     (default 3 with two sampling lanes, 2 with one: the sampling of batch
+                     i+depth is issued before batch i+1's is waited for, which takes the
+                     sampler's issue + execution latency off the critical path),
+                     fetch_feature(async_enqueue=True) on the current stream.
     pipelined=False: the plain loop `mfgs = sampler.sample(r, t); cache.fetch_feature(mfgs, e)`.
     cache=None     : sampling only; pipelined=True keeps `depth` (at least 2 per lane) samples in
                      flight over the lanes and waits for them in batch order — what
@@ -86,7 +87,7 @@ class ReplayPipeline:
 
     def __init__(self, sampler, cache, batches: Sequence[Tuple[torch.Tensor, torch.Tensor,
                                                                 torch.Tensor]],
-                 device: torch.device, pipelined: bool = True, depth: int = 2,
+                 device: torch.device, pipelined: bool = True, depth: Optional[int] = None,
                  sample_lanes: Optional[int] = None):
         self.sampler, self.cache, self.batches = sampler, cache, batches
         self.device = torch.device(device)
@@ -103,6 +104,11 @@ class ReplayPipeline:
                 self.lanes.append((sampler.clone(), side_stream(self.device, k)))
         # a sampler (of a lane of the partitioned sampler: one per sample of a shared chain)
         # holds 4 begun samples at most
+        if depth is None:
+            # two sampling lanes: a sample's chain (4 launches through the enqueue thread, ~45 us
+            # from begin to done) must be three steps ahead of its fetch, or the loop waits for it
+            # (26.2-27.2 against 28.8-29.0 us per step on a slow host, same box)
+            depth = 3 if len(self.lanes) > 1 else 2
         self.depth = max(1, min(int(depth), 3 * max(1, getattr(self.sampler, "lanes", 1)) *
                                 max(1, getattr(self.sampler, "chain_samples", 1))))
         # GNNFLOW_PIPELINE_FETCH_FIRST=1: submit batch i's fetch before the sample of batch

@@ -3,6 +3,7 @@ reference's Python wrapper (gnnflow/temporal_sampler.py:14-177); all layers and
 snapshots are sampled in one device-resident call (gf_sampler_sample) and the returned
 blocks hold torch tensors in HBM, so mfgs_to_cuda (gnnflow/utils.py:477-481) is a no-op."""
 import ctypes as C
+import struct
 from collections import deque
 from typing import List, Union
 
@@ -107,6 +108,9 @@ class TemporalSampler:
         self._max_inflight = 4         # gf::Sampler::kMaxInFlight
         self._slab = None
         self._gf_blocks = (_capi.GfBlock * (self._num_layers * self._num_snapshots))()
+        # struct gf_block = six addresses + three counts (include/gnnflow_hip.h)
+        self._blocks_unpack = struct.Struct(
+            "=%dQ" % (9 * self._num_layers * self._num_snapshots)).unpack_from
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -293,8 +297,33 @@ class TemporalSampler:
         base = None
         if isinstance(buf, list):          # a slab record of _output_buffer
             buf, marks, base = buf[0], buf[4], buf[5]
-        mfgs = [[self._block(buf, blocks[layer * ns + s], marks, base) for s in range(ns)]
-                for layer in range(self._num_layers)]
+        # every field of every gf_block in ONE unpack (nine ctypes field reads per block cost more
+        # host time than the block's sampling kernel runs), one view function for the sample
+        vals = self._blocks_unpack(blocks)
+        device = self._device
+        if base is None:
+            base = buf.data_ptr()
+
+        def view(ptr, count, dtype, itemsize):
+            if count == 0:
+                return torch.empty(0, dtype=dtype, device=device)
+            off = ptr - base
+            return buf[off:off + count * itemsize].view(dtype)
+
+        mfgs = []
+        k = 0
+        for layer in range(self._num_layers):
+            row_ = []
+            for s in range(ns):
+                an, ats, dts, eids, row, col, ndst, nsrc, ne = vals[k:k + 9]
+                k += 9
+                if not an:
+                    raise RuntimeError("sampler returned a null block")
+                b = MFGBlock(nsrc, ndst, keepalive=buf, num_edges=ne, device=device,
+                             raw=(view, an, ats, dts, eids, col, row))
+                b._stream_marks = marks
+                row_.append(b)
+            mfgs.append(row_)
         if self._strategy == "recent":
             # Layer l+1's roots start with layer l's roots (all_nodes = roots ++ neighbours,
             # temporal_sampler.cu:294-299) carrying the same timestamps, so with the same

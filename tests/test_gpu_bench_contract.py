@@ -118,7 +118,7 @@ def test_driver_command_line_is_representative():
     assert d["roofline"].get("traffic_source", "").startswith("profiles/") or \
         "traffic_from_profile" not in d["roofline"]
     full = _run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-config3",
-                 "--min-seconds", "0.1"])
+                 "--min-seconds", "0.05"])      # (four replays take ~0.1 s)
     assert full["repeats"] == 4
     assert d["config"]["edges_per_step"] == pytest.approx(full["config"]["edges_per_step"],
                                                          rel=0.02)
