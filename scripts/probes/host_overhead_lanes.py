@@ -31,6 +31,26 @@ batches = [(torch.from_numpy(r).to(dev), torch.from_numpy(t).to(dev), torch.from
            for r, t, e in synthetic.replay_batches(g, 600, seed=42)]
 nb = len(batches)
 now = time.perf_counter_ns
+# time spent inside the native calls of the loop (wrappers on the CDLL's cached functions)
+from gnnflow_amd import _capi  # noqa: E402
+lib = _capi.load()
+NATIVE = {}
+
+
+def _wrap(name):
+    fn = getattr(lib, name)
+
+    def timed(*a):
+        t0 = now()
+        r = fn(*a)
+        NATIVE[name] = NATIVE.get(name, 0) + now() - t0
+        return r
+    setattr(lib, name, timed)
+
+
+for _n in ("gf_sampler_sample_end", "gf_sampler_sample_begin_async", "gf_cache_fetch_blocks_async",
+           "gf_cache_fetch_wait"):
+    _wrap(_n)
 for ratio in (0.2, 0.0):
     cache = LRUCache(ratio, ratio, g["num_nodes"], g["num_edges"], dev, nf, ef, 172, 172)
     cache.init_cache()
@@ -45,6 +65,7 @@ for ratio in (0.2, 0.0):
         s, side = lanes[j % nl]
         return s.sample_async(r, t, stream=side, worker_enqueue=True)
     T = dict(wait=0, begin=0, rec=0, fetch=0)
+    NATIVE.clear()
     last = 4 * nb
     pending = deque()
     nxt = 0
@@ -77,4 +98,5 @@ for ratio in (0.2, 0.0):
           "fetch_feature %.1f | rest (loop, timers) %.1f" % (
               ratio, total, T["wait"] / last / 1e3, T["begin"] / last / 1e3, T["rec"] / last / 1e3,
               T["fetch"] / last / 1e3, total - sum(T.values()) / last / 1e3))
+    print("   inside native calls: " + ", ".join("%s %.1f" % (k, v / last / 1e3) for k, v in NATIVE.items()))
     del pipe, cache
