@@ -2319,7 +2319,9 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
                tid * kPer < tiles ? &c.g_cnt[tid * kPer] : nullptr,
                tid * kPer + 1 < tiles ? &c.g_cnt[tid * kPer + 1] : nullptr, tag, pv);
     if (pv[0] == ~0u) pv[0] = fuse_recount_rows(c, tid);
+    GF_STAMP(5);   // thread 0's own granules are in (diagnostics)
     const uint32_t pm = wide_sum(pv[0], ws);
+    GF_STAMP(6);   // every thread's are (the sum is a barrier)
     // hits per list tile -> prefix of not-hit / hit entries per tile
     uint32_t hv[kPer], run_h = 0;
 #pragma unroll

@@ -45,7 +45,8 @@ _capi.check(lib.gf_debug_lru_trace_enable(cache._edge.h, 1))
 STAGES = {"count": ["entry", "marks / list / parity / counters in", "entries staged + drained, count published"],
           "row": ["entry", "rows read, representatives ranked, count published",
                   "look-back complete (row + count granules), prefixes in LDS",
-                  "victims read, map / slot_id written", "installed rows copied"],
+                  "victims read, map / slot_id written", "installed rows copied",
+                  "(thread 0's own granules in)", "(all threads' granules in: first barrier behind the polls)"],
           "write": ["entry", "row + count granules in", "list tile(s) rewritten"]}
 acc = {role: [[] for _ in names] for role, names in STAGES.items()}
 ends = []
