@@ -2414,6 +2414,13 @@ __global__ __launch_bounds__(kWide) void lru_list_fused_kernel(Round r, uint32_t
     sl0 = par ? a1 : a0;
   }
   if (total_miss(c.ctr) == 0) return;   // the list stays as it is
+  // Stay off the granules' lines for ~2 us: nothing this role waits for is there before, and every
+  // poll of a line slows the hand-over of the granules in it down — the row role's look-back, which
+  // is the launch's critical path, completes 1.1 us earlier when the 132 write workgroups of the
+  // headline's update do not poll beside it (profiles/r06_lru_hop_trace.txt; a longer nap makes
+  // the late-dispatched write workgroups the tail instead: 3 / 4 / 5 us: +0.5 / +1.3 / +2.1 us)
+  __builtin_amdgcn_s_sleep(32);
+  __builtin_amdgcn_s_sleep(32);
   // #distinct misses of the whole block (every row granule) and the hits per tile, all in
   // flight together
   constexpr uint32_t kPer = kFuseMaxTiles / kWide;
