@@ -66,6 +66,10 @@ for ratio in (0.2, 0.0):
         return s.sample_async(r, t, stream=side, worker_enqueue=True)
     T = dict(wait=0, begin=0, rec=0, fetch=0)
     NATIVE.clear()
+    import ctypes as C
+    _b, _j = C.c_double(0), C.c_uint64(0)
+    sys.stderr.write("[before] "); sys.stderr.flush()
+    lib.gf_worker_stats(C.byref(_b), C.byref(_j))
     last = 4 * nb
     pending = deque()
     nxt = 0
@@ -98,5 +102,7 @@ for ratio in (0.2, 0.0):
           "fetch_feature %.1f | rest (loop, timers) %.1f" % (
               ratio, total, T["wait"] / last / 1e3, T["begin"] / last / 1e3, T["rec"] / last / 1e3,
               T["fetch"] / last / 1e3, total - sum(T.values()) / last / 1e3))
+    sys.stderr.write("[after %d steps] " % last); sys.stderr.flush()
+    lib.gf_worker_stats(C.byref(_b), C.byref(_j))
     print("   inside native calls: " + ", ".join("%s %.1f" % (k, v / last / 1e3) for k, v in NATIVE.items()))
     del pipe, cache
