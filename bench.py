@@ -834,8 +834,14 @@ def main():
 
     def run_main(kind):
         graph, sampler, build_s = build_leg(ctx, kind)
+        def worker_probe():      # issuing time of the library's enqueue threads so far
+            import ctypes as C
+            busy, jobs = C.c_double(0), C.c_uint64(0)
+            lib.gf_worker_stats(C.byref(busy), C.byref(jobs))
+            return {"_worker_only": (busy.value, jobs.value)}
         res = time_leg(ctx, sampler, cache, True, args.min_seconds, args.min_replays,
-                       probe=staging_probe if (cache is not None and cache.staging) else None)
+                       probe=staging_probe if (cache is not None and cache.staging)
+                       else worker_probe)
         res.update(graph=graph, sampler=sampler, build_s=build_s, kind=kind)
         return res
 
@@ -1026,7 +1032,12 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/" + PMC_TRAFFIC_FILE
         out["cache_edge_ratio"] = float(cache.cache_edge_ratio)
         out["cache_node_ratio"] = float(cache.cache_node_ratio)
-        if res.get("probe1") is not None:
+        if res.get("probe1") is not None and "_worker_only" in res["probe1"]:
+            # how busy the enqueue threads (fetch launches; sampling launches) were: with the
+            # kernels' times above it says whether the GPU or the host's issuing path sets the step
+            w0, w1 = res["probe0"]["_worker_only"], res["probe1"]["_worker_only"]
+            out["config"]["enqueue_threads_busy_us_per_step"] = (w1[0] - w0[0]) / max(timed_steps, 1)
+        elif res.get("probe1") is not None:
             # host-resident tables: what crossed the host link (gnnflow/cache/cache.py:288-313,
             # 381-388 move every miss host -> pinned -> device inside fetch_feature)
             s0, s1 = res["probe0"], res["probe1"]

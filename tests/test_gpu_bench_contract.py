@@ -56,6 +56,8 @@ def test_single_gpu_line_with_roofline_and_cpu_baseline():
     assert d["repeats"] >= 75 and d["timed_steps"] == 60 * d["repeats"]
     assert d["config"]["timed_steps"] == d["timed_steps"]
     assert d["ms_per_step"] == pytest.approx(1e3 * d["timed_seconds"] / d["timed_steps"])
+    # issuing time of the library's enqueue threads per step: GPU-bound or host-bound?
+    assert 0 < d["config"]["enqueue_threads_busy_us_per_step"] < 2e3 * d["ms_per_step"]
     assert d["timed_seconds"] >= 0.1 and d["config"]["timed_seconds"] == d["timed_seconds"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "edges/s" and c["value"] > 0
