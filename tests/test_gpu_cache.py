@@ -301,6 +301,36 @@ def test_large_block_round_trip_properties():
     assert float(cache.cache_edge_ratio) >= r1
 
 
+@pytest.mark.parametrize("rows", [(0, 36000, 600), (25000, 0, 600), (25000, 11000, 0),
+                                  (24832, 11264, 600), (300000, 5, 1), (40, 70000, 3)])
+def test_direct_gather_one_row_grid_shapes(rows):
+    """The direct gather (tables in HBM, no row mirror, 16-byte rows) launches ONE row of
+    workgroups, the contexts' back to back, with tiles fitted to two workgroups per CU where that
+    is possible: empty contexts in every position, the headline's sizes, a block beyond the
+    1 024-workgroup cap of a context (grid-stride tiles), tiny blocks beside large ones — every
+    fetched row equals its table row, twice (the second fetch hits)."""
+    import torch
+    from gnnflow_amd.cache import LRUCache
+    n_node, n_edge, n_target = rows
+    N, E, d = 20000, 400000, 172
+    g = torch.Generator(device="cuda").manual_seed(sum(rows))
+    nf = torch.rand((N, d), generator=g, device="cuda")
+    ef = torch.rand((E, d), generator=g, device="cuda")
+    cache = LRUCache(0.2, 0.2, N, E, "cuda:0", nf, ef, d, d)
+    cache.init_cache()
+    nid = torch.randint(0, N, (n_node,), generator=g, device="cuda")
+    eid = torch.randint(0, E, (n_edge,), generator=g, device="cuda")
+    tid = torch.randint(0, E, (n_target,), generator=g, device="cuda")
+    for _ in range(2):
+        b = [[Blk(nid, eid)]]
+        cache.fetch_feature(b, eid=tid if n_target else None)
+        assert torch.equal(b[0][0].srcdata["h"], nf[nid])
+        if n_edge:
+            assert torch.equal(b[0][0].edata["f"], ef[eid])
+        if n_target:
+            assert torch.equal(cache.target_edge_features, ef[tid])
+
+
 def test_async_enqueue_matches_sync():
     """fetch_feature(async_enqueue=True) hands the launches to the library's enqueue thread;
     results, hit ratios and LRU state must be those of the synchronous call."""
