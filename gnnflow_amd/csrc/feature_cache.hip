@@ -573,25 +573,38 @@ __global__ __launch_bounds__(kThreads) void gather_rows_any_kernel(Round r) {
 // SIMD) — same-box A/B in profiles/README, round 5.  gather_rows_kernel: every context direct
 // (tables in HBM, no row mirror: the headline replay); _mirror_: rows come from wherever the probe
 // says (row mirror, pulled rows, remapped local rows).
-// gather_rows_kernel's grid is ONE row of workgroups, the contexts' workgroups back to back
+// The lean kernels' grid is ONE row of workgroups, the contexts' workgroups back to back
 // (first[k] = first workgroup of context k + 1, first.w = all): the dispatcher hands workgroups to
 // the 256 CUs round robin and a CU moves its workgroups' rows at ~44 GB/s however many it holds —
 // the launch ends with the fullest CU (profiles/r06_gather_hop_trace.txt), and in a (x, context)
 // grid the contexts' unused workgroups shift the round robin so that some CUs get one more.
-__global__ __launch_bounds__(kThreads) void gather_rows_kernel(uint4 first, Round r) {
+// (the lean kernels' one-row grid: which context a workgroup belongs to, its index there and
+// that context's workgroup count)
+__device__ inline uint32_t packed_ctx(const uint4& first, uint32_t* bx, uint32_t* gx) {
   const uint32_t b = blockIdx.x;
   const uint32_t y = (b >= first.x ? 1u : 0u) + (b >= first.y ? 1u : 0u) + (b >= first.z ? 1u : 0u);
   const uint32_t lo = y == 0 ? 0u : y == 1 ? first.x : y == 2 ? first.y : first.z;
   const uint32_t hi = y == 0 ? first.x : y == 1 ? first.y : y == 2 ? first.z : first.w;
-  gather_body<float4, false, true, false, true>(r.c[y], b - lo, hi - lo);
+  *bx = b - lo;
+  *gx = hi - lo;
+  return y;
 }
-__global__ __launch_bounds__(kThreads) void gather_rows_mirror_kernel(Round r) {
-  gather_body<float4, false, true>(r.c[blockIdx.y], blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(uint4 first, Round r) {
+  uint32_t bx, gx;
+  const uint32_t y = packed_ctx(first, &bx, &gx);
+  gather_body<float4, false, true, false, true>(r.c[y], bx, gx);
+}
+__global__ __launch_bounds__(kThreads) void gather_rows_mirror_kernel(uint4 first, Round r) {
+  uint32_t bx, gx;
+  const uint32_t y = packed_ctx(first, &bx, &gx);
+  gather_body<float4, false, true>(r.c[y], bx, gx);
 }
 
 // ... and the lean kernel for rounds over a host-resident table with a staging ring
-__global__ __launch_bounds__(kThreads) void gather_rows_staged_kernel(Round r) {
-  gather_body<float4, false, true, true>(r.c[blockIdx.y], blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(kThreads) void gather_rows_staged_kernel(uint4 first, Round r) {
+  uint32_t bx, gx;
+  const uint32_t y = packed_ctx(first, &bx, &gx);
+  gather_body<float4, false, true, true>(r.c[y], bx, gx);
 }
 
 // ---- staging ring: rows of a HOST-resident table pulled into HBM ahead of the gather ----------
@@ -2851,7 +2864,9 @@ void launch_round(Round& r, hipStream_t stream) {
       }
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (lean && direct && !staged) {
+    if (lean) {
+      auto* kernel = staged ? gather_rows_staged_kernel
+                   : direct ? gather_rows_kernel : gather_rows_mirror_kernel;
       uint32_t first[5] = {0, 0, 0, 0, 0};
       for (int i = 0; i < kMaxCtx; ++i)
         first[i + 1] = first[i] + (i < r.count && r.c[i].n ? gather_grid_for(r.c[i].n, r.c[i].tile_rows) : 0u);
@@ -2859,14 +2874,13 @@ void launch_round(Round& r, hipStream_t stream) {
       const unsigned total = std::max(1u, first[4]);
       if (profile_begin(kProfGather, &e0, &e1)) {
         // the events ride on the dispatch itself: its begin / end timestamps
-        hipExtLaunchKernelGGL(gather_rows_kernel, dim3(total), dim3(kThreads), 0, stream, e0, e1, 0, f, r);
+        hipExtLaunchKernelGGL(kernel, dim3(total), dim3(kThreads), 0, stream, e0, e1, 0, f, r);
         profile_end(kProfGather, e0, e1);
       } else {
-        gather_rows_kernel<<<dim3(total), dim3(kThreads), 0, stream>>>(f, r);
+        kernel<<<dim3(total), dim3(kThreads), 0, stream>>>(f, r);
       }
     } else {
-      auto* kernel = !lean ? gather_rows_any_kernel
-                   : staged ? gather_rows_staged_kernel : gather_rows_mirror_kernel;
+      auto* kernel = gather_rows_any_kernel;
       if (profile_begin(kProfGather, &e0, &e1)) {
         hipExtLaunchKernelGGL(kernel, dim3(ggrid, r.count), dim3(kThreads), 0, stream, e0, e1, 0, r);
         profile_end(kProfGather, e0, e1);
