@@ -147,6 +147,7 @@ PROTOTYPES = {
     "gf_sampler_sample_begin": (C.c_int, [_p, _p, _p, _sz, _p, _sz, _p]),
     "gf_sampler_sample_begin_async": (C.c_int, [_p, _p, _p, _sz, _p, _sz, _p]),
     "gf_sampler_sample_end": (C.c_int, [_p, C.POINTER(GfBlock)]),
+    "gf_sampler_set_enqueue_lane": (C.c_int, [_p, C.c_int]),
     "gf_sampler_call_counter": (C.c_int, [_p, C.POINTER(C.c_uint64)]),
     "gf_sampler_set_call_counter": (C.c_int, [_p, C.c_uint64, C.c_int]),
     "gf_sampler_layer_output_bytes": (C.c_int, [_p, _sz, C.c_uint32, C.POINTER(_sz)]),

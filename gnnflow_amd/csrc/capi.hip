@@ -22,7 +22,7 @@
 #include "sampler.hpp"
 
 struct gf_graph { gf::EdgeStore impl; template <typename... A> explicit gf_graph(A&&... a) : impl(std::forward<A>(a)...) {} };
-struct gf_sampler { gf::Sampler impl; std::deque<uint64_t> begin_tickets; /* 0 = begun synchronously */ template <typename... A> explicit gf_sampler(A&&... a) : impl(std::forward<A>(a)...) {} };
+struct gf_sampler { gf::Sampler impl; std::deque<uint64_t> begin_tickets; /* 0 = begun synchronously */ int plain_lane = 1; /* enqueue thread of sample_begin_async (gf_sampler_set_enqueue_lane) */ template <typename... A> explicit gf_sampler(A&&... a) : impl(std::forward<A>(a)...) {} };
 struct gf_cache { gf::FeatureCache impl; template <typename... A> explicit gf_cache(A&&... a) : impl(std::forward<A>(a)...) {} };
 struct gf_comm {
   std::unique_ptr<gf::Exchange> owned;
@@ -153,7 +153,12 @@ class EnqueueWorker {
     static EnqueueWorker* w0 = new EnqueueWorker();   // intentionally leaked: no exit-order issues
     if (lane == 0 || !two) return *w0;
     static EnqueueWorker* w1 = new EnqueueWorker();
-    return *w1;
+    if (lane != 2) return *w1;
+    // lane 2: a second sampling issuer (gf_sampler_set_enqueue_lane) — a sample's four launches +
+    // event cost 19 us of issuing time, which ONE thread serving both lanes of a sampling-only
+    // loop spends per step: that loop runs at the issuer's pace, not at the GPU's
+    static EnqueueWorker* w2 = new EnqueueWorker();
+    return *w2;
   }
   uint64_t submit(Job&& job) {
     bool wake;
@@ -447,10 +452,20 @@ int gf_sampler_sample_begin_async(gf_sampler* s, const int64_t* d_roots, const f
                "sample_begin_async: too many samples in flight on this sampler");
     gf::Sampler* impl = &s->impl;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    s->begin_tickets.push_back(gf::EnqueueWorker::get(1).submit(
+    const int lane = s->plain_lane;
+    const uint64_t mark = lane == 2 ? (1ull << 62) : 0ull;
+    s->begin_tickets.push_back(mark | gf::EnqueueWorker::get(lane).submit(
         [impl, d_roots, d_root_ts, num_roots, d_out, out_bytes, st]() {
           impl->sample_begin(d_roots, d_root_ts, num_roots, d_out, out_bytes, st);
         }));
+  });
+}
+int gf_sampler_set_enqueue_lane(gf_sampler* s, int lane) {
+  return guarded([&] {
+    GF_S(s);
+    GF_REQUIRE(lane == 1 || lane == 2, "gf_sampler_set_enqueue_lane: lane must be 1 or 2");
+    GF_REQUIRE(s->begin_tickets.empty(), "gf_sampler_set_enqueue_lane: samples are in flight");
+    s->plain_lane = lane;
   });
 }
 int gf_sampler_call_counter(const gf_sampler* s, uint64_t* out) {
@@ -466,7 +481,7 @@ int gf_sampler_set_call_counter(gf_sampler* s, uint64_t value, int through_enque
     gf::Sampler* impl = &s->impl;
     if (through_enqueue_thread) {
       // (jobs of the sampling lane run in submission order: the begin submitted next sees it)
-      gf::EnqueueWorker::get(1).submit([impl, value]() { impl->set_call_counter(value); });
+      gf::EnqueueWorker::get(s->plain_lane).submit([impl, value]() { impl->set_call_counter(value); });
     } else {
       GF_REQUIRE(s->begin_tickets.empty() || s->begin_tickets.back() == 0,
                  "set_call_counter: samples begun through the enqueue thread are in flight");
@@ -480,8 +495,10 @@ int gf_sampler_sample_end(gf_sampler* s, gf_block* blocks) {
     s->begin_tickets.pop_front();
     if (t) {   // begun through the enqueue thread: wait for the enqueue of THIS sample
       std::string err;
-      // bit 63: the job went to the fetch lane's thread (the chains of a communicator)
-      const int rc = gf::EnqueueWorker::get((t >> 63) ? 0 : 1).wait(t & ~(1ull << 63), &err);
+      // bit 63: the job went to the fetch lane's thread (the chains of a communicator), bit 62:
+      // to the second sampling issuer
+      const int lane = (t >> 63) ? 0 : ((t >> 62) & 1) ? 2 : 1;
+      const int rc = gf::EnqueueWorker::get(lane).wait(t & ~(3ull << 62), &err);
       if (rc != GF_OK) { gf::set_last_error(err); return rc; }
     }
   }
@@ -808,11 +825,14 @@ int gf_worker_stats(double* busy_us, uint64_t* jobs) {
     uint64_t j1 = 0;
     if (&gf::EnqueueWorker::get(1) != &gf::EnqueueWorker::get(0)) {
       gf::EnqueueWorker::get(1).stats(&b1, &j1);
+      double b2 = 0;
+      uint64_t j2 = 0;
+      gf::EnqueueWorker::get(2).stats(&b2, &j2);
       if (std::getenv("GNNFLOW_WORKER_STATS"))
-        std::fprintf(stderr, "[worker] lane0 %.0f us / %llu jobs, lane1 %.0f us / %llu jobs\n", *busy_us,
-                     (unsigned long long)*jobs, b1, (unsigned long long)j1);
-      *busy_us += b1;
-      *jobs += j1;
+        std::fprintf(stderr, "[worker] lane0 %.0f us / %llu jobs, lane1 %.0f us / %llu jobs, lane2 %.0f us / %llu jobs\n",
+                     *busy_us, (unsigned long long)*jobs, b1, (unsigned long long)j1, b2, (unsigned long long)j2);
+      *busy_us += b1 + b2;
+      *jobs += j1 + j2;
     }
   });
 }

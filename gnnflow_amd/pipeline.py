@@ -100,8 +100,16 @@ class ReplayPipeline:
                 getattr(sampler, "_strategy", None) in ("recent", "uniform") and \
                 hasattr(sampler, "set_call_counter") and \
                 not hasattr(sampler, "chain_samples"):
+            # sampling only: the loop runs at the pace of the thread that issues the samples'
+            # launches (19 us per sample) unless each lane has an issuer of its own; with a cache
+            # the fetch's issuer is a third busy thread and a fourth did not pay (profiles/README)
+            two_issuers = cache is None and \
+                os.environ.get("GNNFLOW_SAMPLE_ENQUEUE_THREADS", "2") != "1"
             for k in range(1, min(int(sample_lanes), 4)):
-                self.lanes.append((sampler.clone(), side_stream(self.device, k)))
+                clone = sampler.clone()
+                if two_issuers and k % 2 == 1 and hasattr(clone, "set_enqueue_lane"):
+                    clone.set_enqueue_lane(2)
+                self.lanes.append((clone, side_stream(self.device, k)))
         # a sampler (of a lane of the partitioned sampler: one per sample of a shared chain)
         # holds 4 begun samples at most
         if depth is None:

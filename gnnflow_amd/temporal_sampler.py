@@ -202,6 +202,11 @@ class TemporalSampler:
         """
         return self.sample_async(target_vertices, timestamps).wait()
 
+    def set_enqueue_lane(self, lane: int):
+        """Which sampling enqueue thread of the library issues this sampler's asynchronous samples
+        (include/gnnflow_hip.h gf_sampler_set_enqueue_lane)."""
+        _capi.check(self._lib.gf_sampler_set_enqueue_lane(self._h, int(lane)))
+
     def call_counter(self) -> int:
         """Number of sample_layer invocations so far = the `call` word of the next uniform draw
         (include/gnnflow_hip.h gf_sampler_call_counter).  No sample may be in flight."""

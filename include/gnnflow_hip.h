@@ -169,6 +169,13 @@ GF_API int gf_sampler_set_call_counter(gf_sampler* s, uint64_t value, int throug
 GF_API int gf_sampler_sample_begin_async(gf_sampler* s, const int64_t* d_roots,
                                          const float* d_root_ts, size_t num_roots,
                                          void* d_out, size_t out_bytes, void* stream);
+/* Which of the library's two sampling enqueue threads issues this sampler's
+ * gf_sampler_sample_begin_async launches (1: the default, 2: the second one).  A sampling-only
+ * pipeline whose lanes are a sampler and its clone puts the clone on 2: the four launches + event
+ * of a sample cost ~19 us of issuing time, and one thread serving both lanes spends that per
+ * sample — the loop then runs at the issuer's pace, not the GPU's.  No sample may be in flight.
+ * (The reference samples on the caller's thread: gnnflow/temporal_sampler.py:149-165.) */
+GF_API int gf_sampler_set_enqueue_lane(gf_sampler* s, int lane);
 
 /* _TemporalSampler.sample_layer (api.cc:119-120 -> TemporalSampler::SampleLayer,
  * temporal_sampler.cu:97-277), device resident; *bytes variant sizes the buffer. */
